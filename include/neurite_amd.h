@@ -1,0 +1,155 @@
+/*
+ * neurite_amd.h -- C ABI of libneurite_amd.so, the MI355X (gfx950 / CDNA4) implementation of
+ * neurite's 3-D volume hot path.
+ *
+ * The reference (adalca/neurite) is pure Python on TensorFlow and has no FFI of its own
+ * (SURVEY.md section 8b); its boundary is a set of Python call signatures.  Each entry point below
+ * replaces the TensorFlow op sequence that one reference function issues, and is what a
+ * `neurite/torch/` backend (the dormant switch at neurite/__init__.py:33-42) would bind.
+ * INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *  - All tensor pointers are DEVICE pointers (HIP), row-major, channels-last, exactly the
+ *    reference layout [B, *spatial, C]; int* shape arguments are HOST pointers.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream), allocates nothing and never synchronises.  Scratch memory is supplied by the
+ *    caller: ask nrt_*_workspace_bytes() and pass a device buffer of at least that size.
+ *  - Return value: NRT_OK or a negative nrt_status; nothing throws across the ABI.
+ *    nrt_status_string() describes a code.
+ *  - Inputs are never written.  Pointers must be 16-byte aligned (torch allocations are).
+ */
+#ifndef NEURITE_AMD_H
+#define NEURITE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    NRT_OK = 0,
+    NRT_ERR_INVALID_ARG = -1,   /* NULL pointer, bad rank, non-positive size ...            */
+    NRT_ERR_UNSUPPORTED = -2,   /* combination not implemented by the HIP path              */
+    NRT_ERR_LAUNCH = -3,        /* hipLaunchKernel / hipGetLastError reported a failure     */
+    NRT_ERR_WORKSPACE = -4      /* workspace missing or too small                           */
+} nrt_status;
+
+const char *nrt_status_string(int status);
+/* ABI version, bumped when a signature changes. */
+int nrt_abi_version(void);
+/* Name of the GPU architecture the library was compiled for ("gfx950"). */
+const char *nrt_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * interpn / SpatialTransformer / Resize
+ * replaces: neurite/tf/utils/utils.py:73-220 (interpn), :223-265 (resize -> interpn on a
+ * linspace grid), :333-476 (identity grids), and voxelmorph's transform()/SpatialTransformer
+ * (call sites neurite/tf/models.py:806-807, 1157-1159).
+ * ------------------------------------------------------------------------------------------ */
+typedef enum {
+    NRT_LOC_ABSOLUTE = 0,  /* loc[b, q, 0:D] are sampling locations (interpn's own contract)   */
+    NRT_LOC_SHIFT = 1,     /* loc[b, q, 0:D] are displacements, location = float(q_d) + loc    */
+                           /* (SpatialTransformer: identity 'ij' grid never materialised)      */
+    NRT_LOC_LINSPACE = 2   /* loc == NULL; location_d = tf.linspace(0, S_d-1, out_d)[q_d]      */
+                           /* (resize()/Resize: align-corners grid computed in registers)      */
+} nrt_loc_mode;
+
+typedef enum { NRT_INTERP_LINEAR = 0, NRT_INTERP_NEAREST = 1 } nrt_interp_method;
+
+/*
+ * out[b, q, c] = interpn(vol[b], location(b, q))     q over out_shape, c < channels
+ *   vol  [batch, vol_shape[0..ndim-1], channels]  (vol_batch_stride elements between volumes;
+ *                                                  0 re-uses one volume for every b)
+ *   loc  [batch, out_shape[0..ndim-1], ndim]      (loc_batch_stride elements between fields;
+ *                                                  0 = single_transform)
+ *   out  [batch, out_shape..., channels]           dense
+ * ndim in {1,2,3}.  Linear: 2^ndim corners blended in itertools.product order with separately
+ * rounded multiplies/adds (bit-identical to the reference's float32 op sequence); nearest:
+ * round-half-even, pure data movement; fill: out*(!oob) + oob*fill on the UNCLIPPED location.
+ */
+int nrt_interpn_f32(const float *vol, const float *loc, float *out,
+                    int ndim, const int *vol_shape, const int *out_shape, int channels,
+                    int batch, long long vol_batch_stride, long long loc_batch_stride,
+                    int loc_mode, int method, int has_fill, float fill_value, void *stream);
+
+/* Same, selecting a specific kernel (for tuning / benchmarking).  variant:
+ *   0 auto | 1 generic element-per-thread | 2 row-per-lane-group (C%4==0)
+ *   3 z-run with register reuse of the shared corner rows (ndim 3, C==32)
+ * tune: variant-specific knob (variant 3: z-chunk length, 0 = whole line). */
+int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out,
+                       int ndim, const int *vol_shape, const int *out_shape, int channels,
+                       int batch, long long vol_batch_stride, long long loc_batch_stride,
+                       int loc_mode, int method, int has_fill, float fill_value,
+                       int variant, int tune, void *stream);
+
+/* Nearest-neighbour lookup on int32 volumes (label maps); fill arithmetic done in int32. */
+int nrt_interpn_nearest_i32(const int32_t *vol, const float *loc, int32_t *out,
+                            int ndim, const int *vol_shape, const int *out_shape, int channels,
+                            int batch, long long vol_batch_stride, long long loc_batch_stride,
+                            int loc_mode, int has_fill, int32_t fill_value, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dice
+ * replaces: neurite/tf/metrics.py:415-482 (Dice.dice) incl. the optional renormalisation
+ * (:434-436), the range asserts (:439-444, returned as min/max) and the hard path (:450-468).
+ * ------------------------------------------------------------------------------------------ */
+size_t nrt_dice_workspace_bytes(long long nvox, int nlabels, int batch);
+
+/*
+ * Soft Dice.  y_true, y_pred [batch, nvox, nlabels] float32.
+ *   sums   [batch, 3, nlabels] float32 : sum_v t*p, sum_v t*t, sum_v p*p
+ *   dice   [batch, nlabels]    float32 : laplace>0 ? (2*tp+eps)/(tt+pp+eps) : divide_no_nan(2*tp, tt+pp)
+ *   minmax [4] float32 (may be NULL)   : min t, max t, min p, max p over the whole call
+ *                                        (after normalisation if normalize != 0)
+ * Deterministic: wavefront shuffles -> LDS -> per-block partials -> fixed-order second stage.
+ */
+int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                      int normalize, float laplace_smoothing,
+                      float *sums, float *dice, float *minmax,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Hard Dice from probabilistic maps: argmax over labels (ties -> lowest index) then one-hot.
+ *   counts [batch, 3, nlabels] int64 : #(a_t==l && a_p==l), #(a_t==l), #(a_p==l)   (exact)
+ *   dice   [batch, nlabels] float32
+ */
+int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                           float laplace_smoothing, long long *counts, float *dice,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* Hard Dice from label maps [batch, nvox] int32; labels outside [0, nlabels) match nothing. */
+int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_pred, long long nvox, int nlabels,
+                            int batch, float laplace_smoothing, long long *counts, float *dice,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* dice[b,l] from externally reduced sums (e.g. after an RCCL all-reduce of `sums`). */
+int nrt_dice_from_sums_f32(const float *sums, int nlabels, int batch, float laplace_smoothing,
+                           float *dice, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Label-weighted categorical cross-entropy
+ * replaces: neurite/tf/metrics.py:640-650 + tf.keras.losses.CategoricalCrossentropy
+ * ------------------------------------------------------------------------------------------ */
+typedef enum { NRT_DT_F32 = 0, NRT_DT_BF16 = 1 } nrt_dtype;
+
+size_t nrt_wcce_workspace_bytes(long long nvox_total, int channels);
+
+/*
+ * y_true, y_pred [nvox_total, channels] of `dtype`; label_weights [channels] float32 or NULL.
+ *   t' = w*t; [t' = t'*(1-s) + s/C]; from_logits ? -sum t' log_softmax(z)
+ *                                               : q = clip(p/sum p, 1e-7, 1-1e-7), -sum t' log q
+ *   loss_sum  [1] float32 : sum over all voxels (the caller divides by nvox_total)
+ *   per_voxel [nvox_total] float32 or NULL
+ * Arithmetic in float32 regardless of the input dtype.
+ */
+int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *label_weights,
+             long long nvox_total, int channels, int from_logits, float label_smoothing,
+             float *loss_sum, float *per_voxel,
+             void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEURITE_AMD_H */

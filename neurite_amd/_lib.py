@@ -1,0 +1,123 @@
+"""
+ctypes binding of libneurite_amd.so (C ABI: include/neurite_amd.h).
+
+PyTorch is only plumbing here: it owns device memory (caching allocator) and streams.  Every
+compute call goes through the C ABI with raw device pointers; there is NO CPU or eager-PyTorch
+fallback -- if the HIP library is missing or a tensor is not on a ROCm device the call raises.
+"""
+
+import ctypes as C
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libneurite_amd.so')
+HEADER_PATH = os.path.join(_HERE, '..', 'include', 'neurite_amd.h')
+
+NRT_OK = 0
+LOC_ABSOLUTE, LOC_SHIFT, LOC_LINSPACE = 0, 1, 2
+INTERP_LINEAR, INTERP_NEAREST = 0, 1
+DT_F32, DT_BF16 = 0, 1
+
+_lib = None
+
+_vp, _i, _ll, _f, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+_SIGNATURES = {
+    'nrt_status_string': (C.c_char_p, [_i]),
+    'nrt_abi_version': (_i, []),
+    'nrt_target_arch': (C.c_char_p, []),
+    'nrt_interpn_f32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _vp]),
+    'nrt_interpn_f32_ex': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _i, _i, _vp]),
+    'nrt_interpn_nearest_i32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, C.c_int32, _vp]),
+    'nrt_dice_workspace_bytes': (_sz, [_ll, _i, _i]),
+    'nrt_dice_soft_f32': (_i, [_vp, _vp, _ll, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nrt_dice_hard_prob_f32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    'nrt_dice_hard_label_i32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    'nrt_dice_from_sums_f32': (_i, [_vp, _i, _i, _f, _vp, _vp]),
+    'nrt_wcce_workspace_bytes': (_sz, [_ll, _i]),
+    'nrt_wcce': (_i, [_vp, _vp, _i, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+class NeuriteAmdError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every function name declared in include/neurite_amd.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(nrt_[a-z0-9_]+)\s*\(', text)))
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NeuriteAmdError(
+                'libneurite_amd.so not found at %s: build it with `python -m neurite_amd.build` '
+                '(hipcc, --offload-arch=gfx950). neurite_amd has no CPU fallback.' % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != NRT_OK:
+        msg = lib().nrt_status_string(rc).decode()
+        raise NeuriteAmdError('%s failed: %s (status %d)' % (what or 'neurite_amd call', msg, rc))
+
+
+def require_device(*tensors):
+    """All tensors must live on one ROCm device; returns it."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor):
+            raise TypeError('expected a torch.Tensor, got %s' % type(t).__name__)
+        if t.device.type != 'cuda':
+            raise NeuriteAmdError(
+                'neurite_amd runs on MI355X (ROCm) tensors only; got a tensor on %s. '
+                'There is deliberately no CPU fallback.' % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise NeuriteAmdError('tensors live on different devices: %s vs %s' % (dev, t.device))
+    return dev
+
+
+def stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def ints(values):
+    return (C.c_int * len(values))(*[int(v) for v in values])
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """A per-device scratch buffer owned by the torch caching allocator, grown on demand.
+    Kernels on one stream are ordered, so one buffer per (device, stream) is enough."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

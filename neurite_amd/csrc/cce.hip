@@ -1,0 +1,242 @@
+// Label-weighted categorical cross-entropy for gfx950 (MI355X).
+//
+// Replaces neurite/tf/metrics.py:640-650 (y_true *= label_weights) followed by
+// tf.keras.losses.CategoricalCrossentropy: [label smoothing], p / sum_c p, clip to [1e-7, 1-1e-7],
+// -sum_c t'_c log p_c, mean over all B*V elements -- about nine TensorFlow ops with V*C-sized
+// temporaries -- with one pass that reads y_true and y_pred once (2*itemsize*C bytes per voxel).
+//
+// Layout: y [N, C] row-major with N = B*V.  Fast path: C % 4 == 0, G = C/4 lanes own one voxel, each
+// lane a fixed quad of channels (16 B loads for fp32, 8 B for bf16); the channel sum / max needed
+// for the normalisation is a log2(G)-step xor-shuffle inside the lane-group.  bf16 inputs are
+// widened to fp32 in registers; all arithmetic and the reduction are fp32 (final stage float64).
+// Reduction: lane partials -> wave shuffles -> LDS -> per-block partial -> fixed-order second stage.
+
+#include "nrt_common.h"
+
+namespace {
+
+constexpr int CCE_BLOCK = 256;
+constexpr int CCE_MAX_BLOCKS = 2048;
+constexpr float KERAS_EPS = 1e-7f;
+
+typedef unsigned short nrt_us4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    static __device__ __forceinline__ nrt_f4 load(const void *base, long long i) {
+        return __builtin_nontemporal_load((const nrt_f4 *)base + i);
+    }
+    static __device__ __forceinline__ float load1(const void *base, long long i) { return ((const float *)base)[i]; }
+};
+template <> struct Quad<unsigned short> {
+    static __device__ __forceinline__ nrt_f4 load(const void *base, long long i) {
+        const nrt_us4 r = __builtin_nontemporal_load((const nrt_us4 *)base + i);
+        return (nrt_f4){bf16_to_f32(r[0]), bf16_to_f32(r[1]), bf16_to_f32(r[2]), bf16_to_f32(r[3])};
+    }
+    static __device__ __forceinline__ float load1(const void *base, long long i) {
+        return bf16_to_f32(((const unsigned short *)base)[i]);
+    }
+};
+
+// per-lane contribution -sum_k t'_k * logq_k for this lane's channels
+template <int G, typename T, bool LOGITS, bool PERVOX>
+__global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ yt, const void *__restrict__ yp,
+                                                      const float *__restrict__ w, long long n, float smooth,
+                                                      float *__restrict__ part, float *__restrict__ per_voxel) {
+    constexpr int NG = CCE_BLOCK / G;
+    constexpr int C = 4 * G;
+    const int lg = threadIdx.x % G;
+    const long long g = threadIdx.x / G;
+    const long long stride = (long long)gridDim.x * NG;
+    float wq[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (w) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wq[k] = w[4 * lg + k];
+    }
+    const float keep = 1.0f - smooth, add = smooth / (float)C;
+    float acc = 0.0f;
+
+#pragma unroll 2
+    for (long long v = (long long)blockIdx.x * NG + g; v < n; v += stride) {
+        const nrt_f4 t = Quad<T>::load(yt, v * G + lg);
+        const nrt_f4 p = Quad<T>::load(yp, v * G + lg);
+        float lq[4];
+        if (LOGITS) {
+            float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, NRT_WAVE));
+            float se = (expf(p[0] - m) + expf(p[1] - m)) + (expf(p[2] - m) + expf(p[3] - m));
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) se += __shfl_xor(se, off, NRT_WAVE);
+            const float lse = logf(se);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lq[k] = (p[k] - m) - lse;
+        } else {
+            float s = (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) s += __shfl_xor(s, off, NRT_WAVE);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float q = p[k] / s;
+                q = fminf(fmaxf(q, KERAS_EPS), 1.0f - KERAS_EPS);
+                lq[k] = logf(q);
+            }
+        }
+        float l = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float tt = wq[k] * t[k];                 // metrics.py:648
+            if (smooth != 0.0f) tt = tt * keep + add;
+            l -= tt * lq[k];
+        }
+        if (PERVOX) {
+            float lv = l;
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) lv += __shfl_xor(lv, off, NRT_WAVE);
+            if (lg == 0) per_voxel[v] = lv;
+        }
+        acc += l;
+    }
+    for (int off = 1; off < NRT_WAVE; off <<= 1) acc += __shfl_xor(acc, off, NRT_WAVE);
+    __shared__ float red[CCE_BLOCK / NRT_WAVE];
+    if ((threadIdx.x & (NRT_WAVE - 1)) == 0) red[threadIdx.x / NRT_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = red[0];
+        for (int i = 1; i < CCE_BLOCK / NRT_WAVE; ++i) s += red[i];
+        part[blockIdx.x] = s;
+    }
+}
+
+// any C: one thread per voxel
+template <typename T, bool LOGITS>
+__global__ __launch_bounds__(CCE_BLOCK) void wcce_generic(const void *__restrict__ yt, const void *__restrict__ yp,
+                                                          const float *__restrict__ w, long long n, int C, float smooth,
+                                                          float *__restrict__ part, float *__restrict__ per_voxel) {
+    const float keep = 1.0f - smooth, add = smooth / (float)C;
+    float acc = 0.0f;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+        float l = 0.0f;
+        if (LOGITS) {
+            float m = -INFINITY;
+            for (int c = 0; c < C; ++c) m = fmaxf(m, Quad<T>::load1(yp, v * C + c));
+            float se = 0.0f;
+            for (int c = 0; c < C; ++c) se += expf(Quad<T>::load1(yp, v * C + c) - m);
+            const float lse = logf(se);
+            for (int c = 0; c < C; ++c) {
+                float tt = (w ? w[c] : 1.0f) * Quad<T>::load1(yt, v * C + c);
+                if (smooth != 0.0f) tt = tt * keep + add;
+                l -= tt * ((Quad<T>::load1(yp, v * C + c) - m) - lse);
+            }
+        } else {
+            float s = 0.0f;
+            for (int c = 0; c < C; ++c) s += Quad<T>::load1(yp, v * C + c);
+            for (int c = 0; c < C; ++c) {
+                float q = Quad<T>::load1(yp, v * C + c) / s;
+                q = fminf(fmaxf(q, KERAS_EPS), 1.0f - KERAS_EPS);
+                float tt = (w ? w[c] : 1.0f) * Quad<T>::load1(yt, v * C + c);
+                if (smooth != 0.0f) tt = tt * keep + add;
+                l -= tt * logf(q);
+            }
+        }
+        if (per_voxel) per_voxel[v] = l;
+        acc += l;
+    }
+    for (int off = 1; off < NRT_WAVE; off <<= 1) acc += __shfl_xor(acc, off, NRT_WAVE);
+    __shared__ float red[CCE_BLOCK / NRT_WAVE];
+    if ((threadIdx.x & (NRT_WAVE - 1)) == 0) red[threadIdx.x / NRT_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = red[0];
+        for (int i = 1; i < CCE_BLOCK / NRT_WAVE; ++i) s += red[i];
+        part[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void wcce_finalize(const float *__restrict__ part, int nblk, float *__restrict__ loss_sum) {
+    __shared__ double sl[256];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 256) a += (double)part[k];
+    sl[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < 256; ++i) s += sl[i];      // fixed order
+        loss_sum[0] = (float)s;
+    }
+}
+
+bool vec_channels(int C) {
+    if (C % 4) return false;
+    const int g = C / 4;
+    return g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64;
+}
+
+template <int G, typename T>
+void launch_vec(const void *t, const void *p, const float *w, long long n, int logits, float smooth, unsigned nblk,
+                float *part, float *pv, hipStream_t st) {
+    dim3 grid(nblk), blk(CCE_BLOCK);
+    if (logits) {
+        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, true, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv);
+        else hipLaunchKernelGGL((wcce_vec<G, T, true, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv);
+    } else {
+        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, false, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv);
+        else hipLaunchKernelGGL((wcce_vec<G, T, false, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv);
+    }
+}
+
+template <typename T>
+void launch_any(const void *t, const void *p, const float *w, long long n, int C, int logits, float smooth,
+                bool aligned, unsigned &nblk, float *part, float *pv, hipStream_t st) {
+    if (vec_channels(C) && aligned) {
+        const int G = C / 4;
+        long long nb = (n + (CCE_BLOCK / G) * 4 - 1) / ((CCE_BLOCK / G) * 4);
+        nblk = (unsigned)(nb < 1 ? 1 : (nb > CCE_MAX_BLOCKS ? CCE_MAX_BLOCKS : nb));
+        switch (G) {
+            case 1: launch_vec<1, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
+            case 2: launch_vec<2, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
+            case 4: launch_vec<4, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
+            case 8: launch_vec<8, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
+            case 16: launch_vec<16, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
+            case 32: launch_vec<32, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
+            default: launch_vec<64, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
+        }
+    } else {
+        long long nb = (n + CCE_BLOCK - 1) / CCE_BLOCK;
+        nblk = (unsigned)(nb < 1 ? 1 : (nb > CCE_MAX_BLOCKS ? CCE_MAX_BLOCKS : nb));
+        if (logits) hipLaunchKernelGGL((wcce_generic<T, true>), dim3(nblk), dim3(CCE_BLOCK), 0, st, t, p, w, n, C, smooth, part, pv);
+        else hipLaunchKernelGGL((wcce_generic<T, false>), dim3(nblk), dim3(CCE_BLOCK), 0, st, t, p, w, n, C, smooth, part, pv);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t nrt_wcce_workspace_bytes(long long nvox_total, int channels) {
+    (void)nvox_total; (void)channels;
+    return (size_t)CCE_MAX_BLOCKS * sizeof(float) + 256;
+}
+
+extern "C" int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *label_weights,
+                        long long nvox_total, int channels, int from_logits, float label_smoothing, float *loss_sum,
+                        float *per_voxel, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!y_true || !y_pred || !loss_sum) return NRT_ERR_INVALID_ARG;
+    if (nvox_total < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (dtype != NRT_DT_F32 && dtype != NRT_DT_BF16) return NRT_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < nrt_wcce_workspace_bytes(nvox_total, channels)) return NRT_ERR_WORKSPACE;
+    hipStream_t st = nrt_stream(stream);
+    float *part = (float *)workspace;
+    unsigned nblk = 1;
+    const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
+    if (dtype == NRT_DT_F32)
+        launch_any<float>(y_true, y_pred, label_weights, nvox_total, channels, from_logits, label_smoothing, aligned,
+                          nblk, part, per_voxel, st);
+    else
+        launch_any<unsigned short>(y_true, y_pred, label_weights, nvox_total, channels, from_logits, label_smoothing,
+                                   aligned, nblk, part, per_voxel, st);
+    NRT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wcce_finalize, dim3(1), dim3(256), 0, st, (const float *)part, (int)nblk, loss_sum);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

@@ -1,0 +1,561 @@
+// Dice kernels for gfx950 (MI355X).
+//
+// Replaces neurite/tf/metrics.py:415-482: TensorFlow runs 3 full reductions + 3 element-wise
+// temporaries (+4 more reductions for the range asserts at :441-444); here y_true and y_pred are
+// read exactly once (2*4*L bytes per voxel) and everything -- sum t*p, sum t^2, sum p^2, optional
+// per-voxel renormalisation (:434-436), min/max for the range asserts, or for the hard path the
+// arg-max + one-hot counting (:450-468) -- happens in registers.
+//
+// Reduction tree (no float atomics, so results are run-to-run identical):
+//   lane accumulators -> wave64 xor-shuffles across lane-groups -> LDS across the block's 4 waves
+//   -> one partial per block in the caller's workspace -> second-stage kernel adds the partials
+//   in a fixed order in float64 and writes sums / dice.
+//
+// Layout: y [B, V, L] row-major (the reference's batch_channel_flatten view, utils.py:1175-1226).
+// Fast path: L % 4 == 0, G = L/4 lanes own one voxel and each lane keeps a FIXED quad of labels
+// (16-byte global_load_dwordx4 per lane; a wave64 reads 64/G consecutive voxels = 1 KiB contiguous).
+
+#include "nrt_common.h"
+
+namespace {
+
+constexpr int DICE_BLOCK = 256;
+constexpr int DICE_MAX_BLOCKS = 2048;      // 8 blocks per CU; the rest is grid-strided
+
+__host__ __device__ inline unsigned dice_num_blocks(long long nvox, int vox_per_pass) {
+    long long nb = (nvox + vox_per_pass - 1) / vox_per_pass;
+    if (nb > DICE_MAX_BLOCKS) nb = DICE_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+// workspace layout (per call):  double-free, float partials then int partials
+//   fpart [B][nblk][3][L] float      soft sums
+//   mpart [B][nblk][4]    float      min t, max t, min p, max p
+//   ipart [B][nblk][3][L] uint32     hard counts
+struct DiceWs {
+    float *fpart;
+    float *mpart;
+    unsigned *ipart;
+};
+
+size_t dice_ws_bytes(int L, int batch) {
+    size_t per = (size_t)batch * DICE_MAX_BLOCKS;
+    return per * 3 * L * sizeof(float) + per * 4 * sizeof(float) + per * 3 * L * sizeof(unsigned) + 256;
+}
+
+DiceWs dice_ws_carve(void *ws, int L, int batch) {
+    DiceWs w;
+    size_t per = (size_t)batch * DICE_MAX_BLOCKS;
+    char *p = (char *)ws;
+    w.fpart = (float *)p; p += per * 3 * L * sizeof(float);
+    w.mpart = (float *)p; p += per * 4 * sizeof(float);
+    w.ipart = (unsigned *)p;
+    return w;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_xor_add(T v, int from) {
+    // sum over lanes that agree in (lane % from): xor offsets from, 2*from, ..., 32
+    for (int off = from; off < NRT_WAVE; off <<= 1) v += __shfl_xor(v, off, NRT_WAVE);
+    return v;
+}
+
+// ============================================================================================
+// soft Dice, vectorised: G lanes per voxel
+// ============================================================================================
+template <int G, bool NORMALIZE>
+__global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const float *__restrict__ yt, const float *__restrict__ yp,
+                                                            long long nvox, float *__restrict__ fpart,
+                                                            float *__restrict__ mpart) {
+    constexpr int NG = DICE_BLOCK / G;           // voxels per block pass
+    constexpr int L = 4 * G;
+    const int b = blockIdx.y;
+    const nrt_f4 *t4 = (const nrt_f4 *)(yt + (long long)b * nvox * L);
+    const nrt_f4 *p4 = (const nrt_f4 *)(yp + (long long)b * nvox * L);
+    const int lg = threadIdx.x % G;
+    const long long g = threadIdx.x / G;
+    const long long stride = (long long)gridDim.x * NG;
+
+    nrt_f4 stp = {0, 0, 0, 0}, stt = {0, 0, 0, 0}, spp = {0, 0, 0, 0};
+    float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
+
+#pragma unroll 4
+    for (long long v = (long long)blockIdx.x * NG + g; v < nvox; v += stride) {
+        nrt_f4 t = __builtin_nontemporal_load(&t4[v * G + lg]);
+        nrt_f4 p = __builtin_nontemporal_load(&p4[v * G + lg]);
+        if (NORMALIZE) {
+            // y / sum_l y with divide_no_nan (metrics.py:435-436); the label sum spans the lane-group
+            float st = (t[0] + t[1]) + (t[2] + t[3]);
+            float sp = (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) {
+                st += __shfl_xor(st, off, NRT_WAVE);
+                sp += __shfl_xor(sp, off, NRT_WAVE);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[k] = (st == 0.0f) ? 0.0f : t[k] / st;
+                p[k] = (sp == 0.0f) ? 0.0f : p[k] / sp;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            stp[k] += t[k] * p[k];
+            stt[k] += t[k] * t[k];
+            spp[k] += p[k] * p[k];
+            mnt = fminf(mnt, t[k]); mxt = fmaxf(mxt, t[k]);
+            mnp = fminf(mnp, p[k]); mxp = fmaxf(mxp, p[k]);
+        }
+    }
+
+    // ---- wave: combine the 64/G lane-groups (same label quad) ---------------------------------
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        stp[k] = wave_xor_add(stp[k], G);
+        stt[k] = wave_xor_add(stt[k], G);
+        spp[k] = wave_xor_add(spp[k], G);
+    }
+    for (int off = 1; off < NRT_WAVE; off <<= 1) {
+        mnt = fminf(mnt, __shfl_xor(mnt, off, NRT_WAVE)); mxt = fmaxf(mxt, __shfl_xor(mxt, off, NRT_WAVE));
+        mnp = fminf(mnp, __shfl_xor(mnp, off, NRT_WAVE)); mxp = fmaxf(mxp, __shfl_xor(mxp, off, NRT_WAVE));
+    }
+    // ---- block: 4 waves through LDS -----------------------------------------------------------
+    __shared__ float red[DICE_BLOCK / NRT_WAVE][3 * L + 4];
+    const int lane = threadIdx.x & (NRT_WAVE - 1), wv = threadIdx.x / NRT_WAVE;
+    if (lane < G) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[wv][0 * L + 4 * lane + k] = stp[k];
+            red[wv][1 * L + 4 * lane + k] = stt[k];
+            red[wv][2 * L + 4 * lane + k] = spp[k];
+        }
+    }
+    if (lane == 0) { red[wv][3 * L + 0] = mnt; red[wv][3 * L + 1] = mxt; red[wv][3 * L + 2] = mnp; red[wv][3 * L + 3] = mxp; }
+    __syncthreads();
+    const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
+    for (int i = threadIdx.x; i < 3 * L; i += DICE_BLOCK) {
+        float s = red[0][i];
+#pragma unroll
+        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2) s += red[w2][i];
+        fpart[pbase * 3 * L + i] = s;
+    }
+    if (threadIdx.x < 4) {
+        float m = red[0][3 * L + threadIdx.x];
+        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2)
+            m = (threadIdx.x & 1) ? fmaxf(m, red[w2][3 * L + threadIdx.x]) : fminf(m, red[w2][3 * L + threadIdx.x]);
+        mpart[pbase * 4 + threadIdx.x] = m;
+    }
+}
+
+// soft Dice, any L (slow path for label counts that are not 4*2^k): thread = (voxel row r, label li)
+// inside a label chunk of up to 256 labels (blockIdx.z); consecutive threads read consecutive labels.
+template <bool NORMALIZE>
+__global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const float *__restrict__ yt, const float *__restrict__ yp,
+                                                                long long nvox, int L, float *__restrict__ fpart,
+                                                                float *__restrict__ mpart) {
+    __shared__ float sh[3 * DICE_BLOCK];
+    __shared__ float mm[DICE_BLOCK / NRT_WAVE][4];
+    const int b = blockIdx.y;
+    const float *t = yt + (long long)b * nvox * L;
+    const float *p = yp + (long long)b * nvox * L;
+    const int Lc = L < DICE_BLOCK ? L : DICE_BLOCK;       // labels in this chunk (last chunk may be short)
+    const int R = DICE_BLOCK / Lc;                        // voxel rows per pass (1 when L >= 256)
+    const int r = threadIdx.x / Lc, li = threadIdx.x % Lc;
+    const int l = blockIdx.z * DICE_BLOCK + li;
+    const bool active = (r < R) && (l < L);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
+    if (active) {
+        for (long long v = (long long)blockIdx.x * R + r; v < nvox; v += (long long)gridDim.x * R) {
+            float tv = t[v * L + l], pv = p[v * L + l];
+            if (NORMALIZE) {
+                float st = 0.0f, sp = 0.0f;
+                for (int k = 0; k < L; ++k) { st += t[v * L + k]; sp += p[v * L + k]; }
+                tv = (st == 0.0f) ? 0.0f : tv / st;
+                pv = (sp == 0.0f) ? 0.0f : pv / sp;
+            }
+            a0 += tv * pv; a1 += tv * tv; a2 += pv * pv;
+            mnt = fminf(mnt, tv); mxt = fmaxf(mxt, tv); mnp = fminf(mnp, pv); mxp = fmaxf(mxp, pv);
+        }
+    }
+    sh[0 * DICE_BLOCK + threadIdx.x] = a0;
+    sh[1 * DICE_BLOCK + threadIdx.x] = a1;
+    sh[2 * DICE_BLOCK + threadIdx.x] = a2;
+    for (int off = 1; off < NRT_WAVE; off <<= 1) {
+        mnt = fminf(mnt, __shfl_xor(mnt, off, NRT_WAVE)); mxt = fmaxf(mxt, __shfl_xor(mxt, off, NRT_WAVE));
+        mnp = fminf(mnp, __shfl_xor(mnp, off, NRT_WAVE)); mxp = fmaxf(mxp, __shfl_xor(mxp, off, NRT_WAVE));
+    }
+    if ((threadIdx.x & (NRT_WAVE - 1)) == 0) {
+        mm[threadIdx.x / NRT_WAVE][0] = mnt; mm[threadIdx.x / NRT_WAVE][1] = mxt;
+        mm[threadIdx.x / NRT_WAVE][2] = mnp; mm[threadIdx.x / NRT_WAVE][3] = mxp;
+    }
+    __syncthreads();
+    const long long pblk = (long long)b * gridDim.x + blockIdx.x;
+    if (threadIdx.x < Lc && l < L) {
+        for (int k = 0; k < 3; ++k) {
+            float s = 0.0f;
+            for (int rr = 0; rr < R; ++rr) s += sh[k * DICE_BLOCK + rr * Lc + li];     // fixed order
+            fpart[pblk * 3 * L + (long long)k * L + l] = s;
+        }
+    }
+    if (threadIdx.x < 4) {
+        float m = mm[0][threadIdx.x];
+        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2)
+            m = (threadIdx.x & 1) ? fmaxf(m, mm[w2][threadIdx.x]) : fminf(m, mm[w2][threadIdx.x]);
+        mpart[(pblk * gridDim.z + blockIdx.z) * 4 + threadIdx.x] = m;
+    }
+}
+
+// second stage: one 1024-thread block per batch entry.  Column i of the [nblk, 3L] partial matrix is
+// summed by S = 1024/(3L) threads over fixed strided slices in float64, the S slice sums are then added
+// in slice order -- a fixed tree, so the result does not depend on scheduling.
+__global__ __launch_bounds__(1024) void dice_soft_finalize(const float *__restrict__ fpart, const float *__restrict__ mpart,
+                                                           int nblk, int nmm, int L, float eps, float *__restrict__ sums,
+                                                           float *__restrict__ dice, float *__restrict__ minmax) {
+    __shared__ double sl[1024];
+    extern __shared__ float fs[];   // [3*L]
+    const int b = blockIdx.x;
+    const int ncol = 3 * L;
+    for (int c0 = 0; c0 < ncol; c0 += 1024) {
+        const int cols = min(ncol - c0, 1024);
+        const int S = 1024 / cols;                         // slices per column (>= 1)
+        const int i = threadIdx.x % cols, s = threadIdx.x / cols;
+        double acc = 0.0;
+        if (s < S)
+            for (int k = s; k < nblk; k += S) acc += (double)fpart[((long long)b * nblk + k) * ncol + c0 + i];
+        sl[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < cols) {
+            double tot = 0.0;
+            for (int ss = 0; ss < S; ++ss) tot += sl[ss * cols + threadIdx.x];
+            const float f = (float)tot;
+            fs[c0 + threadIdx.x] = f;
+            sums[(long long)b * ncol + c0 + threadIdx.x] = f;
+        }
+        __syncthreads();
+    }
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const float top = nrt_mul(2.0f, fs[l]);                         // metrics.py:476
+        const float bottom = nrt_add(fs[L + l], fs[2 * L + l]);         // :477
+        float d;
+        if (eps > 0.0f) d = nrt_add(top, eps) / nrt_add(bottom, eps);   // :478-480
+        else d = (bottom == 0.0f) ? 0.0f : top / bottom;                // :482 divide_no_nan
+        dice[(long long)b * L + l] = d;
+    }
+    if (minmax && b == 0) {
+        // min t, max t, min p, max p over every partial of every batch entry
+        float m[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+        for (long long k = threadIdx.x; k < (long long)gridDim.x * nmm; k += blockDim.x) {
+            m[0] = fminf(m[0], mpart[k * 4 + 0]); m[1] = fmaxf(m[1], mpart[k * 4 + 1]);
+            m[2] = fminf(m[2], mpart[k * 4 + 2]); m[3] = fmaxf(m[3], mpart[k * 4 + 3]);
+        }
+        for (int off = 1; off < NRT_WAVE; off <<= 1) {
+            m[0] = fminf(m[0], __shfl_xor(m[0], off, NRT_WAVE)); m[1] = fmaxf(m[1], __shfl_xor(m[1], off, NRT_WAVE));
+            m[2] = fminf(m[2], __shfl_xor(m[2], off, NRT_WAVE)); m[3] = fmaxf(m[3], __shfl_xor(m[3], off, NRT_WAVE));
+        }
+        __syncthreads();
+        float *mf = (float *)sl;
+        if ((threadIdx.x & (NRT_WAVE - 1)) == 0)
+            for (int i = 0; i < 4; ++i) mf[(threadIdx.x / NRT_WAVE) * 4 + i] = m[i];
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float r = mf[threadIdx.x];
+            for (int w2 = 1; w2 < (int)blockDim.x / NRT_WAVE; ++w2)
+                r = (threadIdx.x & 1) ? fmaxf(r, mf[w2 * 4 + threadIdx.x]) : fminf(r, mf[w2 * 4 + threadIdx.x]);
+            minmax[threadIdx.x] = r;
+        }
+    }
+}
+
+// ============================================================================================
+// hard Dice from probabilities: arg-max (ties -> lowest label) + one-hot counting, G lanes/voxel
+// ============================================================================================
+template <int G>
+__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const float *__restrict__ yt, const float *__restrict__ yp,
+                                                            long long nvox, unsigned *__restrict__ ipart) {
+    constexpr int NG = DICE_BLOCK / G;
+    constexpr int L = 4 * G;
+    const int b = blockIdx.y;
+    const nrt_f4 *t4 = (const nrt_f4 *)(yt + (long long)b * nvox * L);
+    const nrt_f4 *p4 = (const nrt_f4 *)(yp + (long long)b * nvox * L);
+    const int lg = threadIdx.x % G;
+    const long long g = threadIdx.x / G;
+    const long long stride = (long long)gridDim.x * NG;
+    unsigned ntp[4] = {0, 0, 0, 0}, nt[4] = {0, 0, 0, 0}, np_[4] = {0, 0, 0, 0};
+
+#pragma unroll 2
+    for (long long v = (long long)blockIdx.x * NG + g; v < nvox; v += stride) {
+        const nrt_f4 t = __builtin_nontemporal_load(&t4[v * G + lg]);
+        const nrt_f4 p = __builtin_nontemporal_load(&p4[v * G + lg]);
+        float bt = t[0], bp = p[0];
+        int at = 4 * lg, ap = 4 * lg;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            if (t[k] > bt) { bt = t[k]; at = 4 * lg + k; }      // strict > keeps the lowest index on ties
+            if (p[k] > bp) { bp = p[k]; ap = 4 * lg + k; }
+        }
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) {
+            const float ot = __shfl_xor(bt, off, NRT_WAVE), op = __shfl_xor(bp, off, NRT_WAVE);
+            const int oat = __shfl_xor(at, off, NRT_WAVE), oap = __shfl_xor(ap, off, NRT_WAVE);
+            if (ot > bt || (ot == bt && oat < at)) { bt = ot; at = oat; }
+            if (op > bp || (op == bp && oap < ap)) { bp = op; ap = oap; }
+        }
+        // every lane of the group now knows (at, ap); it counts only its own 4 labels
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lab = 4 * lg + k;
+            nt[k] += (at == lab);
+            np_[k] += (ap == lab);
+            ntp[k] += (at == lab) & (ap == lab);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ntp[k] = wave_xor_add(ntp[k], G);
+        nt[k] = wave_xor_add(nt[k], G);
+        np_[k] = wave_xor_add(np_[k], G);
+    }
+    __shared__ unsigned red[DICE_BLOCK / NRT_WAVE][3 * L];
+    const int lane = threadIdx.x & (NRT_WAVE - 1), wv = threadIdx.x / NRT_WAVE;
+    if (lane < G) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[wv][0 * L + 4 * lane + k] = ntp[k];
+            red[wv][1 * L + 4 * lane + k] = nt[k];
+            red[wv][2 * L + 4 * lane + k] = np_[k];
+        }
+    }
+    __syncthreads();
+    const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
+    for (int i = threadIdx.x; i < 3 * L; i += DICE_BLOCK) {
+        unsigned s = red[0][i];
+        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2) s += red[w2][i];
+        ipart[pbase * 3 * L + i] = s;
+    }
+}
+
+// hard Dice, any L, from probabilities: one thread per voxel
+__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_generic(const float *__restrict__ yt, const float *__restrict__ yp,
+                                                                     long long nvox, int L, long long *counts) {
+    const int b = blockIdx.y;
+    const float *t = yt + (long long)b * nvox * L;
+    const float *p = yp + (long long)b * nvox * L;
+    unsigned long long *c = (unsigned long long *)counts + (long long)b * 3 * L;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+        int at = 0, ap = 0;
+        float bt = t[v * L], bp = p[v * L];
+        for (int l = 1; l < L; ++l) {
+            const float tv = t[v * L + l], pv = p[v * L + l];
+            if (tv > bt) { bt = tv; at = l; }
+            if (pv > bp) { bp = pv; ap = l; }
+        }
+        atomicAdd(&c[L + at], 1ull);
+        atomicAdd(&c[2 * L + ap], 1ull);
+        if (at == ap) atomicAdd(&c[at], 1ull);
+    }
+}
+
+// hard Dice from int32 label maps: per-block LDS histogram (integer atomics: order-independent)
+__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_label(const int *__restrict__ yt, const int *__restrict__ yp,
+                                                              long long nvox, int L, int use_lds, long long *counts) {
+    extern __shared__ unsigned hist[];      // [3*L] when use_lds
+    const int b = blockIdx.y;
+    const int *t = yt + (long long)b * nvox;
+    const int *p = yp + (long long)b * nvox;
+    unsigned long long *c = (unsigned long long *)counts + (long long)b * 3 * L;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < 3 * L; i += blockDim.x) hist[i] = 0u;
+        __syncthreads();
+    }
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+        const int a = t[v], q = p[v];
+        const bool oka = a >= 0 && a < L, okq = q >= 0 && q < L;   // tf.one_hot: out of range -> zero row
+        if (use_lds) {
+            if (oka) atomicAdd(&hist[L + a], 1u);
+            if (okq) atomicAdd(&hist[2 * L + q], 1u);
+            if (oka && okq && a == q) atomicAdd(&hist[a], 1u);
+        } else {
+            if (oka) atomicAdd(&c[L + a], 1ull);
+            if (okq) atomicAdd(&c[2 * L + q], 1ull);
+            if (oka && okq && a == q) atomicAdd(&c[a], 1ull);
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * L; i += blockDim.x)
+            if (hist[i]) atomicAdd(&c[i], (unsigned long long)hist[i]);
+    }
+}
+
+__global__ void dice_counts_reduce(const unsigned *__restrict__ ipart, int nblk, int L, long long *counts) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 3 * L; i += blockDim.x) {
+        long long s = 0;
+        for (int k = 0; k < nblk; ++k) s += (long long)ipart[((long long)b * nblk + k) * 3 * L + i];
+        counts[(long long)b * 3 * L + i] = s;
+    }
+}
+
+// dice from exact counts: one-hot squares are the counts themselves; float32 like the reference
+__global__ void dice_from_counts(const long long *__restrict__ counts, int L, float eps, float *__restrict__ dice) {
+    const int b = blockIdx.x;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const long long *c = counts + (long long)b * 3 * L;
+        const float top = nrt_mul(2.0f, (float)c[l]);
+        const float bottom = nrt_add((float)c[L + l], (float)c[2 * L + l]);
+        float d;
+        if (eps > 0.0f) d = nrt_add(top, eps) / nrt_add(bottom, eps);
+        else d = (bottom == 0.0f) ? 0.0f : top / bottom;
+        dice[(long long)b * L + l] = d;
+    }
+}
+
+__global__ void dice_from_sums(const float *__restrict__ sums, int L, float eps, float *__restrict__ dice) {
+    const int b = blockIdx.x;
+    const float *s = sums + (long long)b * 3 * L;
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const float top = nrt_mul(2.0f, s[l]);
+        const float bottom = nrt_add(s[L + l], s[2 * L + l]);
+        float d;
+        if (eps > 0.0f) d = nrt_add(top, eps) / nrt_add(bottom, eps);
+        else d = (bottom == 0.0f) ? 0.0f : top / bottom;
+        dice[(long long)b * L + l] = d;
+    }
+}
+
+bool vec_labels(int L) {
+    if (L % 4) return false;
+    const int g = L / 4;
+    return g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64;
+}
+
+template <int G>
+void launch_soft_vec(const float *t, const float *p, long long nvox, int batch, int normalize, unsigned nblk,
+                     const DiceWs &w, hipStream_t st) {
+    dim3 grid(nblk, batch);
+    if (normalize) hipLaunchKernelGGL((dice_soft_vec<G, true>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart);
+    else hipLaunchKernelGGL((dice_soft_vec<G, false>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart);
+}
+
+template <int G>
+void launch_hard_vec(const float *t, const float *p, long long nvox, int batch, unsigned nblk, const DiceWs &w,
+                     hipStream_t st) {
+    hipLaunchKernelGGL((dice_hard_vec<G>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart);
+}
+
+}  // namespace
+
+extern "C" size_t nrt_dice_workspace_bytes(long long nvox, int nlabels, int batch) {
+    (void)nvox;
+    if (nlabels < 1 || batch < 1) return 0;
+    return dice_ws_bytes(nlabels, batch);
+}
+
+extern "C" int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                                 int normalize, float laplace_smoothing, float *sums, float *dice, float *minmax,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    if (!y_true || !y_pred || !sums || !dice) return NRT_ERR_INVALID_ARG;
+    if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dice_ws_bytes(nlabels, batch)) return NRT_ERR_WORKSPACE;
+    if (nlabels > 4096) return NRT_ERR_UNSUPPORTED;
+    hipStream_t st = nrt_stream(stream);
+    DiceWs w = dice_ws_carve(workspace, nlabels, batch);
+    unsigned nblk, gz = 1;
+    const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
+    if (vec_labels(nlabels) && aligned) {
+        const int G = nlabels / 4;
+        nblk = dice_num_blocks(nvox, (DICE_BLOCK / G) * 4);
+        switch (G) {
+            case 1: launch_soft_vec<1>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 2: launch_soft_vec<2>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 4: launch_soft_vec<4>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 8: launch_soft_vec<8>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 16: launch_soft_vec<16>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 32: launch_soft_vec<32>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            default: launch_soft_vec<64>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+        }
+    } else {
+        const int Lc = nlabels < DICE_BLOCK ? nlabels : DICE_BLOCK;
+        gz = (unsigned)((nlabels + DICE_BLOCK - 1) / DICE_BLOCK);
+        nblk = dice_num_blocks(nvox, DICE_BLOCK / Lc);
+        if (nblk > DICE_MAX_BLOCKS / gz) nblk = DICE_MAX_BLOCKS / gz;
+        dim3 grid(nblk, batch, gz);
+        if (normalize) hipLaunchKernelGGL((dice_soft_generic<true>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
+        else hipLaunchKernelGGL((dice_soft_generic<false>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
+    }
+    NRT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dice_soft_finalize, dim3(batch), dim3(1024), (size_t)3 * nlabels * sizeof(float), st,
+                       (const float *)w.fpart, (const float *)w.mpart, (int)nblk, (int)(nblk * gz), nlabels,
+                       laplace_smoothing, sums, dice, minmax);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                                      float laplace_smoothing, long long *counts, float *dice, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    if (!y_true || !y_pred || !counts || !dice) return NRT_ERR_INVALID_ARG;
+    if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < dice_ws_bytes(nlabels, batch)) return NRT_ERR_WORKSPACE;
+    hipStream_t st = nrt_stream(stream);
+    DiceWs w = dice_ws_carve(workspace, nlabels, batch);
+    const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
+    if (vec_labels(nlabels) && aligned) {
+        const int G = nlabels / 4;
+        const unsigned nblk = dice_num_blocks(nvox, (DICE_BLOCK / G) * 4);
+        switch (G) {
+            case 1: launch_hard_vec<1>(y_true, y_pred, nvox, batch, nblk, w, st); break;
+            case 2: launch_hard_vec<2>(y_true, y_pred, nvox, batch, nblk, w, st); break;
+            case 4: launch_hard_vec<4>(y_true, y_pred, nvox, batch, nblk, w, st); break;
+            case 8: launch_hard_vec<8>(y_true, y_pred, nvox, batch, nblk, w, st); break;
+            case 16: launch_hard_vec<16>(y_true, y_pred, nvox, batch, nblk, w, st); break;
+            case 32: launch_hard_vec<32>(y_true, y_pred, nvox, batch, nblk, w, st); break;
+            default: launch_hard_vec<64>(y_true, y_pred, nvox, batch, nblk, w, st); break;
+        }
+        NRT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dice_counts_reduce, dim3(batch), dim3(256), 0, st, (const unsigned *)w.ipart, (int)nblk,
+                           nlabels, counts);
+    } else {
+        if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
+            return NRT_ERR_LAUNCH;
+        const unsigned nblk = dice_num_blocks(nvox, DICE_BLOCK);
+        hipLaunchKernelGGL(dice_hard_prob_generic, dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox,
+                           nlabels, counts);
+    }
+    NRT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dice_from_counts, dim3(batch), dim3(256), 0, st, (const long long *)counts, nlabels,
+                       laplace_smoothing, dice);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_pred, long long nvox, int nlabels,
+                                       int batch, float laplace_smoothing, long long *counts, float *dice,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (!y_true || !y_pred || !counts || !dice) return NRT_ERR_INVALID_ARG;
+    if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    hipStream_t st = nrt_stream(stream);
+    if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
+        return NRT_ERR_LAUNCH;
+    const int use_lds = (size_t)3 * nlabels * sizeof(unsigned) <= 64 * 1024;
+    const size_t shm = use_lds ? (size_t)3 * nlabels * sizeof(unsigned) : 0;
+    const unsigned nblk = dice_num_blocks(nvox, DICE_BLOCK * 8);
+    hipLaunchKernelGGL(dice_hard_label, dim3(nblk, batch), dim3(DICE_BLOCK), shm, st, (const int *)y_true,
+                       (const int *)y_pred, nvox, nlabels, use_lds, counts);
+    NRT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dice_from_counts, dim3(batch), dim3(256), 0, st, (const long long *)counts, nlabels,
+                       laplace_smoothing, dice);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_dice_from_sums_f32(const float *sums, int nlabels, int batch, float laplace_smoothing, float *dice,
+                                      void *stream) {
+    if (!sums || !dice || nlabels < 1 || batch < 1) return NRT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(dice_from_sums, dim3(batch), dim3(256), 0, nrt_stream(stream), sums, nlabels, laplace_smoothing, dice);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

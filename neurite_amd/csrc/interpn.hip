@@ -1,0 +1,594 @@
+// interpn / SpatialTransformer / Resize kernels for gfx950 (MI355X).
+//
+// Replaces the ~100 TensorFlow ops that neurite/tf/utils/utils.py:73-220 issues per call (8 gathers +
+// ~90 element-wise ops, each materialising a V- or V*C-sized temporary) with ONE pass: every source
+// row is read once from HBM, every output row written once, the identity grid (utils.py:333-476)
+// and the linspace grid of resize() (utils.py:259-260) are computed in registers.
+//
+// Layout in HBM (the reference's): vol [B, X, Y, Z, C], loc/shift [B, X', Y', Z', D],
+// out [B, X', Y', Z', C]; row-major, channel fastest.  A voxel's C channels are one contiguous
+// "row" (128 B at C = 32 fp32 = exactly one cache line / HBM burst).
+//
+// Three kernels:
+//   interpn_generic   one thread per output element, any C, D in {1,2,3}, float32 (linear/nearest)
+//                     or int32 (nearest).  Coalesced over channels.
+//   interpn_rows      C % 4 == 0: G = C/4 lanes own one voxel, each lane moves 16 B of every corner
+//                     row (global_load_dwordx4); a wave64 covers 64/G consecutive-z voxels, so the
+//                     corner rows of one wave instruction are (for smooth fields) one contiguous run.
+//   interpn_zrun_c32  C == 32, D == 3, linear: an 8-lane group walks a run of consecutive-z outputs
+//                     and keeps the four upper-z corner rows in registers as the next voxel's lower-z
+//                     rows (4 row loads per voxel instead of 8); loc/shift is fetched 8 voxels at a
+//                     time (96 B, coalesced) and broadcast inside the group with wave shuffles; the
+//                     next voxel's rows are in flight while the current one is blended.
+//
+// Arithmetic follows the reference op-for-op in float32 with one rounding per TF op (no FMA
+// contraction), corners accumulated in itertools.product order (utils.py:159-191), so the linear
+// path is bit-identical to the CPU restatement, not merely within 1e-5.
+
+#include "nrt_common.h"
+
+namespace {
+
+struct InterpArgs {
+    const void *vol;
+    const float *loc;
+    void *out;
+    int S[NRT_MAXD];       // source spatial shape (unused dims = 1)
+    int O[NRT_MAXD];       // output spatial shape
+    int C;
+    long long vol_bs, loc_bs, out_bs;   // batch strides in elements
+    float delta[NRT_MAXD]; // linspace step per dim: fl((S-1)/(O-1))
+    unsigned nout;         // prod(O)
+    int has_fill;
+    float fill_f;
+    int fill_i;
+};
+
+// ---- sampling location of output voxel q (coordinates qd) -------------------------------------
+template <int D, int MODE>
+__device__ __forceinline__ void load_loc(const InterpArgs &a, const float *locb, unsigned q,
+                                         const int (&qd)[NRT_MAXD], float (&p)[NRT_MAXD]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (MODE == NRT_LOC_ABSOLUTE) {
+            p[d] = locb[(long long)q * D + d];
+        } else if (MODE == NRT_LOC_SHIFT) {
+            // vxm transform(): cast(mesh, float32) + shift     (one rounding)
+            p[d] = nrt_add((float)qd[d], locb[(long long)q * D + d]);
+        } else {
+            // tf.linspace(0., S-1., O): first = 0, last = S-1 exactly, middle = 0 + delta*i
+            p[d] = (qd[d] == 0) ? 0.0f
+                 : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void decode(const InterpArgs &a, unsigned q, int (&qd)[NRT_MAXD]) {
+    unsigned r = q;
+#pragma unroll
+    for (int d = D - 1; d > 0; --d) { qd[d] = (int)(r % (unsigned)a.O[d]); r /= (unsigned)a.O[d]; }
+    qd[0] = (int)r;
+}
+
+// utils.py:139-153 for one dimension
+__device__ __forceinline__ void corner_1d(float p, int size, int &i0, int &i1, float &w0, float &w1) {
+    const float mx = (float)(size - 1);
+    const float f = floorf(p);                       // :139
+    const float cl = nrt_clip(p, 0.0f, mx);          // :142
+    const float l0 = nrt_clip(f, 0.0f, mx);          // :143
+    const float l1 = nrt_clip(nrt_add(l0, 1.0f), 0.0f, mx);   // :146
+    i0 = (int)l0; i1 = (int)l1;                      // :147
+    w0 = nrt_sub(l1, cl);                            // :152  weight of the lower corner
+    w1 = nrt_sub(1.0f, w0);                          // :153  weight of the upper corner
+}
+
+__device__ __forceinline__ int nearest_1d(float p, int size) {
+    // :196-197  int32(round_half_even(p)) clipped to [0, size-1]; v_cvt_i32_f32 saturates, NaN -> 0
+    return nrt_clampi((int)rintf(p), 0, size - 1);
+}
+
+template <int D>
+__device__ __forceinline__ bool out_of_bounds(const InterpArgs &a, const float (&p)[NRT_MAXD]) {
+    bool oob = false;                                // :209-211 (unclipped location)
+#pragma unroll
+    for (int d = 0; d < D; ++d) oob = oob || (p[d] < 0.0f) || (p[d] > (float)(a.S[d] - 1));
+    return oob;
+}
+
+__device__ __forceinline__ float apply_fill(float v, bool oob, float fill) {
+    // :212-213   v * float(!oob) + float(oob) * fill   (NaN/Inf propagate exactly as in the reference)
+    return nrt_add(nrt_mul(v, oob ? 0.0f : 1.0f), nrt_mul(oob ? 1.0f : 0.0f, fill));
+}
+
+// ============================================================================================
+// generic: one thread per output element
+// ============================================================================================
+template <int D, int MODE, int METHOD, typename T>
+__global__ __launch_bounds__(256) void interpn_generic(InterpArgs a) {
+    const int b = blockIdx.y;
+    const T *vol = (const T *)a.vol + (long long)b * a.vol_bs;
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    T *out = (T *)a.out + (long long)b * a.out_bs;
+    const unsigned long long total = (unsigned long long)a.nout * (unsigned)a.C;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const unsigned q = (unsigned)(e / (unsigned)a.C);
+        const int c = (int)(e - (unsigned long long)q * (unsigned)a.C);
+        int qd[NRT_MAXD];
+        float p[NRT_MAXD];
+        decode<D>(a, q, qd);
+        load_loc<D, MODE>(a, locb, q, qd, p);
+        const bool oob = a.has_fill ? out_of_bounds<D>(a, p) : false;
+        if (METHOD == NRT_INTERP_NEAREST) {
+            long long idx = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) idx = idx * a.S[d] + nearest_1d(p[d], a.S[d]);
+            T v = vol[idx * a.C + c];
+            if (a.has_fill) {
+                if (sizeof(T) == 4 && __is_same(T, float)) {
+                    float fv = apply_fill(*(float *)&v, oob, a.fill_f);
+                    v = *(T *)&fv;
+                } else {
+                    int iv = *(int *)&v;
+                    iv = iv * (oob ? 0 : 1) + (oob ? 1 : 0) * a.fill_i;
+                    v = *(T *)&iv;
+                }
+            }
+            out[e] = v;
+        } else {
+            int i0[NRT_MAXD], i1[NRT_MAXD];
+            float w0[NRT_MAXD], w1[NRT_MAXD];
+#pragma unroll
+            for (int d = 0; d < D; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+            float acc = 0.0f;                                    // :160
+#pragma unroll
+            for (int corner = 0; corner < (1 << D); ++corner) {  // product([0,1], repeat=D) order
+                long long idx = 0;
+                float wt = 0.0f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int bit = (corner >> (D - 1 - d)) & 1;
+                    idx = idx * a.S[d] + (bit ? i1[d] : i0[d]);              // sub2ind2d :1068-1082
+                    const float w = bit ? w1[d] : w0[d];
+                    wt = (d == 0) ? w : nrt_mul(wt, w);                      // prod_n :1085-1092
+                }
+                const float v = ((const float *)vol)[idx * a.C + c];
+                acc = nrt_add(acc, nrt_mul(wt, v));                          // :191
+            }
+            if (a.has_fill) acc = apply_fill(acc, oob, a.fill_f);
+            ((float *)out)[e] = acc;
+        }
+    }
+}
+
+// ============================================================================================
+// rows: G = C/4 lanes per voxel, float4 per lane, D == 3 (D < 3 is padded with size-1 dims by the host)
+// ============================================================================================
+template <int G, int MODE, int METHOD>
+__global__ __launch_bounds__(256) void interpn_rows(InterpArgs a, unsigned nblk, unsigned vox_per_block) {
+    constexpr int D = 3;
+    constexpr int NG = 256 / G;      // voxels per block pass
+    const unsigned lb = nrt_xcd_block(blockIdx.x, gridDim.x);
+    if (lb >= nblk) return;
+    const int b = blockIdx.y;
+    const nrt_f4 *vol = (const nrt_f4 *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
+    const int lg = threadIdx.x % G;
+    const unsigned g = threadIdx.x / G;
+    const unsigned q0 = lb * vox_per_block;
+    const unsigned q1 = min(q0 + vox_per_block, a.nout);
+    const int Y = a.S[1], Z = a.S[2];
+
+#pragma unroll 2
+    for (unsigned q = q0 + g; q < q1; q += NG) {
+        int qd[NRT_MAXD];
+        float p[NRT_MAXD];
+        decode<D>(a, q, qd);
+        load_loc<D, MODE>(a, locb, q, qd, p);
+        const bool oob = a.has_fill ? out_of_bounds<D>(a, p) : false;
+        nrt_f4 acc;
+        if (METHOD == NRT_INTERP_NEAREST) {
+            const long long idx = ((long long)nearest_1d(p[0], a.S[0]) * Y + nearest_1d(p[1], Y)) * Z
+                                  + nearest_1d(p[2], Z);
+            acc = vol[idx * G + lg];
+        } else {
+            int i0[3], i1[3];
+            float w0[3], w1[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+            nrt_f4 v[8];
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const int ix = (corner & 4) ? i1[0] : i0[0];
+                const int iy = (corner & 2) ? i1[1] : i0[1];
+                const int iz = (corner & 1) ? i1[2] : i0[2];
+                v[corner] = vol[(((long long)ix * Y + iy) * Z + iz) * G + lg];
+            }
+            acc = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const float wt = nrt_mul(nrt_mul((corner & 4) ? w1[0] : w0[0], (corner & 2) ? w1[1] : w0[1]),
+                                         (corner & 1) ? w1[2] : w0[2]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = nrt_add(acc[k], nrt_mul(wt, v[corner][k]));
+            }
+        }
+        if (a.has_fill) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = apply_fill(acc[k], oob, a.fill_f);
+        }
+        __builtin_nontemporal_store(acc, &out[(long long)q * G + lg]);
+    }
+}
+
+// ============================================================================================
+// z-run: C == 32 (8 lanes x float4 per row), D == 3, linear.
+// Block = 256 threads = 32 lane-groups = a 4(x) x 8(y) patch of output columns; each group walks
+// z in [zc*LZ, zc*LZ+LZ).  Logical blocks are XCD-contiguous in x so neighbouring patches share L2.
+// ============================================================================================
+struct ZIdx {
+    int ix0, ix1, iy0, iy1, iz0, iz1;
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+    bool oob;
+};
+
+template <int MODE>
+__device__ __forceinline__ void zrun_index(const InterpArgs &a, int x, int y, int z, float sx, float sy, float sz,
+                                           ZIdx &o) {
+    float p[NRT_MAXD];
+    if (MODE == NRT_LOC_ABSOLUTE) {
+        p[0] = sx; p[1] = sy; p[2] = sz;
+    } else if (MODE == NRT_LOC_SHIFT) {
+        p[0] = nrt_add((float)x, sx); p[1] = nrt_add((float)y, sy); p[2] = nrt_add((float)z, sz);
+    } else {
+        const int qd[3] = {x, y, z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            p[d] = (qd[d] == 0) ? 0.0f
+                 : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
+    }
+    corner_1d(p[0], a.S[0], o.ix0, o.ix1, o.wx0, o.wx1);
+    corner_1d(p[1], a.S[1], o.iy0, o.iy1, o.wy0, o.wy1);
+    corner_1d(p[2], a.S[2], o.iz0, o.iz1, o.wz0, o.wz1);
+    o.oob = a.has_fill ? out_of_bounds<3>(a, p) : false;
+}
+
+__device__ __forceinline__ unsigned zrun_col(const InterpArgs &a, const ZIdx &i, int c) {
+    // column base (row index at z = 0) of xy-corner c = cx*2 + cy; the host guarantees that a whole
+    // volume is < 4 GiB so that rows are addressed as uniform base (SGPR pair) + 32-bit byte offset
+    const int ix = (c & 2) ? i.ix1 : i.ix0;
+    const int iy = (c & 1) ? i.iy1 : i.iy0;
+    return ((unsigned)ix * (unsigned)a.S[1] + (unsigned)iy) * (unsigned)a.S[2];
+}
+
+__device__ __forceinline__ nrt_f4 zrun_row(const char *__restrict__ volb, unsigned row, int lg) {
+    return *(const nrt_f4 *)(volb + (size_t)((row * 8u + (unsigned)lg) * 16u));
+}
+
+// One z-step.  Planes A (lower-z rows of the current voxel), B (its upper-z rows) are complete or in
+// flight from earlier steps; C is free.  Order matters for latency hiding:
+//   1. index voxel z+1 and issue its upper-z rows into C          (4 x 16 B per lane in flight)
+//   2. blend voxel z from A and B, store                          (waits only for A/B: vmcnt(4))
+//   3. if the run is not coherent (rare), reload B in place with voxel z+1's lower-z rows
+// The caller rotates roles (A,B,C) -> (B,C,A) -> (C,A,B) by unrolling x3, so no register is ever
+// copied while its load is outstanding.
+struct ZShift {
+    float s0, s1, s2;   // current batch of 8 voxels (24 floats): lane lg holds flat elements lg, lg+8, lg+16
+    float n0, n1, n2;   // next batch, prefetched one batch ahead
+};
+
+template <int MODE>
+__device__ __forceinline__ bool zrun_step(const InterpArgs &a, const char *__restrict__ vol,
+                                          const float *__restrict__ locq, nrt_f4 *__restrict__ outq,
+                                          int x, int y, int z, int zbeg, int zend, int lg, int grp_base,
+                                          ZIdx &cur, ZShift &sh, nrt_f4 (&A)[4], nrt_f4 (&B)[4], nrt_f4 (&C)[4]) {
+    const bool has_next = (z + 1 < zend);
+    ZIdx nxt = cur;
+    bool reuse = true;
+    if (has_next) {
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        if (MODE != NRT_LOC_LINSPACE) {
+            const int kb = (z + 1 - zbeg) & 7;
+            if (kb == 0) {                                   // uniform: entering the prefetched batch
+                sh.s0 = sh.n0; sh.s1 = sh.n1; sh.s2 = sh.n2;
+                const int zn = z + 1 + 8;
+                if (zn < zend) {
+                    const int nrem = (zend - zn) * 3;
+                    const float *sp = locq + (long long)zn * 3;
+                    sh.n0 = (lg < nrem) ? __builtin_nontemporal_load(sp + lg) : 0.0f;
+                    sh.n1 = (lg + 8 < nrem) ? __builtin_nontemporal_load(sp + lg + 8) : 0.0f;
+                    sh.n2 = (lg + 16 < nrem) ? __builtin_nontemporal_load(sp + lg + 16) : 0.0f;
+                }
+            }
+            const int e = 3 * kb;
+            // element e+d lives in register (e+d)>>3 of lane (e+d)&7 of this lane-group
+            const int e1 = e + 1, e2 = e + 2;
+            const float r0 = (e < 8) ? sh.s0 : ((e < 16) ? sh.s1 : sh.s2);
+            const float r1 = (e1 < 8) ? sh.s0 : ((e1 < 16) ? sh.s1 : sh.s2);
+            const float r2 = (e2 < 8) ? sh.s0 : ((e2 < 16) ? sh.s1 : sh.s2);
+            sx = __shfl(r0, grp_base | (e & 7), 64);
+            sy = __shfl(r1, grp_base | (e1 & 7), 64);
+            sz = __shfl(r2, grp_base | (e2 & 7), 64);
+        }
+        zrun_index<MODE>(a, x, y, z + 1, sx, sy, sz, nxt);
+        reuse = (nxt.ix0 == cur.ix0) && (nxt.ix1 == cur.ix1) && (nxt.iy0 == cur.iy0) &&
+                (nxt.iy1 == cur.iy1) && (nxt.iz0 == cur.iz1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) C[c] = zrun_row(vol, zrun_col(a, nxt, c) + (unsigned)nxt.iz1, lg);
+    }
+    // blend the current voxel (utils.py:159-191 corner order: x, y, z with z fastest)
+    nrt_f4 acc = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const float wt = nrt_mul(nrt_mul((corner & 4) ? cur.wx1 : cur.wx0, (corner & 2) ? cur.wy1 : cur.wy0),
+                                 (corner & 1) ? cur.wz1 : cur.wz0);
+        const nrt_f4 v = (corner & 1) ? B[corner >> 1] : A[corner >> 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = nrt_add(acc[k], nrt_mul(wt, v[k]));
+    }
+    if (a.has_fill) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = apply_fill(acc[k], cur.oob, a.fill_f);
+    }
+    __builtin_nontemporal_store(acc, &outq[(long long)z * 8 + lg]);
+    if (!reuse) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) B[c] = zrun_row(vol, zrun_col(a, nxt, c) + (unsigned)nxt.iz0, lg);
+    }
+    cur = nxt;
+    return !has_next;
+}
+
+template <int MODE, int MINW>
+__global__ __launch_bounds__(256, MINW) void interpn_zrun_c32(InterpArgs a, int LZ, unsigned nTy, unsigned nZc, unsigned nblk) {
+    const unsigned lb = nrt_xcd_block(blockIdx.x, gridDim.x);
+    if (lb >= nblk) return;
+    const int b = blockIdx.y;
+    const char *vol = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
+
+    const unsigned zc = lb % nZc;
+    const unsigned t = lb / nZc;
+    const unsigned ty = t % nTy, tx = t / nTy;
+    const int lane = threadIdx.x & 63;
+    const int lg = lane & 7;                 // 16-byte slice of the 128-byte row
+    const int j = lane >> 3;                 // group within the wave: 2(x) x 4(y)
+    const int w = threadIdx.x >> 6;          // wave within the block: 2(x) x 2(y)
+    const int x = (int)tx * 4 + (w >> 1) * 2 + (j >> 2);
+    const int y = (int)ty * 8 + (w & 1) * 4 + (j & 3);
+    if (x >= a.O[0] || y >= a.O[1]) return;  // whole lane-groups leave together; no block barrier below
+    const int zbeg = (int)zc * LZ;
+    const int zend = min(zbeg + LZ, a.O[2]);
+    const long long colq = ((long long)x * a.O[1] + y) * a.O[2];   // output voxel index at z = 0
+    const int grp_base = lane & 56;
+    const float *locq = locb ? locb + colq * 3 : nullptr;
+    nrt_f4 *outq = out + colq * 8;
+
+    nrt_f4 P0[4], P1[4], P2[4];
+    ZIdx cur;
+    ZShift sh = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    if (MODE != NRT_LOC_LINSPACE) {
+        {
+            const int nrem = (zend - zbeg) * 3;
+            const float *sp = locq + (long long)zbeg * 3;
+            sh.s0 = (lg < nrem) ? __builtin_nontemporal_load(sp + lg) : 0.0f;
+            sh.s1 = (lg + 8 < nrem) ? __builtin_nontemporal_load(sp + lg + 8) : 0.0f;
+            sh.s2 = (lg + 16 < nrem) ? __builtin_nontemporal_load(sp + lg + 16) : 0.0f;
+        }
+        if (zbeg + 8 < zend) {
+            const int nrem = (zend - zbeg - 8) * 3;
+            const float *sp = locq + (long long)(zbeg + 8) * 3;
+            sh.n0 = (lg < nrem) ? __builtin_nontemporal_load(sp + lg) : 0.0f;
+            sh.n1 = (lg + 8 < nrem) ? __builtin_nontemporal_load(sp + lg + 8) : 0.0f;
+            sh.n2 = (lg + 16 < nrem) ? __builtin_nontemporal_load(sp + lg + 16) : 0.0f;
+        }
+        sx = __shfl(sh.s0, grp_base | 0, 64);
+        sy = __shfl(sh.s0, grp_base | 1, 64);
+        sz = __shfl(sh.s0, grp_base | 2, 64);
+    }
+    zrun_index<MODE>(a, x, y, zbeg, sx, sy, sz, cur);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned col = zrun_col(a, cur, c);
+        P0[c] = zrun_row(vol, col + (unsigned)cur.iz0, lg);
+        P1[c] = zrun_row(vol, col + (unsigned)cur.iz1, lg);
+    }
+    int z = zbeg;
+    while (true) {
+        if (zrun_step<MODE>(a, vol, locq, outq, x, y, z, zbeg, zend, lg, grp_base, cur, sh, P0, P1, P2)) break;
+        ++z;
+        if (zrun_step<MODE>(a, vol, locq, outq, x, y, z, zbeg, zend, lg, grp_base, cur, sh, P1, P2, P0)) break;
+        ++z;
+        if (zrun_step<MODE>(a, vol, locq, outq, x, y, z, zbeg, zend, lg, grp_base, cur, sh, P2, P0, P1)) break;
+        ++z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int fill_args(InterpArgs &a, const void *vol, const float *loc, void *out, int ndim, const int *vol_shape,
+              const int *out_shape, int channels, int batch, long long vol_bs, long long loc_bs, int loc_mode,
+              int has_fill) {
+    if (!vol || !out || !vol_shape || !out_shape) return NRT_ERR_INVALID_ARG;
+    if (ndim < 1 || ndim > NRT_MAXD || channels < 1 || batch < 1) return NRT_ERR_INVALID_ARG;
+    if (loc_mode < 0 || loc_mode > 2) return NRT_ERR_INVALID_ARG;
+    if (loc_mode != NRT_LOC_LINSPACE && !loc) return NRT_ERR_INVALID_ARG;
+    if (batch > 65535) return NRT_ERR_UNSUPPORTED;
+    a.vol = vol; a.loc = loc; a.out = out; a.C = channels;
+    unsigned long long nin = 1, nout = 1;
+    for (int d = 0; d < NRT_MAXD; ++d) {
+        a.S[d] = d < ndim ? vol_shape[d] : 1;
+        a.O[d] = d < ndim ? out_shape[d] : 1;
+        if (a.S[d] < 1 || a.O[d] < 0) return NRT_ERR_INVALID_ARG;
+        nin *= (unsigned long long)a.S[d];
+        nout *= (unsigned long long)a.O[d];
+        // tf.linspace: delta = (stop - start) / (num - 1) in float32
+        a.delta[d] = a.O[d] > 1 ? (float)(a.S[d] - 1) / (float)(a.O[d] - 1) : 0.0f;
+    }
+    if (nin * (unsigned long long)channels >= (1ull << 40) || nout >= (1ull << 31)) return NRT_ERR_UNSUPPORTED;
+    a.nout = (unsigned)nout;
+    a.vol_bs = vol_bs; a.loc_bs = loc_bs; a.out_bs = (long long)nout * channels;
+    a.has_fill = has_fill ? 1 : 0;
+    a.fill_f = 0.0f; a.fill_i = 0;
+    return NRT_OK;
+}
+
+template <int MODE, int METHOD, typename T>
+void launch_generic_d(const InterpArgs &a, int ndim, int batch, hipStream_t st) {
+    const unsigned long long total = (unsigned long long)a.nout * (unsigned)a.C;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 256u * 16u) blocks = 256u * 16u;     // grid-stride the rest
+    dim3 grid(blocks, batch);
+    switch (ndim) {
+        case 1: hipLaunchKernelGGL((interpn_generic<1, MODE, METHOD, T>), grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((interpn_generic<2, MODE, METHOD, T>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((interpn_generic<3, MODE, METHOD, T>), grid, dim3(256), 0, st, a); break;
+    }
+}
+
+template <int METHOD, typename T>
+void launch_generic(const InterpArgs &a, int ndim, int batch, int mode, hipStream_t st) {
+    switch (mode) {
+        case NRT_LOC_ABSOLUTE: launch_generic_d<NRT_LOC_ABSOLUTE, METHOD, T>(a, ndim, batch, st); break;
+        case NRT_LOC_SHIFT: launch_generic_d<NRT_LOC_SHIFT, METHOD, T>(a, ndim, batch, st); break;
+        default: launch_generic_d<NRT_LOC_LINSPACE, METHOD, T>(a, ndim, batch, st); break;
+    }
+}
+
+template <int G, int MODE>
+void launch_rows_m(const InterpArgs &a, int batch, int method, int tune, hipStream_t st) {
+    constexpr unsigned NG = 256 / G;
+    unsigned passes = tune > 0 ? (unsigned)tune : 4u;
+    const unsigned vpb = NG * passes;
+    const unsigned nblk = (a.nout + vpb - 1) / vpb;
+    dim3 grid(nrt_xcd_grid(nblk), batch);
+    if (method == NRT_INTERP_NEAREST)
+        hipLaunchKernelGGL((interpn_rows<G, MODE, NRT_INTERP_NEAREST>), grid, dim3(256), 0, st, a, nblk, vpb);
+    else
+        hipLaunchKernelGGL((interpn_rows<G, MODE, NRT_INTERP_LINEAR>), grid, dim3(256), 0, st, a, nblk, vpb);
+}
+
+template <int G>
+void launch_rows(const InterpArgs &a, int batch, int mode, int method, int tune, hipStream_t st) {
+    switch (mode) {
+        case NRT_LOC_ABSOLUTE: launch_rows_m<G, NRT_LOC_ABSOLUTE>(a, batch, method, tune, st); break;
+        case NRT_LOC_SHIFT: launch_rows_m<G, NRT_LOC_SHIFT>(a, batch, method, tune, st); break;
+        default: launch_rows_m<G, NRT_LOC_LINSPACE>(a, batch, method, tune, st); break;
+    }
+}
+
+bool rows_supported(int channels) {
+    if (channels % 4) return false;
+    const int g = channels / 4;
+    return g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64;
+}
+
+void launch_rows_any(const InterpArgs &a, int batch, int mode, int method, int tune, hipStream_t st) {
+    switch (a.C / 4) {
+        case 1: launch_rows<1>(a, batch, mode, method, tune, st); break;
+        case 2: launch_rows<2>(a, batch, mode, method, tune, st); break;
+        case 4: launch_rows<4>(a, batch, mode, method, tune, st); break;
+        case 8: launch_rows<8>(a, batch, mode, method, tune, st); break;
+        case 16: launch_rows<16>(a, batch, mode, method, tune, st); break;
+        case 32: launch_rows<32>(a, batch, mode, method, tune, st); break;
+        default: launch_rows<64>(a, batch, mode, method, tune, st); break;
+    }
+}
+
+template <int MINW>
+void launch_zrun_w(const InterpArgs &a, int batch, int mode, int LZ, hipStream_t st) {
+    const unsigned nTx = (a.O[0] + 3) / 4, nTy = (a.O[1] + 7) / 8, nZc = (a.O[2] + LZ - 1) / LZ;
+    const unsigned nblk = nTx * nTy * nZc;
+    dim3 grid(nrt_xcd_grid(nblk), batch);
+    switch (mode) {
+        case NRT_LOC_ABSOLUTE:
+            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_ABSOLUTE, MINW>), grid, dim3(256), 0, st, a, LZ, nTy, nZc, nblk); break;
+        case NRT_LOC_SHIFT:
+            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_SHIFT, MINW>), grid, dim3(256), 0, st, a, LZ, nTy, nZc, nblk); break;
+        default:
+            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_LINSPACE, MINW>), grid, dim3(256), 0, st, a, LZ, nTy, nZc, nblk); break;
+    }
+}
+
+// variant 3: register budget <= 128 VGPR (4 waves/SIMD); variant 4: <= 96 (5 waves/SIMD)
+void launch_zrun(const InterpArgs &a, int batch, int mode, int variant, int tune, hipStream_t st) {
+    int LZ = tune > 0 ? tune : a.O[2];
+    if (LZ > a.O[2]) LZ = a.O[2];
+    if (LZ < 1) LZ = 1;
+    if (variant == 4) launch_zrun_w<5>(a, batch, mode, LZ, st);
+    else launch_zrun_w<4>(a, batch, mode, LZ, st);
+}
+
+}  // namespace
+
+// Default kernel choice, set from measurements on MI355X (profiles/): see DESIGN.md.
+static int g_auto_c32_variant = 3;
+static int g_auto_c32_tune = 40;
+
+extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out, int ndim, const int *vol_shape,
+                                  const int *out_shape, int channels, int batch, long long vol_batch_stride,
+                                  long long loc_batch_stride, int loc_mode, int method, int has_fill,
+                                  float fill_value, int variant, int tune, void *stream) {
+    InterpArgs a;
+    int rc = fill_args(a, vol, loc, out, ndim, vol_shape, out_shape, channels, batch, vol_batch_stride,
+                       loc_batch_stride, loc_mode, has_fill);
+    if (rc != NRT_OK) return rc;
+    if (method != NRT_INTERP_LINEAR && method != NRT_INTERP_NEAREST) return NRT_ERR_INVALID_ARG;
+    a.fill_f = fill_value;
+    if (a.nout == 0) return NRT_OK;
+    hipStream_t st = nrt_stream(stream);
+    const bool aligned = (((uintptr_t)vol | (uintptr_t)out) & 15) == 0 &&
+                         ((vol_batch_stride * 4) % 16 == 0);
+    const bool can_rows = rows_supported(channels) && aligned && ndim == 3;
+    unsigned long long vol_bytes = 4ull * channels;
+    for (int d = 0; d < ndim; ++d) vol_bytes *= (unsigned long long)vol_shape[d];
+    const bool can_zrun = can_rows && channels == 32 && ndim == 3 && method == NRT_INTERP_LINEAR &&
+                          vol_bytes < (1ull << 32);
+    if (variant == 0) {
+        if (can_zrun) { variant = g_auto_c32_variant; if (tune == 0) tune = (variant >= 3) ? g_auto_c32_tune : 0; }
+        else if (can_rows) variant = 2;
+        else variant = 1;
+    }
+    if ((variant == 3 || variant == 4) && !can_zrun) return NRT_ERR_UNSUPPORTED;
+    if (variant == 2 && !can_rows) return NRT_ERR_UNSUPPORTED;
+    switch (variant) {
+        case 1:
+            if (method == NRT_INTERP_LINEAR) launch_generic<NRT_INTERP_LINEAR, float>(a, ndim, batch, loc_mode, st);
+            else launch_generic<NRT_INTERP_NEAREST, float>(a, ndim, batch, loc_mode, st);
+            break;
+        case 2: launch_rows_any(a, batch, loc_mode, method, tune, st); break;
+        case 3:
+        case 4: launch_zrun(a, batch, loc_mode, variant, tune, st); break;
+        default: return NRT_ERR_INVALID_ARG;
+    }
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_interpn_f32(const float *vol, const float *loc, float *out, int ndim, const int *vol_shape,
+                               const int *out_shape, int channels, int batch, long long vol_batch_stride,
+                               long long loc_batch_stride, int loc_mode, int method, int has_fill,
+                               float fill_value, void *stream) {
+    return nrt_interpn_f32_ex(vol, loc, out, ndim, vol_shape, out_shape, channels, batch, vol_batch_stride,
+                              loc_batch_stride, loc_mode, method, has_fill, fill_value, 0, 0, stream);
+}
+
+extern "C" int nrt_interpn_nearest_i32(const int32_t *vol, const float *loc, int32_t *out, int ndim,
+                                       const int *vol_shape, const int *out_shape, int channels, int batch,
+                                       long long vol_batch_stride, long long loc_batch_stride, int loc_mode,
+                                       int has_fill, int32_t fill_value, void *stream) {
+    InterpArgs a;
+    int rc = fill_args(a, vol, loc, out, ndim, vol_shape, out_shape, channels, batch, vol_batch_stride,
+                       loc_batch_stride, loc_mode, has_fill);
+    if (rc != NRT_OK) return rc;
+    a.fill_i = fill_value;
+    if (a.nout == 0) return NRT_OK;
+    launch_generic<NRT_INTERP_NEAREST, int32_t>(a, ndim, batch, loc_mode, nrt_stream(stream));
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

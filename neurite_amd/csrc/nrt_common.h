@@ -1,0 +1,46 @@
+// Shared device/host helpers for the gfx950 kernels (wave64 everywhere; no CUDA compatibility).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/neurite_amd.h"
+
+#define NRT_WAVE 64
+#define NRT_NXCD 8          // MI355X: 8 XCDs, block b is observed to run on XCD b % 8
+#define NRT_MAXD 3
+
+typedef float nrt_f4 __attribute__((ext_vector_type(4)));
+typedef int nrt_i4 __attribute__((ext_vector_type(4)));
+
+#define NRT_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return NRT_ERR_LAUNCH;        \
+    } while (0)
+
+// Separately rounded float ops.  The library is built with -ffp-contract=off as well; these keep
+// the reference's one-rounding-per-op sequence explicit where bit-parity depends on it.
+__device__ __forceinline__ float nrt_mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float nrt_add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float nrt_sub(float a, float b) { return __fsub_rn(a, b); }
+
+// tf.clip_by_value(v, lo, hi) = min(max(v, lo), hi).  fmaxf/fminf also squash NaN to a finite
+// bound, so an index derived from the result can never leave the volume.
+__device__ __forceinline__ float nrt_clip(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+__device__ __forceinline__ int nrt_clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// XCD-aware logical block id: consecutive logical blocks stay on one XCD (one L2), XCD k owns the
+// k-th contiguous eighth of the logical range.  Launch with gridDim.x = NRT_NXCD * ceil(n / NRT_NXCD);
+// ids >= n must exit.  Placement only affects speed, never results.
+__device__ __forceinline__ unsigned nrt_xcd_block(unsigned bid, unsigned grid) {
+    unsigned per = grid / NRT_NXCD;
+    return (bid % NRT_NXCD) * per + bid / NRT_NXCD;
+}
+
+static inline unsigned nrt_xcd_grid(unsigned nblocks) {
+    return NRT_NXCD * ((nblocks + NRT_NXCD - 1) / NRT_NXCD);
+}
+
+static inline hipStream_t nrt_stream(void *s) { return (hipStream_t)s; }

@@ -1,0 +1,93 @@
+"""
+Data-parallel use of the hot path: one process per GPU (torch.distributed, backend "nccl" = RCCL over
+xGMI), volumes sharded over ranks by batch entry.
+
+The path shards by independent units: warping and per-(batch, label) Dice need
+no communication at all.  Only the reductions that cross batch entries do:
+
+  mean_dice  = mean over ALL B*L entries of dice*weights   (neurite/tf/metrics.py:499-510)
+  cce        = mean over ALL B*V voxels                      (Keras SUM_OVER_BATCH_SIZE)
+
+Both are ONE all-reduce of a handful of floats per step (latency-bound, ~2L+2 floats): each rank
+contributes [sum of its weighted dice entries, number of entries] (or [loss sum, voxel count]).
+For a batch entry split spatially across ranks the Dice numerator/denominator partials
+`sums [B, 3, L]` are all-reduced instead, before the division (reduce_dice_sums).
+
+The reference's own multi-device code is keras.utils.multi_gpu_model (neurite/tf/utils/model.py:298-321),
+single-process tower replication; nothing of it is reproduced here.
+"""
+
+import torch
+import torch.distributed as dist
+
+__all__ = ['shard_range', 'all_reduce_mean_dice', 'all_reduce_mean', 'reduce_dice_sums', 'dice_from_sums']
+
+
+def _world(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_range(n_items, rank=None, world_size=None):
+    """Contiguous shard [lo, hi) of n_items for `rank`; remainders go to the first ranks."""
+    r, w = _world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_reduce_mean_dice(local_dice, weights=None, group=None):
+    """
+    local_dice [B_local, L] (this rank's batch entries).  Returns the global mean over all ranks'
+    entries of dice*weights -- what Dice.mean_dice would return on the gathered batch.  One all-reduce
+    of 2 floats.
+    """
+    d = local_dice
+    if weights is not None:
+        d = d * torch.as_tensor(weights, dtype=d.dtype, device=d.device)
+    buf = torch.stack([d.sum(dtype=torch.float32), torch.tensor(float(d.numel()), device=d.device)])
+    _, w = _world(group)
+    if w > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[0] / buf[1]
+
+
+def all_reduce_mean(local_sum, local_count, group=None):
+    """Global mean from per-rank (sum, count): the cross-entropy reduction over all B*V voxels."""
+    buf = torch.stack([local_sum.reshape(()).to(torch.float32),
+                       torch.tensor(float(local_count), device=local_sum.device)])
+    _, w = _world(group)
+    if w > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[0] / buf[1]
+
+
+def reduce_dice_sums(sums, group=None):
+    """All-reduce the numerator/denominator partials [B, 3, L] of spatially split batch entries."""
+    _, w = _world(group)
+    if w > 1:
+        sums = sums.clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+def dice_from_sums(sums, laplace_smoothing=0.):
+    """
+    dice [B, L] from (all-reduced) sums [B, 3, L] = sum t*p, sum t^2, sum p^2 (metrics.py:476-482),
+    computed by the HIP finalize kernel (ROCm tensors only, like every compute entry point).
+    """
+    from . import _lib
+    lib = _lib.lib()
+    dev = _lib.require_device(sums)
+    B, three, L = sums.shape
+    assert three == 3, 'sums must be [B, 3, L]'
+    s = sums.contiguous().to(torch.float32)
+    out = torch.empty((B, L), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_dice_from_sums_f32(_lib.ptr(s), L, B, float(laplace_smoothing), _lib.ptr(out),
+                                        _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_dice_from_sums_f32')
+    return out

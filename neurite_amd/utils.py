@@ -1,0 +1,336 @@
+"""
+neurite_amd.utils -- the tensor utilities of neurite's hot path on MI355X.
+
+Mirrors the names, arguments, defaults and error behaviour of neurite/tf/utils/utils.py for
+interpn (:73), resize/zoom (:223,:265), volshape_to_ndgrid (:333), volshape_to_meshgrid (:356),
+ndgrid (:382), meshgrid (:398), sub2ind2d (:1068), prod_n (:1085), batch_channel_flatten (:1175),
+flatten_axes (:1195); plus voxelmorph's transform()/affine_to_dense_shift, which the reference
+calls but does not vendor (neurite/tf/models.py:806-807, 1157-1159).
+
+Tensors are torch tensors on a ROCm device in the reference's channels-last layout.  All sampling
+work is done by the HIP kernels in csrc/interpn.hip through the C ABI; nothing here falls back
+to PyTorch or the CPU.
+"""
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ['interpn', 'resize', 'zoom', 'transform', 'affine_to_dense_shift', 'volshape_to_ndgrid',
+           'volshape_to_meshgrid', 'ndgrid', 'meshgrid', 'sub2ind2d', 'prod_n', 'batch_channel_flatten',
+           'flatten_batch_channel', 'flatten_axes']
+
+_METHODS = {'linear': _lib.INTERP_LINEAR, 'nearest': _lib.INTERP_NEAREST}
+_SMALL_INTS = (torch.int8, torch.uint8, torch.int16, torch.bool)
+
+
+class _NoBackward(torch.autograd.Function):
+    """Forward-only ops: reaching backward is an error, never a silent zero gradient."""
+
+    @staticmethod
+    def forward(ctx, fn, *tensors):
+        with torch.no_grad():
+            return fn()
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError('neurite_amd: backward of the HIP hot-path ops is not implemented yet '
+                                  '(forward-only build; see DESIGN.md "what comes next").')
+
+
+def _maybe_tracked(fn, *tensors):
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        return _NoBackward.apply(fn, *[t for t in tensors if isinstance(t, torch.Tensor)])
+    return fn()
+
+
+def _launch_interpn(vol, loc, out_spatial, loc_mode, method, fill_value, batched, single_transform=False,
+                    variant=0, tune=0):
+    """
+    vol [B?, *S, C] contiguous; loc [B?, *S', D] float32 contiguous or None (LINSPACE).
+    Returns out [B?, *S', C] with vol's dtype.
+    """
+    lib = _lib.lib()
+    dev = _lib.require_device(vol, loc)
+    vol = vol.contiguous()
+    if batched:
+        B = vol.shape[0]
+        S = list(vol.shape[1:-1])
+    else:
+        B = 1
+        S = list(vol.shape[:-1])
+    Cc = vol.shape[-1]
+    D = len(S)
+    if D < 1 or D > 3:
+        raise NotImplementedError('neurite_amd.interpn supports 1-, 2- and 3-D volumes, got %d-D' % D)
+    out_spatial = [int(s) for s in out_spatial]
+    out_shape = ([B] if batched else []) + out_spatial + [Cc]
+    out = torch.empty(out_shape, dtype=vol.dtype, device=dev)
+    if out.numel() == 0:
+        return out
+    nvol = int(np.prod(S)) * Cc
+    nloc = int(np.prod(out_spatial)) * D
+    if loc is not None:
+        loc = loc.contiguous()
+    vol_bs = nvol
+    loc_bs = 0 if (single_transform or loc is None) else nloc
+    has_fill = fill_value is not None
+    st = _lib.stream_ptr(dev)
+    with torch.cuda.device(dev):
+        if vol.dtype == torch.float32:
+            rc = lib.nrt_interpn_f32_ex(_lib.ptr(vol), _lib.ptr(loc), _lib.ptr(out), D, _lib.ints(S),
+                                        _lib.ints(out_spatial), Cc, B, vol_bs, loc_bs, loc_mode, method,
+                                        int(has_fill), float(fill_value) if has_fill else 0.0,
+                                        int(variant), int(tune), st)
+        elif vol.dtype == torch.int32:
+            assert method == _lib.INTERP_NEAREST
+            rc = lib.nrt_interpn_nearest_i32(_lib.ptr(vol), _lib.ptr(loc), _lib.ptr(out), D, _lib.ints(S),
+                                             _lib.ints(out_spatial), Cc, B, vol_bs, loc_bs, loc_mode,
+                                             int(has_fill), int(fill_value) if has_fill else 0, st)
+        else:
+            raise NotImplementedError('unsupported volume dtype %s' % vol.dtype)
+    _lib.check(rc, 'nrt_interpn')
+    return out
+
+
+def _prepare_vol(vol, interp_method):
+    """dtype policy of the HIP path.  Returns (vol32, restore_dtype)."""
+    if vol.dtype == torch.float32:
+        return vol, None
+    if vol.dtype in (torch.float16, torch.bfloat16, torch.float64):
+        raise NotImplementedError(
+            'neurite_amd.interpn computes in float32 like the reference does for float32 inputs; '
+            '%s volumes are not implemented (cast explicitly if that is what you want)' % vol.dtype)
+    # integer volumes
+    if interp_method == 'linear':
+        # the reference multiplies float weights with the gathered values (utils.py:191): TF raises
+        raise TypeError('linear interpolation of an integer volume (%s) is a dtype error in the reference; '
+                        'cast the volume to float32 first' % vol.dtype)
+    if vol.dtype == torch.int32:
+        return vol, None
+    if vol.dtype in _SMALL_INTS:
+        return vol.to(torch.int32), vol.dtype
+    raise NotImplementedError('nearest interpolation of %s volumes is not implemented' % vol.dtype)
+
+
+def interpn(vol, loc, interp_method='linear', fill_value=None, *, _variant=0, _tune=0):
+    """
+    N-D gridded interpolation (neurite/tf/utils/utils.py:73-220).
+
+    vol: [*vol_shape] or [*vol_shape, C];  loc: list of D tensors or a [*new_shape, D] tensor;
+    interp_method 'linear' | 'nearest'; fill_value: value outside the domain (None = edge clamp).
+    Returns a tensor shaped like the entries of loc (+ channel axis if vol had one).
+    """
+    if isinstance(loc, (list, tuple)):
+        loc = torch.stack([torch.as_tensor(l) for l in loc], -1)             # :106-107
+    nb_dims = loc.shape[-1]                                                  # :108
+    input_vol_ndim = vol.dim()
+
+    if vol.dim() not in [nb_dims, nb_dims + 1]:                              # :111-113
+        raise Exception("Number of loc Tensors %d does not match volume dimension %d"
+                        % (nb_dims, len(vol.shape[:-1])))
+    if nb_dims > vol.dim():                                                  # :115-117
+        raise Exception("Loc dimension %d does not match volume dimension %d" % (nb_dims, vol.dim()))
+    if interp_method != 'linear':                                            # :193-195
+        assert interp_method == 'nearest', 'method should be linear or nearest, got: %s' % interp_method
+
+    _lib.require_device(vol, loc)
+    if vol.dim() == nb_dims:                                                 # :119-120
+        vol = vol.unsqueeze(-1)
+    # loc is cast to the volume's float dtype (:123-127); the HIP path is float32
+    if loc.dtype != torch.float32:
+        loc = loc.to(torch.float32)
+    vol32, restore = _prepare_vol(vol, interp_method)
+    if vol32.dtype == torch.int32 and fill_value is not None and float(fill_value) != int(fill_value):
+        raise ValueError('fill_value %r is not representable in the integer volume dtype' % (fill_value,))
+
+    def run():
+        out = _launch_interpn(vol32, loc, loc.shape[:-1], _lib.LOC_ABSOLUTE, _METHODS[interp_method],
+                              fill_value, batched=False, variant=_variant, tune=_tune)
+        if restore is not None:
+            out = out.to(restore)
+        if input_vol_ndim == nb_dims:                                        # :216-218
+            out = out[..., 0]
+        return out
+
+    return _maybe_tracked(run, vol, loc)
+
+
+def _new_shape(vol_shape, zoom_factor):
+    return [int(vol_shape[f] * zoom_factor[f]) for f in range(len(zoom_factor))]     # :256-257
+
+
+def resize(vol, zoom_factor, interp_method='linear'):
+    """
+    Align-corners resize of one (un-batched) volume (neurite/tf/utils/utils.py:223-262).
+    If zoom_factor is a list it determines ndims and vol may or may not carry a channel axis; if it
+    is a scalar, vol must be [*vol_shape, C].
+    """
+    if isinstance(zoom_factor, (list, tuple)):                               # :237-242
+        ndims = len(zoom_factor)
+        vol_shape = list(vol.shape[:ndims])
+        assert len(vol_shape) in (ndims, ndims + 1), \
+            "zoom_factor length %d does not match ndims %d" % (len(vol_shape), ndims)
+    else:                                                                    # :244-247
+        vol_shape = list(vol.shape[:-1])
+        ndims = len(vol_shape)
+        zoom_factor = [zoom_factor] * ndims
+    if all(z == 1 for z in zoom_factor):                                     # :250-251
+        return vol
+    if interp_method != 'linear':
+        assert interp_method == 'nearest', 'method should be linear or nearest, got: %s' % interp_method
+    _lib.require_device(vol)
+    if vol.dim() not in (ndims, ndims + 1):
+        raise Exception("Number of loc Tensors %d does not match volume dimension %d"
+                        % (ndims, len(vol.shape[:-1])))
+    new_shape = _new_shape(vol_shape, zoom_factor)
+    squeeze = vol.dim() == ndims
+    v = vol.unsqueeze(-1) if squeeze else vol
+    vol32, restore = _prepare_vol(v, interp_method)
+
+    def run():
+        out = _launch_interpn(vol32, None, new_shape, _lib.LOC_LINSPACE, _METHODS[interp_method], None,
+                              batched=False)
+        if restore is not None:
+            out = out.to(restore)
+        return out[..., 0] if squeeze else out
+
+    return _maybe_tracked(run, vol)
+
+
+zoom = resize
+
+
+def transform(vol, loc_shift, interp_method='linear', indexing='ij', fill_value=None):
+    """
+    voxelmorph.utils.transform for one (un-batched) volume: out[q] = interpn(vol, q + loc_shift[q]).
+    The identity grid is never materialised (the kernel derives q from its thread index).
+    vol [*S, C] (or [*S]); loc_shift [*S', D] in voxel units.
+    """
+    if indexing not in ('ij', 'xy'):
+        raise ValueError("indexing has to be 'ij' (matrix) or 'xy' (cartesian)")
+    D = loc_shift.shape[-1]
+    if vol.dim() not in (D, D + 1):
+        raise Exception("Number of loc Tensors %d does not match volume dimension %d"
+                        % (D, len(vol.shape[:-1])))
+    if interp_method != 'linear':
+        assert interp_method == 'nearest', 'method should be linear or nearest, got: %s' % interp_method
+    _lib.require_device(vol, loc_shift)
+    squeeze = vol.dim() == D
+    v = vol.unsqueeze(-1) if squeeze else vol
+    shift = loc_shift.to(torch.float32)
+    if indexing == 'xy' and D > 1:
+        shift = torch.cat([shift[..., 1:2], shift[..., 0:1], shift[..., 2:]], -1)
+    vol32, restore = _prepare_vol(v, interp_method)
+
+    def run():
+        out = _launch_interpn(vol32, shift, shift.shape[:-1], _lib.LOC_SHIFT, _METHODS[interp_method],
+                              fill_value, batched=False)
+        if restore is not None:
+            out = out.to(restore)
+        return out[..., 0] if squeeze else out
+
+    return _maybe_tracked(run, vol, loc_shift)
+
+
+def affine_to_dense_shift(matrix, shape, shift_center=True, indexing='ij'):
+    """
+    voxelmorph.utils.affine_to_dense_shift: dense displacement field [*shape, D] of an affine
+    [D, D+1] (or [D+1, D+1]).  Host-side glue (tiny matmul over the grid), float32.
+    """
+    D = len(shape)
+    matrix = torch.as_tensor(matrix, dtype=torch.float32)
+    if matrix.shape[-2] == D + 1:
+        matrix = matrix[..., :D, :]
+    if tuple(matrix.shape[-2:]) != (D, D + 1):
+        raise ValueError('affine matrix must be [%d, %d] or [%d, %d]' % (D, D + 1, D + 1, D + 1))
+    mesh = volshape_to_meshgrid(shape, indexing=indexing)
+    mesh = [m.to(matrix.device, torch.float32) for m in mesh]
+    if shift_center:
+        mesh = [mesh[d] - (shape[d] - 1) / 2 for d in range(D)]
+    flat = [m.reshape(-1) for m in mesh]
+    flat.append(torch.ones_like(flat[0]))
+    mesh_matrix = torch.stack(flat, 0)                        # [D+1, V]
+    loc = (matrix @ mesh_matrix).transpose(0, 1).reshape(list(shape) + [D])
+    return loc - torch.stack(mesh, -1)
+
+
+# --------------------------------------------------------------------------------------
+# index / grid helpers (host-side; the kernels never need the materialised grids)
+# --------------------------------------------------------------------------------------
+
+def volshape_to_ndgrid(volshape, **kwargs):
+    """neurite/tf/utils/utils.py:333-353."""
+    if not all(float(d).is_integer() for d in volshape):
+        raise ValueError("volshape needs to be a list of integers")
+    linvec = [torch.arange(0, int(d), dtype=torch.int32) for d in volshape]
+    return ndgrid(*linvec, **kwargs)
+
+
+def volshape_to_meshgrid(volshape, **kwargs):
+    """neurite/tf/utils/utils.py:356-379 ('xy' default like tf.meshgrid)."""
+    if not all(float(d).is_integer() for d in volshape):
+        raise ValueError("volshape needs to be a list of integers")
+    linvec = [torch.arange(0, int(d), dtype=torch.int32) for d in volshape]
+    return meshgrid(*linvec, **kwargs)
+
+
+def ndgrid(*args, **kwargs):
+    """neurite/tf/utils/utils.py:382-395."""
+    return meshgrid(*args, indexing='ij', **kwargs)
+
+
+def meshgrid(*args, **kwargs):
+    """neurite/tf/utils/utils.py:398-476."""
+    indexing = kwargs.pop("indexing", "xy")
+    kwargs.pop("name", None)
+    if kwargs:
+        key = list(kwargs.keys())[0]
+        raise TypeError("'{}' is an invalid keyword argument for this function".format(key))
+    if indexing not in ("xy", "ij"):
+        raise ValueError("indexing parameter must be either 'xy' or 'ij'")
+    args = [torch.as_tensor(a) for a in args]
+    return [g.contiguous() for g in torch.meshgrid(*args, indexing=indexing)]
+
+
+def sub2ind2d(siz, subs, **kwargs):
+    """neurite/tf/utils/utils.py:1068-1082 (row-major flat index)."""
+    assert len(siz) == len(subs), 'found inconsistent siz and subs: %d %d' % (len(siz), len(subs))
+    k = np.cumprod(list(siz)[::-1])
+    ndx = subs[-1]
+    for i, v in enumerate(list(subs[:-1])[::-1]):
+        ndx = ndx + v * int(k[i])
+    return ndx
+
+
+def prod_n(lst):
+    """neurite/tf/utils/utils.py:1085-1092."""
+    prod = lst[0]
+    for p in lst[1:]:
+        prod = prod * p
+    return prod
+
+
+def batch_channel_flatten(x):
+    """neurite/tf/utils/utils.py:1175-1188: [B, ..., C] -> [B, V, C] (a view, never a copy)."""
+    return flatten_axes(x, range(1, x.dim() - 1))
+
+
+flatten_batch_channel = batch_channel_flatten
+
+
+def flatten_axes(x, axes):
+    """neurite/tf/utils/utils.py:1195-1226."""
+    assert isinstance(axes, (list, tuple, range)), 'axes must be list or tuple of axes to be flattened'
+    assert np.all(np.diff(axes) == 1), 'axes need to be contiguous'
+    if axes[0] < 0:
+        assert axes[-1] < 0, 'if one axis is negative, all have to be negative'
+    assert axes[-1] < x.dim(), 'axis %d outside max axis %d' % (axes[-1], x.dim() - 1)
+    shp = list(x.shape)
+    new = shp[:axes[0]] + [-1]
+    if axes[-1] < x.dim() - 1 and not (axes[-1] == -1):
+        new += shp[axes[-1] + 1:]
+    return x.reshape(new)

@@ -1,0 +1,479 @@
+"""
+NumPy restatement of the neurite hot path (TEST INFRASTRUCTURE -- see oracle/__init__.py).
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).  Arithmetic is done in the dtype the TensorFlow graph would use
+(float32 unless the caller passes something else), one NumPy op per TF op, in the
+same order, so results of the float paths are reproducible bit-for-bit by any
+IEEE-754 implementation that performs the same sequence of roundings.
+
+Reductions (Dice sums, CCE mean) have no defined order in TF; they are accumulated
+in float64 here and the tests compare with a relative tolerance of 1e-5, except for
+one-hot / label inputs where all partial sums are small integers and any order is
+exact.
+"""
+
+import itertools
+
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------------------
+# index helpers
+# --------------------------------------------------------------------------------------
+
+def sub2ind2d(siz, subs):
+    """neurite/tf/utils/utils.py:1068-1082 -- row-major flat index (despite the docstring)."""
+    assert len(siz) == len(subs), 'found inconsistent siz and subs: %d %d' % (len(siz), len(subs))
+    k = np.cumprod(siz[::-1])
+    ndx = subs[-1]
+    for i, v in enumerate(subs[:-1][::-1]):
+        ndx = ndx + v * k[i]
+    return ndx
+
+
+def prod_n(lst):
+    """neurite/tf/utils/utils.py:1085-1092 -- sequential left-to-right product."""
+    prod = lst[0]
+    for p in lst[1:]:
+        prod = prod * p
+    return prod
+
+
+def meshgrid(*args, indexing='xy'):
+    """neurite/tf/utils/utils.py:398-476 (tile-based meshgrid; 'xy' swaps the first two axes)."""
+    if indexing not in ('xy', 'ij'):
+        raise ValueError("indexing parameter must be either 'xy' or 'ij'")
+    return [np.ascontiguousarray(g) for g in np.meshgrid(*args, indexing=indexing)]
+
+
+def ndgrid(*args):
+    """neurite/tf/utils/utils.py:382-395."""
+    return meshgrid(*args, indexing='ij')
+
+
+def volshape_to_ndgrid(volshape):
+    """neurite/tf/utils/utils.py:333-353."""
+    if not all(float(d).is_integer() for d in volshape):
+        raise ValueError('volshape needs to be a list of integers')
+    return ndgrid(*[np.arange(0, d, dtype=np.int32) for d in volshape])
+
+
+def volshape_to_meshgrid(volshape, indexing='xy'):
+    """neurite/tf/utils/utils.py:356-379."""
+    if not all(float(d).is_integer() for d in volshape):
+        raise ValueError('volshape needs to be a list of integers')
+    return meshgrid(*[np.arange(0, d, dtype=np.int32) for d in volshape], indexing=indexing)
+
+
+def batch_channel_flatten(x):
+    """neurite/tf/utils/utils.py:1175-1226 -- [B, ..., C] -> [B, V, C] (a view)."""
+    return x.reshape(x.shape[0], -1, x.shape[-1])
+
+
+# --------------------------------------------------------------------------------------
+# interpn  (neurite/tf/utils/utils.py:73-220)
+# --------------------------------------------------------------------------------------
+
+def interpn(vol, loc, interp_method='linear', fill_value=None):
+    """
+    Op-for-op restatement of neurite/tf/utils/utils.py:73-220.
+
+    vol: [*S] or [*S, C]; loc: list of D arrays or [*S', D] array.
+    """
+    vol = np.asarray(vol)
+    if isinstance(loc, (list, tuple)):
+        loc = np.stack(loc, -1)                                            # :106-107
+    loc = np.asarray(loc)
+    nb_dims = loc.shape[-1]                                                # :108
+    input_vol_shape = vol.shape
+
+    if vol.ndim not in [nb_dims, nb_dims + 1]:                             # :111-113
+        raise Exception("Number of loc Tensors %d does not match volume dimension %d"
+                        % (nb_dims, len(vol.shape[:-1])))
+    if nb_dims > vol.ndim:                                                 # :115-117
+        raise Exception("Loc dimension %d does not match volume dimension %d"
+                        % (nb_dims, vol.ndim))
+    if vol.ndim == nb_dims:                                                # :119-120
+        vol = vol[..., None]
+
+    vol_floating = np.issubdtype(vol.dtype, np.floating)
+    if not np.issubdtype(loc.dtype, np.floating):                          # :123-125
+        loc = loc.astype(vol.dtype if vol_floating else np.float32)
+    elif vol_floating and vol.dtype != loc.dtype:                          # :126-127
+        loc = loc.astype(vol.dtype)
+    ldt = loc.dtype.type
+
+    volshape = vol.shape
+    max_loc = [d - 1 for d in vol.shape]                                   # :134
+    vol_reshape = vol.reshape(-1, volshape[-1])                            # :177
+
+    if interp_method == 'linear':
+        loc0 = np.floor(loc)                                               # :139
+        clipped_loc = [np.clip(loc[..., d], ldt(0), ldt(max_loc[d])) for d in range(nb_dims)]   # :142
+        loc0lst = [np.clip(loc0[..., d], ldt(0), ldt(max_loc[d])) for d in range(nb_dims)]      # :143
+        loc1 = [np.clip(loc0lst[d] + ldt(1), ldt(0), ldt(max_loc[d])) for d in range(nb_dims)]  # :146
+        locs = [[f.astype(np.int32) for f in loc0lst], [f.astype(np.int32) for f in loc1]]      # :147
+        diff_loc1 = [loc1[d] - clipped_loc[d] for d in range(nb_dims)]     # :152
+        diff_loc0 = [ldt(1) - d for d in diff_loc1]                        # :153
+        weights_loc = [diff_loc1, diff_loc0]                               # :155
+
+        cube_pts = list(itertools.product([0, 1], repeat=nb_dims))         # :159
+        interp_vol = 0                                                     # :160
+        for c in cube_pts:                                                 # :162
+            subs = [locs[c[d]][d] for d in range(nb_dims)]                 # :170
+            idx = sub2ind2d(vol.shape[:-1], subs)                          # :176
+            vol_val = vol_reshape[idx]                                     # :178
+            wts_lst = [weights_loc[c[d]][d] for d in range(nb_dims)]       # :183
+            wt = prod_n(wts_lst)[..., None]                                # :187-188
+            interp_vol = interp_vol + wt * vol_val                         # :191
+    else:
+        assert interp_method == 'nearest', \
+            'method should be linear or nearest, got: %s' % interp_method  # :194-195
+        roundloc = np.rint(loc).astype(np.int32)                           # :196  (tf.round = half-to-even)
+        roundloc = [np.clip(roundloc[..., d], 0, max_loc[d]) for d in range(nb_dims)]   # :197
+        idx = sub2ind2d(vol.shape[:-1], roundloc)                          # :203
+        interp_vol = vol_reshape[idx]                                      # :204
+
+    if fill_value is not None:                                             # :206-213
+        out_type = interp_vol.dtype
+        fill = np.asarray(fill_value).astype(out_type)
+        below = [loc[..., d] < 0 for d in range(nb_dims)]
+        above = [loc[..., d] > max_loc[d] for d in range(nb_dims)]
+        oob = np.any(np.stack(below + above, axis=-1), axis=-1, keepdims=True)
+        with np.errstate(invalid='ignore'):
+            interp_vol = interp_vol * np.logical_not(oob).astype(out_type)
+            interp_vol = interp_vol + oob.astype(out_type) * fill
+
+    if len(input_vol_shape) == nb_dims:                                    # :216-218
+        assert interp_vol.shape[-1] == 1, 'Something went wrong with interpn channels'
+        interp_vol = interp_vol[..., 0]
+    return interp_vol
+
+
+def interpn_f64(vol, loc, fill_value=None):
+    """Independent float64 'truth' for the linear path (same clamping rules, exact weights)."""
+    vol = np.asarray(vol, np.float64)
+    squeeze = False
+    loc = np.asarray(loc, np.float64)
+    D = loc.shape[-1]
+    if vol.ndim == D:
+        vol = vol[..., None]
+        squeeze = True
+    S = vol.shape[:-1]
+    out = np.zeros(loc.shape[:-1] + (vol.shape[-1],))
+    i0, i1, w0 = [], [], []
+    for d in range(D):
+        m = S[d] - 1
+        cl = np.clip(loc[..., d], 0, m)
+        l0 = np.clip(np.floor(loc[..., d]), 0, m)
+        l1 = np.clip(l0 + 1, 0, m)
+        i0.append(l0.astype(np.int64)); i1.append(l1.astype(np.int64)); w0.append(l1 - cl)
+    for c in itertools.product([0, 1], repeat=D):
+        idx = tuple((i1 if c[d] else i0)[d] for d in range(D))
+        wt = np.ones(loc.shape[:-1])
+        for d in range(D):
+            wt = wt * ((1 - w0[d]) if c[d] else w0[d])
+        out += wt[..., None] * vol[idx]
+    if fill_value is not None:
+        oob = np.zeros(loc.shape[:-1], bool)
+        for d in range(D):
+            oob |= (loc[..., d] < 0) | (loc[..., d] > S[d] - 1)
+        out = np.where(oob[..., None], float(fill_value), out)
+    return out[..., 0] if squeeze else out
+
+
+# --------------------------------------------------------------------------------------
+# resize / zoom  (neurite/tf/utils/utils.py:223-265)
+# --------------------------------------------------------------------------------------
+
+def tf_linspace(start, stop, num, dtype=np.float32):
+    """
+    tf.linspace(start, stop, num) as TF2 computes it (TF semantics, restated):
+    delta = (stop-start)/(num-1) in dtype; x_i = start + delta*i for 0<i<num-1;
+    first element = start, last element = stop exactly; num==1 -> [start].
+    """
+    t = np.dtype(dtype).type
+    start, stop = t(start), t(stop)
+    if num == 1:
+        return np.array([start], dtype)
+    delta = t((stop - start) / t(num - 1))
+    i = np.arange(1, num - 1).astype(dtype)
+    mid = (start + delta * i).astype(dtype)
+    return np.concatenate([[start], mid, [stop]]).astype(dtype)
+
+
+def resize_new_shape(vol_shape, zoom_factor):
+    """neurite/tf/utils/utils.py:256-257 (python float multiply, int() truncation)."""
+    return [int(vol_shape[f] * zoom_factor[f]) for f in range(len(zoom_factor))]
+
+
+def resize(vol, zoom_factor, interp_method='linear'):
+    """neurite/tf/utils/utils.py:223-262."""
+    vol = np.asarray(vol)
+    if isinstance(zoom_factor, (list, tuple)):                             # :237-242
+        ndims = len(zoom_factor)
+        vol_shape = vol.shape[:ndims]
+        assert len(vol_shape) in (ndims, ndims + 1), \
+            "zoom_factor length %d does not match ndims %d" % (len(vol_shape), ndims)
+    else:                                                                  # :244-247
+        vol_shape = vol.shape[:-1]
+        ndims = len(vol_shape)
+        zoom_factor = [zoom_factor] * ndims
+    if all(z == 1 for z in zoom_factor):                                   # :250-251
+        return vol
+    new_shape = resize_new_shape(vol_shape, zoom_factor)                   # :256-257
+    lin = [tf_linspace(0., vol_shape[d] - 1., new_shape[d]) for d in range(ndims)]   # :259
+    grid = ndgrid(*lin)                                                    # :260
+    return interpn(vol, grid, interp_method=interp_method)                 # :262
+
+
+zoom = resize
+
+
+def resize_layer(x, zoom_factor, interp_method='linear'):
+    """neurite/tf/layers.py:154-181 -- Resize.call: map utils.resize over the batch axis."""
+    x = np.asarray(x)
+    ndims = x.ndim - 2
+    if not isinstance(zoom_factor, (list, tuple)):                         # layers.py:142-147
+        zoom_factor = [zoom_factor] * ndims
+    else:
+        assert len(zoom_factor) == ndims, \
+            'zoom factor length {} does not match number of dimensions {}'.format(len(zoom_factor), ndims)
+    return np.stack([resize(x[b], list(zoom_factor), interp_method) for b in range(x.shape[0])], 0)
+
+
+# --------------------------------------------------------------------------------------
+# SpatialTransformer / transform  (voxelmorph, not in tree; call sites
+# neurite/tf/models.py:806-807, 1157-1159; behaviour per SURVEY.md A.4)
+# --------------------------------------------------------------------------------------
+
+def transform(vol, loc_shift, interp_method='linear', indexing='ij', fill_value=None):
+    """vxm.utils.transform: loc = cast(meshgrid, shift.dtype) + shift; interpn(vol, loc)."""
+    loc_shift = np.asarray(loc_shift)
+    volshape = loc_shift.shape[:-1]
+    nb_dims = len(volshape)
+    mesh = volshape_to_meshgrid(volshape, indexing=indexing)
+    loc = [mesh[d].astype(loc_shift.dtype) + loc_shift[..., d] for d in range(nb_dims)]
+    return interpn(vol, loc, interp_method=interp_method, fill_value=fill_value)
+
+
+def affine_to_dense_shift(matrix, shape, shift_center=True, indexing='ij'):
+    """
+    vxm.utils.affine_to_dense_shift (believed semantics): shift[q] = A [q-c;1] - (q-c).
+    matrix: [D, D+1] (or [D+1, D+1], last row dropped).  float32 throughout.
+    """
+    matrix = np.asarray(matrix, F32)
+    D = len(shape)
+    if matrix.shape[-2] == D + 1:
+        matrix = matrix[:D]
+    mesh = volshape_to_meshgrid(shape, indexing=indexing)
+    mesh = [m.astype(F32) for m in mesh]
+    if shift_center:
+        mesh = [mesh[d] - F32((shape[d] - 1) / 2) for d in range(D)]
+    flat = [m.reshape(-1) for m in mesh]
+    flat.append(np.ones(flat[0].shape, F32))
+    mesh_matrix = np.stack(flat, 1).T                       # [D+1, V]
+    loc_matrix = (matrix @ mesh_matrix).astype(F32)         # [D, V]
+    loc = loc_matrix.T.reshape(list(shape) + [D])
+    return loc - np.stack(mesh, -1)
+
+
+def spatial_transformer(vol, trf, interp_method='linear', indexing='ij', single_transform=False,
+                        fill_value=None, shift_center=True):
+    """vxm.layers.SpatialTransformer.call on [vol [B,*S,C], trf [B,*S',D] | affine [B,D,D+1]]."""
+    vol = np.asarray(vol)
+    trf = np.asarray(trf)
+    D = vol.ndim - 2
+    outs = []
+    for b in range(vol.shape[0]):
+        t = trf[0] if single_transform else trf[b]
+        if t.ndim == 2:    # affine
+            t = affine_to_dense_shift(t, vol.shape[1:-1], shift_center=shift_center, indexing=indexing)
+        elif indexing == 'xy':
+            # voxelmorph swaps the first two displacement components for 'xy' flows
+            t = np.concatenate([t[..., 1:2], t[..., 0:1], t[..., 2:]], -1)
+        outs.append(transform(vol[b], t, interp_method=interp_method, indexing='ij',
+                              fill_value=fill_value))
+    return np.stack(outs, 0)
+
+
+# --------------------------------------------------------------------------------------
+# Dice  (neurite/tf/metrics.py:415-510, neurite/tf/losses.py:68-95)
+# --------------------------------------------------------------------------------------
+
+def divide_no_nan(x, y):
+    """tf.math.divide_no_nan: 0 where y == 0."""
+    x = np.asarray(x)
+    y = np.asarray(y)
+    out = np.zeros(np.broadcast(x, y).shape, dtype=np.result_type(x, y))
+    np.divide(x, y, out=out, where=(y != 0))
+    return out
+
+
+def one_hot(idx, nb_labels, dtype=F32):
+    """tf.one_hot: out-of-range index -> all-zero row."""
+    idx = np.asarray(idx)
+    out = np.zeros(idx.shape + (nb_labels,), dtype)
+    ok = (idx >= 0) & (idx < nb_labels)
+    np.put_along_axis(out, np.where(ok, idx, 0)[..., None].astype(np.int64), ok[..., None].astype(dtype), -1)
+    return out
+
+
+def dice_sums(y_true, y_pred):
+    """Σ_v t*p, Σ_v t², Σ_v p² per (batch,label), accumulated in float64. metrics.py:471-477."""
+    t = batch_channel_flatten(np.asarray(y_true)).astype(np.float64)
+    p = batch_channel_flatten(np.asarray(y_pred)).astype(np.float64)
+    return (t * p).sum(1), (t * t).sum(1), (p * p).sum(1)
+
+
+def dice(y_true, y_pred, dice_type='soft', input_type='prob', nb_labels=None,
+         laplace_smoothing=0., normalize=False, check_input_limits=True):
+    """neurite/tf/metrics.py:415-482.  Returns float32 [B, L]."""
+    y_true = np.asarray(y_true)
+    y_pred = np.asarray(y_pred)
+    if input_type in ['prob', 'one_hot']:
+        if normalize:                                                       # :434-436
+            y_true = divide_no_nan(y_true, y_true.sum(-1, keepdims=True))
+            y_pred = divide_no_nan(y_pred, y_pred.sum(-1, keepdims=True))
+        if check_input_limits:                                              # :439-444
+            for a in (y_true, y_pred):
+                if not (a.min() >= 0. and a.max() <= 1.):
+                    raise ValueError('value outside range')
+    if dice_type == 'hard':                                                 # :450-468
+        if input_type == 'prob':
+            if nb_labels is None:
+                nb_labels = y_pred.shape[-1]
+            y_pred = np.argmax(y_pred, -1)
+            y_true = np.argmax(y_true, -1)
+        y_pred = one_hot(np.asarray(y_pred).astype(np.int64), nb_labels)
+        y_true = one_hot(np.asarray(y_true).astype(np.int64), nb_labels)
+    stp, stt, spp = dice_sums(y_true, y_pred)                               # :471-477
+    top = (2 * stp).astype(F32)
+    bottom = (stt.astype(F32) + spp.astype(F32)).astype(F32)
+    if laplace_smoothing > 0:                                               # :478-480
+        eps = F32(laplace_smoothing)
+        return ((top + eps) / (bottom + eps)).astype(F32)
+    return divide_no_nan(top, bottom).astype(F32)                           # :482
+
+
+def mean_dice(y_true, y_pred, weights=None, **kw):
+    """neurite/tf/metrics.py:484-510."""
+    d = dice(y_true, y_pred, **kw)
+    if weights is not None:
+        weights = np.asarray(weights)
+        assert weights.ndim == 2, 'weights should be a matrix broadcastable to [batch_size, nb_labels]'
+        d = d * weights.astype(F32)
+    m = np.mean(d.astype(np.float64)).astype(F32)
+    assert np.isfinite(m), 'metric not finite'
+    return m
+
+
+# --------------------------------------------------------------------------------------
+# label-weighted categorical cross-entropy (neurite/tf/metrics.py:619-650 + Keras CCE)
+# --------------------------------------------------------------------------------------
+
+KERAS_EPSILON = 1e-7
+
+
+def cce_per_voxel(y_true, y_pred, label_weights=None, from_logits=False, label_smoothing=0.):
+    """
+    Per-element loss [B, *S] in float64 from inputs first rounded to float32 (bf16 callers pass
+    values already representable in bf16).  metrics.py:641-648 then Keras
+    categorical_crossentropy (TF semantics restated: smoothing, p/sum(p), clip, -sum t log p).
+    """
+    p = np.asarray(y_pred).astype(np.float64)
+    t = np.asarray(y_true).astype(np.float64)
+    C = p.shape[-1]
+    if label_weights is not None:
+        w = np.asarray(label_weights)
+        if w.shape[-1] != C:
+            raise ValueError(f'Label weights must be of len {C}, but got {w.shape[-1]}.')   # :644-645
+        t = w.astype(np.float64) * t                                                         # :648
+    if label_smoothing:
+        t = t * (1.0 - label_smoothing) + (label_smoothing / C)
+    if from_logits:
+        z = p - p.max(-1, keepdims=True)
+        logq = z - np.log(np.exp(z).sum(-1, keepdims=True))
+    else:
+        q = p / p.sum(-1, keepdims=True)
+        q = np.clip(q, KERAS_EPSILON, 1. - KERAS_EPSILON)
+        logq = np.log(q)
+    return -(t * logq).sum(-1)
+
+
+def cce(y_true, y_pred, label_weights=None, sample_weight=None, **kw):
+    """Scalar loss, reduction SUM_OVER_BATCH_SIZE (mean over all B*V elements)."""
+    l = cce_per_voxel(y_true, y_pred, label_weights, **kw)
+    if sample_weight is not None:
+        sw = np.asarray(sample_weight, np.float64)
+        while sw.ndim < l.ndim:
+            sw = sw[..., None]
+        l = l * sw
+    return np.float32(l.sum() / l.size)
+
+
+# --------------------------------------------------------------------------------------
+# LocallyConnected3D implementation 1 (neurite/tf/layers.py:951-1047, 1072-1102, 1126-1197)
+# --------------------------------------------------------------------------------------
+
+def conv_output_length(input_length, filter_size, padding, stride, dilation=1):
+    """keras conv_utils.conv_output_length (TF semantics)."""
+    if input_length is None:
+        return None
+    dilated = filter_size + (filter_size - 1) * (dilation - 1)
+    if padding in ('same', 'causal'):
+        out = input_length
+    elif padding == 'valid':
+        out = input_length - dilated + 1
+    elif padding == 'full':
+        out = input_length + dilated - 1
+    else:
+        raise ValueError(padding)
+    return (out + stride - 1) // stride
+
+
+def lc3d(x, kernel, bias=None, kernel_size=(3, 3, 3), strides=(1, 1, 1), accumulate=np.float64):
+    """
+    x [B,R,C,Z,Cin]; kernel [O, kr*kc*kz*Cin, Cout]; bias [or,oc,oz,Cout] or None.
+    Patch flatten order (kr,kc,kz,cin) row-major (layers.py:1179-1186), output positions
+    row-major (:1172-1173), out[b,o,:] = patch[b,o,:] @ kernel[o] (:1189), + bias (:1098-1099).
+    """
+    x = np.asarray(x)
+    B, R, Cc, Z, Cin = x.shape
+    kr, kc, kz = kernel_size
+    sr, sc, sz = strides
+    orr = conv_output_length(R, kr, 'valid', sr)
+    occ = conv_output_length(Cc, kc, 'valid', sc)
+    ozz = conv_output_length(Z, kz, 'valid', sz)
+    Cout = kernel.shape[-1]
+    out = np.zeros((B, orr, occ, ozz, Cout), accumulate)
+    o = 0
+    for r in range(orr):
+        for c in range(occ):
+            for z in range(ozz):
+                patch = x[:, r * sr:r * sr + kr, c * sc:c * sc + kc, z * sz:z * sz + kz, :]
+                patch = patch.reshape(B, -1).astype(accumulate)
+                out[:, r, c, z, :] = patch @ kernel[o].astype(accumulate)
+                o += 1
+    if bias is not None:
+        out = out + np.asarray(bias).astype(accumulate)[None]
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Keras layers the unet instantiates (TF semantics, restated; used by the unet oracle)
+# --------------------------------------------------------------------------------------
+
+def elu(x):
+    """Keras ELU alpha=1: x>0 ? x : exp(x)-1."""
+    x = np.asarray(x)
+    return np.where(x > 0, x, np.exp(np.minimum(x, 0)) - 1).astype(x.dtype)
+
+
+def softmax_lastdim(x):
+    x = np.asarray(x, np.float64)
+    e = np.exp(x - x.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)

@@ -1,0 +1,275 @@
+"""
+Generate tests/golden/*.npz by running the REFERENCE'S OWN SOURCE (/root/reference/neurite)
+on top of tests/golden/tf_shim.py (a NumPy stand-in for the TensorFlow leaf primitives).
+
+    MPLBACKEND=Agg python tests/golden/make_golden.py
+
+Runs only in the build container (it needs /root/reference); the produced fixtures are
+committed and travel to the GPU box.  Nothing at test/bench run time reads /root/reference.
+Each fixture stores the inputs, the call's keyword arguments and the reference's outputs.
+"""
+
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import tf_shim  # noqa: E402
+
+tf_shim.install()
+sys.path.insert(0, '/root/reference')
+import neurite as ne  # noqa: E402  (the real reference package)
+
+T = tf_shim.Tensor
+F = np.float32
+
+
+def A(x):
+    return x.a if isinstance(x, T) else np.asarray(x)
+
+
+def ijk(shape):
+    return np.stack(np.meshgrid(*[np.arange(s) for s in shape], indexing='ij'), -1).astype(F)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('%-28s %7.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
+def gen_interpn():
+    rng = np.random.default_rng(1234)
+    cases = {}
+
+    def add(tag, vol, loc, method='linear', fill=None, loc_list=False):
+        lv = [T(np.ascontiguousarray(loc[..., d])) for d in range(loc.shape[-1])] if loc_list else T(loc)
+        out = A(ne.utils.interpn(T(vol), lv, interp_method=method, fill_value=fill))
+        cases[tag + '__vol'] = vol
+        cases[tag + '__loc'] = loc
+        cases[tag + '__method'] = np.array(method)
+        cases[tag + '__fill'] = np.array(np.nan if fill is None else fill, F)
+        cases[tag + '__hasfill'] = np.array(fill is not None)
+        cases[tag + '__out'] = out
+
+    S = (9, 7, 11)
+    vol3 = rng.standard_normal(S + (3,)).astype(F)
+    loc3 = (ijk(S) + rng.normal(0, 3, S + (3,))).astype(F)
+    for method in ('linear', 'nearest'):
+        for fill in (None, 0.0, -2.5):
+            add('d3c3_%s_%s' % (method, 'nofill' if fill is None else ('fill%g' % fill)), vol3, loc3, method, fill)
+    # half-integer and exactly-on-grid locations (round-half-even, unit weights), far out of range
+    special = np.array([-3.5, -1.0, -0.5, -0.0, 0.0, 0.5, 1.0, 1.5, 2.5, 3.0, 5.5, 6.0, 6.5, 7.0, 10.0, 10.5,
+                        11.0, 1e6, -1e6], F)
+    g = np.stack(np.meshgrid(special, special[:7], special, indexing='ij'), -1).astype(F)
+    for method in ('linear', 'nearest'):
+        add('d3c3_special_%s' % method, vol3, g, method, None)
+        add('d3c3_special_%s_fill' % method, vol3, g, method, 7.0)
+    # list-of-tensors loc, volume without channel axis, different output shape
+    volnc = rng.standard_normal((6, 8, 5)).astype(F)
+    locnc = rng.uniform(-2, 9, (4, 3, 7, 3)).astype(F)
+    add('d3_nochan_list', volnc, locnc, 'linear', None, loc_list=True)
+    # C = 32 (the headline channel count), C = 1, a singleton spatial dim
+    vol32 = rng.standard_normal((6, 5, 7, 32)).astype(F)
+    loc32 = (ijk((6, 5, 7)) + rng.normal(0, 1.5, (6, 5, 7, 3))).astype(F)
+    add('d3c32_linear', vol32, loc32, 'linear', None)
+    add('d3c32_nearest_fill', vol32, loc32, 'nearest', 0.0)
+    vol1s = rng.standard_normal((1, 6, 4, 2)).astype(F)
+    loc1s = rng.uniform(-1, 6, (3, 6, 4, 3)).astype(F)
+    add('d3_singleton_dim', vol1s, loc1s, 'linear', None)
+    # 2-D and 1-D
+    vol2 = rng.standard_normal((13, 5, 4)).astype(F)
+    loc2 = rng.uniform(-2, 15, (6, 8, 2)).astype(F)
+    add('d2c4_linear', vol2, loc2, 'linear', None)
+    add('d2c4_nearest_fill', vol2, loc2, 'nearest', 1.5)
+    vol1 = rng.standard_normal((13, 4)).astype(F)
+    loc1 = rng.uniform(-2, 15, (20, 1)).astype(F)
+    add('d1c4_linear_fill', vol1, loc1, 'linear', 0.0)
+    # integer locations (cast to float32, utils.py:123-125) and integer-valued volume with nearest
+    loci = rng.integers(-2, 12, (5, 4, 6, 3)).astype(np.int32)
+    add('d3c3_intloc', vol3, loci, 'linear', None)
+    voli = rng.integers(0, 32, S + (1,)).astype(np.int32)
+    add('d3_intvol_nearest', voli, loc3, 'nearest', None)
+    save('interpn_small', **cases)
+
+    # BASELINE config 1: 32^3 fp32 volume, loc = ijk + N(0, 3), seed 0
+    rng = np.random.default_rng(0)
+    vol = rng.standard_normal((32, 32, 32)).astype(F)
+    loc = (ijk((32, 32, 32)) + rng.normal(0, 3, (32, 32, 32, 3)).astype(F)).astype(F)
+    out = A(ne.utils.interpn(T(vol), T(loc), interp_method='linear'))
+    save('interpn_cfg1_32', vol=vol, loc=loc, out=out)
+
+
+def gen_resize():
+    rng = np.random.default_rng(77)
+    cases = {}
+    vol = rng.standard_normal((5, 6, 7, 2)).astype(F)
+    for tag, z, method in (('x2', 2, 'linear'), ('half', 0.5, 'linear'), ('aniso', [1.5, 2, 0.7], 'linear'),
+                           ('x3_nearest', 3, 'nearest'), ('mixed1', [1, 2, 1], 'linear')):
+        out = A(ne.utils.resize(T(vol), z, interp_method=method))
+        cases[tag + '__vol'] = vol
+        cases[tag + '__zoom'] = np.atleast_1d(np.array(z, np.float64))
+        cases[tag + '__method'] = np.array(method)
+        cases[tag + '__out'] = out
+    # identity zoom returns the input object (utils.py:250-251)
+    v = T(vol)
+    assert ne.utils.zoom(v, 1) is v
+    # Resize layer: batch map (layers.py:154-181); deformation-field upsample 2x as in models.py:804
+    x = rng.standard_normal((2, 4, 5, 3, 3)).astype(F)
+    layer = ne.layers.Resize(2, interp_method='linear')
+    out = A(layer(T(x)))
+    cases['layer__x'] = x
+    cases['layer__zoom'] = np.array([2.0])
+    cases['layer__out'] = out
+    cases['layer__out_shape'] = np.array(layer.compute_output_shape(x.shape))
+    x2 = rng.standard_normal((3, 6, 4, 2)).astype(F)          # 2-D, anisotropic zoom list
+    layer2 = ne.layers.Zoom([0.5, 1.5])
+    cases['layer2d__x'] = x2
+    cases['layer2d__zoom'] = np.array([0.5, 1.5])
+    cases['layer2d__out'] = A(layer2(T(x2)))
+    save('resize_small', **cases)
+
+
+def gen_index_helpers():
+    rng = np.random.default_rng(5)
+    cases = {}
+    siz = (4, 5, 6)
+    subs = [rng.integers(0, s, (7, 3)).astype(np.int32) for s in siz]
+    cases['sub2ind__siz'] = np.array(siz)
+    for d in range(3):
+        cases['sub2ind__sub%d' % d] = subs[d]
+    cases['sub2ind__out'] = A(ne.utils.sub2ind2d(tf_shim.TensorShape(siz), [T(s) for s in subs]))
+    ws = [rng.standard_normal(11).astype(F) for _ in range(3)]
+    for d in range(3):
+        cases['prodn__w%d' % d] = ws[d]
+    cases['prodn__out'] = A(ne.utils.prod_n([T(w) for w in ws]))
+    for d, g in enumerate(ne.utils.volshape_to_ndgrid((3, 4, 2))):
+        cases['ndgrid__%d' % d] = A(g)
+    # NOTE: for 'xy' indexing the reference's tile-based meshgrid (utils.py:471-475) swaps the tile
+    # multiples incorrectly when the first two sizes differ: it returns grids of shape (3, 3, 2) for
+    # sizes (3, 4, 2) where tf.meshgrid returns (4, 3, 2).  Both are recorded; neurite_amd follows
+    # tf.meshgrid (the documented intent) -- see DESIGN.md.  'ij' (all the hot path uses) is unaffected.
+    for d, g in enumerate(ne.utils.volshape_to_meshgrid((3, 4, 2), indexing='xy')):
+        cases['meshgrid_xy_nonsquare_refbug__%d' % d] = A(g)
+    for d, g in enumerate(ne.utils.volshape_to_meshgrid((3, 3, 2), indexing='xy')):
+        cases['meshgrid_xy__%d' % d] = A(g)
+    for d, g in enumerate(ne.utils.volshape_to_meshgrid((3, 4, 2), indexing='ij')):
+        cases['meshgrid_ij__%d' % d] = A(g)
+    x = rng.standard_normal((2, 3, 4, 5, 6)).astype(F)
+    cases['bcf__x'] = x
+    cases['bcf__out'] = A(ne.utils.batch_channel_flatten(T(x)))
+    cases['flatten_axes_12__out'] = A(ne.utils.flatten_axes(T(x), [1, 2]))
+    save('index_helpers', **cases)
+
+
+def gen_dice():
+    import warnings
+    warnings.simplefilter('ignore')
+    rng = np.random.default_rng(99)
+    cases = {}
+    B, S, L = 2, (6, 5, 7), 5
+    lab_t = rng.integers(0, L, (B,) + S)
+    lab_p = np.where(rng.random((B,) + S) < 0.7, lab_t, rng.integers(0, L, (B,) + S))
+    lab_p[0][lab_p[0] == 3] = 0                     # label 3 absent from batch 0's prediction
+    lab_t[1][lab_t[1] == 4] = 1
+    lab_p[1][lab_p[1] == 4] = 1                     # label 4 absent from both in batch 1 (0/0 -> 0)
+    oh_t = np.eye(L, dtype=F)[lab_t]
+    oh_p = np.eye(L, dtype=F)[lab_p]
+    pr_t = rng.random((B,) + S + (L,)).astype(F)
+    pr_t /= pr_t.sum(-1, keepdims=True)
+    pr_p = rng.random((B,) + S + (L,)).astype(F)
+    pr_p /= pr_p.sum(-1, keepdims=True)
+    pr_t = np.clip(pr_t, 0, 1).astype(F)
+    pr_p = np.clip(pr_p, 0, 1).astype(F)
+    w = rng.random((1, L)).astype(F)
+    cases.update(lab_t=lab_t.astype(np.int32), lab_p=lab_p.astype(np.int32), oh_t=oh_t, oh_p=oh_p,
+                 pr_t=pr_t, pr_p=pr_p, w=w)
+
+    cases['soft_onehot'] = A(ne.metrics.Dice().dice(T(oh_t), T(oh_p)))
+    cases['soft_prob'] = A(ne.metrics.SoftDice().dice(T(pr_t), T(pr_p)))
+    cases['soft_prob_laplace'] = A(ne.metrics.SoftDice(laplace_smoothing=0.1).dice(T(pr_t), T(pr_p)))
+    unn_t, unn_p = (pr_t * F(0.5)).astype(F), (pr_p * F(0.25)).astype(F)
+    cases['soft_prob_normalize'] = A(ne.metrics.SoftDice(normalize=True).dice(T(unn_t), T(unn_p)))
+    cases['unn_t'], cases['unn_p'] = unn_t, unn_p
+    cases['mean_soft_prob'] = A(ne.metrics.Dice().mean_dice(T(pr_t), T(pr_p)))
+    cases['mean_soft_prob_w'] = A(ne.metrics.Dice(weights=T(w)).mean_dice(T(pr_t), T(pr_p)))
+    cases['hard_prob'] = A(ne.metrics.HardDice(L, input_type='prob').dice(T(pr_t), T(pr_p)))
+    cases['hard_prob_nolabels'] = A(ne.metrics.Dice(dice_type='hard', input_type='prob').dice(T(pr_t), T(pr_p)))
+    cases['hard_label'] = A(ne.metrics.HardDice(L).dice(T(lab_t.astype(np.int32)), T(lab_p.astype(np.int32))))
+    cases['hard_label_laplace'] = A(ne.metrics.HardDice(L, laplace_smoothing=1.0).dice(
+        T(lab_t.astype(np.int32)), T(lab_p.astype(np.int32))))
+    cases['loss_soft_prob'] = A(ne.losses.Dice().loss(T(pr_t), T(pr_p)))
+    cases['mean_loss_soft_prob'] = A(ne.losses.Dice().mean_loss(T(pr_t), T(pr_p)))
+    cases['loss_hard_label'] = A(ne.losses.HardDice(L).loss(T(lab_t.astype(np.int32)), T(lab_p.astype(np.int32))))
+    # range assert fires (metrics.py:439-444)
+    bad = pr_p.copy()
+    bad[0, 0, 0, 0, 0] = 1.5
+    try:
+        ne.metrics.Dice().dice(T(pr_t), T(bad))
+        raised = False
+    except tf_shim.InvalidArgumentError:
+        raised = True
+    assert raised
+    cases['not_checked_bad'] = A(ne.metrics.Dice(check_input_limits=False).dice(T(pr_t), T(bad)))
+    cases['bad'] = bad
+    save('dice_small', **cases)
+
+
+def gen_cce():
+    rng = np.random.default_rng(321)
+    cases = {}
+    B, S, C = 2, (4, 5, 3), 6
+    lab = rng.integers(0, C, (B,) + S)
+    t = np.eye(C, dtype=F)[lab]
+    p = rng.random((B,) + S + (C,)).astype(F) + F(0.01)
+    p[0, 0, 0, 0, :] = 0
+    p[0, 0, 0, 0, 2] = 1.0                        # exercises the 1e-7 clip on both sides
+    w = (rng.random(C) + 0.2).astype(F)
+    sw = rng.random((B,) + S).astype(F)
+    z = rng.standard_normal((B,) + S + (C,)).astype(F) * 3
+    cases.update(t=t, p=p, w=w, sw=sw, z=z)
+    cases['plain'] = A(ne.metrics.CategoricalCrossentropy()(T(t), T(p)))
+    cases['weighted'] = A(ne.metrics.CategoricalCrossentropy(label_weights=w).cce(T(t), T(p)))
+    cases['weighted_smooth'] = A(ne.metrics.CategoricalCrossentropy(label_weights=w, label_smoothing=0.1)(T(t), T(p)))
+    cases['weighted_logits'] = A(ne.metrics.CategoricalCrossentropy(label_weights=w, from_logits=True)(T(t), T(z)))
+    cases['weighted_sw'] = A(ne.metrics.CategoricalCrossentropy(label_weights=w)(T(t), T(p), sample_weight=T(sw)))
+    cases['loss_weighted'] = A(ne.losses.CategoricalCrossentropy(label_weights=w).loss(T(t), T(p)))
+    try:
+        ne.metrics.CategoricalCrossentropy(label_weights=w[:-1])(T(t), T(p))
+        raised = False
+    except ValueError:
+        raised = True
+    assert raised
+    save('cce_small', **cases)
+
+
+def gen_lc3d():
+    rng = np.random.default_rng(2024)
+    cases = {}
+    for tag, in_shape, ks, st, cout in (('k323_s112', (2, 5, 4, 6, 3), (3, 2, 3), (1, 1, 2), 4),
+                                        ('k333_s111', (1, 5, 5, 5, 2), (3, 3, 3), (1, 1, 1), 3)):
+        x = rng.standard_normal(in_shape).astype(F)
+        osh = tuple((in_shape[1 + d] - ks[d]) // st[d] + 1 for d in range(3))
+        O, Fdim = int(np.prod(osh)), int(np.prod(ks)) * in_shape[-1]
+        k = (rng.standard_normal((O, Fdim, cout)) / np.sqrt(Fdim)).astype(F)
+        b = rng.standard_normal(osh + (cout,)).astype(F)
+        out = ne.layers.LocallyConnected3D.local_conv(T(x), T(k), ks, st, osh, 'channels_last')
+        out = A(tf_shim.k_bias_add(out, T(b), data_format='channels_last'))
+        cases[tag + '__x'] = x
+        cases[tag + '__kernel'] = k
+        cases[tag + '__bias'] = b
+        cases[tag + '__ks'] = np.array(ks)
+        cases[tag + '__strides'] = np.array(st)
+        cases[tag + '__out'] = out
+    save('lc3d_small', **cases)
+
+
+if __name__ == '__main__':
+    gen_interpn()
+    gen_resize()
+    gen_index_helpers()
+    gen_dice()
+    gen_cce()
+    gen_lc3d()

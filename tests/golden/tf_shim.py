@@ -1,0 +1,548 @@
+"""
+A small NumPy stand-in for the TensorFlow / Keras-backend *leaf primitives* that the reference's
+hot path calls, so that the reference's OWN Python source under /root/reference can be executed
+in a container that has no TensorFlow (TEST INFRASTRUCTURE; used only by make_golden.py).
+
+What this pins: everything the reference itself decides -- control flow, op order, index
+arithmetic, corner ordering, weight pairing, clamping order, reshape/flatten conventions.
+What this does NOT pin: the leaf semantics of the TF ops themselves, which are restated here from
+their documented behaviour (tf.round = half-to-even, float->int32 cast truncates,
+tf.clip_by_value = min(max(x, lo), hi) in the tensor dtype, tf.linspace endpoints exact,
+tf.math.divide_no_nan, tf.argmax ties -> lowest index, tf.one_hot out-of-range -> zero row,
+Keras CCE: normalise, clip to [1e-7, 1-1e-7], -sum t log p, mean over elements).
+
+Typing rule enforced on purpose: a binary op between two tensors of different dtypes raises
+(as TensorFlow does); Python / NumPy scalars adopt the tensor's dtype.  Every op is computed in
+the tensor dtype with one rounding, like an eager TF CPU kernel.
+"""
+
+import importlib.abc
+import importlib.machinery
+import sys
+import types
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- dtypes / shapes
+
+class DType:
+    def __init__(self, np_dtype):
+        self.np = np.dtype(np_dtype)
+
+    @property
+    def is_floating(self):
+        return np.issubdtype(self.np, np.floating)
+
+    @property
+    def is_integer(self):
+        return np.issubdtype(self.np, np.integer)
+
+    @property
+    def base_dtype(self):
+        return self
+
+    @property
+    def name(self):
+        return self.np.name
+
+    @property
+    def as_numpy_dtype(self):
+        return self.np.type
+
+    def __eq__(self, other):
+        try:
+            return self.np == as_np_dtype(other)
+        except TypeError:
+            return False
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(self.np)
+
+    def __repr__(self):
+        return 'tf.' + self.np.name
+
+
+def as_np_dtype(d):
+    if isinstance(d, DType):
+        return d.np
+    return np.dtype(d)
+
+
+class Dimension(int):
+    pass
+
+
+class TensorShape(tuple):
+    def as_list(self):
+        return list(self)
+
+    @property
+    def rank(self):
+        return len(self)
+
+    def __getitem__(self, i):
+        r = tuple.__getitem__(self, i)
+        return TensorShape(r) if isinstance(i, slice) else r
+
+
+class Tensor:
+    __array_priority__ = 1000
+
+    def __init__(self, a, dtype=None):
+        if isinstance(a, Tensor):
+            a = a.a
+        self.a = np.asarray(a, dtype=None if dtype is None else as_np_dtype(dtype))
+
+    # -- TF-ish surface
+    @property
+    def shape(self):
+        return TensorShape(self.a.shape)
+
+    def get_shape(self):
+        return self.shape
+
+    @property
+    def dtype(self):
+        return DType(self.a.dtype)
+
+    def numpy(self):
+        return self.a
+
+    def __array__(self, dtype=None, copy=None):
+        return self.a if dtype is None else self.a.astype(dtype)
+
+    def __len__(self):
+        return self.a.shape[0]
+
+    def __iter__(self):
+        for i in range(self.a.shape[0]):
+            yield Tensor(self.a[i])
+
+    def __getitem__(self, idx):
+        if isinstance(idx, list):
+            idx = tuple(idx)
+        if isinstance(idx, Tensor):
+            idx = idx.a
+        return Tensor(self.a[idx])
+
+    def __repr__(self):
+        return 'ShimTensor(%r)' % (self.a,)
+
+    __hash__ = object.__hash__
+
+    # -- arithmetic in the tensor dtype
+    def _co(self, other):
+        if isinstance(other, Tensor):
+            if other.a.dtype != self.a.dtype:
+                raise TypeError('dtype mismatch in binary op: %s vs %s' % (self.a.dtype, other.a.dtype))
+            return other.a
+        return np.asarray(other).astype(self.a.dtype)
+
+    def _bin(self, other, fn, swap=False):
+        o = self._co(other)
+        with np.errstate(all='ignore'):
+            r = fn(o, self.a) if swap else fn(self.a, o)
+        return Tensor(np.asarray(r))
+
+    def __add__(self, o): return self._bin(o, np.add)
+    def __radd__(self, o): return self._bin(o, np.add, True)
+    def __sub__(self, o): return self._bin(o, np.subtract)
+    def __rsub__(self, o): return self._bin(o, np.subtract, True)
+    def __mul__(self, o): return self._bin(o, np.multiply)
+    def __rmul__(self, o): return self._bin(o, np.multiply, True)
+    def __truediv__(self, o): return self._bin(o, np.divide)
+    def __rtruediv__(self, o): return self._bin(o, np.divide, True)
+    def __neg__(self): return Tensor(-self.a)
+    def __lt__(self, o): return self._bin(o, np.less)
+    def __le__(self, o): return self._bin(o, np.less_equal)
+    def __gt__(self, o): return self._bin(o, np.greater)
+    def __ge__(self, o): return self._bin(o, np.greater_equal)
+
+
+def T(x, dtype=None):
+    return x if (isinstance(x, Tensor) and dtype is None) else Tensor(x, dtype)
+
+
+def A(x):
+    return x.a if isinstance(x, Tensor) else np.asarray(x)
+
+
+# ----------------------------------------------------------------------------- tf.* primitives
+
+def convert_to_tensor(x, dtype=None, **kw):
+    if isinstance(x, Tensor):
+        return x if dtype is None else cast(x, dtype)
+    a = np.asarray(x)
+    if dtype is None:
+        if a.dtype == np.float64 and not isinstance(x, np.ndarray):
+            a = a.astype(np.float32)       # python floats -> float32, like TF
+        if a.dtype == np.int64 and not isinstance(x, np.ndarray):
+            a = a.astype(np.int32)         # python ints -> int32
+    else:
+        a = a.astype(as_np_dtype(dtype))
+    return Tensor(a)
+
+
+def constant(v, dtype=None, **kw):
+    return convert_to_tensor(v, dtype)
+
+
+def cast(x, dtype):
+    a = A(x)
+    nd = as_np_dtype(dtype)
+    with np.errstate(all='ignore'):
+        if np.issubdtype(nd, np.integer) and np.issubdtype(a.dtype, np.floating):
+            return Tensor(np.trunc(a).astype(nd))          # float -> int truncates toward zero
+        return Tensor(a.astype(nd))
+
+
+def stack(values, axis=0, **kw):
+    if isinstance(values, Tensor):
+        return values
+    arrs = [A(convert_to_tensor(v)) for v in values]
+    if len({a.dtype for a in arrs}) != 1:
+        raise TypeError('stack of mixed dtypes')
+    return Tensor(np.stack(arrs, axis))
+
+
+def concat(values, axis, **kw):
+    arrs = [A(convert_to_tensor(v)) for v in values]
+    return Tensor(np.concatenate(arrs, axis))
+
+
+def floor(x): return Tensor(np.floor(A(x)))
+def round_(x): return Tensor(np.rint(A(x)))                 # half-to-even
+def exp(x): return Tensor(np.exp(A(x)))
+def log(x): return Tensor(np.log(A(x)))
+def square(x): return Tensor(np.square(A(x)))
+def less(x, y): return T(x) < y
+def greater(x, y): return T(x) > y
+def logical_not(x): return Tensor(np.logical_not(A(x)))
+
+
+def clip_by_value(t, lo, hi, **kw):
+    a = A(t)
+    lo = np.asarray(A(lo)).astype(a.dtype)
+    hi = np.asarray(A(hi)).astype(a.dtype)
+    return Tensor(np.minimum(np.maximum(a, lo), hi))
+
+
+def _shape_arg(shape):
+    if isinstance(shape, Tensor):
+        shape = shape.a
+    return tuple(int(A(s)) for s in shape)
+
+
+def reshape(x, shape, **kw):
+    return Tensor(A(x).reshape(_shape_arg(shape)))
+
+
+def gather(params, indices, axis=0, **kw):
+    return Tensor(np.take(A(params), A(indices), axis=axis))
+
+
+def reduce_any(x, axis=None, keepdims=False):
+    return Tensor(np.any(A(x), axis=axis, keepdims=keepdims))
+
+
+def reduce_sum(x, axis=None, keepdims=False):
+    a = A(x)
+    return Tensor(np.sum(a.astype(np.float64), axis=axis, keepdims=keepdims).astype(a.dtype))
+
+
+def linspace(start, stop, num, **kw):
+    """tf.linspace in float32 for python-float endpoints (TF semantics restated)."""
+    f = np.float32
+    start, stop, num = f(start), f(stop), int(num)
+    if num == 1:
+        return Tensor(np.array([start], f))
+    delta = f((stop - start) / f(num - 1))
+    i = np.arange(1, num - 1).astype(f)
+    return Tensor(np.concatenate([[start], (start + delta * i).astype(f), [stop]]).astype(f))
+
+
+def range_(start, limit=None, delta=1, dtype=None, **kw):
+    if limit is None:
+        start, limit = 0, start
+    a = np.arange(start, limit, delta)
+    if dtype is not None:
+        a = a.astype(as_np_dtype(dtype))
+    elif np.issubdtype(a.dtype, np.integer):
+        a = a.astype(np.int32)
+    return Tensor(a)
+
+
+def size(x, **kw):
+    return Tensor(np.int32(A(x).size))
+
+
+def tile(x, multiples, **kw):
+    return Tensor(np.tile(A(x), _shape_arg(multiples)))
+
+
+def ones(shape, dtype=np.float32, **kw):
+    return Tensor(np.ones(_shape_arg(shape), as_np_dtype(dtype)))
+
+
+def zeros(shape, dtype=np.float32, **kw):
+    return Tensor(np.zeros(_shape_arg(shape), as_np_dtype(dtype)))
+
+
+def map_fn(fn, elems, **kw):
+    if isinstance(elems, (list, tuple)):
+        n = A(elems[0]).shape[0]
+        outs = [fn([T(A(e)[i]) for e in elems]) for i in range(n)]
+    else:
+        outs = [fn(T(A(elems)[i])) for i in range(A(elems).shape[0])]
+    return Tensor(np.stack([A(o) for o in outs], 0))
+
+
+def divide_no_nan(x, y, **kw):
+    x, y = A(x), A(y)
+    if x.dtype != y.dtype:
+        raise TypeError('divide_no_nan dtype mismatch')
+    out = np.zeros(np.broadcast(x, y).shape, x.dtype)
+    np.divide(x, y, out=out, where=(y != 0))
+    return Tensor(out)
+
+
+class InvalidArgumentError(Exception):
+    pass
+
+
+def _assert(cond, msg):
+    if not bool(np.all(cond)):
+        raise InvalidArgumentError(msg)
+
+
+def assert_greater_equal(x, y, message='', **kw): _assert(A(x) >= A(y), message)
+def assert_less_equal(x, y, message='', **kw): _assert(A(x) <= A(y), message)
+def assert_all_finite(x, message='', **kw): _assert(np.isfinite(A(x)), message)
+
+
+# ----------------------------------------------------------------------------- keras.backend
+
+def k_expand_dims(x, axis=-1): return Tensor(np.expand_dims(A(x), axis))
+def k_shape(x): return Tensor(np.array(A(x).shape, np.int32))
+def k_int_shape(x): return tuple(A(x).shape)
+def k_ndim(x): return A(x).ndim
+def k_square(x): return Tensor(np.square(A(x)))
+def k_epsilon(): return 1e-7
+
+
+def k_sum(x, axis=None, keepdims=False):
+    # TF's reduction order is unspecified; accumulate wide and round once
+    a = A(x)
+    return Tensor(np.sum(a.astype(np.float64), axis=axis, keepdims=keepdims).astype(a.dtype))
+
+
+def k_mean(x, axis=None, keepdims=False):
+    a = A(x)
+    return Tensor(np.mean(a.astype(np.float64), axis=axis, keepdims=keepdims).astype(a.dtype))
+
+
+def k_argmax(x, axis=-1): return Tensor(np.argmax(A(x), axis=axis).astype(np.int64))
+
+
+def k_one_hot(indices, num_classes):
+    idx = A(indices).astype(np.int64)
+    out = np.zeros(idx.shape + (int(num_classes),), np.float32)
+    ok = (idx >= 0) & (idx < num_classes)
+    np.put_along_axis(out, np.where(ok, idx, 0)[..., None], ok[..., None].astype(np.float32), -1)
+    return Tensor(out)
+
+
+def k_concatenate(tensors, axis=-1): return Tensor(np.concatenate([A(t) for t in tensors], axis))
+def k_permute_dimensions(x, pattern): return Tensor(np.transpose(A(x), tuple(pattern)))
+
+
+def k_batch_dot(x, y, axes=None):
+    x, y = A(x), A(y)
+    assert axes is None and x.ndim == 3 and y.ndim == 3
+    return Tensor(np.einsum('obf,ofc->obc', x.astype(np.float64), y.astype(np.float64)).astype(x.dtype))
+
+
+def k_bias_add(x, bias, data_format=None):
+    assert data_format in (None, 'channels_last')
+    return T(x) + T(A(bias)[None])
+
+
+# ----------------------------------------------------------------------------- keras classes
+
+class Layer:
+    """Just enough of keras.layers.Layer: build on first call with the input shape, then call."""
+
+    def __init__(self, name=None, **kwargs):
+        self.name = name
+        self.built = False
+        self._weights = {}
+
+    def build(self, input_shape):
+        self.built = True
+
+    def add_weight(self, shape=None, initializer=None, name=None, **kw):
+        w = Tensor(np.zeros(tuple(shape), np.float32))
+        self._weights[name] = w
+        return w
+
+    def __call__(self, inputs, **kw):
+        if not self.built:
+            if isinstance(inputs, (list, tuple)):
+                shp = [tuple(A(i).shape) for i in inputs]
+            else:
+                shp = tuple(A(inputs).shape)
+            self.build(shp)
+            self.built = True
+        return self.call(inputs, **kw)
+
+    def get_config(self):
+        return {'name': self.name}
+
+
+class KerasCCE:
+    """tf.keras.losses.CategoricalCrossentropy (TF semantics restated; float64 internally)."""
+
+    def __init__(self, from_logits=False, label_smoothing=0., **kw):
+        self.from_logits = from_logits
+        self.label_smoothing = label_smoothing
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        p = A(y_pred).astype(np.float64)
+        t = A(y_true).astype(np.float64)
+        C = p.shape[-1]
+        if self.label_smoothing:
+            t = t * (1.0 - self.label_smoothing) + self.label_smoothing / C
+        if self.from_logits:
+            z = p - p.max(-1, keepdims=True)
+            logq = z - np.log(np.exp(z).sum(-1, keepdims=True))
+        else:
+            q = p / p.sum(-1, keepdims=True)
+            logq = np.log(np.clip(q, 1e-7, 1 - 1e-7))
+        l = -(t * logq).sum(-1)
+        if sample_weight is not None:
+            sw = A(sample_weight).astype(np.float64)
+            while sw.ndim < l.ndim:
+                sw = sw[..., None]
+            l = l * sw
+        return Tensor(np.float32(l.sum() / l.size))
+
+
+# ----------------------------------------------------------------------------- module plumbing
+
+class _Stub:
+    """Permissive placeholder for everything the hot path never touches."""
+
+    def __init__(self, name='stub'):
+        self.__name__ = name
+
+    def __call__(self, *a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]                      # behaves as an identity decorator
+        return _Stub(self.__name__ + '()')
+
+    def __getattr__(self, n):
+        if n.startswith('__'):
+            raise AttributeError(n)
+        return _Stub(self.__name__ + '.' + n)
+
+    def __mro_entries__(self, bases):
+        return (object,)
+
+
+class _AutoModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        if name[:1].isupper():
+            v = type(name, (object,), {'__init__': lambda self, *a, **k: None})
+        else:
+            v = _Stub(self.__name__ + '.' + name)
+        setattr(self, name, v)
+        return v
+
+
+_ROOTS = ('tensorflow', 'pystrum', 'nibabel', 'h5py')
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split('.')[0] in _ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _AutoModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        _populate(module)
+
+
+def _populate(m):
+    n = m.__name__
+    if n == 'pystrum':
+        m.__version__ = '0.2'
+    if n == 'tensorflow':
+        d = dict(
+            Tensor=Tensor, TensorShape=TensorShape, convert_to_tensor=convert_to_tensor, constant=constant,
+            cast=cast, stack=stack, concat=concat, floor=floor, round=round_, exp=exp, square=square,
+            less=less, greater=greater, logical_not=logical_not, clip_by_value=clip_by_value,
+            reshape=reshape, gather=gather, reduce_any=reduce_any, reduce_sum=reduce_sum, linspace=linspace,
+            range=range_, size=size, tile=tile, ones=ones, zeros=zeros, map_fn=map_fn,
+            float32=DType(np.float32), float64=DType(np.float64), int32=DType(np.int32),
+            int64=DType(np.int64), bool=DType(np.bool_), float16=DType(np.float16),
+            expand_dims=lambda x, axis: k_expand_dims(x, axis),
+        )
+        for k, v in d.items():
+            setattr(m, k, v)
+        m.__version__ = '2.99.shim'
+    if n == 'tensorflow.math':
+        m.divide_no_nan = divide_no_nan
+        m.log = log
+        m.exp = exp
+    if n == 'tensorflow.debugging':
+        m.assert_greater_equal = assert_greater_equal
+        m.assert_less_equal = assert_less_equal
+        m.assert_all_finite = assert_all_finite
+    if n == 'tensorflow.errors':
+        m.InvalidArgumentError = InvalidArgumentError
+    if n == 'tensorflow.compat.v1':
+        m.Dimension = Dimension
+    if n == 'tensorflow.dtypes':
+        m.as_dtype = lambda d: d if isinstance(d, DType) else DType(d)
+    if n == 'tensorflow.keras.backend':
+        d = dict(expand_dims=k_expand_dims, shape=k_shape, int_shape=k_int_shape, ndim=k_ndim, sum=k_sum,
+                 mean=k_mean, square=k_square, argmax=k_argmax, one_hot=k_one_hot, reshape=reshape,
+                 concatenate=k_concatenate, permute_dimensions=k_permute_dimensions, batch_dot=k_batch_dot,
+                 bias_add=k_bias_add, epsilon=k_epsilon, floor=floor, exp=exp, log=log,
+                 cast=cast, stack=stack, clip=clip_by_value)
+        for k, v in d.items():
+            setattr(m, k, v)
+    if n == 'tensorflow.keras.layers':
+        m.Layer = Layer
+    if n == 'tensorflow.keras.losses':
+        m.CategoricalCrossentropy = KerasCCE
+
+
+def install():
+    """Install the shim; afterwards `import tensorflow` etc. resolve to it."""
+    if any(isinstance(f, _Finder) for f in sys.meta_path):
+        return
+    sys.meta_path.insert(0, _Finder())
+    import importlib
+    # make attribute access and `import a.b.c` agree for the sub-modules we populate
+    for name in ('tensorflow', 'tensorflow.math', 'tensorflow.debugging', 'tensorflow.errors',
+                 'tensorflow.compat', 'tensorflow.compat.v1', 'tensorflow.dtypes', 'tensorflow.keras',
+                 'tensorflow.keras.backend', 'tensorflow.keras.layers', 'tensorflow.keras.losses',
+                 'tensorflow.keras.models', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
+                 'tensorflow.python', 'tensorflow.python.keras', 'tensorflow.python.keras.utils',
+                 'tensorflow.python.ops', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
+        mod = importlib.import_module(name)
+        if '.' in name:
+            parent, child = name.rsplit('.', 1)
+            setattr(sys.modules[parent], child, mod)
