@@ -1,0 +1,294 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark of the neurite hot path on MI355X.
+
+Metric (BASELINE.json): Mvoxels/sec of interpn+Dice on 160^3 x 32-label volumes.
+A step = one pass of the hot path over one batch of synthetic volumes already resident in HBM:
+    warped = SpatialTransformer('linear')([moving, trf])        one batched HIP launch
+    dice   = Dice(check_input_limits=False).dice(fixed, warped)  one HIP launch + finalize
+    N > 1: one RCCL all-reduce of [sum of dice, count] (mean Dice over the global batch)
+Workload: BASELINE config 2 (SpatialTransformer + Dice, 160^3 x 32 one-hot, fp32); every GPU holds
+`--batch-per-gpu` volumes (default 4 = config 4's sharding of B=32 over 8 GPUs), so scaling is weak
+and N=8 is exactly config 4.  1 voxel = 1 spatial output location.
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line on stdout.  `roofline` is the dominant kernel (the interpn gather):
+achieved = algorithmic bytes per launch (268 B/voxel x voxels per launch) / its average
+duration measured with HIP events inside the timed region.  `cpu_baseline` is the C oracle (a port of
+the reference algorithm, oracle/oracle.c) on the host cores over a bounded sample -- reported, not a target.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+INTERPN_BYTES_PER_VOXEL = lambda C, D: 4 * C + 4 * D + 4 * C      # read row once + loc + write row
+DICE_BYTES_PER_VOXEL = lambda L: 2 * 4 * L
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch-per-gpu', type=int, default=4)
+    ap.add_argument('--size', type=int, default=160)
+    ap.add_argument('--labels', type=int, default=32)
+    ap.add_argument('--rough', action='store_true', help='worst-case incoherent field U(-80,80)')
+    ap.add_argument('--variant', type=int, default=0, help='interpn kernel variant (0 = library default)')
+    ap.add_argument('--tune', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sweep', action='store_true', help='time every interpn kernel variant and exit')
+    return ap.parse_args()
+
+
+def cpu_baseline(mov, fix, trf, budget_s=10.0):
+    """C oracle (port of the reference algorithm) on all host cores, bounded sample of the workload."""
+    from oracle import c_oracle as co
+    m, f, t = mov[0].cpu().numpy(), fix[0].cpu().numpy(), trf[0].cpu().numpy()
+    cores = os.cpu_count() or 1
+    co.set_num_threads(cores)
+    V = int(np.prod(m.shape[:-1]))
+
+    def once():
+        w = co.interpn(m, t, 'linear', None, loc_mode=1)
+        sums, _ = co.dice_sums(f[None], w[None])
+        return co.dice_from_sums(sums)
+
+    t0 = time.perf_counter()
+    d = once()
+    t1 = time.perf_counter() - t0
+    reps = int(max(1, min(20, budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    dt = (time.perf_counter() - t0) / reps
+    return {'value': round(V / dt / 1e6, 3), 'unit': 'Mvoxels/s', 'cores': co.num_threads(), 'kind': 'port',
+            'sample': '%d x (SpatialTransformer linear + Dice on one %s x %d-label volume of the bench batch), '
+                      'C oracle with OpenMP' % (reps, 'x'.join(str(s) for s in m.shape[:-1]), m.shape[-1])}, d
+
+
+def sweep(args, dev, mov, fix, trf):
+    """Time every interpn kernel variant (and the Dice kernel) on the bench batch; JSON lines to stderr."""
+    import neurite_amd as ne
+    B, S = mov.shape[0], args.size
+    V = S ** 3
+    res = []
+    cfgs = [(1, 0), (2, 1), (2, 2), (2, 4), (2, 8), (2, 16), (3, 0), (3, 80), (3, 40), (3, 20), (3, 10),
+            (4, 0), (4, 40), (4, 20)]
+    ref = None
+    for variant, tune in cfgs:
+        st = ne.layers.SpatialTransformer()
+        st._variant, st._tune = variant, tune
+        try:
+            out = st([mov, trf])
+        except Exception as e:      # noqa
+            log('variant', variant, tune, 'failed:', e)
+            continue
+        if ref is None:
+            ref = out
+        same = bool(torch.equal(out, ref))
+        for _ in range(2):
+            st([mov, trf])
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        n = 10
+        e0.record()
+        for _ in range(n):
+            st([mov, trf])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        gbs = INTERPN_BYTES_PER_VOXEL(args.labels, 3) * V * B / ms / 1e6
+        r = {'kernel': 'interpn', 'variant': variant, 'tune': tune, 'ms': round(ms, 4), 'GBs': round(gbs, 1),
+             'frac': round(gbs / HBM_PEAK_GBS, 4), 'bit_identical_to_first': same}
+        log(json.dumps(r))
+        res.append(r)
+    D = ne.metrics.Dice(check_input_limits=False)
+    warped = ref
+    for _ in range(2):
+        D.dice(fix, warped)
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(10):
+        D.dice(fix, warped)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    gbs = DICE_BYTES_PER_VOXEL(args.labels) * V * B / ms / 1e6
+    r = {'kernel': 'dice_soft', 'ms': round(ms, 4), 'GBs': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4)}
+    log(json.dumps(r))
+    res.append(r)
+    # reference point: plain device-to-device copy of the same volume (achievable HBM rate on this box)
+    dst = torch.empty_like(mov)
+    for _ in range(2):
+        dst.copy_(mov)
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(mov)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    r = {'kernel': 'torch_copy_d2d', 'ms': round(ms, 4), 'GBs': round(2 * mov.numel() * 4 / ms / 1e6, 1)}
+    log(json.dumps(r))
+    res.append(r)
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'sweep_%s.json' % ('rough' if args.rough else 'smooth')), 'w') as f:
+        json.dump(res, f, indent=1)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (MI355X); there is no CPU path.')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        log('warning: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d' % (args.gpus, world, world))
+
+    import neurite_amd as ne
+    from neurite_amd import distributed as nd
+    from neurite_amd import synth
+
+    B = args.batch_per_gpu
+    S, L = args.size, args.labels
+    V = S ** 3
+    # rank r owns global batch entries [r*B, (r+1)*B): seeds follow the global entry index
+    mov, fix, trf = synth.cfg2_batch(B, S, L, device=dev, seed0=100 + 3 * rank * B, rough=args.rough)
+    torch.cuda.synchronize()
+
+    if args.sweep:
+        sweep(args, dev, mov, fix, trf)
+        return
+
+    st = ne.layers.SpatialTransformer(interp_method='linear')
+    st._variant, st._tune = args.variant, args.tune
+    # a warped one-hot map overshoots 1.0 by an ulp, so the reference's default range assert would
+    # abort the pipeline (see tests/test_gpu_dice_cce.py); min/max are still computed by the kernel
+    dice = ne.metrics.Dice(check_input_limits=False)
+
+    def step(events=None):
+        if events is not None:
+            events[0].record()
+        warped = st([mov, trf])
+        if events is not None:
+            events[1].record()
+        d = dice.dice(fix, warped)                      # [B, L]
+        if events is not None:
+            events[2].record()
+        return nd.all_reduce_mean_dice(d)               # one all-reduce of 2 floats when world > 1
+
+    for _ in range(args.warmup):
+        m = step()
+    torch.cuda.synchronize()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        m = step(evs[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+
+    interp_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    dice_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_vox = world * B * V * args.steps
+    value = total_vox / elapsed / 1e6
+    alg_bytes = INTERPN_BYTES_PER_VOXEL(L, 3) * V * B
+    achieved = alg_bytes / (interp_ms * 1e-3) / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get('interpn_bytes_per_launch_B%d' % B)
+        except Exception:   # noqa
+            traffic = None
+    out = {
+        'metric': 'Mvoxels/sec interpn+Dice on 160^3 x 32-label',
+        'value': round(value, 2),
+        'unit': 'Mvoxels/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': 'BASELINE config 2/4: SpatialTransformer(linear)+Dice on %d^3 x %d-label one-hot fp32, '
+                        '%d volumes per GPU per step (global batch %d), %s displacement field'
+                        % (S, L, B, B * world, 'worst-case U(-80,80)' if args.rough else 'smooth sigma=3 voxel'),
+            'volumes_per_gpu': B, 'global_batch': B * world, 'size': S, 'labels': L,
+            'parallelism': 'dp%d (batch-sharded, one RCCL all-reduce of 2 floats per step)' % world,
+            'mean_dice': round(float(m), 6),
+        },
+        'roofline': {
+            'kernel': 'interpn (SpatialTransformer gather), one launch per step',
+            'bound': 'hbm',
+            'achieved': round(achieved, 1),
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': traffic,
+            'algorithmic_bytes_per_launch': alg_bytes,
+            'avg_launch_ms': round(interp_ms, 4),
+            'dice_kernel': {'avg_ms': round(dice_ms, 4),
+                            'achieved': round(DICE_BYTES_PER_VOXEL(L) * V * B / (dice_ms * 1e-3) / 1e9, 1),
+                            'unit': 'GB/s'},
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            base, d_cpu = cpu_baseline(mov, fix, trf)
+            out['cpu_baseline'] = base
+            d_gpu = dice.dice(fix[:1], st([mov[:1], trf[:1]])).cpu().numpy()
+            out['config']['max_abs_dice_diff_vs_oracle'] = float(np.abs(d_gpu - d_cpu).max())
+        except Exception as e:   # noqa
+            out['cpu_baseline'] = {'value': None, 'unit': 'Mvoxels/s', 'cores': 0, 'kind': 'port',
+                                   'sample': 'failed: %s' % e}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -144,6 +144,7 @@ class SpatialTransformer(_Layer):
         self.add_identity = add_identity
         self.shape = shape
         self.ndims = None
+        self._variant, self._tune = 0, 0      # kernel selection override (tuning / tests); 0 = auto
 
     def get_config(self):
         config = super().get_config().copy()
@@ -201,7 +202,8 @@ class SpatialTransformer(_Layer):
         def run():
             out = utils._launch_interpn(vol32, shift, shift.shape[1:-1], _lib.LOC_SHIFT,
                                         utils._METHODS[self.interp_method], self.fill_value, batched=True,
-                                        single_transform=self.single_transform)
+                                        single_transform=self.single_transform, variant=self._variant,
+                                        tune=self._tune)
             return out if restore is None else out.to(restore)
 
         return utils._maybe_tracked(run, vol, trf)

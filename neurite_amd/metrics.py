@@ -52,6 +52,16 @@ def dice_partial_sums(y_true, y_pred, normalize=False, laplace_smoothing=0.):
     sums = torch.empty((B, 3, L), dtype=torch.float32, device=dev)
     dice = torch.empty((B, L), dtype=torch.float32, device=dev)
     minmax = torch.empty((4,), dtype=torch.float32, device=dev)
+    if t.numel() == 0:          # no voxels: all sums are zero; the finalize kernel still does the division
+        if B * L == 0:
+            return sums, dice, minmax.fill_(0)
+        sums.zero_()
+        with torch.cuda.device(dev):
+            rc = lib.nrt_dice_from_sums_f32(_lib.ptr(sums), L, B, float(laplace_smoothing), _lib.ptr(dice),
+                                            _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_dice_from_sums_f32')
+        minmax.copy_(torch.tensor([float('inf'), float('-inf'), float('inf'), float('-inf')]))
+        return sums, dice, minmax
     nws = lib.nrt_dice_workspace_bytes(V, L, B)
     ws = _lib.workspace(dev, nws)
     with torch.cuda.device(dev):

@@ -1,0 +1,79 @@
+"""
+world_size-2 `gloo` test of the N > 1 path (CPU): the batch is sharded by entry, each rank reduces
+its shard to a handful of floats, ONE all-reduce rebuilds the global mean -- exactly the value the
+un-sharded computation gives.  Per-rank Dice values come from the oracle here (tests may use it; the
+GPU path produces them with the HIP kernels, test_gpu_pipeline.py).
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from neurite_amd import distributed as nd
+        from oracle import np_oracle as npo
+        rng = np.random.default_rng(2024)                      # same stream on every rank
+        B, S, L = 5, (6, 5, 4), 7
+        t = rng.random((B,) + S + (L,)).astype(np.float32)
+        p = rng.random((B,) + S + (L,)).astype(np.float32)
+        w = rng.random((1, L)).astype(np.float32)
+        lo, hi = nd.shard_range(B)
+        assert (lo, hi) == nd.shard_range(B, rank, world)
+        local = torch.from_numpy(npo.dice(t[lo:hi], p[lo:hi]))
+        got = nd.all_reduce_mean_dice(local, weights=w)
+        want = npo.mean_dice(t, p, weights=w)
+        # spatially split batch entry: all-reduce the numerator/denominator partials, then divide
+        half = S[0] // 2
+        sl = slice(0, half) if rank == 0 else slice(half, None)
+        stp, stt, spp = npo.dice_sums(t[:, sl], p[:, sl])
+        sums = torch.from_numpy(np.stack([stp, stt, spp], 1).astype(np.float32))
+        tot = nd.reduce_dice_sums(sums)
+        full = np.stack(npo.dice_sums(t, p), 1)
+        # cross-entropy: mean over ALL voxels from per-rank (sum, count)
+        lv = npo.cce_per_voxel(t[lo:hi], p[lo:hi])
+        ce = nd.all_reduce_mean(torch.tensor(lv.sum(), dtype=torch.float32), lv.size)
+        q.put((rank, float(got), float(want), np.abs(tot.numpy() - full).max() / np.abs(full).max(),
+               float(ce), float(npo.cce(t, p))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_sharded_reductions_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, got, want, rel, ce, ce_want in res:
+        assert abs(got - want) <= 1e-6 * abs(want), (rank, got, want)
+        assert rel < 1e-6
+        assert abs(ce - ce_want) <= 1e-5 * abs(ce_want)
+    assert res[0][1] == res[1][1]          # every rank holds the same reduced value
+
+
+def test_world1_is_identity():
+    from neurite_amd import distributed as nd
+    d = torch.rand(3, 4)
+    assert torch.allclose(nd.all_reduce_mean_dice(d), d.mean())
+    s = torch.rand(2, 3, 4)
+    assert nd.reduce_dice_sums(s) is s
+    assert nd.shard_range(10) == (0, 10)

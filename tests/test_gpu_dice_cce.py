@@ -1,0 +1,224 @@
+"""
+GPU parity tests of Dice (soft / hard) and label-weighted categorical cross-entropy against the golden
+vectors of the reference's own source and against the oracle.
+Tolerances: hard / one-hot Dice BIT-EXACT (integer counting); soft Dice and CCE 1e-5 relative
+(float32 reduction order is unspecified in TensorFlow; the oracle accumulates in float64).
+"""
+
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import neurite_amd as ne
+from conftest import bits_equal, load_golden
+from neurite_amd import synth
+from oracle import c_oracle as co
+from oracle import np_oracle as npo
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+RTOL = 1e-5
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def test_dice_golden(dev):
+    g = load_golden('dice_small')
+    L = g['oh_t'].shape[-1]
+    t, p = G(g['pr_t'], dev), G(g['pr_p'], dev)
+    oh_t, oh_p = G(g['oh_t'], dev), G(g['oh_p'], dev)
+    lt, lp = G(g['lab_t'], dev), G(g['lab_p'], dev)
+    assert bits_equal(N(ne.metrics.Dice().dice(oh_t, oh_p)), g['soft_onehot'])
+    np.testing.assert_allclose(N(ne.metrics.SoftDice().dice(t, p)), g['soft_prob'], rtol=RTOL)
+    np.testing.assert_allclose(N(ne.metrics.SoftDice(laplace_smoothing=0.1).dice(t, p)), g['soft_prob_laplace'], rtol=RTOL)
+    np.testing.assert_allclose(N(ne.metrics.SoftDice(normalize=True).dice(G(g['unn_t'], dev), G(g['unn_p'], dev))),
+                               g['soft_prob_normalize'], rtol=RTOL)
+    np.testing.assert_allclose(N(ne.metrics.Dice().mean_dice(t, p)), g['mean_soft_prob'], rtol=RTOL)
+    np.testing.assert_allclose(N(ne.metrics.Dice(weights=g['w']).mean_dice(t, p)), g['mean_soft_prob_w'], rtol=RTOL)
+    np.testing.assert_allclose(N(ne.metrics.Dice(weights=G(g['w'], dev)).mean_dice(t, p)), g['mean_soft_prob_w'], rtol=RTOL)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert bits_equal(N(ne.metrics.HardDice(L, input_type='prob').dice(t, p)), g['hard_prob'])
+        assert any('hard* dice' in str(x.message) for x in w)            # metrics.py:455
+        assert bits_equal(N(ne.metrics.Dice(dice_type='hard', input_type='prob').dice(t, p)), g['hard_prob_nolabels'])
+    assert bits_equal(N(ne.metrics.HardDice(L).dice(lt, lp)), g['hard_label'])
+    assert bits_equal(N(ne.metrics.HardDice(L, laplace_smoothing=1.0).dice(lt, lp)), g['hard_label_laplace'])
+    assert bits_equal(N(ne.metrics.HardDice(L).dice(lt.to(torch.int64), lp.to(torch.uint8))), g['hard_label'])
+    np.testing.assert_allclose(N(ne.losses.Dice().loss(t, p)), g['loss_soft_prob'], rtol=RTOL)
+    np.testing.assert_allclose(N(ne.losses.Dice().mean_loss(t, p)), g['mean_loss_soft_prob'], rtol=RTOL)
+    assert bits_equal(N(ne.losses.HardDice(L).loss(lt, lp)), g['loss_hard_label'])
+    with pytest.raises(ne.errors.InvalidArgumentError, match='value outside range'):    # metrics.py:439-444
+        ne.metrics.Dice().dice(t, G(g['bad'], dev))
+    np.testing.assert_allclose(N(ne.metrics.Dice(check_input_limits=False).dice(t, G(g['bad'], dev))),
+                               g['not_checked_bad'], rtol=RTOL)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        dl = ne.metrics.Dice().loss(t, p)                                  # deprecated path, :512-519
+        assert any('deprecated' in str(x.message) for x in w)
+    np.testing.assert_allclose(N(dl), -g['mean_soft_prob'], rtol=RTOL)
+    with pytest.raises(TypeError, match='integer label ids'):
+        ne.metrics.HardDice(L).dice(t[..., 0], p[..., 0])
+    with pytest.raises(AssertionError, match='weights should be a matrix'):
+        ne.metrics.Dice(weights=np.ones(L, F)).mean_dice(t, p)
+
+
+@pytest.mark.parametrize('L', [1, 3, 4, 5, 8, 16, 32, 64, 128, 256, 300])
+def test_soft_dice_label_counts(dev, L):
+    rng = np.random.default_rng(L)
+    B, V = 2, 3001
+    t = rng.random((B, V, L)).astype(F)
+    p = rng.random((B, V, L)).astype(F)
+    for normalize in (False, True):
+        for eps in (0., 0.5):
+            got = N(ne.metrics.Dice(normalize=normalize, laplace_smoothing=eps).dice(G(t, dev), G(p, dev)))
+            want = npo.dice(t, p, normalize=normalize, laplace_smoothing=eps)
+            np.testing.assert_allclose(got, want, rtol=RTOL, err_msg=str((normalize, eps)))
+    sums, d, mm = ne.metrics.dice_partial_sums(G(t, dev), G(p, dev))
+    ref = np.stack(npo.dice_sums(t, p), 1)
+    np.testing.assert_allclose(N(sums), ref, rtol=RTOL)
+    assert N(mm).tolist() == [t.min(), t.max(), p.min(), p.max()]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        hard = N(ne.metrics.Dice(dice_type='hard', input_type='prob').dice(G(t, dev), G(p, dev)))
+        assert bits_equal(hard, npo.dice(t, p, dice_type='hard'))
+        # ties -> lowest label (tf.argmax)
+        tt = np.zeros((1, 50, L), F)
+        pp = np.zeros((1, 50, L), F)
+        pp[0, :, L - 1] = 0
+        hard0 = N(ne.metrics.Dice(dice_type='hard', input_type='prob').dice(G(tt, dev), G(pp, dev)))
+        assert hard0[0, 0] == 1 and np.all(hard0[0, 1:] == 0)
+
+
+def test_hard_label_dice_many_labels_and_out_of_range(dev):
+    rng = np.random.default_rng(12)
+    for L in (2, 33, 2036, 20000):
+        t = rng.integers(-2, L + 3, (3, 7, 9, 11)).astype(np.int32)
+        p = np.where(rng.random(t.shape) < 0.6, t, rng.integers(-2, L + 3, t.shape)).astype(np.int32)
+        got = N(ne.metrics.HardDice(L).dice(G(t, dev), G(p, dev)))
+        want = npo.dice(t, p, dice_type='hard', input_type='max_label', nb_labels=L)
+        assert bits_equal(got, want), L
+
+
+def test_dice_deterministic_and_empty(dev):
+    t = torch.rand(2, 40, 40, 40, 32, device=dev)
+    p = torch.rand(2, 40, 40, 40, 32, device=dev)
+    a = N(ne.metrics.Dice().dice(t, p))
+    for _ in range(3):
+        assert bits_equal(N(ne.metrics.Dice().dice(t, p)), a)            # no float atomics anywhere
+    z = torch.zeros(1, 4, 4, 4, 32, device=dev)
+    assert float(ne.metrics.Dice().dice(z, z).abs().max()) == 0           # divide_no_nan
+    e = torch.zeros(2, 0, 32, device=dev)
+    assert tuple(ne.metrics.Dice(check_input_limits=False).dice(e, e).shape) == (2, 32)
+
+
+def test_full_size_dice_cfg2(dev):
+    """160^3 x 32 one-hot volumes: every sum is an integer < 2^24, so any summation order is exact."""
+    mov, fix, trf = synth.cfg2_batch(2, 160, 32, device=dev, seed0=1)
+    got = N(ne.metrics.Dice().dice(fix, mov))
+    sums, _ = co.dice_sums(N(fix), N(mov))
+    assert bits_equal(got, co.dice_from_sums(sums))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        hard = N(ne.metrics.HardDice(32, input_type='prob').dice(fix, mov))
+    assert bits_equal(hard, got)                                           # one-hot: hard == soft
+    # warped (soft) probabilities at full size vs float64 sums
+    warped = ne.layers.SpatialTransformer()([mov, trf])
+    # a tri-linearly warped one-hot map overshoots 1.0 by an ulp at a few voxels (the float32 weights of a
+    # cell sum to 1 +- 2^-23), so the reference's default range assert (metrics.py:443-444) fires on it;
+    # the pipeline therefore runs with check_input_limits=False -- and the default must still raise
+    D = ne.metrics.Dice(check_input_limits=False)
+    got = N(D.dice(fix, warped))
+    sums, mm = co.dice_sums(N(fix), N(warped))
+    np.testing.assert_allclose(got, co.dice_from_sums(sums), rtol=RTOL)
+    assert mm[2] >= 0 and 1.0 < mm[3] <= 1.0 + 1e-6
+    with pytest.raises(ne.errors.InvalidArgumentError, match='value outside range'):
+        ne.metrics.Dice().dice(fix, warped)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        hard = N(ne.metrics.HardDice(32, input_type='prob', check_input_limits=False).dice(fix, warped))
+    c = co.dice_hard_counts_prob(N(fix), N(warped))
+    assert bits_equal(hard, co.dice_from_sums(c.astype(np.float64)))
+    # label-map pipeline of models.py:806-807: nearest warp of the label volume, hard Dice on ids
+    lab_m = torch.argmax(mov, -1).to(torch.float32).unsqueeze(-1)
+    lab_f = torch.argmax(fix, -1).to(torch.int32)
+    wl = ne.layers.SpatialTransformer('nearest', fill_value=0)([lab_m, trf])[..., 0].to(torch.int32)
+    got = N(ne.metrics.HardDice(32).dice(lab_f, wl))
+    c = co.dice_hard_counts_label(N(lab_f), N(wl), 32)
+    assert bits_equal(got, co.dice_from_sums(c.astype(np.float64)))
+    # sharding invariants (the multi-GPU path): per-entry dice is independent of the batch split,
+    # and spatially split partial sums add up to the whole
+    d_all = D.dice(fix, warped)
+    d_0 = D.dice(fix[:1], warped[:1])
+    assert bits_equal(N(d_all[:1]), N(d_0))
+    s_a, _, _ = ne.metrics.dice_partial_sums(fix[:, :80], warped[:, :80])
+    s_b, _, _ = ne.metrics.dice_partial_sums(fix[:, 80:], warped[:, 80:])
+    s_all, _, _ = ne.metrics.dice_partial_sums(fix, warped)
+    np.testing.assert_allclose(N(s_a + s_b), N(s_all), rtol=1e-6)
+    d_split = ne.distributed.dice_from_sums(ne.distributed.reduce_dice_sums(s_a + s_b))
+    np.testing.assert_allclose(N(d_split), N(d_all), rtol=1e-6)
+    m = ne.distributed.all_reduce_mean_dice(d_all)
+    np.testing.assert_allclose(float(m), float(D.mean_dice(fix, warped)), rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- CCE
+def test_cce_golden(dev):
+    g = load_golden('cce_small')
+    t, p, z, w, sw = G(g['t'], dev), G(g['p'], dev), G(g['z'], dev), g['w'], G(g['sw'], dev)
+    C = ne.metrics.CategoricalCrossentropy
+    np.testing.assert_allclose(N(C()(t, p)), g['plain'], rtol=RTOL)
+    np.testing.assert_allclose(N(C(label_weights=w).cce(t, p)), g['weighted'], rtol=RTOL)
+    np.testing.assert_allclose(N(C(label_weights=list(w))(t, p)), g['weighted'], rtol=RTOL)
+    np.testing.assert_allclose(N(C(label_weights=w, label_smoothing=0.1)(t, p)), g['weighted_smooth'], rtol=RTOL)
+    np.testing.assert_allclose(N(C(label_weights=w, from_logits=True)(t, z)), g['weighted_logits'], rtol=RTOL)
+    np.testing.assert_allclose(N(C(label_weights=w)(t, p, sample_weight=sw)), g['weighted_sw'], rtol=RTOL)
+    np.testing.assert_allclose(N(ne.losses.CategoricalCrossentropy(label_weights=w).loss(t, p)), g['loss_weighted'], rtol=RTOL)
+    pv = N(C(label_weights=w, reduction='none')(t, p))
+    np.testing.assert_allclose(pv, npo.cce_per_voxel(g['t'], g['p'], w), rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(N(C(label_weights=w, reduction='sum')(t, p)), pv.sum(), rtol=RTOL)
+
+
+@pytest.mark.parametrize('C', [2, 4, 6, 16, 32, 64, 100])
+def test_cce_channel_counts_and_bf16(dev, C):
+    rng = np.random.default_rng(C)
+    N_ = (2, 13, 11, 7)
+    lab = rng.integers(0, C, N_)
+    t = np.eye(C, dtype=F)[lab]
+    p = (rng.random(N_ + (C,)) + 0.01).astype(F)
+    w = (rng.random(C) + 0.3).astype(F)
+    z = (rng.standard_normal(N_ + (C,)) * 2).astype(F)
+    for kw in ({}, {'label_smoothing': 0.2}):
+        got = float(ne.metrics.CategoricalCrossentropy(label_weights=w, **kw)(G(t, dev), G(p, dev)))
+        np.testing.assert_allclose(got, npo.cce(t, p, w, **kw), rtol=RTOL)
+        got = float(ne.metrics.CategoricalCrossentropy(label_weights=w, from_logits=True, **kw)(G(t, dev), G(z, dev)))
+        np.testing.assert_allclose(got, npo.cce(t, z, w, from_logits=True, **kw), rtol=RTOL)
+    # bf16 inputs: arithmetic in float32 on the bf16-rounded values (tolerance from SURVEY A.9: 1e-3)
+    tb, pb = G(t, dev).to(torch.bfloat16), G(p, dev).to(torch.bfloat16)
+    got = float(ne.metrics.CategoricalCrossentropy(label_weights=w)(tb, pb))
+    want = npo.cce(N(tb.float()), N(pb.float()), w)
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+
+
+def test_cce_cfg5_size_bf16(dev):
+    """BASELINE config 5 loss stage: [1, 94, 94, 94, 16] bf16, inverse-frequency label weights."""
+    rng = np.random.default_rng(6)
+    S, C = (94, 94, 94), 16
+    lab = rng.integers(0, C, S)
+    t = torch.from_numpy(np.eye(C, dtype=F)[lab])[None].to(dev)
+    p = torch.softmax(torch.randn((1,) + S + (C,), device=dev), -1)
+    freq = np.bincount(lab.ravel(), minlength=C) / lab.size
+    w = (1.0 / freq)
+    w = (w / w.sum()).astype(F)
+    tb, pb = t.to(torch.bfloat16), p.to(torch.bfloat16)
+    got = float(ne.metrics.WeightedCategoricalCrossentropy(label_weights=w)(tb, pb))
+    want = co.wcce(N(tb.float()), N(pb.float()), w)
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    got32 = float(ne.metrics.CategoricalCrossentropy(label_weights=w)(t, p))
+    np.testing.assert_allclose(got32, co.wcce(N(t), N(p), w), rtol=RTOL)

@@ -1,0 +1,72 @@
+#!/bin/bash
+# One MI355X session: smoke, GPU parity tests, kernel-variant sweep, headline bench, rocprofv3 summaries.
+# Run through:  gpurun --timeout 1800 -- 'bash tools/gpu_session.sh [stages...]'
+# Every stage logs to gpurun_out/<stage>.log and never aborts the others.
+set -u
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd "$ROOT"
+OUT="$ROOT/gpurun_out"
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export PYTHONUNBUFFERED=1
+STAGES="${*:-info smoke tests sweep bench prof pmc}"
+echo "stages: $STAGES" | tee "$OUT/session.log"
+
+stage() { echo "=== $1 ($(date +%T))" | tee -a "$OUT/session.log"; }
+
+for s in $STAGES; do
+case $s in
+info)
+  stage info
+  { rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock|gfx" | head -12; rocm-smi --showmeminfo vram | head -8; nproc; free -g | head -2; lscpu | grep -E "Model name|^CPU\(s\)"; } > "$OUT/info.log" 2>&1
+  ;;
+smoke)
+  stage smoke
+  timeout 600 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?" | tee -a "$OUT/session.log"
+  ;;
+tests)
+  stage tests
+  timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 -x > "$OUT/tests.log" 2>&1; echo "tests rc=$?" | tee -a "$OUT/session.log"
+  tail -5 "$OUT/tests.log" | tee -a "$OUT/session.log"
+  ;;
+tests_all)
+  stage tests_all
+  timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 600 > "$OUT/tests.log" 2>&1; echo "tests rc=$?" | tee -a "$OUT/session.log"
+  tail -15 "$OUT/tests.log" | tee -a "$OUT/session.log"
+  ;;
+sweep)
+  stage sweep
+  timeout 600 python bench.py --sweep > "$OUT/sweep_smooth.log" 2>&1; echo "sweep rc=$?" | tee -a "$OUT/session.log"
+  timeout 600 python bench.py --sweep --rough > "$OUT/sweep_rough.log" 2>&1
+  timeout 600 python bench.py --sweep --batch-per-gpu 1 > "$OUT/sweep_smooth_b1.log" 2>&1
+  grep -h '"kernel"' "$OUT/sweep_smooth.log" | tee -a "$OUT/session.log"
+  ;;
+bench)
+  stage bench
+  timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"; echo "bench rc=$?" | tee -a "$OUT/session.log"
+  cat "$OUT/bench.json" | tee -a "$OUT/session.log"
+  timeout 600 python bench.py --batch-per-gpu 1 --no-cpu-baseline > "$OUT/bench_b1.json" 2>> "$OUT/bench.log"
+  timeout 600 python bench.py --rough --no-cpu-baseline > "$OUT/bench_rough.json" 2>> "$OUT/bench.log"
+  cat "$OUT/bench_b1.json" "$OUT/bench_rough.json" | tee -a "$OUT/session.log"
+  ;;
+prof)
+  stage prof
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- \
+      python "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.log" )
+  echo "prof rc=$?" | tee -a "$OUT/session.log"
+  find "$OUT/prof" -name "*kernel_stats.csv" | head -3 | while read f; do echo "$f"; head -12 "$f"; done | tee -a "$OUT/session.log"
+  ;;
+pmc)
+  stage pmc
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o bench -- \
+        python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$c.log" )
+    echo "pmc $c rc=$?" | tee -a "$OUT/session.log"
+  done
+  python tools/summarize_pmc.py "$OUT" 2>&1 | tee -a "$OUT/session.log"
+  ;;
+esac
+done
+# keep the merged output small: drop bulky traces, keep csv summaries
+find "$OUT" -name "*.db" -size +8M -delete 2>/dev/null
+du -sh "$OUT" | tee -a "$OUT/session.log"
