@@ -90,8 +90,15 @@ def sweep(args, dev, mov, fix, trf):
     B, S = mov.shape[0], args.size
     V = S ** 3
     res = []
-    cfgs = [(1, 0), (2, 1), (2, 2), (2, 4), (2, 8), (2, 16), (3, 0), (3, 80), (3, 40), (3, 20), (3, 10),
-            (4, 0), (4, 40), (4, 20)]
+    def T(lx, ly, lz, zo):
+        return lx | (ly << 4) | (lz << 8) | (zo << 12)
+    cfgs = [(1, 0), (2, 1), (2, 2), (2, 4), (3, 40), (3, 20), (3, 10)]
+    for zo in (0, 1):
+        cfgs += [(5, T(0, 0, 5, zo)), (5, T(1, 1, 3, zo)), (5, T(1, 1, 5, zo)), (5, T(2, 2, 3, zo)), (5, T(2, 2, 4, zo)),
+                 (5, T(2, 3, 4, zo)), (5, T(3, 3, 3, zo)), (5, T(3, 3, 4, zo)), (5, T(2, 2, 5, zo)), (5, T(3, 2, 4, zo)),
+                 (5, T(4, 4, 3, zo))]
+    if os.environ.get('NRT_SWEEP'):
+        cfgs = [tuple(int(v) for v in c.split(':')) for c in os.environ['NRT_SWEEP'].split(',')]
     ref = None
     for variant, tune in cfgs:
         st = ne.layers.SpatialTransformer()
@@ -115,7 +122,9 @@ def sweep(args, dev, mov, fix, trf):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / n
         gbs = INTERPN_BYTES_PER_VOXEL(args.labels, 3) * V * B / ms / 1e6
-        r = {'kernel': 'interpn', 'variant': variant, 'tune': tune, 'ms': round(ms, 4), 'GBs': round(gbs, 1),
+        r = {'kernel': 'interpn', 'variant': variant, 'tune': tune,
+             'tile': [1 << (tune & 15), 1 << ((tune >> 4) & 15), 1 << ((tune >> 8) & 15), (tune >> 12) & 1] if variant == 5 else None,
+             'ms': round(ms, 4), 'GBs': round(gbs, 1),
              'frac': round(gbs / HBM_PEAK_GBS, 4), 'bit_identical_to_first': same}
         log(json.dumps(r))
         res.append(r)

@@ -20,7 +20,10 @@ ARCH = 'gfx950'
 
 # -ffp-contract=off: the interpolation kernels reproduce the reference's float32 op sequence with one
 # rounding per op; an FMA would change the bits.
-FLAGS = ['-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC', '-ffp-contract=off',
+# -fno-slp-vectorize: hipcc otherwise packs the corner blends into v_pk_*_f32 across rows, which needs
+# register shuffles of values whose loads are still in flight and drains the load queue (s_waitcnt
+# vmcnt(0)) in every loop iteration of the pipelined gather kernels.
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize',
          '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
 
 

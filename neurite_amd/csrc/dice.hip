@@ -37,11 +37,15 @@ struct DiceWs {
     float *fpart;
     float *mpart;
     unsigned *ipart;
+    double *gsum;        // [B][ngrp][3L] level-1 sums (float64; reinterpreted as int64 for the hard path)
+    float *gmm;          // [B][ngrp][4]
 };
 
 size_t dice_ws_bytes(int L, int batch) {
     size_t per = (size_t)batch * DICE_MAX_BLOCKS;
-    return per * 3 * L * sizeof(float) + per * 4 * sizeof(float) + per * 3 * L * sizeof(unsigned) + 256;
+    size_t grp = (size_t)batch * ((DICE_MAX_BLOCKS + 63) / 64);
+    return per * 3 * L * sizeof(float) + per * 4 * sizeof(float) + per * 3 * L * sizeof(unsigned) +
+           grp * 3 * L * sizeof(double) + grp * 4 * sizeof(float) + 256;
 }
 
 DiceWs dice_ws_carve(void *ws, int L, int batch) {
@@ -50,7 +54,11 @@ DiceWs dice_ws_carve(void *ws, int L, int batch) {
     char *p = (char *)ws;
     w.fpart = (float *)p; p += per * 3 * L * sizeof(float);
     w.mpart = (float *)p; p += per * 4 * sizeof(float);
-    w.ipart = (unsigned *)p;
+    w.ipart = (unsigned *)p; p += per * 3 * L * sizeof(unsigned);
+    size_t grp = (size_t)batch * ((DICE_MAX_BLOCKS + 63) / 64);
+    p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    w.gsum = (double *)p; p += grp * 3 * L * sizeof(double);
+    w.gmm = (float *)p;
     return w;
 }
 
@@ -207,34 +215,60 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const float *__r
     }
 }
 
-// second stage: one 1024-thread block per batch entry.  Column i of the [nblk, 3L] partial matrix is
-// summed by S = 1024/(3L) threads over fixed strided slices in float64, the S slice sums are then added
-// in slice order -- a fixed tree, so the result does not depend on scheduling.
-__global__ __launch_bounds__(1024) void dice_soft_finalize(const float *__restrict__ fpart, const float *__restrict__ mpart,
-                                                           int nblk, int nmm, int L, float eps, float *__restrict__ sums,
-                                                           float *__restrict__ dice, float *__restrict__ minmax) {
-    __shared__ double sl[1024];
-    extern __shared__ float fs[];   // [3*L]
-    const int b = blockIdx.x;
-    const int ncol = 3 * L;
-    for (int c0 = 0; c0 < ncol; c0 += 1024) {
-        const int cols = min(ncol - c0, 1024);
-        const int S = 1024 / cols;                         // slices per column (>= 1)
-        const int i = threadIdx.x % cols, s = threadIdx.x / cols;
-        double acc = 0.0;
-        if (s < S)
-            for (int k = s; k < nblk; k += S) acc += (double)fpart[((long long)b * nblk + k) * ncol + c0 + i];
+// Second stage, two levels so that no thread walks a long dependent chain (a single-level version took
+// 63 us for 2048 partials, profiles/r01_session1): level 1 reduces groups of RED_ROWS block partials in
+// float64 (one block per group), level 2 adds the <= 32 group sums in a fixed order and does the
+// division.  Fixed partition + fixed order => bit-reproducible.
+constexpr int RED_ROWS = 64;
+
+template <typename TIN, typename TACC>
+__global__ __launch_bounds__(256) void reduce_rows(const TIN *__restrict__ in, int rows, int ncol, TACC *__restrict__ out,
+                                                    const float *__restrict__ mm_in, float *__restrict__ mm_out, int mm_rows) {
+    __shared__ TACC sl[256];
+    const int b = blockIdx.x, grp = blockIdx.y;
+    const int r0 = grp * RED_ROWS, r1 = min(r0 + RED_ROWS, rows);
+    for (int c0 = 0; c0 < ncol; c0 += 256) {
+        const int cols = min(ncol - c0, 256);
+        const int S = 256 / cols;
+        const int i = threadIdx.x % cols, sidx = threadIdx.x / cols;
+        TACC acc = 0;
+        if (sidx < S)
+            for (int k = r0 + sidx; k < r1; k += S) acc += (TACC)in[((long long)b * rows + k) * ncol + c0 + i];
         sl[threadIdx.x] = acc;
         __syncthreads();
         if (threadIdx.x < cols) {
-            double tot = 0.0;
+            TACC tot = 0;
             for (int ss = 0; ss < S; ++ss) tot += sl[ss * cols + threadIdx.x];
-            const float f = (float)tot;
-            fs[c0 + threadIdx.x] = f;
-            sums[(long long)b * ncol + c0 + threadIdx.x] = f;
+            out[((long long)b * gridDim.y + grp) * ncol + c0 + threadIdx.x] = tot;
         }
         __syncthreads();
     }
+    if (mm_in && threadIdx.x < 4) {            // min t, max t, min p, max p of this group's partials
+        const int i = threadIdx.x;
+        const int q0 = (int)((long long)r0 * mm_rows / rows), q1 = (int)((long long)r1 * mm_rows / rows);
+        float m = (i & 1) ? -INFINITY : INFINITY;
+        for (int k = q0; k < q1; ++k) {
+            const float v = mm_in[((long long)b * mm_rows + k) * 4 + i];
+            m = (i & 1) ? fmaxf(m, v) : fminf(m, v);
+        }
+        mm_out[((long long)b * gridDim.y + grp) * 4 + i] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void dice_soft_finalize(const double *__restrict__ gsum, const float *__restrict__ gmm,
+                                                          int ngrp, int L, float eps, float *__restrict__ sums,
+                                                          float *__restrict__ dice, float *__restrict__ minmax) {
+    extern __shared__ float fs[];   // [3*L]
+    const int b = blockIdx.x;
+    const int ncol = 3 * L;
+    for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
+        double tot = 0.0;
+        for (int g = 0; g < ngrp; ++g) tot += gsum[((long long)b * ngrp + g) * ncol + i];
+        const float f = (float)tot;
+        fs[i] = f;
+        sums[(long long)b * ncol + i] = f;
+    }
+    __syncthreads();
     for (int l = threadIdx.x; l < L; l += blockDim.x) {
         const float top = nrt_mul(2.0f, fs[l]);                         // metrics.py:476
         const float bottom = nrt_add(fs[L + l], fs[2 * L + l]);         // :477
@@ -243,28 +277,14 @@ __global__ __launch_bounds__(1024) void dice_soft_finalize(const float *__restri
         else d = (bottom == 0.0f) ? 0.0f : top / bottom;                // :482 divide_no_nan
         dice[(long long)b * L + l] = d;
     }
-    if (minmax && b == 0) {
-        // min t, max t, min p, max p over every partial of every batch entry
-        float m[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
-        for (long long k = threadIdx.x; k < (long long)gridDim.x * nmm; k += blockDim.x) {
-            m[0] = fminf(m[0], mpart[k * 4 + 0]); m[1] = fmaxf(m[1], mpart[k * 4 + 1]);
-            m[2] = fminf(m[2], mpart[k * 4 + 2]); m[3] = fmaxf(m[3], mpart[k * 4 + 3]);
+    if (minmax && b == 0 && threadIdx.x < 4) {
+        const int i = threadIdx.x;
+        float m = (i & 1) ? -INFINITY : INFINITY;
+        for (int k = 0; k < (int)gridDim.x * ngrp; ++k) {
+            const float v = gmm[(long long)k * 4 + i];
+            m = (i & 1) ? fmaxf(m, v) : fminf(m, v);
         }
-        for (int off = 1; off < NRT_WAVE; off <<= 1) {
-            m[0] = fminf(m[0], __shfl_xor(m[0], off, NRT_WAVE)); m[1] = fmaxf(m[1], __shfl_xor(m[1], off, NRT_WAVE));
-            m[2] = fminf(m[2], __shfl_xor(m[2], off, NRT_WAVE)); m[3] = fmaxf(m[3], __shfl_xor(m[3], off, NRT_WAVE));
-        }
-        __syncthreads();
-        float *mf = (float *)sl;
-        if ((threadIdx.x & (NRT_WAVE - 1)) == 0)
-            for (int i = 0; i < 4; ++i) mf[(threadIdx.x / NRT_WAVE) * 4 + i] = m[i];
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            float r = mf[threadIdx.x];
-            for (int w2 = 1; w2 < (int)blockDim.x / NRT_WAVE; ++w2)
-                r = (threadIdx.x & 1) ? fmaxf(r, mf[w2 * 4 + threadIdx.x]) : fminf(r, mf[w2 * 4 + threadIdx.x]);
-            minmax[threadIdx.x] = r;
-        }
+        minmax[i] = m;
     }
 }
 
@@ -389,11 +409,11 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_label(const int *__restr
     }
 }
 
-__global__ void dice_counts_reduce(const unsigned *__restrict__ ipart, int nblk, int L, long long *counts) {
+__global__ void dice_counts_reduce(const long long *__restrict__ gcnt, int ngrp, int L, long long *counts) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < 3 * L; i += blockDim.x) {
         long long s = 0;
-        for (int k = 0; k < nblk; ++k) s += (long long)ipart[((long long)b * nblk + k) * 3 * L + i];
+        for (int k = 0; k < ngrp; ++k) s += gcnt[((long long)b * ngrp + k) * 3 * L + i];
         counts[(long long)b * 3 * L + i] = s;
     }
 }
@@ -486,9 +506,16 @@ extern "C" int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long 
         else hipLaunchKernelGGL((dice_soft_generic<false>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
     }
     NRT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dice_soft_finalize, dim3(batch), dim3(1024), (size_t)3 * nlabels * sizeof(float), st,
-                       (const float *)w.fpart, (const float *)w.mpart, (int)nblk, (int)(nblk * gz), nlabels,
-                       laplace_smoothing, sums, dice, minmax);
+    {
+        const int rows = (int)(nblk);
+        const int ngrp = (rows + RED_ROWS - 1) / RED_ROWS;
+        hipLaunchKernelGGL((reduce_rows<float, double>), dim3(batch, ngrp), dim3(256), 0, st, (const float *)w.fpart,
+                           rows, 3 * nlabels, w.gsum, (const float *)w.mpart, w.gmm, (int)(nblk * gz));
+        NRT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dice_soft_finalize, dim3(batch), dim3(256), (size_t)3 * nlabels * sizeof(float), st,
+                           (const double *)w.gsum, (const float *)w.gmm, ngrp, nlabels, laplace_smoothing, sums, dice,
+                           minmax);
+    }
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
@@ -515,7 +542,12 @@ extern "C" int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, 
             default: launch_hard_vec<64>(y_true, y_pred, nvox, batch, nblk, w, st); break;
         }
         NRT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(dice_counts_reduce, dim3(batch), dim3(256), 0, st, (const unsigned *)w.ipart, (int)nblk,
+        const int ngrp = ((int)nblk + RED_ROWS - 1) / RED_ROWS;
+        hipLaunchKernelGGL((reduce_rows<unsigned, long long>), dim3(batch, ngrp), dim3(256), 0, st,
+                           (const unsigned *)w.ipart, (int)nblk, 3 * nlabels, (long long *)w.gsum,
+                           (const float *)nullptr, (float *)nullptr, 0);
+        NRT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dice_counts_reduce, dim3(batch), dim3(256), 0, st, (const long long *)w.gsum, ngrp,
                            nlabels, counts);
     } else {
         if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)

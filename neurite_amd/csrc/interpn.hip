@@ -408,6 +408,158 @@ __global__ __launch_bounds__(256, MINW) void interpn_zrun_c32(InterpArgs a, int 
     }
 }
 
+// ============================================================================================
+// tile: G = C/4 lanes per voxel, 3-D output tiles, two voxels per lane-group in flight.
+//
+// Measured on MI355X (profiles/r01_session1): the one-voxel-at-a-time kernels above run at ~3.3 TB/s
+// although the chip moves 9 TB/s of rows in the incoherent worst case -- they are bound by the
+// dependent chain  loc load -> address -> 8 row loads -> blend  (two HBM latencies per voxel), and a
+// z-line traversal re-fetches every row for its x-neighbour line (FETCH_SIZE 1.9x algorithmic).  So:
+//  * a block owns a TX x TY x TZ output tile (tz fastest: a wave64 still reads 64/G consecutive-z rows
+//    = one contiguous run) and sweeps it in passes, so x/y/z neighbours re-use rows through L1/L2;
+//  * tiles are dealt to XCDs in contiguous x-slabs, and inside a slab either z-fastest or z-outermost
+//    so that the blocks resident on one XCD form a compact brick;
+//  * software pipeline, depth 2: loc of pass p+2 and the 8 rows of pass p+1 are in flight while pass p
+//    is blended; every load is unconditional (edge voxels clamp their address, only the store is
+//    predicated) so the compiler's vmcnt counts stay exact and nothing drains the queue.
+// ============================================================================================
+struct TileGeom {
+    int ltx, lty, ltz;          // log2 of the tile extent
+    unsigned nTy, nTz;          // tiles along y and z
+    unsigned nT2;               // tiles in the (x,y) plane = nTx * nTy
+    unsigned per2;              // (x,y) tiles owned by one XCD = ceil(nT2 / 8)
+    int z_outer;                // order inside an XCD's slab: 0 = z fastest, 1 = z outermost
+};
+
+struct TileMeta {
+    float w0[3], w1[3];
+    unsigned q;
+    bool oob, valid;
+};
+
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void interpn_tile(InterpArgs a, TileGeom tg) {
+    constexpr int NG = 256 / G;
+    const unsigned per = tg.per2 * tg.nTz;                     // blocks per XCD
+    const unsigned k = blockIdx.x % NRT_NXCD, j = blockIdx.x / NRT_NXCD;
+    if (j >= per) return;
+    unsigned t2l, tzi;
+    if (tg.z_outer) { tzi = j / tg.per2; t2l = j % tg.per2; }
+    else { tzi = j % tg.nTz; t2l = j / tg.nTz; }
+    const unsigned t2 = k * tg.per2 + t2l;
+    if (t2 >= tg.nT2) return;
+    const int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi << tg.ltz;
+
+    const int b = blockIdx.y;
+    const char *volb = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
+    const int lg = threadIdx.x % G;
+    const int g = threadIdx.x / G;
+    const int npass = (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
+    const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
+
+    // output voxel of (pass, this lane-group); coordinates clamped into the volume for addressing
+    auto voxel = [&](int pass, int (&qd)[NRT_MAXD], bool &valid) {
+        const int s = pass * NG + g;
+        const int x = x0 + (s >> (tg.ltz + tg.lty));
+        const int y = y0 + ((s >> tg.ltz) & ((1 << tg.lty) - 1));
+        const int z = z0 + (s & ((1 << tg.ltz) - 1));
+        valid = (x < a.O[0]) && (y < a.O[1]) && (z < a.O[2]);
+        qd[0] = min(x, a.O[0] - 1); qd[1] = min(y, a.O[1] - 1); qd[2] = min(z, a.O[2] - 1);
+    };
+    auto fetch_loc = [&](int pass, float (&p)[NRT_MAXD]) {
+        int qd[NRT_MAXD]; bool valid;
+        voxel(pass, qd, valid);
+        const unsigned q = ((unsigned)qd[0] * (unsigned)a.O[1] + (unsigned)qd[1]) * (unsigned)a.O[2] + (unsigned)qd[2];
+        if (MODE != NRT_LOC_LINSPACE) {
+            const float *lp = locb + (long long)q * 3;
+            p[0] = lp[0]; p[1] = lp[1]; p[2] = lp[2];
+        }
+    };
+    // finish the location of `pass` from the prefetched loc; compute corners, weights and row offsets
+    auto prepare = [&](int pass, const float (&praw)[NRT_MAXD], TileMeta &m, unsigned (&off)[8]) {
+        int qd[NRT_MAXD];
+        voxel(pass, qd, m.valid);
+        m.q = ((unsigned)qd[0] * (unsigned)a.O[1] + (unsigned)qd[1]) * (unsigned)a.O[2] + (unsigned)qd[2];
+        float p[NRT_MAXD];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (MODE == NRT_LOC_ABSOLUTE) p[d] = praw[d];
+            else if (MODE == NRT_LOC_SHIFT) p[d] = nrt_add((float)qd[d], praw[d]);
+            else p[d] = (qd[d] == 0) ? 0.0f
+                      : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
+        }
+        int i0[3], i1[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], m.w0[d], m.w1[d]);
+        m.oob = a.has_fill ? out_of_bounds<3>(a, p) : false;
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const unsigned ix = (corner & 4) ? i1[0] : i0[0];
+            const unsigned iy = (corner & 2) ? i1[1] : i0[1];
+            const unsigned iz = (corner & 1) ? i1[2] : i0[2];
+            off[corner] = (((ix * SY + iy) * SZ + iz) * (unsigned)G + (unsigned)lg) * 16u;
+        }
+    };
+    auto load_rows = [&](const unsigned (&off)[8], nrt_f4 (&R)[8]) {
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) R[corner] = *(const nrt_f4 *)(volb + (size_t)off[corner]);
+    };
+    auto finish = [&](const TileMeta &m, const nrt_f4 (&R)[8]) {
+        nrt_f4 acc = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const float wt = nrt_mul(nrt_mul((corner & 4) ? m.w1[0] : m.w0[0], (corner & 2) ? m.w1[1] : m.w0[1]),
+                                     (corner & 1) ? m.w1[2] : m.w0[2]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, R[corner][c]));
+        }
+        if (a.has_fill) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], m.oob, a.fill_f);
+        }
+        if (m.valid) __builtin_nontemporal_store(acc, &out[(long long)m.q * G + lg]);
+    };
+
+    // Issue order in steady state:  L(p+1) R(p) | L(p+2) R(p+1) | L(p+3) R(p+2) ...   (L = loc, R = 8 rows)
+    // so that waiting for L(p+1) leaves R(p) in flight (vmcnt 8) and blending pass p leaves L(p+2),
+    // R(p+1) in flight (vmcnt 11): nothing ever drains the queue.
+    nrt_f4 Ra[8], Rb[8];
+    TileMeta Ma, Mb;
+    unsigned off[8];
+    float pn[NRT_MAXD] = {0.0f, 0.0f, 0.0f};
+    const int last = npass - 1;
+    // No load below sits under a condition: passes beyond the tile re-address its last pass (cache hits)
+    // and only their store is suppressed.
+    // sched_barrier(0) pins the issue order: without it hipcc sinks the row loads below the previous
+    // pass's blend (to save registers) and the pipeline degenerates to one pass in flight.
+    fetch_loc(0, pn);
+    prepare(0, pn, Ma, off);
+    fetch_loc(min(1, last), pn);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(off, Ra);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int pass = 0; pass < npass; pass += 2) {
+        prepare(min(pass + 1, last), pn, Mb, off);
+        Mb.valid = Mb.valid && (pass + 1 < npass);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_loc(min(pass + 2, last), pn);
+        load_rows(off, Rb);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(Ma, Ra);
+        __builtin_amdgcn_sched_barrier(0);
+        prepare(min(pass + 2, last), pn, Ma, off);
+        Ma.valid = Ma.valid && (pass + 2 < npass);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_loc(min(pass + 3, last), pn);
+        load_rows(off, Ra);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(Mb, Rb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -524,6 +676,41 @@ void launch_zrun(const InterpArgs &a, int batch, int mode, int variant, int tune
     else launch_zrun_w<4>(a, batch, mode, LZ, st);
 }
 
+template <int G>
+void launch_tile(const InterpArgs &a, int batch, int mode, int tune, hipStream_t st) {
+    // tune = ltx | lty << 4 | ltz << 8 | z_outer << 12 ; 0 = default
+    constexpr int NG = 256 / G;
+    constexpr int WZ = 64 / G;                    // consecutive-z voxels per wave
+    if (tune <= 0) tune = 2 | (2 << 4) | (4 << 8) | (1 << 12);
+    TileGeom tg;
+    tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
+    while ((1 << tg.ltz) < WZ) ++tg.ltz;                       // a wave must stay inside one z-run
+    while ((1 << (tg.ltx + tg.lty + tg.ltz)) < NG) ++tg.lty;  // at least one pass
+    const unsigned nTx = (a.O[0] + (1 << tg.ltx) - 1) >> tg.ltx;
+    tg.nTy = (a.O[1] + (1 << tg.lty) - 1) >> tg.lty;
+    tg.nTz = (a.O[2] + (1 << tg.ltz) - 1) >> tg.ltz;
+    tg.nT2 = nTx * tg.nTy;
+    tg.per2 = (tg.nT2 + NRT_NXCD - 1) / NRT_NXCD;
+    dim3 grid(NRT_NXCD * tg.per2 * tg.nTz, batch);
+    switch (mode) {
+        case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((interpn_tile<G, NRT_LOC_ABSOLUTE>), grid, dim3(256), 0, st, a, tg); break;
+        case NRT_LOC_SHIFT: hipLaunchKernelGGL((interpn_tile<G, NRT_LOC_SHIFT>), grid, dim3(256), 0, st, a, tg); break;
+        default: hipLaunchKernelGGL((interpn_tile<G, NRT_LOC_LINSPACE>), grid, dim3(256), 0, st, a, tg); break;
+    }
+}
+
+void launch_tile_any(const InterpArgs &a, int batch, int mode, int tune, hipStream_t st) {
+    switch (a.C / 4) {
+        case 1: launch_tile<1>(a, batch, mode, tune, st); break;
+        case 2: launch_tile<2>(a, batch, mode, tune, st); break;
+        case 4: launch_tile<4>(a, batch, mode, tune, st); break;
+        case 8: launch_tile<8>(a, batch, mode, tune, st); break;
+        case 16: launch_tile<16>(a, batch, mode, tune, st); break;
+        case 32: launch_tile<32>(a, batch, mode, tune, st); break;
+        default: launch_tile<64>(a, batch, mode, tune, st); break;
+    }
+}
+
 }  // namespace
 
 // Default kernel choice, set from measurements on MI355X (profiles/): see DESIGN.md.
@@ -555,6 +742,8 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         else variant = 1;
     }
     if ((variant == 3 || variant == 4) && !can_zrun) return NRT_ERR_UNSUPPORTED;
+    const bool can_tile = can_rows && method == NRT_INTERP_LINEAR && vol_bytes < (1ull << 32);
+    if (variant == 5 && !can_tile) return NRT_ERR_UNSUPPORTED;
     if (variant == 2 && !can_rows) return NRT_ERR_UNSUPPORTED;
     switch (variant) {
         case 1:
@@ -564,6 +753,7 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 2: launch_rows_any(a, batch, loc_mode, method, tune, st); break;
         case 3:
         case 4: launch_zrun(a, batch, loc_mode, variant, tune, st); break;
+        case 5: launch_tile_any(a, batch, loc_mode, tune, st); break;
         default: return NRT_ERR_INVALID_ARG;
     }
     NRT_CHECK_LAUNCH();

@@ -179,7 +179,8 @@ class SpatialTransformer(_Layer):
             raise NotImplementedError('add_identity=False (absolute coordinates): call utils.interpn directly')
         B = vol.shape[0]
 
-        if trf.dim() == 3:          # affine [B, D, D+1] or [B, D+1, D+1] -> dense shift
+        # affine [B, D, D+1] or [B, D+1, D+1] -> dense shift (a dense 1-D flow [B, X, 1] also has rank 3)
+        if trf.dim() == 3 and trf.shape[-1] == D + 1 and trf.shape[-2] in (D, D + 1):
             out_spatial = list(self.shape) if self.shape is not None else list(vol.shape[1:-1])
             nb = 1 if self.single_transform else trf.shape[0]
             trf = torch.stack([utils.affine_to_dense_shift(trf[b], out_spatial, shift_center=self.shift_center,

@@ -63,8 +63,14 @@ def test_interpn_cfg1_golden_bit_exact(dev):
     np.testing.assert_allclose(out, npo.interpn_f64(g['vol'], g['loc']), rtol=1e-5, atol=1e-5)
 
 
+def _tile(lx, ly, lz, zo):
+    return lx | (ly << 4) | (lz << 8) | (zo << 12)
+
+
 @pytest.mark.parametrize('variant,tune', [(1, 0), (2, 0), (2, 1), (2, 7), (3, 0), (3, 5), (3, 8), (3, 40), (4, 0),
-                                          (4, 13)])
+                                          (4, 13), (5, 0), (5, _tile(0, 0, 5, 0)), (5, _tile(1, 1, 3, 1)),
+                                          (5, _tile(2, 3, 4, 1)), (5, _tile(3, 3, 3, 0)), (5, _tile(4, 4, 3, 1)),
+                                          (5, _tile(0, 0, 0, 0))])
 def test_c32_every_kernel_variant(dev, variant, tune):
     """All kernels that can serve C = 32 must agree bit-for-bit with the oracle, for sizes that are not
     multiples of the 4x8 patch / z-chunk / 8-voxel shift batch, smooth and rough fields, all loc modes."""
@@ -163,12 +169,15 @@ def test_non_finite_locations_are_memory_safe(dev):
     loc = rng.uniform(0, 5, (4, 4, 8, 3)).astype(F)
     loc[0, 0, 0] = [np.inf, -np.inf, 1e30]
     loc[1, 1, 1] = [np.nan, np.nan, np.nan]
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 5):
         for method in ('linear', 'nearest'):
-            if variant == 3 and method == 'nearest':
+            if variant in (3, 5) and method == 'nearest':
                 continue
             out = N(ne.utils.interpn(G(vol, dev), G(loc, dev), method, _variant=variant))
-            want = npo.interpn(vol, loc, method)
+            loc_ref = loc.copy()
+            loc_ref[1, 1, 1] = 0                     # NumPy cannot index with int32(NaN)
+            with np.errstate(invalid='ignore'):
+                want = npo.interpn(vol, loc_ref, method)
             ok = np.ones(loc.shape[:3], bool)
             ok[1, 1, 1] = False                      # NaN locations are undefined in the reference
             if method == 'nearest':
@@ -222,7 +231,7 @@ def test_full_size_cfg2_spatial_transformer(dev):
     assert bits_equal(got, want)
     # warped one-hot stays a partition of unity up to rounding
     assert np.abs(got.sum(-1) - 1).max() < 1e-5
-    for variant, tune in ((2, 0), (3, 0), (3, 40), (4, 40)):
+    for variant, tune in ((2, 0), (3, 0), (3, 40), (4, 40), (5, 0), (5, _tile(3, 3, 3, 1))):
         st._variant, st._tune = variant, tune
         assert bits_equal(N(st([mov, trf]))[0], want), (variant, tune)
     gotn = N(ne.layers.SpatialTransformer('nearest', fill_value=0)([mov, trf]))[0]

@@ -56,6 +56,15 @@ prof)
   echo "prof rc=$?" | tee -a "$OUT/session.log"
   find "$OUT/prof" -name "*kernel_stats.csv" | head -3 | while read f; do echo "$f"; head -12 "$f"; done | tee -a "$OUT/session.log"
   ;;
+pmcsweep)
+  stage pmcsweep
+  for c in FETCH_SIZE; do
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmcsweep_$c" -o sweep -- \
+        python "$ROOT/bench.py" --sweep --batch-per-gpu 1 > /dev/null 2> "$OUT/pmcsweep_$c.log" )
+    echo "pmcsweep $c rc=$?" | tee -a "$OUT/session.log"
+  done
+  python tools/summarize_pmc.py "$OUT" sweep 2>&1 | tail -60 | tee -a "$OUT/session.log"
+  ;;
 pmc)
   stage pmc
   for c in FETCH_SIZE WRITE_SIZE; do
