@@ -4,9 +4,12 @@ bench.py -- headline benchmark of the neurite hot path on MI355X.
 
 Metric (BASELINE.json): Mvoxels/sec of interpn+Dice on 160^3 x 32-label volumes.
 A step = one pass of the hot path over one batch of synthetic volumes already resident in HBM:
-    warped = SpatialTransformer('linear')([moving, trf])        one batched HIP launch
-    dice   = Dice(check_input_limits=False).dice(fixed, warped)  one HIP launch + finalize
+    dice = SpatialTransformer('linear')([moving, trf])  ->  Dice(fixed, warped)   [B, L]
     N > 1: one RCCL all-reduce of [sum of dice, count] (mean Dice over the global batch)
+computed by default with the fused kernel (neurite_amd.fused.warp_dice: the warped volume is consumed in
+registers, never written -- SURVEY.md 8d anticipates exactly this), or with --unfused by the drop-in
+two-kernel pipeline (layers.SpatialTransformer -> metrics.Dice).  The JSON line always carries the other
+form too (`other_pipeline`), measured in the same process.
 Workload: BASELINE config 2 (SpatialTransformer + Dice, 160^3 x 32 one-hot, fp32); every GPU holds
 `--batch-per-gpu` volumes (default 4 = config 4's sharding of B=32 over 8 GPUs), so scaling is weak
 and N=8 is exactly config 4.  1 voxel = 1 spatial output location.
@@ -15,10 +18,11 @@ and N=8 is exactly config 4.  1 voxel = 1 spatial output location.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line on stdout.  `roofline` is the dominant kernel (the interpn gather):
-achieved = algorithmic bytes per launch (268 B/voxel x voxels per launch) / its average
-duration measured with HIP events inside the timed region.  `cpu_baseline` is the C oracle (a port of
-the reference algorithm, oracle/oracle.c) on the host cores over a bounded sample -- reported, not a target.
+Rank 0 prints ONE JSON line on stdout.  `roofline` is the dominant kernel: achieved = algorithmic bytes per
+launch / its average duration measured with HIP events inside the timed region.  Algorithmic bytes per
+voxel (DESIGN.md 4): fused kernel 4C (moving row) + 12 (shift) + 4L (fixed row) = 268 B at C=L=32;
+unfused interpn 4C + 12 + 4C = 268 B, Dice 2*4L = 256 B.  `cpu_baseline` is the C oracle (a port of the
+reference algorithm, oracle/oracle.c) on the host cores over a bounded sample -- reported, not a target.
 """
 
 import argparse
@@ -55,6 +59,7 @@ def parse():
     ap.add_argument('--tune', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sweep', action='store_true', help='time every interpn kernel variant and exit')
+    ap.add_argument('--unfused', action='store_true', help='run the drop-in two-kernel pipeline instead of the fused kernel')
     return ap.parse_args()
 
 
@@ -143,8 +148,64 @@ def sweep(args, dev, mov, fix, trf):
     r = {'kernel': 'dice_soft', 'ms': round(ms, 4), 'GBs': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4)}
     log(json.dumps(r))
     res.append(r)
-    # reference point: plain device-to-device copy of the same volume (achievable HBM rate on this box)
+    # fused SpatialTransformer+Dice, tile shapes
+    for tune in (0, T(2, 2, 4, 1), T(2, 3, 4, 0), T(3, 3, 3, 0), T(3, 3, 3, 1), T(2, 2, 5, 0), T(1, 1, 5, 0), T(3, 3, 4, 0)):
+        for _ in range(2):
+            d = ne.fused.warp_dice(mov, trf, fix, _tune=tune)
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for _ in range(10):
+            ne.fused.warp_dice(mov, trf, fix, _tune=tune)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        r = {'kernel': 'fused_warp_dice', 'tune': tune, 'tile': [1 << (tune & 15), 1 << ((tune >> 4) & 15), 1 << ((tune >> 8) & 15), (tune >> 12) & 1],
+             'ms': round(ms, 4), 'Mvox_s': round(V * B / ms / 1e3, 1),
+             'GBs_524': round((INTERPN_BYTES_PER_VOXEL(args.labels, 3) + DICE_BYTES_PER_VOXEL(args.labels)) * V * B / ms / 1e6, 1),
+             'max_abs_diff_vs_unfused': float((d - D.dice(fix, warped)).abs().max())}
+        log(json.dumps(r))
+        res.append(r)
+    # how fast is the gather when re-use is perfect?  zero / constant half-voxel displacement
+    if os.environ.get('NRT_SWEEP_COHERENT', '1') == '1':
+        for name, val in (('zero', 0.0), ('half', 0.5)):
+            tr0 = torch.full_like(trf, val)
+            for variant, tune in ((2, 1), (3, 20), (5, T(2, 2, 4, 0)), (5, T(3, 3, 3, 0))):
+                st = ne.layers.SpatialTransformer()
+                st._variant, st._tune = variant, tune
+                for _ in range(2):
+                    st([mov, tr0])
+                e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+                e0.record()
+                for _ in range(10):
+                    st([mov, tr0])
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                gbs = INTERPN_BYTES_PER_VOXEL(args.labels, 3) * V * B / ms / 1e6
+                r = {'kernel': 'interpn_' + name + '_shift', 'variant': variant, 'tune': tune, 'ms': round(ms, 4),
+                     'GBs': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4)}
+                log(json.dumps(r))
+                res.append(r)
+            del tr0
+    # calibration: our own float4 copy kernel (plain / non-temporal, several grid sizes)
+    lib = ne._lib.lib()
     dst = torch.empty_like(mov)
+    for nt in (0, 1):
+        for blocks in (1024, 2048, 4096, 8192):
+            for _ in range(2):
+                lib.nrt_membench_copy_f32(ne._lib.ptr(mov), ne._lib.ptr(dst), mov.numel(), nt, blocks, ne._lib.stream_ptr(dev))
+            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+            e0.record()
+            for _ in range(10):
+                lib.nrt_membench_copy_f32(ne._lib.ptr(mov), ne._lib.ptr(dst), mov.numel(), nt, blocks, ne._lib.stream_ptr(dev))
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            r = {'kernel': 'membench_copy', 'nontemporal': nt, 'blocks': blocks, 'ms': round(ms, 4),
+                 'GBs': round(2 * mov.numel() * 4 / ms / 1e6, 1)}
+            log(json.dumps(r))
+            res.append(r)
+    # reference point: plain device-to-device copy of the same volume (achievable HBM rate on this box)
     for _ in range(2):
         dst.copy_(mov)
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -200,7 +261,7 @@ def main():
     # abort the pipeline (see tests/test_gpu_dice_cce.py); min/max are still computed by the kernel
     dice = ne.metrics.Dice(check_input_limits=False)
 
-    def step(events=None):
+    def step_unfused(events=None):
         if events is not None:
             events[0].record()
         warped = st([mov, trf])
@@ -211,28 +272,44 @@ def main():
             events[2].record()
         return nd.all_reduce_mean_dice(d)               # one all-reduce of 2 floats when world > 1
 
-    for _ in range(args.warmup):
-        m = step()
-    torch.cuda.synchronize()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        m = step(evs[k])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
+    def step_fused(events=None):
+        if events is not None:
+            events[0].record()
+        d = ne.fused.warp_dice(mov, trf, fix, _tune=args.tune)      # [B, L]; `warped` never leaves registers
+        if events is not None:
+            events[1].record()
+            events[2].record()
+        return nd.all_reduce_mean_dice(d)
 
-    interp_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    dice_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            m = step()
+        torch.cuda.synchronize()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            m = step(evs[k])
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax[0])
+        k0 = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+        k1 = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+        return elapsed, k0, k1, float(m)
+
+    fused = not args.unfused
+    elapsed, k0_ms, k1_ms, m = timed(step_fused if fused else step_unfused, args.steps, args.warmup)
+    # the other form of the same pipeline, shorter run, for the record
+    o_elapsed, o_k0, o_k1, o_m = timed(step_unfused if fused else step_fused, max(5, args.steps // 5), 2)
+    o_steps = max(5, args.steps // 5)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -240,15 +317,39 @@ def main():
 
     total_vox = world * B * V * args.steps
     value = total_vox / elapsed / 1e6
-    alg_bytes = INTERPN_BYTES_PER_VOXEL(L, 3) * V * B
-    achieved = alg_bytes / (interp_ms * 1e-3) / 1e9
+    interp_bytes = INTERPN_BYTES_PER_VOXEL(L, 3) * V * B
+    if fused:
+        # one kernel; it must move: moving row (4C) + loc (4D) + fixed row (4L) per voxel = 268 B at C=L=32
+        kname = 'warp_dice_tile (fused SpatialTransformer gather + Dice reduction), one launch per step'
+        alg_bytes = (4 * L + 12 + 4 * L) * V * B
+        kms = k0_ms
+    else:
+        kname = 'interpn (SpatialTransformer gather), one launch per step'
+        alg_bytes = interp_bytes
+        kms = k0_ms
+    achieved = alg_bytes / (kms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get('interpn_bytes_per_launch_B%d' % B)
+            traffic = json.load(open(tfile)).get(('fused' if fused else 'interpn') + '_bytes_per_launch_B%d' % B)
         except Exception:   # noqa
             traffic = None
+
+    def other_block():
+        ov = world * B * V * o_steps / o_elapsed / 1e6
+        if fused:
+            return {'what': 'drop-in two-kernel pipeline (layers.SpatialTransformer -> metrics.Dice), %d steps' % o_steps,
+                    'value': round(ov, 2), 'unit': 'Mvoxels/s', 'ms_per_step': round(o_elapsed / o_steps * 1e3, 4),
+                    'interpn_ms': round(o_k0, 4), 'interpn_GBs': round(interp_bytes / (o_k0 * 1e-3) / 1e9, 1),
+                    'interpn_frac_of_peak': round(interp_bytes / (o_k0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    'dice_ms': round(o_k1, 4),
+                    'dice_GBs': round(DICE_BYTES_PER_VOXEL(L) * V * B / (o_k1 * 1e-3) / 1e9, 1),
+                    'mean_dice': round(o_m, 6)}
+        return {'what': 'fused warp+Dice kernel (neurite_amd.fused.warp_dice), %d steps' % o_steps,
+                'value': round(ov, 2), 'unit': 'Mvoxels/s', 'ms_per_step': round(o_elapsed / o_steps * 1e3, 4),
+                'kernel_ms': round(o_k0, 4), 'mean_dice': round(o_m, 6)}
+
     out = {
         'metric': 'Mvoxels/sec interpn+Dice on 160^3 x 32-label',
         'value': round(value, 2),
@@ -264,14 +365,16 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': 'BASELINE config 2/4: SpatialTransformer(linear)+Dice on %d^3 x %d-label one-hot fp32, '
-                        '%d volumes per GPU per step (global batch %d), %s displacement field'
-                        % (S, L, B, B * world, 'worst-case U(-80,80)' if args.rough else 'smooth sigma=3 voxel'),
+                        '%d volumes per GPU per step (global batch %d), %s displacement field; %s'
+                        % (S, L, B, B * world, 'worst-case U(-80,80)' if args.rough else 'smooth sigma=3 voxel',
+                           'fused kernel (warped volume never written)' if fused else 'drop-in two-kernel pipeline'),
             'volumes_per_gpu': B, 'global_batch': B * world, 'size': S, 'labels': L,
+            'pipeline': 'fused' if fused else 'unfused',
             'parallelism': 'dp%d (batch-sharded, one RCCL all-reduce of 2 floats per step)' % world,
             'mean_dice': round(float(m), 6),
         },
         'roofline': {
-            'kernel': 'interpn (SpatialTransformer gather), one launch per step',
+            'kernel': kname,
             'bound': 'hbm',
             'achieved': round(achieved, 1),
             'peak': HBM_PEAK_GBS,
@@ -279,17 +382,23 @@ def main():
             'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic,
             'algorithmic_bytes_per_launch': alg_bytes,
-            'avg_launch_ms': round(interp_ms, 4),
-            'dice_kernel': {'avg_ms': round(dice_ms, 4),
-                            'achieved': round(DICE_BYTES_PER_VOXEL(L) * V * B / (dice_ms * 1e-3) / 1e9, 1),
-                            'unit': 'GB/s'},
+            'avg_launch_ms': round(kms, 4),
         },
+        'other_pipeline': other_block(),
     }
+    if fused:
+        out['roofline']['unfused_api_accounting_524B_per_voxel_GBs'] = round(
+            (INTERPN_BYTES_PER_VOXEL(L, 3) + DICE_BYTES_PER_VOXEL(L)) * V * B / (kms * 1e-3) / 1e9, 1)
+    else:
+        out['roofline']['dice_kernel'] = {'avg_ms': round(k1_ms, 4),
+                                          'achieved': round(DICE_BYTES_PER_VOXEL(L) * V * B / (k1_ms * 1e-3) / 1e9, 1),
+                                          'unit': 'GB/s'}
     if world == 1 and not args.no_cpu_baseline:
         try:
             base, d_cpu = cpu_baseline(mov, fix, trf)
             out['cpu_baseline'] = base
-            d_gpu = dice.dice(fix[:1], st([mov[:1], trf[:1]])).cpu().numpy()
+            d_gpu = (ne.fused.warp_dice(mov[:1], trf[:1], fix[:1]) if fused
+                     else dice.dice(fix[:1], st([mov[:1], trf[:1]]))).cpu().numpy()
             out['config']['max_abs_dice_diff_vs_oracle'] = float(np.abs(d_gpu - d_cpu).max())
         except Exception as e:   # noqa
             out['cpu_baseline'] = {'value': None, 'unit': 'Mvoxels/s', 'cores': 0, 'kind': 'port',

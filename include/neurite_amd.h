@@ -129,6 +129,22 @@ int nrt_dice_from_sums_f32(const float *sums, int nlabels, int batch, float lapl
                            float *dice, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused SpatialTransformer + soft Dice  (the BASELINE "interpn+Dice" pipeline in one pass)
+ * replaces: SpatialTransformer (see nrt_interpn_f32, NRT_LOC_SHIFT) immediately followed by
+ * Dice.dice(fixed, warped) (neurite/tf/metrics.py:415-482) without materialising `warped`.
+ *   moving [batch, vol_shape, nlabels], loc [batch, out_shape, 3] (or NULL for NRT_LOC_LINSPACE),
+ *   fixed  [batch, out_shape, nlabels];  warped [batch, out_shape, nlabels] or NULL (not written).
+ *   sums / dice / minmax as nrt_dice_soft_f32 with y_true = fixed, y_pred = warped.
+ * 3-D only, nlabels in {4, 8, 16, 32, 64, 128, 256}.  tune: tile shape knob (0 = default).
+ * ------------------------------------------------------------------------------------------ */
+size_t nrt_warp_dice_workspace_bytes(const int *out_shape, int nlabels, int batch, int tune);
+int nrt_warp_dice_soft_f32(const float *moving, const float *loc, const float *fixed, float *warped,
+                           const int *vol_shape, const int *out_shape, int nlabels, int batch,
+                           long long loc_batch_stride, int loc_mode, int has_fill, float fill_value,
+                           float laplace_smoothing, float *sums, float *dice, float *minmax,
+                           int tune, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Label-weighted categorical cross-entropy
  * replaces: neurite/tf/metrics.py:640-650 + tf.keras.losses.CategoricalCrossentropy
  * ------------------------------------------------------------------------------------------ */
@@ -148,6 +164,12 @@ int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *lab
              long long nvox_total, int channels, int from_logits, float label_smoothing,
              float *loss_sum, float *per_voxel,
              void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or
+ * non-temporal; calibrates the achievable mixed read/write HBM rate next to the kernels above.
+ * ------------------------------------------------------------------------------------------ */
+int nrt_membench_copy_f32(const float *src, float *dst, long long n, int nontemporal, int blocks, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,290 @@
+// Fused SpatialTransformer + soft Dice for gfx950 (MI355X).
+//
+// The metric pipeline of BASELINE config 2/4 is  warped = SpatialTransformer(moving, trf);
+// dice = Dice(fixed, warped).  Run as two kernels it moves 268 + 256 = 524 B per voxel:
+// `warped` (128 B/voxel at L = 32) is written by one kernel and immediately re-read by the other.
+// Here the blended row never leaves the registers: the lane that holds labels 4*lg..4*lg+3 of the warped
+// voxel loads the same 16 bytes of `fixed` and accumulates sum t*p, sum t^2, sum p^2 (+ min/max) on the
+// spot -- 268 + 128 - 128 = 268 B/voxel of algorithmic traffic, no `warped` tensor unless asked for.
+//
+// The arithmetic of the warp is bit-identical to interpn.hip (same op sequence), the Dice reduction is
+// the same deterministic tree as dice.hip (lane registers -> wave xor-shuffles -> LDS -> per-block
+// partial -> two-level fixed-order second stage), so fused and unfused results agree to the last bit
+// in `warped` and to float32 reduction-order noise (<= 1e-6 relative) in the sums.
+//
+// Structure = interpn_tile (3-D output tiles, XCD-contiguous slabs, depth-2 software pipeline with
+// unconditional loads); the `fixed` row rides along as a ninth load of every pass.
+
+#include "dice_reduce.h"
+#include "interpn_core.h"
+
+namespace {
+
+template <int G, int MODE, bool STORE>
+__global__ __launch_bounds__(256) void warp_dice_tile(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
+                                                      float *__restrict__ fpart, float *__restrict__ mpart) {
+    constexpr int NG = 256 / G;
+    constexpr int L = 4 * G;
+    // persistent blocks: block (k = XCD, jb) walks the tiles jb, jb + nb, jb + 2 nb ... of XCD k's slab and
+    // writes ONE partial at the end (gridDim.x <= 2048 keeps the second stage short)
+    const unsigned per = tg.per2 * tg.nTz;                     // tiles per XCD
+    const unsigned k = blockIdx.x % NRT_NXCD, jb = blockIdx.x / NRT_NXCD, nb = gridDim.x / NRT_NXCD;
+
+    const int b = blockIdx.y;
+    const char *volb = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
+    const nrt_f4 *fix = (const nrt_f4 *)(fixed + (long long)b * a.out_bs);
+    const int lg = threadIdx.x % G;
+    const int g = threadIdx.x / G;
+    const int npass = (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
+    const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
+
+    nrt_f4 stp = {0, 0, 0, 0}, stt = {0, 0, 0, 0}, spp = {0, 0, 0, 0};
+    float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
+
+    for (unsigned j = jb; j < per; j += nb) {
+        unsigned t2l, tzi;
+        if (tg.z_outer) { tzi = j / tg.per2; t2l = j % tg.per2; }
+        else { tzi = j % tg.nTz; t2l = j / tg.nTz; }
+        const unsigned t2 = k * tg.per2 + t2l;
+        if (t2 >= tg.nT2) continue;
+        const int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi << tg.ltz;
+        auto voxel = [&](int pass, int (&qd)[NRT_MAXD], bool &valid) {
+            const int s = pass * NG + g;
+            const int x = x0 + (s >> (tg.ltz + tg.lty));
+            const int y = y0 + ((s >> tg.ltz) & ((1 << tg.lty) - 1));
+            const int z = z0 + (s & ((1 << tg.ltz) - 1));
+            valid = (x < a.O[0]) && (y < a.O[1]) && (z < a.O[2]);
+            qd[0] = min(x, a.O[0] - 1); qd[1] = min(y, a.O[1] - 1); qd[2] = min(z, a.O[2] - 1);
+        };
+        auto fetch_loc = [&](int pass, float (&p)[NRT_MAXD]) {
+            int qd[NRT_MAXD]; bool valid;
+            voxel(pass, qd, valid);
+            const unsigned q = ((unsigned)qd[0] * (unsigned)a.O[1] + (unsigned)qd[1]) * (unsigned)a.O[2] + (unsigned)qd[2];
+            if (MODE != NRT_LOC_LINSPACE) {
+                const float *lp = locb + (long long)q * 3;
+                p[0] = lp[0]; p[1] = lp[1]; p[2] = lp[2];
+            }
+        };
+        auto prepare = [&](int pass, const float (&praw)[NRT_MAXD], TileMeta &m, unsigned (&off)[8]) {
+            int qd[NRT_MAXD];
+            voxel(pass, qd, m.valid);
+            m.q = ((unsigned)qd[0] * (unsigned)a.O[1] + (unsigned)qd[1]) * (unsigned)a.O[2] + (unsigned)qd[2];
+            float p[NRT_MAXD];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (MODE == NRT_LOC_ABSOLUTE) p[d] = praw[d];
+                else if (MODE == NRT_LOC_SHIFT) p[d] = nrt_add((float)qd[d], praw[d]);
+                else p[d] = (qd[d] == 0) ? 0.0f
+                          : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
+            }
+            int i0[3], i1[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], m.w0[d], m.w1[d]);
+            m.oob = a.has_fill ? out_of_bounds<3>(a, p) : false;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const unsigned ix = (corner & 4) ? i1[0] : i0[0];
+                const unsigned iy = (corner & 2) ? i1[1] : i0[1];
+                const unsigned iz = (corner & 1) ? i1[2] : i0[2];
+                off[corner] = (((ix * SY + iy) * SZ + iz) * (unsigned)G + (unsigned)lg) * 16u;
+            }
+        };
+        auto load_rows = [&](const unsigned (&off)[8], unsigned q, nrt_f4 (&R)[8], nrt_f4 &T) {
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) R[corner] = *(const nrt_f4 *)(volb + (size_t)off[corner]);
+            T = __builtin_nontemporal_load(&fix[(long long)q * G + lg]);
+        };
+        auto finish = [&](const TileMeta &m, const nrt_f4 (&R)[8], const nrt_f4 &T) {
+            nrt_f4 acc = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const float wt = nrt_mul(nrt_mul((corner & 4) ? m.w1[0] : m.w0[0], (corner & 2) ? m.w1[1] : m.w0[1]),
+                                         (corner & 1) ? m.w1[2] : m.w0[2]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, R[corner][c]));
+            }
+            if (a.has_fill) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], m.oob, a.fill_f);
+            }
+            if (m.valid) {
+                if (STORE) __builtin_nontemporal_store(acc, &out[(long long)m.q * G + lg]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    stp[c] += T[c] * acc[c];
+                    stt[c] += T[c] * T[c];
+                    spp[c] += acc[c] * acc[c];
+                    mnt = fminf(mnt, T[c]); mxt = fmaxf(mxt, T[c]);
+                    mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
+                }
+            }
+        };
+
+        nrt_f4 Ra[8], Rb[8], Ta, Tb;
+        TileMeta Ma, Mb;
+        unsigned off[8];
+        float pn[NRT_MAXD] = {0.0f, 0.0f, 0.0f};
+        const int last = npass - 1;
+        fetch_loc(0, pn);
+        prepare(0, pn, Ma, off);
+        fetch_loc(min(1, last), pn);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(off, Ma.q, Ra, Ta);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int pass = 0; pass < npass; pass += 2) {
+            prepare(min(pass + 1, last), pn, Mb, off);
+            Mb.valid = Mb.valid && (pass + 1 < npass);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_loc(min(pass + 2, last), pn);
+            load_rows(off, Mb.q, Rb, Tb);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(Ma, Ra, Ta);
+            __builtin_amdgcn_sched_barrier(0);
+            prepare(min(pass + 2, last), pn, Ma, off);
+            Ma.valid = Ma.valid && (pass + 2 < npass);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_loc(min(pass + 3, last), pn);
+            load_rows(off, Ma.q, Ra, Ta);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(Mb, Rb, Tb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- block reduction (identical tree to dice_soft_vec) -------------------------------------
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        stp[c] = wave_xor_add(stp[c], G);
+        stt[c] = wave_xor_add(stt[c], G);
+        spp[c] = wave_xor_add(spp[c], G);
+    }
+    for (int off = 1; off < NRT_WAVE; off <<= 1) {
+        mnt = fminf(mnt, __shfl_xor(mnt, off, NRT_WAVE)); mxt = fmaxf(mxt, __shfl_xor(mxt, off, NRT_WAVE));
+        mnp = fminf(mnp, __shfl_xor(mnp, off, NRT_WAVE)); mxp = fmaxf(mxp, __shfl_xor(mxp, off, NRT_WAVE));
+    }
+    __shared__ float red[4][3 * L + 4];
+    const int lane = threadIdx.x & (NRT_WAVE - 1), wv = threadIdx.x / NRT_WAVE;
+    if (lane < G) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[wv][0 * L + 4 * lane + c] = stp[c];
+            red[wv][1 * L + 4 * lane + c] = stt[c];
+            red[wv][2 * L + 4 * lane + c] = spp[c];
+        }
+    }
+    if (lane == 0) { red[wv][3 * L + 0] = mnt; red[wv][3 * L + 1] = mxt; red[wv][3 * L + 2] = mnp; red[wv][3 * L + 3] = mxp; }
+    __syncthreads();
+    const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
+    for (int i = threadIdx.x; i < 3 * L; i += 256) {
+        float s = red[0][i];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) s += red[w2][i];
+        fpart[pbase * 3 * L + i] = s;
+    }
+    if (threadIdx.x < 4) {
+        float m = red[0][3 * L + threadIdx.x];
+        for (int w2 = 1; w2 < 4; ++w2)
+            m = (threadIdx.x & 1) ? fmaxf(m, red[w2][3 * L + threadIdx.x]) : fminf(m, red[w2][3 * L + threadIdx.x]);
+        mpart[pbase * 4 + threadIdx.x] = m;
+    }
+}
+
+// the fused kernel writes one partial per block: size the workspace for its grid
+size_t fused_ws_bytes(unsigned nblocks, int L, int batch) {
+    const size_t rows = (size_t)batch * nblocks;
+    const size_t grp = (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS);
+    return rows * 3 * L * sizeof(float) + rows * 4 * sizeof(float) + 16 + grp * 3 * L * sizeof(double) +
+           grp * 4 * sizeof(float) + 256;
+}
+
+void fused_geom(const int *out_shape, int G, int tune, TileGeom &tg, unsigned &nblocks) {
+    const int NG = 256 / G, WZ = 64 / G;
+    if (tune <= 0) tune = 3 | (3 << 4) | (4 << 8);             // 8 x 8 x 16 tiles (profiles/r01: fused sweep)
+    tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
+    while ((1 << tg.ltz) < WZ) ++tg.ltz;
+    while ((1 << (tg.ltx + tg.lty + tg.ltz)) < NG) ++tg.lty;
+    const unsigned nTx = (out_shape[0] + (1 << tg.ltx) - 1) >> tg.ltx;
+    tg.nTy = (out_shape[1] + (1 << tg.lty) - 1) >> tg.lty;
+    tg.nTz = (out_shape[2] + (1 << tg.ltz) - 1) >> tg.ltz;
+    tg.nT2 = nTx * tg.nTy;
+    tg.per2 = (tg.nT2 + NRT_NXCD - 1) / NRT_NXCD;
+    nblocks = NRT_NXCD * tg.per2 * tg.nTz;
+    if (nblocks > (unsigned)DICE_MAX_BLOCKS) nblocks = DICE_MAX_BLOCKS;      // multiple of 8; blocks loop over tiles
+}
+
+template <int G>
+void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store,
+                  const float *fixed, float *fpart, float *mpart, hipStream_t st) {
+    dim3 grid(nblocks, batch), blk(256);
+#define NRT_FUSED(MODE)                                                                                          \
+    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
+    else hipLaunchKernelGGL((warp_dice_tile<G, MODE, false>), grid, blk, 0, st, a, tg, fixed, fpart, mpart)
+    switch (mode) {
+        case NRT_LOC_ABSOLUTE: NRT_FUSED(NRT_LOC_ABSOLUTE); break;
+        case NRT_LOC_SHIFT: NRT_FUSED(NRT_LOC_SHIFT); break;
+        default: NRT_FUSED(NRT_LOC_LINSPACE); break;
+    }
+#undef NRT_FUSED
+}
+
+}  // namespace
+
+extern "C" size_t nrt_warp_dice_workspace_bytes(const int *out_shape, int nlabels, int batch, int tune) {
+    if (!out_shape || nlabels < 4 || nlabels % 4 || batch < 1) return 0;
+    TileGeom tg;
+    unsigned nblocks;
+    fused_geom(out_shape, nlabels / 4, tune, tg, nblocks);
+    return fused_ws_bytes(nblocks, nlabels, batch);
+}
+
+extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, const float *fixed, float *warped,
+                                      const int *vol_shape, const int *out_shape, int nlabels, int batch,
+                                      long long loc_batch_stride, int loc_mode, int has_fill, float fill_value,
+                                      float laplace_smoothing, float *sums, float *dice, float *minmax,
+                                      int tune, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!fixed || !sums || !dice) return NRT_ERR_INVALID_ARG;
+    if (nlabels % 4) return NRT_ERR_UNSUPPORTED;
+    const int G = nlabels / 4;
+    if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64)) return NRT_ERR_UNSUPPORTED;
+    InterpArgs a;
+    long long vol_bs = (long long)nlabels;
+    if (vol_shape) for (int d = 0; d < 3; ++d) vol_bs *= vol_shape[d];
+    float dummy;
+    int rc = fill_args(a, moving, loc, warped ? (void *)warped : (void *)&dummy, 3, vol_shape, out_shape, nlabels, batch,
+                       vol_bs, loc_batch_stride, loc_mode, has_fill);
+    if (rc != NRT_OK) return rc;
+    if (!warped) a.out = nullptr;
+    a.fill_f = fill_value;
+    if ((unsigned long long)vol_bs * 4ull >= (1ull << 32)) return NRT_ERR_UNSUPPORTED;
+    if ((((uintptr_t)moving | (uintptr_t)fixed | (uintptr_t)warped) & 15) != 0) return NRT_ERR_INVALID_ARG;
+    if (a.nout == 0) return NRT_ERR_INVALID_ARG;
+    TileGeom tg;
+    unsigned nblocks;
+    fused_geom(out_shape, G, tune, tg, nblocks);
+    if (!workspace || workspace_bytes < fused_ws_bytes(nblocks, nlabels, batch)) return NRT_ERR_WORKSPACE;
+    // carve: fpart, mpart, gsum, gmm
+    DiceWs w;
+    const size_t rows = (size_t)batch * nblocks;
+    char *p = (char *)workspace;
+    w.fpart = (float *)p; p += rows * 3 * nlabels * sizeof(float);
+    w.mpart = (float *)p; p += rows * 4 * sizeof(float);
+    p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+    w.gsum = (double *)p; p += (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS) * 3 * nlabels * sizeof(double);
+    w.gmm = (float *)p;
+    w.ipart = nullptr;
+    hipStream_t st = nrt_stream(stream);
+    const bool store = warped != nullptr;
+    switch (G) {
+        case 1: launch_fused<1>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 2: launch_fused<2>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 4: launch_fused<4>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 8: launch_fused<8>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 16: launch_fused<16>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 32: launch_fused<32>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        default: launch_fused<64>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+    }
+    NRT_CHECK_LAUNCH();
+    return dice_finalize_soft(w, nblocks, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
+}

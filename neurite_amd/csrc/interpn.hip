@@ -25,81 +25,9 @@
 // contraction), corners accumulated in itertools.product order (utils.py:159-191), so the linear
 // path is bit-identical to the CPU restatement, not merely within 1e-5.
 
-#include "nrt_common.h"
+#include "interpn_core.h"
 
 namespace {
-
-struct InterpArgs {
-    const void *vol;
-    const float *loc;
-    void *out;
-    int S[NRT_MAXD];       // source spatial shape (unused dims = 1)
-    int O[NRT_MAXD];       // output spatial shape
-    int C;
-    long long vol_bs, loc_bs, out_bs;   // batch strides in elements
-    float delta[NRT_MAXD]; // linspace step per dim: fl((S-1)/(O-1))
-    unsigned nout;         // prod(O)
-    int has_fill;
-    float fill_f;
-    int fill_i;
-};
-
-// ---- sampling location of output voxel q (coordinates qd) -------------------------------------
-template <int D, int MODE>
-__device__ __forceinline__ void load_loc(const InterpArgs &a, const float *locb, unsigned q,
-                                         const int (&qd)[NRT_MAXD], float (&p)[NRT_MAXD]) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if (MODE == NRT_LOC_ABSOLUTE) {
-            p[d] = locb[(long long)q * D + d];
-        } else if (MODE == NRT_LOC_SHIFT) {
-            // vxm transform(): cast(mesh, float32) + shift     (one rounding)
-            p[d] = nrt_add((float)qd[d], locb[(long long)q * D + d]);
-        } else {
-            // tf.linspace(0., S-1., O): first = 0, last = S-1 exactly, middle = 0 + delta*i
-            p[d] = (qd[d] == 0) ? 0.0f
-                 : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
-        }
-    }
-}
-
-template <int D>
-__device__ __forceinline__ void decode(const InterpArgs &a, unsigned q, int (&qd)[NRT_MAXD]) {
-    unsigned r = q;
-#pragma unroll
-    for (int d = D - 1; d > 0; --d) { qd[d] = (int)(r % (unsigned)a.O[d]); r /= (unsigned)a.O[d]; }
-    qd[0] = (int)r;
-}
-
-// utils.py:139-153 for one dimension
-__device__ __forceinline__ void corner_1d(float p, int size, int &i0, int &i1, float &w0, float &w1) {
-    const float mx = (float)(size - 1);
-    const float f = floorf(p);                       // :139
-    const float cl = nrt_clip(p, 0.0f, mx);          // :142
-    const float l0 = nrt_clip(f, 0.0f, mx);          // :143
-    const float l1 = nrt_clip(nrt_add(l0, 1.0f), 0.0f, mx);   // :146
-    i0 = (int)l0; i1 = (int)l1;                      // :147
-    w0 = nrt_sub(l1, cl);                            // :152  weight of the lower corner
-    w1 = nrt_sub(1.0f, w0);                          // :153  weight of the upper corner
-}
-
-__device__ __forceinline__ int nearest_1d(float p, int size) {
-    // :196-197  int32(round_half_even(p)) clipped to [0, size-1]; v_cvt_i32_f32 saturates, NaN -> 0
-    return nrt_clampi((int)rintf(p), 0, size - 1);
-}
-
-template <int D>
-__device__ __forceinline__ bool out_of_bounds(const InterpArgs &a, const float (&p)[NRT_MAXD]) {
-    bool oob = false;                                // :209-211 (unclipped location)
-#pragma unroll
-    for (int d = 0; d < D; ++d) oob = oob || (p[d] < 0.0f) || (p[d] > (float)(a.S[d] - 1));
-    return oob;
-}
-
-__device__ __forceinline__ float apply_fill(float v, bool oob, float fill) {
-    // :212-213   v * float(!oob) + float(oob) * fill   (NaN/Inf propagate exactly as in the reference)
-    return nrt_add(nrt_mul(v, oob ? 0.0f : 1.0f), nrt_mul(oob ? 1.0f : 0.0f, fill));
-}
 
 // ============================================================================================
 // generic: one thread per output element
@@ -341,24 +269,35 @@ __device__ __forceinline__ bool zrun_step(const InterpArgs &a, const char *__res
     return !has_next;
 }
 
-template <int MODE, int MINW>
-__global__ __launch_bounds__(256, MINW) void interpn_zrun_c32(InterpArgs a, int LZ, unsigned nTy, unsigned nZc, unsigned nblk) {
-    const unsigned lb = nrt_xcd_block(blockIdx.x, gridDim.x);
-    if (lb >= nblk) return;
+// Block = WX x WY waves, each wave a 2(x) x 4(y) patch of lane-groups: output patch (2 WX) x (4 WY) columns.
+// Bigger patches shrink the halo that every block re-fetches beyond L2 (measured, profiles/: with the
+// 4x8 patch FETCH_SIZE was 1.6x the algorithmic bytes = exactly the (5*9)/(4*8) halo of unshared blocks).
+// zc_outer: order of the blocks inside one XCD's slab -- 0: z-chunks of one patch are consecutive;
+// 1: neighbouring patches of one z-chunk are consecutive, so blocks resident together are x/y
+// neighbours marching through z in step and meet their shared halo rows in L2.
+template <int MODE, int WX, int WY>
+__global__ __launch_bounds__(WX * WY * 64) void interpn_zrun_c32(InterpArgs a, int LZ, unsigned nTy, unsigned nZc,
+                                                                 unsigned nblk, int zc_outer) {
+    const unsigned per = gridDim.x / NRT_NXCD;
+    const unsigned kx = blockIdx.x % NRT_NXCD, jx = blockIdx.x / NRT_NXCD;
+    const unsigned nT2 = nblk / nZc;                        // (x,y) patches
+    const unsigned per2 = per / nZc;                        // patches owned by one XCD
+    unsigned t, zc;
+    if (zc_outer) { zc = jx / per2; t = kx * per2 + jx % per2; }
+    else { zc = jx % nZc; t = kx * per2 + jx / nZc; }
+    if (t >= nT2) return;
     const int b = blockIdx.y;
     const char *vol = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
     const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
     nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
 
-    const unsigned zc = lb % nZc;
-    const unsigned t = lb / nZc;
     const unsigned ty = t % nTy, tx = t / nTy;
     const int lane = threadIdx.x & 63;
     const int lg = lane & 7;                 // 16-byte slice of the 128-byte row
     const int j = lane >> 3;                 // group within the wave: 2(x) x 4(y)
-    const int w = threadIdx.x >> 6;          // wave within the block: 2(x) x 2(y)
-    const int x = (int)tx * 4 + (w >> 1) * 2 + (j >> 2);
-    const int y = (int)ty * 8 + (w & 1) * 4 + (j & 3);
+    const int w = threadIdx.x >> 6;          // wave within the block: WX(x) x WY(y)
+    const int x = (int)tx * (2 * WX) + (w / WY) * 2 + (j >> 2);
+    const int y = (int)ty * (4 * WY) + (w % WY) * 4 + (j & 3);
     if (x >= a.O[0] || y >= a.O[1]) return;  // whole lane-groups leave together; no block barrier below
     const int zbeg = (int)zc * LZ;
     const int zend = min(zbeg + LZ, a.O[2]);
@@ -423,20 +362,6 @@ __global__ __launch_bounds__(256, MINW) void interpn_zrun_c32(InterpArgs a, int 
 //    is blended; every load is unconditional (edge voxels clamp their address, only the store is
 //    predicated) so the compiler's vmcnt counts stay exact and nothing drains the queue.
 // ============================================================================================
-struct TileGeom {
-    int ltx, lty, ltz;          // log2 of the tile extent
-    unsigned nTy, nTz;          // tiles along y and z
-    unsigned nT2;               // tiles in the (x,y) plane = nTx * nTy
-    unsigned per2;              // (x,y) tiles owned by one XCD = ceil(nT2 / 8)
-    int z_outer;                // order inside an XCD's slab: 0 = z fastest, 1 = z outermost
-};
-
-struct TileMeta {
-    float w0[3], w1[3];
-    unsigned q;
-    bool oob, valid;
-};
-
 template <int G, int MODE>
 __global__ __launch_bounds__(256) void interpn_tile(InterpArgs a, TileGeom tg) {
     constexpr int NG = 256 / G;
@@ -563,33 +488,6 @@ __global__ __launch_bounds__(256) void interpn_tile(InterpArgs a, TileGeom tg) {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-int fill_args(InterpArgs &a, const void *vol, const float *loc, void *out, int ndim, const int *vol_shape,
-              const int *out_shape, int channels, int batch, long long vol_bs, long long loc_bs, int loc_mode,
-              int has_fill) {
-    if (!vol || !out || !vol_shape || !out_shape) return NRT_ERR_INVALID_ARG;
-    if (ndim < 1 || ndim > NRT_MAXD || channels < 1 || batch < 1) return NRT_ERR_INVALID_ARG;
-    if (loc_mode < 0 || loc_mode > 2) return NRT_ERR_INVALID_ARG;
-    if (loc_mode != NRT_LOC_LINSPACE && !loc) return NRT_ERR_INVALID_ARG;
-    if (batch > 65535) return NRT_ERR_UNSUPPORTED;
-    a.vol = vol; a.loc = loc; a.out = out; a.C = channels;
-    unsigned long long nin = 1, nout = 1;
-    for (int d = 0; d < NRT_MAXD; ++d) {
-        a.S[d] = d < ndim ? vol_shape[d] : 1;
-        a.O[d] = d < ndim ? out_shape[d] : 1;
-        if (a.S[d] < 1 || a.O[d] < 0) return NRT_ERR_INVALID_ARG;
-        nin *= (unsigned long long)a.S[d];
-        nout *= (unsigned long long)a.O[d];
-        // tf.linspace: delta = (stop - start) / (num - 1) in float32
-        a.delta[d] = a.O[d] > 1 ? (float)(a.S[d] - 1) / (float)(a.O[d] - 1) : 0.0f;
-    }
-    if (nin * (unsigned long long)channels >= (1ull << 40) || nout >= (1ull << 31)) return NRT_ERR_UNSUPPORTED;
-    a.nout = (unsigned)nout;
-    a.vol_bs = vol_bs; a.loc_bs = loc_bs; a.out_bs = (long long)nout * channels;
-    a.has_fill = has_fill ? 1 : 0;
-    a.fill_f = 0.0f; a.fill_i = 0;
-    return NRT_OK;
-}
-
 template <int MODE, int METHOD, typename T>
 void launch_generic_d(const InterpArgs &a, int ndim, int batch, hipStream_t st) {
     const unsigned long long total = (unsigned long long)a.nout * (unsigned)a.C;
@@ -652,28 +550,35 @@ void launch_rows_any(const InterpArgs &a, int batch, int mode, int method, int t
     }
 }
 
-template <int MINW>
-void launch_zrun_w(const InterpArgs &a, int batch, int mode, int LZ, hipStream_t st) {
-    const unsigned nTx = (a.O[0] + 3) / 4, nTy = (a.O[1] + 7) / 8, nZc = (a.O[2] + LZ - 1) / LZ;
+template <int WX, int WY>
+void launch_zrun_w(const InterpArgs &a, int batch, int mode, int LZ, int zc_outer, hipStream_t st) {
+    const unsigned nTx = (a.O[0] + 2 * WX - 1) / (2 * WX), nTy = (a.O[1] + 4 * WY - 1) / (4 * WY);
+    const unsigned nZc = (a.O[2] + LZ - 1) / LZ;
+    const unsigned per2 = (nTx * nTy + NRT_NXCD - 1) / NRT_NXCD;       // patches per XCD
     const unsigned nblk = nTx * nTy * nZc;
-    dim3 grid(nrt_xcd_grid(nblk), batch);
+    dim3 grid(NRT_NXCD * per2 * nZc, batch), blk(WX * WY * 64);
     switch (mode) {
         case NRT_LOC_ABSOLUTE:
-            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_ABSOLUTE, MINW>), grid, dim3(256), 0, st, a, LZ, nTy, nZc, nblk); break;
+            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_ABSOLUTE, WX, WY>), grid, blk, 0, st, a, LZ, nTy, nZc, nblk, zc_outer); break;
         case NRT_LOC_SHIFT:
-            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_SHIFT, MINW>), grid, dim3(256), 0, st, a, LZ, nTy, nZc, nblk); break;
+            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_SHIFT, WX, WY>), grid, blk, 0, st, a, LZ, nTy, nZc, nblk, zc_outer); break;
         default:
-            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_LINSPACE, MINW>), grid, dim3(256), 0, st, a, LZ, nTy, nZc, nblk); break;
+            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_LINSPACE, WX, WY>), grid, blk, 0, st, a, LZ, nTy, nZc, nblk, zc_outer); break;
     }
 }
 
-// variant 3: register budget <= 128 VGPR (4 waves/SIMD); variant 4: <= 96 (5 waves/SIMD)
+// tune = LZ | zc_outer << 12 | patch << 16   (patch 0: 4x8, 1: 8x8, 2: 8x16, 3: 4x16 columns)
 void launch_zrun(const InterpArgs &a, int batch, int mode, int variant, int tune, hipStream_t st) {
-    int LZ = tune > 0 ? tune : a.O[2];
-    if (LZ > a.O[2]) LZ = a.O[2];
-    if (LZ < 1) LZ = 1;
-    if (variant == 4) launch_zrun_w<5>(a, batch, mode, LZ, st);
-    else launch_zrun_w<4>(a, batch, mode, LZ, st);
+    (void)variant;
+    int LZ = tune & 0xfff;
+    const int zc_outer = (tune >> 12) & 1, patch = (tune >> 16) & 3;
+    if (LZ <= 0 || LZ > a.O[2]) LZ = a.O[2];
+    switch (patch) {
+        case 1: launch_zrun_w<4, 2>(a, batch, mode, LZ, zc_outer, st); break;
+        case 2: launch_zrun_w<4, 4>(a, batch, mode, LZ, zc_outer, st); break;
+        case 3: launch_zrun_w<2, 4>(a, batch, mode, LZ, zc_outer, st); break;
+        default: launch_zrun_w<2, 2>(a, batch, mode, LZ, zc_outer, st); break;
+    }
 }
 
 template <int G>
@@ -715,7 +620,7 @@ void launch_tile_any(const InterpArgs &a, int batch, int mode, int tune, hipStre
 
 // Default kernel choice, set from measurements on MI355X (profiles/): see DESIGN.md.
 static int g_auto_c32_variant = 3;
-static int g_auto_c32_tune = 40;
+static int g_auto_c32_tune = 20 | (1 << 16);     // z-run, 8x8 patch, z-chunks of 20 (profiles/r01: sweeps)
 
 extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out, int ndim, const int *vol_shape,
                                   const int *out_shape, int channels, int batch, long long vol_batch_stride,

@@ -1,0 +1,122 @@
+// Shared device/host pieces of the interpn kernels (interpn.hip, fused.hip): argument block, sampling
+// location, the per-dimension corner arithmetic of neurite/tf/utils/utils.py:139-153, fill, tile geometry.
+#pragma once
+
+#include "nrt_common.h"
+
+namespace {
+
+struct InterpArgs {
+    const void *vol;
+    const float *loc;
+    void *out;
+    int S[NRT_MAXD];       // source spatial shape (unused dims = 1)
+    int O[NRT_MAXD];       // output spatial shape
+    int C;
+    long long vol_bs, loc_bs, out_bs;   // batch strides in elements
+    float delta[NRT_MAXD]; // linspace step per dim: fl((S-1)/(O-1))
+    unsigned nout;         // prod(O)
+    int has_fill;
+    float fill_f;
+    int fill_i;
+};
+
+// ---- sampling location of output voxel q (coordinates qd) -------------------------------------
+template <int D, int MODE>
+__device__ __forceinline__ void load_loc(const InterpArgs &a, const float *locb, unsigned q,
+                                         const int (&qd)[NRT_MAXD], float (&p)[NRT_MAXD]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (MODE == NRT_LOC_ABSOLUTE) {
+            p[d] = locb[(long long)q * D + d];
+        } else if (MODE == NRT_LOC_SHIFT) {
+            // vxm transform(): cast(mesh, float32) + shift     (one rounding)
+            p[d] = nrt_add((float)qd[d], locb[(long long)q * D + d]);
+        } else {
+            // tf.linspace(0., S-1., O): first = 0, last = S-1 exactly, middle = 0 + delta*i
+            p[d] = (qd[d] == 0) ? 0.0f
+                 : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
+        }
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void decode(const InterpArgs &a, unsigned q, int (&qd)[NRT_MAXD]) {
+    unsigned r = q;
+#pragma unroll
+    for (int d = D - 1; d > 0; --d) { qd[d] = (int)(r % (unsigned)a.O[d]); r /= (unsigned)a.O[d]; }
+    qd[0] = (int)r;
+}
+
+// utils.py:139-153 for one dimension
+__device__ __forceinline__ void corner_1d(float p, int size, int &i0, int &i1, float &w0, float &w1) {
+    const float mx = (float)(size - 1);
+    const float f = floorf(p);                       // :139
+    const float cl = nrt_clip(p, 0.0f, mx);          // :142
+    const float l0 = nrt_clip(f, 0.0f, mx);          // :143
+    const float l1 = nrt_clip(nrt_add(l0, 1.0f), 0.0f, mx);   // :146
+    i0 = (int)l0; i1 = (int)l1;                      // :147
+    w0 = nrt_sub(l1, cl);                            // :152  weight of the lower corner
+    w1 = nrt_sub(1.0f, w0);                          // :153  weight of the upper corner
+}
+
+__device__ __forceinline__ int nearest_1d(float p, int size) {
+    // :196-197  int32(round_half_even(p)) clipped to [0, size-1]; v_cvt_i32_f32 saturates, NaN -> 0
+    return nrt_clampi((int)rintf(p), 0, size - 1);
+}
+
+template <int D>
+__device__ __forceinline__ bool out_of_bounds(const InterpArgs &a, const float (&p)[NRT_MAXD]) {
+    bool oob = false;                                // :209-211 (unclipped location)
+#pragma unroll
+    for (int d = 0; d < D; ++d) oob = oob || (p[d] < 0.0f) || (p[d] > (float)(a.S[d] - 1));
+    return oob;
+}
+
+__device__ __forceinline__ float apply_fill(float v, bool oob, float fill) {
+    // :212-213   v * float(!oob) + float(oob) * fill   (NaN/Inf propagate exactly as in the reference)
+    return nrt_add(nrt_mul(v, oob ? 0.0f : 1.0f), nrt_mul(oob ? 1.0f : 0.0f, fill));
+}
+
+struct TileGeom {
+    int ltx, lty, ltz;          // log2 of the tile extent
+    unsigned nTy, nTz;          // tiles along y and z
+    unsigned nT2;               // tiles in the (x,y) plane = nTx * nTy
+    unsigned per2;              // (x,y) tiles owned by one XCD = ceil(nT2 / 8)
+    int z_outer;                // order inside an XCD's slab: 0 = z fastest, 1 = z outermost
+};
+
+struct TileMeta {
+    float w0[3], w1[3];
+    unsigned q;
+    bool oob, valid;
+};
+
+inline int fill_args(InterpArgs &a, const void *vol, const float *loc, void *out, int ndim, const int *vol_shape,
+              const int *out_shape, int channels, int batch, long long vol_bs, long long loc_bs, int loc_mode,
+              int has_fill) {
+    if (!vol || !out || !vol_shape || !out_shape) return NRT_ERR_INVALID_ARG;
+    if (ndim < 1 || ndim > NRT_MAXD || channels < 1 || batch < 1) return NRT_ERR_INVALID_ARG;
+    if (loc_mode < 0 || loc_mode > 2) return NRT_ERR_INVALID_ARG;
+    if (loc_mode != NRT_LOC_LINSPACE && !loc) return NRT_ERR_INVALID_ARG;
+    if (batch > 65535) return NRT_ERR_UNSUPPORTED;
+    a.vol = vol; a.loc = loc; a.out = out; a.C = channels;
+    unsigned long long nin = 1, nout = 1;
+    for (int d = 0; d < NRT_MAXD; ++d) {
+        a.S[d] = d < ndim ? vol_shape[d] : 1;
+        a.O[d] = d < ndim ? out_shape[d] : 1;
+        if (a.S[d] < 1 || a.O[d] < 0) return NRT_ERR_INVALID_ARG;
+        nin *= (unsigned long long)a.S[d];
+        nout *= (unsigned long long)a.O[d];
+        // tf.linspace: delta = (stop - start) / (num - 1) in float32
+        a.delta[d] = a.O[d] > 1 ? (float)(a.S[d] - 1) / (float)(a.O[d] - 1) : 0.0f;
+    }
+    if (nin * (unsigned long long)channels >= (1ull << 40) || nout >= (1ull << 31)) return NRT_ERR_UNSUPPORTED;
+    a.nout = (unsigned)nout;
+    a.vol_bs = vol_bs; a.loc_bs = loc_bs; a.out_bs = (long long)nout * channels;
+    a.has_fill = has_fill ? 1 : 0;
+    a.fill_f = 0.0f; a.fill_i = 0;
+    return NRT_OK;
+}
+
+}  // namespace

@@ -1,0 +1,83 @@
+"""
+neurite_amd.fused -- SpatialTransformer + soft Dice in one pass over HBM.
+
+    d = ne.fused.warp_dice(moving, trf, fixed)                # [B, L]
+is numerically the pipeline
+    warped = ne.layers.SpatialTransformer()([moving, trf]);  d = ne.metrics.Dice(check_input_limits=False).dice(fixed, warped)
+(neurite/tf/models.py:806-807 + neurite/tf/metrics.py:415-482) but never writes `warped`: the blended row is
+consumed in registers (csrc/fused.hip).  This is the Dice-of-a-warped-segmentation loss/metric of
+VoxelMorph-style training; the reference has no fused form (TensorFlow materialises every intermediate).
+"""
+
+import torch
+
+from . import _lib
+from . import utils
+from .errors import InvalidArgumentError
+
+__all__ = ['warp_dice']
+
+
+def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_value=None, laplace_smoothing=0.,
+              check_input_limits=False, return_warped=False, return_sums=False, _tune=0):
+    """
+    moving [B, X, Y, Z, L], trf [B, X', Y', Z', 3] (voxel displacements), fixed [B, X', Y', Z', L]; float32, 3-D,
+    L in {4, 8, 16, 32, 64, 128, 256}.  Linear interpolation.  Returns dice [B, L] (optionally also the warped
+    volume and the partial sums [B, 3, L]).  check_input_limits defaults to False because a tri-linearly
+    warped one-hot map exceeds 1.0 by an ulp (see tests); pass True for the reference's asserts.
+    """
+    lib = _lib.lib()
+    dev = _lib.require_device(moving, trf, fixed)
+    if moving.dim() != 5 or fixed.dim() != 5 or trf.dim() != 5 or trf.shape[-1] != 3:
+        raise Exception('warp_dice expects 3-D volumes [B, X, Y, Z, L] and a displacement field [B, X, Y, Z, 3]')
+    if indexing not in ('ij', 'xy'):
+        raise ValueError("indexing has to be 'ij' (matrix) or 'xy' (cartesian)")
+    for name, t in (('moving', moving), ('fixed', fixed)):
+        if t.dtype != torch.float32:
+            raise NotImplementedError('%s: warp_dice takes float32 maps, got %s' % (name, t.dtype))
+    B, L = moving.shape[0], moving.shape[-1]
+    if L % 4 or (L // 4) not in (1, 2, 4, 8, 16, 32, 64):
+        raise NotImplementedError('warp_dice: nb_labels must be 4 * 2^k, got %d (use the unfused layers)' % L)
+    if fixed.shape[0] != B or fixed.shape[-1] != L or tuple(fixed.shape[1:-1]) != tuple(trf.shape[1:-1]):
+        raise ValueError('fixed must be [B, *trf_spatial, L]')
+    if not single_transform and trf.shape[0] != B:
+        raise ValueError('batch size of the transform does not match the volume')
+    mov = moving.contiguous()
+    fix = fixed.contiguous()
+    shift = trf.to(torch.float32)
+    if indexing == 'xy':
+        shift = torch.cat([shift[..., 1:2], shift[..., 0:1], shift[..., 2:]], -1)
+    shift = (shift[:1] if single_transform else shift).contiguous()
+    S = list(mov.shape[1:-1])
+    O = list(fix.shape[1:-1])
+    sums = torch.empty((B, 3, L), dtype=torch.float32, device=dev)
+    dice = torch.empty((B, L), dtype=torch.float32, device=dev)
+    minmax = torch.empty((4,), dtype=torch.float32, device=dev)
+    warped = torch.empty_like(fix) if return_warped else None
+    o_shape = _lib.ints(O)
+    nws = lib.nrt_warp_dice_workspace_bytes(o_shape, L, B, int(_tune))
+    ws = _lib.workspace(dev, nws)
+    has_fill = fill_value is not None
+
+    def run():
+        with torch.cuda.device(dev):
+            rc = lib.nrt_warp_dice_soft_f32(_lib.ptr(mov), _lib.ptr(shift), _lib.ptr(fix), _lib.ptr(warped),
+                                            _lib.ints(S), o_shape, L, B,
+                                            0 if single_transform else shift[0].numel(), _lib.LOC_SHIFT,
+                                            int(has_fill), float(fill_value) if has_fill else 0.0,
+                                            float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice), _lib.ptr(minmax),
+                                            int(_tune), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_warp_dice_soft_f32')
+        if check_input_limits:
+            mn_t, mx_t, mn_p, mx_p = [float(v) for v in minmax.tolist()]
+            if not (mn_t >= 0. and mn_p >= 0. and mx_t <= 1. and mx_p <= 1.):
+                raise InvalidArgumentError('value outside range')
+        return dice
+
+    d = utils._maybe_tracked(run, moving, trf, fixed)
+    out = (d,)
+    if return_warped:
+        out += (warped,)
+    if return_sums:
+        out += (sums,)
+    return out[0] if len(out) == 1 else out

@@ -290,7 +290,7 @@ def spatial_transformer(vol, trf, interp_method='linear', indexing='ij', single_
     outs = []
     for b in range(vol.shape[0]):
         t = trf[0] if single_transform else trf[b]
-        if t.ndim == 2:    # affine
+        if t.ndim == 2 and t.shape[-1] == D + 1 and t.shape[0] in (D, D + 1):    # affine (a dense 1-D flow [X, 1] is also 2-D)
             t = affine_to_dense_shift(t, vol.shape[1:-1], shift_center=shift_center, indexing=indexing)
         elif indexing == 'xy':
             # voxelmorph swaps the first two displacement components for 'xy' flows

@@ -168,6 +168,39 @@ def test_full_size_dice_cfg2(dev):
     np.testing.assert_allclose(float(m), float(D.mean_dice(fix, warped)), rtol=1e-6)
 
 
+def test_fused_warp_dice(dev):
+    """Fused SpatialTransformer+Dice == the two-kernel pipeline: warped bit-identical, Dice to 1e-6."""
+    rng = np.random.default_rng(5)
+    for (B, S, So, L) in ((2, (19, 14, 27), (19, 14, 27), 32), (1, (9, 8, 12), (7, 11, 5), 8), (2, (12, 12, 12), (12, 12, 12), 4),
+                          (1, (10, 9, 17), (10, 9, 17), 64)):
+        mov = rng.random((B,) + S + (L,)).astype(F)
+        fix = rng.random((B,) + So + (L,)).astype(F)
+        trf = rng.normal(0, 2.5, (B,) + So + (3,)).astype(F)
+        for fill in (None, 0.0):
+            for tune in (0, 1 | (1 << 4) | (3 << 8), 3 | (3 << 4) | (3 << 8) | (1 << 12)):
+                d, w, s = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, return_warped=True,
+                                             return_sums=True, laplace_smoothing=0.25, _tune=tune)
+                w_ref = npo.spatial_transformer(mov, trf, fill_value=fill)
+                assert bits_equal(N(w), w_ref), (S, L, fill, tune)
+                np.testing.assert_allclose(N(s), np.stack(npo.dice_sums(fix, w_ref), 1), rtol=RTOL)
+                np.testing.assert_allclose(N(d), npo.dice(fix, w_ref, laplace_smoothing=0.25, check_input_limits=False), rtol=RTOL)
+                d2 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, laplace_smoothing=0.25, _tune=tune)
+                assert bits_equal(N(d2), N(d))                      # with / without writing `warped`
+    # full size, against the unfused HIP pipeline and the C oracle
+    mov, fix, trf = synth.cfg2_batch(2, 160, 32, device=dev, seed0=1)
+    d, w = ne.fused.warp_dice(mov, trf, fix, return_warped=True)
+    w2 = ne.layers.SpatialTransformer()([mov, trf])
+    assert torch.equal(w, w2)
+    d2 = ne.metrics.Dice(check_input_limits=False).dice(fix, w2)
+    np.testing.assert_allclose(N(d), N(d2), rtol=1e-6)
+    sums, _ = co.dice_sums(N(fix), N(w2))
+    np.testing.assert_allclose(N(d), co.dice_from_sums(sums), rtol=RTOL)
+    with pytest.raises(ne.errors.InvalidArgumentError):
+        ne.fused.warp_dice(mov, trf, fix, check_input_limits=True)
+    with pytest.raises(NotImplementedError):
+        ne.fused.warp_dice(mov[..., :5], trf, fix[..., :5])
+
+
 # ------------------------------------------------------------------------------------------- CCE
 def test_cce_golden(dev):
     g = load_golden('cce_small')

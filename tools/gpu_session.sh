@@ -45,15 +45,18 @@ bench)
   stage bench
   timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.log"; echo "bench rc=$?" | tee -a "$OUT/session.log"
   cat "$OUT/bench.json" | tee -a "$OUT/session.log"
+  timeout 600 python bench.py --unfused --no-cpu-baseline > "$OUT/bench_unfused.json" 2>> "$OUT/bench.log"
   timeout 600 python bench.py --batch-per-gpu 1 --no-cpu-baseline > "$OUT/bench_b1.json" 2>> "$OUT/bench.log"
   timeout 600 python bench.py --rough --no-cpu-baseline > "$OUT/bench_rough.json" 2>> "$OUT/bench.log"
-  cat "$OUT/bench_b1.json" "$OUT/bench_rough.json" | tee -a "$OUT/session.log"
+  cat "$OUT/bench_unfused.json" "$OUT/bench_b1.json" "$OUT/bench_rough.json" | tee -a "$OUT/session.log"
   ;;
 prof)
   stage prof
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- \
       python "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_bench.json" 2> "$OUT/prof.log" )
   echo "prof rc=$?" | tee -a "$OUT/session.log"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_unfused" -o bench -- \
+      python "$ROOT/bench.py" --unfused --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_bench_unfused.json" 2>> "$OUT/prof.log" )
   find "$OUT/prof" -name "*kernel_stats.csv" | head -3 | while read f; do echo "$f"; head -12 "$f"; done | tee -a "$OUT/session.log"
   ;;
 pmcsweep)
