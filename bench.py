@@ -149,7 +149,12 @@ def sweep(args, dev, mov, fix, trf):
     log(json.dumps(r))
     res.append(r)
     # fused SpatialTransformer+Dice, tile shapes
-    for tune in (0, T(2, 2, 4, 1), T(2, 3, 4, 0), T(3, 3, 3, 0), T(3, 3, 3, 1), T(2, 2, 5, 0), T(1, 1, 5, 0), T(3, 3, 4, 0)):
+    def PM(lz, zo):
+        return (1 << 13) | (zo << 12) | (lz << 16)
+    ftunes = (0, T(3, 3, 3, 0), T(3, 3, 4, 0), PM(10, 0), PM(20, 0), PM(40, 0), PM(160, 0), PM(20, 1), PM(40, 1))
+    if os.environ.get('NRT_FUSED_SWEEP'):
+        ftunes = tuple(int(v) for v in os.environ['NRT_FUSED_SWEEP'].split(','))
+    for tune in ftunes:
         for _ in range(2):
             d = ne.fused.warp_dice(mov, trf, fix, _tune=tune)
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -159,7 +164,9 @@ def sweep(args, dev, mov, fix, trf):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        r = {'kernel': 'fused_warp_dice', 'tune': tune, 'tile': [1 << (tune & 15), 1 << ((tune >> 4) & 15), 1 << ((tune >> 8) & 15), (tune >> 12) & 1],
+        r = {'kernel': 'fused_warp_dice', 'tune': tune,
+             'tile': (['plane-major 4x8', 'LZ', tune >> 16, (tune >> 12) & 1] if (tune >> 13) & 1 else
+                      [1 << (tune & 15), 1 << ((tune >> 4) & 15), 1 << ((tune >> 8) & 15), (tune >> 12) & 1]),
              'ms': round(ms, 4), 'Mvox_s': round(V * B / ms / 1e3, 1),
              'GBs_524': round((INTERPN_BYTES_PER_VOXEL(args.labels, 3) + DICE_BYTES_PER_VOXEL(args.labels)) * V * B / ms / 1e6, 1),
              'max_abs_diff_vs_unfused': float((d - D.dice(fix, warped)).abs().max())}

@@ -73,8 +73,20 @@ __global__ __launch_bounds__(256) void reduce_rows(const TIN *__restrict__ in, i
         const int S = 256 / cols;
         const int i = threadIdx.x % cols, sidx = threadIdx.x / cols;
         TACC acc = 0;
-        if (sidx < S)
-            for (int k = r0 + sidx; k < r1; k += S) acc += (TACC)in[((long long)b * rows + k) * ncol + c0 + i];
+        if (sidx < S) {
+            // 8 independent loads in flight per thread, then a fixed-order add (a dependent load-add chain
+            // cost ~0.6 us per row here: the partials sit in another XCD's L2)
+            for (int k = r0 + sidx; k < r1; k += 8 * S) {
+                TIN v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = k + u * S;
+                    v[u] = kk < r1 ? in[((long long)b * rows + kk) * ncol + c0 + i] : (TIN)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (TACC)v[u];
+            }
+        }
         sl[threadIdx.x] = acc;
         __syncthreads();
         if (threadIdx.x < cols) {
@@ -104,7 +116,13 @@ __global__ __launch_bounds__(256) void dice_soft_finalize(const double *__restri
     const int ncol = 3 * L;
     for (int i = threadIdx.x; i < ncol; i += blockDim.x) {
         double tot = 0.0;
-        for (int g = 0; g < ngrp; ++g) tot += gsum[((long long)b * ngrp + g) * ncol + i];
+        for (int g = 0; g < ngrp; g += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (g + u < ngrp) ? gsum[((long long)b * ngrp + g + u) * ncol + i] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tot += v[u];
+        }
         const float f = (float)tot;
         fs[i] = f;
         sums[(long long)b * ncol + i] = f;

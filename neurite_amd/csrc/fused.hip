@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void warp_dice_tile(InterpArgs a, TileGeom tg,
     const nrt_f4 *fix = (const nrt_f4 *)(fixed + (long long)b * a.out_bs);
     const int lg = threadIdx.x % G;
     const int g = threadIdx.x / G;
-    const int npass = (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
+    const int npass = tg.plane_major ? tg.tz : (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
     const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
 
     nrt_f4 stp = {0, 0, 0, 0}, stt = {0, 0, 0, 0}, spp = {0, 0, 0, 0};
@@ -49,12 +49,10 @@ __global__ __launch_bounds__(256) void warp_dice_tile(InterpArgs a, TileGeom tg,
         else { tzi = j % tg.nTz; t2l = j / tg.nTz; }
         const unsigned t2 = k * tg.per2 + t2l;
         if (t2 >= tg.nT2) continue;
-        const int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi << tg.ltz;
+        const int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi * tg.tz;
         auto voxel = [&](int pass, int (&qd)[NRT_MAXD], bool &valid) {
-            const int s = pass * NG + g;
-            const int x = x0 + (s >> (tg.ltz + tg.lty));
-            const int y = y0 + ((s >> tg.ltz) & ((1 << tg.lty) - 1));
-            const int z = z0 + (s & ((1 << tg.ltz) - 1));
+            int x, y, z;
+            tile_voxel(tg, NG, pass, g, x0, y0, z0, x, y, z);
             valid = (x < a.O[0]) && (y < a.O[1]) && (z < a.O[2]);
             qd[0] = min(x, a.O[0] - 1); qd[1] = min(y, a.O[1] - 1); qd[2] = min(z, a.O[2] - 1);
         };
@@ -200,18 +198,8 @@ size_t fused_ws_bytes(unsigned nblocks, int L, int batch) {
 }
 
 void fused_geom(const int *out_shape, int G, int tune, TileGeom &tg, unsigned &nblocks) {
-    const int NG = 256 / G, WZ = 64 / G;
-    if (tune <= 0) tune = 3 | (3 << 4) | (4 << 8);             // 8 x 8 x 16 tiles (profiles/r01: fused sweep)
-    tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
-    while ((1 << tg.ltz) < WZ) ++tg.ltz;
-    while ((1 << (tg.ltx + tg.lty + tg.ltz)) < NG) ++tg.lty;
-    const unsigned nTx = (out_shape[0] + (1 << tg.ltx) - 1) >> tg.ltx;
-    tg.nTy = (out_shape[1] + (1 << tg.lty) - 1) >> tg.lty;
-    tg.nTz = (out_shape[2] + (1 << tg.ltz) - 1) >> tg.ltz;
-    tg.nT2 = nTx * tg.nTy;
-    tg.per2 = (tg.nT2 + NRT_NXCD - 1) / NRT_NXCD;
-    nblocks = NRT_NXCD * tg.per2 * tg.nTz;
-    if (nblocks > (unsigned)DICE_MAX_BLOCKS) nblocks = DICE_MAX_BLOCKS;      // multiple of 8; blocks loop over tiles
+    tile_geometry(out_shape, G, tune, 3 | (3 << 4) | (4 << 8), tg, nblocks);   // default 8 x 8 x 16 tiles (profiles/r01)
+    if (nblocks > (unsigned)DICE_MAX_BLOCKS) nblocks = DICE_MAX_BLOCKS;        // multiple of 8; blocks loop over tiles
 }
 
 template <int G>

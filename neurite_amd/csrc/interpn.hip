@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void interpn_tile(InterpArgs a, TileGeom tg) {
     else { tzi = j % tg.nTz; t2l = j / tg.nTz; }
     const unsigned t2 = k * tg.per2 + t2l;
     if (t2 >= tg.nT2) return;
-    const int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi << tg.ltz;
+    const int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi * tg.tz;
 
     const int b = blockIdx.y;
     const char *volb = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
@@ -381,15 +381,13 @@ __global__ __launch_bounds__(256) void interpn_tile(InterpArgs a, TileGeom tg) {
     nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
     const int lg = threadIdx.x % G;
     const int g = threadIdx.x / G;
-    const int npass = (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
+    const int npass = tg.plane_major ? tg.tz : (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
     const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
 
     // output voxel of (pass, this lane-group); coordinates clamped into the volume for addressing
     auto voxel = [&](int pass, int (&qd)[NRT_MAXD], bool &valid) {
-        const int s = pass * NG + g;
-        const int x = x0 + (s >> (tg.ltz + tg.lty));
-        const int y = y0 + ((s >> tg.ltz) & ((1 << tg.lty) - 1));
-        const int z = z0 + (s & ((1 << tg.ltz) - 1));
+        int x, y, z;
+        tile_voxel(tg, NG, pass, g, x0, y0, z0, x, y, z);
         valid = (x < a.O[0]) && (y < a.O[1]) && (z < a.O[2]);
         qd[0] = min(x, a.O[0] - 1); qd[1] = min(y, a.O[1] - 1); qd[2] = min(z, a.O[2] - 1);
     };
@@ -583,20 +581,10 @@ void launch_zrun(const InterpArgs &a, int batch, int mode, int variant, int tune
 
 template <int G>
 void launch_tile(const InterpArgs &a, int batch, int mode, int tune, hipStream_t st) {
-    // tune = ltx | lty << 4 | ltz << 8 | z_outer << 12 ; 0 = default
-    constexpr int NG = 256 / G;
-    constexpr int WZ = 64 / G;                    // consecutive-z voxels per wave
-    if (tune <= 0) tune = 2 | (2 << 4) | (4 << 8) | (1 << 12);
     TileGeom tg;
-    tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
-    while ((1 << tg.ltz) < WZ) ++tg.ltz;                       // a wave must stay inside one z-run
-    while ((1 << (tg.ltx + tg.lty + tg.ltz)) < NG) ++tg.lty;  // at least one pass
-    const unsigned nTx = (a.O[0] + (1 << tg.ltx) - 1) >> tg.ltx;
-    tg.nTy = (a.O[1] + (1 << tg.lty) - 1) >> tg.lty;
-    tg.nTz = (a.O[2] + (1 << tg.ltz) - 1) >> tg.ltz;
-    tg.nT2 = nTx * tg.nTy;
-    tg.per2 = (tg.nT2 + NRT_NXCD - 1) / NRT_NXCD;
-    dim3 grid(NRT_NXCD * tg.per2 * tg.nTz, batch);
+    unsigned ntiles;
+    tile_geometry(a.O, G, tune, 2 | (2 << 4) | (4 << 8) | (1 << 12), tg, ntiles);
+    dim3 grid(ntiles, batch);
     switch (mode) {
         case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((interpn_tile<G, NRT_LOC_ABSOLUTE>), grid, dim3(256), 0, st, a, tg); break;
         case NRT_LOC_SHIFT: hipLaunchKernelGGL((interpn_tile<G, NRT_LOC_SHIFT>), grid, dim3(256), 0, st, a, tg); break;

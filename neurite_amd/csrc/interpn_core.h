@@ -84,7 +84,48 @@ struct TileGeom {
     unsigned nT2;               // tiles in the (x,y) plane = nTx * nTy
     unsigned per2;              // (x,y) tiles owned by one XCD = ceil(nT2 / 8)
     int z_outer;                // order inside an XCD's slab: 0 = z fastest, 1 = z outermost
+    int plane_major;            // C == 32 only: a pass is one z-plane of a 4(x) x 8(y) patch, tz = z-chunk length
+    int tz;                     // tile extent along z (= 1 << ltz unless plane_major)
 };
+
+// tune word of the tiled kernels: ltx | lty << 4 | ltz << 8 | z_outer << 12 | plane_major << 13 | LZ << 16
+inline void tile_geometry(const int *out_shape, int G, int tune, int default_tune, TileGeom &tg, unsigned &ntiles) {
+    const int NG = 256 / G, WZ = 64 / G;
+    if (tune <= 0) tune = default_tune;
+    tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
+    tg.plane_major = ((tune >> 13) & 1) && G == 8;
+    if (tg.plane_major) {
+        tg.ltx = 2; tg.lty = 3; tg.ltz = 0;
+        tg.tz = (tune >> 16) & 0xfff;
+        if (tg.tz <= 0 || tg.tz > out_shape[2]) tg.tz = out_shape[2];
+    } else {
+        while ((1 << tg.ltz) < WZ) ++tg.ltz;                       // a wave must stay inside one z-run
+        while ((1 << (tg.ltx + tg.lty + tg.ltz)) < NG) ++tg.lty;  // at least one pass
+        tg.tz = 1 << tg.ltz;
+    }
+    const unsigned nTx = (out_shape[0] + (1 << tg.ltx) - 1) >> tg.ltx;
+    tg.nTy = (out_shape[1] + (1 << tg.lty) - 1) >> tg.lty;
+    tg.nTz = (out_shape[2] + tg.tz - 1) / tg.tz;
+    tg.nT2 = nTx * tg.nTy;
+    tg.per2 = (tg.nT2 + NRT_NXCD - 1) / NRT_NXCD;
+    ntiles = NRT_NXCD * tg.per2 * tg.nTz;
+}
+
+// output voxel handled by lane-group g in pass `pass` of the tile at (x0, y0, z0)
+__device__ __forceinline__ void tile_voxel(const TileGeom &tg, int NG, int pass, int g, int x0, int y0, int z0,
+                                           int &x, int &y, int &z) {
+    if (tg.plane_major) {
+        const int w = g >> 3, j = g & 7;            // wave 2x2 in (x,y), lane-groups 2x4 inside the wave
+        x = x0 + (w >> 1) * 2 + (j >> 2);
+        y = y0 + (w & 1) * 4 + (j & 3);
+        z = z0 + pass;
+    } else {
+        const int s = pass * NG + g;
+        x = x0 + (s >> (tg.ltz + tg.lty));
+        y = y0 + ((s >> tg.ltz) & ((1 << tg.lty) - 1));
+        z = z0 + (s & ((1 << tg.ltz) - 1));
+    }
+}
 
 struct TileMeta {
     float w0[3], w1[3];

@@ -177,7 +177,7 @@ def test_fused_warp_dice(dev):
         fix = rng.random((B,) + So + (L,)).astype(F)
         trf = rng.normal(0, 2.5, (B,) + So + (3,)).astype(F)
         for fill in (None, 0.0):
-            for tune in (0, 1 | (1 << 4) | (3 << 8), 3 | (3 << 4) | (3 << 8) | (1 << 12)):
+            for tune in (0, 1 | (1 << 4) | (3 << 8), 3 | (3 << 4) | (3 << 8) | (1 << 12), (1 << 13) | (5 << 16), (1 << 13) | (1 << 12)):
                 d, w, s = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, return_warped=True,
                                              return_sums=True, laplace_smoothing=0.25, _tune=tune)
                 w_ref = npo.spatial_transformer(mov, trf, fill_value=fill)

@@ -70,7 +70,8 @@ def _tile(lx, ly, lz, zo):
 @pytest.mark.parametrize('variant,tune', [(1, 0), (2, 0), (2, 1), (2, 7), (3, 0), (3, 5), (3, 8), (3, 40), (4, 0),
                                           (4, 13), (5, 0), (5, _tile(0, 0, 5, 0)), (5, _tile(1, 1, 3, 1)),
                                           (5, _tile(2, 3, 4, 1)), (5, _tile(3, 3, 3, 0)), (5, _tile(4, 4, 3, 1)),
-                                          (5, _tile(0, 0, 0, 0))])
+                                          (5, _tile(0, 0, 0, 0)), (5, (1 << 13) | (7 << 16)), (5, (1 << 13) | (1 << 12)),
+                                          (5, (1 << 13) | (20 << 16))])
 def test_c32_every_kernel_variant(dev, variant, tune):
     """All kernels that can serve C = 32 must agree bit-for-bit with the oracle, for sizes that are not
     multiples of the 4x8 patch / z-chunk / 8-voxel shift batch, smooth and rough fields, all loc modes."""
