@@ -166,6 +166,49 @@ int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *lab
              void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * unet layers
+ * replaces the Keras layers that neurite/tf/models.py instantiates: Conv3D (:1378-1388, :1545-1555,
+ * :1596), MaxPooling3D (:1436-1438), UpSampling3D + concatenate (:1531-1542), the channel softmax
+ * (:1601-1605) and the residual add / activation / BatchNormalization (:1401-1433).
+ * All tensors channels-last float32 [batch, X, Y, Z, C]; `shape`, `ksize`, `pool`, `up` are host int[3].
+ * ------------------------------------------------------------------------------------------ */
+typedef enum { NRT_ACT_NONE = 0, NRT_ACT_ELU = 1, NRT_ACT_RELU = 2 } nrt_activation;
+
+/* Weights re-ordered for the MFMA kernel ("packed"): query the size, pack once per layer. */
+size_t nrt_conv3d_packed_weight_floats(const int *ksize, int cin, int cout);
+int nrt_conv3d_pack_weights_f32(const float *weights /* Keras [kx,ky,kz,cin,cout] */, const int *ksize,
+                                int cin, int cout, float *packed, void *stream);
+
+/*
+ * y = act(conv3d(concat(src0, upsample_nearest(src1, up)), W) + bias), cross-correlation, stride 1,
+ * dilation `dilation`, SAME (output = shape) or VALID padding.
+ *   src0 [batch, shape, c0]; src1 [batch, shape/up, c1] or NULL with c1 = 0 (plain convolution);
+ *   weights Keras layout [kx,ky,kz,c0+c1,cout] (direct kernel), packed_weights from
+ *   nrt_conv3d_pack_weights_f32 (MFMA kernel; may be NULL => direct kernel); bias [cout] or NULL.
+ * variant 0 = auto (MFMA implicit GEMM when k in {1,3}^3, SAME, dilation <= 2, cout <= 64, cin >= 8),
+ * 1 = direct, 2 = MFMA.
+ */
+int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int c1, const int *up,
+                   const float *weights, const float *packed_weights, const float *bias, float *out,
+                   int batch, const int *shape, const int *ksize, int cout, int dilation,
+                   int padding_same, int activation, int variant, void *stream);
+
+/* 1x1 convolution with the channel softmax (or an activation) fused; cout <= 64. x [nvox, cin]. */
+int nrt_conv1x1_softmax_f32(const float *x, const float *weights /* [cin, cout] */, const float *bias,
+                            float *y, long long nvox, int cin, int cout, int softmax, int activation,
+                            void *stream);
+int nrt_softmax_lastdim_f32(const float *x, float *y, long long n, int channels, void *stream);
+/* MaxPooling3D, stride = pool; SAME keeps partial windows (output ceil(n/p)), VALID drops them. */
+int nrt_maxpool3d_f32(const float *x, float *y, int batch, const int *shape, int channels,
+                      const int *pool, int padding_same, void *stream);
+/* y = concat(skip [batch, shape, c0] (may be NULL with c0 = 0), upsample_nearest(lo [batch, shape/up, c1])) */
+int nrt_upsample_concat_f32(const float *skip, int c0, const float *lo, int c1, float *y, int batch,
+                            const int *shape, const int *up, void *stream);
+/* y = act(a + b) * scale[c] + shift[c]   (b, scale/shift optional): residual merge / inference BatchNorm */
+int nrt_add_act_affine_f32(const float *a, const float *b, const float *scale, const float *shift,
+                           float *y, long long n, int channels, int activation, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or
  * non-temporal; calibrates the achievable mixed read/write HBM rate next to the kernels above.
  * ------------------------------------------------------------------------------------------ */

@@ -21,6 +21,7 @@ from . import utils  # noqa: F401
 from . import layers  # noqa: F401
 from . import metrics  # noqa: F401
 from . import losses  # noqa: F401
+from . import models  # noqa: F401
 from . import fused  # noqa: F401
 from . import distributed  # noqa: F401
 

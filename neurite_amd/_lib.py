@@ -41,6 +41,14 @@ _SIGNATURES = {
     'nrt_wcce_workspace_bytes': (_sz, [_ll, _i]),
     'nrt_warp_dice_workspace_bytes': (_sz, [_ip, _i, _i, _i]),
     'nrt_warp_dice_soft_f32': (_i, [_vp, _vp, _vp, _vp, _ip, _ip, _i, _i, _ll, _i, _i, _f, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    'nrt_conv3d_packed_weight_floats': (_sz, [_ip, _i, _i]),
+    'nrt_conv3d_pack_weights_f32': (_i, [_vp, _ip, _i, _i, _vp, _vp]),
+    'nrt_conv3d_f32': (_i, [_vp, _i, _vp, _i, _ip, _vp, _vp, _vp, _vp, _i, _ip, _ip, _i, _i, _i, _i, _i, _vp]),
+    'nrt_conv1x1_softmax_f32': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp]),
+    'nrt_softmax_lastdim_f32': (_i, [_vp, _vp, _ll, _i, _vp]),
+    'nrt_maxpool3d_f32': (_i, [_vp, _vp, _i, _ip, _i, _ip, _i, _vp]),
+    'nrt_upsample_concat_f32': (_i, [_vp, _i, _vp, _i, _vp, _i, _ip, _ip, _vp]),
+    'nrt_add_act_affine_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     'nrt_membench_copy_f32': (_i, [_vp, _vp, _ll, _i, _i, _vp]),
     'nrt_wcce': (_i, [_vp, _vp, _i, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -1,0 +1,514 @@
+// Conv3D stack of neurite's unet for gfx950 (MI355X): the Keras layers models.py:1378-1388 (encoder
+// convs), :1436-1438 (MaxPooling3D), :1531-1542 (UpSampling3D + concatenate), :1545-1555 (decoder
+// convs), :1596 (1x1 "likelihood" conv) and :1601-1605 (channel softmax).
+//
+// Layout: channels-last fp32 exactly as Keras: x [B, X, Y, Z, Cin], kernel [kx, ky, kz, Cin, Cout],
+// y [B, X, Y, Z, Cout]; cross-correlation, stride 1, SAME padding (floor((k-1)*dil/2) before).
+//
+// conv3d_mfma_f32  -- implicit GEMM on the matrix cores, M = output voxels, N = Cout, K = taps * Cin,
+//   with v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD = the 157 TFLOP/s fp32 peak).
+//   Block = 4 waves = a 4(x) x 4(y) x 16(z) output tile; wave w owns the x-slab w: 4 M-tiles (one per
+//   y) of 16 consecutive-z voxels, all N-tiles.  K is walked in chunks of 16 input channels: the halo
+//   tile [4+2p][4+2p][16+2p] x 16 ch of the chunk is staged in LDS (row stride 20 floats: the 16-lane
+//   groups of ds_read_b128 then fall on distinct banks), each lane reads ONE float4 (4 consecutive
+//   channels of one voxel) per tap and M-tile and feeds 4 MFMAs with it; weights are pre-packed in
+//   fragment order so that a lane's 4 B-operands are one 16-byte load from L2.
+//   UpSampling3D + concatenate are fused into the halo loader: channels >= c0 are read from a second
+//   tensor at (x/ux, y/uy, z/uz), so the 786 MB concat tensor of the last decoder level never exists.
+//   Epilogue: + bias, ELU as exp(x)-1 (TF semantics), 64-byte row segments per voxel.
+// conv3d_direct_f32 -- any shape (Cin = 1 first layer, odd channel counts, VALID padding, big dilation):
+//   one thread per output voxel, 16 output channels at a time in registers.  HBM-bound cases only.
+// conv1x1_softmax_f32 -- the likelihood conv with the channel softmax fused (one pass, no logits tensor).
+// maxpool3d_f32, upsample_concat_f32, softmax_lastdim_f32 -- the remaining Keras layers.
+
+#include "nrt_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2 };
+
+__device__ __forceinline__ float activate(float v, int act) {
+    if (act == ACT_ELU) return v > 0.0f ? v : (expf(v) - 1.0f);      // Keras elu, alpha = 1
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+struct ConvArgs {
+    const float *src0;       // [B, X, Y, Z, c0]
+    const float *src1;       // [B, X/ux, Y/uy, Z/uz, c1] or null
+    const float *bias;       // [Cout] or null
+    float *out;              // [B, OX, OY, OZ, Cout]
+    int X, Y, Z;             // input (= src0) spatial shape
+    int OX, OY, OZ;          // output spatial shape
+    int c0, c1, Cout;
+    int ux, uy, uz;          // up-sampling factors of src1
+    int X1, Y1, Z1;          // src1 spatial shape
+    int kx, ky, kz;
+    int dil;
+    int px, py, pz;          // padding before
+    int act;
+};
+
+// ============================================================================================
+// MFMA implicit GEMM
+// ============================================================================================
+constexpr int CT_X = 4, CT_Y = 4, CT_Z = 16;   // output tile
+constexpr int LDS_ROW = 20;                     // floats per staged voxel row (16 channels + 4 pad)
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__restrict__ wpacked, unsigned nblk,
+                                                   unsigned nbx, unsigned nby, unsigned nbz) {
+    extern __shared__ float lds[];
+    const unsigned lb = nrt_xcd_block(blockIdx.x, gridDim.x);
+    if (lb >= nblk) return;
+    const int b = blockIdx.y;
+    const int bz = lb % nbz, by = (lb / nbz) % nby, bx = lb / (nbz * nby);
+    const int x0 = bx * CT_X, y0 = by * CT_Y, z0 = bz * CT_Z;
+    const int hx = a.kx > 1 ? a.dil : 0, hy = a.ky > 1 ? a.dil : 0, hz = a.kz > 1 ? a.dil : 0;   // halo per side
+    const int HX = CT_X + 2 * hx, HY = CT_Y + 2 * hy, HZ = CT_Z + 2 * hz;
+    const int nrows = HX * HY * HZ;
+    const int Cin = a.c0 + a.c1;
+    const int nchunk = (Cin + 15) / 16;
+    const int ntap = a.kx * a.ky * a.kz;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+
+    const float *s0 = a.src0 + (long long)b * a.X * a.Y * a.Z * a.c0;
+    const float *s1 = a.src1 ? a.src1 + (long long)b * a.X1 * a.Y1 * a.Z1 * a.c1 : nullptr;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        __syncthreads();                                   // previous chunk fully consumed
+        // ---- stage the halo tile of channels [16 ch, 16 ch + 16) -------------------------------
+        const int cbase = ch * 16;
+        for (int r = threadIdx.x >> 2; r < nrows; r += 64) {
+            const int q4 = threadIdx.x & 3;                // which float4 of the 16-channel row
+            const int rz = r % HZ, ry = (r / HZ) % HY, rx = r / (HZ * HY);
+            const int x = x0 - hx + rx, y = y0 - hy + ry, z = z0 - hz + rz;
+            f32x4 v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (x >= 0 && x < a.X && y >= 0 && y < a.Y && z >= 0 && z < a.Z) {
+                const int c = cbase + 4 * q4;
+                if (c < a.c0) {
+                    const float *p = s0 + (((long long)x * a.Y + y) * a.Z + z) * a.c0 + c;
+                    if (c + 3 < a.c0 && (a.c0 & 3) == 0) v = *(const f32x4 *)p;
+                    else { for (int e = 0; e < 4; ++e) if (c + e < a.c0) v[e] = p[e]; }
+                } else if (c < Cin) {
+                    const int c1 = c - a.c0;
+                    const float *p = s1 + (((long long)(x / a.ux) * a.Y1 + (y / a.uy)) * a.Z1 + (z / a.uz)) * a.c1 + c1;
+                    if (c1 + 3 < a.c1 && (a.c1 & 3) == 0 && (a.c0 & 3) == 0) v = *(const f32x4 *)p;
+                    else { for (int e = 0; e < 4; ++e) if (c1 + e < a.c1) v[e] = p[e]; }
+                }
+            }
+            *(f32x4 *)&lds[r * LDS_ROW + 4 * q4] = v;
+        }
+        __syncthreads();
+        // ---- taps ------------------------------------------------------------------------------
+        const f32x4 *wp = (const f32x4 *)wpacked + ((long long)ch * ntap) * NT * 64 + lane;
+        f32x4 bfrag[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bfrag[nt] = wp[nt * 64];
+        for (int t = 0; t < ntap; ++t) {
+            f32x4 bnext[NT];
+            const int tn = (t + 1 < ntap) ? t + 1 : t;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bnext[nt] = wp[((long long)tn * NT + nt) * 64];
+            const int dz = t % a.kz, dy = (t / a.kz) % a.ky, dx = t / (a.kz * a.ky);
+            const int rx = w + dx * a.dil, rz = li + dz * a.dil;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int ry = mt + dy * a.dil;
+                const f32x4 av = *(const f32x4 *)&lds[((rx * HY + ry) * HZ + rz) * LDS_ROW + 4 * kq];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bfrag[nt][0], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bfrag[nt][1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bfrag[nt][2], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bfrag[nt][3], acc[mt][nt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfrag[nt] = bnext[nt];
+        }
+    }
+    // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] ---------------------------------------
+    float *ob = a.out + (long long)b * a.OX * a.OY * a.OZ * a.Cout;
+    const int x = x0 + w;
+    if (x < a.OX) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int y = y0 + mt;
+            if (y >= a.OY) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = nt * 16 + li;
+                if (co >= a.Cout) continue;
+                const float bv = a.bias ? a.bias[co] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int z = z0 + kq * 4 + r;
+                    if (z < a.OZ)
+                        ob[(((long long)x * a.OY + y) * a.OZ + z) * a.Cout + co] = activate(acc[mt][nt][r] + bv, a.act);
+                }
+            }
+        }
+    }
+}
+
+// pack Keras-layout weights [ntap, Cin, Cout] into fragment order [chunk][tap][nt][lane][m]:
+// value = W[tap][16 chunk + 4 (lane>>4) + m][16 nt + (lane & 15)], zero outside
+__global__ void conv3d_pack_weights(const float *__restrict__ w, int ntap, int Cin, int Cout, int NT, int nchunk,
+                                    float *__restrict__ packed) {
+    const long long total = (long long)nchunk * ntap * NT * 64 * 4;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int m = e & 3, lane = (e >> 2) & 63;
+        long long r = e >> 8;
+        const int nt = r % NT; r /= NT;
+        const int t = r % ntap; const int ch = r / ntap;
+        const int ci = ch * 16 + 4 * (lane >> 4) + m, co = nt * 16 + (lane & 15);
+        packed[e] = (ci < Cin && co < Cout) ? w[((long long)t * Cin + ci) * Cout + co] : 0.0f;
+    }
+}
+
+// ============================================================================================
+// direct convolution: one thread per output voxel, 16 output channels per pass
+// ============================================================================================
+__global__ __launch_bounds__(256) void conv3d_direct(ConvArgs a, const float *__restrict__ w) {
+    const int b = blockIdx.y;
+    const int Cin = a.c0 + a.c1;
+    const float *s0 = a.src0 + (long long)b * a.X * a.Y * a.Z * a.c0;
+    const float *s1 = a.src1 ? a.src1 + (long long)b * a.X1 * a.Y1 * a.Z1 * a.c1 : nullptr;
+    float *ob = a.out + (long long)b * a.OX * a.OY * a.OZ * a.Cout;
+    const long long nvox = (long long)a.OX * a.OY * a.OZ;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nvox; q += (long long)gridDim.x * blockDim.x) {
+        const int oz = q % a.OZ, oy = (q / a.OZ) % a.OY, ox = q / ((long long)a.OZ * a.OY);
+        for (int cb = 0; cb < a.Cout; cb += 16) {
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+            for (int dx = 0; dx < a.kx; ++dx) {
+                const int x = ox + dx * a.dil - a.px;
+                if (x < 0 || x >= a.X) continue;
+                for (int dy = 0; dy < a.ky; ++dy) {
+                    const int y = oy + dy * a.dil - a.py;
+                    if (y < 0 || y >= a.Y) continue;
+                    for (int dz = 0; dz < a.kz; ++dz) {
+                        const int z = oz + dz * a.dil - a.pz;
+                        if (z < 0 || z >= a.Z) continue;
+                        const float *wt = w + ((long long)((dx * a.ky + dy) * a.kz + dz) * Cin) * a.Cout + cb;
+                        const float *p0 = s0 + (((long long)x * a.Y + y) * a.Z + z) * a.c0;
+                        for (int ci = 0; ci < a.c0; ++ci) {
+                            const float xv = p0[ci];
+#pragma unroll
+                            for (int j = 0; j < 16; ++j)
+                                if (cb + j < a.Cout) acc[j] = fmaf(xv, wt[(long long)ci * a.Cout + j], acc[j]);
+                        }
+                        if (s1) {
+                            const float *p1 = s1 + (((long long)(x / a.ux) * a.Y1 + (y / a.uy)) * a.Z1 + (z / a.uz)) * a.c1;
+                            for (int ci = 0; ci < a.c1; ++ci) {
+                                const float xv = p1[ci];
+#pragma unroll
+                                for (int j = 0; j < 16; ++j)
+                                    if (cb + j < a.Cout) acc[j] = fmaf(xv, wt[(long long)(a.c0 + ci) * a.Cout + j], acc[j]);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (cb + j < a.Cout) ob[q * a.Cout + cb + j] = activate(acc[j] + (a.bias ? a.bias[cb + j] : 0.0f), a.act);
+        }
+    }
+}
+
+// ============================================================================================
+// 1x1 conv (+ optional channel softmax) : the likelihood / prediction head.  Cout <= 64 in registers.
+// ============================================================================================
+template <int CO_MAX>
+__global__ __launch_bounds__(256) void conv1x1_softmax(const float *__restrict__ x, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, float *__restrict__ y,
+                                                       long long nvox, int Cin, int Cout, int softmax, int act) {
+    extern __shared__ float wl[];          // [Cin][Cout] + [Cout]
+    for (int i = threadIdx.x; i < Cin * Cout; i += blockDim.x) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) wl[Cin * Cout + i] = bias ? bias[i] : 0.0f;
+    __syncthreads();
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nvox; q += (long long)gridDim.x * blockDim.x) {
+        float acc[CO_MAX];
+#pragma unroll
+        for (int j = 0; j < CO_MAX; ++j) acc[j] = j < Cout ? wl[Cin * Cout + j] : 0.0f;
+        const float *xp = x + q * Cin;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = xp[ci];
+#pragma unroll
+            for (int j = 0; j < CO_MAX; ++j)
+                if (j < Cout) acc[j] = fmaf(xv, wl[ci * Cout + j], acc[j]);
+        }
+        if (softmax) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CO_MAX; ++j) if (j < Cout) m = fmaxf(m, acc[j]);
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CO_MAX; ++j) if (j < Cout) { acc[j] = expf(acc[j] - m); s += acc[j]; }
+            const float inv = 1.0f / s;
+#pragma unroll
+            for (int j = 0; j < CO_MAX; ++j) if (j < Cout) acc[j] *= inv;
+        } else {
+#pragma unroll
+            for (int j = 0; j < CO_MAX; ++j) if (j < Cout) acc[j] = activate(acc[j], act);
+        }
+        float *yp = y + q * Cout;
+#pragma unroll
+        for (int j = 0; j < CO_MAX; ++j) if (j < Cout) yp[j] = acc[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_lastdim(const float *__restrict__ x, float *__restrict__ y, long long n, int C) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+        const float *xp = x + q * C;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, xp[c]);
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) s += expf(xp[c] - m);
+        const float inv = 1.0f / s;
+        for (int c = 0; c < C; ++c) y[q * C + c] = expf(xp[c] - m) * inv;
+    }
+}
+
+// MaxPooling3D, stride = pool size, SAME (partial windows at the end) or VALID; one thread per (voxel, channel)
+__global__ __launch_bounds__(256) void maxpool3d(const float *__restrict__ x, float *__restrict__ y, int X, int Y, int Z,
+                                                 int C, int OX, int OY, int OZ, int px, int py, int pz) {
+    const int b = blockIdx.y;
+    const float *xb = x + (long long)b * X * Y * Z * C;
+    float *yb = y + (long long)b * OX * OY * OZ * C;
+    const long long total = (long long)OX * OY * OZ * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = e % C;
+        long long q = e / C;
+        const int oz = q % OZ, oy = (q / OZ) % OY, ox = q / ((long long)OZ * OY);
+        float m = -INFINITY;
+        for (int dx = 0; dx < px; ++dx) {
+            const int xx = ox * px + dx; if (xx >= X) break;
+            for (int dy = 0; dy < py; ++dy) {
+                const int yy = oy * py + dy; if (yy >= Y) break;
+                for (int dz = 0; dz < pz; ++dz) {
+                    const int zz = oz * pz + dz; if (zz >= Z) break;
+                    m = fmaxf(m, xb[(((long long)xx * Y + yy) * Z + zz) * C + c]);
+                }
+            }
+        }
+        yb[e] = m;
+    }
+}
+
+// UpSampling3D (nearest repeat) of `lo` + concatenate([skip, up], channel axis) -- stand-alone form
+__global__ __launch_bounds__(256) void upsample_concat(const float *__restrict__ skip, int c0, const float *__restrict__ lo,
+                                                       int c1, float *__restrict__ y, int X, int Y, int Z, int ux, int uy,
+                                                       int uz) {
+    const int b = blockIdx.y;
+    const int C = c0 + c1, X1 = X / ux, Y1 = Y / uy, Z1 = Z / uz;
+    const float *sb = skip ? skip + (long long)b * X * Y * Z * c0 : nullptr;
+    const float *lb = lo + (long long)b * X1 * Y1 * Z1 * c1;
+    float *yb = y + (long long)b * X * Y * Z * C;
+    const long long total = (long long)X * Y * Z * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = e % C;
+        long long q = e / C;
+        const int z = q % Z, yy = (q / Z) % Y, x = q / ((long long)Z * Y);
+        yb[e] = (c < c0) ? sb[q * c0 + c]
+                         : lb[(((long long)(x / ux) * Y1 + (yy / uy)) * Z1 + (z / uz)) * c1 + (c - c0)];
+    }
+}
+
+// y = act(a + b) [+ per-channel affine]: residual merges (models.py:1423-1429) and inference BatchNorm
+__global__ __launch_bounds__(256) void add_act_affine(const float *__restrict__ a, const float *__restrict__ bsrc,
+                                                      const float *__restrict__ scale, const float *__restrict__ shift,
+                                                      float *__restrict__ y, long long n, int C, int act) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        float v = a[e];
+        if (bsrc) v += bsrc[e];
+        v = activate(v, act);
+        if (scale) v = v * scale[e % C] + shift[e % C];
+        y[e] = v;
+    }
+}
+
+int conv_args(ConvArgs &a, const float *src0, int c0, const float *src1, int c1, const int *up, const float *bias,
+              float *out, const int *shape, const int *ksize, int cout, int dilation, int padding_same, int act) {
+    if (!src0 || !out || !shape || !ksize) return NRT_ERR_INVALID_ARG;
+    if (c0 < 1 || c1 < 0 || cout < 1 || dilation < 1) return NRT_ERR_INVALID_ARG;
+    if (c1 > 0 && (!src1 || !up)) return NRT_ERR_INVALID_ARG;
+    a.src0 = src0; a.src1 = c1 > 0 ? src1 : nullptr; a.bias = bias; a.out = out;
+    a.X = shape[0]; a.Y = shape[1]; a.Z = shape[2];
+    a.c0 = c0; a.c1 = c1; a.Cout = cout;
+    a.ux = c1 > 0 ? up[0] : 1; a.uy = c1 > 0 ? up[1] : 1; a.uz = c1 > 0 ? up[2] : 1;
+    if (a.ux < 1 || a.uy < 1 || a.uz < 1) return NRT_ERR_INVALID_ARG;
+    if (c1 > 0 && (a.X % a.ux || a.Y % a.uy || a.Z % a.uz)) return NRT_ERR_INVALID_ARG;
+    a.X1 = a.X / a.ux; a.Y1 = a.Y / a.uy; a.Z1 = a.Z / a.uz;
+    a.kx = ksize[0]; a.ky = ksize[1]; a.kz = ksize[2]; a.dil = dilation;
+    if (a.kx < 1 || a.ky < 1 || a.kz < 1) return NRT_ERR_INVALID_ARG;
+    if (padding_same) {
+        a.px = ((a.kx - 1) * dilation) / 2; a.py = ((a.ky - 1) * dilation) / 2; a.pz = ((a.kz - 1) * dilation) / 2;
+        a.OX = a.X; a.OY = a.Y; a.OZ = a.Z;
+    } else {
+        a.px = a.py = a.pz = 0;
+        a.OX = a.X - (a.kx - 1) * dilation; a.OY = a.Y - (a.ky - 1) * dilation; a.OZ = a.Z - (a.kz - 1) * dilation;
+        if (a.OX < 1 || a.OY < 1 || a.OZ < 1) return NRT_ERR_INVALID_ARG;
+    }
+    a.act = act;
+    return NRT_OK;
+}
+
+bool mfma_ok(const ConvArgs &a, int padding_same) {
+    if (!padding_same) return false;
+    auto okk = [](int k) { return k == 1 || k == 3; };
+    if (!okk(a.kx) || !okk(a.ky) || !okk(a.kz)) return false;
+    if (a.dil > 2) return false;
+    if (a.Cout > 64) return false;
+    if ((a.c0 + a.c1) < 8) return false;                         // K too thin: the direct kernel is HBM-bound anyway
+    if (a.c1 > 0 && (a.c0 % 4)) return false;
+    return true;
+}
+
+size_t mfma_lds_bytes(const ConvArgs &a) {
+    const int hx = a.kx > 1 ? a.dil : 0, hy = a.ky > 1 ? a.dil : 0, hz = a.kz > 1 ? a.dil : 0;
+    return (size_t)(CT_X + 2 * hx) * (CT_Y + 2 * hy) * (CT_Z + 2 * hz) * LDS_ROW * sizeof(float);
+}
+
+template <int NT>
+int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st) {
+    const unsigned nbx = (a.OX + CT_X - 1) / CT_X, nby = (a.OY + CT_Y - 1) / CT_Y, nbz = (a.OZ + CT_Z - 1) / CT_Z;
+    const unsigned nblk = nbx * nby * nbz;
+    const size_t shm = mfma_lds_bytes(a);
+    if (shm > 64 * 1024) {
+        if (hipFuncSetAttribute((const void *)conv3d_mfma<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+            return NRT_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((conv3d_mfma<NT>), dim3(nrt_xcd_grid(nblk), batch), dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t nrt_conv3d_packed_weight_floats(const int *ksize, int cin, int cout) {
+    if (!ksize || cin < 1 || cout < 1) return 0;
+    const size_t ntap = (size_t)ksize[0] * ksize[1] * ksize[2];
+    return (size_t)((cin + 15) / 16) * ntap * ((cout + 15) / 16) * 256;
+}
+
+extern "C" int nrt_conv3d_pack_weights_f32(const float *weights, const int *ksize, int cin, int cout, float *packed,
+                                           void *stream) {
+    if (!weights || !packed || !ksize || cin < 1 || cout < 1) return NRT_ERR_INVALID_ARG;
+    const int ntap = ksize[0] * ksize[1] * ksize[2], NT = (cout + 15) / 16, nchunk = (cin + 15) / 16;
+    hipLaunchKernelGGL(conv3d_pack_weights, dim3(256), dim3(256), 0, nrt_stream(stream), weights, ntap, cin, cout, NT, nchunk,
+                       packed);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int c1, const int *up, const float *weights,
+                              const float *packed_weights, const float *bias, float *out, int batch, const int *shape,
+                              const int *ksize, int cout, int dilation, int padding_same, int activation, int variant,
+                              void *stream) {
+    ConvArgs a;
+    int rc = conv_args(a, src0, c0, src1, c1, up, bias, out, shape, ksize, cout, dilation, padding_same, activation);
+    if (rc != NRT_OK) return rc;
+    if (batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_RELU) return NRT_ERR_INVALID_ARG;
+    hipStream_t st = nrt_stream(stream);
+    const bool can_mfma = mfma_ok(a, padding_same) && packed_weights != nullptr;
+    if (variant == 0) variant = can_mfma ? 2 : 1;
+    if (variant == 2) {
+        if (!can_mfma) return NRT_ERR_UNSUPPORTED;
+        switch ((cout + 15) / 16) {
+            case 1: return launch_mfma<1>(a, packed_weights, batch, st);
+            case 2: return launch_mfma<2>(a, packed_weights, batch, st);
+            case 3: return launch_mfma<3>(a, packed_weights, batch, st);
+            default: return launch_mfma<4>(a, packed_weights, batch, st);
+        }
+    }
+    if (variant != 1 || !weights) return NRT_ERR_INVALID_ARG;
+    const long long nvox = (long long)a.OX * a.OY * a.OZ;
+    unsigned blocks = (unsigned)((nvox + 255) / 256);
+    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    hipLaunchKernelGGL(conv3d_direct, dim3(blocks, batch), dim3(256), 0, st, a, weights);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_conv1x1_softmax_f32(const float *x, const float *weights, const float *bias, float *y,
+                                       long long nvox, int cin, int cout, int softmax, int activation, void *stream) {
+    if (!x || !weights || !y || nvox < 0 || cin < 1 || cout < 1) return NRT_ERR_INVALID_ARG;
+    if (cout > 64 || (size_t)(cin + 1) * cout * sizeof(float) > 64 * 1024) return NRT_ERR_UNSUPPORTED;
+    if (nvox == 0) return NRT_OK;
+    unsigned blocks = (unsigned)((nvox + 255) / 256);
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    const size_t shm = (size_t)(cin + 1) * cout * sizeof(float);
+    hipStream_t st = nrt_stream(stream);
+    if (cout <= 16) hipLaunchKernelGGL((conv1x1_softmax<16>), dim3(blocks), dim3(256), shm, st, x, weights, bias, y, nvox, cin, cout, softmax, activation);
+    else if (cout <= 32) hipLaunchKernelGGL((conv1x1_softmax<32>), dim3(blocks), dim3(256), shm, st, x, weights, bias, y, nvox, cin, cout, softmax, activation);
+    else hipLaunchKernelGGL((conv1x1_softmax<64>), dim3(blocks), dim3(256), shm, st, x, weights, bias, y, nvox, cin, cout, softmax, activation);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_softmax_lastdim_f32(const float *x, float *y, long long n, int channels, void *stream) {
+    if (!x || !y || n < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (n == 0) return NRT_OK;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    hipLaunchKernelGGL(softmax_lastdim, dim3(blocks), dim3(256), 0, nrt_stream(stream), x, y, n, channels);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_maxpool3d_f32(const float *x, float *y, int batch, const int *shape, int channels, const int *pool,
+                                 int padding_same, void *stream) {
+    if (!x || !y || !shape || !pool || batch < 1 || batch > 65535 || channels < 1) return NRT_ERR_INVALID_ARG;
+    for (int d = 0; d < 3; ++d) if (pool[d] < 1 || shape[d] < 1) return NRT_ERR_INVALID_ARG;
+    int o[3];
+    for (int d = 0; d < 3; ++d) o[d] = padding_same ? (shape[d] + pool[d] - 1) / pool[d] : shape[d] / pool[d];
+    const long long total = (long long)o[0] * o[1] * o[2] * channels;
+    if (total == 0) return NRT_OK;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    hipLaunchKernelGGL(maxpool3d, dim3(blocks, batch), dim3(256), 0, nrt_stream(stream), x, y, shape[0], shape[1], shape[2],
+                       channels, o[0], o[1], o[2], pool[0], pool[1], pool[2]);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_upsample_concat_f32(const float *skip, int c0, const float *lo, int c1, float *y, int batch,
+                                       const int *shape, const int *up, void *stream) {
+    if (!lo || !y || !shape || !up || batch < 1 || batch > 65535 || c0 < 0 || c1 < 1) return NRT_ERR_INVALID_ARG;
+    if (c0 > 0 && !skip) return NRT_ERR_INVALID_ARG;
+    for (int d = 0; d < 3; ++d) if (up[d] < 1 || shape[d] < 1 || shape[d] % up[d]) return NRT_ERR_INVALID_ARG;
+    const long long total = (long long)shape[0] * shape[1] * shape[2] * (c0 + c1);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    hipLaunchKernelGGL(upsample_concat, dim3(blocks, batch), dim3(256), 0, nrt_stream(stream), c0 > 0 ? skip : nullptr, c0, lo,
+                       c1, y, shape[0], shape[1], shape[2], up[0], up[1], up[2]);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_add_act_affine_f32(const float *a, const float *b, const float *scale, const float *shift, float *y,
+                                      long long n, int channels, int activation, void *stream) {
+    if (!a || !y || n < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if ((scale == nullptr) != (shift == nullptr)) return NRT_ERR_INVALID_ARG;
+    if (n == 0) return NRT_OK;
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 256u * 32u) blocks = 256u * 32u;
+    hipLaunchKernelGGL(add_act_affine, dim3(blocks), dim3(256), 0, nrt_stream(stream), a, b, scale, shift, y, n, channels,
+                       activation);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

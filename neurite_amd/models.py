@@ -1,0 +1,634 @@
+"""
+neurite_amd.models -- neurite's U-Net builders on MI355X.
+
+unet      neurite/tf/models.py:88-246
+conv_enc  neurite/tf/models.py:1309-1442
+conv_dec  neurite/tf/models.py:1445-1617
+conv_block: alias of conv_enc (the name BASELINE.json uses for the conv stacks; not in the reference tree)
+
+Same arguments, defaults, layer names ('{prefix}_conv_downarm_{level}_{conv}', '{prefix}_maxpool_{level}',
+'{prefix}_up_{n}', '{prefix}_merge_{n}', '{prefix}_conv_uparm_{n}_{conv}', '{prefix}_likelihood',
+'{prefix}_prediction' ...) and graph as the Keras builders; the returned object is a torch.nn.Module whose
+parameters keep the Keras layouts (Conv kernel [k.., Cin, Cout], bias [Cout]) so trained Keras weights map
+one to one.  Forward runs on the HIP kernels of csrc/conv.hip: Conv3D = MFMA implicit GEMM (fp32), with
+UpSampling3D + concatenate fused into the following convolution's loader and the final 1x1 conv fused
+with the channel softmax.  1-D / 2-D nets are lifted to 3-D with unit leading dimensions.
+Inference only: Dropout is the identity, BatchNormalization uses its moving statistics.
+"""
+
+import math
+import warnings
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from . import utils
+
+__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet']
+
+_ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}
+
+
+def _act_code(activation):
+    if activation not in _ACTS:
+        raise NotImplementedError('activation %r is not implemented by the HIP path (elu, relu, linear/None are)'
+                                  % (activation,))
+    return _ACTS[activation]
+
+
+def _triple(v, ndims, what):
+    if isinstance(v, (int, np.integer)):
+        v = (int(v),) * ndims
+    v = tuple(int(x) for x in v)
+    if len(v) != ndims:
+        raise ValueError('%s must have %d entries, got %r' % (what, ndims, v))
+    return (1,) * (3 - ndims) + v
+
+
+def _lift(x, ndims):
+    """[B, *S, C] with len(S) = ndims -> [B, 1.., *S, C] (3 spatial dims)."""
+    for _ in range(3 - ndims):
+        x = x.unsqueeze(1)
+    return x.contiguous()
+
+
+def _unlift(x, ndims):
+    for _ in range(3 - ndims):
+        x = x.squeeze(1)
+    return x
+
+
+class _Conv(nn.Module):
+    """Keras Conv{N}D (channels-last, stride 1): kernel [k1..kN, Cin, Cout], glorot_uniform; bias zeros."""
+
+    def __init__(self, name, cin, cout, ksize3, dilation=1, padding='same', activation=None):
+        super().__init__()
+        self.layer_name = name
+        self.cin, self.cout = int(cin), int(cout)
+        self.ksize3 = tuple(ksize3)
+        self.dilation = int(dilation)
+        if padding not in ('same', 'valid'):
+            raise ValueError('padding must be same or valid')
+        self.padding = padding
+        self.activation = activation
+        self.act = _act_code(activation)
+        k = self.ksize3
+        fan = k[0] * k[1] * k[2]
+        limit = math.sqrt(6.0 / (fan * self.cin + fan * self.cout))
+        self.kernel = nn.Parameter((torch.rand(*k, self.cin, self.cout) * 2 - 1) * limit)
+        self.bias = nn.Parameter(torch.zeros(self.cout))
+        self._packed = None
+        self._packed_version = None
+
+    def _packed_weights(self):
+        ver = (self.kernel._version, self.kernel.data_ptr(), self.kernel.device)
+        if self._packed is None or self._packed_version != ver:
+            lib = _lib.lib()
+            dev = self.kernel.device
+            n = lib.nrt_conv3d_packed_weight_floats(_lib.ints(self.ksize3), self.cin, self.cout)
+            packed = torch.empty(int(n), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.nrt_conv3d_pack_weights_f32(_lib.ptr(self.kernel.detach().contiguous()), _lib.ints(self.ksize3),
+                                                     self.cin, self.cout, _lib.ptr(packed), _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_conv3d_pack_weights_f32')
+            self._packed, self._packed_version = packed, ver
+        return self._packed
+
+    def forward(self, x, lo=None, up=None, variant=0):
+        """x [B, X, Y, Z, c0]; optional lo [B, X/up, Y/up, Z/up, c1] is nearest-upsampled and concatenated after x."""
+        lib = _lib.lib()
+        dev = _lib.require_device(x, lo, self.kernel)
+        if x.dtype != torch.float32:
+            raise NotImplementedError('the HIP conv path is float32')
+        x = x.contiguous()
+        c0 = x.shape[-1]
+        c1 = 0 if lo is None else lo.shape[-1]
+        if c0 + c1 != self.cin:
+            raise ValueError('%s expects %d input channels, got %d' % (self.layer_name, self.cin, c0 + c1))
+        B, S = x.shape[0], list(x.shape[1:4])
+        if lo is not None:
+            lo = lo.contiguous()
+            if [S[d] // up[d] for d in range(3)] != list(lo.shape[1:4]) or any(S[d] % up[d] for d in range(3)):
+                raise ValueError('%s: skip %s and up-sampled %s x %s shapes do not match'
+                                 % (self.layer_name, S, list(lo.shape[1:4]), up))
+        if self.padding == 'same':
+            O = S
+        else:
+            O = [S[d] - (self.ksize3[d] - 1) * self.dilation for d in range(3)]
+        out = torch.empty([B] + O + [self.cout], dtype=torch.float32, device=dev)
+        w = self.kernel.detach().contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.nrt_conv3d_f32(_lib.ptr(x), c0, _lib.ptr(lo), c1, _lib.ints(up) if lo is not None else None,
+                                    _lib.ptr(w), _lib.ptr(self._packed_weights()), _lib.ptr(self.bias.detach()),
+                                    _lib.ptr(out), B, _lib.ints(S), _lib.ints(self.ksize3), self.cout, self.dilation,
+                                    int(self.padding == 'same'), self.act, int(variant), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv3d_f32')
+        return out
+
+
+class _BatchNorm(nn.Module):
+    """Keras BatchNormalization at inference: gamma, beta, moving_mean, moving_variance, epsilon = 1e-3."""
+
+    def __init__(self, name, channels, epsilon=1e-3):
+        super().__init__()
+        self.layer_name = name
+        self.epsilon = epsilon
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+        self.register_buffer('moving_mean', torch.zeros(channels))
+        self.register_buffer('moving_variance', torch.ones(channels))
+
+
+def _elementwise(a, b=None, scale=None, shift=None, act=0):
+    lib = _lib.lib()
+    dev = _lib.require_device(a, b)
+    a = a.contiguous()
+    b = None if b is None else b.contiguous()
+    y = torch.empty_like(a)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_add_act_affine_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(y),
+                                        a.numel(), a.shape[-1], int(act), _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_add_act_affine_f32')
+    return y
+
+
+def _maxpool(x, pool3, padding):
+    lib = _lib.lib()
+    dev = _lib.require_device(x)
+    x = x.contiguous()
+    B, S, C = x.shape[0], list(x.shape[1:4]), x.shape[-1]
+    same = padding == 'same'
+    O = [(S[d] + pool3[d] - 1) // pool3[d] if same else S[d] // pool3[d] for d in range(3)]
+    y = torch.empty([B] + O + [C], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_maxpool3d_f32(_lib.ptr(x), _lib.ptr(y), B, _lib.ints(S), C, _lib.ints(pool3), int(same),
+                                   _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_maxpool3d_f32')
+    return y
+
+
+def _upsample_concat(skip, lo, up3):
+    lib = _lib.lib()
+    dev = _lib.require_device(skip, lo)
+    lo = lo.contiguous()
+    B, S1, c1 = lo.shape[0], list(lo.shape[1:4]), lo.shape[-1]
+    S = [S1[d] * up3[d] for d in range(3)]
+    c0 = 0 if skip is None else skip.shape[-1]
+    if skip is not None:
+        skip = skip.contiguous()
+        if list(skip.shape[1:4]) != S:
+            raise ValueError('concatenate: shapes %s and %s do not match' % (list(skip.shape[1:4]), S))
+    y = torch.empty([B] + S + [c0 + c1], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_upsample_concat_f32(_lib.ptr(skip), c0, _lib.ptr(lo), c1, _lib.ptr(y), B, _lib.ints(S),
+                                         _lib.ints(up3), _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_upsample_concat_f32')
+    return y
+
+
+def _conv1x1_softmax(x, kernel, bias, softmax, act):
+    lib = _lib.lib()
+    dev = _lib.require_device(x, kernel)
+    x = x.contiguous()
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    y = torch.empty(list(x.shape[:-1]) + [cout], dtype=torch.float32, device=dev)
+    w = kernel.detach().reshape(cin, cout).contiguous()
+    with torch.cuda.device(dev):
+        rc = lib.nrt_conv1x1_softmax_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias.detach()), _lib.ptr(y),
+                                         x.numel() // cin, cin, cout, int(softmax), int(act), _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_conv1x1_softmax_f32')
+    return y
+
+
+def _softmax(x):
+    lib = _lib.lib()
+    dev = _lib.require_device(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_softmax_lastdim_f32(_lib.ptr(x), _lib.ptr(y), x.numel() // x.shape[-1], x.shape[-1],
+                                         _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_softmax_lastdim_f32')
+    return y
+
+
+class ConvNet(nn.Module):
+    """
+    A built conv_enc / conv_dec / unet graph: an ordered list of named Keras-equivalent layers
+    (`self.layer_names`, `self.get_layer(name)`) executed on the HIP kernels.
+    """
+
+    def __init__(self, name, ndims, input_shapes, ops, output, modules):
+        super().__init__()
+        self.name = name
+        self.ndims = ndims
+        self.input_shapes = input_shapes            # list of per-input shapes (without batch)
+        self.ops = ops                              # list of dicts, executed in order
+        self.output_name = output
+        self.layers_by_name = nn.ModuleDict()
+        for k, m in modules.items():
+            self.layers_by_name[k] = m
+        self.layer_names = [op['name'] for op in ops]
+        self.output_shape = ops[-1].get('shape') if ops else None
+        self.conv_variant = 0                       # 0 auto, 1 direct, 2 MFMA (tests / tuning)
+
+    def get_layer(self, name):
+        if name in self.layers_by_name:
+            return self.layers_by_name[name]
+        if name in self.layer_names:
+            return self.ops[self.layer_names.index(name)]
+        raise ValueError('No such layer: %s' % name)
+
+    def _affine(self, bn):
+        scale = bn.gamma.detach() / torch.sqrt(bn.moving_variance + bn.epsilon)
+        shift = bn.beta.detach() - bn.moving_mean * scale
+        return scale.contiguous(), shift.contiguous()
+
+    def forward(self, inputs, return_tensors=None):
+        """inputs: [B, *spatial, C] (or a list for multi-input nets).  Returns the prediction tensor
+        (or a dict of the named intermediate tensors listed in return_tensors)."""
+        if isinstance(inputs, (list, tuple)):
+            xs = list(inputs)
+        else:
+            xs = [inputs]
+        if len(xs) != len(self.input_shapes):
+            raise ValueError('%s expects %d input(s), got %d' % (self.name, len(self.input_shapes), len(xs)))
+        for x, shp in zip(xs, self.input_shapes):
+            _lib.require_device(x)
+            if tuple(x.shape[1:]) != tuple(shp):
+                raise ValueError('input shape %s does not match the model input %s' % (tuple(x.shape[1:]), tuple(shp)))
+        nd = self.ndims
+        t = {}
+        keep = set(return_tensors or [])
+        with torch.no_grad():
+            for op in self.ops:
+                kind, name = op['kind'], op['name']
+                if kind == 'input':
+                    t[name] = _lift(xs[op['index']].to(torch.float32), nd)
+                elif kind == 'input_concat':
+                    t[name] = torch.cat([t[s] for s in op['src']], -1).contiguous()      # host glue (rare)
+                elif kind == 'conv':
+                    lo = t[op['lo']] if op.get('lo') else None
+                    t[name] = self.layers_by_name[name](t[op['src']], lo=lo, up=op.get('up'),
+                                                        variant=self.conv_variant)
+                elif kind == 'dropout':
+                    t[name] = t[op['src']]                                                # inference: identity
+                elif kind == 'maxpool':
+                    t[name] = _maxpool(t[op['src']], op['pool'], op['padding'])
+                elif kind == 'upsample':
+                    t[name] = _upsample_concat(None, t[op['src']], op['up'])
+                elif kind == 'merge':
+                    if op.get('fused') and name not in keep:
+                        t[name] = None            # consumed by the next conv's loader (skip + lo), never materialised
+                    else:
+                        t[name] = _upsample_concat(t[op['skip']], t[op['lo']], op['up'])
+                elif kind == 'add':
+                    t[name] = _elementwise(t[op['a']], t[op['b']])
+                elif kind == 'activation':
+                    t[name] = _elementwise(t[op['src']], act=_act_code(op['activation']))
+                elif kind == 'bn':
+                    scale, shift = self._affine(self.layers_by_name[name])
+                    t[name] = _elementwise(t[op['src']], scale=scale, shift=shift)
+                elif kind == 'likelihood':
+                    m = self.layers_by_name[name]
+                    if op.get('fuse_softmax'):
+                        t[name] = _conv1x1_softmax(t[op['src']], m.kernel, m.bias, False, 0) if name in keep else None
+                        t[op['pred_name']] = _conv1x1_softmax(t[op['src']], m.kernel, m.bias, True, 0)
+                    else:
+                        t[name] = _conv1x1_softmax(t[op['src']], m.kernel, m.bias, False, 0) \
+                            if m.cout <= 64 else m(t[op['src']])
+                elif kind == 'prediction':
+                    if name in t and t[name] is not None:
+                        pass                                    # produced by the fused likelihood
+                    elif op['activation'] == 'softmax':
+                        t[name] = _softmax(t[op['src']])
+                    else:
+                        t[name] = _elementwise(t[op['src']], act=_act_code(op['activation']))
+                else:
+                    raise RuntimeError('unknown op ' + kind)
+        if return_tensors:
+            return {k: _unlift(t[k], nd) for k in keep}
+        return _unlift(t[self.output_name], nd)
+
+
+# --------------------------------------------------------------------------------------
+# builders
+# --------------------------------------------------------------------------------------
+
+class _Builder:
+    def __init__(self, ndims):
+        self.ndims = ndims
+        self.ops = []
+        self.modules = {}
+        self.shapes = {}        # name -> (spatial3 tuple, channels)
+
+    def add(self, op, shape):
+        self.ops.append(op)
+        self.shapes[op['name']] = shape
+        op['shape'] = shape
+        return op['name']
+
+
+def _encoder(bld, nb_features, input_shape, nb_levels, conv_size, prefix, feat_mult, pool_size, dilation_rate_mult,
+             padding, activation, layer_nb_feats, use_residuals, nb_conv_per_level, conv_dropout, batch_norm,
+             src_name):
+    """neurite/tf/models.py:1360-1438.  Returns the name of the last tensor."""
+    ndims = bld.ndims
+    pool3 = _triple(pool_size, ndims, 'pool_size')
+    k3 = _triple(conv_size, ndims, 'conv_size')
+    last = src_name
+    lfidx = 0
+    for level in range(nb_levels):
+        lvl_first = last
+        if isinstance(nb_features, list):                                        # :1367-1373
+            lfidx = 0
+            if isinstance(nb_features[level], list):
+                layer_nb_feats = nb_features[level]
+                nb_conv_per_level = len(layer_nb_feats)
+            else:
+                nb_lvl_feats = nb_conv_per_level * [nb_features[level]]
+        else:
+            nb_lvl_feats = int(np.round(nb_features * feat_mult ** level))      # :1375
+        dil = dilation_rate_mult ** level                                        # :1376
+        for conv in range(nb_conv_per_level):
+            if layer_nb_feats is not None:                                       # :1379-1381
+                nb_lvl_feats = layer_nb_feats[lfidx]
+                lfidx += 1
+            name = '%s_conv_downarm_%d_%d' % (prefix, level, conv)
+            act = activation if (conv < (nb_conv_per_level - 1) or (not use_residuals)) else None   # :1384-1388
+            sp, cin = bld.shapes[last]
+            bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, dil, padding, act)
+            last = bld.add({'kind': 'conv', 'name': name, 'src': last}, (_conv_out(sp, k3, dil, padding), int(nb_lvl_feats)))
+            if conv_dropout > 0:                                                 # :1390-1399
+                name = '%s_dropout_downarm_%d_%d' % (prefix, level, conv)
+                last = bld.add({'kind': 'dropout', 'name': name, 'src': last, 'rate': conv_dropout}, bld.shapes[last])
+        if use_residuals:                                                        # :1401-1429
+            convarm = last
+            nb_in, nb_out = bld.shapes[lvl_first][1], bld.shapes[convarm][1]
+            add_layer = lvl_first
+            if nb_in > 1 and nb_out > 1 and nb_in != nb_out:
+                name = '%s_expand_down_merge_%d' % (prefix, level)
+                sp, cin = bld.shapes[lvl_first]
+                bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, dil, padding, activation)
+                add_layer = bld.add({'kind': 'conv', 'name': name, 'src': lvl_first},
+                                    (_conv_out(sp, k3, dil, padding), int(nb_lvl_feats)))
+                if conv_dropout > 0:
+                    name = '%s_dropout_down_merge_%d_%d' % (prefix, level, nb_conv_per_level - 1)
+                    bld.add({'kind': 'dropout', 'name': name, 'src': add_layer, 'rate': conv_dropout}, bld.shapes[add_layer])
+            name = '%s_res_down_merge_%d' % (prefix, level)
+            last = bld.add({'kind': 'add', 'name': name, 'a': add_layer, 'b': convarm}, bld.shapes[convarm])
+            name = '%s_res_down_merge_act_%d' % (prefix, level)
+            last = bld.add({'kind': 'activation', 'name': name, 'src': last, 'activation': activation}, bld.shapes[last])
+        if batch_norm is not None:                                               # :1431-1433
+            name = '%s_bn_down_%d' % (prefix, level)
+            bld.modules[name] = _BatchNorm(name, bld.shapes[last][1])
+            last = bld.add({'kind': 'bn', 'name': name, 'src': last, 'axis': batch_norm}, bld.shapes[last])
+        if level < (nb_levels - 1):                                              # :1436-1438
+            name = '%s_maxpool_%d' % (prefix, level)
+            sp, c = bld.shapes[last]
+            osp = tuple((sp[d] + pool3[d] - 1) // pool3[d] if padding == 'same' else sp[d] // pool3[d] for d in range(3))
+            last = bld.add({'kind': 'maxpool', 'name': name, 'src': last, 'pool': pool3, 'padding': padding}, (osp, c))
+    return last
+
+
+def _conv_out(sp, k3, dil, padding):
+    if padding == 'same':
+        return tuple(sp)
+    return tuple(sp[d] - (k3[d] - 1) * dil for d in range(3))
+
+
+def _decoder(bld, nb_features, nb_levels, conv_size, nb_labels, prefix, feat_mult, pool_size, use_skip_connections,
+             padding, dilation_rate_mult, activation, use_residuals, final_pred_activation, nb_conv_per_level,
+             layer_nb_feats, batch_norm, conv_dropout, last, enc_conv_per_level):
+    """neurite/tf/models.py:1510-1613."""
+    ndims = bld.ndims
+    pool3 = _triple(pool_size, ndims, 'pool_size')
+    k3 = _triple(conv_size, ndims, 'conv_size')
+    lfidx = 0
+    for level in range(nb_levels - 1):
+        if isinstance(nb_features, list):                                        # :1517-1524
+            lfidx = 0
+            lindex = nb_levels - level - 2
+            if isinstance(nb_features[lindex], list):
+                layer_nb_feats = nb_features[lindex]
+                nb_conv_per_level = len(layer_nb_feats)
+            else:
+                nb_lvl_feats = nb_features[lindex]
+        else:
+            nb_lvl_feats = int(np.round(nb_features * feat_mult ** (nb_levels - 2 - level)))   # :1526
+        dil = dilation_rate_mult ** (nb_levels - 2 - level)                     # :1527
+        up_name = '%s_up_%d' % (prefix, nb_levels + level)                      # :1530-1532
+        lo = last
+        sp_lo, c_lo = bld.shapes[lo]
+        sp_up = tuple(sp_lo[d] * pool3[d] for d in range(3))
+        need_up_tensor = use_residuals or not use_skip_connections
+        if need_up_tensor:
+            last = bld.add({'kind': 'upsample', 'name': up_name, 'src': lo, 'up': pool3}, (sp_up, c_lo))
+        up_tensor = last
+        fused = None
+        if use_skip_connections:                                                 # :1536-1542
+            ncpl = enc_conv_per_level[nb_levels - 2 - level] if isinstance(enc_conv_per_level, list) else enc_conv_per_level
+            conv_name = '%s_conv_downarm_%d_%d' % (prefix, nb_levels - 2 - level, ncpl - 1)
+            if conv_name not in bld.shapes:
+                raise ValueError('No such layer: %s' % conv_name)
+            sp_s, c_s = bld.shapes[conv_name]
+            if tuple(sp_s) != tuple(sp_up):
+                raise ValueError('A `Concatenate` layer requires inputs with matching shapes except for the concat axis. '
+                                 'Got inputs shapes: %s, %s' % (sp_s, sp_up))
+            name = '%s_merge_%d' % (prefix, nb_levels + level)
+            if not need_up_tensor:
+                bld.shapes[up_name] = (sp_up, c_lo)      # UpSampling3D happens inside the next conv's loader
+            fused = {'skip': conv_name, 'lo': lo, 'up': pool3}
+            last = bld.add({'kind': 'merge', 'name': name, 'skip': conv_name, 'lo': lo, 'up': pool3, 'fused': True},
+                           (sp_up, c_s + c_lo))
+        for conv in range(nb_conv_per_level):                                    # :1545-1555
+            if layer_nb_feats is not None:
+                nb_lvl_feats = layer_nb_feats[lfidx]
+                lfidx += 1
+            name = '%s_conv_uparm_%d_%d' % (prefix, nb_levels + level, conv)
+            act = activation if (conv < (nb_conv_per_level - 1) or (not use_residuals)) else None
+            sp, cin = bld.shapes[last]
+            bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, dil, padding, act)
+            op = {'kind': 'conv', 'name': name, 'src': last}
+            if conv == 0 and fused is not None:
+                op.update({'src': fused['skip'], 'lo': fused['lo'], 'up': fused['up']})
+            last = bld.add(op, (_conv_out(sp, k3, dil, padding), int(nb_lvl_feats)))
+            if conv_dropout > 0:
+                name = '%s_dropout_uparm_%d_%d' % (prefix, level, conv)
+                last = bld.add({'kind': 'dropout', 'name': name, 'src': last, 'rate': conv_dropout}, bld.shapes[last])
+        if use_residuals:                                                        # :1568-1588
+            add_layer = up_tensor
+            nb_in, nb_out = bld.shapes[add_layer][1], bld.shapes[last][1]
+            if nb_in > 1 and nb_out > 1 and nb_in != nb_out:
+                name = '%s_expand_up_merge_%d' % (prefix, level)
+                sp, cin = bld.shapes[add_layer]
+                bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, dil, padding, activation)
+                add_layer = bld.add({'kind': 'conv', 'name': name, 'src': add_layer},
+                                    (_conv_out(sp, k3, dil, padding), int(nb_lvl_feats)))
+            name = '%s_res_up_merge_%d' % (prefix, level)
+            last = bld.add({'kind': 'add', 'name': name, 'a': last, 'b': add_layer}, bld.shapes[add_layer])
+            name = '%s_res_up_merge_act_%d' % (prefix, level)
+            last = bld.add({'kind': 'activation', 'name': name, 'src': last, 'activation': activation}, bld.shapes[last])
+        if batch_norm is not None:                                               # :1590-1592
+            name = '%s_bn_up_%d' % (prefix, level)
+            bld.modules[name] = _BatchNorm(name, bld.shapes[last][1])
+            last = bld.add({'kind': 'bn', 'name': name, 'src': last, 'axis': batch_norm}, bld.shapes[last])
+
+    # likelihood (1x1 conv, no activation) and prediction  :1594-1613
+    name = '%s_likelihood' % prefix
+    sp, cin = bld.shapes[last]
+    bld.modules[name] = _Conv(name, cin, int(nb_labels), (1, 1, 1), 1, 'same', None)
+    pred = '%s_prediction' % prefix
+    fuse = final_pred_activation == 'softmax' and nb_labels <= 64
+    last = bld.add({'kind': 'likelihood', 'name': name, 'src': last, 'fuse_softmax': fuse, 'pred_name': pred},
+                   (sp, int(nb_labels)))
+    if final_pred_activation == 'softmax':
+        print("using final_pred_activation %s for %s" % (final_pred_activation, prefix))
+        act = 'softmax'
+    else:
+        act = 'linear' if final_pred_activation is None else final_pred_activation
+        _act_code(act)
+    last = bld.add({'kind': 'prediction', 'name': pred, 'src': name, 'activation': act}, (sp, int(nb_labels)))
+    return last
+
+
+def _fix_residual_adds(bld):
+    # the decoder's `add` takes (conv arm, add_layer); keep explicit operands consistent
+    for op in bld.ops:
+        if op['kind'] == 'add' and op['a'] == op['b']:
+            raise RuntimeError('degenerate residual add in ' + op['name'])
+
+
+def conv_enc(nb_features, input_shape, nb_levels, conv_size, name=None, prefix=None, feat_mult=1, pool_size=2,
+             dilation_rate_mult=1, padding='same', activation='elu', layer_nb_feats=None, use_residuals=False,
+             nb_conv_per_level=2, conv_dropout=0, batch_norm=None, convL=None, src=None, src_input=None):
+    """Fully convolutional encoder (neurite/tf/models.py:1309-1442)."""
+    if convL is not None or src is not None or src_input is not None:
+        raise NotImplementedError('convL / src / src_input are Keras-graph arguments; pass input_shape (or a list of '
+                                  'input shapes to unet) instead')
+    model_name = name
+    if prefix is None:
+        prefix = model_name
+    ndims = len(input_shape) - 1
+    if ndims < 1 or ndims > 3:
+        raise NotImplementedError('1-, 2- and 3-D networks are supported')
+    input_shape = tuple(int(s) for s in input_shape)
+    bld = _Builder(ndims)
+    in_name = '%s_input' % prefix
+    sp3 = (1,) * (3 - ndims) + input_shape[:-1]
+    bld.add({'kind': 'input', 'name': in_name, 'index': 0}, (sp3, input_shape[-1]))
+    last = _encoder(bld, nb_features, input_shape, nb_levels, conv_size, prefix, feat_mult, pool_size,
+                    dilation_rate_mult, padding, activation, layer_nb_feats, use_residuals, nb_conv_per_level,
+                    conv_dropout, batch_norm, in_name)
+    net = ConvNet(model_name, ndims, [input_shape], bld.ops, last, bld.modules)
+    net._builder_state = dict(shapes=bld.shapes, nb_conv_per_level=nb_conv_per_level, nb_levels=nb_levels,
+                              nb_features=nb_features)
+    return net
+
+
+conv_block = conv_enc
+
+
+def conv_dec(nb_features, input_shape, nb_levels, conv_size, nb_labels, name=None, prefix=None, feat_mult=1,
+             pool_size=2, use_skip_connections=False, padding='same', dilation_rate_mult=1, activation='elu',
+             use_residuals=False, final_pred_activation='softmax', nb_conv_per_level=2, layer_nb_feats=None,
+             batch_norm=None, conv_dropout=0, convL=None, input_model=None):
+    """Fully convolutional decoder (neurite/tf/models.py:1445-1617); with input_model = an encoder built by
+    conv_enc and use_skip_connections it is the U-Net."""
+    if convL is not None:
+        raise NotImplementedError('convL is a Keras-graph argument')
+    model_name = name
+    if prefix is None:
+        prefix = model_name
+    if use_skip_connections:                                                     # :1479-1480
+        assert input_model is not None, "is using skip connections, tensors dictionary is required"
+    if input_model is None:
+        ndims = len(input_shape) - 1
+        input_shape = tuple(int(s) for s in input_shape)
+        bld = _Builder(ndims)
+        in_name = '%s_input' % prefix
+        bld.add({'kind': 'input', 'name': in_name, 'index': 0}, ((1,) * (3 - ndims) + input_shape[:-1], input_shape[-1]))
+        last = in_name
+        input_shapes = [input_shape]
+        enc_ncpl = nb_conv_per_level
+    else:
+        ndims = input_model.ndims
+        bld = _Builder(ndims)
+        bld.ops = list(input_model.ops)
+        bld.modules = dict(input_model.layers_by_name.items())
+        bld.shapes = dict(input_model._builder_state['shapes'])
+        last = input_model.output_name
+        input_shapes = input_model.input_shapes
+        enc_ncpl = nb_conv_per_level
+        if isinstance(nb_features, list):
+            enc_ncpl = [len(f) if isinstance(f, list) else nb_conv_per_level for f in nb_features]
+    last = _decoder(bld, nb_features, nb_levels, conv_size, nb_labels, prefix, feat_mult, pool_size,
+                    use_skip_connections, padding, dilation_rate_mult, activation, use_residuals,
+                    final_pred_activation, nb_conv_per_level, layer_nb_feats, batch_norm, conv_dropout, last, enc_ncpl)
+    _fix_residual_adds(bld)
+    net = ConvNet(model_name, ndims, input_shapes, bld.ops, last, bld.modules)
+    net._builder_state = dict(shapes=bld.shapes)
+    return net
+
+
+def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None, feat_mult=1,
+         pool_size=2, use_logp=True, padding='same', dilation_rate_mult=1, activation='elu', use_residuals=False,
+         final_pred_activation='softmax', nb_conv_per_level=1, add_prior_layer=False, add_prior_layer_reg=0,
+         layer_nb_feats=None, conv_dropout=0, batch_norm=None):
+    """unet-style model with the reference's parametrisation (neurite/tf/models.py:88-246)."""
+    model_name = name
+    if prefix is None:
+        prefix = model_name
+    if add_prior_layer:
+        raise NotImplementedError('add_prior_layer (models.add_prior, models.py:378) is outside the hot path')
+    multi = isinstance(input_shape[0], (tuple, list, np.ndarray))
+    if multi:                                                                    # :155-170
+        shapes = [tuple(int(v) for v in s) for s in input_shape]
+        for s in shapes:
+            if not np.array_equal(s[:-1], shapes[0][:-1]):
+                raise ValueError('spatial dimensions must match if multiple input shapes '
+                                 'are provided, but got shapes '
+                                 f'{shapes[0][:-1]} and {s[:-1]}')
+        first = shapes[0]
+    else:
+        shapes = [tuple(int(v) for v in input_shape)]
+        first = shapes[0]
+    ndims = len(first) - 1
+    if isinstance(nb_features, list):                                            # :179-190
+        if nb_levels is not None:
+            warnings.warn('nb_levels is not None while ' + 'nb_features list of lists specified - overriding')
+        if feat_mult is not None:
+            warnings.warn('feat_mult is not None while ' + 'nb_features list of lists specified - overriding')
+        nb_levels = len(nb_features)
+        assert isinstance(nb_features[0], list), \
+            'nb_features must be a scalar or a list of lists (not a list of scalars)'
+
+    if ndims < 1 or ndims > 3:
+        raise NotImplementedError('1-, 2- and 3-D networks are supported')
+    bld = _Builder(ndims)
+    if multi:
+        names = []
+        for i, s in enumerate(shapes):
+            n = f'{prefix}_input_{i}'
+            bld.add({'kind': 'input', 'name': n, 'index': i}, ((1,) * (3 - ndims) + s[:-1], s[-1]))
+            names.append(n)
+        src = bld.add({'kind': 'input_concat', 'name': f'{prefix}_input_concat', 'src': names},
+                      ((1,) * (3 - ndims) + first[:-1], sum(s[-1] for s in shapes)))
+    else:
+        src = bld.add({'kind': 'input', 'name': '%s_input' % prefix, 'index': 0},
+                      ((1,) * (3 - ndims) + first[:-1], first[-1]))
+    last = _encoder(bld, nb_features, first, nb_levels, conv_size, prefix, feat_mult, pool_size, dilation_rate_mult,
+                    padding, activation, layer_nb_feats, use_residuals, nb_conv_per_level, conv_dropout, batch_norm, src)
+    lnf = layer_nb_feats[(nb_levels * nb_conv_per_level):] if layer_nb_feats is not None else None      # :214
+    enc_ncpl = nb_conv_per_level
+    if isinstance(nb_features, list):
+        enc_ncpl = [len(f) for f in nb_features]
+    last = _decoder(bld, nb_features, nb_levels, conv_size, nb_labels, prefix, feat_mult, pool_size, 1, padding,
+                    dilation_rate_mult, activation, use_residuals, final_pred_activation, nb_conv_per_level, lnf,
+                    batch_norm, conv_dropout, last, enc_ncpl)
+    _fix_residual_adds(bld)
+    net = ConvNet(model_name, ndims, shapes, bld.ops, last, bld.modules)
+    net._builder_state = dict(shapes=bld.shapes)
+    return net

@@ -1,0 +1,218 @@
+"""
+GPU parity tests of the unet layers (Conv3D on MFMA, pooling, fused upsample+concat, 1x1+softmax head) and of
+the assembled models.unet against the CPU oracle.  Tolerance (floating point, north_star): 1e-5 relative --
+written as allclose(rtol=1e-5, atol=1e-5 * max|ref|) per tensor (fp32 accumulation over K <= 2592 vs float64).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import neurite_amd as ne
+from neurite_amd import models as nm
+from oracle import c_oracle as co
+from oracle import unet_oracle as uo
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def close(got, ref, tol=1e-5):
+    ref = np.asarray(ref, np.float64)
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1e-30, np.abs(ref).max()))
+
+
+def set_weights(conv, rng, scale=None):
+    k = conv.kernel.shape
+    fan = int(np.prod(k[:-1]))
+    w = (rng.standard_normal(k) * (scale or 1.0 / np.sqrt(fan))).astype(F)
+    b = (rng.standard_normal(k[-1]) * 0.1).astype(F)
+    with torch.no_grad():
+        conv.kernel.copy_(torch.from_numpy(w))
+        conv.bias.copy_(torch.from_numpy(b))
+    return w, b
+
+
+@pytest.mark.parametrize('cin,cout,shape,k,dil,act', [
+    (16, 16, (9, 7, 21), (3, 3, 3), 1, 'elu'), (48, 16, (8, 8, 32), (3, 3, 3), 1, 'elu'),
+    (32, 64, (6, 10, 17), (3, 3, 3), 1, None), (16, 32, (12, 5, 16), (3, 3, 3), 2, 'elu'),
+    (24, 5, (7, 9, 18), (3, 3, 3), 1, 'relu'), (16, 40, (5, 6, 19), (1, 3, 3), 1, 'elu'),
+    (64, 16, (4, 4, 16), (1, 1, 1), 1, None), (8, 16, (10, 10, 10), (3, 3, 3), 1, 'elu'),
+])
+def test_conv3d_mfma_vs_oracle(dev, cin, cout, shape, k, dil, act):
+    rng = np.random.default_rng(cin * 100 + cout)
+    conv = nm._Conv('c', cin, cout, k, dil, 'same', act).to(dev)
+    w, b = set_weights(conv, rng)
+    x = rng.standard_normal((2,) + shape + (cin,)).astype(F)
+    for variant in (2, 1):                       # MFMA implicit GEMM, direct
+        y = N(conv(G(x, dev), variant=variant))
+        for bi in range(2):
+            if k == (3, 3, 3) or k == (1, 1, 1) or k == (1, 3, 3):
+                ref = co.conv3d_same(x[bi], w, b, dilation=dil, elu=False).astype(np.float64)
+                ref = uo.elu(ref) if act == 'elu' else (np.maximum(ref, 0) if act == 'relu' else ref)
+                close(y[bi], ref)
+
+
+def test_conv3d_fused_upsample_concat(dev):
+    rng = np.random.default_rng(3)
+    for (c0, c1, cout, S) in ((32, 64, 32, (8, 12, 16)), (16, 32, 16, (10, 6, 18)), (4, 12, 7, (6, 6, 6))):
+        conv = nm._Conv('c', c0 + c1, cout, (3, 3, 3), 1, 'same', 'elu').to(dev)
+        w, b = set_weights(conv, rng)
+        skip = rng.standard_normal((2,) + S + (c0,)).astype(F)
+        lo = rng.standard_normal((2,) + tuple(s // 2 for s in S) + (c1,)).astype(F)
+        cat = np.concatenate([skip, lo.repeat(2, 1).repeat(2, 2).repeat(2, 3)], -1)
+        mat = N(nm._upsample_concat(G(skip, dev), G(lo, dev), (2, 2, 2)))
+        assert np.array_equal(mat, cat)
+        for variant in (2, 1):
+            y = N(conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2), variant=variant))
+            y2 = N(conv(G(cat, dev), variant=variant))
+            for bi in range(2):
+                close(y[bi], uo.conv(cat[bi], w, b, 'elu'))
+            np.testing.assert_allclose(y, y2, rtol=1e-6, atol=1e-6)
+
+
+def test_direct_conv_shapes(dev):
+    """First layer (Cin = 1), odd channel counts, VALID padding, large dilation: the direct kernel."""
+    rng = np.random.default_rng(8)
+    for (cin, cout, S, k, dil, pad) in ((1, 16, (12, 11, 20), (3, 3, 3), 1, 'same'), (3, 5, (9, 8, 7), (3, 3, 3), 1, 'valid'),
+                                        (2, 70, (6, 7, 8), (3, 3, 3), 1, 'same'), (4, 4, (14, 13, 12), (3, 3, 3), 4, 'same'),
+                                        (5, 3, (6, 6, 9), (2, 2, 2), 1, 'same')):
+        conv = nm._Conv('c', cin, cout, k, dil, pad, 'elu').to(dev)
+        w, b = set_weights(conv, rng)
+        x = rng.standard_normal((1,) + S + (cin,)).astype(F)
+        y = N(conv(G(x, dev)))[0]
+        xt = torch.from_numpy(x).permute(0, 4, 1, 2, 3).double()
+        wt = torch.from_numpy(w).permute(4, 3, 0, 1, 2).double()
+        if pad == 'same':
+            tot = [(kk - 1) * dil for kk in k]
+            padding = []
+            for tpad in reversed(tot):                       # F.pad order: last dim first; TF pads floor before
+                padding += [tpad // 2, tpad - tpad // 2]
+            xt = torch.nn.functional.pad(xt, padding)
+        ref = torch.nn.functional.conv3d(xt, wt, torch.from_numpy(b).double(), dilation=dil)
+        ref = torch.where(ref > 0, ref, torch.exp(ref) - 1)[0].permute(1, 2, 3, 0).numpy()
+        close(y, ref)
+
+
+def test_pool_softmax_head_elementwise(dev):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 9, 8, 7, 5)).astype(F)
+    for pool in ((2, 2, 2), (3, 1, 2)):
+        got = N(nm._maxpool(G(x, dev), pool, 'same'))
+        for b in range(2):
+            assert np.array_equal(got[b], uo.maxpool_same(x[b], pool))
+        gotv = N(nm._maxpool(G(x, dev), pool, 'valid'))
+        ox, oy, oz = [s // p for s, p in zip(x.shape[1:4], pool)]
+        ref = x[:, :ox * pool[0], :oy * pool[1], :oz * pool[2]].reshape(2, ox, pool[0], oy, pool[1], oz, pool[2], 5).max((2, 4, 6))
+        assert np.array_equal(gotv, ref)
+    z = (rng.standard_normal((3, 11, 13, 33)) * 4).astype(F)
+    e = np.exp(z.astype(np.float64) - z.max(-1, keepdims=True))
+    close(N(nm._softmax(G(z, dev))), e / e.sum(-1, keepdims=True))
+    for cin, cout in ((16, 32), (16, 4), (7, 50)):
+        k = (rng.standard_normal((1, 1, 1, cin, cout)) / np.sqrt(cin)).astype(F)
+        bb = rng.standard_normal(cout).astype(F)
+        xin = rng.standard_normal((2, 5, 6, 7, cin)).astype(F)
+        lin = xin.astype(np.float64) @ k.reshape(cin, cout).astype(np.float64) + bb
+        close(N(nm._conv1x1_softmax(G(xin, dev), G(k, dev), G(bb, dev), False, 0)), lin)
+        e = np.exp(lin - lin.max(-1, keepdims=True))
+        close(N(nm._conv1x1_softmax(G(xin, dev), G(k, dev), G(bb, dev), True, 0)), e / e.sum(-1, keepdims=True))
+    a, b2 = rng.standard_normal((2, 4, 4, 4, 6)).astype(F), rng.standard_normal((2, 4, 4, 4, 6)).astype(F)
+    sc, sh = rng.standard_normal(6).astype(F), rng.standard_normal(6).astype(F)
+    close(N(nm._elementwise(G(a, dev), G(b2, dev), act=1)), uo.elu(a.astype(np.float64) + b2))
+    close(N(nm._elementwise(G(a, dev), scale=G(sc, dev), shift=G(sh, dev))), a.astype(np.float64) * sc + sh)
+
+
+def _randomise(model, rng):
+    weights, bns = {}, {}
+    for name, m in model.layers_by_name.items():
+        if isinstance(m, nm._Conv):
+            weights[name] = set_weights(m, rng)
+        else:
+            C = m.gamma.shape[0]
+            p = [(1 + 0.1 * rng.standard_normal(C)).astype(F), (0.1 * rng.standard_normal(C)).astype(F),
+                 (0.1 * rng.standard_normal(C)).astype(F), (1 + 0.1 * rng.random(C)).astype(F)]
+            with torch.no_grad():
+                m.gamma.copy_(torch.from_numpy(p[0])); m.beta.copy_(torch.from_numpy(p[1]))
+                m.moving_mean.copy_(torch.from_numpy(p[2])); m.moving_variance.copy_(torch.from_numpy(p[3]))
+            bns[name] = p
+    return weights, bns
+
+
+def test_unet_small_configs_vs_oracle(dev):
+    rng = np.random.default_rng(11)
+    # (kwargs, input shape) -- default topology, 2 convs per level, residual + batch-norm, 2-D
+    cases = [
+        (dict(nb_features=8, nb_levels=3, conv_size=3, nb_labels=6, feat_mult=2), (24, 20, 28, 1), {}),
+        (dict(nb_features=8, nb_levels=3, conv_size=3, nb_labels=4, feat_mult=2, nb_conv_per_level=2), (16, 16, 24, 2), {}),
+        (dict(nb_features=8, nb_levels=2, conv_size=3, nb_labels=3, feat_mult=2, nb_conv_per_level=2, use_residuals=True,
+              batch_norm=-1, conv_dropout=0.2), (12, 16, 20, 2), dict(use_residuals=True)),
+        (dict(nb_features=16, nb_levels=3, conv_size=3, nb_labels=5, feat_mult=1, final_pred_activation='linear'),
+         (18, 21, 1), {}),          # odd sizes: SAME max-pool keeps partial windows -> skip shapes must still match
+    ]
+    for kw, ishape, okw in cases:
+        if ishape == (18, 21, 1):
+            ishape = (16, 24, 1)                         # 2-D net
+        model = ne.models.unet(input_shape=ishape, **kw).to(dev)
+        weights, bns = _randomise(model, rng)
+        x = rng.standard_normal((2,) + ishape).astype(F)
+        y = N(model(G(x, dev)))
+        assert y.shape == (2,) + ishape[:-1] + (kw['nb_labels'],)
+        nd = len(ishape) - 1
+        for b in range(2):
+            xb = x[b].reshape((1,) * (3 - nd) + ishape)
+            w3 = {n: (k.reshape((1,) * (3 - nd) + k.shape) if k.ndim < 5 else k, bb) for n, (k, bb) in weights.items()}
+            ref = uo.unet_forward(xb, w3, kw['nb_levels'], kw.get('nb_conv_per_level', 1), pool=(1,) * (3 - nd) + (2,) * nd,
+                                  bn_params=bns or None, final_pred_activation=kw.get('final_pred_activation', 'softmax'),
+                                  **okw)
+            close(y[b].reshape(ref.shape), ref, tol=2e-5)
+        if 'final_pred_activation' not in kw:
+            np.testing.assert_allclose(y.sum(-1), 1.0, rtol=1e-5)
+        # MFMA and direct kernels agree
+        model.conv_variant = 1
+        y1 = N(model(G(x, dev)))
+        model.conv_variant = 0
+        np.testing.assert_allclose(y, y1, rtol=1e-4, atol=1e-5)
+
+
+def test_unet_layer_names_and_errors(dev):
+    m = ne.models.unet(16, (32, 32, 32, 1), 3, 3, 4, feat_mult=2)
+    assert m.layer_names == ['unet_input', 'unet_conv_downarm_0_0', 'unet_maxpool_0', 'unet_conv_downarm_1_0',
+                             'unet_maxpool_1', 'unet_conv_downarm_2_0', 'unet_merge_3', 'unet_conv_uparm_3_0',
+                             'unet_merge_4', 'unet_conv_uparm_4_0', 'unet_likelihood', 'unet_prediction']
+    assert tuple(m.get_layer('unet_conv_uparm_3_0').kernel.shape) == (3, 3, 3, 96, 32)
+    assert tuple(m.get_layer('unet_conv_uparm_4_0').kernel.shape) == (3, 3, 3, 48, 16)
+    with pytest.raises(ne.errors.NeuriteAmdError):
+        m(torch.zeros(1, 32, 32, 32, 1))
+    with pytest.raises(ValueError, match='spatial dimensions must match'):
+        ne.models.unet(4, [(8, 8, 8, 1), (8, 8, 4, 1)], 2, 3, 2)
+    with pytest.raises(AssertionError, match='list of lists'):
+        ne.models.unet([4, 8], (8, 8, 8, 1), None, 3, 2, feat_mult=None)
+    with pytest.raises(NotImplementedError):
+        ne.models.unet(4, (8, 8, 8, 1), 2, 3, 2, add_prior_layer=True)
+    # multi-input and intermediate tensors
+    mi = ne.models.unet(4, [(8, 8, 8, 1), (8, 8, 8, 2)], 2, 3, 2).to(dev)
+    out = mi([torch.randn(1, 8, 8, 8, 1, device=dev), torch.randn(1, 8, 8, 8, 2, device=dev)],
+             return_tensors=['unet_merge_2', 'unet_likelihood', 'unet_prediction'])
+    assert out['unet_merge_2'].shape == (1, 8, 8, 8, 8) and out['unet_likelihood'].shape == (1, 8, 8, 8, 2)
+
+
+def test_unet_cfg3_full_size(dev):
+    """BASELINE config 3: unet(16, (160,160,160,1), 3, 3, nb_labels=32, feat_mult=2) forward on 160^3 fp32."""
+    rng = np.random.default_rng(5)
+    model = ne.models.unet(16, (160, 160, 160, 1), 3, 3, 32, feat_mult=2).to(dev)
+    weights, _ = _randomise(model, rng)
+    x = np.random.default_rng(4).standard_normal((1, 160, 160, 160, 1)).astype(F)
+    names = ['unet_conv_downarm_0_0', 'unet_conv_downarm_1_0', 'unet_conv_downarm_2_0', 'unet_conv_uparm_3_0',
+             'unet_conv_uparm_4_0', 'unet_prediction']
+    out = model(G(x, dev), return_tensors=names)
+    ref = uo.unet_forward(x[0], weights, 3, 1, return_all=True)
+    for n in names:
+        close(N(out[n])[0], ref[n], tol=2e-5)
