@@ -59,6 +59,8 @@ def parse():
     ap.add_argument('--tune', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sweep', action='store_true', help='time every interpn kernel variant and exit')
+    ap.add_argument('--unet', action='store_true', help='only run the unet forward benchmark (BASELINE config 3)')
+    ap.add_argument('--no-unet', action='store_true', help='skip the unet forward measurement in the default run')
     ap.add_argument('--unfused', action='store_true', help='run the drop-in two-kernel pipeline instead of the fused kernel')
     return ap.parse_args()
 
@@ -230,6 +232,68 @@ def sweep(args, dev, mov, fix, trf):
         json.dump(res, f, indent=1)
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
+
+
+def unet_bench(dev, size=160, labels=32, nb_conv_per_level=1, reps=20, warmup=5):
+    """BASELINE config 3: unet(16, (160,160,160,1), 3, 3, nb_labels, feat_mult=2) forward on one fp32 volume.
+    Returns total forward ms (median) and per-conv-layer time / TFLOP/s / fraction of the fp32 MFMA peak."""
+    import neurite_amd as ne
+    torch.manual_seed(5)
+    model = ne.models.unet(16, (size, size, size, 1), 3, 3, labels, feat_mult=2, nb_conv_per_level=nb_conv_per_level).to(dev)
+    x = torch.randn(1, size, size, size, 1, device=dev)
+    for _ in range(warmup):
+        y = model(x)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        y = model(x)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    total = float(np.median(times))
+    # per-layer timing: run the graph op by op with events (same kernels, same tensors)
+    layers = []
+    t = {}
+    with torch.no_grad():
+        for op in model.ops:
+            kind, name = op['kind'], op['name']
+            if kind != 'conv':
+                continue
+            m = model.layers_by_name[name]
+            sp, cin = op['shape'][0], m.cin
+            flops = 2.0 * sp[0] * sp[1] * sp[2] * m.ksize3[0] * m.ksize3[1] * m.ksize3[2] * m.cin * m.cout
+            layers.append({'name': name, 'cin': m.cin, 'cout': m.cout, 'shape': list(sp), 'gflop': round(flops / 1e9, 2)})
+    inter = model(x, return_tensors=[l['name'] for l in layers] + [o['name'] for o in model.ops if o['kind'] == 'maxpool'])
+    for l in layers:
+        op = model.ops[model.layer_names.index(l['name'])]
+        m = model.layers_by_name[l['name']]
+        src = x.reshape(1, size, size, size, 1) if op['src'].endswith('_input') else inter[op['src']]
+        lo = inter[op['lo']] if op.get('lo') else None
+        for _ in range(3):
+            m(src, lo=lo, up=op.get('up'))
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for _ in range(10):
+            m(src, lo=lo, up=op.get('up'))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        l['ms'] = round(ms, 4)
+        l['tflops'] = round(l['gflop'] / ms, 2)
+        l['frac_of_fp32_mfma_peak'] = round(l['gflop'] / ms / MFMA_F32_PEAK_TFLOPS, 4)
+    mf = [l for l in layers if l['cin'] >= 8]
+    gf = sum(l['gflop'] for l in mf)
+    ms = sum(l['ms'] for l in mf)
+    return {'config': 'BASELINE config 3: unet(16, (%d,%d,%d,1), 3, 3, nb_labels=%d, feat_mult=2, nb_conv_per_level=%d), fp32, batch 1'
+                      % (size, size, size, labels, nb_conv_per_level),
+            'fwd_ms': round(total, 3), 'fwd_ms_min': round(float(np.min(times)), 3), 'layers': layers,
+            'mfma_layers': {'gflop': round(gf, 1), 'ms': round(ms, 3), 'tflops': round(gf / ms, 1),
+                            'frac_of_fp32_mfma_peak': round(gf / ms / MFMA_F32_PEAK_TFLOPS, 4)}}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -260,6 +324,11 @@ def main():
 
     if args.sweep:
         sweep(args, dev, mov, fix, trf)
+        return
+    if args.unet:
+        del mov, fix, trf
+        for ncpl in (1, 2):
+            log(json.dumps(unet_bench(dev, nb_conv_per_level=ncpl)))
         return
 
     st = ne.layers.SpatialTransformer(interp_method='linear')
@@ -410,6 +479,13 @@ def main():
         except Exception as e:   # noqa
             out['cpu_baseline'] = {'value': None, 'unit': 'Mvoxels/s', 'cores': 0, 'kind': 'port',
                                    'sample': 'failed: %s' % e}
+    if world == 1 and not args.no_unet:
+        try:
+            del mov, fix, trf
+            torch.cuda.empty_cache()
+            out['unet_fwd'] = unet_bench(dev)
+        except Exception as e:   # noqa
+            out['unet_fwd'] = {'error': str(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
