@@ -294,6 +294,40 @@ def unet_bench(dev, size=160, labels=32, nb_conv_per_level=1, reps=20, warmup=5)
                             'frac_of_fp32_mfma_peak': round(gf / ms / MFMA_F32_PEAK_TFLOPS, 4)}}
 
 
+def lc3d_bench(dev, reps=10):
+    """BASELINE config 5: LocallyConnected3D 3x3x3 on [1, 96, 96, 96, 16] bf16 (+ weighted CCE on the output)."""
+    import neurite_amd as ne
+    torch.manual_seed(6)
+    x = torch.randn(1, 96, 96, 96, 16, device=dev, dtype=torch.bfloat16)
+    layer = ne.layers.LocallyConnected3D(16, (3, 3, 3))
+    with torch.no_grad():
+        y = layer(x)
+        layer.kernel.normal_(0, 1.0 / np.sqrt(432))
+        lab = torch.randint(0, 16, (1, 94, 94, 94), device=dev)
+        t = torch.nn.functional.one_hot(lab, 16).to(torch.bfloat16)
+        w = np.linspace(0.5, 1.5, 16).astype(np.float32)
+        cce = ne.metrics.WeightedCategoricalCrossentropy(label_weights=w, from_logits=True)
+        for _ in range(2):
+            y = layer(x)
+            cce(t, y)
+        e = [torch.cuda.Event(True) for _ in range(3)]
+        e[0].record()
+        for _ in range(reps):
+            y = layer(x)
+        e[1].record()
+        for _ in range(reps):
+            l = cce(t, y)
+        e[2].record()
+        torch.cuda.synchronize()
+    ms = e[0].elapsed_time(e[1]) / reps
+    ms2 = e[1].elapsed_time(e[2]) / reps
+    nbytes = layer.kernel.numel() * 2 + x.numel() * 2 + y.numel() * 2 + layer.bias.numel() * 2
+    return {'config': 'BASELINE config 5: LocallyConnected3D(16, 3x3x3) on [1,96,96,96,16] bf16 + weighted CCE',
+            'lc3d_ms': round(ms, 4), 'algorithmic_GB': round(nbytes / 1e9, 3), 'GBs': round(nbytes / ms / 1e6, 1),
+            'frac_of_hbm_peak': round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+            'wcce_ms': round(ms2, 4), 'wcce_GBs': round(2 * 2 * 16 * 94 ** 3 / ms2 / 1e6, 1), 'loss': round(float(l), 5)}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -329,6 +363,7 @@ def main():
         del mov, fix, trf
         for ncpl in (1, 2):
             log(json.dumps(unet_bench(dev, nb_conv_per_level=ncpl)))
+        log(json.dumps(lc3d_bench(dev)))
         return
 
     st = ne.layers.SpatialTransformer(interp_method='linear')
@@ -486,6 +521,10 @@ def main():
             out['unet_fwd'] = unet_bench(dev)
         except Exception as e:   # noqa
             out['unet_fwd'] = {'error': str(e)}
+        try:
+            out['lc3d_wcce'] = lc3d_bench(dev)
+        except Exception as e:   # noqa
+            out['lc3d_wcce'] = {'error': str(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

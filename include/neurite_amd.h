@@ -209,6 +209,19 @@ int nrt_add_act_affine_f32(const float *a, const float *b, const float *scale, c
                            float *y, long long n, int channels, int activation, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * LocallyConnected3D, implementation 1 ('valid' padding, channels-last)
+ * replaces: neurite/tf/layers.py:1126-1197 (local_conv: O slice ops + concat + K.batch_dot) and the
+ * bias / activation of :1098-1101.
+ *   x [batch, in_shape, cin]; kernel [O, kr*kc*kz*cin, cout] (feature order kr,kc,kz,cin; O = output
+ *   positions row-major); bias [O, cout] or NULL; y [batch, out_shape, cout]; all of `dtype`
+ *   (NRT_DT_F32 or NRT_DT_BF16), accumulation in float32.  Weights are read exactly once.
+ * variant 0 auto | 1 generic | 2 weight-streaming wave-per-position kernel.
+ * ------------------------------------------------------------------------------------------ */
+int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, void *y, int dtype, int batch,
+               const int *in_shape, int cin, const int *ksize, const int *strides, int cout,
+               int activation, int variant, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or
  * non-temporal; calibrates the achievable mixed read/write HBM rate next to the kernels above.
  * ------------------------------------------------------------------------------------------ */

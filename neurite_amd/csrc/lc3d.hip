@@ -1,0 +1,217 @@
+// LocallyConnected3D (implementation 1) for gfx950 (MI355X).
+//
+// Replaces neurite/tf/layers.py:1126-1197: the reference builds O = prod(out_dims) Python-level slice
+// ops (830 584 at 96^3 / k=3), concatenates them into a [O, B, F] tensor (27 copies of the input) and
+// runs one K.batch_dot([O,B,F],[O,F,Cout]).  Here: out[b,o,:] = patch[b,o,:] @ kernel[o] + bias[o] with
+//   * the un-shared weights kernel[O, F, Cout] streamed from HBM exactly once (non-temporal 16-byte
+//     loads; at BASELINE config 5 they are 11.5 GB of bf16 -- the whole cost, AI ~ 1 flop/byte);
+//   * the input patch gathered straight from the (L2-resident, 28 MB) input volume -- never unfolded;
+//   * fp32 accumulation; bias + activation fused; output in the input dtype.
+// One wave64 per output position: lane l owns the 16-byte slice (l % LPR) of weight rows
+// f = l / LPR, l / LPR + 64/LPR, ...  (LPR = lanes per weight row = Cout * itemsize / 16), so each wave
+// instruction reads 1 KiB of contiguous weights; the per-lane partial sums are combined with wave
+// xor-shuffles.  All weight loads of a position are issued before the first use (deep MLP).
+// F order (kr, kc, kz, cin) row-major (layers.py:1179-1186), positions row-major (:1172-1173).
+
+#include "nrt_common.h"
+
+namespace {
+
+struct LcArgs {
+    const void *x;        // [B, R, C, Z, Cin]
+    const void *k;        // [O, F, Cout]
+    const void *bias;     // [O, Cout] or null
+    void *y;              // [B, or, oc, oz, Cout]
+    int B, R, C, Z, Cin;
+    int kr, kc, kz, sr, sc, sz;
+    int orr, occ, ozz, Cout;
+    int act;
+};
+
+__device__ __forceinline__ float to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                   // round to nearest even
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
+__device__ __forceinline__ void store_out(unsigned short *p, float v) { *p = f32_to_bf16(v); }
+
+__device__ __forceinline__ float lc_act(float v, int act) {
+    if (act == 1) return v > 0.0f ? v : (expf(v) - 1.0f);
+    if (act == 2) return fmaxf(v, 0.0f);
+    return v;
+}
+
+// T = float or unsigned short (bf16 bits); VEC = elements per 16-byte load; NB = batch entries per pass
+template <typename T, int NB, int MAXIT>
+__global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int LPR = a.Cout / VEC;                  // lanes per weight row (power of two, <= 64)
+    const int RPW = 64 / LPR;                      // weight rows per wave iteration
+    const int F = a.kr * a.kc * a.kz * a.Cin;
+    const int nit = (F + RPW - 1) / RPW;           // <= MAXIT
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    const int lane = threadIdx.x & 63;
+    const int sl = lane % LPR, row0 = lane / LPR;
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    const T *xb = (const T *)a.x;
+    // a lane touches the same patch elements f = it * RPW + row0 at every position: their offsets
+    // relative to the patch origin are computed once (the divisions are not in the streaming loop)
+    int xoff[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int f = it * RPW + row0;
+        const int ff = ((it < nit) && (f < F)) ? f : F - 1;   // dead slots re-read a valid element (no branch around loads)
+        const int ci = ff % a.Cin, tap = ff / a.Cin;
+        const int dz = tap % a.kz, dc = (tap / a.kz) % a.kc, dr = tap / (a.kz * a.kc);
+        xoff[it] = ((dr * a.C + dc) * a.Z + dz) * a.Cin + ci;
+    }
+    // weight slice of (row f, slice sl) sits at byte ((f * LPR + sl) * 16) of the position's block; rows advance
+    // by RPW per iteration = 1 KiB, so one base offset per lane + constants; dead rows are clamped to the last row
+    const unsigned wlast = ((unsigned)(F - 1) * (unsigned)LPR + (unsigned)sl) * 16u;
+    const unsigned w0 = (unsigned)lane * 16u;
+    const long long xbs = (long long)a.R * a.C * a.Z * a.Cin;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform: weights via SGPR base
+    for (long long o = (long long)blockIdx.x * (blockDim.x >> 6) + wave; o < O; o += nwaves) {
+        const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
+        const long long xbase = (((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin;
+        const char *kp = (const char *)((const T *)a.k + o * (long long)F * a.Cout);
+        // ---- issue every load of this position before the first use (unconditional: exact vmcnt accounting)
+        vec_t w[MAXIT];
+        T xr[NB][MAXIT];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const unsigned off = w0 + (unsigned)it * 1024u;
+            w[it] = __builtin_nontemporal_load((const vec_t *)(kp + min(off, wlast)));
+        }
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) xr[b][it] = xb[(long long)(b0 + (b < nb ? b : 0)) * xbs + xbase + xoff[it]];
+        __builtin_amdgcn_sched_barrier(0);
+        float acc[NB][VEC];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[b][e] = 0.0f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const bool live = (it < nit) && (it * RPW + row0 < F);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float xv = live ? to_f32(xr[b][it]) : 0.0f;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[b][e] = fmaf(xv, to_f32(w[it][e]), acc[b][e]);
+            }
+        }
+        // ---- combine the 64 / LPR row slices ----------------------------------------------------
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                for (int off = LPR; off < 64; off <<= 1) acc[b][e] += __shfl_xor(acc[b][e], off, 64);
+        if (lane < LPR) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (b < nb) {
+                    T *yp = (T *)a.y + ((long long)(b0 + b) * O + o) * a.Cout + sl * VEC;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        float v = acc[b][e];
+                        if (a.bias) v += to_f32(((const T *)a.bias)[o * a.Cout + sl * VEC + e]);
+                        store_out(yp + e, lc_act(v, a.act));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// any Cout / F: one thread per (position, cout)
+template <typename T>
+__global__ __launch_bounds__(256) void lc3d_generic(LcArgs a) {
+    const int F = a.kr * a.kc * a.kz * a.Cin;
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    const long long total = O * a.Cout;
+    const T *xb = (const T *)a.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(e % a.Cout);
+        const long long o = e / a.Cout;
+        const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
+        const T *kp = (const T *)a.k + o * (long long)F * a.Cout + co;
+        for (int b = 0; b < a.B; ++b) {
+            float acc = 0.0f;
+            for (int f = 0; f < F; ++f) {
+                const int ci = f % a.Cin, tap = f / a.Cin;
+                const int dz = tap % a.kz, dc = (tap / a.kz) % a.kc, dr = tap / (a.kz * a.kc);
+                const long long xi = ((((long long)b * a.R + (orr * a.sr + dr)) * a.C + (oc * a.sc + dc)) * a.Z + (oz * a.sz + dz)) * a.Cin + ci;
+                acc = fmaf(to_f32(xb[xi]), to_f32(kp[(long long)f * a.Cout]), acc);
+            }
+            if (a.bias) acc += to_f32(((const T *)a.bias)[o * a.Cout + co]);
+            store_out((T *)a.y + ((long long)b * O + o) * a.Cout + co, lc_act(acc, a.act));
+        }
+    }
+}
+
+template <typename T, int MAXIT>
+void launch_vec(const LcArgs &a, hipStream_t st) {
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    unsigned blocks = (unsigned)((O + 3) / 4);
+    if (blocks > 256u * 8u) blocks = 256u * 8u;
+    for (int b0 = 0; b0 < a.B; b0 += 4) {
+        const int nb = a.B - b0 < 4 ? a.B - b0 : 4;
+        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+    }
+}
+
+template <typename T>
+int launch_any(const LcArgs &a, int variant, hipStream_t st) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int F = a.kr * a.kc * a.kz * a.Cin;
+    bool vec_ok = (a.Cout % VEC) == 0;
+    int LPR = vec_ok ? a.Cout / VEC : 0;
+    vec_ok = vec_ok && LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0 && (((uintptr_t)a.k) & 15) == 0;
+    int nit = vec_ok ? (F + (64 / LPR) - 1) / (64 / LPR) : 0;
+    vec_ok = vec_ok && nit <= 32;
+    if (variant == 0) variant = vec_ok ? 2 : 1;
+    if (variant == 2) {
+        if (!vec_ok) return NRT_ERR_UNSUPPORTED;
+        if (nit <= 8) launch_vec<T, 8>(a, st);
+        else if (nit <= 16) launch_vec<T, 16>(a, st);
+        else launch_vec<T, 32>(a, st);
+    } else {
+        const long long total = (long long)a.orr * a.occ * a.ozz * a.Cout;
+        unsigned blocks = (unsigned)((total + 255) / 256);
+        if (blocks > 256u * 16u) blocks = 256u * 16u;
+        hipLaunchKernelGGL((lc3d_generic<T>), dim3(blocks), dim3(256), 0, st, a);
+    }
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+}  // namespace
+
+extern "C" int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, void *y, int dtype, int batch,
+                          const int *in_shape, int cin, const int *ksize, const int *strides, int cout, int activation,
+                          int variant, void *stream) {
+    if (!x || !kernel || !y || !in_shape || !ksize || !strides) return NRT_ERR_INVALID_ARG;
+    if (batch < 1 || cin < 1 || cout < 1) return NRT_ERR_INVALID_ARG;
+    if (dtype != NRT_DT_F32 && dtype != NRT_DT_BF16) return NRT_ERR_UNSUPPORTED;
+    LcArgs a;
+    a.x = x; a.k = kernel; a.bias = bias; a.y = y; a.B = batch;
+    a.R = in_shape[0]; a.C = in_shape[1]; a.Z = in_shape[2]; a.Cin = cin;
+    a.kr = ksize[0]; a.kc = ksize[1]; a.kz = ksize[2]; a.sr = strides[0]; a.sc = strides[1]; a.sz = strides[2];
+    if (a.kr < 1 || a.kc < 1 || a.kz < 1 || a.sr < 1 || a.sc < 1 || a.sz < 1) return NRT_ERR_INVALID_ARG;
+    if (a.R < a.kr || a.C < a.kc || a.Z < a.kz) return NRT_ERR_INVALID_ARG;
+    a.orr = (a.R - a.kr) / a.sr + 1; a.occ = (a.C - a.kc) / a.sc + 1; a.ozz = (a.Z - a.kz) / a.sz + 1;   // 'valid'
+    a.Cout = cout; a.act = activation;
+    hipStream_t st = nrt_stream(stream);
+    if (dtype == NRT_DT_F32) return launch_any<float>(a, variant, st);
+    return launch_any<unsigned short>(a, variant, st);
+}

@@ -17,7 +17,7 @@ from torch import nn
 from . import _lib
 from . import utils
 
-__all__ = ['Resize', 'Zoom', 'SpatialTransformer']
+__all__ = ['Resize', 'Zoom', 'SpatialTransformer', 'LocallyConnected3D']
 
 
 class _Layer(nn.Module):
@@ -45,6 +45,8 @@ class _Layer(nn.Module):
 
     def _maybe_build(self, inputs):
         if not self.built:
+            first = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+            self._build_device, self._build_dtype = first.device, first.dtype    # weights are created where the data lives
             if isinstance(inputs, (list, tuple)):
                 self.build([tuple(i.shape) for i in inputs])
             else:
@@ -208,3 +210,160 @@ class SpatialTransformer(_Layer):
             return out if restore is None else out.to(restore)
 
         return utils._maybe_tracked(run, vol, trf)
+
+
+def _normalize_tuple(value, n, name):
+    """keras conv_utils.normalize_tuple."""
+    if isinstance(value, int):
+        return (value,) * n
+    try:
+        value_tuple = tuple(value)
+    except TypeError:
+        raise ValueError('The `' + name + '` argument must be a tuple of ' + str(n) + ' integers. Received: ' + str(value))
+    if len(value_tuple) != n:
+        raise ValueError('The `' + name + '` argument must be a tuple of ' + str(n) + ' integers. Received: ' + str(value))
+    for v in value_tuple:
+        if not isinstance(v, int):
+            raise ValueError('The `' + name + '` argument must be a tuple of ' + str(n) + ' integers. Received: ' + str(value))
+    return value_tuple
+
+
+class LocallyConnected3D(_Layer):
+    """
+    Locally-connected layer for 3D inputs: a Conv3D whose weights are NOT shared between output positions
+    (neurite/tf/layers.py:811-1532).  Implementation 1 semantics ('valid' padding): kernel
+    [O, kr*kc*kz*Cin, filters] with the patch flattened in (kr, kc, kz, cin) order, O = output positions in
+    row-major order, bias [or, oc, oz, filters].  Runs on the weight-streaming HIP kernel (csrc/lc3d.hip):
+    every weight is read once, fp32 accumulation, bias + activation fused; float32 or bfloat16 tensors.
+    """
+
+    def __init__(self, filters, kernel_size, strides=(1, 1, 1), padding='valid', data_format=None, activation=None,
+                 use_bias=True, kernel_initializer='glorot_uniform', bias_initializer='zeros',
+                 kernel_regularizer=None, bias_regularizer=None, activity_regularizer=None, kernel_constraint=None,
+                 bias_constraint=None, implementation=1, **kwargs):
+        super().__init__(**kwargs)
+        self.filters = filters
+        self.kernel_size = _normalize_tuple(kernel_size, 3, 'kernel_size')
+        self.strides = _normalize_tuple(strides, 3, 'strides')
+        self.padding = str(padding).lower()
+        if self.padding not in ('valid', 'same'):
+            raise ValueError('The `padding` argument must be a list/tuple or one of "valid", "same". Received: '
+                             + str(padding))
+        if self.padding != 'valid' and implementation == 1:                              # layers.py:934-936
+            raise ValueError('Invalid border mode for LocallyConnected3D '
+                             '(only "valid" is supported if implementation is 1): ' + padding)
+        self.data_format = 'channels_last' if data_format is None else str(data_format).lower()
+        if self.data_format not in ('channels_last', 'channels_first'):
+            raise ValueError('The `data_format` argument must be one of "channels_first", "channels_last". Received: '
+                             + str(data_format))
+        if activation not in (None, 'linear', 'elu', 'relu'):
+            raise NotImplementedError('activation %r is not fused by the HIP path (linear, elu, relu are)' % (activation,))
+        self.activation = activation
+        self.use_bias = use_bias
+        self.kernel_initializer = kernel_initializer
+        self.bias_initializer = bias_initializer
+        self.kernel_regularizer = kernel_regularizer
+        self.bias_regularizer = bias_regularizer
+        self.activity_regularizer = activity_regularizer
+        self.kernel_constraint = kernel_constraint
+        self.bias_constraint = bias_constraint
+        if implementation not in (1, 2, 3):
+            raise ValueError('Unrecognized implementation mode: %d.' % implementation)
+        if implementation != 1:
+            raise NotImplementedError('implementation %d stores the same un-shared weights in a dense-masked / sparse '
+                                      'layout (layers.py:986-1028); only the implementation-1 layout [O, F, filters] is '
+                                      'implemented on the HIP path' % implementation)
+        self.implementation = implementation
+        self.kernel = None
+        self.bias = None
+        self._variant = 0
+
+    def build(self, input_shape):
+        if self.data_format == 'channels_last':                                           # layers.py:952-958
+            input_row, input_col, input_z = input_shape[1:-1]
+            input_filter = input_shape[4]
+        else:
+            input_row, input_col, input_z = input_shape[2:]
+            input_filter = input_shape[1]
+        if input_row is None or input_col is None or input_z is None:
+            raise ValueError('The spatial dimensions of the inputs to  a LocallyConnected3D layer should be '
+                             'fully-defined, but layer received the inputs shape ' + str(input_shape))
+        out = [(n - k) // s + 1 for n, k, s in zip((input_row, input_col, input_z), self.kernel_size, self.strides)]
+        self.output_row, self.output_col, self.output_z = out                              # conv_output_length, valid
+        F = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2] * input_filter
+        O = out[0] * out[1] * out[2]
+        self.kernel_shape = (O, F, self.filters)                                           # :974-977
+        # glorot_uniform with Keras' fan computation for a rank-3 shape (receptive field = O)
+        limit = (6.0 / (F * O + self.filters * O)) ** 0.5
+        dev = getattr(self, '_build_device', None)
+        dt = getattr(self, '_build_dtype', torch.float32)
+        dt = dt if dt in (torch.float32, torch.bfloat16) else torch.float32
+        if self.kernel_initializer == 'glorot_uniform':
+            k = torch.empty(self.kernel_shape, dtype=dt, device=dev).uniform_(-limit, limit)
+        elif self.kernel_initializer == 'zeros':
+            k = torch.zeros(self.kernel_shape, dtype=dt, device=dev)
+        else:
+            raise NotImplementedError('kernel_initializer %r' % (self.kernel_initializer,))
+        self.kernel = nn.Parameter(k)
+        if self.use_bias:                                                                  # :1030-1039
+            self.bias = nn.Parameter(torch.zeros(out[0], out[1], out[2], self.filters, dtype=dt, device=dev))
+        self.input_filter = input_filter
+        self.built = True
+
+    def compute_output_shape(self, input_shape):
+        if self.data_format == 'channels_first':
+            dims = input_shape[2:5]
+        else:
+            dims = input_shape[1:4]
+        o = [(n - k) // s + 1 for n, k, s in zip(dims, self.kernel_size, self.strides)]
+        if self.data_format == 'channels_first':
+            return (input_shape[0], self.filters, o[0], o[1], o[2])
+        return (input_shape[0], o[0], o[1], o[2], self.filters)
+
+    def get_config(self):
+        config = {
+            'filters': self.filters, 'kernel_size': self.kernel_size, 'strides': self.strides, 'padding': self.padding,
+            'data_format': self.data_format, 'activation': self.activation, 'use_bias': self.use_bias,
+            'kernel_initializer': self.kernel_initializer, 'bias_initializer': self.bias_initializer,
+            'kernel_regularizer': self.kernel_regularizer, 'bias_regularizer': self.bias_regularizer,
+            'activity_regularizer': self.activity_regularizer, 'kernel_constraint': self.kernel_constraint,
+            'bias_constraint': self.bias_constraint, 'implementation': self.implementation,
+        }
+        base_config = super().get_config()
+        return dict(list(base_config.items()) + list(config.items()))
+
+    def call(self, inputs):
+        lib = _lib.lib()
+        dev = _lib.require_device(inputs, self.kernel)
+        x = inputs
+        if x.dim() != 5:
+            raise ValueError('LocallyConnected3D expects a 5D input, got shape %s' % (tuple(x.shape),))
+        if self.data_format == 'channels_first':
+            x = x.permute(0, 2, 3, 4, 1)
+        x = x.contiguous()
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise NotImplementedError('LocallyConnected3D: float32 or bfloat16 tensors, got %s' % x.dtype)
+        if self.kernel.dtype != x.dtype:
+            raise TypeError('input dtype %s does not match the layer weights %s (use layer.to(dtype))'
+                            % (x.dtype, self.kernel.dtype))
+        B, S, cin = x.shape[0], list(x.shape[1:4]), x.shape[-1]
+        if cin != self.input_filter:
+            raise ValueError('expected %d input channels, got %d' % (self.input_filter, cin))
+        O = [self.output_row, self.output_col, self.output_z]
+        if [(n - k) // s + 1 for n, k, s in zip(S, self.kernel_size, self.strides)] != O:
+            raise ValueError('input spatial shape %s does not match the shape the layer was built for' % S)
+        y = torch.empty([B] + O + [self.filters], dtype=x.dtype, device=dev)
+        act = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}[self.activation]
+        dt = _lib.DT_F32 if x.dtype == torch.float32 else _lib.DT_BF16
+        k = self.kernel.detach().contiguous()
+        bias = None if self.bias is None else self.bias.detach().contiguous()
+
+        def run():
+            with torch.cuda.device(dev):
+                rc = lib.nrt_lc3d_f(_lib.ptr(x), _lib.ptr(k), _lib.ptr(bias), _lib.ptr(y), dt, B, _lib.ints(S), cin,
+                                    _lib.ints(self.kernel_size), _lib.ints(self.strides), self.filters, act,
+                                    int(self._variant), _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_lc3d_f')
+            return y.permute(0, 4, 1, 2, 3) if self.data_format == 'channels_first' else y
+
+        return utils._maybe_tracked(run, inputs, self.kernel)

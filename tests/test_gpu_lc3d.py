@@ -1,0 +1,132 @@
+"""
+GPU parity tests of LocallyConnected3D (implementation 1) against the golden vectors produced by the
+reference's own local_conv (tests/golden/lc3d_small.npz) and against the oracle.
+Tolerances: float32 1e-5 relative (atol 1e-5 max|ref|); bfloat16 2^-8 relative per element against float64
+math on the bf16-rounded inputs and weights.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import neurite_amd as ne
+from conftest import golden_cases, load_golden
+from oracle import np_oracle as npo
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def G(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+def close(got, ref, tol):
+    ref = np.asarray(ref, np.float64)
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1e-30, np.abs(ref).max()))
+
+
+def make_layer(dev, x, filters, ks, strides, k, b, act=None, variant=0, **kw):
+    layer = ne.layers.LocallyConnected3D(filters, ks, strides=strides, activation=act, **kw)
+    y0 = layer(x)                                   # builds on x's device / dtype
+    with torch.no_grad():
+        layer.kernel.copy_(k.to(layer.kernel.dtype))
+        layer.bias.copy_(b.to(layer.bias.dtype))
+    layer._variant = variant
+    assert tuple(y0.shape) == layer.compute_output_shape(tuple(x.shape))
+    return layer
+
+
+def test_lc3d_golden(dev):
+    cases = golden_cases(load_golden('lc3d_small'))
+    assert len(cases) == 2
+    for tag, c in cases.items():
+        ks, st = tuple(int(v) for v in c['ks']), tuple(int(v) for v in c['strides'])
+        x = G(c['x'], dev)
+        for variant in (0, 1, 2):
+            if variant == 2 and c['kernel'].shape[-1] % 4:
+                continue                                  # the streaming kernel needs 16-byte weight rows
+            layer = make_layer(dev, x, c['kernel'].shape[-1], ks, st, G(c['kernel'], dev), G(c['bias'], dev), variant=variant)
+            assert tuple(layer.kernel.shape) == c['kernel'].shape and tuple(layer.bias.shape) == c['bias'].shape
+            close(N(layer(x)), c['out'], 1e-5)
+
+
+@pytest.mark.parametrize('cin,cout,S,ks,st', [(16, 16, (12, 12, 12), (3, 3, 3), (1, 1, 1)), (3, 5, (7, 8, 9), (2, 3, 2), (1, 2, 1)),
+                                               (8, 32, (6, 9, 7), (3, 3, 3), (1, 1, 1)), (4, 8, (9, 9, 9), (3, 3, 3), (2, 2, 2)),
+                                               (16, 64, (5, 5, 6), (3, 3, 3), (1, 1, 1))])
+def test_lc3d_vs_oracle(dev, cin, cout, S, ks, st):
+    rng = np.random.default_rng(cin + cout)
+    osh = tuple((S[d] - ks[d]) // st[d] + 1 for d in range(3))
+    O, Fd = int(np.prod(osh)), int(np.prod(ks)) * cin
+    x = rng.standard_normal((2,) + S + (cin,)).astype(F)
+    k = (rng.standard_normal((O, Fd, cout)) / np.sqrt(Fd)).astype(F)
+    b = rng.standard_normal(osh + (cout,)).astype(F)
+    ref = npo.lc3d(x, k, b, ks, st)
+    for act, fn in ((None, lambda v: v), ('elu', lambda v: np.where(v > 0, v, np.exp(np.minimum(v, 0)) - 1))):
+        layer = make_layer(dev, G(x, dev), cout, ks, st, G(k, dev), G(b, dev), act=act)
+        close(N(layer(G(x, dev))), fn(ref), 1e-5)
+    # bf16: fp32 accumulation of bf16-rounded operands
+    xb, kb, bb = G(x, dev).bfloat16(), G(k, dev).bfloat16(), G(b, dev).bfloat16()
+    layer = make_layer(dev, xb, cout, ks, st, kb, bb)
+    refb = npo.lc3d(N(xb), N(kb), N(bb), ks, st)
+    y = layer(xb)
+    assert y.dtype == torch.bfloat16
+    close(N(y), refb, 2.0 ** -8)
+    # channels_first in / out
+    layer_cf = make_layer(dev, G(x, dev).permute(0, 4, 1, 2, 3).contiguous(), cout, ks, st, G(k, dev), G(b, dev),
+                          data_format='channels_first')
+    ycf = layer_cf(G(x, dev).permute(0, 4, 1, 2, 3).contiguous())
+    close(N(ycf.permute(0, 2, 3, 4, 1)), ref, 1e-5)
+
+
+def test_lc3d_contract():
+    with pytest.raises(ValueError, match='only "valid" is supported if implementation is 1'):
+        ne.layers.LocallyConnected3D(4, 3, padding='same')                 # layers.py:934-936
+    with pytest.raises(ValueError, match='kernel_size'):
+        ne.layers.LocallyConnected3D(4, (3, 3))
+    with pytest.raises(ValueError, match='Unrecognized implementation mode'):
+        ne.layers.LocallyConnected3D(4, 3, implementation=7)
+    l = ne.layers.LocallyConnected3D(4, 3, strides=2, activation='elu', name='lc')
+    cfg = l.get_config()
+    assert cfg['filters'] == 4 and cfg['kernel_size'] == (3, 3, 3) and cfg['strides'] == (2, 2, 2)
+    assert cfg['padding'] == 'valid' and cfg['implementation'] == 1 and cfg['use_bias'] is True and cfg['name'] == 'lc'
+    assert l.compute_output_shape((2, 9, 9, 9, 3)) == (2, 4, 4, 4, 4)
+
+
+def test_lc3d_cfg5_size_bf16_sampled(dev):
+    """BASELINE config 5: [1, 96, 96, 96, 16] bf16, 3x3x3, 16 filters: 830 584 positions x 432 x 16 weights
+    (11.5 GB bf16).  The CPU check covers 4096 sampled output positions exactly."""
+    torch.manual_seed(7)
+    x = torch.randn(1, 96, 96, 96, 16, device=dev, dtype=torch.bfloat16)
+    layer = ne.layers.LocallyConnected3D(16, (3, 3, 3))
+    y = layer(x)
+    assert tuple(layer.kernel.shape) == (94 ** 3, 432, 16) and layer.kernel.dtype == torch.bfloat16
+    with torch.no_grad():
+        layer.kernel.normal_(0, 1.0 / np.sqrt(432))
+        layer.bias.normal_(0, 0.1)
+    y = layer(x)
+    assert tuple(y.shape) == (1, 94, 94, 94, 16)
+    rng = np.random.default_rng(0)
+    pos = np.unique(np.concatenate([rng.integers(0, 94 ** 3, 4090), [0, 1, 93, 94 * 94, 94 ** 3 - 1, 94 ** 3 - 94]]))
+    kk = layer.kernel.detach()[torch.from_numpy(pos).to(dev)].float().cpu().numpy().astype(np.float64)
+    bb = layer.bias.detach().reshape(-1, 16)[torch.from_numpy(pos).to(dev)].float().cpu().numpy().astype(np.float64)
+    xh = x[0].float().cpu().numpy().astype(np.float64)
+    yh = N(y)[0].reshape(-1, 16)
+    r, c, z = pos // (94 * 94), (pos // 94) % 94, pos % 94
+    ref = np.empty((len(pos), 16))
+    for i in range(len(pos)):
+        patch = xh[r[i]:r[i] + 3, c[i]:c[i] + 3, z[i]:z[i] + 3].reshape(-1)
+        ref[i] = patch @ kk[i] + bb[i]
+    close(yh[pos], ref, 2.0 ** -8)
+    # the rest of the config: softmax + label-weighted CCE on the bf16 output (from_logits form)
+    lab = torch.randint(0, 16, (1, 94, 94, 94), device=dev)
+    t = torch.nn.functional.one_hot(lab, 16).to(torch.bfloat16)
+    w = np.linspace(0.5, 1.5, 16).astype(F)
+    loss = float(ne.metrics.WeightedCategoricalCrossentropy(label_weights=w, from_logits=True)(t, y.detach()))
+    from oracle import c_oracle as co
+    want = co.wcce(N(t), N(y), w, from_logits=True)
+    np.testing.assert_allclose(loss, want, rtol=1e-4)
