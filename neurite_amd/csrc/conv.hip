@@ -57,21 +57,23 @@ struct ConvArgs {
 constexpr int CT_X = 4, CT_Y = 4, CT_Z = 16;   // output tile
 constexpr int LDS_ROW = 20;                     // floats per staged voxel row (16 channels + 4 pad)
 
-template <int NT>
+// FAST: 3x3x3 kernel, dilation 1 -- the tap loop is fully unrolled, every LDS address is base + immediate
+template <int NT, bool FAST>
 __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__restrict__ wpacked, unsigned nblk,
                                                    unsigned nbx, unsigned nby, unsigned nbz) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lb = nrt_xcd_block(blockIdx.x, gridDim.x);
     if (lb >= nblk) return;
     const int b = blockIdx.y;
     const int bz = lb % nbz, by = (lb / nbz) % nby, bx = lb / (nbz * nby);
     const int x0 = bx * CT_X, y0 = by * CT_Y, z0 = bz * CT_Z;
-    const int hx = a.kx > 1 ? a.dil : 0, hy = a.ky > 1 ? a.dil : 0, hz = a.kz > 1 ? a.dil : 0;   // halo per side
+    const int hx = FAST ? 1 : (a.kx > 1 ? a.dil : 0), hy = FAST ? 1 : (a.ky > 1 ? a.dil : 0),
+              hz = FAST ? 1 : (a.kz > 1 ? a.dil : 0);                                               // halo per side
     const int HX = CT_X + 2 * hx, HY = CT_Y + 2 * hy, HZ = CT_Z + 2 * hz;
     const int nrows = HX * HY * HZ;
     const int Cin = a.c0 + a.c1;
     const int nchunk = (Cin + 15) / 16;
-    const int ntap = a.kx * a.ky * a.kz;
+    const int ntap = FAST ? 27 : a.kx * a.ky * a.kz;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
@@ -84,36 +86,83 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+    // halo-tile loader: row r (voxel of the halo tile), float4 q4 of its 16-channel chunk -> registers
+    const int q4 = threadIdx.x & 3;
+    auto load_row = [&](int r, int cbase) -> f32x4 {
+        const int rz = r % HZ, ry = (r / HZ) % HY, rx = r / (HZ * HY);
+        const int x = x0 - hx + rx, y = y0 - hy + ry, z = z0 - hz + rz;
+        f32x4 v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (r < nrows && x >= 0 && x < a.X && y >= 0 && y < a.Y && z >= 0 && z < a.Z) {
+            const int c = cbase + 4 * q4;
+            if (c < a.c0) {
+                const float *p = s0 + (((long long)x * a.Y + y) * a.Z + z) * a.c0 + c;
+                if (c + 3 < a.c0 && (a.c0 & 3) == 0) v = *(const f32x4 *)p;
+                else { for (int e = 0; e < 4; ++e) if (c + e < a.c0) v[e] = p[e]; }
+            } else if (c < Cin) {
+                const int c1 = c - a.c0;
+                const float *p = s1 + (((long long)(x / a.ux) * a.Y1 + (y / a.uy)) * a.Z1 + (z / a.uz)) * a.c1 + c1;
+                if (c1 + 3 < a.c1 && (a.c1 & 3) == 0 && (a.c0 & 3) == 0) v = *(const f32x4 *)p;
+                else { for (int e = 0; e < 4; ++e) if (c1 + e < a.c1) v[e] = p[e]; }
+            }
+        }
+        return v;
+    };
+    // The next chunk's halo tile is fetched into registers while the current chunk is on the matrix cores
+    // (PF rows per thread), and only written to LDS after the barrier that retires the current chunk.
+    constexpr int PF = 11;                                    // 64 * 11 = 704 >= 648 rows (3x3x3, dilation 1)
+    const bool prefetch = nrows <= 64 * PF;
+    f32x4 stage[PF];
+    if (prefetch) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) stage[i] = load_row((threadIdx.x >> 2) + 64 * i, 0);
+    }
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();                                   // previous chunk fully consumed
-        // ---- stage the halo tile of channels [16 ch, 16 ch + 16) -------------------------------
         const int cbase = ch * 16;
-        for (int r = threadIdx.x >> 2; r < nrows; r += 64) {
-            const int q4 = threadIdx.x & 3;                // which float4 of the 16-channel row
-            const int rz = r % HZ, ry = (r / HZ) % HY, rx = r / (HZ * HY);
-            const int x = x0 - hx + rx, y = y0 - hy + ry, z = z0 - hz + rz;
-            f32x4 v = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            if (x >= 0 && x < a.X && y >= 0 && y < a.Y && z >= 0 && z < a.Z) {
-                const int c = cbase + 4 * q4;
-                if (c < a.c0) {
-                    const float *p = s0 + (((long long)x * a.Y + y) * a.Z + z) * a.c0 + c;
-                    if (c + 3 < a.c0 && (a.c0 & 3) == 0) v = *(const f32x4 *)p;
-                    else { for (int e = 0; e < 4; ++e) if (c + e < a.c0) v[e] = p[e]; }
-                } else if (c < Cin) {
-                    const int c1 = c - a.c0;
-                    const float *p = s1 + (((long long)(x / a.ux) * a.Y1 + (y / a.uy)) * a.Z1 + (z / a.uz)) * a.c1 + c1;
-                    if (c1 + 3 < a.c1 && (a.c1 & 3) == 0 && (a.c0 & 3) == 0) v = *(const f32x4 *)p;
-                    else { for (int e = 0; e < 4; ++e) if (c1 + e < a.c1) v[e] = p[e]; }
-                }
+        if (prefetch) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int r = (threadIdx.x >> 2) + 64 * i;
+                if (r < nrows) *(f32x4 *)&lds[r * LDS_ROW + 4 * q4] = stage[i];
             }
-            *(f32x4 *)&lds[r * LDS_ROW + 4 * q4] = v;
+        } else {
+            for (int r = threadIdx.x >> 2; r < nrows; r += 64) *(f32x4 *)&lds[r * LDS_ROW + 4 * q4] = load_row(r, cbase);
         }
         __syncthreads();
+        if (prefetch && ch + 1 < nchunk) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) stage[i] = load_row((threadIdx.x >> 2) + 64 * i, cbase + 16);
+        }
         // ---- taps ------------------------------------------------------------------------------
         const f32x4 *wp = (const f32x4 *)wpacked + ((long long)ch * ntap) * NT * 64 + lane;
         f32x4 bfrag[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bfrag[nt] = wp[nt * 64];
+        if (FAST) {
+            constexpr int FHY = CT_Y + 2, FHZ = CT_Z + 2;
+            const float *abase = &lds[((w * FHY) * FHZ + li) * LDS_ROW + 4 * kq];
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                f32x4 bnext[NT];
+                const int tn = (t + 1 < 27) ? t + 1 : t;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bnext[nt] = wp[(tn * NT + nt) * 64];
+                const int dz = t % 3, dy = (t / 3) % 3, dx = t / 9;
+                f32x4 av[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    av[mt] = *(const f32x4 *)(abase + ((dx * FHY + (mt + dy)) * FHZ + dz) * LDS_ROW);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][m], bfrag[nt][m], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bfrag[nt] = bnext[nt];
+            }
+        } else {
         for (int t = 0; t < ntap; ++t) {
             f32x4 bnext[NT];
             const int tn = (t + 1 < ntap) ? t + 1 : t;
@@ -121,20 +170,22 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
             for (int nt = 0; nt < NT; ++nt) bnext[nt] = wp[((long long)tn * NT + nt) * 64];
             const int dz = t % a.kz, dy = (t / a.kz) % a.ky, dx = t / (a.kz * a.ky);
             const int rx = w + dx * a.dil, rz = li + dz * a.dil;
+            f32x4 av[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int ry = mt + dy * a.dil;
-                const f32x4 av = *(const f32x4 *)&lds[((rx * HY + ry) * HZ + rz) * LDS_ROW + 4 * kq];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bfrag[nt][0], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bfrag[nt][1], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bfrag[nt][2], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bfrag[nt][3], acc[mt][nt], 0, 0, 0);
-                }
+                av[mt] = *(const f32x4 *)&lds[((rx * HY + ry) * HZ + rz) * LDS_ROW + 4 * kq];
             }
 #pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][m], bfrag[nt][m], acc[mt][nt], 0, 0, 0);
+#pragma unroll
             for (int nt = 0; nt < NT; ++nt) bfrag[nt] = bnext[nt];
+        }
         }
     }
     // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15] ---------------------------------------
@@ -270,6 +321,91 @@ __global__ __launch_bounds__(256) void conv1x1_softmax(const float *__restrict__
     }
 }
 
+// ---- vectorised forms of the two HBM-bound layers: G = Cout/4 lanes per voxel, each lane owns 4 output
+// channels, so a voxel's output row is written as one contiguous Cout*4-byte segment (the one-thread-per-voxel
+// forms above write 64-128 B per thread at a 64-128 B stride: 64 cache lines per store instruction).
+// conv1x1_vec: the likelihood head (+ softmax across the lane-group with xor-shuffles).
+template <int G>
+__global__ __launch_bounds__(256) void conv1x1_vec(const float *__restrict__ x, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, float *__restrict__ y, long long nvox,
+                                                   int Cin, int softmax, int act) {
+    constexpr int Cout = 4 * G;
+    constexpr int NG = 256 / G;
+    extern __shared__ float wl[];          // [Cin][Cout] + [Cout]
+    for (int i = threadIdx.x; i < Cin * Cout; i += blockDim.x) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) wl[Cin * Cout + i] = bias ? bias[i] : 0.0f;
+    __syncthreads();
+    const int lg = threadIdx.x % G;
+    const long long g = threadIdx.x / G;
+    for (long long q = (long long)blockIdx.x * NG + g; q < nvox; q += (long long)gridDim.x * NG) {
+        f32x4 acc = *(const f32x4 *)&wl[Cin * Cout + 4 * lg];
+        const float *xp = x + q * Cin;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float xv = xp[ci];                       // same address for the G lanes of the voxel (broadcast)
+            const f32x4 wv = *(const f32x4 *)&wl[ci * Cout + 4 * lg];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+        }
+        if (softmax) {
+            float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] = expf(acc[e] - m); sum += acc[e]; }
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= inv;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = activate(acc[e], act);
+        }
+        __builtin_nontemporal_store(acc, (f32x4 *)(y + q * Cout) + lg);
+    }
+}
+
+// conv3d_c1_vec: first encoder layer, Cin == 1 (27 taps of a scalar image -> Cout channels), SAME padding.
+template <int G>
+__global__ __launch_bounds__(256) void conv3d_c1_vec(ConvArgs a, const float *__restrict__ w) {
+    constexpr int Cout = 4 * G;
+    constexpr int NG = 256 / G;
+    extern __shared__ float wl[];          // [ntap][Cout] + [Cout]
+    const int ntap = a.kx * a.ky * a.kz;
+    for (int i = threadIdx.x; i < ntap * Cout; i += blockDim.x) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += blockDim.x) wl[ntap * Cout + i] = a.bias ? a.bias[i] : 0.0f;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const float *s0 = a.src0 + (long long)b * a.X * a.Y * a.Z;
+    float *ob = a.out + (long long)b * a.OX * a.OY * a.OZ * Cout;
+    const long long nvox = (long long)a.OX * a.OY * a.OZ;
+    const int lg = threadIdx.x % G;
+    const long long g = threadIdx.x / G;
+    for (long long q = (long long)blockIdx.x * NG + g; q < nvox; q += (long long)gridDim.x * NG) {
+        const int oz = (int)(q % a.OZ), oy = (int)((q / a.OZ) % a.OY), ox = (int)(q / ((long long)a.OZ * a.OY));
+        f32x4 acc = *(const f32x4 *)&wl[ntap * Cout + 4 * lg];
+        int t = 0;
+        for (int dx = 0; dx < a.kx; ++dx) {
+            const int x = ox + dx * a.dil - a.px;
+            for (int dy = 0; dy < a.ky; ++dy) {
+                const int y = oy + dy * a.dil - a.py;
+                for (int dz = 0; dz < a.kz; ++dz, ++t) {
+                    const int z = oz + dz * a.dil - a.pz;
+                    const bool in = x >= 0 && x < a.X && y >= 0 && y < a.Y && z >= 0 && z < a.Z;
+                    const float xv = in ? s0[((long long)x * a.Y + y) * a.Z + z] : 0.0f;
+                    const f32x4 wv = *(const f32x4 *)&wl[t * Cout + 4 * lg];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = activate(acc[e], a.act);
+        *((f32x4 *)(ob + q * Cout) + lg) = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void softmax_lastdim(const float *__restrict__ x, float *__restrict__ y, long long n, int C) {
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
         const float *xp = x + q * C;
@@ -387,11 +523,14 @@ int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t 
     const unsigned nbx = (a.OX + CT_X - 1) / CT_X, nby = (a.OY + CT_Y - 1) / CT_Y, nbz = (a.OZ + CT_Z - 1) / CT_Z;
     const unsigned nblk = nbx * nby * nbz;
     const size_t shm = mfma_lds_bytes(a);
+    const bool fast = a.kx == 3 && a.ky == 3 && a.kz == 3 && a.dil == 1;
     if (shm > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)conv3d_mfma<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)conv3d_mfma<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return NRT_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((conv3d_mfma<NT>), dim3(nrt_xcd_grid(nblk), batch), dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
+    dim3 grid(nrt_xcd_grid(nblk), batch);
+    if (fast) hipLaunchKernelGGL((conv3d_mfma<NT, true>), grid, dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
+    else hipLaunchKernelGGL((conv3d_mfma<NT, false>), grid, dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
@@ -435,8 +574,28 @@ extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int 
             default: return launch_mfma<4>(a, packed_weights, batch, st);
         }
     }
-    if (variant != 1 || !weights) return NRT_ERR_INVALID_ARG;
+    if ((variant != 1 && variant != 3) || !weights) return NRT_ERR_INVALID_ARG;
     const long long nvox = (long long)a.OX * a.OY * a.OZ;
+    const int Gc = cout / 4;
+    const bool c1_ok = (c0 == 1 && c1 == 0 && padding_same && cout % 4 == 0 && (Gc == 1 || Gc == 2 || Gc == 4 || Gc == 8 || Gc == 16) &&
+                        (((uintptr_t)out) & 15) == 0);
+    if (variant == 3 && !c1_ok) return NRT_ERR_UNSUPPORTED;
+    if (c1_ok && (variant == 3 || variant == 1)) {        // variant 1 with Cin == 1 takes the vectorised form too
+        const size_t shm = (size_t)(a.kx * a.ky * a.kz + 1) * cout * sizeof(float);
+        const unsigned ng = 256 / Gc;
+        unsigned blocks = (unsigned)((nvox + ng - 1) / ng);
+        if (blocks > 256u * 32u) blocks = 256u * 32u;
+        dim3 grid(blocks, batch);
+        switch (Gc) {
+            case 1: hipLaunchKernelGGL((conv3d_c1_vec<1>), grid, dim3(256), shm, st, a, weights); break;
+            case 2: hipLaunchKernelGGL((conv3d_c1_vec<2>), grid, dim3(256), shm, st, a, weights); break;
+            case 4: hipLaunchKernelGGL((conv3d_c1_vec<4>), grid, dim3(256), shm, st, a, weights); break;
+            case 8: hipLaunchKernelGGL((conv3d_c1_vec<8>), grid, dim3(256), shm, st, a, weights); break;
+            default: hipLaunchKernelGGL((conv3d_c1_vec<16>), grid, dim3(256), shm, st, a, weights); break;
+        }
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
     unsigned blocks = (unsigned)((nvox + 255) / 256);
     if (blocks > 256u * 32u) blocks = 256u * 32u;
     hipLaunchKernelGGL(conv3d_direct, dim3(blocks, batch), dim3(256), 0, st, a, weights);
@@ -453,6 +612,21 @@ extern "C" int nrt_conv1x1_softmax_f32(const float *x, const float *weights, con
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     const size_t shm = (size_t)(cin + 1) * cout * sizeof(float);
     hipStream_t st = nrt_stream(stream);
+    const int G = cout / 4;
+    if (cout % 4 == 0 && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16) && (((uintptr_t)y) & 15) == 0) {
+        const unsigned ng = 256 / G;
+        unsigned vb = (unsigned)((nvox + ng - 1) / ng);
+        if (vb > 256u * 32u) vb = 256u * 32u;
+        switch (G) {
+            case 1: hipLaunchKernelGGL((conv1x1_vec<1>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation); break;
+            case 2: hipLaunchKernelGGL((conv1x1_vec<2>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation); break;
+            case 4: hipLaunchKernelGGL((conv1x1_vec<4>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation); break;
+            case 8: hipLaunchKernelGGL((conv1x1_vec<8>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation); break;
+            default: hipLaunchKernelGGL((conv1x1_vec<16>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation); break;
+        }
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
     if (cout <= 16) hipLaunchKernelGGL((conv1x1_softmax<16>), dim3(blocks), dim3(256), shm, st, x, weights, bias, y, nvox, cin, cout, softmax, activation);
     else if (cout <= 32) hipLaunchKernelGGL((conv1x1_softmax<32>), dim3(blocks), dim3(256), shm, st, x, weights, bias, y, nvox, cin, cout, softmax, activation);
     else hipLaunchKernelGGL((conv1x1_softmax<64>), dim3(blocks), dim3(256), shm, st, x, weights, bias, y, nvox, cin, cout, softmax, activation);
