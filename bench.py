@@ -240,7 +240,10 @@ def unet_bench(dev, size=160, labels=32, nb_conv_per_level=1, reps=20, warmup=5)
     Returns total forward ms (median) and per-conv-layer time / TFLOP/s / fraction of the fp32 MFMA peak."""
     import neurite_amd as ne
     torch.manual_seed(5)
-    model = ne.models.unet(16, (size, size, size, 1), 3, 3, labels, feat_mult=2, nb_conv_per_level=nb_conv_per_level).to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the builder prints like the reference does; stdout is the JSON line
+        model = ne.models.unet(16, (size, size, size, 1), 3, 3, labels, feat_mult=2,
+                               nb_conv_per_level=nb_conv_per_level).to(dev)
     x = torch.randn(1, size, size, size, 1, device=dev)
     for _ in range(warmup):
         y = model(x)
