@@ -341,7 +341,7 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or (os.environ.get('NRT_FORCE_DIST') and 'RANK' in os.environ):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)

@@ -29,6 +29,18 @@ def _world(group=None):
     return 0, 1
 
 
+_count_cache = {}
+
+
+def _count_tensor(n, device):
+    key = (int(n), str(device))
+    t = _count_cache.get(key)
+    if t is None:
+        t = torch.full((1,), float(n), dtype=torch.float32, device=device)
+        _count_cache[key] = t
+    return t
+
+
 def shard_range(n_items, rank=None, world_size=None):
     """Contiguous shard [lo, hi) of n_items for `rank`; remainders go to the first ranks."""
     r, w = _world()
@@ -48,20 +60,22 @@ def all_reduce_mean_dice(local_dice, weights=None, group=None):
     d = local_dice
     if weights is not None:
         d = d * torch.as_tensor(weights, dtype=d.dtype, device=d.device)
-    buf = torch.stack([d.sum(dtype=torch.float32), torch.tensor(float(d.numel()), device=d.device)])
     _, w = _world(group)
-    if w > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if w == 1 and not (dist.is_available() and dist.is_initialized()):
+        return d.mean(dtype=torch.float32)
+    # [sum, count] in one device buffer; the count constant is cached per (device, value): no H2D copy per step
+    buf = torch.cat([d.sum(dtype=torch.float32).reshape(1), _count_tensor(d.numel(), d.device)])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf[0] / buf[1]
 
 
 def all_reduce_mean(local_sum, local_count, group=None):
     """Global mean from per-rank (sum, count): the cross-entropy reduction over all B*V voxels."""
-    buf = torch.stack([local_sum.reshape(()).to(torch.float32),
-                       torch.tensor(float(local_count), device=local_sum.device)])
     _, w = _world(group)
-    if w > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if w == 1:
+        return local_sum.reshape(()).to(torch.float32) / float(local_count)
+    buf = torch.cat([local_sum.reshape(1).to(torch.float32), _count_tensor(local_count, local_sum.device)])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf[0] / buf[1]
 
 
