@@ -222,6 +222,31 @@ int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, void *y, int
                int activation, int variant, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward passes (what tf.GradientTape derives from the reference graphs; float32)
+ *
+ * nrt_interpn_bwd_f32: gradients of linear interpn / transform (neurite/tf/utils/utils.py:137-191, :206-213).
+ *   grad_out [batch, out_shape, C]; grad_vol [batch, vol_shape, C] must be ZERO-FILLED by the caller and is
+ *   accumulated with float atomics (tf.gather's scatter-add gradient), or NULL; grad_loc [batch, out_shape, D]
+ *   is overwritten (gradient wrt loc == gradient wrt the displacement in NRT_LOC_SHIFT mode), or NULL.
+ *   The location gradient flows only through clipped_loc (:142; tf.floor has none) on the closed range
+ *   [0, size-1]; with has_fill the gradient is zero at out-of-bounds voxels (:209-213).
+ * nrt_dice_soft_bwd_f32: d dice[b,l] / d y_pred and / d y_true from the saved sums [batch, 3, L]
+ *   (neurite/tf/metrics.py:476-482; divide_no_nan => zero gradient where the denominator is 0).
+ * nrt_wcce_bwd_f32: d loss / d y_pred of the weighted CCE (metrics.py:648-650 + Keras normalise/clip/log);
+ *   upstream gradient either one device scalar (grad_scalar) or per voxel (grad_per_voxel), times `scale`.
+ * ------------------------------------------------------------------------------------------ */
+int nrt_interpn_bwd_f32(const float *vol, const float *loc, const float *grad_out, float *grad_vol,
+                        float *grad_loc, int ndim, const int *vol_shape, const int *out_shape, int channels,
+                        int batch, long long vol_batch_stride, long long loc_batch_stride, int loc_mode,
+                        int has_fill, void *stream);
+int nrt_dice_soft_bwd_f32(const float *y_true, const float *y_pred, const float *sums, const float *grad_dice,
+                          long long nvox, int nlabels, int batch, float laplace_smoothing, float *grad_pred,
+                          float *grad_true, void *stream);
+int nrt_wcce_bwd_f32(const float *y_true, const float *y_pred, const float *label_weights,
+                     const float *grad_scalar, const float *grad_per_voxel, long long nvox_total, int channels,
+                     int from_logits, float label_smoothing, float scale, float *grad_pred, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or
  * non-temporal; calibrates the achievable mixed read/write HBM rate next to the kernels above.
  * ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,459 @@
+// Backward kernels of the hot path: what TensorFlow's autodiff derives from the
+// reference graphs, written out by hand so that the ops are usable as layers / losses in training.
+//
+// interpn (neurite/tf/utils/utils.py:137-191, 206-213), linear:
+//   out[q,c] = sum_corner (prod_d w_{corner_d,d}) * vol[idx(corner), c]          [* (1-oob) + oob*fill]
+//   d out / d vol   : scatter-add of wt * g[q,c] into the gathered rows            (tf.gather gradient)
+//   d out / d loc_d : only through clipped_loc (tf.floor has no gradient): d w0_d = -m_d, d w1_d = +m_d with
+//                     m_d = [0 <= loc_d <= max_d]  (tf.clip_by_value passes the gradient on the closed range)
+//   fill: the gradient is masked by (1 - oob).  SHIFT mode: d/d shift = d/d loc.
+// soft Dice (metrics.py:476-482): dice = (2 Stp + eps)/(Stt + Spp + eps)  [divide_no_nan when eps = 0]
+//   d dice/d p_v = (2 t_v den - 2 p_v num) / den^2 , symmetric in t.
+// weighted CCE (metrics.py:648-650 + Keras): q = p / sum p, qc = clip(q, 1e-7, 1-1e-7), l = -sum t'_c log qc_c
+//   d l / d p_j = -(1/s) ( r_j - sum_c r_c q_c ),  r_c = t'_c [1e-7 <= q_c <= 1-1e-7] / qc_c
+//   from logits: d l / d z_j = (sum_c t'_c) softmax_j - t'_j.
+// Float atomics (global_atomic_add_f32) make grad_vol's summation order non-deterministic, like TF's own
+// scatter-add on GPU; everything else is deterministic.
+
+#include "interpn_core.h"
+
+namespace {
+
+struct InterpBwdArgs {
+    InterpArgs f;                 // forward geometry (vol, loc; out unused)
+    const float *gout;            // [B, nout, C]
+    float *gvol;                  // [B, nin, C]  zero-initialised by the caller, or null
+    float *gloc;                  // [B, nout, D] or null
+};
+
+__device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
+
+// one thread per output voxel, loops over channels: any C, D in {1,2,3}
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void interpn_bwd_generic(InterpBwdArgs ba) {
+    const InterpArgs &a = ba.f;
+    const int b = blockIdx.y;
+    const float *vol = (const float *)a.vol + (long long)b * a.vol_bs;
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    const float *go = ba.gout + (long long)b * a.out_bs;
+    float *gv = ba.gvol ? ba.gvol + (long long)b * a.vol_bs : nullptr;
+    float *gl = ba.gloc ? ba.gloc + (long long)b * a.nout * D : nullptr;
+    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < a.nout; q += gridDim.x * blockDim.x) {
+        int qd[NRT_MAXD];
+        float p[NRT_MAXD];
+        decode<D>(a, q, qd);
+        load_loc<D, MODE>(a, locb, q, qd, p);
+        const bool oob = a.has_fill ? out_of_bounds<D>(a, p) : false;
+        int i0[NRT_MAXD], i1[NRT_MAXD];
+        float w0[NRT_MAXD], w1[NRT_MAXD], m[NRT_MAXD];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+            m[d] = (p[d] >= 0.0f && p[d] <= (float)(a.S[d] - 1)) ? 1.0f : 0.0f;
+        }
+        float gacc[NRT_MAXD] = {0.0f, 0.0f, 0.0f};
+        if (!oob) {
+            for (int c = 0; c < a.C; ++c) {
+                const float g = go[(long long)q * a.C + c];
+#pragma unroll
+                for (int corner = 0; corner < (1 << D); ++corner) {
+                    long long idx = 0;
+                    float wt = 1.0f;
+                    float wexc[NRT_MAXD];                 // product of the other dims' weights, signed
+#pragma unroll
+                    for (int d = 0; d < D; ++d) wexc[d] = 1.0f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const int bit = (corner >> (D - 1 - d)) & 1;
+                        idx = idx * a.S[d] + (bit ? i1[d] : i0[d]);
+                        const float w = bit ? w1[d] : w0[d];
+                        wt *= w;
+#pragma unroll
+                        for (int e = 0; e < D; ++e) wexc[e] *= (e == d) ? (bit ? m[d] : -m[d]) : w;
+                    }
+                    if (gv) atomic_add_f32(&gv[idx * a.C + c], wt * g);
+                    if (gl) {
+                        const float v = vol[idx * a.C + c];
+#pragma unroll
+                        for (int d = 0; d < D; ++d) gacc[d] += g * wexc[d] * v;
+                    }
+                }
+            }
+        }
+        if (gl) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) gl[(long long)q * D + d] = gacc[d];
+        }
+    }
+}
+
+// G = C/4 lanes per voxel, 3-D
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void interpn_bwd_rows(InterpBwdArgs ba) {
+    constexpr int D = 3;
+    constexpr int NG = 256 / G;
+    const InterpArgs &a = ba.f;
+    const int b = blockIdx.y;
+    const nrt_f4 *vol = (const nrt_f4 *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    const nrt_f4 *go = (const nrt_f4 *)(ba.gout + (long long)b * a.out_bs);
+    float *gv = ba.gvol ? ba.gvol + (long long)b * a.vol_bs : nullptr;
+    float *gl = ba.gloc ? ba.gloc + (long long)b * a.nout * D : nullptr;
+    const int lg = threadIdx.x % G;
+    const unsigned g = threadIdx.x / G;
+    const int Y = a.S[1], Z = a.S[2];
+    const unsigned ngroups = gridDim.x * NG;
+    // every lane-group runs the same number of iterations so that the shuffles below are convergent
+    const unsigned niter = (a.nout + ngroups - 1) / ngroups;
+    for (unsigned it = 0; it < niter; ++it) {
+        const unsigned qq = blockIdx.x * NG + g + it * ngroups;
+        const bool live = qq < a.nout;
+        const unsigned q = live ? qq : a.nout - 1;
+        int qd[NRT_MAXD];
+        float p[NRT_MAXD];
+        decode<D>(a, q, qd);
+        load_loc<D, MODE>(a, locb, q, qd, p);
+        const bool oob = a.has_fill ? out_of_bounds<D>(a, p) : false;
+        int i0[3], i1[3];
+        float w0[3], w1[3], m[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+            m[d] = (p[d] >= 0.0f && p[d] <= (float)(a.S[d] - 1)) ? 1.0f : 0.0f;
+        }
+        nrt_f4 gq = go[(long long)q * G + lg];
+        if (oob || !live) gq = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+        float gacc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+            const long long idx = ((long long)(bx ? i1[0] : i0[0]) * Y + (by ? i1[1] : i0[1])) * Z + (bz ? i1[2] : i0[2]);
+            const float wx = bx ? w1[0] : w0[0], wy = by ? w1[1] : w0[1], wz = bz ? w1[2] : w0[2];
+            if (gv && live && !oob) {
+                const float wt = wx * wy * wz;
+                float *dst = gv + (idx * G + lg) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomic_add_f32(dst + e, wt * gq[e]);
+            }
+            if (gl) {
+                const nrt_f4 v = vol[idx * G + lg];
+                const float dot = gq[0] * v[0] + gq[1] * v[1] + gq[2] * v[2] + gq[3] * v[3];
+                gacc[0] += dot * (bx ? m[0] : -m[0]) * wy * wz;
+                gacc[1] += dot * wx * (by ? m[1] : -m[1]) * wz;
+                gacc[2] += dot * wx * wy * (bz ? m[2] : -m[2]);
+            }
+        }
+        if (gl) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+                for (int off = 1; off < G; off <<= 1) gacc[d] += __shfl_xor(gacc[d], off, 64);
+            if (live && lg == 0) {
+                float *dst = gl + (long long)q * 3;
+                dst[0] = gacc[0]; dst[1] = gacc[1]; dst[2] = gacc[2];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// soft Dice backward: elementwise over [B, V, L]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dice_soft_bwd(const float *__restrict__ t, const float *__restrict__ p,
+                                                     const float *__restrict__ sums, const float *__restrict__ gdice,
+                                                     long long nvox, int L, float eps, float *__restrict__ gp,
+                                                     float *__restrict__ gt) {
+    const int b = blockIdx.y;
+    const long long n = nvox * L;
+    const float *tb = t + (long long)b * n, *pb = p + (long long)b * n;
+    const float *s = sums + (long long)b * 3 * L;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(e % L);
+        const float num = 2.0f * s[l] + eps, den = s[L + l] + s[2 * L + l] + eps;
+        const float g = gdice[(long long)b * L + l];
+        float ca = 0.0f, cb = 0.0f;                       // d dice = ca * other + cb * self
+        if (den != 0.0f) { ca = 2.0f * g / den; cb = -2.0f * g * num / (den * den); }
+        const float tv = tb[e], pv = pb[e];
+        if (gp) gp[(long long)b * n + e] = ca * tv + cb * pv;
+        if (gt) gt[(long long)b * n + e] = ca * pv + cb * tv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weighted CCE backward wrt y_pred: one thread per voxel (C in a loop), float32
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wcce_bwd(const float *__restrict__ t, const float *__restrict__ p,
+                                                const float *__restrict__ w, const float *__restrict__ gscalar,
+                                                const float *__restrict__ gper_voxel, long long n, int C, int logits,
+                                                float smooth, float scale, float *__restrict__ gp) {
+    const float keep = 1.0f - smooth, add = smooth / (float)C;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+        const float g = (gper_voxel ? gper_voxel[v] : gscalar[0]) * scale;
+        const float *tv = t + v * C, *pv = p + v * C;
+        float *gv = gp + v * C;
+        if (logits) {
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, pv[c]);
+            float se = 0.0f, st = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                se += expf(pv[c] - mx);
+                float tt = (w ? w[c] : 1.0f) * tv[c];
+                if (smooth != 0.0f) tt = tt * keep + add;
+                st += tt;
+            }
+            for (int c = 0; c < C; ++c) {
+                float tt = (w ? w[c] : 1.0f) * tv[c];
+                if (smooth != 0.0f) tt = tt * keep + add;
+                gv[c] = g * (st * expf(pv[c] - mx) / se - tt);
+            }
+        } else {
+            float s = 0.0f;
+            for (int c = 0; c < C; ++c) s += pv[c];
+            float rq = 0.0f;
+            for (int c = 0; c < C; ++c) {
+                const float q = pv[c] / s;
+                const bool in = q >= 1e-7f && q <= 1.0f - 1e-7f;
+                float tt = (w ? w[c] : 1.0f) * tv[c];
+                if (smooth != 0.0f) tt = tt * keep + add;
+                rq += in ? tt : 0.0f;                     // r_c q_c = t'_c when the clip is inactive
+            }
+            for (int c = 0; c < C; ++c) {
+                const float q = pv[c] / s;
+                const bool in = q >= 1e-7f && q <= 1.0f - 1e-7f;
+                float tt = (w ? w[c] : 1.0f) * tv[c];
+                if (smooth != 0.0f) tt = tt * keep + add;
+                const float r = in ? tt / q : 0.0f;
+                gv[c] = -g * (r - rq) / s;
+            }
+        }
+    }
+}
+
+// float4 version: L % 4 == 0 and 256 % (L/4) == 0, so that a thread keeps its 4 labels over the whole grid-stride loop
+__global__ __launch_bounds__(256) void dice_soft_bwd_vec(const nrt_f4 *__restrict__ t, const nrt_f4 *__restrict__ p,
+                                                         const float *__restrict__ sums, const float *__restrict__ gdice,
+                                                         long long nvox, int L, float eps, nrt_f4 *__restrict__ gp,
+                                                         nrt_f4 *__restrict__ gt) {
+    const int b = blockIdx.y;
+    const int G4 = L >> 2;
+    const long long n4 = nvox * G4;
+    const nrt_f4 *tb = t + (long long)b * n4, *pb = p + (long long)b * n4;
+    const float *s = sums + (long long)b * 3 * L;
+    const int l0 = (threadIdx.x % G4) * 4;
+    float ca[4], cb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int l = l0 + k;
+        const float num = 2.0f * s[l] + eps, den = s[L + l] + s[2 * L + l] + eps;
+        const float g = gdice[(long long)b * L + l];
+        ca[k] = 0.0f; cb[k] = 0.0f;
+        if (den != 0.0f) { ca[k] = 2.0f * g / den; cb[k] = -2.0f * g * num / (den * den); }
+    }
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += stride) {
+        const nrt_f4 tv = tb[e], pv = pb[e];
+        if (gp) {
+            nrt_f4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ca[k] * tv[k] + cb[k] * pv[k];
+            __builtin_nontemporal_store(o, &gp[(long long)b * n4 + e]);
+        }
+        if (gt) {
+            nrt_f4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = ca[k] * pv[k] + cb[k] * tv[k];
+            __builtin_nontemporal_store(o, &gt[(long long)b * n4 + e]);
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// G = C/4 lanes per voxel
+template <int G, int LOGITS>
+__global__ __launch_bounds__(256) void wcce_bwd_vec(const nrt_f4 *__restrict__ t, const nrt_f4 *__restrict__ p,
+                                                    const float *__restrict__ w, const float *__restrict__ gscalar,
+                                                    const float *__restrict__ gper_voxel, long long n, float smooth,
+                                                    float scale, nrt_f4 *__restrict__ gp) {
+    constexpr int C = G * 4;
+    constexpr int NG = 256 / G;
+    const int lg = threadIdx.x % G;
+    const float keep = 1.0f - smooth, add = smooth / (float)C;
+    float wl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wl[k] = w ? w[lg * 4 + k] : 1.0f;
+    const float gs = gscalar ? gscalar[0] * scale : 0.0f;
+    const long long ngroups = (long long)gridDim.x * NG;
+    const long long niter = (n + ngroups - 1) / ngroups;
+    for (long long it = 0; it < niter; ++it) {
+        const long long vv = (long long)blockIdx.x * NG + threadIdx.x / G + it * ngroups;
+        const bool live = vv < n;
+        const long long v = live ? vv : n - 1;
+        const nrt_f4 tv = t[v * G + lg], pv = p[v * G + lg];
+        const float g = gper_voxel ? gper_voxel[v] * scale : gs;
+        float tt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tt[k] = wl[k] * tv[k];
+            if (smooth != 0.0f) tt[k] = tt[k] * keep + add;
+        }
+        nrt_f4 o;
+        if (LOGITS) {
+            const float mx = group_max<G>(fmaxf(fmaxf(pv[0], pv[1]), fmaxf(pv[2], pv[3])));
+            float ex[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ex[k] = expf(pv[k] - mx);
+            const float se = group_sum<G>((ex[0] + ex[1]) + (ex[2] + ex[3]));
+            const float st = group_sum<G>((tt[0] + tt[1]) + (tt[2] + tt[3]));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = g * (st * ex[k] / se - tt[k]);
+        } else {
+            const float s = group_sum<G>((pv[0] + pv[1]) + (pv[2] + pv[3]));
+            float q[4], rq = 0.0f;
+            bool in[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                q[k] = pv[k] / s;
+                in[k] = q[k] >= 1e-7f && q[k] <= 1.0f - 1e-7f;
+                rq += in[k] ? tt[k] : 0.0f;
+            }
+            rq = group_sum<G>(rq);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = -g * ((in[k] ? tt[k] / q[k] : 0.0f) - rq) / s;
+        }
+        if (live) __builtin_nontemporal_store(o, &gp[v * G + lg]);
+    }
+}
+
+}  // namespace
+
+extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const float *grad_out, float *grad_vol,
+                                   float *grad_loc, int ndim, const int *vol_shape, const int *out_shape, int channels,
+                                   int batch, long long vol_batch_stride, long long loc_batch_stride, int loc_mode,
+                                   int has_fill, void *stream) {
+    if (!grad_out || (!grad_vol && !grad_loc)) return NRT_ERR_INVALID_ARG;
+    if (loc_mode == NRT_LOC_LINSPACE && grad_loc) return NRT_ERR_INVALID_ARG;
+    InterpBwdArgs ba;
+    float dummy;
+    int rc = fill_args(ba.f, vol, loc, &dummy, ndim, vol_shape, out_shape, channels, batch, vol_batch_stride,
+                       loc_batch_stride, loc_mode, has_fill);
+    if (rc != NRT_OK) return rc;
+    ba.f.out = nullptr;
+    ba.gout = grad_out; ba.gvol = grad_vol; ba.gloc = grad_loc;
+    if (ba.f.nout == 0) return NRT_OK;
+    hipStream_t st = nrt_stream(stream);
+    const int G = channels / 4;
+    const bool vec = ndim == 3 && channels % 4 == 0 && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64) &&
+                     ((((uintptr_t)vol | (uintptr_t)grad_out) & 15) == 0) && (vol_batch_stride % 4 == 0);
+#define NRT_BWD_MODE(KERNEL, ...)                                                                              \
+    switch (loc_mode) {                                                                                          \
+        case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, NRT_LOC_ABSOLUTE>), grid, dim3(256), 0, st, ba); break; \
+        case NRT_LOC_SHIFT: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, NRT_LOC_SHIFT>), grid, dim3(256), 0, st, ba); break;       \
+        default: hipLaunchKernelGGL((KERNEL<__VA_ARGS__, NRT_LOC_LINSPACE>), grid, dim3(256), 0, st, ba); break;               \
+    }
+    if (vec) {
+        const unsigned ng = 256 / G;
+        unsigned blocks = (ba.f.nout + ng - 1) / ng;
+        if (blocks > 256u * 16u) blocks = 256u * 16u;
+        dim3 grid(blocks, batch);
+        switch (G) {
+            case 1: NRT_BWD_MODE(interpn_bwd_rows, 1) break;
+            case 2: NRT_BWD_MODE(interpn_bwd_rows, 2) break;
+            case 4: NRT_BWD_MODE(interpn_bwd_rows, 4) break;
+            case 8: NRT_BWD_MODE(interpn_bwd_rows, 8) break;
+            case 16: NRT_BWD_MODE(interpn_bwd_rows, 16) break;
+            case 32: NRT_BWD_MODE(interpn_bwd_rows, 32) break;
+            default: NRT_BWD_MODE(interpn_bwd_rows, 64) break;
+        }
+    } else {
+        unsigned blocks = (ba.f.nout + 255) / 256;
+        if (blocks > 256u * 16u) blocks = 256u * 16u;
+        dim3 grid(blocks, batch);
+        switch (ndim) {
+            case 1: NRT_BWD_MODE(interpn_bwd_generic, 1) break;
+            case 2: NRT_BWD_MODE(interpn_bwd_generic, 2) break;
+            default: NRT_BWD_MODE(interpn_bwd_generic, 3) break;
+        }
+    }
+#undef NRT_BWD_MODE
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_dice_soft_bwd_f32(const float *y_true, const float *y_pred, const float *sums, const float *grad_dice,
+                                     long long nvox, int nlabels, int batch, float laplace_smoothing, float *grad_pred,
+                                     float *grad_true, void *stream) {
+    if (!y_true || !y_pred || !sums || !grad_dice || (!grad_pred && !grad_true)) return NRT_ERR_INVALID_ARG;
+    if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (nvox == 0) return NRT_OK;
+    const long long n = nvox * nlabels;
+    const int G4 = nlabels / 4;
+    const uintptr_t al = (uintptr_t)y_true | (uintptr_t)y_pred | (uintptr_t)grad_pred | (uintptr_t)grad_true;
+    if (nlabels % 4 == 0 && 256 % G4 == 0 && (al & 15) == 0) {
+        unsigned blocks = (unsigned)((n / 4 + 255) / 256);
+        if (blocks > 256u * 8u) blocks = 256u * 8u;
+        hipLaunchKernelGGL(dice_soft_bwd_vec, dim3(blocks, batch), dim3(256), 0, nrt_stream(stream), (const nrt_f4 *)y_true,
+                           (const nrt_f4 *)y_pred, sums, grad_dice, nvox, nlabels, laplace_smoothing, (nrt_f4 *)grad_pred,
+                           (nrt_f4 *)grad_true);
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    hipLaunchKernelGGL(dice_soft_bwd, dim3(blocks, batch), dim3(256), 0, nrt_stream(stream), y_true, y_pred, sums, grad_dice,
+                       nvox, nlabels, laplace_smoothing, grad_pred, grad_true);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_wcce_bwd_f32(const float *y_true, const float *y_pred, const float *label_weights,
+                                const float *grad_scalar, const float *grad_per_voxel, long long nvox_total, int channels,
+                                int from_logits, float label_smoothing, float scale, float *grad_pred, void *stream) {
+    if (!y_true || !y_pred || !grad_pred || (!grad_scalar && !grad_per_voxel)) return NRT_ERR_INVALID_ARG;
+    if (nvox_total < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (nvox_total == 0) return NRT_OK;
+    const int G = channels / 4;
+    const uintptr_t al = (uintptr_t)y_true | (uintptr_t)y_pred | (uintptr_t)grad_pred;
+    if (channels % 4 == 0 && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16) && (al & 15) == 0) {
+        const long long per_block = 256 / G;
+        unsigned vb = (unsigned)((nvox_total + per_block - 1) / per_block);
+        if (vb > 256u * 16u) vb = 256u * 16u;
+        hipStream_t st = nrt_stream(stream);
+#define NRT_CCE_BWD(GG)                                                                                              \
+    if (from_logits)                                                                                                 \
+        hipLaunchKernelGGL((wcce_bwd_vec<GG, 1>), dim3(vb), dim3(256), 0, st, (const nrt_f4 *)y_true,                \
+                           (const nrt_f4 *)y_pred, label_weights, grad_scalar, grad_per_voxel, nvox_total,           \
+                           label_smoothing, scale, (nrt_f4 *)grad_pred);                                             \
+    else                                                                                                             \
+        hipLaunchKernelGGL((wcce_bwd_vec<GG, 0>), dim3(vb), dim3(256), 0, st, (const nrt_f4 *)y_true,                \
+                           (const nrt_f4 *)y_pred, label_weights, grad_scalar, grad_per_voxel, nvox_total,           \
+                           label_smoothing, scale, (nrt_f4 *)grad_pred);
+        switch (G) {
+            case 1: NRT_CCE_BWD(1) break;
+            case 2: NRT_CCE_BWD(2) break;
+            case 4: NRT_CCE_BWD(4) break;
+            case 8: NRT_CCE_BWD(8) break;
+            default: NRT_CCE_BWD(16) break;
+        }
+#undef NRT_CCE_BWD
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
+    unsigned blocks = (unsigned)((nvox_total + 255) / 256);
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    hipLaunchKernelGGL(wcce_bwd, dim3(blocks), dim3(256), 0, nrt_stream(stream), y_true, y_pred, label_weights, grad_scalar,
+                       grad_per_voxel, nvox_total, channels, from_logits, label_smoothing, scale, grad_pred);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

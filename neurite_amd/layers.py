@@ -114,12 +114,9 @@ class Resize(_Layer):
         new_shape = utils._new_shape(list(vol.shape[1:-1]), zf)
         vol32, restore = utils._prepare_vol(vol, self.interp_method)
 
-        def run():
-            out = utils._launch_interpn(vol32, None, new_shape, _lib.LOC_LINSPACE,
-                                        utils._METHODS[self.interp_method], None, batched=True)
-            return out if restore is None else out.to(restore)
-
-        return utils._maybe_tracked(run, vol)
+        out = utils._interp_op(vol32, None, new_shape, _lib.LOC_LINSPACE, utils._METHODS[self.interp_method],
+                               None, batched=True)
+        return out if restore is None else out.to(restore)
 
 
 Zoom = Resize
@@ -202,14 +199,10 @@ class SpatialTransformer(_Layer):
         shift = trf[:1] if self.single_transform else trf
         vol32, restore = utils._prepare_vol(vol, self.interp_method)
 
-        def run():
-            out = utils._launch_interpn(vol32, shift, shift.shape[1:-1], _lib.LOC_SHIFT,
-                                        utils._METHODS[self.interp_method], self.fill_value, batched=True,
-                                        single_transform=self.single_transform, variant=self._variant,
-                                        tune=self._tune)
-            return out if restore is None else out.to(restore)
-
-        return utils._maybe_tracked(run, vol, trf)
+        out = utils._interp_op(vol32, shift, shift.shape[1:-1], _lib.LOC_SHIFT,
+                               utils._METHODS[self.interp_method], self.fill_value, batched=True,
+                               single_transform=self.single_transform, variant=self._variant, tune=self._tune)
+        return out if restore is None else out.to(restore)
 
 
 def _normalize_tuple(value, n, name):

@@ -72,6 +72,88 @@ def dice_partial_sums(y_true, y_pred, normalize=False, laplace_smoothing=0.):
     return sums, dice, minmax
 
 
+class _SoftDiceFn(torch.autograd.Function):
+    """Soft Dice [B, L] with the backward of csrc/backward.hip (gradients wrt both maps)."""
+
+    @staticmethod
+    def forward(ctx, y_true, y_pred, eps, normalize, check_limits):
+        t = _as_f32(y_true, 'y_true')
+        p = _as_f32(y_pred, 'y_pred')
+        sums, d, mm = dice_partial_sums(t, p, normalize, eps)
+        if check_limits:
+            _check_limits(mm)
+        ctx.save_for_backward(t, p, sums)
+        ctx.eps, ctx.normalize = eps, normalize
+        return d
+
+    @staticmethod
+    def backward(ctx, grad_dice):
+        if ctx.normalize:
+            raise NotImplementedError('neurite_amd: backward of Dice(normalize=True) is not implemented')
+        t, p, sums = ctx.saved_tensors
+        lib = _lib.lib()
+        dev = t.device
+        B, L = t.shape[0], t.shape[-1]
+        V = t.numel() // max(B * L, 1)
+        g = grad_dice.to(torch.float32).contiguous()
+        gt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
+        gp = torch.empty_like(p) if ctx.needs_input_grad[1] else None
+        if t.numel() and (gt is not None or gp is not None):
+            with torch.cuda.device(dev):
+                rc = lib.nrt_dice_soft_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(sums), _lib.ptr(g), V, L, B,
+                                               float(ctx.eps), _lib.ptr(gp), _lib.ptr(gt), _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_dice_soft_bwd_f32')
+        return gt, gp, None, None, None
+
+
+class _WcceFn(torch.autograd.Function):
+    """Weighted CCE: returns (sum of the per-voxel losses [1]) or the per-voxel losses; backward wrt y_pred."""
+
+    @staticmethod
+    def forward(ctx, t, p, w, from_logits, label_smoothing, per_voxel):
+        lib = _lib.lib()
+        dev = p.device
+        yf = p.shape[-1]
+        N = p.numel() // max(yf, 1)
+        loss_sum = torch.empty((1,), dtype=torch.float32, device=dev)
+        pv = torch.empty(p.shape[:-1], dtype=torch.float32, device=dev) if per_voxel else None
+        nws = lib.nrt_wcce_workspace_bytes(N, yf)
+        ws = _lib.workspace(dev, nws)
+        dt = _lib.DT_F32 if p.dtype == torch.float32 else _lib.DT_BF16
+        with torch.cuda.device(dev):
+            rc = lib.nrt_wcce(_lib.ptr(t), _lib.ptr(p), dt, _lib.ptr(w), N, yf, int(from_logits),
+                              float(label_smoothing), _lib.ptr(loss_sum), _lib.ptr(pv), _lib.ptr(ws), nws,
+                              _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_wcce')
+        ctx.save_for_backward(t, p, w)
+        ctx.cfg = (from_logits, label_smoothing, per_voxel)
+        return pv if per_voxel else loss_sum
+
+    @staticmethod
+    def backward(ctx, grad):
+        t, p, w = ctx.saved_tensors
+        from_logits, label_smoothing, per_voxel = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError('neurite_amd: gradient of the CCE wrt y_true is not implemented')
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None, None
+        if p.dtype != torch.float32:
+            raise NotImplementedError('neurite_amd: CCE backward takes float32 inputs')
+        lib = _lib.lib()
+        dev = p.device
+        yf = p.shape[-1]
+        N = p.numel() // max(yf, 1)
+        g = grad.to(torch.float32).contiguous()
+        gp = torch.empty_like(p)
+        if N:
+            with torch.cuda.device(dev):
+                rc = lib.nrt_wcce_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(w), None if per_voxel else _lib.ptr(g),
+                                          _lib.ptr(g) if per_voxel else None, N, yf, int(from_logits),
+                                          float(label_smoothing), 1.0, _lib.ptr(gp), _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_wcce_bwd_f32')
+        return None, gp, None, None, None, None
+
+
 def _check_limits(minmax):
     mn_t, mx_t, mn_p, mx_p = [float(v) for v in minmax.tolist()]      # one device->host sync
     msg = 'value outside range'
@@ -113,12 +195,12 @@ class Dice:
         eps = float(self.laplace_smoothing)
 
         if self.dice_type != 'hard':
-            def run():
-                _, d, mm = dice_partial_sums(y_true, y_pred, self.normalize, eps)
-                if self.check_input_limits:                                               # :439-444
-                    _check_limits(mm)
-                return d
-            return utils._maybe_tracked(run, y_true, y_pred)
+            if torch.is_grad_enabled() and (y_true.requires_grad or y_pred.requires_grad):
+                return _SoftDiceFn.apply(y_true, y_pred, eps, bool(self.normalize), bool(self.check_input_limits))
+            _, d, mm = dice_partial_sums(y_true, y_pred, self.normalize, eps)
+            if self.check_input_limits:                                                   # :439-444
+                _check_limits(mm)
+            return d
 
         # ---- hard Dice (:450-468): integer counting, bit-exact -------------------------------
         if self.input_type == 'prob':
@@ -260,33 +342,20 @@ class CategoricalCrossentropy:
         w = None if self.label_weights is None else self.label_weights.to(dev, torch.float32).contiguous()
         N = p.numel() // max(yf, 1)
         need_pv = sample_weight is not None or self.reduction == 'none'
-        loss_sum = torch.empty((1,), dtype=torch.float32, device=dev)
-        pv = torch.empty(p.shape[:-1], dtype=torch.float32, device=dev) if need_pv else None
-        nws = lib.nrt_wcce_workspace_bytes(N, yf)
-        ws = _lib.workspace(dev, nws)
-        dt = _lib.DT_F32 if p.dtype == torch.float32 else _lib.DT_BF16
-
-        def run():
-            with torch.cuda.device(dev):
-                rc = lib.nrt_wcce(_lib.ptr(t), _lib.ptr(p), dt, _lib.ptr(w), N, yf, int(self.from_logits),
-                                  self.label_smoothing, _lib.ptr(loss_sum), _lib.ptr(pv), _lib.ptr(ws), nws,
-                                  _lib.stream_ptr(dev))
-            _lib.check(rc, 'nrt_wcce')
-            if not need_pv:
-                return loss_sum[0] if self.reduction == 'sum' else loss_sum[0] / N
-            losses = pv
-            if sample_weight is not None:
-                sw = torch.as_tensor(sample_weight, dtype=torch.float32, device=dev)
-                while sw.dim() < losses.dim():
-                    sw = sw.unsqueeze(-1)
-                losses = losses * sw
-            if self.reduction == 'none':
-                return losses
-            if self.reduction == 'sum':
-                return losses.sum()
-            return losses.sum() / losses.numel()
-
-        return utils._maybe_tracked(run, y_true, y_pred)
+        res = _WcceFn.apply(t, p, w, self.from_logits, self.label_smoothing, need_pv)
+        if not need_pv:
+            return res[0] if self.reduction == 'sum' else res[0] / N
+        losses = res
+        if sample_weight is not None:
+            sw = torch.as_tensor(sample_weight, dtype=torch.float32, device=dev)
+            while sw.dim() < losses.dim():
+                sw = sw.unsqueeze(-1)
+            losses = losses * sw
+        if self.reduction == 'none':
+            return losses
+        if self.reduction == 'sum':
+            return losses.sum()
+        return losses.sum() / losses.numel()
 
 
 WeightedCategoricalCrossentropy = CategoricalCrossentropy

@@ -47,6 +47,74 @@ def _maybe_tracked(fn, *tensors):
     return fn()
 
 
+class _InterpnFn(torch.autograd.Function):
+    """
+    Linear interpn with the hand-written backward of csrc/backward.hip: gradients wrt the volume (scatter-add)
+    and wrt the sampling locations / displacement field (what TF's autodiff derives from utils.py:137-213).
+    """
+
+    @staticmethod
+    def forward(ctx, vol, loc, cfg):
+        vol = vol.contiguous()
+        loc = None if loc is None else loc.contiguous()
+        with torch.no_grad():
+            out = _launch_interpn(vol, loc, **cfg)
+        ctx.save_for_backward(vol, loc)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        vol, loc = ctx.saved_tensors
+        need_vol = ctx.needs_input_grad[0]
+        need_loc = loc is not None and ctx.needs_input_grad[1]
+        gvol, gloc = _launch_interpn_bwd(vol, loc, grad_out, ctx.cfg, need_vol, need_loc)
+        return gvol, gloc, None
+
+
+def _launch_interpn_bwd(vol, loc, grad_out, cfg, need_vol, need_loc):
+    lib = _lib.lib()
+    dev = _lib.require_device(vol, loc, grad_out)
+    batched, single = cfg['batched'], cfg.get('single_transform', False)
+    B = vol.shape[0] if batched else 1
+    S = list(vol.shape[1:-1]) if batched else list(vol.shape[:-1])
+    Cc, D = vol.shape[-1], len(S)
+    out_spatial = [int(s) for s in cfg['out_spatial']]
+    g = grad_out.to(torch.float32).contiguous()
+    gvol = torch.zeros_like(vol) if need_vol else None
+    gloc = None
+    if need_loc:
+        gloc = torch.empty(([B] if batched else []) + out_spatial + [D], dtype=torch.float32, device=dev)
+    if g.numel() == 0 or not (need_vol or need_loc):
+        if gloc is not None:
+            gloc.zero_()
+    else:
+        nvol = int(np.prod(S)) * Cc
+        nloc = int(np.prod(out_spatial)) * D
+        loc_bs = 0 if (single or loc is None) else nloc
+        with torch.cuda.device(dev):
+            rc = lib.nrt_interpn_bwd_f32(_lib.ptr(vol), _lib.ptr(loc), _lib.ptr(g), _lib.ptr(gvol), _lib.ptr(gloc), D,
+                                         _lib.ints(S), _lib.ints(out_spatial), Cc, B, nvol, loc_bs, cfg['loc_mode'],
+                                         int(cfg['fill_value'] is not None), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_interpn_bwd_f32')
+    if gloc is not None and single and batched:
+        gloc = gloc.sum(0, keepdim=True)       # one transform shared by the whole batch
+    return gvol, gloc
+
+
+def _interp_op(vol, loc, out_spatial, loc_mode, method, fill_value, batched, single_transform=False,
+               variant=0, tune=0):
+    """Forward launch, recorded for autograd when an input requires grad (linear float32 only)."""
+    cfg = dict(out_spatial=[int(s) for s in out_spatial], loc_mode=loc_mode, method=method, fill_value=fill_value,
+               batched=batched, single_transform=single_transform, variant=variant, tune=tune)
+    needs = torch.is_grad_enabled() and (vol.requires_grad or (loc is not None and loc.requires_grad))
+    if not needs:
+        return _launch_interpn(vol, loc, **cfg)
+    if method == _lib.INTERP_LINEAR and vol.dtype == torch.float32:
+        return _InterpnFn.apply(vol, loc, cfg)
+    return _NoBackward.apply(lambda: _launch_interpn(vol, loc, **cfg), vol, *([] if loc is None else [loc]))
+
+
 def _launch_interpn(vol, loc, out_spatial, loc_mode, method, fill_value, batched, single_transform=False,
                     variant=0, tune=0):
     """
@@ -147,16 +215,13 @@ def interpn(vol, loc, interp_method='linear', fill_value=None, *, _variant=0, _t
     if vol32.dtype == torch.int32 and fill_value is not None and float(fill_value) != int(fill_value):
         raise ValueError('fill_value %r is not representable in the integer volume dtype' % (fill_value,))
 
-    def run():
-        out = _launch_interpn(vol32, loc, loc.shape[:-1], _lib.LOC_ABSOLUTE, _METHODS[interp_method],
-                              fill_value, batched=False, variant=_variant, tune=_tune)
-        if restore is not None:
-            out = out.to(restore)
-        if input_vol_ndim == nb_dims:                                        # :216-218
-            out = out[..., 0]
-        return out
-
-    return _maybe_tracked(run, vol, loc)
+    out = _interp_op(vol32, loc, loc.shape[:-1], _lib.LOC_ABSOLUTE, _METHODS[interp_method],
+                     fill_value, batched=False, variant=_variant, tune=_tune)
+    if restore is not None:
+        out = out.to(restore)
+    if input_vol_ndim == nb_dims:                                            # :216-218
+        out = out[..., 0]
+    return out
 
 
 def _new_shape(vol_shape, zoom_factor):
@@ -191,14 +256,10 @@ def resize(vol, zoom_factor, interp_method='linear'):
     v = vol.unsqueeze(-1) if squeeze else vol
     vol32, restore = _prepare_vol(v, interp_method)
 
-    def run():
-        out = _launch_interpn(vol32, None, new_shape, _lib.LOC_LINSPACE, _METHODS[interp_method], None,
-                              batched=False)
-        if restore is not None:
-            out = out.to(restore)
-        return out[..., 0] if squeeze else out
-
-    return _maybe_tracked(run, vol)
+    out = _interp_op(vol32, None, new_shape, _lib.LOC_LINSPACE, _METHODS[interp_method], None, batched=False)
+    if restore is not None:
+        out = out.to(restore)
+    return out[..., 0] if squeeze else out
 
 
 zoom = resize
@@ -226,14 +287,11 @@ def transform(vol, loc_shift, interp_method='linear', indexing='ij', fill_value=
         shift = torch.cat([shift[..., 1:2], shift[..., 0:1], shift[..., 2:]], -1)
     vol32, restore = _prepare_vol(v, interp_method)
 
-    def run():
-        out = _launch_interpn(vol32, shift, shift.shape[:-1], _lib.LOC_SHIFT, _METHODS[interp_method],
-                              fill_value, batched=False)
-        if restore is not None:
-            out = out.to(restore)
-        return out[..., 0] if squeeze else out
-
-    return _maybe_tracked(run, vol, loc_shift)
+    out = _interp_op(vol32, shift, shift.shape[:-1], _lib.LOC_SHIFT, _METHODS[interp_method], fill_value,
+                     batched=False)
+    if restore is not None:
+        out = out.to(restore)
+    return out[..., 0] if squeeze else out
 
 
 def affine_to_dense_shift(matrix, shape, shift_center=True, indexing='ij'):

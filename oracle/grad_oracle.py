@@ -1,0 +1,92 @@
+"""
+TEST INFRASTRUCTURE ONLY -- gradient oracle of the hot path (CPU, float64, torch autograd).
+
+The reference has no hand-written backward: TensorFlow differentiates the forward graphs.  This module restates
+those forward graphs with differentiable torch ops whose gradient rules coincide with TF's for every op on the
+path (floor: no gradient; clip_by_value / clamp: gradient on the closed range; gather: scatter-add; divide_no_nan:
+zero where the denominator is zero) and lets torch.autograd produce the gradients the HIP backward kernels
+(neurite_amd/csrc/backward.hip) are checked against.
+
+Pinning: TensorFlow is not available here, so the gradients are pinned in tests/test_oracle.py against central
+finite differences of the pinned forward oracle (oracle/np_oracle.py: interpn_f64, dice, cce) away from the
+kinks, and the forward values of these restatements against the same oracle.
+
+Only tests/ may import this module.
+"""
+
+import itertools
+
+import torch
+
+F64 = torch.float64
+
+
+def interpn(vol, loc, fill_value=None):
+    """neurite/tf/utils/utils.py:137-191 (linear) and :206-213 (fill).  vol [*S, C], loc [*O, D]."""
+    D = loc.shape[-1]
+    S = list(vol.shape[:D])
+    C = vol.shape[-1]
+    flat = vol.reshape(-1, C)
+    loc0 = torch.floor(loc)                                                     # :139
+    mx = [float(s - 1) for s in S]
+    clipped = [torch.clamp(loc[..., d], 0., mx[d]) for d in range(D)]           # :142
+    l0 = [torch.clamp(loc0[..., d], 0., mx[d]) for d in range(D)]               # :143
+    l1 = [torch.clamp(l0[d] + 1, 0., mx[d]) for d in range(D)]                  # :146
+    locs = [[x.long() for x in l0], [x.long() for x in l1]]                     # :147
+    d1 = [l1[d] - clipped[d] for d in range(D)]                                 # :152
+    d0 = [1 - d1[d] for d in range(D)]                                          # :153
+    w = [d1, d0]
+    out = 0
+    for c in itertools.product([0, 1], repeat=D):                               # :160-189
+        idx = 0
+        for d in range(D):
+            idx = idx * S[d] + locs[c[d]][d]
+        wt = 1
+        for d in range(D):
+            wt = wt * w[c[d]][d]
+        out = out + wt[..., None] * flat[idx]
+    if fill_value is not None:                                                  # :206-213
+        oob = torch.zeros(loc.shape[:-1], dtype=torch.bool)
+        for d in range(D):
+            oob = oob | (loc[..., d] < 0) | (loc[..., d] > mx[d])
+        keep = (~oob).to(out.dtype)[..., None]
+        out = out * keep + (1 - keep) * fill_value
+    return out
+
+
+def transform(vol, shift, fill_value=None):
+    """voxelmorph transform(): interpn at identity grid + shift ('ij' indexing)."""
+    D = shift.shape[-1]
+    grid = torch.stack(torch.meshgrid(*[torch.arange(s, dtype=shift.dtype) for s in shift.shape[:-1]], indexing='ij'), -1)
+    return interpn(vol, grid + shift, fill_value)
+
+
+def resize_locs(S, O, dtype=F64):
+    """linspace(0, S-1, O) grid of neurite/tf/utils/utils.py:259-261."""
+    lin = [torch.linspace(0., S[d] - 1., O[d], dtype=dtype) for d in range(len(S))]
+    return torch.stack(torch.meshgrid(*lin, indexing='ij'), -1)
+
+
+def soft_dice(y_true, y_pred, laplace_smoothing=0.):
+    """neurite/tf/metrics.py:470-482.  [B, ..., L] -> [B, L]."""
+    B, L = y_true.shape[0], y_true.shape[-1]
+    t = y_true.reshape(B, -1, L)
+    p = y_pred.reshape(B, -1, L)
+    top = 2 * (t * p).sum(1) + laplace_smoothing
+    bottom = (t * t).sum(1) + (p * p).sum(1) + laplace_smoothing
+    zero = bottom == 0
+    return torch.where(zero, torch.zeros_like(top), top / torch.where(zero, torch.ones_like(bottom), bottom))
+
+
+def cce_per_voxel(y_true, y_pred, label_weights=None, from_logits=False, label_smoothing=0.):
+    """neurite/tf/metrics.py:648-650 + tf.keras categorical_crossentropy (axis -1)."""
+    t = y_true
+    if label_weights is not None:
+        t = t * label_weights
+    if label_smoothing:
+        t = t * (1 - label_smoothing) + label_smoothing / y_pred.shape[-1]
+    if from_logits:
+        return -(t * torch.log_softmax(y_pred, -1)).sum(-1)
+    q = y_pred / y_pred.sum(-1, keepdim=True)
+    q = torch.clamp(q, 1e-7, 1 - 1e-7)
+    return -(t * torch.log(q)).sum(-1)

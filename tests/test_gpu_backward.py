@@ -1,0 +1,291 @@
+"""
+GPU parity tests of the backward kernels (csrc/backward.hip) against the gradient oracle (oracle/grad_oracle.py:
+the reference's forward graphs restated in float64 torch, differentiated by autograd with TF's gradient rules;
+pinned against finite differences in tests/test_oracle.py).
+Tolerance: 1e-4 relative to the gradient scale (float32 products and sums vs float64).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import neurite_amd as ne
+from neurite_amd import synth
+from oracle import grad_oracle as go
+from oracle import np_oracle as npo
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+TOL = 1e-4
+
+
+def G(a, dev, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.requires_grad_() if grad else t
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def D64(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).double()
+    return t.requires_grad_() if grad else t
+
+
+def close(got, want, what=''):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = max(float(np.abs(want).max()), 1e-30)
+    err = float(np.abs(got - want).max()) / scale
+    assert got.shape == want.shape and err < TOL, '%s: max err / scale = %.3g' % (what, err)
+
+
+def rand_loc(rng, S, O, kinks=True):
+    """absolute locations: mostly inside, some outside on both sides, some exactly on integers / the borders"""
+    D = len(S)
+    loc = np.stack([rng.uniform(-1.5, S[d] + 0.5, size=O) for d in range(D)], -1).astype(F)
+    if kinks:
+        flat = loc.reshape(-1, D)
+        n = flat.shape[0]
+        for k in range(0, n, 7):
+            flat[k, k % D] = np.float32(rng.integers(0, S[k % D]))
+        for k in range(3, n, 11):
+            flat[k, k % D] = np.float32(S[k % D] - 1)
+        for k in range(5, n, 13):
+            flat[k, k % D] = 0.0
+    return loc
+
+
+@pytest.mark.parametrize('S,C,O', [((9, 8, 7), 4, (6, 5, 7)), ((9, 8, 7), 32, (5, 6, 7)), ((9, 8, 7), 3, (4, 5, 6)),
+                                    ((9, 8, 7), 1, (4, 5, 6)), ((11, 9), 2, (7, 8)), ((11, 9), 8, (7, 8)), ((13,), 3, (9,))])
+@pytest.mark.parametrize('fill', [None, 0.5])
+def test_interpn_backward(dev, S, C, O, fill):
+    rng = np.random.default_rng(hash((S, C, fill is None)) % 2**32)
+    vol = rng.standard_normal(S + (C,)).astype(F)
+    loc = rand_loc(rng, S, O)
+    w = rng.standard_normal(O + (C,)).astype(F)
+    v, l = G(vol, dev, True), G(loc, dev, True)
+    out = ne.utils.interpn(v, l, fill_value=fill)
+    (out * G(w, dev)).sum().backward()
+    vo, lo = D64(vol, True), D64(loc, True)
+    ref = go.interpn(vo, lo, fill)
+    (ref * D64(w)).sum().backward()
+    close(N(out), ref.detach().numpy(), 'forward')
+    close(N(l.grad), lo.grad.numpy(), 'grad_loc')
+    close(N(v.grad), vo.grad.numpy(), 'grad_vol')
+
+
+def test_interpn_backward_partial_requires(dev):
+    rng = np.random.default_rng(3)
+    S, C, O = (6, 7, 8), 8, (5, 5, 5)
+    vol, loc = rng.standard_normal(S + (C,)).astype(F), rand_loc(rng, S, O)
+    lo = D64(loc, True)
+    vo = D64(vol, True)
+    go.interpn(vo, lo).sum().backward()
+    l = G(loc, dev, True)
+    ne.utils.interpn(G(vol, dev), l).sum().backward()
+    close(N(l.grad), lo.grad.numpy(), 'loc only')
+    v = G(vol, dev, True)
+    ne.utils.interpn(v, G(loc, dev)).sum().backward()
+    close(N(v.grad), vo.grad.numpy(), 'vol only')
+    # no channel axis, list-of-tensors loc (utils.py:106-107, 119-120)
+    v1 = G(vol[..., 0], dev, True)
+    ll = [G(loc[..., d], dev, True) for d in range(3)]
+    ne.utils.interpn(v1, ll).sum().backward()
+    vo1, lo1 = D64(vol[..., :1], True), D64(loc, True)
+    go.interpn(vo1, lo1).sum().backward()
+    close(N(v1.grad), vo1.grad.numpy()[..., 0], 'squeezed vol')
+    for d in range(3):
+        close(N(ll[d].grad), lo1.grad.numpy()[..., d], 'list loc %d' % d)
+
+
+def test_nearest_backward_is_an_error(dev):
+    v = torch.randn(5, 5, 5, 2, device=dev, requires_grad=True)
+    l = torch.rand(4, 4, 4, 3, device=dev) * 4
+    out = ne.utils.interpn(v, l, interp_method='nearest')
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
+
+
+def _shift_oracle(vol, shift, fill=None):
+    """float32 location (grid + shift, one rounding) like the kernel, then float64 interpolation"""
+    O = shift.shape[:-1]
+    grid = np.stack(np.meshgrid(*[np.arange(s, dtype=F) for s in O], indexing='ij'), -1)
+    loc32 = (grid + shift).astype(F)
+    lo = D64(loc32, True)
+    vo = D64(vol, True)
+    return go.interpn(vo, lo, fill), vo, lo
+
+
+@pytest.mark.parametrize('C', [32, 5])
+@pytest.mark.parametrize('fill', [None, 0.0])
+def test_spatial_transformer_backward(dev, C, fill):
+    rng = np.random.default_rng(5 + C)
+    B, S = 2, (12, 10, 9)
+    vol = rng.standard_normal((B,) + S + (C,)).astype(F)
+    shift = (rng.standard_normal((B,) + S + (3,)) * 2.5).astype(F)
+    shift[0, :3] = 0                                          # identity region: every location on a kink
+    w = rng.standard_normal((B,) + S + (C,)).astype(F)
+    v, s = G(vol, dev, True), G(shift, dev, True)
+    out = ne.layers.SpatialTransformer(fill_value=fill)([v, s])
+    (out * G(w, dev)).sum().backward()
+    for b in range(B):
+        ref, vo, lo = _shift_oracle(vol[b], shift[b], fill)
+        (ref * D64(w[b])).sum().backward()
+        close(N(out[b]), ref.detach().numpy(), 'fwd')
+        close(N(s.grad[b]), lo.grad.numpy(), 'grad_shift b%d' % b)
+        close(N(v.grad[b]), vo.grad.numpy(), 'grad_vol b%d' % b)
+
+
+def test_spatial_transformer_backward_variants(dev):
+    rng = np.random.default_rng(9)
+    B, S, C = 3, (8, 9, 10), 4
+    vol = rng.standard_normal((B,) + S + (C,)).astype(F)
+    w = rng.standard_normal((B,) + S + (C,)).astype(F)
+    # single_transform: one field shared by the batch, gradient summed over the batch
+    shift = (rng.standard_normal((1,) + S + (3,)) * 2).astype(F)
+    v, s = G(vol, dev, True), G(shift, dev, True)
+    out = ne.layers.SpatialTransformer(single_transform=True)([v, s])
+    (out * G(w, dev)).sum().backward()
+    gsum = 0
+    for b in range(B):
+        ref, vo, lo = _shift_oracle(vol[b], shift[0])
+        (ref * D64(w[b])).sum().backward()
+        gsum = gsum + lo.grad.numpy()
+        close(N(v.grad[b]), vo.grad.numpy(), 'single grad_vol')
+    close(N(s.grad[0]), gsum, 'single grad_shift')
+    # 'xy' indexing: first two flow components swapped
+    shift = (rng.standard_normal((B,) + S + (3,)) * 2).astype(F)
+    s = G(shift, dev, True)
+    out = ne.layers.SpatialTransformer(indexing='xy')([G(vol, dev), s])
+    (out * G(w, dev)).sum().backward()
+    for b in range(B):
+        sw = shift[b][..., [1, 0, 2]]
+        ref, vo, lo = _shift_oracle(vol[b], sw)
+        (ref * D64(w[b])).sum().backward()
+        close(N(s.grad[b]), lo.grad.numpy()[..., [1, 0, 2]], 'xy grad_shift')
+    # affine transform: gradient reaches the matrix through the dense-shift glue
+    mat = (np.eye(3, 4)[None] + rng.standard_normal((B, 3, 4)) * 0.05).astype(F)
+    m = G(mat, dev, True)
+    out = ne.layers.SpatialTransformer()([G(vol, dev), m])
+    (out * G(w, dev)).sum().backward()
+    for b in range(B):
+        mo = D64(mat[b], True)
+        mesh = torch.stack(torch.meshgrid(*[torch.arange(n, dtype=torch.float64) for n in S], indexing='ij'), -1)
+        cen = mesh - torch.tensor([(n - 1) / 2 for n in S], dtype=torch.float64)
+        loc = cen @ mo[:, :3].T + mo[:, 3] - cen + mesh
+        ref = go.interpn(D64(vol[b]), loc)
+        (ref * D64(w[b])).sum().backward()
+        got, want = N(m.grad[b]), mo.grad.numpy()
+        assert np.abs(got - want).max() / np.abs(want).max() < 2e-3      # float32 affine glue moves a few kinks
+
+
+def test_transform_and_resize_backward(dev):
+    rng = np.random.default_rng(11)
+    S, C = (9, 7), 4
+    vol = rng.standard_normal(S + (C,)).astype(F)
+    shift = (rng.standard_normal(S + (2,)) * 1.5).astype(F)
+    v, s = G(vol, dev, True), G(shift, dev, True)
+    ne.utils.transform(v, s).square().sum().backward()
+    ref, vo, lo = _shift_oracle(vol, shift)
+    ref.square().sum().backward()
+    close(N(s.grad), lo.grad.numpy(), 'transform grad_shift')
+    close(N(v.grad), vo.grad.numpy(), 'transform grad_vol')
+    # Resize layer / utils.resize: gradient wrt the volume only (linspace grid is constant)
+    B, S3 = 2, (6, 5, 4)
+    x = rng.standard_normal((B,) + S3 + (4,)).astype(F)
+    xv = G(x, dev, True)
+    out = ne.layers.Resize(2)(xv)
+    w = rng.standard_normal(tuple(out.shape)).astype(F)
+    (out * G(w, dev)).sum().backward()
+    O = tuple(out.shape[1:-1])
+    lin = [npo.tf_linspace(0., S3[d] - 1., O[d]) for d in range(3)]
+    loc = np.stack(np.meshgrid(*lin, indexing='ij'), -1)
+    for b in range(B):
+        xo = D64(x[b], True)
+        (go.interpn(xo, D64(loc)) * D64(w[b])).sum().backward()
+        close(N(xv.grad[b]), xo.grad.numpy(), 'resize grad_vol')
+
+
+@pytest.mark.parametrize('eps', [0., 0.1])
+def test_soft_dice_backward(dev, eps):
+    rng = np.random.default_rng(13)
+    B, S, L = 2, (7, 6, 5), 8
+    t = rng.uniform(0, 1, (B,) + S + (L,)).astype(F)
+    p = rng.uniform(0, 1, (B,) + S + (L,)).astype(F)
+    t[..., 3] = 0; p[..., 3] = 0                                # empty label: divide_no_nan
+    wl = rng.uniform(0.5, 1.5, (B, L)).astype(F)
+    tt, pt = G(t, dev, True), G(p, dev, True)
+    m = ne.metrics.Dice(weights=wl, laplace_smoothing=eps)
+    loss = -m.mean_dice(tt, pt)
+    loss.backward()
+    to, po = D64(t, True), D64(p, True)
+    ref = -(go.soft_dice(to, po, eps) * D64(wl)).mean()
+    ref.backward()
+    close(float(loss.detach()), float(ref.detach()), 'loss')
+    close(N(pt.grad), po.grad.numpy(), 'grad_pred')
+    close(N(tt.grad), to.grad.numpy(), 'grad_true')
+    # odd label count (scalar path), only y_pred tracked, losses.Dice wrapper
+    t3, p3 = t[..., :3].copy(), p[..., :3].copy()
+    p3t = G(p3, dev, True)
+    ne.losses.Dice().mean_loss(G(t3, dev), p3t).backward()
+    po3 = D64(p3, True)
+    (-go.soft_dice(D64(t3), po3).mean()).backward()
+    close(N(p3t.grad), po3.grad.numpy(), 'grad_pred L=3')
+
+
+@pytest.mark.parametrize('logits,ls,reduction', [(False, 0., 'auto'), (False, 0.1, 'sum'), (True, 0., 'auto'),
+                                                 (True, 0.1, 'none'), (False, 0., 'none')])
+@pytest.mark.parametrize('C', [6, 8, 32])
+def test_cce_backward(dev, logits, ls, reduction, C):
+    rng = np.random.default_rng(17)
+    B, S = 2, (5, 6, 7)
+    lab = rng.integers(0, C, (B,) + S)
+    t = np.eye(C, dtype=F)[lab]
+    x = rng.standard_normal((B,) + S + (C,)).astype(F) if logits else rng.uniform(0, 1, (B,) + S + (C,)).astype(F)
+    if not logits:
+        x[0, 0, 0, :2] = 0.
+        x[0, 0, 0, :2, -1] = 1.                                  # clipped probabilities: zero gradient there
+    wl = rng.uniform(0.5, 2, C).astype(F)
+    sw = rng.uniform(0.5, 2, (B,)).astype(F)
+    xt = G(x, dev, True)
+    loss = ne.losses.CategoricalCrossentropy(wl, from_logits=logits, label_smoothing=ls, reduction=reduction)
+    use_sw = reduction != 'auto'
+    got = loss.cce(G(t, dev), xt, sample_weight=sw if use_sw else None)
+    xo = D64(x, True)
+    pv = go.cce_per_voxel(D64(t), xo, D64(wl), logits, ls)
+    if use_sw:
+        pv = pv * D64(sw)[:, None, None, None]
+    ref = pv if reduction == 'none' else (pv.sum() if reduction == 'sum' else pv.mean())
+    close(N(got), ref.detach().numpy(), 'fwd')
+    up = rng.standard_normal(tuple(ref.shape)).astype(F) if reduction == 'none' else np.float32(1.7)
+    (got * G(np.asarray(up), dev)).sum().backward()
+    (ref * D64(np.asarray(up))).sum().backward()
+    close(N(xt.grad), xo.grad.numpy(), 'grad_pred')
+
+
+def test_registration_loss_backward_end_to_end(dev):
+    """-mean Dice(fixed, warp(moving, flow)) + CCE: gradient wrt the flow through both kernels."""
+    rng = np.random.default_rng(19)
+    B, S, L = 2, (16, 16, 16), 32
+    mov = np.stack([synth.one_hot_volume(40 + b, size=S[0], nb_labels=L).numpy() for b in range(B)], 0).astype(F)
+    assert mov.shape == (B,) + S + (L,)
+    fix = np.roll(mov, 1, axis=2)
+    flow = (rng.standard_normal((B,) + S + (3,)) * 1.2).astype(F)
+    f = G(flow, dev, True)
+    warped = ne.layers.SpatialTransformer()([G(mov, dev), f])
+    loss = -ne.metrics.Dice(check_input_limits=False).mean_dice(G(fix, dev), warped) \
+        + 0.1 * ne.losses.CategoricalCrossentropy()(G(fix, dev), warped + 0.01)
+    loss.backward()
+    tot = 0
+    grads = []
+    for b in range(B):
+        ref, vo, lo = _shift_oracle(mov[b], flow[b])
+        d = go.soft_dice(D64(fix[b:b + 1]), ref[None]).sum() / (B * L)
+        c = go.cce_per_voxel(D64(fix[b]), ref + 0.01).sum() / (B * np.prod(S))
+        l = -d + 0.1 * c
+        l.backward()
+        tot = tot + float(l.detach())
+        grads.append(lo.grad.numpy())
+    close(float(loss.detach()), tot, 'loss')
+    close(N(f.grad), np.stack(grads, 0), 'grad_flow')
