@@ -242,6 +242,13 @@ int nrt_interpn_bwd_f32(const float *vol, const float *loc, const float *grad_ou
 int nrt_dice_soft_bwd_f32(const float *y_true, const float *y_pred, const float *sums, const float *grad_dice,
                           long long nvox, int nlabels, int batch, float laplace_smoothing, float *grad_pred,
                           float *grad_true, void *stream);
+/* Fused backward of nrt_warp_dice_soft_f32 wrt the displacement / location field: rebuilds the warped row in
+ * registers, forms d dice / d warped from `sums` (as returned by the forward) and grad_dice [batch, L], and writes
+ * grad_loc [batch, out_shape, 3] only.  `warped` and its gradient never touch HBM. */
+int nrt_warp_dice_bwd_f32(const float *moving, const float *loc, const float *fixed, const float *sums,
+                          const float *grad_dice, float *grad_loc, const int *vol_shape, const int *out_shape,
+                          int nlabels, int batch, long long loc_batch_stride, int loc_mode, int has_fill,
+                          float laplace_smoothing, void *stream);
 int nrt_wcce_bwd_f32(const float *y_true, const float *y_pred, const float *label_weights,
                      const float *grad_scalar, const float *grad_per_voxel, long long nvox_total, int channels,
                      int from_logits, float label_smoothing, float scale, float *grad_pred, void *stream);

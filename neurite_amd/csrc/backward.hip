@@ -336,6 +336,98 @@ __global__ __launch_bounds__(256) void wcce_bwd_vec(const nrt_f4 *__restrict__ t
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused backward of warp + soft Dice wrt the displacement field: the warped row is rebuilt in registers,
+// d dice / d warped is formed on the fly from the saved sums, and only grad_loc (12 B/voxel) is written.
+// G = L/4 lanes per voxel, 3-D.
+// ---------------------------------------------------------------------------------------------
+template <int G, int MODE>
+__global__ __launch_bounds__(256) void warp_dice_bwd_rows(InterpBwdArgs ba, const float *__restrict__ fixed,
+                                                          const float *__restrict__ sums,
+                                                          const float *__restrict__ gdice, float eps) {
+    constexpr int D = 3;
+    constexpr int NG = 256 / G;
+    constexpr int L = G * 4;
+    const InterpArgs &a = ba.f;
+    const int b = blockIdx.y;
+    const nrt_f4 *vol = (const nrt_f4 *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const float *locb = a.loc + (long long)b * a.loc_bs;
+    const nrt_f4 *fix = (const nrt_f4 *)(fixed + (long long)b * a.out_bs);
+    float *gl = ba.gloc + (long long)b * a.nout * D;
+    const int lg = threadIdx.x % G;
+    const unsigned g = threadIdx.x / G;
+    const int Y = a.S[1], Z = a.S[2];
+    float ca[4], cb[4];
+    {
+        const float *s = sums + (long long)b * 3 * L;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int l = lg * 4 + k;
+            const float num = 2.0f * s[l] + eps, den = s[L + l] + s[2 * L + l] + eps;
+            const float gd = gdice[(long long)b * L + l];
+            ca[k] = 0.0f; cb[k] = 0.0f;
+            if (den != 0.0f) { ca[k] = 2.0f * gd / den; cb[k] = -2.0f * gd * num / (den * den); }
+        }
+    }
+    const unsigned ngroups = gridDim.x * NG;
+    const unsigned niter = (a.nout + ngroups - 1) / ngroups;
+    for (unsigned it = 0; it < niter; ++it) {
+        const unsigned qq = blockIdx.x * NG + g + it * ngroups;
+        const bool live = qq < a.nout;
+        const unsigned q = live ? qq : a.nout - 1;
+        int qd[NRT_MAXD];
+        float p[NRT_MAXD];
+        decode<D>(a, q, qd);
+        load_loc<D, MODE>(a, locb, q, qd, p);
+        const bool oob = a.has_fill ? out_of_bounds<D>(a, p) : false;
+        int i0[3], i1[3];
+        float w0[3], w1[3], m[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+            m[d] = (p[d] >= 0.0f && p[d] <= (float)(a.S[d] - 1)) ? 1.0f : 0.0f;
+        }
+        const nrt_f4 t = fix[(long long)q * G + lg];
+        nrt_f4 v[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+            const long long idx = ((long long)(bx ? i1[0] : i0[0]) * Y + (by ? i1[1] : i0[1])) * Z + (bz ? i1[2] : i0[2]);
+            v[corner] = vol[idx * G + lg];
+        }
+        nrt_f4 wp = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+            const float wt = (bx ? w1[0] : w0[0]) * (by ? w1[1] : w0[1]) * (bz ? w1[2] : w0[2]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wp[k] += wt * v[corner][k];
+        }
+        nrt_f4 gq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gq[k] = (oob || !live) ? 0.0f : ca[k] * t[k] + cb[k] * wp[k];
+        float gacc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+            const float wx = bx ? w1[0] : w0[0], wy = by ? w1[1] : w0[1], wz = bz ? w1[2] : w0[2];
+            const nrt_f4 c = v[corner];
+            const float dot = gq[0] * c[0] + gq[1] * c[1] + gq[2] * c[2] + gq[3] * c[3];
+            gacc[0] += dot * (bx ? m[0] : -m[0]) * wy * wz;
+            gacc[1] += dot * wx * (by ? m[1] : -m[1]) * wz;
+            gacc[2] += dot * wx * wy * (bz ? m[2] : -m[2]);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) gacc[d] += __shfl_xor(gacc[d], off, 64);
+        if (live && lg == 0) {
+            float *dst = gl + (long long)q * 3;
+            dst[0] = gacc[0]; dst[1] = gacc[1]; dst[2] = gacc[2];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const float *grad_out, float *grad_vol,
@@ -454,6 +546,51 @@ extern "C" int nrt_wcce_bwd_f32(const float *y_true, const float *y_pred, const 
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     hipLaunchKernelGGL(wcce_bwd, dim3(blocks), dim3(256), 0, nrt_stream(stream), y_true, y_pred, label_weights, grad_scalar,
                        grad_per_voxel, nvox_total, channels, from_logits, label_smoothing, scale, grad_pred);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_warp_dice_bwd_f32(const float *moving, const float *loc, const float *fixed, const float *sums,
+                                     const float *grad_dice, float *grad_loc, const int *vol_shape, const int *out_shape,
+                                     int nlabels, int batch, long long loc_batch_stride, int loc_mode, int has_fill,
+                                     float laplace_smoothing, void *stream) {
+    if (!moving || !loc || !fixed || !sums || !grad_dice || !grad_loc) return NRT_ERR_INVALID_ARG;
+    if (loc_mode != NRT_LOC_ABSOLUTE && loc_mode != NRT_LOC_SHIFT) return NRT_ERR_INVALID_ARG;
+    const int G = nlabels / 4;
+    if (nlabels % 4 || !(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64)) return NRT_ERR_UNSUPPORTED;
+    if ((((uintptr_t)moving | (uintptr_t)fixed) & 15) != 0) return NRT_ERR_UNSUPPORTED;
+    InterpBwdArgs ba;
+    float dummy;
+    long long nin = 1;
+    for (int d = 0; d < 3; ++d) nin *= vol_shape[d];
+    int rc = fill_args(ba.f, moving, loc, &dummy, 3, vol_shape, out_shape, nlabels, batch, nin * nlabels,
+                       loc_batch_stride, loc_mode, has_fill);
+    if (rc != NRT_OK) return rc;
+    ba.f.out = nullptr;
+    ba.gout = nullptr; ba.gvol = nullptr; ba.gloc = grad_loc;
+    if (ba.f.nout == 0) return NRT_OK;
+    hipStream_t st = nrt_stream(stream);
+    const unsigned ng = 256 / G;
+    unsigned blocks = (ba.f.nout + ng - 1) / ng;
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    dim3 grid(blocks, batch);
+#define NRT_WDB(GG)                                                                                              \
+    if (loc_mode == NRT_LOC_SHIFT)                                                                               \
+        hipLaunchKernelGGL((warp_dice_bwd_rows<GG, NRT_LOC_SHIFT>), grid, dim3(256), 0, st, ba, fixed, sums,     \
+                           grad_dice, laplace_smoothing);                                                        \
+    else                                                                                                         \
+        hipLaunchKernelGGL((warp_dice_bwd_rows<GG, NRT_LOC_ABSOLUTE>), grid, dim3(256), 0, st, ba, fixed, sums,  \
+                           grad_dice, laplace_smoothing);
+    switch (G) {
+        case 1: NRT_WDB(1) break;
+        case 2: NRT_WDB(2) break;
+        case 4: NRT_WDB(4) break;
+        case 8: NRT_WDB(8) break;
+        case 16: NRT_WDB(16) break;
+        case 32: NRT_WDB(32) break;
+        default: NRT_WDB(64) break;
+    }
+#undef NRT_WDB
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

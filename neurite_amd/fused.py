@@ -18,6 +18,19 @@ from .errors import InvalidArgumentError
 __all__ = ['warp_dice']
 
 
+class _WarpDiceFn(torch.autograd.Function):
+    """dice [B, L] as a function of the (already 'ij'-ordered) displacement field; backward in csrc/backward.hip."""
+
+    @staticmethod
+    def forward(ctx, shift, run, run_backward):
+        ctx.run_backward = run_backward
+        return run()
+
+    @staticmethod
+    def backward(ctx, grad_dice):
+        return ctx.run_backward(grad_dice), None, None
+
+
 def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_value=None, laplace_smoothing=0.,
               check_input_limits=False, return_warped=False, return_sums=False, _tune=0):
     """
@@ -59,11 +72,12 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
     ws = _lib.workspace(dev, nws)
     has_fill = fill_value is not None
 
+    loc_bs = 0 if single_transform else shift[0].numel()
+
     def run():
         with torch.cuda.device(dev):
             rc = lib.nrt_warp_dice_soft_f32(_lib.ptr(mov), _lib.ptr(shift), _lib.ptr(fix), _lib.ptr(warped),
-                                            _lib.ints(S), o_shape, L, B,
-                                            0 if single_transform else shift[0].numel(), _lib.LOC_SHIFT,
+                                            _lib.ints(S), o_shape, L, B, loc_bs, _lib.LOC_SHIFT,
                                             int(has_fill), float(fill_value) if has_fill else 0.0,
                                             float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice), _lib.ptr(minmax),
                                             int(_tune), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
@@ -74,7 +88,23 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
                 raise InvalidArgumentError('value outside range')
         return dice
 
-    d = utils._maybe_tracked(run, moving, trf, fixed)
+    def run_backward(grad_dice):
+        gshift = torch.empty((B,) + tuple(shift.shape[1:]), dtype=torch.float32, device=dev)
+        g = grad_dice.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.nrt_warp_dice_bwd_f32(_lib.ptr(mov), _lib.ptr(shift), _lib.ptr(fix), _lib.ptr(sums), _lib.ptr(g),
+                                           _lib.ptr(gshift), _lib.ints(S), o_shape, L, B, loc_bs, _lib.LOC_SHIFT,
+                                           int(has_fill), float(laplace_smoothing), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_warp_dice_bwd_f32')
+        return gshift.sum(0, keepdim=True) if single_transform else gshift
+
+    if torch.is_grad_enabled() and (moving.requires_grad or fixed.requires_grad):
+        raise NotImplementedError('warp_dice: only the transform is differentiable in the fused form; use '
+                                  'layers.SpatialTransformer + metrics.Dice for gradients wrt the volumes')
+    if torch.is_grad_enabled() and shift.requires_grad:
+        d = _WarpDiceFn.apply(shift, run, run_backward)
+    else:
+        d = run()
     out = (d,)
     if return_warped:
         out += (warped,)

@@ -289,3 +289,39 @@ def test_registration_loss_backward_end_to_end(dev):
         grads.append(lo.grad.numpy())
     close(float(loss.detach()), tot, 'loss')
     close(N(f.grad), np.stack(grads, 0), 'grad_flow')
+
+
+@pytest.mark.parametrize('L,fill,eps', [(32, None, 0.), (8, 0.0, 0.1), (4, None, 0.)])
+def test_fused_warp_dice_backward(dev, L, fill, eps):
+    """ne.fused.warp_dice backward == SpatialTransformer -> Dice backward == oracle."""
+    rng = np.random.default_rng(23 + L)
+    B, S = 2, (14, 12, 10)
+    mov = np.eye(L, dtype=F)[rng.integers(0, L, (B,) + S)]
+    fix = np.eye(L, dtype=F)[rng.integers(0, L, (B,) + S)]
+    flow = (rng.standard_normal((B,) + S + (3,)) * 2.0).astype(F)
+    flow[1, :2] = 0
+    wl = rng.uniform(0.5, 1.5, (B, L)).astype(F)
+    f = G(flow, dev, True)
+    d = ne.fused.warp_dice(G(mov, dev), f, G(fix, dev), fill_value=fill, laplace_smoothing=eps)
+    (-(d * G(wl, dev)).mean()).backward()
+    f2 = G(flow, dev, True)
+    warped = ne.layers.SpatialTransformer(fill_value=fill)([G(mov, dev), f2])
+    d2 = ne.metrics.Dice(check_input_limits=False, laplace_smoothing=eps).dice(G(fix, dev), warped)
+    (-(d2 * G(wl, dev)).mean()).backward()
+    close(N(f.grad), N(f2.grad), 'fused vs unfused')
+    for b in range(B):
+        ref, vo, lo = _shift_oracle(mov[b], flow[b], fill)
+        dd = go.soft_dice(D64(fix[b:b + 1]), ref[None], eps)
+        (-(dd * D64(wl[b:b + 1])).sum() / (B * L)).backward()
+        close(N(d[b]), dd.detach().numpy()[0], 'dice')
+        close(N(f.grad[b]), lo.grad.numpy(), 'grad_flow b%d' % b)
+    # single transform and 'xy' indexing
+    f1 = G(flow[:1], dev, True)
+    d = ne.fused.warp_dice(G(mov, dev), f1, G(fix, dev), single_transform=True, indexing='xy')
+    d.sum().backward()
+    f3 = G(flow[:1], dev, True)
+    warped = ne.layers.SpatialTransformer(single_transform=True, indexing='xy')([G(mov, dev), f3])
+    ne.metrics.Dice(check_input_limits=False).dice(G(fix, dev), warped).sum().backward()
+    close(N(f1.grad), N(f3.grad), 'single/xy')
+    with pytest.raises(NotImplementedError):
+        ne.fused.warp_dice(G(mov, dev, True), f1, G(fix, dev), single_transform=True)

@@ -55,6 +55,19 @@ def main():
         l.backward()
     res['reg_step_fwd_bwd_ms'] = timeit(step)
     res['Mvox_per_s_fwd_bwd'] = nvox / res['reg_step_fwd_bwd_ms'] / 1e3
+
+    fg = flow.clone().requires_grad_()
+    df = ne.fused.warp_dice(mov, fg, fix)
+    gd = torch.full_like(df, -1.0 / df.numel())
+    res['fused_fwd_ms'] = timeit(lambda: ne.fused.warp_dice(mov, flow, fix))
+    res['fused_bwd_ms'] = timeit(lambda: torch.autograd.grad(df, fg, gd, retain_graph=True))
+
+    def fstep():
+        f = flow.clone().requires_grad_()
+        l = -ne.fused.warp_dice(mov, f, fix).mean()
+        l.backward()
+    res['fused_step_fwd_bwd_ms'] = timeit(fstep)
+    res['fused_Mvox_per_s_fwd_bwd'] = nvox / res['fused_step_fwd_bwd_ms'] / 1e3
     print(json.dumps(res))
 
 
