@@ -90,6 +90,15 @@ int nrt_interpn_nearest_i32(const int32_t *vol, const float *loc, int32_t *out,
                             int batch, long long vol_batch_stride, long long loc_batch_stride,
                             int loc_mode, int has_fill, int32_t fill_value, void *stream);
 
+/* out = addend + interpn_linear(vol, loc): the update of voxelmorph's compose() (curr + transform(nxt, curr)) and of
+ * integrate_vec() (vec += transform(vec, vec); scaling and squaring) in one pass -- call sites
+ * neurite/tf/models.py:802-804, 1131, 1149-1154 (VecInt / ComposeTransform next to SpatialTransformer).
+ * addend [batch, out_shape, channels]; same rounding as the two separate TF ops (interp, then one add). */
+int nrt_interpn_add_f32(const float *vol, const float *loc, const float *addend, float *out, int ndim,
+                        const int *vol_shape, const int *out_shape, int channels, int batch,
+                        long long vol_batch_stride, long long loc_batch_stride, long long addend_batch_stride,
+                        int loc_mode, int has_fill, float fill_value, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dice
  * replaces: neurite/tf/metrics.py:415-482 (Dice.dice) incl. the optional renormalisation

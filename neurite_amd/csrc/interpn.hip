@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void interpn_generic(InterpArgs a) {
                 acc = nrt_add(acc, nrt_mul(wt, v));                          // :191
             }
             if (a.has_fill) acc = apply_fill(acc, oob, a.fill_f);
+            if (a.addend) acc = nrt_add(a.addend[(long long)b * a.addend_bs + (long long)e], acc);
             ((float *)out)[e] = acc;
         }
     }
@@ -649,6 +650,24 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 5: launch_tile_any(a, batch, loc_mode, tune, st); break;
         default: return NRT_ERR_INVALID_ARG;
     }
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_interpn_add_f32(const float *vol, const float *loc, const float *addend, float *out, int ndim,
+                                   const int *vol_shape, const int *out_shape, int channels, int batch,
+                                   long long vol_batch_stride, long long loc_batch_stride,
+                                   long long addend_batch_stride, int loc_mode, int has_fill, float fill_value,
+                                   void *stream) {
+    if (!addend) return NRT_ERR_INVALID_ARG;
+    InterpArgs a;
+    int rc = fill_args(a, vol, loc, out, ndim, vol_shape, out_shape, channels, batch, vol_batch_stride,
+                       loc_batch_stride, loc_mode, has_fill);
+    if (rc != NRT_OK) return rc;
+    a.fill_f = fill_value;
+    a.addend = addend; a.addend_bs = addend_batch_stride;
+    if (a.nout == 0) return NRT_OK;
+    launch_generic<NRT_INTERP_LINEAR, float>(a, ndim, batch, loc_mode, nrt_stream(stream));
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

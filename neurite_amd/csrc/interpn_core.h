@@ -19,6 +19,8 @@ struct InterpArgs {
     int has_fill;
     float fill_f;
     int fill_i;
+    const float *addend;   // generic linear kernel only: out = addend + interp (vxm compose / integrate), or null
+    long long addend_bs;
 };
 
 // ---- sampling location of output voxel q (coordinates qd) -------------------------------------
@@ -157,6 +159,7 @@ inline int fill_args(InterpArgs &a, const void *vol, const float *loc, void *out
     a.vol_bs = vol_bs; a.loc_bs = loc_bs; a.out_bs = (long long)nout * channels;
     a.has_fill = has_fill ? 1 : 0;
     a.fill_f = 0.0f; a.fill_i = 0;
+    a.addend = nullptr; a.addend_bs = 0;
     return NRT_OK;
 }
 

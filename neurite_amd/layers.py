@@ -17,7 +17,8 @@ from torch import nn
 from . import _lib
 from . import utils
 
-__all__ = ['Resize', 'Zoom', 'SpatialTransformer', 'LocallyConnected3D']
+__all__ = ['Resize', 'Zoom', 'SpatialTransformer', 'LocallyConnected3D', 'VecInt', 'RescaleTransform',
+           'ComposeTransform', 'AffineToDenseShift']
 
 
 class _Layer(nn.Module):
@@ -203,6 +204,147 @@ class SpatialTransformer(_Layer):
                                utils._METHODS[self.interp_method], self.fill_value, batched=True,
                                single_transform=self.single_transform, variant=self._variant, tune=self._tune)
         return out if restore is None else out.to(restore)
+
+
+# ------------------------------------------------------------------------------------------
+# VoxelMorph companions of SpatialTransformer: the layers neurite/tf/models.py instantiates right
+# next to it (:802-804 RescaleTransform/VecInt in labels_to_image, :1131, :1149-1154).  voxelmorph is not
+# vendored by the reference; constructor arguments follow its published layers.
+# ------------------------------------------------------------------------------------------
+
+class VecInt(_Layer):
+    """
+    Integrate a stationary velocity field [B, *S, D] into a displacement field by scaling and squaring
+    (int_steps self-compositions, each one warp+add kernel pass) or by quadrature.
+    """
+
+    def __init__(self, indexing='ij', method='ss', int_steps=7, out_time_pt=1, ode_args=None, odeint_fn=None,
+                 **kwargs):
+        super().__init__(**kwargs)
+        assert indexing in ['ij', 'xy'], "indexing has to be 'ij' (matrix) or 'xy' (cartesian)"
+        self.indexing = indexing
+        self.method = method
+        self.int_steps = int_steps
+        self.inshape = None
+        self.out_time_pt = out_time_pt
+        self.odeint_fn = odeint_fn
+        self.ode_args = ode_args
+        if ode_args is None:
+            self.ode_args = {'rtol': 1e-6, 'atol': 1e-12}
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'indexing': self.indexing, 'method': self.method, 'int_steps': self.int_steps,
+                       'out_time_pt': self.out_time_pt, 'ode_args': self.ode_args, 'odeint_fn': self.odeint_fn})
+        return config
+
+    def build(self, input_shape):
+        self.built = True
+        trf_shape = input_shape[0] if isinstance(input_shape[0], (list, tuple)) else input_shape
+        self.inshape = trf_shape
+        if trf_shape[-1] != len(trf_shape) - 2:
+            raise Exception('transform ndims %d does not match expected ndims %d'
+                            % (trf_shape[-1], len(trf_shape) - 2))
+
+    def call(self, inputs):
+        if isinstance(inputs, (list, tuple)):
+            if len(inputs) > 1:
+                raise NotImplementedError('VecInt: out_time_pt input is not implemented')
+            inputs = inputs[0]
+        loc_shift = inputs
+        _lib.require_device(loc_shift)
+        loc_shift = loc_shift.reshape([-1, *self.inshape[1:]])
+        if self.indexing == 'xy' and loc_shift.shape[-1] > 1:          # cartesian: swap the first two components
+            loc_shift = torch.cat([loc_shift[..., 1:2], loc_shift[..., 0:1], loc_shift[..., 2:]], -1)
+        return utils.integrate_vec(loc_shift, method=self.method, nb_steps=self.int_steps, _batched=True)
+
+
+class RescaleTransform(_Layer):
+    """Rescale a transform: dense [B, *S, D] fields are resized and their vectors scaled; affines get a scaled translation."""
+
+    def __init__(self, zoom_factor, interp_method='linear', **kwargs):
+        super().__init__(**kwargs)
+        self.zoom_factor = zoom_factor
+        self.interp_method = interp_method
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'zoom_factor': self.zoom_factor, 'interp_method': self.interp_method})
+        return config
+
+    def compute_output_shape(self, input_shape):
+        if utils.is_affine_shape(input_shape[1:]):
+            return (input_shape[0], self.ndims, self.ndims + 1)
+        shape = [int(d * self.zoom_factor) for d in input_shape[1:-1]]
+        return (input_shape[0], *shape, self.ndims)
+
+    def build(self, input_shape):
+        self.ndims = (input_shape[-1] - 1) if utils.is_affine_shape(input_shape[1:]) else input_shape[-1]
+        self.built = True
+
+    def call(self, transform):
+        _lib.require_device(transform)
+        if utils.is_affine_shape(transform.shape[1:]):
+            return utils.rescale_affine(transform, self.zoom_factor)
+        return utils.rescale_dense_transform(transform, self.zoom_factor, interp_method=self.interp_method,
+                                             _batched=True)
+
+
+class ComposeTransform(_Layer):
+    """
+    Compose a list of affine [B, N, N+1] and/or dense [B, *S, N] transforms, T = T0 o T1 o ...; dense if any input is.
+    """
+
+    def __init__(self, interp_method='linear', shift_center=True, indexing='ij', **kwargs):
+        super().__init__(**kwargs)
+        self.interp_method = interp_method
+        self.shift_center = shift_center
+        self.indexing = indexing
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'interp_method': self.interp_method, 'shift_center': self.shift_center,
+                       'indexing': self.indexing})
+        return config
+
+    def build(self, input_shape):
+        if not isinstance(input_shape, (list, tuple)) or not isinstance(input_shape[0], (list, tuple)):
+            raise Exception('ComposeTransform must be called for a list of transforms.')
+        self.built = True
+
+    def call(self, transforms):
+        if len(transforms) == 1:
+            raise ValueError('ComposeTransform must be called for a list of transforms.')
+        _lib.require_device(*transforms)
+        return utils.compose(list(transforms), interp_method=self.interp_method, shift_center=self.shift_center,
+                             indexing=self.indexing, _batched=True)
+
+
+class AffineToDenseShift(_Layer):
+    """Affine [B, N, N+1] -> dense displacement field [B, *shape, N]."""
+
+    def __init__(self, shape, shift_center=True, **kwargs):
+        super().__init__(**kwargs)
+        self.shape = shape
+        self.ndims = len(shape)
+        self.shift_center = shift_center
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'shape': self.shape, 'shift_center': self.shift_center})
+        return config
+
+    def compute_output_shape(self, input_shape):
+        return (input_shape[0], *self.shape, self.ndims)
+
+    def build(self, input_shape):
+        utils.validate_affine_shape(input_shape)
+        self.built = True
+
+    def call(self, mat):
+        _lib.require_device(mat)
+        return torch.stack([utils.affine_to_dense_shift(mat[b], self.shape, shift_center=self.shift_center)
+                            for b in range(mat.shape[0])], 0)
 
 
 def _normalize_tuple(value, n, name):

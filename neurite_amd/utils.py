@@ -19,7 +19,8 @@ import torch
 
 from . import _lib
 
-__all__ = ['interpn', 'resize', 'zoom', 'transform', 'affine_to_dense_shift', 'volshape_to_ndgrid',
+__all__ = ['interpn', 'resize', 'zoom', 'transform', 'affine_to_dense_shift', 'integrate_vec', 'compose',
+           'rescale_dense_transform', 'rescale_affine', 'is_affine_shape', 'validate_affine_shape', 'make_square_affine', 'volshape_to_ndgrid',
            'volshape_to_meshgrid', 'ndgrid', 'meshgrid', 'sub2ind2d', 'prod_n', 'batch_channel_flatten',
            'flatten_batch_channel', 'flatten_axes']
 
@@ -314,6 +315,162 @@ def affine_to_dense_shift(matrix, shape, shift_center=True, indexing='ij'):
     mesh_matrix = torch.stack(flat, 0)                        # [D+1, V]
     loc = (matrix @ mesh_matrix).transpose(0, 1).reshape(list(shape) + [D])
     return loc - torch.stack(mesh, -1)
+
+
+# --------------------------------------------------------------------------------------
+# VoxelMorph companions of SpatialTransformer (called by the reference next to it, neurite/tf/models.py:802-804,
+# 1131, 1149-1154; voxelmorph itself is not vendored, so these follow its published semantics)
+# --------------------------------------------------------------------------------------
+
+def _warp_add(src, shift, batched, interp_method='linear', fill_value=None):
+    """
+    shift + transform(src, shift) in 'ij' coordinates: one kernel pass (csrc/interpn.hip, nrt_interpn_add_f32).
+    src [B?, *S, C], shift [B?, *S', D] float32.  Falls back to the differentiable two-op form under autograd.
+    """
+    lib = _lib.lib()
+    dev = _lib.require_device(src, shift)
+    if interp_method != 'linear':
+        assert interp_method == 'nearest', 'method should be linear or nearest, got: %s' % interp_method
+    if src.dtype != torch.float32 or shift.dtype != torch.float32:
+        raise NotImplementedError('displacement fields must be float32')
+    D = shift.shape[-1]
+    if src.shape[-1] != shift.shape[-1] and src.shape[-1] != D:
+        raise ValueError('cannot add a %d-channel warped field to a %d-D displacement' % (src.shape[-1], D))
+    needs = torch.is_grad_enabled() and (src.requires_grad or shift.requires_grad)
+    out_spatial = list(shift.shape[1:-1] if batched else shift.shape[:-1])
+    if needs or interp_method != 'linear':
+        return shift + _interp_op(src, shift, out_spatial, _lib.LOC_SHIFT, _METHODS[interp_method], fill_value,
+                                  batched=batched)
+    src = src.contiguous()
+    shift = shift.contiguous()
+    B = src.shape[0] if batched else 1
+    S = list(src.shape[1:-1] if batched else src.shape[:-1])
+    if len(S) != D or D < 1 or D > 3:
+        raise Exception("Number of loc Tensors %d does not match volume dimension %d" % (D, len(S)))
+    if batched and shift.shape[0] != B:
+        raise ValueError('batch size of the two transforms differs')
+    Cc = src.shape[-1]
+    out = torch.empty_like(shift)
+    if out.numel() == 0:
+        return out
+    has_fill = fill_value is not None
+    with torch.cuda.device(dev):
+        rc = lib.nrt_interpn_add_f32(_lib.ptr(src), _lib.ptr(shift), _lib.ptr(shift), _lib.ptr(out), D, _lib.ints(S),
+                                     _lib.ints(out_spatial), Cc, B, int(np.prod(S)) * Cc,
+                                     int(np.prod(out_spatial)) * D, int(np.prod(out_spatial)) * Cc, _lib.LOC_SHIFT,
+                                     int(has_fill), float(fill_value) if has_fill else 0.0, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_interpn_add_f32')
+    return out
+
+
+def integrate_vec(vec, time_dep=False, method='ss', _batched=False, **kwargs):
+    """
+    voxelmorph.utils.integrate_vec for one stationary velocity field [*S, D] ('ij' coordinates).
+    'ss' / 'scaling_and_squaring': vec /= 2**nb_steps; nb_steps x (vec += transform(vec, vec)).
+    'quadrature': vec /= nb_steps; disp = vec; (nb_steps - 1) x (disp += transform(vec, disp)).
+    """
+    if method not in ['ss', 'scaling_and_squaring', 'ode', 'quadrature']:
+        raise ValueError("method has to be 'scaling_and_squaring' or 'ode'. found: %s" % method)
+    if time_dep:
+        raise NotImplementedError('integrate_vec: time-dependent velocity fields are not implemented')
+    if method == 'ode':
+        raise NotImplementedError("integrate_vec: method='ode' (tf odeint) is not implemented")
+    _lib.require_device(vec)
+    vec = vec.to(torch.float32)
+    nb_steps = kwargs['nb_steps']
+    if method in ['ss', 'scaling_and_squaring']:
+        assert nb_steps >= 0, 'nb_steps should be >= 0, found: %d' % nb_steps
+        vec = vec / (2 ** nb_steps)
+        for _ in range(nb_steps):
+            vec = _warp_add(vec, vec, _batched)
+        return vec
+    assert nb_steps >= 1, 'nb_steps should be >= 1, found: %d' % nb_steps
+    vec = vec / nb_steps
+    disp = vec
+    for _ in range(nb_steps - 1):
+        disp = _warp_add(vec, disp, _batched)
+    return disp
+
+
+def validate_affine_shape(shape):
+    """voxelmorph.utils.validate_affine_shape: (..., N, N+1) or (..., N+1, N+1) with N in (2, 3)."""
+    ndim = shape[-1] - 1
+    rows = shape[-2]
+    if ndim not in (2, 3) or rows not in (ndim, ndim + 1):
+        raise ValueError(f'Affine matrix must be of shape (2, 3) or (3, 4), got {tuple(shape[-2:])}.')
+
+
+def is_affine_shape(shape):
+    """voxelmorph.utils.is_affine_shape on a shape without the batch axis."""
+    if len(shape) == 2 and shape[-1] != 1:
+        validate_affine_shape(shape)
+        return True
+    return False
+
+
+def make_square_affine(mat):
+    """voxelmorph.utils.make_square_affine: append the homogeneous row to [..., N, N+1] matrices."""
+    validate_affine_shape(mat.shape)
+    if mat.shape[-2] == mat.shape[-1]:
+        return mat
+    row = torch.zeros(tuple(mat.shape[:-2]) + (1, mat.shape[-1]), dtype=mat.dtype, device=mat.device)
+    row[..., -1] = 1
+    return torch.cat([mat, row], -2)
+
+
+def rescale_affine(mat, factor):
+    """voxelmorph.utils.rescale_affine: scale the translation column."""
+    return torch.cat([mat[..., :-1], (mat[..., -1] * factor).unsqueeze(-1)], -1)
+
+
+def rescale_dense_transform(transform_field, factor, interp_method='linear', _batched=False):
+    """
+    voxelmorph.utils.rescale_dense_transform: resize a displacement field and scale its vectors; the resize comes
+    first when shrinking (factor < 1) and last when growing, as upstream.
+    """
+    from . import layers as _layers
+
+    def rs(t):
+        if _batched:
+            return _layers.Resize(factor, interp_method=interp_method)(t)
+        return resize(t, factor, interp_method=interp_method)
+
+    if factor < 1:
+        return rs(transform_field) * factor
+    return rs(transform_field * factor)
+
+
+def compose(transforms, interp_method='linear', shift_center=True, indexing='ij', _batched=False):
+    """
+    voxelmorph.utils.compose: compose a list of affine matrices and/or dense displacement fields (un-batched) into
+    one transform, T = transforms[0] o transforms[1] o ...; the result is dense if any input is.
+    """
+    if indexing != 'ij':
+        raise ValueError('Compose transform only supports ij indexing')
+    if len(transforms) < 2:
+        raise ValueError('Compose transform list size must be greater than 1')
+
+    def affine(t):
+        return is_affine_shape(t.shape[1:] if _batched else t.shape)
+
+    def densify(t, shape):
+        if not affine(t):
+            return t
+        if _batched:
+            return torch.stack([affine_to_dense_shift(t[b], shape, shift_center=shift_center, indexing=indexing)
+                                for b in range(t.shape[0])], 0)
+        return affine_to_dense_shift(t, shape, shift_center=shift_center, indexing=indexing)
+
+    curr = transforms[-1]
+    for nxt in reversed(transforms[:-1]):
+        dense = next((t for t in (nxt, curr) if not affine(t)), None)
+        if dense is not None:
+            shape = list(dense.shape[1:-1] if _batched else dense.shape[:-1])
+            nxt_d, curr_d = densify(nxt, shape), densify(curr, shape)
+            curr = _warp_add(nxt_d.to(torch.float32), curr_d.to(torch.float32), _batched, interp_method)
+        else:
+            curr = torch.matmul(make_square_affine(nxt), make_square_affine(curr))[..., :-1, :]
+    return curr
 
 
 # --------------------------------------------------------------------------------------

@@ -301,6 +301,66 @@ def spatial_transformer(vol, trf, interp_method='linear', indexing='ij', single_
 
 
 # --------------------------------------------------------------------------------------
+# voxelmorph companions built on transform() (call sites neurite/tf/models.py:802-804, 1131, 1149-1154).
+# voxelmorph is not vendored: published semantics restated -- parity unpinned, like SpatialTransformer.
+# --------------------------------------------------------------------------------------
+
+def integrate_vec(vec, method='ss', nb_steps=7):
+    """vxm.utils.integrate_vec, stationary field [*S, D] float32."""
+    vec = np.asarray(vec, F32)
+    if method in ('ss', 'scaling_and_squaring'):
+        vec = (vec / F32(2 ** nb_steps)).astype(F32)
+        for _ in range(nb_steps):
+            vec = (vec + transform(vec, vec)).astype(F32)
+        return vec
+    assert method == 'quadrature'
+    vec = (vec / F32(nb_steps)).astype(F32)
+    disp = vec
+    for _ in range(nb_steps - 1):
+        disp = (disp + transform(vec, disp)).astype(F32)
+    return disp
+
+
+def rescale_dense_transform(trf, factor, interp_method='linear'):
+    """vxm.utils.rescale_dense_transform for one field [*S, D]."""
+    trf = np.asarray(trf, F32)
+    if factor < 1:
+        return (resize(trf, factor, interp_method) * F32(factor)).astype(F32)
+    return resize((trf * F32(factor)).astype(F32), factor, interp_method)
+
+
+def is_affine_shape(shape):
+    return len(shape) == 2 and shape[-1] != 1
+
+
+def make_square_affine(mat):
+    mat = np.asarray(mat, F32)
+    if mat.shape[-2] == mat.shape[-1]:
+        return mat
+    row = np.zeros(mat.shape[:-2] + (1, mat.shape[-1]), F32)
+    row[..., -1] = 1
+    return np.concatenate([mat, row], -2)
+
+
+def compose(transforms, interp_method='linear', shift_center=True):
+    """vxm.utils.compose ('ij' indexing), un-batched."""
+    curr = np.asarray(transforms[-1], F32)
+    for nxt in reversed(transforms[:-1]):
+        nxt = np.asarray(nxt, F32)
+        dense = next((t for t in (nxt, curr) if not is_affine_shape(t.shape)), None)
+        if dense is not None:
+            shape = dense.shape[:-1]
+            if is_affine_shape(nxt.shape):
+                nxt = affine_to_dense_shift(nxt, shape, shift_center=shift_center)
+            if is_affine_shape(curr.shape):
+                curr = affine_to_dense_shift(curr, shape, shift_center=shift_center)
+            curr = (curr + transform(nxt, curr, interp_method=interp_method)).astype(F32)
+        else:
+            curr = (make_square_affine(nxt) @ make_square_affine(curr))[:-1].astype(F32)
+    return curr
+
+
+# --------------------------------------------------------------------------------------
 # Dice  (neurite/tf/metrics.py:415-510, neurite/tf/losses.py:68-95)
 # --------------------------------------------------------------------------------------
 

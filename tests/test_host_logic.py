@@ -189,3 +189,25 @@ def test_shard_range():
                 covered += list(range(lo, hi))
             assert covered == list(range(n))
     assert shard_range(32, 3, 8) == (12, 16)
+
+
+def test_affine_helpers_cpu():
+    """pure shape / matrix helpers of the voxelmorph companions need no device"""
+    import torch
+    from neurite_amd import utils
+    assert utils.is_affine_shape((3, 4)) and utils.is_affine_shape((4, 4)) and utils.is_affine_shape((2, 3))
+    assert not utils.is_affine_shape((8, 8, 8, 3)) and not utils.is_affine_shape((16, 1))
+    with pytest.raises(ValueError, match='Affine matrix must be of shape'):
+        utils.is_affine_shape((5, 6))
+    m = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    sq = utils.make_square_affine(m)
+    assert sq.shape == (4, 4) and sq[3].tolist() == [0, 0, 0, 1] and torch.equal(sq[:3], m)
+    assert utils.make_square_affine(sq) is sq
+    r = utils.rescale_affine(m, 0.5)
+    assert torch.equal(r[:, :3], m[:, :3]) and torch.equal(r[:, 3], m[:, 3] * 0.5)
+    with pytest.raises(ValueError, match='only supports ij'):
+        utils.compose([m, m], indexing='xy')
+    with pytest.raises(ValueError, match='greater than 1'):
+        utils.compose([m])
+    c = utils.compose([m, m])                      # affine o affine never touches the device
+    assert torch.allclose(c, (sq @ sq)[:3])
