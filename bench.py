@@ -195,6 +195,20 @@ def sweep(args, dev, mov, fix, trf):
                      'GBs': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4)}
                 log(json.dumps(r))
                 res.append(r)
+            for tune in (0, 318784291):
+                for _ in range(2):
+                    ne.fused.warp_dice(mov, tr0, fix, _tune=tune)
+                e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+                e0.record()
+                for _ in range(10):
+                    ne.fused.warp_dice(mov, tr0, fix, _tune=tune)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 10
+                r = {'kernel': 'fused_' + name + '_shift', 'tune': tune, 'ms': round(ms, 4),
+                     'frac_268': round(INTERPN_BYTES_PER_VOXEL(args.labels, 3) * V * B / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                log(json.dumps(r))
+                res.append(r)
             del tr0
     # calibration: our own float4 copy kernel (plain / non-temporal, several grid sizes)
     lib = ne._lib.lib()

@@ -267,6 +267,10 @@ int nrt_wcce_bwd_f32(const float *y_true, const float *y_pred, const float *labe
  * non-temporal; calibrates the achievable mixed read/write HBM rate next to the kernels above.
  * ------------------------------------------------------------------------------------------ */
 int nrt_membench_copy_f32(const float *src, float *dst, long long n, int nontemporal, int blocks, void *stream);
+/* Diagnostic: L1-resident row gather with the lane pattern of the interpn kernels (8 lanes x 16 B per 128-byte row);
+ * src holds blocks * rows * 32 floats, every block re-reads its own window `iters` x 8 times.  pattern 0 contiguous,
+ * 1 scattered rows, 2 corner-like overlapping rows.  Calibrates the TA/L1 hit bandwidth next to the kernels. */
+int nrt_membench_l1_f32(const float *src, float *sink, int rows, int iters, int pattern, int blocks, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,29 +15,44 @@
 // Structure = interpn_tile (3-D output tiles, XCD-contiguous slabs, depth-2 software pipeline with
 // unconditional loads); the `fixed` row rides along as a ninth load of every pass.
 
+#include <stdlib.h>
+
 #include "dice_reduce.h"
 #include "interpn_core.h"
 
 namespace {
 
-template <int G, int MODE, bool STORE>
-__global__ __launch_bounds__(256) void warp_dice_tile(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
+template <int G, int MODE, bool STORE, int MINW>
+__global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
                                                       float *__restrict__ fpart, float *__restrict__ mpart) {
     constexpr int NG = 256 / G;
     constexpr int L = 4 * G;
     // persistent blocks: block (k = XCD, jb) walks the tiles jb, jb + nb, jb + 2 nb ... of XCD k's slab and
     // writes ONE partial at the end (gridDim.x <= 2048 keeps the second stage short)
-    const unsigned per = tg.per2 * tg.nTz;                     // tiles per XCD
-    const unsigned k = blockIdx.x % NRT_NXCD, jb = blockIdx.x / NRT_NXCD, nb = gridDim.x / NRT_NXCD;
+    const unsigned k = blockIdx.x % NRT_NXCD, jb = blockIdx.x / NRT_NXCD;
+    unsigned per = tg.per2 * tg.nTz;                           // tiles per XCD
+    unsigned nb = gridDim.x / NRT_NXCD;
+    int b = blockIdx.y;
+    unsigned ucol = 0, useg = 0, prow = blockIdx.x;            // x-march: patch, segment, partial row inside the batch
+    if (tg.x_march) {
+        // one tile per block: XCD k owns the contiguous range [k * perU, (k + 1) * perU) of (batch, segment, patch)
+        const unsigned per_batch = tg.ncol * tg.nseg, U = per_batch * tg.nbatch;
+        const unsigned perU = gridDim.x / NRT_NXCD;
+        const unsigned u = k * perU + jb;
+        if (jb >= perU || u >= U) return;
+        b = (int)(u / per_batch);
+        prow = u % per_batch;
+        useg = prow / tg.ncol; ucol = prow % tg.ncol;
+        per = jb + 1; nb = 1;                                  // the tile loop below runs exactly once
+    }
 
-    const int b = blockIdx.y;
     const char *volb = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
     const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
     nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
     const nrt_f4 *fix = (const nrt_f4 *)(fixed + (long long)b * a.out_bs);
     const int lg = threadIdx.x % G;
     const int g = threadIdx.x / G;
-    const int npass = tg.plane_major ? tg.tz : (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
+    int npass = tg.plane_major ? tg.tz : (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
     const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
 
     nrt_f4 stp = {0, 0, 0, 0}, stt = {0, 0, 0, 0}, spp = {0, 0, 0, 0};
@@ -48,8 +63,23 @@ __global__ __launch_bounds__(256) void warp_dice_tile(InterpArgs a, TileGeom tg,
         if (tg.z_outer) { tzi = j / tg.per2; t2l = j % tg.per2; }
         else { tzi = j % tg.nTz; t2l = j / tg.nTz; }
         const unsigned t2 = k * tg.per2 + t2l;
-        if (t2 >= tg.nT2) continue;
-        const int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi * tg.tz;
+        if (!tg.x_march && t2 >= tg.nT2) continue;
+        int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi * tg.tz;
+        if (tg.x_march) {
+            x0 = (int)(useg * tg.seglen);
+            // patches are enumerated region by region (2^lry x 2^lrz patches, row-major inside and across regions) so
+            // that the blocks resident on an XCD at one time cover a compact (y,z) window
+            const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
+            const unsigned nRz = (tg.nTz + RZ - 1) / RZ;
+            const unsigned reg = ucol / (RY * RZ), w = ucol % (RY * RZ);
+            const unsigned cy = (reg / nRz) * RY + w / RZ, cz = (reg % nRz) * RZ + w % RZ;
+            y0 = (int)cy << tg.lty;
+            z0 = (int)cz << tg.ltz;
+            if (cy >= tg.nTy || cz >= tg.nTz) npass = 0;
+            const int xlen = min((int)tg.seglen, a.O[0] - x0);
+            if (npass) npass = (xlen << (tg.lty + tg.ltz)) / NG;
+            if (npass <= 0) continue;
+        }
         auto voxel = [&](int pass, int (&qd)[NRT_MAXD], bool &valid) {
             int x, y, z;
             tile_voxel(tg, NG, pass, g, x0, y0, z0, x, y, z);
@@ -174,7 +204,7 @@ __global__ __launch_bounds__(256) void warp_dice_tile(InterpArgs a, TileGeom tg,
     }
     if (lane == 0) { red[wv][3 * L + 0] = mnt; red[wv][3 * L + 1] = mxt; red[wv][3 * L + 2] = mnp; red[wv][3 * L + 3] = mxp; }
     __syncthreads();
-    const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
+    const long long pbase = tg.x_march ? ((long long)b * (tg.ncol * tg.nseg) + prow) : ((long long)b * gridDim.x + blockIdx.x);
     for (int i = threadIdx.x; i < 3 * L; i += 256) {
         float s = red[0][i];
 #pragma unroll
@@ -197,18 +227,79 @@ size_t fused_ws_bytes(unsigned nblocks, int L, int batch) {
            grp * 4 * sizeof(float) + 256;
 }
 
-void fused_geom(const int *out_shape, int G, int tune, TileGeom &tg, unsigned &nblocks) {
+// nblocks = partial rows per batch entry
+void fused_geom(const int *out_shape, int G, int batch, int tune, TileGeom &tg, unsigned &nblocks) {
     tile_geometry(out_shape, G, tune, 3 | (3 << 4) | (4 << 8), tg, nblocks);   // default 8 x 8 x 16 tiles (profiles/r01)
     if (nblocks > (unsigned)DICE_MAX_BLOCKS) nblocks = DICE_MAX_BLOCKS;        // multiple of 8; blocks loop over tiles
+    int t = tune <= 0 ? 0 : tune;
+    if (t == 0 && G == 8) {
+        // default for 32 labels: x-march over 4 x 8 (y,z) patches, blocks dealt to the XCDs region by region
+        // (8 x 4 patches = 32 x 32 voxels).  Same speed as the 8 x 8 x 16 tiles (both sit on the L1-miss path, see
+        // DESIGN.md 4.3) but 0.69x their L2-miss traffic: 1.11x instead of 1.61x the algorithmic bytes (profiles/).
+        const unsigned cols = ((unsigned)(out_shape[1] + 3) / 4) * ((unsigned)(out_shape[2] + 7) / 8);
+        if (out_shape[0] >= 16 && cols * (unsigned)batch >= 512) {
+            t = 3 | (2 << 4) | (3 << 8) | (1 << 14) | (3 << 24) | (2 << 27);
+            tile_geometry(out_shape, G, t, t, tg, nblocks);
+        }
+    }
+    if (((t >> 14) & 1) && !tg.plane_major && out_shape[0] > 0) {
+        tg.x_march = 1;
+        tg.nbatch = (unsigned)batch;
+        tg.lry = (t >> 24) & 7; tg.lrz = (t >> 27) & 7;
+        {   // regions are padded to full size; out-of-range patches are empty blocks
+            const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
+            tg.ncol = ((tg.nTy + RY - 1) / RY) * ((tg.nTz + RZ - 1) / RZ) * RY * RZ;
+        }
+        unsigned nseg = (unsigned)(t >> 16) & 0xffu;
+        if (nseg == 0) {                                       // auto: at least two blocks per CU over the launch
+            nseg = (512u + tg.ncol * batch - 1) / (tg.ncol * batch);
+            if (nseg < 1) nseg = 1;
+        }
+        if (nseg > (unsigned)out_shape[0]) nseg = (unsigned)out_shape[0];
+        tg.seglen = ((unsigned)out_shape[0] + nseg - 1) / nseg;
+        tg.nseg = ((unsigned)out_shape[0] + tg.seglen - 1) / tg.seglen;
+        nblocks = tg.ncol * tg.nseg;
+    }
 }
 
 template <int G>
 void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store,
                   const float *fixed, float *fpart, float *mpart, hipStream_t st) {
     dim3 grid(nblocks, batch), blk(256);
+    // experiment knob: NRT_FUSED_LDS_KB pads every block with unused dynamic LDS to cap the blocks per CU
+    // NRT_FUSED_LDS_KB (experiments): unused dynamic LDS per block, caps the blocks per CU.  The x-march default is
+    // 75 KB = one block per CU, so that the 32 blocks an XCD runs together are one region whose rows stay in its L2.
+    static int lds_kb = -2;
+    if (lds_kb == -2) { const char *e = getenv("NRT_FUSED_LDS_KB"); lds_kb = e ? atoi(e) : -1; }
+    const unsigned dyn = (unsigned)(lds_kb >= 0 ? lds_kb : (tg.x_march ? 75 : 0)) * 1024u;
+    if (tg.x_march) {
+        grid = dim3(nrt_xcd_grid(nblocks * (unsigned)batch), 1);
+#define NRT_FUSED_X(MODE)                                                                                           \
+    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, 4>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
+    else {                                                                                                          \
+        static unsigned attr_dyn = 0;                                                                               \
+        if (dyn > 48 * 1024 && attr_dyn != dyn) {                                                                   \
+            (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, 4>,                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                        \
+            attr_dyn = dyn;                                                                                         \
+        }                                                                                                           \
+        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 4>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart);    \
+    }
+        switch (mode) {
+            case NRT_LOC_ABSOLUTE: NRT_FUSED_X(NRT_LOC_ABSOLUTE); break;
+            case NRT_LOC_SHIFT: NRT_FUSED_X(NRT_LOC_SHIFT); break;
+            default: NRT_FUSED_X(NRT_LOC_LINSPACE); break;
+        }
+#undef NRT_FUSED_X
+        return;
+    }
 #define NRT_FUSED(MODE)                                                                                          \
-    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
-    else hipLaunchKernelGGL((warp_dice_tile<G, MODE, false>), grid, blk, 0, st, a, tg, fixed, fpart, mpart)
+    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, 1>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
+    else {                                                                                                       \
+        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, 1>,                \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);    \
+        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 1>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
+    }
     switch (mode) {
         case NRT_LOC_ABSOLUTE: NRT_FUSED(NRT_LOC_ABSOLUTE); break;
         case NRT_LOC_SHIFT: NRT_FUSED(NRT_LOC_SHIFT); break;
@@ -223,7 +314,7 @@ extern "C" size_t nrt_warp_dice_workspace_bytes(const int *out_shape, int nlabel
     if (!out_shape || nlabels < 4 || nlabels % 4 || batch < 1) return 0;
     TileGeom tg;
     unsigned nblocks;
-    fused_geom(out_shape, nlabels / 4, tune, tg, nblocks);
+    fused_geom(out_shape, nlabels / 4, batch, tune, tg, nblocks);
     return fused_ws_bytes(nblocks, nlabels, batch);
 }
 
@@ -250,7 +341,7 @@ extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, con
     if (a.nout == 0) return NRT_ERR_INVALID_ARG;
     TileGeom tg;
     unsigned nblocks;
-    fused_geom(out_shape, G, tune, tg, nblocks);
+    fused_geom(out_shape, G, batch, tune, tg, nblocks);
     if (!workspace || workspace_bytes < fused_ws_bytes(nblocks, nlabels, batch)) return NRT_ERR_WORKSPACE;
     // carve: fpart, mpart, gsum, gmm
     DiceWs w;

@@ -278,16 +278,33 @@ __device__ __forceinline__ bool zrun_step(const InterpArgs &a, const char *__res
 // neighbours marching through z in step and meet their shared halo rows in L2.
 template <int MODE, int WX, int WY>
 __global__ __launch_bounds__(WX * WY * 64) void interpn_zrun_c32(InterpArgs a, int LZ, unsigned nTy, unsigned nZc,
-                                                                 unsigned nblk, int zc_outer) {
+                                                                 unsigned nblk, int zc_outer, int lreg, int nbatch) {
     const unsigned per = gridDim.x / NRT_NXCD;
     const unsigned kx = blockIdx.x % NRT_NXCD, jx = blockIdx.x / NRT_NXCD;
     const unsigned nT2 = nblk / nZc;                        // (x,y) patches
     const unsigned per2 = per / nZc;                        // patches owned by one XCD
     unsigned t, zc;
-    if (zc_outer) { zc = jx / per2; t = kx * per2 + jx % per2; }
-    else { zc = jx % nZc; t = kx * per2 + jx / nZc; }
-    if (t >= nT2) return;
-    const int b = blockIdx.y;
+    int b = blockIdx.y;
+    if (lreg > 0) {
+        // region order: the blocks an XCD runs together are the 2^lreg x 2^lreg patches of one compact (x,y) window
+        // of one volume, all marching through z; their shared halo rows meet in that XCD's L2 (grid.y == 1)
+        const unsigned R = 1u << lreg, nTx = nT2 / nTy;
+        const unsigned nRx = (nTx + R - 1) / R, nRy = (nTy + R - 1) / R;
+        const unsigned nT2p = nRx * nRy * R * R;
+        const unsigned u = kx * per + jx, U = (unsigned)nbatch * nZc * nT2p;
+        if (u >= U) return;
+        const unsigned tp = u % nT2p, rest = u / nT2p;
+        zc = rest % nZc;
+        b = (int)(rest / nZc);
+        const unsigned reg = tp / (R * R), w = tp % (R * R);
+        const unsigned tx = (reg / nRy) * R + w / R, ty = (reg % nRy) * R + w % R;
+        if (tx >= nTx || ty >= nTy) return;
+        t = tx * nTy + ty;
+    } else {
+        if (zc_outer) { zc = jx / per2; t = kx * per2 + jx % per2; }
+        else { zc = jx % nZc; t = kx * per2 + jx / nZc; }
+        if (t >= nT2) return;
+    }
     const char *vol = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
     const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
     nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
@@ -550,33 +567,46 @@ void launch_rows_any(const InterpArgs &a, int batch, int mode, int method, int t
 }
 
 template <int WX, int WY>
-void launch_zrun_w(const InterpArgs &a, int batch, int mode, int LZ, int zc_outer, hipStream_t st) {
+void launch_zrun_w(const InterpArgs &a, int batch, int mode, int LZ, int zc_outer, int lreg, unsigned dyn, hipStream_t st) {
     const unsigned nTx = (a.O[0] + 2 * WX - 1) / (2 * WX), nTy = (a.O[1] + 4 * WY - 1) / (4 * WY);
     const unsigned nZc = (a.O[2] + LZ - 1) / LZ;
     const unsigned per2 = (nTx * nTy + NRT_NXCD - 1) / NRT_NXCD;       // patches per XCD
     const unsigned nblk = nTx * nTy * nZc;
     dim3 grid(NRT_NXCD * per2 * nZc, batch), blk(WX * WY * 64);
-    switch (mode) {
-        case NRT_LOC_ABSOLUTE:
-            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_ABSOLUTE, WX, WY>), grid, blk, 0, st, a, LZ, nTy, nZc, nblk, zc_outer); break;
-        case NRT_LOC_SHIFT:
-            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_SHIFT, WX, WY>), grid, blk, 0, st, a, LZ, nTy, nZc, nblk, zc_outer); break;
-        default:
-            hipLaunchKernelGGL((interpn_zrun_c32<NRT_LOC_LINSPACE, WX, WY>), grid, blk, 0, st, a, LZ, nTy, nZc, nblk, zc_outer); break;
+    if (lreg > 0) {
+        const unsigned R = 1u << lreg;
+        const unsigned nT2p = ((nTx + R - 1) / R) * ((nTy + R - 1) / R) * R * R;
+        grid = dim3(nrt_xcd_grid(nT2p * nZc * (unsigned)batch), 1);
     }
+#define NRT_ZRUN(MODE)                                                                                              \
+    do {                                                                                                            \
+        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)interpn_zrun_c32<MODE, WX, WY>,               \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);       \
+        hipLaunchKernelGGL((interpn_zrun_c32<MODE, WX, WY>), grid, blk, dyn, st, a, LZ, nTy, nZc, nblk, zc_outer,   \
+                           lreg, batch);                                                                            \
+    } while (0)
+    switch (mode) {
+        case NRT_LOC_ABSOLUTE: NRT_ZRUN(NRT_LOC_ABSOLUTE); break;
+        case NRT_LOC_SHIFT: NRT_ZRUN(NRT_LOC_SHIFT); break;
+        default: NRT_ZRUN(NRT_LOC_LINSPACE); break;
+    }
+#undef NRT_ZRUN
 }
 
-// tune = LZ | zc_outer << 12 | patch << 16   (patch 0: 4x8, 1: 8x8, 2: 8x16, 3: 4x16 columns)
+// tune = LZ | zc_outer << 12 | patch << 16 | lreg << 20 | lds_kb << 24
+//   patch 0: 4x8, 1: 8x8, 2: 8x16, 3: 4x16 columns per block; lreg > 0: region order (2^lreg x 2^lreg patches per
+//   region); lds_kb: unused dynamic LDS per block, caps the blocks per CU so that an XCD's L2 holds one region's rows
 void launch_zrun(const InterpArgs &a, int batch, int mode, int variant, int tune, hipStream_t st) {
     (void)variant;
     int LZ = tune & 0xfff;
-    const int zc_outer = (tune >> 12) & 1, patch = (tune >> 16) & 3;
+    const int zc_outer = (tune >> 12) & 1, patch = (tune >> 16) & 3, lreg = (tune >> 20) & 7;
+    const unsigned dyn = (unsigned)((tune >> 24) & 0x7f) * 1024u;
     if (LZ <= 0 || LZ > a.O[2]) LZ = a.O[2];
     switch (patch) {
-        case 1: launch_zrun_w<4, 2>(a, batch, mode, LZ, zc_outer, st); break;
-        case 2: launch_zrun_w<4, 4>(a, batch, mode, LZ, zc_outer, st); break;
-        case 3: launch_zrun_w<2, 4>(a, batch, mode, LZ, zc_outer, st); break;
-        default: launch_zrun_w<2, 2>(a, batch, mode, LZ, zc_outer, st); break;
+        case 1: launch_zrun_w<4, 2>(a, batch, mode, LZ, zc_outer, lreg, dyn, st); break;
+        case 2: launch_zrun_w<4, 4>(a, batch, mode, LZ, zc_outer, lreg, dyn, st); break;
+        case 3: launch_zrun_w<2, 4>(a, batch, mode, LZ, zc_outer, lreg, dyn, st); break;
+        default: launch_zrun_w<2, 2>(a, batch, mode, LZ, zc_outer, lreg, dyn, st); break;
     }
 }
 

@@ -88,14 +88,23 @@ struct TileGeom {
     int z_outer;                // order inside an XCD's slab: 0 = z fastest, 1 = z outermost
     int plane_major;            // C == 32 only: a pass is one z-plane of a 4(x) x 8(y) patch, tz = z-chunk length
     int tz;                     // tile extent along z (= 1 << ltz unless plane_major)
+    // x-march (fused kernel): a block owns one (y,z) patch of 2^lty x 2^ltz voxels and walks x over one of nseg
+    // segments; every block is resident at once and the blocks of an XCD advance through the source x-planes
+    // together, so plane i+1 of a step is the L2-resident plane i of the next one
+    int x_march;
+    unsigned ncol, nseg, seglen;   // (y,z) patches per volume, x segments, x planes per segment
+    unsigned nbatch;
+    int lry, lrz;                  // log2 of the region extent in patches: consecutive blocks fill a (2^lry x 2^lrz) patch region
 };
 
-// tune word of the tiled kernels: ltx | lty << 4 | ltz << 8 | z_outer << 12 | plane_major << 13 | LZ << 16
+// tune word of the tiled kernels: ltx | lty << 4 | ltz << 8 | z_outer << 12 | plane_major << 13 | x_march << 14 | LZ << 16
+// (x_march, fused kernel only: bits 16.. = number of x segments, 0 = auto)
 inline void tile_geometry(const int *out_shape, int G, int tune, int default_tune, TileGeom &tg, unsigned &ntiles) {
     const int NG = 256 / G, WZ = 64 / G;
     if (tune <= 0) tune = default_tune;
     tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
     tg.plane_major = ((tune >> 13) & 1) && G == 8;
+    tg.x_march = 0; tg.ncol = 0; tg.nseg = 1; tg.seglen = 0; tg.nbatch = 1; tg.lry = 0; tg.lrz = 0;
     if (tg.plane_major) {
         tg.ltx = 2; tg.lty = 3; tg.ltz = 0;
         tg.tz = (tune >> 16) & 0xfff;

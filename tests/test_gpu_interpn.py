@@ -215,11 +215,15 @@ def test_properties(dev):
 
 
 def test_backward_is_loud(dev):
+    """ops without a backward kernel raise in backward instead of returning a silent zero gradient
+    (linear interpolation has one: tests/test_gpu_backward.py)"""
     vol = torch.randn(1, 6, 6, 6, 4, device=dev, requires_grad=True)
     trf = torch.zeros(1, 6, 6, 6, 3, device=dev)
-    out = ne.layers.SpatialTransformer()([vol, trf])
+    out = ne.layers.SpatialTransformer(interp_method='nearest')([vol, trf])
     with pytest.raises(NotImplementedError, match='backward'):
         out.sum().backward()
+    ne.layers.SpatialTransformer()([vol, trf]).sum().backward()
+    assert vol.grad is not None and torch.allclose(vol.grad, torch.ones_like(vol.grad))
 
 
 def test_full_size_cfg2_spatial_transformer(dev):
