@@ -77,7 +77,9 @@ int nrt_interpn_f32(const float *vol, const float *loc, float *out,
 /* Same, selecting a specific kernel (for tuning / benchmarking).  variant:
  *   0 auto | 1 generic element-per-thread | 2 row-per-lane-group (C%4==0)
  *   3 z-run with register reuse of the shared corner rows (ndim 3, C==32)
- * tune: variant-specific knob (variant 3: z-chunk length, 0 = whole line). */
+ *   5 3-D tiles with a depth-2 software pipeline (C%4==0, linear)
+ *   6 LDS-staged source box per 8x8x16 tile (ndim 3, C<=4, linear, >= 1024 outputs)
+ * tune: variant-specific knob (variant 3: z-chunk length | order | patch | region bits; variant 5: tile geometry). */
 int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out,
                        int ndim, const int *vol_shape, const int *out_shape, int channels,
                        int batch, long long vol_batch_stride, long long loc_batch_stride,

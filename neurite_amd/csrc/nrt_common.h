@@ -11,6 +11,7 @@
 #define NRT_MAXD 3
 
 typedef float nrt_f4 __attribute__((ext_vector_type(4)));
+typedef float nrt_f2 __attribute__((ext_vector_type(2)));
 typedef int nrt_i4 __attribute__((ext_vector_type(4)));
 
 #define NRT_CHECK_LAUNCH()                                   \

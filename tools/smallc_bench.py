@@ -1,0 +1,35 @@
+"""Warp / resize of few-channel volumes (images, flow fields): ms and fraction of the HBM roof (algorithmic bytes)."""
+import json, torch
+import neurite_amd as ne
+from neurite_amd import synth
+dev = torch.device('cuda:0')
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+S, B = 160, 4
+flow = torch.stack([synth.smooth_displacement(7 + b, S, device=dev) for b in range(B)])
+for C in (1, 2, 3, 4, 8, 16):
+    vol = torch.randn(B, S, S, S, C, device=dev)
+    for method in ('linear', 'nearest'):
+        st = ne.layers.SpatialTransformer(interp_method=method)
+        ms = timeit(lambda: st([vol, flow]))
+        nbytes = B * S ** 3 * (8 * C + 12)
+        print(json.dumps({'op': 'warp', 'C': C, 'method': method, 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1),
+                          'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
+# Resize x2 of a half-resolution flow field (RescaleTransform / labels_to_image, models.py:802-804)
+half = torch.randn(B, 80, 80, 80, 3, device=dev)
+rs = ne.layers.Resize(2)
+ms = timeit(lambda: rs(half))
+nbytes = B * (80 ** 3 * 12 + 160 ** 3 * 12)
+print(json.dumps({'op': 'resize x2 C=3', 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
+vi = ne.layers.VecInt(int_steps=7)
+ms = timeit(lambda: vi(flow), n=5)
+nbytes = 7 * B * S ** 3 * 36
+print(json.dumps({'op': 'VecInt 7 steps 160^3', 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
