@@ -220,6 +220,29 @@ int nrt_add_act_affine_f32(const float *a, const float *b, const float *scale, c
                            float *y, long long n, int channels, int activation, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward of the conv stack (what tf.GradientTape derives for neurite/tf/models.py:1345-1347, 1385, 1438,
+ * 1506-1508, 1531, 1604; float32, channels-last, stride 1)
+ *   nrt_act_bwd_f32        grad_pre = grad_out * act'(y), from the layer OUTPUT y (ELU: y > 0 ? 1 : y + 1)
+ *   nrt_conv3d_wgrad_f32   grad_weights [kx,ky,kz,cin,cout] += sum_v x[v + off(tap)] (x) grad_pre[v] (SAME padding) and
+ *                          grad_bias [cout] += sum_v grad_pre[v]; both must be ZERO-FILLED by the caller (float
+ *                          atomics, one per weight and block); x is the conv input as the layer saw it
+ *                          (the concatenation, if any, materialised); ksize entries 1 or 3, dilation <= 2
+ *   (grad_x = nrt_conv3d_f32(grad_pre, weights flipped in space and transposed in the channel axes))
+ *   nrt_maxpool3d_bwd_f32  stride == pool: the window's gradient goes to its first maximum
+ *   nrt_upsample_sum_f32   nearest up-sampling: grad_lo[v] = sum over the up^3 fine voxels of channels
+ *                          [channel_offset, channel_offset + channels) of grad_up [.., grad_channels]
+ *   nrt_softmax_bwd_f32    grad_in = y * (grad_out - sum_c grad_out_c y_c)
+ * ------------------------------------------------------------------------------------------ */
+int nrt_act_bwd_f32(const float *grad_out, const float *y, int activation, float *grad_pre, long long n, void *stream);
+int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float *grad_weights, float *grad_bias, int batch,
+                         const int *shape, int cin, int cout, const int *ksize, int dilation, void *stream);
+int nrt_maxpool3d_bwd_f32(const float *x, const float *grad_out, float *grad_x, int batch, const int *shape,
+                          int channels, const int *pool, int padding_same, void *stream);
+int nrt_upsample_sum_f32(const float *grad_up, int grad_channels, int channel_offset, float *grad_lo, int channels,
+                         int batch, const int *lo_shape, const int *up, void *stream);
+int nrt_softmax_bwd_f32(const float *y, const float *grad_out, float *grad_in, long long nvox, int channels, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * LocallyConnected3D, implementation 1 ('valid' padding, channels-last)
  * replaces: neurite/tf/layers.py:1126-1197 (local_conv: O slice ops + concat + K.batch_dot) and the
  * bias / activation of :1098-1101.

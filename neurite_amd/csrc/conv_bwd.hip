@@ -1,0 +1,434 @@
+// Backward kernels of the unet layer set (conv3d dgrad / wgrad and the small Keras layers), gfx950.
+//
+// Keras Conv3D (neurite/tf/models.py:1345-1347, 1506-1508), stride 1, SAME padding, y = act(conv(x, W) + b):
+//   dpre = g * act'(y)                         nrt_act_bwd_f32   (ELU: y > 0 ? 1 : y + 1; ReLU: y > 0)
+//   dX   = conv(dpre, flip(W)^T)               the forward MFMA kernel with transformed weights (host side)
+//   dW[t][ci][co] = sum_v x[v + off(t)][ci] * dpre[v][co],  db[co] = sum_v dpre[v][co]       nrt_conv3d_wgrad_f32
+// MaxPooling3D (:1438), UpSampling3D (:1531, nearest) and the channel softmax (:1604) have the elementwise backward
+// kernels below.
+//
+// wgrad as MFMA implicit GEMM (v_mfma_f32_16x16x4_f32, fp32 in / fp32 accumulate): for every tap the contraction runs
+// over voxels, D[ci][co] += A[ci][k = voxel] * B[k = voxel][co], and both operands are rows of channels-last tiles in
+// LDS -- lane l of a wave reads x[voxel(l >> 4)][16 cib + (l & 15)] and dpre[voxel(l >> 4)][16 cob + (l & 15)]: 16
+// consecutive floats per voxel, conflict-free when the row stride is 16 mod 32.  A block keeps a 4 x 4 x 8 voxel
+// tile of dpre and its halo tile of x in LDS, the four waves split the taps (wave w: taps w, w + 4, ...), and the
+// D tiles stay in registers over all the voxel tiles a (persistent) block visits; one float atomic per weight and
+// block at the end.  x is read once per (cin chunk, cout chunk) pair, weights never.
+
+#include "nrt_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2 };
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd(const nrt_f4 *__restrict__ g, const nrt_f4 *__restrict__ y, int act,
+                                               nrt_f4 *__restrict__ d, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const nrt_f4 gv = g[i], yv = y[i];
+        nrt_f4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float s = 1.0f;
+            if (act == ACT_ELU) s = yv[k] > 0.0f ? 1.0f : yv[k] + 1.0f;
+            else if (act == ACT_RELU) s = yv[k] > 0.0f ? 1.0f : 0.0f;
+            o[k] = gv[k] * s;
+        }
+        d[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_tail(const float *__restrict__ g, const float *__restrict__ y, int act,
+                                                    float *__restrict__ d, long long from, long long n) {
+    const long long i = from + threadIdx.x;
+    if (i < n) {
+        float s = 1.0f;
+        if (act == ACT_ELU) s = y[i] > 0.0f ? 1.0f : y[i] + 1.0f;
+        else if (act == ACT_RELU) s = y[i] > 0.0f ? 1.0f : 0.0f;
+        d[i] = g[i] * s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// max pooling, stride == pool: every input voxel belongs to at most one window; the window's gradient goes to its
+// first maximum (scan order x, y, z), zeros to the rest
+__global__ __launch_bounds__(256) void maxpool_bwd(const float *__restrict__ x, const float *__restrict__ g,
+                                                   float *__restrict__ dx, int X, int Y, int Z, int C, int OX, int OY, int OZ,
+                                                   int px, int py, int pz) {
+    const int b = blockIdx.y;
+    const float *xb = x + (long long)b * X * Y * Z * C;
+    const float *gb = g + (long long)b * OX * OY * OZ * C;
+    float *db = dx + (long long)b * X * Y * Z * C;
+    const long long total = (long long)OX * OY * OZ * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long long q = e / C;
+        const int oz = (int)(q % OZ), oy = (int)((q / OZ) % OY), ox = (int)(q / ((long long)OZ * OY));
+        float best = -INFINITY;
+        long long arg = -1;
+        for (int i = 0; i < px; ++i) for (int j = 0; j < py; ++j) for (int k = 0; k < pz; ++k) {
+            const int xx = ox * px + i, yy = oy * py + j, zz = oz * pz + k;
+            if (xx >= X || yy >= Y || zz >= Z) continue;
+            const long long idx = (((long long)xx * Y + yy) * Z + zz) * C + c;
+            const float v = xb[idx];
+            if (arg < 0 || v > best) { best = v; arg = idx; }
+        }
+        const float gv = gb[e];
+        for (int i = 0; i < px; ++i) for (int j = 0; j < py; ++j) for (int k = 0; k < pz; ++k) {
+            const int xx = ox * px + i, yy = oy * py + j, zz = oz * pz + k;
+            if (xx >= X || yy >= Y || zz >= Z) continue;
+            const long long idx = (((long long)xx * Y + yy) * Z + zz) * C + c;
+            db[idx] = idx == arg ? gv : 0.0f;
+        }
+    }
+}
+
+// nearest up-sampling backward: dlo[v] = sum of the up^3 fine voxels
+__global__ __launch_bounds__(256) void upsample_sum(const float *__restrict__ g, int gstride, int goff, float *__restrict__ dlo,
+                                                    int X1, int Y1, int Z1, int C, int ux, int uy, int uz) {
+    const int b = blockIdx.y;
+    const int Y = Y1 * uy, Z = Z1 * uz;
+    const float *gb = g + (long long)b * X1 * ux * Y * Z * gstride + goff;
+    float *db = dlo + (long long)b * X1 * Y1 * Z1 * C;
+    const long long total = (long long)X1 * Y1 * Z1 * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long long q = e / C;
+        const int z = (int)(q % Z1), y = (int)((q / Z1) % Y1), x = (int)(q / ((long long)Z1 * Y1));
+        float s = 0.0f;
+        for (int i = 0; i < ux; ++i) for (int j = 0; j < uy; ++j) for (int k = 0; k < uz; ++k)
+            s += gb[((((long long)(x * ux + i)) * Y + (y * uy + j)) * Z + (z * uz + k)) * gstride + c];
+        db[e] = s;
+    }
+}
+
+// softmax backward over the last axis: dz = y * (g - sum_c g_c y_c); one thread per voxel
+__global__ __launch_bounds__(256) void softmax_bwd(const float *__restrict__ y, const float *__restrict__ g,
+                                                   float *__restrict__ dz, long long nvox, int C) {
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (long long)gridDim.x * 256) {
+        const float *yv = y + v * C, *gv = g + v * C;
+        float dot = 0.0f;
+        for (int c = 0; c < C; ++c) dot += gv[c] * yv[c];
+        for (int c = 0; c < C; ++c) dz[v * C + c] = yv[c] * (gv[c] - dot);
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void softmax_bwd_vec(const nrt_f4 *__restrict__ y, const nrt_f4 *__restrict__ g,
+                                                       nrt_f4 *__restrict__ dz, long long nvox) {
+    constexpr int NG = 256 / G;
+    const int lg = threadIdx.x % G;
+    const long long ngroups = (long long)gridDim.x * NG;
+    const long long niter = (nvox + ngroups - 1) / ngroups;
+    for (long long it = 0; it < niter; ++it) {
+        const long long vv = (long long)blockIdx.x * NG + threadIdx.x / G + it * ngroups;
+        const bool live = vv < nvox;
+        const long long v = live ? vv : nvox - 1;
+        const nrt_f4 yv = y[v * G + lg], gv = g[v * G + lg];
+        float dot = (gv[0] * yv[0] + gv[1] * yv[1]) + (gv[2] * yv[2] + gv[3] * yv[3]);
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) dot += __shfl_xor(dot, off, 64);
+        nrt_f4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = yv[k] * (gv[k] - dot);
+        if (live) dz[v * G + lg] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad
+// ---------------------------------------------------------------------------------------------
+struct WgArgs {
+    const float *x;          // [B, X, Y, Z, Cin]
+    const float *dp;         // [B, X, Y, Z, Cout]
+    float *dw;               // [kx, ky, kz, Cin, Cout], accumulated with atomics
+    float *db;               // [Cout] or null, accumulated with atomics
+    int B, X, Y, Z, Cin, Cout;
+    int kx, ky, kz, dil;
+    int ntx, nty, ntz;       // voxel tiles per volume
+    int ncic, ncoc;          // channel chunks
+    int im2col;              // single-channel input, 3x3x3 kernel: the 27 taps are staged as 27 "channels" of a 1x1x1 conv
+                             // (Cin = 27, kx = ky = kz = 1 above; dW[tap][0][co] and dW[0][tap][co] are the same memory)
+};
+
+constexpr int WT_X = 4, WT_Y = 4, WT_Z = 8;     // voxel tile: 128 voxels = 32 k-steps of 4
+constexpr int WG_MAXT = 7;                       // taps per wave: ceil(27 / 4)
+
+// NA, NB: 16-channel blocks of the cin / cout chunk handled by one block
+template <int NA, int NB>
+__global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CC = 16 * NA, CO = 16 * NB;
+    constexpr int RSA = (CC % 32 == 0) ? CC + 16 : CC;          // row strides: 16 mod 32 floats
+    constexpr int RSB = (CO % 32 == 0) ? CO + 16 : CO;
+    const int hx = a.kx > 1 ? a.dil : 0, hy = a.ky > 1 ? a.dil : 0, hz = a.kz > 1 ? a.dil : 0;
+    const int HX = WT_X + 2 * hx, HY = WT_Y + 2 * hy, HZ = WT_Z + 2 * hz;
+    const int nrowsA = HX * HY * HZ;
+    float *la = lds;                                            // [nrowsA][RSA]
+    float *lb = lds + nrowsA * RSA;                             // [128][RSB]
+    const int ntap = a.kx * a.ky * a.kz;
+    const int cic = blockIdx.y % a.ncic, coc = blockIdx.y / a.ncic;
+    const int ci0 = cic * CC, co0 = coc * CO;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    f32x4 acc[WG_MAXT][NA][NB];
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i)
+#pragma unroll
+        for (int na = 0; na < NA; ++na)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[i][na][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum = 0.0f;
+
+    // tap offsets (in LDS rows) of this wave's taps
+    int toff[WG_MAXT];
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i) {
+        const int t = min(wv + 4 * i, ntap - 1);
+        const int dz = t % a.kz, dy = (t / a.kz) % a.ky, dx = t / (a.kz * a.ky);
+        toff[i] = ((dx * a.dil) * HY + dy * a.dil) * HZ + dz * a.dil;
+    }
+
+    const long long tiles_per_vol = (long long)a.ntx * a.nty * a.ntz;
+    const long long ntiles = tiles_per_vol * a.B;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_vol);
+        const long long tv = tile % tiles_per_vol;
+        const int x0 = (int)(tv / ((long long)a.nty * a.ntz)) * WT_X, y0 = (int)((tv / a.ntz) % a.nty) * WT_Y,
+                  z0 = (int)(tv % a.ntz) * WT_Z;
+        const float *xb = a.x + (long long)b * a.X * a.Y * a.Z * a.Cin;
+        const float *pb = a.dp + (long long)b * a.X * a.Y * a.Z * a.Cout;
+        __syncthreads();                                        // previous tile fully consumed
+        // ---- stage the x halo tile (zero outside the volume = SAME padding, zero beyond Cin) ---------------
+        if (a.im2col) {
+            const float *x1 = a.x + (long long)b * a.X * a.Y * a.Z;
+            for (int e = threadIdx.x; e < 128 * CC; e += 256) {
+                const int r = e / CC, tl = e % CC, t = ci0 + tl;
+                const int rz = r % WT_Z, ry = (r / WT_Z) % WT_Y, rx = r / (WT_Z * WT_Y);
+                const int gx = x0 + rx + (t / 9 - 1) * a.dil, gy = y0 + ry + ((t / 3) % 3 - 1) * a.dil, gz = z0 + rz + (t % 3 - 1) * a.dil;
+                float v = 0.0f;
+                if (t < 27 && gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z)
+                    v = x1[((long long)gx * a.Y + gy) * a.Z + gz];
+                la[r * RSA + tl] = v;
+            }
+        } else
+        for (int e = threadIdx.x; e < nrowsA * (CC / 4); e += 256) {
+            const int r = e / (CC / 4), c4 = (e % (CC / 4)) * 4;
+            const int rz = r % HZ, ry = (r / HZ) % HY, rx = r / (HZ * HY);
+            const int gx = x0 + rx - hx, gy = y0 + ry - hy, gz = z0 + rz - hz;
+            nrt_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
+                const float *src = xb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.Cin + ci0 + c4;
+                if (ci0 + c4 + 3 < a.Cin && (a.Cin & 3) == 0) v = *(const nrt_f4 *)src;
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (ci0 + c4 + k < a.Cin) v[k] = src[k];
+                }
+            }
+            *(nrt_f4 *)(la + r * RSA + c4) = v;
+        }
+        // ---- stage the dpre tile (zero outside the volume and beyond Cout) ------------------------------------
+        for (int e = threadIdx.x; e < 128 * (CO / 4); e += 256) {
+            const int r = e / (CO / 4), c4 = (e % (CO / 4)) * 4;
+            const int rz = r % WT_Z, ry = (r / WT_Z) % WT_Y, rx = r / (WT_Z * WT_Y);
+            const int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
+            nrt_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (gx < a.X && gy < a.Y && gz < a.Z) {
+                const float *src = pb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.Cout + co0 + c4;
+                if (co0 + c4 + 3 < a.Cout && (a.Cout & 3) == 0) v = *(const nrt_f4 *)src;
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (co0 + c4 + k < a.Cout) v[k] = src[k];
+                }
+            }
+            *(nrt_f4 *)(lb + r * RSB + c4) = v;
+        }
+        __syncthreads();
+        // ---- bias gradient: column sums of the dpre tile (cin chunk 0 only) --------------------------------
+        if (a.db && cic == 0 && threadIdx.x < CO) {
+            float s = 0.0f;
+            for (int r = 0; r < 128; ++r) s += lb[r * RSB + threadIdx.x];
+            bsum += s;
+        }
+        // ---- 32 k-steps of 4 consecutive-z voxels --------------------------------------------------------------
+        for (int ks = 0; ks < 32; ++ks) {
+            const int zh = ks & 1, yy = (ks >> 1) & 3, xx = ks >> 3;
+            const int vrow = (xx * WT_Y + yy) * WT_Z + zh * 4 + l4;                       // row in the dpre tile
+            const int arow = (xx * HY + yy) * HZ + zh * 4 + l4;                           // row in the halo tile, tap (0,0,0)
+            float bf[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bf[nb] = lb[vrow * RSB + nb * 16 + l15];
+#pragma unroll
+            for (int i = 0; i < WG_MAXT; ++i) {
+                if (wv + 4 * i < ntap) {
+#pragma unroll
+                    for (int na = 0; na < NA; ++na) {
+                        const float af = la[(arow + toff[i]) * RSA + na * 16 + l15];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[i][na][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[nb], acc[i][na][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- accumulate into global memory: D row = 4 (lane >> 4) + r (ci), col = lane & 15 (co) -----------------------
+#pragma unroll
+    for (int i = 0; i < WG_MAXT; ++i) {
+        const int t = wv + 4 * i;
+        if (t < ntap) {
+#pragma unroll
+            for (int na = 0; na < NA; ++na)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int co = co0 + nb * 16 + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = ci0 + na * 16 + l4 * 4 + r;
+                        if (ci < a.Cin && co < a.Cout)
+                            unsafeAtomicAdd(&a.dw[((long long)t * a.Cin + ci) * a.Cout + co], acc[i][na][nb][r]);
+                    }
+                }
+        }
+    }
+    if (a.db && cic == 0 && threadIdx.x < CO && co0 + (int)threadIdx.x < a.Cout) unsafeAtomicAdd(&a.db[co0 + threadIdx.x], bsum);
+}
+
+template <int NA, int NB>
+int launch_wgrad(WgArgs &a, hipStream_t st) {
+    constexpr int CC = 16 * NA, CO = 16 * NB;
+    constexpr int RSA = (CC % 32 == 0) ? CC + 16 : CC, RSB = (CO % 32 == 0) ? CO + 16 : CO;
+    const int hx = a.kx > 1 ? a.dil : 0, hy = a.ky > 1 ? a.dil : 0, hz = a.kz > 1 ? a.dil : 0;
+    const size_t lds = ((size_t)(WT_X + 2 * hx) * (WT_Y + 2 * hy) * (WT_Z + 2 * hz) * RSA + 128 * RSB) * sizeof(float);
+    if (lds > 160 * 1024) return NRT_ERR_UNSUPPORTED;
+    a.ncic = (a.Cin + CC - 1) / CC;
+    a.ncoc = (a.Cout + CO - 1) / CO;
+    const long long ntiles = (long long)a.ntx * a.nty * a.ntz * a.B;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    long long bx = 256ll * per_cu / (a.ncic * a.ncoc);           // about one resident wave of blocks
+    if (bx < 64) bx = 64;
+    if (bx > ntiles) bx = ntiles;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)conv3d_wgrad<NA, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv3d_wgrad<NA, NB>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+unsigned ew_blocks(long long n, int per) {
+    long long b = (n + per - 1) / per;
+    if (b > 256ll * 16) b = 256ll * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int nrt_act_bwd_f32(const float *grad_out, const float *y, int activation, float *grad_pre, long long n,
+                               void *stream) {
+    if (!grad_out || !y || !grad_pre || n < 0) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_RELU) return NRT_ERR_INVALID_ARG;
+    if (n == 0) return NRT_OK;
+    hipStream_t st = nrt_stream(stream);
+    const bool al = ((((uintptr_t)grad_out | (uintptr_t)y | (uintptr_t)grad_pre) & 15) == 0);
+    const long long n4 = al ? n / 4 : 0;
+    if (n4) hipLaunchKernelGGL(act_bwd, dim3(ew_blocks(n4, 256)), dim3(256), 0, st, (const nrt_f4 *)grad_out, (const nrt_f4 *)y,
+                               activation, (nrt_f4 *)grad_pre, n4);
+    for (long long from = n4 * 4; from < n; from += 256)
+        hipLaunchKernelGGL(act_bwd_tail, dim3(1), dim3(256), 0, st, grad_out, y, activation, grad_pre, from, n);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_maxpool3d_bwd_f32(const float *x, const float *grad_out, float *grad_x, int batch, const int *shape,
+                                     int channels, const int *pool, int padding_same, void *stream) {
+    if (!x || !grad_out || !grad_x || !shape || !pool || batch < 1 || batch > 65535 || channels < 1) return NRT_ERR_INVALID_ARG;
+    const int X = shape[0], Y = shape[1], Z = shape[2];
+    if (pool[0] < 1 || pool[1] < 1 || pool[2] < 1) return NRT_ERR_INVALID_ARG;
+    const int OX = padding_same ? (X + pool[0] - 1) / pool[0] : X / pool[0];
+    const int OY = padding_same ? (Y + pool[1] - 1) / pool[1] : Y / pool[1];
+    const int OZ = padding_same ? (Z + pool[2] - 1) / pool[2] : Z / pool[2];
+    hipStream_t st = nrt_stream(stream);
+    if (!padding_same && (X % pool[0] || Y % pool[1] || Z % pool[2]))       // voxels outside every window get zero
+        if (hipMemsetAsync(grad_x, 0, (size_t)batch * X * Y * Z * channels * sizeof(float), st) != hipSuccess) return NRT_ERR_LAUNCH;
+    const long long total = (long long)OX * OY * OZ * channels;
+    if (total == 0) return NRT_OK;
+    hipLaunchKernelGGL(maxpool_bwd, dim3(ew_blocks(total, 256), batch), dim3(256), 0, st, x, grad_out, grad_x, X, Y, Z, channels,
+                       OX, OY, OZ, pool[0], pool[1], pool[2]);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_upsample_sum_f32(const float *grad_up, int grad_channels, int channel_offset, float *grad_lo, int channels,
+                                    int batch, const int *lo_shape, const int *up, void *stream) {
+    if (!grad_up || !grad_lo || !lo_shape || !up || batch < 1 || batch > 65535 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (channel_offset < 0 || channel_offset + channels > grad_channels) return NRT_ERR_INVALID_ARG;
+    if (up[0] < 1 || up[1] < 1 || up[2] < 1) return NRT_ERR_INVALID_ARG;
+    const long long total = (long long)lo_shape[0] * lo_shape[1] * lo_shape[2] * channels;
+    if (total == 0) return NRT_OK;
+    hipLaunchKernelGGL(upsample_sum, dim3(ew_blocks(total, 256), batch), dim3(256), 0, nrt_stream(stream), grad_up, grad_channels,
+                       channel_offset, grad_lo, lo_shape[0], lo_shape[1], lo_shape[2], channels, up[0], up[1], up[2]);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_softmax_bwd_f32(const float *y, const float *grad_out, float *grad_in, long long nvox, int channels,
+                                   void *stream) {
+    if (!y || !grad_out || !grad_in || nvox < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (nvox == 0) return NRT_OK;
+    hipStream_t st = nrt_stream(stream);
+    const int G = channels / 4;
+    const bool al = ((((uintptr_t)y | (uintptr_t)grad_out | (uintptr_t)grad_in) & 15) == 0);
+    if (al && channels % 4 == 0 && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16)) {
+        const unsigned vb = ew_blocks(nvox, 256 / G);
+#define NRT_SMB(GG) hipLaunchKernelGGL((softmax_bwd_vec<GG>), dim3(vb), dim3(256), 0, st, (const nrt_f4 *)y, (const nrt_f4 *)grad_out, (nrt_f4 *)grad_in, nvox)
+        switch (G) {
+            case 1: NRT_SMB(1); break;
+            case 2: NRT_SMB(2); break;
+            case 4: NRT_SMB(4); break;
+            case 8: NRT_SMB(8); break;
+            default: NRT_SMB(16); break;
+        }
+#undef NRT_SMB
+    } else {
+        hipLaunchKernelGGL(softmax_bwd, dim3(ew_blocks(nvox, 256)), dim3(256), 0, st, y, grad_out, grad_in, nvox, channels);
+    }
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float *grad_weights, float *grad_bias, int batch,
+                                    const int *shape, int cin, int cout, const int *ksize, int dilation, void *stream) {
+    if (!x || !grad_pre || !grad_weights || !shape || !ksize) return NRT_ERR_INVALID_ARG;
+    if (batch < 1 || cin < 1 || cout < 1 || dilation < 1) return NRT_ERR_INVALID_ARG;
+    for (int d = 0; d < 3; ++d) {
+        if (shape[d] < 1 || ksize[d] < 1) return NRT_ERR_INVALID_ARG;
+        if (ksize[d] != 1 && ksize[d] != 3) return NRT_ERR_UNSUPPORTED;           // the kernel sizes of the conv stacks
+    }
+    if (dilation > 2) return NRT_ERR_UNSUPPORTED;
+    WgArgs a;
+    a.x = x; a.dp = grad_pre; a.dw = grad_weights; a.db = grad_bias;
+    a.B = batch; a.X = shape[0]; a.Y = shape[1]; a.Z = shape[2]; a.Cin = cin; a.Cout = cout;
+    a.kx = ksize[0]; a.ky = ksize[1]; a.kz = ksize[2]; a.dil = dilation;
+    a.ntx = (a.X + WT_X - 1) / WT_X; a.nty = (a.Y + WT_Y - 1) / WT_Y; a.ntz = (a.Z + WT_Z - 1) / WT_Z;
+    a.im2col = 0;
+    if (cin == 1 && ksize[0] == 3 && ksize[1] == 3 && ksize[2] == 3) {
+        a.im2col = 1; a.Cin = 27; a.kx = a.ky = a.kz = 1;
+        cin = 27;
+    }
+    hipStream_t st = nrt_stream(stream);
+    int na = cin <= 16 ? 1 : (cin <= 32 ? 2 : 3);
+    const int nb = cout <= 16 ? 1 : 2;
+    // dilated kernels have larger halo tiles: shrink the cin chunk until the tiles fit the LDS
+    for (; na >= 1; --na) {
+        int rc;
+        if (na == 1) rc = nb == 1 ? launch_wgrad<1, 1>(a, st) : launch_wgrad<1, 2>(a, st);
+        else if (na == 2) rc = nb == 1 ? launch_wgrad<2, 1>(a, st) : launch_wgrad<2, 2>(a, st);
+        else rc = nb == 1 ? launch_wgrad<3, 1>(a, st) : launch_wgrad<3, 2>(a, st);
+        if (rc != NRT_ERR_UNSUPPORTED) return rc;
+    }
+    return NRT_ERR_UNSUPPORTED;
+}

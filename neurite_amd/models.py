@@ -98,6 +98,12 @@ class _Conv(nn.Module):
 
     def forward(self, x, lo=None, up=None, variant=0):
         """x [B, X, Y, Z, c0]; optional lo [B, X/up, Y/up, Z/up, c1] is nearest-upsampled and concatenated after x."""
+        if torch.is_grad_enabled() and (x.requires_grad or (lo is not None and lo.requires_grad)
+                                        or self.kernel.requires_grad or self.bias.requires_grad):
+            return _ConvFn.apply(x, lo, self.kernel, self.bias, self, up, variant, False)
+        return self._run(x, lo, up, variant)
+
+    def _run(self, x, lo=None, up=None, variant=0):
         lib = _lib.lib()
         dev = _lib.require_device(x, lo, self.kernel)
         if x.dtype != torch.float32:
@@ -214,6 +220,204 @@ def _softmax(x):
     return y
 
 
+# --------------------------------------------------------------------------------------
+# autograd: the backward kernels of csrc/conv_bwd.hip behind torch.autograd.Function
+# --------------------------------------------------------------------------------------
+
+def _act_bwd(g, y, act):
+    if act == 0:
+        return g.contiguous()
+    lib = _lib.lib()
+    dev = g.device
+    g = g.contiguous()
+    d = torch.empty_like(g)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_act_bwd_f32(_lib.ptr(g), _lib.ptr(y), int(act), _lib.ptr(d), g.numel(), _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_act_bwd_f32')
+    return d
+
+
+def _upsample_sum(g, c_off, c, lo_shape, up3):
+    """grad of nearest up-sampling: channels [c_off, c_off + c) of g [B, S, Cg] summed over up^3 blocks -> [B, S/up, c]."""
+    lib = _lib.lib()
+    dev = g.device
+    g = g.contiguous()
+    B = g.shape[0]
+    d = torch.empty([B] + list(lo_shape) + [c], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_upsample_sum_f32(_lib.ptr(g), g.shape[-1], int(c_off), _lib.ptr(d), int(c), B, _lib.ints(lo_shape),
+                                      _lib.ints(up3), _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_upsample_sum_f32')
+    return d
+
+
+def _conv_dgrad(dpre, wpart, ksize3, dilation):
+    """grad wrt the conv input: conv(dpre, weights flipped in space and transposed in the channel axes) on the forward kernel."""
+    lib = _lib.lib()
+    dev = dpre.device
+    cout, cpart = wpart.shape[-1], wpart.shape[-2]
+    wt = wpart.flip(0, 1, 2).transpose(3, 4).contiguous()             # [k, k, k, cout, cpart]; a few KB of glue
+    n = lib.nrt_conv3d_packed_weight_floats(_lib.ints(ksize3), cout, cpart)
+    packed = torch.empty(int(n), dtype=torch.float32, device=dev)
+    B, S = dpre.shape[0], list(dpre.shape[1:4])
+    out = torch.empty([B] + S + [cpart], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_conv3d_pack_weights_f32(_lib.ptr(wt), _lib.ints(ksize3), cout, cpart, _lib.ptr(packed), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv3d_pack_weights_f32')
+        rc = lib.nrt_conv3d_f32(_lib.ptr(dpre), cout, None, 0, None, _lib.ptr(wt), _lib.ptr(packed), None, _lib.ptr(out), B,
+                                _lib.ints(S), _lib.ints(ksize3), cpart, int(dilation), 1, 0, 0, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_conv3d_f32 (dgrad)')
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    """Conv3D (+ fused up-sample/concat loader, bias, activation) with dgrad / wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, lo, kernel, bias, mod, up, variant, one_by_one):
+        with torch.no_grad():
+            if one_by_one:
+                out = _conv1x1_softmax(x, kernel, bias, False, mod.act)
+            else:
+                out = mod._run(x, lo, up, variant)
+        ctx.mod, ctx.up = mod, up
+        ctx.save_for_backward(x, lo, kernel, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lo, kernel, out = ctx.saved_tensors
+        mod, up = ctx.mod, ctx.up
+        if mod.padding != 'same':
+            raise NotImplementedError("neurite_amd: conv backward is implemented for padding='same'")
+        lib = _lib.lib()
+        dev = g.device
+        dpre = _act_bwd(g, out, mod.act)
+        need_x, need_lo, need_w, need_b = ctx.needs_input_grad[:4]
+        dx = dlo = dw = db = None
+        c0 = x.shape[-1]
+        if need_w or need_b:
+            xin = x.contiguous() if lo is None else _upsample_concat(x, lo, up)
+            dw = torch.zeros_like(kernel, dtype=torch.float32)
+            db = torch.zeros(mod.cout, dtype=torch.float32, device=dev)
+            B, S = xin.shape[0], list(xin.shape[1:4])
+            with torch.cuda.device(dev):
+                rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xin), _lib.ptr(dpre), _lib.ptr(dw), _lib.ptr(db), B, _lib.ints(S),
+                                              mod.cin, mod.cout, _lib.ints(mod.ksize3), mod.dilation, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_conv3d_wgrad_f32')
+            del xin
+        k5 = kernel.detach()
+        if need_x:
+            dx = _conv_dgrad(dpre, k5[..., :c0, :], mod.ksize3, mod.dilation)
+        if lo is not None and need_lo:
+            full = _conv_dgrad(dpre, k5[..., c0:, :], mod.ksize3, mod.dilation)
+            dlo = _upsample_sum(full, 0, full.shape[-1], list(lo.shape[1:4]), up)
+        return dx, dlo, dw if need_w else None, db if need_b else None, None, None, None, None
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pool3, padding):
+        with torch.no_grad():
+            y = _maxpool(x, pool3, padding)
+        ctx.save_for_backward(x)
+        ctx.cfg = (tuple(pool3), padding)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        pool3, padding = ctx.cfg
+        lib = _lib.lib()
+        dev = g.device
+        x = x.contiguous()
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_maxpool3d_bwd_f32(_lib.ptr(x), _lib.ptr(g), _lib.ptr(dx), x.shape[0], _lib.ints(list(x.shape[1:4])),
+                                           x.shape[-1], _lib.ints(pool3), int(padding == 'same'), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_maxpool3d_bwd_f32')
+        return dx, None, None
+
+
+class _MergeFn(torch.autograd.Function):
+    """concatenate([skip, UpSampling3D(lo)]) (skip may be None: plain up-sampling)."""
+
+    @staticmethod
+    def forward(ctx, skip, lo, up3):
+        with torch.no_grad():
+            y = _upsample_concat(skip, lo, up3)
+        ctx.cfg = (0 if skip is None else skip.shape[-1], lo.shape[-1], list(lo.shape[1:4]), tuple(up3))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        c0, c1, lo_shape, up3 = ctx.cfg
+        dskip = g[..., :c0].contiguous() if c0 and ctx.needs_input_grad[0] else None
+        dlo = _upsample_sum(g, c0, c1, lo_shape, up3) if ctx.needs_input_grad[1] else None
+        return dskip, dlo, None
+
+
+class _HeadFn(torch.autograd.Function):
+    """likelihood 1x1 conv + channel softmax in one pass (no logits tensor); backward from the prediction alone."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, mod):
+        with torch.no_grad():
+            y = _conv1x1_softmax(x, kernel, bias, True, 0)
+        ctx.mod = mod
+        ctx.save_for_backward(x, kernel, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, kernel, y = ctx.saved_tensors
+        mod = ctx.mod
+        lib = _lib.lib()
+        dev = g.device
+        g = g.contiguous()
+        dz = torch.empty_like(y)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_softmax_bwd_f32(_lib.ptr(y), _lib.ptr(g), _lib.ptr(dz), y.numel() // y.shape[-1], y.shape[-1],
+                                         _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_softmax_bwd_f32')
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            xin = x.contiguous()
+            dw = torch.zeros_like(kernel, dtype=torch.float32)
+            db = torch.zeros(mod.cout, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xin), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(db), xin.shape[0],
+                                              _lib.ints(list(xin.shape[1:4])), mod.cin, mod.cout, _lib.ints(mod.ksize3), 1,
+                                              _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_conv3d_wgrad_f32')
+        if ctx.needs_input_grad[0]:
+            dx = _conv_dgrad(dz, kernel.detach(), mod.ksize3, 1)
+        return dx, dw, db, None
+
+
+class _SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        with torch.no_grad():
+            y = _softmax(z)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        lib = _lib.lib()
+        dev = g.device
+        g = g.contiguous()
+        dz = torch.empty_like(y)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_softmax_bwd_f32(_lib.ptr(y), _lib.ptr(g), _lib.ptr(dz), y.numel() // y.shape[-1], y.shape[-1],
+                                         _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_softmax_bwd_f32')
+        return dz
+
+
 class ConvNet(nn.Module):
     """
     A built conv_enc / conv_dec / unet graph: an ordered list of named Keras-equivalent layers
@@ -233,6 +437,7 @@ class ConvNet(nn.Module):
         self.layer_names = [op['name'] for op in ops]
         self.output_shape = ops[-1].get('shape') if ops else None
         self.conv_variant = 0                       # 0 auto, 1 direct, 2 MFMA (tests / tuning)
+        self.eval()                                 # Keras predict semantics; model.train() records the graph for autograd
 
     def get_layer(self, name):
         if name in self.layers_by_name:
@@ -262,6 +467,8 @@ class ConvNet(nn.Module):
         nd = self.ndims
         t = {}
         keep = set(return_tensors or [])
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(xs, keep, return_tensors)
         with torch.no_grad():
             for op in self.ops:
                 kind, name = op['kind'], op['name']
@@ -308,6 +515,59 @@ class ConvNet(nn.Module):
                         t[name] = _elementwise(t[op['src']], act=_act_code(op['activation']))
                 else:
                     raise RuntimeError('unknown op ' + kind)
+        if return_tensors:
+            return {k: _unlift(t[k], nd) for k in keep}
+        return _unlift(t[self.output_name], nd)
+
+
+    def _forward_train(self, xs, keep, return_tensors):
+        """model.train(): the same graph with every op recorded for autograd (csrc/conv_bwd.hip); the likelihood conv
+        and the softmax run unfused so that the logits are available to the backward."""
+        nd = self.ndims
+        t = {}
+        for op in self.ops:
+            kind, name = op['kind'], op['name']
+            if kind == 'input':
+                t[name] = _lift(xs[op['index']].to(torch.float32), nd)
+            elif kind == 'input_concat':
+                t[name] = torch.cat([t[s] for s in op['src']], -1).contiguous()
+            elif kind == 'conv':
+                lo = t[op['lo']] if op.get('lo') else None
+                m = self.layers_by_name[name]
+                t[name] = _ConvFn.apply(t[op['src']], lo, m.kernel, m.bias, m, op.get('up'), self.conv_variant, False)
+            elif kind == 'dropout':
+                if op.get('rate', 0):
+                    raise NotImplementedError('neurite_amd: training-mode Dropout is not implemented')
+                t[name] = t[op['src']]
+            elif kind == 'maxpool':
+                t[name] = _MaxPoolFn.apply(t[op['src']], op['pool'], op['padding'])
+            elif kind == 'upsample':
+                t[name] = _MergeFn.apply(None, t[op['src']], op['up'])
+            elif kind == 'merge':
+                if op.get('fused') and name not in keep:
+                    t[name] = None
+                else:
+                    t[name] = _MergeFn.apply(t[op['skip']], t[op['lo']], op['up'])
+            elif kind == 'likelihood':
+                m = self.layers_by_name[name]
+                if op.get('fuse_softmax') and name not in keep and m.cout <= 64 and tuple(m.ksize3) == (1, 1, 1):
+                    t[name] = None
+                    t[op['pred_name']] = _HeadFn.apply(t[op['src']], m.kernel, m.bias, m)
+                elif m.cout <= 64:
+                    t[name] = _ConvFn.apply(t[op['src']], None, m.kernel, m.bias, m, None, 0, True)
+                else:
+                    t[name] = _ConvFn.apply(t[op['src']], None, m.kernel, m.bias, m, None, self.conv_variant, False)
+            elif kind == 'prediction':
+                if name in t and t[name] is not None:
+                    pass                                    # produced by the fused head
+                elif op['activation'] == 'softmax':
+                    t[name] = _SoftmaxFn.apply(t[op['src']])
+                elif op['activation'] in (None, 'linear'):
+                    t[name] = t[op['src']]
+                else:
+                    raise NotImplementedError('neurite_amd: training with final activation %r' % (op['activation'],))
+            else:
+                raise NotImplementedError('neurite_amd: training through %r layers (%s) is not implemented' % (kind, name))
         if return_tensors:
             return {k: _unlift(t[k], nd) for k in keep}
         return _unlift(t[self.output_name], nd)

@@ -1,0 +1,89 @@
+"""
+TEST INFRASTRUCTURE ONLY -- differentiable float64 restatement of the conv_enc / conv_dec / unet graphs
+(neurite/tf/models.py:88-246, 1309-1617) with torch CPU ops, used as the gradient oracle of csrc/conv_bwd.hip.
+
+Keras semantics restated: Conv3D = cross-correlation, SAME padding, kernel [kd,kh,kw,Cin,Cout];
+ELU = x > 0 ? x : exp(x) - 1; MaxPooling3D stride = pool size (SAME pads -inf at the end); UpSampling3D = nearest repeat;
+softmax over channels.  Forward values are pinned against oracle/unet_oracle.py (C conv oracle) in tests/test_oracle.py;
+the gradients are torch.autograd's (TF's gradient rules for these ops are the textbook ones).
+Only tests/ may import this module.
+"""
+
+import torch
+import torch.nn.functional as Fn
+
+F64 = torch.float64
+
+
+def _cf(x):      # [B, X, Y, Z, C] -> [B, C, X, Y, Z]
+    return x.permute(0, 4, 1, 2, 3)
+
+
+def _cl(x):
+    return x.permute(0, 2, 3, 4, 1)
+
+
+def conv3d_same(x, kernel, bias, dilation=1, activation=None):
+    """x [B,X,Y,Z,Cin] channels-last, kernel [kx,ky,kz,Cin,Cout]."""
+    w = kernel.permute(4, 3, 0, 1, 2)
+    pad = [dilation * (k - 1) // 2 for k in kernel.shape[:3]]
+    y = Fn.conv3d(_cf(x), w, bias, padding=pad, dilation=dilation)
+    y = _cl(y)
+    if activation == 'elu':
+        y = torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0.0)) - 1)
+    elif activation == 'relu':
+        y = torch.relu(y)
+    return y
+
+
+def maxpool_same(x, pool):
+    B, X, Y, Z, C = x.shape
+    pads = []
+    for n, p in zip((Z, Y, X), (pool[2], pool[1], pool[0])):      # F.pad order: last dim first
+        pads += [0, (-n) % p]
+    xc = Fn.pad(_cf(x), pads, value=float('-inf'))
+    return _cl(Fn.max_pool3d(xc, kernel_size=tuple(pool), stride=tuple(pool)))
+
+
+def upsample(x, up):
+    for d, u in enumerate(up):
+        x = x.repeat_interleave(u, dim=1 + d)
+    return x
+
+
+def forward(net, x, params=None, return_tensors=None):
+    """Run a neurite_amd.models.ConvNet graph (3-D nets) in float64 on the CPU.  params: {layer: (kernel, bias)} of
+    float64 tensors (requires_grad as the caller likes); default: copies of the model's weights."""
+    if params is None:
+        params = {k: (m.kernel.detach().cpu().double(), m.bias.detach().cpu().double())
+                  for k, m in net.layers_by_name.items() if hasattr(m, 'kernel')}
+    t = {}
+    for op in net.ops:
+        kind, name = op['kind'], op['name']
+        if kind == 'input':
+            t[name] = x
+        elif kind == 'conv':
+            src = t[op['src']]
+            if op.get('lo'):
+                src = torch.cat([src, upsample(t[op['lo']], op['up'])], -1)
+            m = net.layers_by_name[name]
+            k, b = params[name]
+            t[name] = conv3d_same(src, k, b, m.dilation, m.activation)
+        elif kind == 'dropout':
+            t[name] = t[op['src']]
+        elif kind == 'maxpool':
+            t[name] = maxpool_same(t[op['src']], op['pool'])
+        elif kind == 'upsample':
+            t[name] = upsample(t[op['src']], op['up'])
+        elif kind == 'merge':
+            t[name] = torch.cat([t[op['skip']], upsample(t[op['lo']], op['up'])], -1)
+        elif kind == 'likelihood':
+            k, b = params[name]
+            t[name] = conv3d_same(t[op['src']], k, b, 1, None)
+        elif kind == 'prediction':
+            t[name] = torch.softmax(t[op['src']], -1) if op['activation'] == 'softmax' else t[op['src']]
+        else:
+            raise NotImplementedError(kind)
+    if return_tensors:
+        return {k: t[k] for k in return_tensors}
+    return t[net.output_name]
