@@ -20,7 +20,8 @@ single-process tower replication; nothing of it is reproduced here.
 import torch
 import torch.distributed as dist
 
-__all__ = ['shard_range', 'all_reduce_mean_dice', 'all_reduce_mean', 'reduce_dice_sums', 'dice_from_sums']
+__all__ = ['shard_range', 'all_reduce_mean_dice', 'all_reduce_mean', 'reduce_dice_sums', 'dice_from_sums',
+           'all_reduce_gradients']
 
 
 def _world(group=None):
@@ -105,3 +106,33 @@ def dice_from_sums(sums, laplace_smoothing=0.):
                                         _lib.stream_ptr(dev))
     _lib.check(rc, 'nrt_dice_from_sums_f32')
     return out
+
+
+def all_reduce_gradients(params, group=None, bucket_mb=256, average=True):
+    """
+    Data-parallel training step of the conv stack: sum (or average) the gradients of `params` over the ranks.
+    Gradients are packed into flat float32 buckets so that a unet (a few MB of weights) is ONE RCCL all-reduce --
+    xGMI is point-to-point (7 links x ~153 GB/s), a ring all-reduce of a small buffer is latency-bound, so fewer and
+    larger messages win; `bucket_mb` only matters for models larger than a bucket.  In place; returns the number of
+    all-reduce calls issued (0 at world size 1).
+    """
+    rank, world = _world(group)
+    grads = [p.grad for p in params if getattr(p, 'grad', None) is not None]
+    if world == 1 or not grads:
+        return 0
+    limit = int(bucket_mb * (1 << 20) // 4)
+    calls, i = 0, 0
+    while i < len(grads):
+        bucket, n = [], 0
+        while i < len(grads) and (not bucket or n + grads[i].numel() <= limit):
+            bucket.append(grads[i]); n += grads[i].numel(); i += 1
+        flat = torch.cat([g.reshape(-1).to(torch.float32) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= world
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        calls += 1
+    return calls

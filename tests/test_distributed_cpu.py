@@ -45,8 +45,19 @@ def _worker(rank, world, port, q):
         # cross-entropy: mean over ALL voxels from per-rank (sum, count)
         lv = npo.cce_per_voxel(t[lo:hi], p[lo:hi])
         ce = nd.all_reduce_mean(torch.tensor(lv.sum(), dtype=torch.float32), lv.size)
+        # data-parallel gradients: flat-bucket all-reduce == the mean of the per-rank gradients
+        g_all = [rng.standard_normal((world, 3, 3, 3, 2, 4)).astype(np.float32), rng.standard_normal((world, 4)).astype(np.float32),
+                 rng.standard_normal((world, 1, 1, 1, 4, 5)).astype(np.float32)]
+        params = []
+        for ga in g_all:
+            prm = torch.nn.Parameter(torch.zeros(ga.shape[1:]))
+            prm.grad = torch.from_numpy(ga[rank].copy())
+            params.append(prm)
+        ncalls = nd.all_reduce_gradients(params)
+        gerr = max(float(np.abs(prm.grad.numpy() - ga.mean(0)).max()) for prm, ga in zip(params, g_all))
+        ncalls2 = nd.all_reduce_gradients(params, bucket_mb=1e-4, average=False)     # tiny buckets: [216] and [4, 20] floats
         q.put((rank, float(got), float(want), np.abs(tot.numpy() - full).max() / np.abs(full).max(),
-               float(ce), float(npo.cce(t, p))))
+               float(ce), float(npo.cce(t, p)), gerr, ncalls, ncalls2))
     finally:
         dist.destroy_process_group()
 
@@ -63,10 +74,11 @@ def test_sharded_reductions_world2():
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
-    for rank, got, want, rel, ce, ce_want in res:
+    for rank, got, want, rel, ce, ce_want, gerr, ncalls, ncalls2 in res:
         assert abs(got - want) <= 1e-6 * abs(want), (rank, got, want)
         assert rel < 1e-6
         assert abs(ce - ce_want) <= 1e-5 * abs(ce_want)
+        assert gerr < 1e-6 and ncalls == 1 and ncalls2 == 2
     assert res[0][1] == res[1][1]          # every rank holds the same reduced value
 
 
@@ -77,3 +89,6 @@ def test_world1_is_identity():
     s = torch.rand(2, 3, 4)
     assert nd.reduce_dice_sums(s) is s
     assert nd.shard_range(10) == (0, 10)
+    prm = torch.nn.Parameter(torch.zeros(3))
+    prm.grad = torch.ones(3)
+    assert nd.all_reduce_gradients([prm]) == 0 and torch.equal(prm.grad, torch.ones(3))
