@@ -10,8 +10,12 @@
 // One wave64 per output position: lane l owns the 16-byte slice (l % LPR) of weight rows
 // f = l / LPR, l / LPR + 64/LPR, ...  (LPR = lanes per weight row = Cout * itemsize / 16), so each wave
 // instruction reads 1 KiB of contiguous weights; the per-lane partial sums are combined with wave
-// xor-shuffles.  All weight loads of a position are issued before the first use (deep MLP).
+// xor-shuffles.  All weight loads of a position are issued before the first use (deep MLP), through SGPR buffer
+// resources: one VGPR of offsets for the 14 weight loads and one per patch element instead of a 64-bit address each
+// took the kernel from 171 to 98 VGPRs = 5 waves per SIMD, and 0.51 -> 0.72 of the HBM roof at BASELINE config 5.
 // F order (kr, kc, kz, cin) row-major (layers.py:1179-1186), positions row-major (:1172-1173).
+
+#include <stdlib.h>
 
 #include "nrt_common.h"
 
@@ -45,8 +49,16 @@ __device__ __forceinline__ float lc_act(float v, int act) {
     return v;
 }
 
+template <typename T> __device__ __forceinline__ T buf_load_elem(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
+template <> __device__ __forceinline__ unsigned short buf_load_elem<unsigned short>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+}
+template <> __device__ __forceinline__ float buf_load_elem<float>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 // T = float or unsigned short (bf16 bits); VEC = elements per 16-byte load; NB = batch entries per pass
-template <typename T, int NB, int MAXIT>
+template <typename T, int NB, int MAXIT, bool NT>
 __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
     constexpr int VEC = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
@@ -70,28 +82,38 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
         const int dz = tap % a.kz, dc = (tap / a.kz) % a.kc, dr = tap / (a.kz * a.kc);
         xoff[it] = ((dr * a.C + dc) * a.Z + dz) * a.Cin + ci;
     }
-    // weight slice of (row f, slice sl) sits at byte ((f * LPR + sl) * 16) of the position's block; rows advance
-    // by RPW per iteration = 1 KiB, so one base offset per lane + constants; dead rows are clamped to the last row
-    const unsigned wlast = ((unsigned)(F - 1) * (unsigned)LPR + (unsigned)sl) * 16u;
+    // Buffer addressing keeps the address registers out of the way of the 14 weight slices in flight: the position's
+    // weight block and the input volume are described by SGPR resources (wave-uniform), a lane contributes one 32-bit
+    // byte offset to all weight loads (row advance = 1 KiB per iteration in the scalar offset) and one per patch
+    // element; slices past the last row read zeros (num_records = the position's exact byte count).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const unsigned w0 = (unsigned)lane * 16u;
+    const unsigned wbytes = (unsigned)F * (unsigned)a.Cout * (unsigned)sizeof(T);
     const long long xbs = (long long)a.R * a.C * a.Z * a.Cin;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform: weights via SGPR base
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform
+    unsigned xvoff[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) xvoff[it] = (unsigned)xoff[it] * (unsigned)sizeof(T);
     for (long long o = (long long)blockIdx.x * (blockDim.x >> 6) + wave; o < O; o += nwaves) {
         const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
-        const long long xbase = (((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin;
+        const unsigned xbase = (unsigned)((((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin * (long long)sizeof(T));
         const char *kp = (const char *)((const T *)a.k + o * (long long)F * a.Cout);
-        // ---- issue every load of this position before the first use (unconditional: exact vmcnt accounting)
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)kp, 0, (int)wbytes, 0x00020000);
+        // ---- issue every load of this position before the first use ---------------------------------------
         vec_t w[MAXIT];
         T xr[NB][MAXIT];
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const unsigned off = w0 + (unsigned)it * 1024u;
-            w[it] = __builtin_nontemporal_load((const vec_t *)(kp + min(off, wlast)));
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, it * 1024, NT ? 2 : 0);
+            w[it] = __builtin_bit_cast(vec_t, raw);
         }
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it)
+        for (int b = 0; b < NB; ++b) {
+            const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) xr[b][it] = xb[(long long)(b0 + (b < nb ? b : 0)) * xbs + xbase + xoff[it]];
+            for (int it = 0; it < MAXIT; ++it) xr[b][it] = buf_load_elem<T>(xres, xvoff[it], xbase);
+        }
         __builtin_amdgcn_sched_barrier(0);
         float acc[NB][VEC];
 #pragma unroll
@@ -157,17 +179,28 @@ __global__ __launch_bounds__(256) void lc3d_generic(LcArgs a) {
     }
 }
 
-template <typename T, int MAXIT>
-void launch_vec(const LcArgs &a, hipStream_t st) {
-    const long long O = (long long)a.orr * a.occ * a.ozz;
-    unsigned blocks = (unsigned)((O + 3) / 4);
-    if (blocks > 256u * 8u) blocks = 256u * 8u;
+template <typename T, int MAXIT, bool NT>
+void launch_vec_nt(const LcArgs &a, unsigned blocks, hipStream_t st) {
     for (int b0 = 0; b0 < a.B; b0 += 4) {
         const int nb = a.B - b0 < 4 ? a.B - b0 : 4;
-        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
-        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
-        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT, NT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT, NT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT, NT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
     }
+}
+
+template <typename T, int MAXIT>
+void launch_vec(const LcArgs &a, hipStream_t st) {
+    // experiment knobs: NRT_LC_BLOCKS (grid size), NRT_LC_NT (0: plain weight loads)
+    static int kblocks = -1, knt = -1;
+    if (kblocks < 0) { const char *e = getenv("NRT_LC_BLOCKS"); kblocks = e ? atoi(e) : 0; }
+    if (knt < 0) { const char *e = getenv("NRT_LC_NT"); knt = e ? atoi(e) : 1; }
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    unsigned blocks = (unsigned)((O + 3) / 4);
+    const unsigned cap = kblocks > 0 ? (unsigned)kblocks : 256u * 20u;     // 5 resident blocks per CU x 4 rounds (profiles/)
+    if (blocks > cap) blocks = cap;
+    if (knt) launch_vec_nt<T, MAXIT, true>(a, blocks, st);
+    else launch_vec_nt<T, MAXIT, false>(a, blocks, st);
 }
 
 template <typename T>
@@ -179,10 +212,13 @@ int launch_any(const LcArgs &a, int variant, hipStream_t st) {
     vec_ok = vec_ok && LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0 && (((uintptr_t)a.k) & 15) == 0;
     int nit = vec_ok ? (F + (64 / LPR) - 1) / (64 / LPR) : 0;
     vec_ok = vec_ok && nit <= 32;
+    vec_ok = vec_ok && (long long)a.R * a.C * a.Z * a.Cin * (long long)sizeof(T) < (1ll << 31) &&
+             (long long)F * a.Cout * (long long)sizeof(T) < (1ll << 31);          // 32-bit buffer offsets
     if (variant == 0) variant = vec_ok ? 2 : 1;
     if (variant == 2) {
         if (!vec_ok) return NRT_ERR_UNSUPPORTED;
         if (nit <= 8) launch_vec<T, 8>(a, st);
+        else if (nit <= 14) launch_vec<T, 14>(a, st);
         else if (nit <= 16) launch_vec<T, 16>(a, st);
         else launch_vec<T, 32>(a, st);
     } else {
