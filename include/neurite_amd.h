@@ -254,6 +254,14 @@ int nrt_softmax_bwd_f32(const float *y, const float *grad_out, float *grad_in, l
 int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, void *y, int dtype, int batch,
                const int *in_shape, int cin, const int *ksize, const int *strides, int cout,
                int activation, int variant, void *stream);
+/* Backward of the same layer (autodiff of the batch_dot of layers.py:1189 + bias/activation :1098-1101):
+ *   grad_kernel [O, F, cout] and grad_bias [O, cout] (`dtype`, written once, may be NULL), grad_x float32
+ *   [batch, in_shape, cin] accumulated with float atomics (ZERO-FILLED by the caller, may be NULL);
+ *   y = the layer output (needed when activation != 0), grad_out [batch, out_shape, cout].
+ *   cout * itemsize must be a multiple of 16 (the weight-streaming lane layout). */
+int nrt_lc3d_bwd_f(const void *x, const void *kernel, const void *y, const void *grad_out, void *grad_kernel,
+                   void *grad_bias, float *grad_x, int dtype, int batch, const int *in_shape, int cin,
+                   const int *ksize, const int *strides, int cout, int activation, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Backward passes (what tf.GradientTape derives from the reference graphs; float32)

@@ -231,6 +231,174 @@ int launch_any(const LcArgs &a, int variant, hipStream_t st) {
     return NRT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward (what TF's autodiff gives for the batch_dot of layers.py:1189): per output position o
+//   dK[o][f][co] = sum_b patch[b][o][f] * dpre[b][o][co]           written once, 16-byte slices (HBM-bound: |K| bytes)
+//   dbias[o][co] = sum_b dpre[b][o][co]
+//   dx[b][patch element f of o] += sum_co K[o][f][co] * dpre[b][o][co]   (float atomics into a float32 buffer)
+// Same wave-per-position lane mapping as the forward: lane = (weight row f mod RPW, 16-byte cout slice).
+// dpre = grad_out * act'(y) is formed on the fly from the layer output y.
+// ---------------------------------------------------------------------------------------------
+struct LcBwdArgs {
+    LcArgs f;                // x, k, (bias unused), y = layer output
+    const void *g;           // grad_out [B, O, Cout]
+    void *dk;                // [O, F, Cout] or null
+    void *dbias;             // [O, Cout] or null
+    float *dx;               // float32 [B, R, C, Z, Cin], zero-filled by the caller, or null
+};
+
+template <typename T>
+__device__ __forceinline__ float lc_dpre(float g, float y, int act) {
+    if (act == 1) return g * (y > 0.0f ? 1.0f : y + 1.0f);
+    if (act == 2) return y > 0.0f ? g : 0.0f;
+    return g;
+}
+
+template <typename T, int MAXIT>
+__global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba) {
+    const LcArgs &a = ba.f;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int LPR = a.Cout / VEC, RPW = 64 / LPR;
+    const int F = a.kr * a.kc * a.kz * a.Cin;
+    const int nit = (F + RPW - 1) / RPW;
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    const int lane = threadIdx.x & 63;
+    const int sl = lane % LPR, row0 = lane / LPR;
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    const T *xb = (const T *)a.x;
+    int xoff[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int f = it * RPW + row0;
+        const int ff = ((it < nit) && (f < F)) ? f : F - 1;
+        const int ci = ff % a.Cin, tap = ff / a.Cin;
+        const int dz = tap % a.kz, dc = (tap / a.kz) % a.kc, dr = tap / (a.kz * a.kc);
+        xoff[it] = ((dr * a.C + dc) * a.Z + dz) * a.Cin + ci;
+    }
+    const unsigned w0 = (unsigned)lane * 16u;
+    const unsigned wbytes = (unsigned)F * (unsigned)a.Cout * (unsigned)sizeof(T);
+    const long long xbs = (long long)a.R * a.C * a.Z * a.Cin;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (long long o = (long long)blockIdx.x * (blockDim.x >> 6) + wave; o < O; o += nwaves) {
+        const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
+        const long long xbase = (((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin;
+        const char *kp = (const char *)((const T *)a.k + o * (long long)F * a.Cout);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)kp, 0, (int)wbytes, 0x00020000);
+        vec_t w[MAXIT];
+        if (ba.dx) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it)
+                w[it] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(wr, w0, it * 1024, 2));
+        }
+        float dk[MAXIT][VEC];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) dk[it][e] = 0.0f;
+        float db[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) db[e] = 0.0f;
+        for (int b = 0; b < a.B; ++b) {
+            // this lane's cout slice of dpre[b][o]
+            const long long go = ((long long)b * O + o) * a.Cout + sl * VEC;
+            const vec_t gv = *(const vec_t *)((const T *)ba.g + go);
+            float dp[VEC];
+            if (a.act != 0) {
+                const vec_t yv = *(const vec_t *)((const T *)a.y + go);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dp[e] = lc_dpre<T>(to_f32(gv[e]), to_f32(yv[e]), a.act);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) dp[e] = to_f32(gv[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) db[e] += dp[e];
+            const T *xp = xb + (long long)b * xbs + xbase;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const bool live = (it < nit) && (it * RPW + row0 < F);
+                if (ba.dk) {
+                    const float xv = live ? to_f32(xp[xoff[it]]) : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) dk[it][e] = fmaf(xv, dp[e], dk[it][e]);
+                }
+                if (ba.dx) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) t = fmaf(to_f32(w[it][e]), dp[e], t);
+                    for (int off = 1; off < LPR; off <<= 1) t += __shfl_xor(t, off, 64);     // over the cout slices of row f
+                    if (live && sl == 0) unsafeAtomicAdd(ba.dx + (long long)b * xbs + xbase + xoff[it], t);
+                }
+            }
+        }
+        if (ba.dk) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const unsigned off = w0 + (unsigned)it * 1024u;
+                if (off < wbytes) {
+                    vec_t ov;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { T tmp; store_out(&tmp, dk[it][e]); ov[e] = tmp; }
+                    __builtin_nontemporal_store(ov, (vec_t *)((char *)ba.dk + o * (long long)wbytes + off));
+                }
+            }
+        }
+        if (ba.dbias && lane < LPR) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) store_out((T *)ba.dbias + o * a.Cout + sl * VEC + e, db[e]);
+        }
+    }
+}
+
+template <typename T>
+int launch_bwd(const LcBwdArgs &ba, hipStream_t st) {
+    const LcArgs &a = ba.f;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int F = a.kr * a.kc * a.kz * a.Cin;
+    if (a.Cout % VEC) return NRT_ERR_UNSUPPORTED;
+    const int LPR = a.Cout / VEC;
+    if (LPR < 1 || LPR > 64 || (LPR & (LPR - 1))) return NRT_ERR_UNSUPPORTED;
+    const int nit = (F + (64 / LPR) - 1) / (64 / LPR);
+    if (nit > 32 || (long long)F * a.Cout * (long long)sizeof(T) >= (1ll << 31)) return NRT_ERR_UNSUPPORTED;
+    if ((((uintptr_t)a.k | (uintptr_t)ba.g | (uintptr_t)a.y | (uintptr_t)ba.dk) & 15) != 0) return NRT_ERR_UNSUPPORTED;
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    unsigned blocks = (unsigned)((O + 3) / 4);
+    if (blocks > 256u * 8u) blocks = 256u * 8u;
+    if (nit <= 8) hipLaunchKernelGGL((lc3d_bwd<T, 8>), dim3(blocks), dim3(256), 0, st, ba);
+    else if (nit <= 14) hipLaunchKernelGGL((lc3d_bwd<T, 14>), dim3(blocks), dim3(256), 0, st, ba);
+    else if (nit <= 16) hipLaunchKernelGGL((lc3d_bwd<T, 16>), dim3(blocks), dim3(256), 0, st, ba);
+    else hipLaunchKernelGGL((lc3d_bwd<T, 32>), dim3(blocks), dim3(256), 0, st, ba);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+}  // namespace
+
+extern "C" int nrt_lc3d_bwd_f(const void *x, const void *kernel, const void *y, const void *grad_out, void *grad_kernel,
+                              void *grad_bias, float *grad_x, int dtype, int batch, const int *in_shape, int cin,
+                              const int *ksize, const int *strides, int cout, int activation, void *stream) {
+    if (!x || !kernel || !grad_out || !in_shape || !ksize || !strides) return NRT_ERR_INVALID_ARG;
+    if (!grad_kernel && !grad_bias && !grad_x) return NRT_ERR_INVALID_ARG;
+    if (activation != 0 && !y) return NRT_ERR_INVALID_ARG;
+    if (batch < 1 || cin < 1 || cout < 1) return NRT_ERR_INVALID_ARG;
+    if (dtype != NRT_DT_F32 && dtype != NRT_DT_BF16) return NRT_ERR_UNSUPPORTED;
+    LcBwdArgs ba;
+    LcArgs &a = ba.f;
+    a.x = x; a.k = kernel; a.bias = nullptr; a.y = (void *)y; a.B = batch;
+    a.R = in_shape[0]; a.C = in_shape[1]; a.Z = in_shape[2]; a.Cin = cin;
+    a.kr = ksize[0]; a.kc = ksize[1]; a.kz = ksize[2]; a.sr = strides[0]; a.sc = strides[1]; a.sz = strides[2];
+    if (a.kr < 1 || a.kc < 1 || a.kz < 1 || a.sr < 1 || a.sc < 1 || a.sz < 1) return NRT_ERR_INVALID_ARG;
+    if (a.R < a.kr || a.C < a.kc || a.Z < a.kz) return NRT_ERR_INVALID_ARG;
+    a.orr = (a.R - a.kr) / a.sr + 1; a.occ = (a.C - a.kc) / a.sc + 1; a.ozz = (a.Z - a.kz) / a.sz + 1;
+    a.Cout = cout; a.act = activation;
+    ba.g = grad_out; ba.dk = grad_kernel; ba.dbias = grad_bias; ba.dx = grad_x;
+    hipStream_t st = nrt_stream(stream);
+    if (dtype == NRT_DT_F32) return launch_bwd<float>(ba, st);
+    return launch_bwd<unsigned short>(ba, st);
+}
+
+namespace {
 }  // namespace
 
 extern "C" int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, void *y, int dtype, int batch,

@@ -11,6 +11,7 @@ The batch loop the reference runs serially with tf.map_fn (layers.py:171) is one
 launch here (blockIdx.y = batch entry).
 """
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -363,6 +364,21 @@ def _normalize_tuple(value, n, name):
     return value_tuple
 
 
+class _Lc3dFn(torch.autograd.Function):
+    """LocallyConnected3D forward / backward on csrc/lc3d.hip (x channels-last, contiguous)."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, run, run_backward):
+        ctx.run_backward = run_backward
+        with torch.no_grad():
+            return run()
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, dk, db = ctx.run_backward(g, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return dx, dk, db, None, None
+
+
 class LocallyConnected3D(_Layer):
     """
     Locally-connected layer for 3D inputs: a Conv3D whose weights are NOT shared between output positions
@@ -499,6 +515,24 @@ class LocallyConnected3D(_Layer):
                                     _lib.ints(self.kernel_size), _lib.ints(self.strides), self.filters, act,
                                     int(self._variant), _lib.stream_ptr(dev))
             _lib.check(rc, 'nrt_lc3d_f')
-            return y.permute(0, 4, 1, 2, 3) if self.data_format == 'channels_first' else y
+            return y
 
-        return utils._maybe_tracked(run, inputs, self.kernel)
+        def run_backward(g, need_x, need_k, need_b):
+            g = g.contiguous()
+            dk = torch.empty_like(k) if need_k else None
+            db = torch.empty((int(np.prod(O)), self.filters), dtype=x.dtype, device=dev) if need_b else None
+            dx = torch.zeros(x.shape, dtype=torch.float32, device=dev) if need_x else None
+            with torch.cuda.device(dev):
+                rc = lib.nrt_lc3d_bwd_f(_lib.ptr(x), _lib.ptr(k), _lib.ptr(y), _lib.ptr(g), _lib.ptr(dk), _lib.ptr(db),
+                                        _lib.ptr(dx), dt, B, _lib.ints(S), cin, _lib.ints(self.kernel_size),
+                                        _lib.ints(self.strides), self.filters, act, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_lc3d_bwd_f')
+            return (None if dx is None else dx.to(x.dtype)), dk, (None if db is None else db.reshape(self.bias.shape))
+
+        needs = torch.is_grad_enabled() and (x.requires_grad or self.kernel.requires_grad
+                                             or (self.bias is not None and self.bias.requires_grad))
+        if needs:
+            out = _Lc3dFn.apply(x, self.kernel, self.bias, run, run_backward)
+        else:
+            out = run()
+        return out.permute(0, 4, 1, 2, 3) if self.data_format == 'channels_first' else out

@@ -90,3 +90,20 @@ def cce_per_voxel(y_true, y_pred, label_weights=None, from_logits=False, label_s
     q = y_pred / y_pred.sum(-1, keepdim=True)
     q = torch.clamp(q, 1e-7, 1 - 1e-7)
     return -(t * torch.log(q)).sum(-1)
+
+
+def lc3d(x, kernel, bias=None, kernel_size=(3, 3, 3), strides=(1, 1, 1), activation=None):
+    """LocallyConnected3D implementation 1 (neurite/tf/layers.py:1126-1197): x [B,R,C,Z,Cin], kernel [O, F, Cout] with the
+    patch flattened in (kr, kc, kz, cin) order, positions row-major; bias [or, oc, oz, Cout]."""
+    kr, kc, kz = kernel_size
+    p = x.unfold(1, kr, strides[0]).unfold(2, kc, strides[1]).unfold(3, kz, strides[2])     # [B, or, oc, oz, Cin, kr, kc, kz]
+    B, orr, occ, ozz = p.shape[:4]
+    p = p.permute(0, 1, 2, 3, 5, 6, 7, 4).reshape(B, orr * occ * ozz, -1)                      # f = (kr, kc, kz, cin)
+    y = torch.einsum('bof,ofc->boc', p, kernel).reshape(B, orr, occ, ozz, -1)
+    if bias is not None:
+        y = y + bias
+    if activation == 'elu':
+        y = torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0.0)) - 1)
+    elif activation == 'relu':
+        y = torch.relu(y)
+    return y

@@ -130,3 +130,45 @@ def test_lc3d_cfg5_size_bf16_sampled(dev):
     from oracle import c_oracle as co
     want = co.wcce(N(t), N(y), w, from_logits=True)
     np.testing.assert_allclose(loss, want, rtol=1e-4)
+
+
+@pytest.mark.parametrize('dtype,cout,ks,strides,act,S,cin', [
+    ('float32', 8, (3, 3, 3), (1, 1, 1), None, (7, 6, 8), 4),
+    ('float32', 4, (3, 3, 3), (1, 1, 1), 'elu', (6, 6, 6), 3),
+    ('float32', 16, (2, 3, 2), (2, 1, 1), 'relu', (8, 7, 6), 5),
+    ('bfloat16', 16, (3, 3, 3), (1, 1, 1), 'elu', (8, 8, 8), 16),
+    ('bfloat16', 8, (3, 3, 3), (1, 1, 1), None, (6, 7, 6), 8),
+])
+def test_lc3d_backward(dev, dtype, cout, ks, strides, act, S, cin):
+    """grad wrt kernel, bias and input vs the float64 autograd oracle (bf16: tolerance of the bf16 rounding)"""
+    from oracle import grad_oracle as go
+    rng = np.random.default_rng(91 + cout)
+    tdt = getattr(torch, dtype)
+    B = 2
+    layer = ne.layers.LocallyConnected3D(cout, ks, strides=strides, activation=act)
+    x = torch.from_numpy(rng.standard_normal((B,) + S + (cin,)).astype(np.float32)).to(dev).to(tdt)
+    y0 = layer(x)                                                            # builds the weights
+    with torch.no_grad():
+        layer.kernel.copy_(torch.from_numpy((rng.standard_normal(tuple(layer.kernel.shape)) * 0.2).astype(np.float32)).to(tdt))
+        layer.bias.copy_(torch.from_numpy((rng.standard_normal(tuple(layer.bias.shape)) * 0.1).astype(np.float32)).to(tdt))
+    w = torch.from_numpy(rng.standard_normal(tuple(y0.shape)).astype(np.float32)).to(dev).to(tdt)
+    xg = x.clone().requires_grad_()
+    y = layer(xg)
+    (y.float() * w.float()).sum().backward()
+    xo = x.detach().cpu().double().requires_grad_()
+    ko = layer.kernel.detach().cpu().double().requires_grad_()
+    bo = layer.bias.detach().cpu().double().requires_grad_()
+    yo = go.lc3d(xo, ko, bo, ks, strides, act)
+    (yo * w.detach().cpu().double()).sum().backward()
+    tol = 2e-5 if dtype == 'float32' else 2e-2
+
+    def close(got, want, what):
+        got = got.detach().cpu().double().numpy(); want = want.numpy()
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+        assert got.shape == want.shape and err < tol, (what, err)
+
+    close(y, yo.detach(), 'forward')
+    close(layer.kernel.grad, ko.grad, 'grad_kernel')
+    close(layer.bias.grad, bo.grad, 'grad_bias')
+    close(xg.grad, xo.grad, 'grad_x')
+    assert layer.kernel.grad.dtype == tdt and xg.grad.dtype == tdt
