@@ -439,6 +439,54 @@ class ConvNet(nn.Module):
         self.conv_variant = 0                       # 0 auto, 1 direct, 2 MFMA (tests / tuning)
         self.eval()                                 # Keras predict semantics; model.train() records the graph for autograd
 
+    # ---- Keras Model weight API (modelio: neurite/tf/modelio.py:111-143 saves/loads `model.get_weights()` lists) ----
+    def _weight_tensors(self):
+        """weights in Keras order: layers in graph order; Conv: kernel, bias; BatchNormalization: gamma, beta, mean, variance"""
+        out = []
+        for name in self.layer_names:
+            if name in self.layers_by_name:
+                m = self.layers_by_name[name]
+                if isinstance(m, _Conv):
+                    out += [(name + '/kernel', m.kernel, self.ndims), (name + '/bias', m.bias, None)]
+                elif isinstance(m, _BatchNorm):
+                    out += [(name + '/gamma', m.gamma, None), (name + '/beta', m.beta, None),
+                            (name + '/moving_mean', m.moving_mean, None), (name + '/moving_variance', m.moving_variance, None)]
+        return out
+
+    def get_weights(self):
+        """list of numpy arrays in Keras `model.get_weights()` order and layout (Conv{N}D kernels [k1..kN, Cin, Cout])."""
+        res = []
+        for _, t, nd in self._weight_tensors():
+            a = t.detach().cpu().numpy()
+            if nd is not None and nd < 3:
+                a = a.reshape(a.shape[3 - nd:])                  # drop the lifted singleton kernel dims
+            res.append(a)
+        return res
+
+    def set_weights(self, weights):
+        """counterpart of `get_weights` (e.g. the arrays of a Keras-trained neurite unet exported with np.savez)."""
+        slots = self._weight_tensors()
+        if len(weights) != len(slots):
+            raise ValueError('You called `set_weights(weights)` on model "%s" with a weight list of length %d, but the '
+                             'model was expecting %d weights.' % (self.name, len(weights), len(slots)))
+        with torch.no_grad():
+            for (name, t, nd), w in zip(slots, weights):
+                w = np.asarray(w, dtype=np.float32)
+                if nd is not None and nd < 3:
+                    w = w.reshape((1,) * (3 - nd) + w.shape)
+                if tuple(w.shape) != tuple(t.shape):
+                    raise ValueError('Layer weight shape %s not compatible with provided weight shape %s (%s)'
+                                     % (tuple(t.shape), tuple(w.shape), name))
+                t.copy_(torch.from_numpy(w))
+
+    def save_weights(self, path):
+        """np.savez archive keyed by `layer/variable` (h5py is not a dependency of this package)."""
+        np.savez(path, **{name: a for (name, _, _), a in zip(self._weight_tensors(), self.get_weights())})
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[name] for name, _, _ in self._weight_tensors()])
+
     def get_layer(self, name):
         if name in self.layers_by_name:
             return self.layers_by_name[name]

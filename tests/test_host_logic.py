@@ -211,3 +211,28 @@ def test_affine_helpers_cpu():
         utils.compose([m])
     c = utils.compose([m, m])                      # affine o affine never touches the device
     assert torch.allclose(c, (sq @ sq)[:3])
+
+
+def test_convnet_weight_api_cpu(tmp_path):
+    """Keras-style get_weights / set_weights / save / load on the (un-run) graph; no device needed"""
+    import contextlib, io
+    import neurite_amd as ne
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ne.models.unet(4, (16, 16, 1), 2, 3, 3, batch_norm=-1)          # 2-D: kernels come back as [3, 3, Cin, Cout]
+    w = net.get_weights()
+    assert w[0].shape == (3, 3, 1, 4) and w[1].shape == (4,)
+    assert any(a.shape == (1, 1, 4, 3) for a in w)                             # likelihood 1x1
+    rng = np.random.default_rng(0)
+    new = [rng.standard_normal(a.shape).astype(np.float32) for a in w]
+    net.set_weights(new)
+    assert all(np.array_equal(a, b) for a, b in zip(net.get_weights(), new))
+    p = str(tmp_path / 'w.npz')
+    net.save_weights(p)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net2 = ne.models.unet(4, (16, 16, 1), 2, 3, 3, batch_norm=-1)
+    net2.load_weights(p)
+    assert all(np.array_equal(a, b) for a, b in zip(net2.get_weights(), new))
+    with pytest.raises(ValueError, match='expecting'):
+        net.set_weights(new[:-1])
+    with pytest.raises(ValueError, match='not compatible'):
+        net.set_weights([new[1]] + new[1:])
