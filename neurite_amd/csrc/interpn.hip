@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void interpn_lds(InterpArgs a, unsigned nTy, u
         int qd[NRT_MAXD] = {x0 + (v >> 7), y0 + ((v >> 4) & 7), z0 + (v & 15)};
         valid[k] = qd[0] < a.O[0] && qd[1] < a.O[1] && qd[2] < a.O[2];
         qd[0] = min(qd[0], a.O[0] - 1); qd[1] = min(qd[1], a.O[1] - 1); qd[2] = min(qd[2], a.O[2] - 1);
-        q[k] = ((unsigned)qd[0] * (unsigned)a.O[1] + (unsigned)qd[1]) * (unsigned)a.O[2] + (unsigned)qd[2];
+        q[k] = __umul24(__umul24((unsigned)qd[0], (unsigned)a.O[1]) + (unsigned)qd[1], (unsigned)a.O[2]) + (unsigned)qd[2];   // dims < 2^12 checked on the host
         float p[NRT_MAXD];
         load_loc<3, MODE>(a, locb, q[k], qd, p);
         oob[k] = a.has_fill ? out_of_bounds<3>(a, p) : false;
@@ -660,29 +660,38 @@ __global__ __launch_bounds__(256) void interpn_lds(InterpArgs a, unsigned nTy, u
         }
     }
     __syncthreads();
-    // ---- gather + blend (interpn_generic's op order) ---------------------------------------------
+    // ---- gather + blend (interpn_generic's op order).  Index arithmetic is strength-reduced: one base offset per
+    // voxel (24-bit multiplies) plus three strides that are zero when the upper corner is clamped onto the lower one ----
 #pragma unroll
     for (int k = 0; k < VPT; ++k) {
+        const int ux = (int)((up >> (3 * k + 0)) & 1u), uy = (int)((up >> (3 * k + 1)) & 1u), uz = (int)((up >> (3 * k + 2)) & 1u);
+        // (w_x * w_y) * w_z : the x*y products are shared by the two z corners (same rounding sequence as prod_n)
+        const float wxy[4] = {nrt_mul(w0[k][0], w0[k][1]), nrt_mul(w0[k][0], w1[k][1]), nrt_mul(w1[k][0], w0[k][1]),
+                              nrt_mul(w1[k][0], w1[k][1])};
         float acc[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+        if (staged) {
+            const int base = __mul24(__mul24(i0[k][0] - lo[0], ey) + (i0[k][1] - lo[1]), rowl) + (i0[k][2] - lo[2]) * CL;
+            const int sx = ux ? __mul24(ey, rowl) : 0, sy = uy ? rowl : 0, sz = uz ? CL : 0;
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
-            const int ix = i0[k][0] + (bx ? (int)((up >> (3 * k + 0)) & 1u) : 0);
-            const int iy = i0[k][1] + (by ? (int)((up >> (3 * k + 1)) & 1u) : 0);
-            const int iz = i0[k][2] + (bz ? (int)((up >> (3 * k + 2)) & 1u) : 0);
-            const float wt = nrt_mul(nrt_mul(bx ? w1[k][0] : w0[k][0], by ? w1[k][1] : w0[k][1]), bz ? w1[k][2] : w0[k][2]);
-            if (staged) {
-                const float *pv = box + ((ix - lo[0]) * ey + (iy - lo[1])) * rowl + (iz - lo[2]) * CL;
+            for (int corner = 0; corner < 8; ++corner) {
+                const float *pv = box + base + ((corner & 4) ? sx : 0) + ((corner & 2) ? sy : 0) + ((corner & 1) ? sz : 0);
+                const float wt = nrt_mul(wxy[corner >> 1], (corner & 1) ? w1[k][2] : w0[k][2]);
                 float vv[CL];
                 if (CL == 4) { const nrt_f4 t4 = *(const nrt_f4 *)pv; vv[0] = t4[0]; vv[1] = t4[1]; vv[2] = t4[2]; vv[CL - 1] = t4[3]; }
                 else if (CL == 2) { const nrt_f2 t2 = *(const nrt_f2 *)pv; vv[0] = t2[0]; vv[CL - 1] = t2[1]; }
                 else vv[0] = pv[0];
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, vv[c]));
-            } else {
-                const float *pv = vol + (((long long)ix * a.S[1] + iy) * a.S[2] + iz) * C;
+            }
+        } else {
+            const float *pb = vol + (((long long)i0[k][0] * a.S[1] + i0[k][1]) * a.S[2] + i0[k][2]) * C;
+            const long long sx = ux ? (long long)a.S[1] * a.S[2] * C : 0, sy = uy ? (long long)a.S[2] * C : 0, sz = uz ? C : 0;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const float *pv = pb + ((corner & 4) ? sx : 0) + ((corner & 2) ? sy : 0) + ((corner & 1) ? sz : 0);
+                const float wt = nrt_mul(wxy[corner >> 1], (corner & 1) ? w1[k][2] : w0[k][2]);
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, pv[c]));
             }
@@ -715,7 +724,7 @@ void launch_lds_c(const InterpArgs &a, int batch, int mode, hipStream_t st) {
 }
 
 bool lds_supported(const InterpArgs &a, int ndim) {
-    return ndim == 3 && a.C >= 1 && a.C <= 4 && a.nout >= 1024;
+    return ndim == 3 && a.C >= 1 && a.C <= 4 && a.nout >= 1024 && a.O[0] < 4096 && a.O[1] < 4096 && a.O[2] < 4096;
 }
 
 void launch_lds(const InterpArgs &a, int batch, int mode, hipStream_t st) {
