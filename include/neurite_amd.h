@@ -296,6 +296,21 @@ int nrt_wcce_bwd_f32(const float *y_true, const float *y_pred, const float *labe
                      int from_logits, float label_smoothing, float scale, float *grad_pred, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Synthesis front-end: separable filtering and min-max normalisation
+ *   nrt_conv1d_axis_f32   one pass of utils.separable_conv (neurite/tf/utils/utils.py:665-751) / layers.GaussianBlur
+ *                         (layers.py:251-364): the tensor viewed as [outer, axis_len, inner] around the filtered axis,
+ *                         y[o, a, i] = sum_t kernel[t] * x[o, a*stride + t*dilation - pad_before, i], zero outside
+ *                         (cross-correlation, as tf.nn.convolution); y is [outer, out_len, inner]
+ *   nrt_minmax_norm_f32   utils.minmax_norm (utils.py:953-968) over a contiguous run of axes: x viewed as
+ *                         [outer, reduce_len, inner]; y = div_no_nan(x - min, max - min) per (outer, inner)
+ * ------------------------------------------------------------------------------------------ */
+int nrt_conv1d_axis_f32(const float *x, const float *kernel, float *y, long long outer, int axis_len, long long inner,
+                        int out_len, int width, int stride, int dilation, int pad_before, void *stream);
+size_t nrt_minmax_workspace_bytes(long long outer, int inner);
+int nrt_minmax_norm_f32(const float *x, float *y, long long outer, long long reduce_len, int inner, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or
  * non-temporal; calibrates the achievable mixed read/write HBM rate next to the kernels above.
  * ------------------------------------------------------------------------------------------ */

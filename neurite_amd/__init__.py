@@ -24,6 +24,8 @@ from . import losses  # noqa: F401
 from . import models  # noqa: F401
 from . import fused  # noqa: F401
 from . import distributed  # noqa: F401
+from . import augment  # noqa: F401
+from . import synth  # noqa: F401
 
 backend = 'pytorch'
 

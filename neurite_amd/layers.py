@@ -19,7 +19,7 @@ from . import _lib
 from . import utils
 
 __all__ = ['Resize', 'Zoom', 'SpatialTransformer', 'LocallyConnected3D', 'VecInt', 'RescaleTransform',
-           'ComposeTransform', 'AffineToDenseShift']
+           'ComposeTransform', 'AffineToDenseShift', 'GaussianBlur']
 
 
 class _Layer(nn.Module):
@@ -346,6 +346,70 @@ class AffineToDenseShift(_Layer):
         _lib.require_device(mat)
         return torch.stack([utils.affine_to_dense_shift(mat[b], self.shape, shift_center=self.shift_center)
                             for b in range(mat.shape[0])], 0)
+
+
+class GaussianBlur(_Layer):
+    """
+    Blur a tensor [B, *S, C] by convolving it with a Gaussian kernel, isotropic or anisotropic, randomised or not
+    (neurite/tf/layers.py:251-364): `utils.gaussian_kernel(separate=True)` + `utils.separable_conv` -- one HIP pass per
+    spatial axis, no transposes.
+    """
+
+    def __init__(self, sigma=None, level=None, random=False, min_sigma=0, isotropic=False, seed=None, **kwargs):
+        assert sigma is not None or level is not None, 'sigma or level must be provided'
+        assert not (sigma is not None and level is not None), 'only sigma or level must be provided'
+        if level is not None:
+            import warnings
+            warnings.warn('The `level` argument to ne.layers.GaussianBlur is deprecated and will '
+                          'be removed in a future version. Please use `sigma` instead.')
+            if level < 1:
+                raise ValueError('Gaussian blur level must not be less than 1')
+            if random:
+                raise ValueError('level argument incompatible with random blurring')
+            sigma = (level - 1) ** 2          # the reference computes this and then overwrites it with None (:297,303)
+        if isotropic and not random:
+            raise ValueError('For non-random blurring, isotropy is implicitly controlled by the '
+                             'number of sigmas provided. Set `isotropic` only for random blur.')
+        self.sigma = sigma
+        self.random = random
+        self.min_sigma = min_sigma
+        self.isotropic = isotropic
+        self.seed = seed
+        super().__init__(**kwargs)
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'sigma': self.sigma, 'random': self.random, 'min_sigma': self.min_sigma,
+                       'isotropic': self.isotropic, 'seed': self.seed})
+        return config
+
+    def _normalize_sigma(self, sigma, ndims):
+        sigma = np.ravel(sigma).tolist()
+        if len(sigma) not in (1, ndims):
+            raise ValueError(f'1 or {ndims} sigmas expected in {ndims}D space, got {len(sigma)}')
+        if any(s < 0 for s in sigma):
+            raise ValueError('Gaussian blur sigma must not be less than 0')
+        if len(sigma) > 1 and self.isotropic:
+            raise ValueError(f'random isotropic blur requires a single sigma, got {len(sigma)}')
+        if len(sigma) == 1:
+            sigma = sigma * ndims
+        return sigma
+
+    def build(self, input_shape):
+        ndims = len(input_shape) - 2
+        self.sigma = self._normalize_sigma(self.sigma, ndims)
+        self.min_sigma = self._normalize_sigma(self.min_sigma, ndims)
+        if self.isotropic and self.random:           # the same random kernel along all axes
+            self.sigma = self.sigma[:1]
+            self.min_sigma = self.min_sigma[:1]
+        self.built = True
+
+    def call(self, x):
+        if not any(s > 0 for s in self.sigma):
+            return x
+        kernel = utils.gaussian_kernel(sigma=self.sigma, random=self.random, min_sigma=self.min_sigma, separate=True,
+                                       dtype=x.dtype, seed=self.seed)
+        return utils.separable_conv(x, kernel, batched=True)
 
 
 def _normalize_tuple(value, n, name):

@@ -20,6 +20,7 @@ import torch
 from . import _lib
 
 __all__ = ['interpn', 'resize', 'zoom', 'transform', 'affine_to_dense_shift', 'integrate_vec', 'compose',
+           'gaussian_kernel', 'separable_conv', 'minmax_norm',
            'rescale_dense_transform', 'rescale_affine', 'is_affine_shape', 'validate_affine_shape', 'make_square_affine', 'volshape_to_ndgrid',
            'volshape_to_meshgrid', 'ndgrid', 'meshgrid', 'sub2ind2d', 'prod_n', 'batch_channel_flatten',
            'flatten_batch_channel', 'flatten_axes']
@@ -471,6 +472,141 @@ def compose(transforms, interp_method='linear', shift_center=True, indexing='ij'
         else:
             curr = torch.matmul(make_square_affine(nxt), make_square_affine(curr))[..., :-1, :]
     return curr
+
+
+# --------------------------------------------------------------------------------------
+# filtering and normalisation (synthesis front-end; neurite/tf/utils/utils.py:581-751, 953-968)
+# --------------------------------------------------------------------------------------
+
+def gaussian_kernel(sigma, windowsize=None, indexing='ij', separate=False, random=False, min_sigma=0,
+                    dtype=torch.float32, seed=None, device=None):
+    """
+    N-dimensional Gaussian kernel (utils.py:581-662), or a list of N 1-D kernels with separate=True.  Host-side: the
+    kernels are a few dozen numbers.  random=True draws each SD uniformly from [min_sigma, sigma) with torch's RNG
+    (the reference uses tf.random.uniform: same distribution, different stream).
+    """
+    if not dtype.is_floating_point:
+        raise AssertionError(f'{dtype} is not a real floating-point type')
+    npdt = {torch.float32: np.float32, torch.float64: np.float64, torch.float16: np.float16}.get(dtype, np.float32)
+    if not isinstance(sigma, (list, tuple)):
+        sigma = [sigma]
+    if not isinstance(min_sigma, (list, tuple)):
+        min_sigma = [min_sigma] * len(sigma)
+    sigma = [max(f, np.finfo(npdt).eps) for f in sigma]
+    min_sigma = [max(f, np.finfo(npdt).eps) for f in min_sigma]
+    if windowsize is None:
+        windowsize = [np.round(f * 3) * 2 + 1 for f in sigma]
+    if not isinstance(windowsize, (list, tuple)):
+        windowsize = [windowsize]
+    if len(sigma) != len(windowsize):
+        raise ValueError(f'sigma {sigma} and width {windowsize} differ in length')
+    center = [(w - 1) / 2 for w in windowsize]
+    mesh = [np.arange(w) - c for w, c in zip(windowsize, center)]
+    mesh = [-0.5 * x ** 2 for x in mesh]
+    if not separate:
+        mesh = np.meshgrid(*mesh, indexing=indexing)
+    mesh = [torch.as_tensor(np.asarray(m), dtype=dtype, device=device) for m in mesh]
+    if random:
+        gen = torch.Generator(device='cpu')
+        gen.manual_seed(int(np.random.default_rng(seed).integers(2 ** 31 - 1)))
+        sigma = [float(a + (b - a) * torch.rand((), generator=gen)) for a, b in zip(min_sigma, sigma)]
+    exponent = [m / torch.tensor(s, dtype=dtype) ** 2 for m, s in zip(mesh, sigma)]
+    if not separate:
+        exponent = [torch.stack(exponent).sum(0)]
+    kernel = [torch.exp(x) for x in exponent]
+    kernel = [x / x.sum() for x in kernel]
+    return kernel if len(kernel) > 1 else kernel[0]
+
+
+def _conv1d_axis(x, k, ax, padding, stride, dilation):
+    """one separable pass along tensor axis `ax` of the contiguous float32 tensor x (csrc/filter.hip)."""
+    lib = _lib.lib()
+    dev = x.device
+    n, w = x.shape[ax], k.numel()
+    ke = (w - 1) * dilation + 1
+    if padding.upper() == 'SAME':
+        o = -(-n // stride)
+        before = max((o - 1) * stride + ke - n, 0) // 2
+    elif padding.upper() == 'VALID':
+        o = (n - ke) // stride + 1
+        before = 0
+        if o < 1:
+            raise ValueError('Negative dimension size caused by a VALID convolution of width %d along a length-%d axis' % (ke, n))
+    else:
+        raise ValueError('padding must be "SAME" or "VALID"')
+    outer = int(np.prod(x.shape[:ax])) if ax else 1
+    inner = int(np.prod(x.shape[ax + 1:]))
+    y = torch.empty(tuple(x.shape[:ax]) + (o,) + tuple(x.shape[ax + 1:]), dtype=torch.float32, device=dev)
+    if y.numel():
+        with torch.cuda.device(dev):
+            rc = lib.nrt_conv1d_axis_f32(_lib.ptr(x), _lib.ptr(k), _lib.ptr(y), outer, n, inner, o, w, int(stride),
+                                         int(dilation), int(before), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv1d_axis_f32')
+    return y
+
+
+def separable_conv(x, kernels, axis=None, batched=False, padding='SAME', strides=None, dilations=None):
+    """
+    Apply 1-D kernels along spatial axes of a tensor with a trailing feature dimension, the same filters across
+    features (utils.py:665-751).  One kernel pass per axis on the tensor as it lies in memory -- no transposes.
+    """
+    dev = _lib.require_device(x)
+    if x.dtype != torch.float32:
+        raise NotImplementedError('separable_conv: float32 tensors, got %s' % x.dtype)
+    if not batched:
+        x = x.unsqueeze(0)
+    num_dim = x.dim() - 2
+    if np.isscalar(axis):
+        axis = [axis]
+    axes_space = range(num_dim)
+    if axis is None:
+        axis = list(axes_space)
+    assert all(ax in axes_space for ax in axis), 'non-spatial axis passed'
+
+    def conform(v):
+        v = np.ravel(1 if v is None else v).tolist()
+        return v * len(axis) if len(v) == 1 else v
+    strides, dilations = conform(strides), conform(dilations)
+    assert len(strides) == len(axis), 'number of strides and axes differ'
+    assert len(dilations) == len(axis), 'number of dilations and axes differ'
+    if not isinstance(kernels, (tuple, list)):
+        kernels = [kernels]
+    if len(kernels) == 1:
+        kernels = list(kernels) * len(axis)
+    assert len(kernels) == len(axis), 'number of kernels and axes differ'
+    x = x.contiguous()
+    for ax, k, s, d in zip(axis, kernels, strides, dilations):
+        k = torch.as_tensor(k, dtype=torch.float32).reshape(-1).to(dev).contiguous()
+        x = _conv1d_axis(x, k, ax + 1, padding, int(s), int(d))
+    return x if batched else x[0]
+
+
+def minmax_norm(x, axis=None):
+    """
+    Min-max normalise with a safe division (utils.py:953-968).  axis: dimensions to reduce (None = all); they must
+    form one contiguous run (e.g. all, all but the batch, all spatial axes of a channels-last batch).
+    """
+    lib = _lib.lib()
+    dev = _lib.require_device(x)
+    if x.dtype != torch.float32:
+        raise NotImplementedError('minmax_norm: float32 tensors, got %s' % x.dtype)
+    nd = x.dim()
+    axes = sorted(set(range(nd))) if axis is None else sorted(set(int(a) % nd for a in np.ravel(axis)))
+    if not axes or axes != list(range(axes[0], axes[-1] + 1)):
+        raise NotImplementedError('minmax_norm: the reduced axes must be contiguous, got %r' % (axis,))
+    x = x.contiguous()
+    outer = int(np.prod(x.shape[:axes[0]])) if axes[0] else 1
+    red = int(np.prod(x.shape[axes[0]:axes[-1] + 1]))
+    inner = int(np.prod(x.shape[axes[-1] + 1:]))
+    y = torch.empty_like(x)
+    if x.numel() == 0:
+        return y
+    nws = lib.nrt_minmax_workspace_bytes(outer, inner)
+    ws = torch.empty((max(int(nws), 16),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_minmax_norm_f32(_lib.ptr(x), _lib.ptr(y), outer, red, inner, _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_minmax_norm_f32')
+    return y
 
 
 # --------------------------------------------------------------------------------------

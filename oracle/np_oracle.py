@@ -537,3 +537,106 @@ def softmax_lastdim(x):
     x = np.asarray(x, np.float64)
     e = np.exp(x - x.max(-1, keepdims=True))
     return e / e.sum(-1, keepdims=True)
+
+
+# --------------------------------------------------------------------------------------
+# filtering / normalisation of the synthesis front-end (neurite/tf/utils/utils.py:581-751, 953-968;
+# neurite/tf/layers.py:251-364; neurite/tf/utils/augment.py:7-62)
+# --------------------------------------------------------------------------------------
+
+def gaussian_kernel(sigma, windowsize=None, indexing='ij', separate=False, dtype=F32):
+    """utils.py:581-662 (non-random): exp(-x^2 / (2 s^2)) on a centred grid, normalised to sum 1."""
+    if not isinstance(sigma, (list, tuple)):
+        sigma = [sigma]
+    sigma = [max(f, np.finfo(dtype).eps) for f in sigma]                     # :628
+    if windowsize is None:
+        windowsize = [np.round(f * 3) * 2 + 1 for f in sigma]                # :633
+    if not isinstance(windowsize, (list, tuple)):
+        windowsize = [windowsize]
+    if len(sigma) != len(windowsize):
+        raise ValueError(f'sigma {sigma} and width {windowsize} differ in length')
+    center = [(w - 1) / 2 for w in windowsize]                               # :640
+    mesh = [np.arange(w) - c for w, c in zip(windowsize, center)]
+    mesh = [-0.5 * x ** 2 for x in mesh]
+    if not separate:
+        mesh = np.meshgrid(*mesh, indexing=indexing)
+    mesh = [np.asarray(m, dtype) for m in mesh]
+    exponent = [(m / dtype(s) ** 2).astype(dtype) for m, s in zip(mesh, sigma)]        # :653
+    if not separate:
+        exponent = [np.sum(np.stack(exponent), axis=0, dtype=dtype)]
+    kernel = [np.exp(x).astype(dtype) for x in exponent]
+    kernel = [(x / x.sum(dtype=dtype)).astype(dtype) for x in kernel]
+    return kernel if len(kernel) > 1 else kernel[0]
+
+
+def conv1d_axis(x, k, axis, padding='SAME', stride=1, dilation=1):
+    """cross-correlation of x [..] with the 1-D kernel k along `axis` (TF SAME/VALID rules), float64 accumulation."""
+    x = np.asarray(x)
+    k = np.asarray(k, np.float64).ravel()
+    n, w = x.shape[axis], k.size
+    ke = (w - 1) * dilation + 1
+    if padding.upper() == 'SAME':
+        o = -(-n // stride)
+        tot = max((o - 1) * stride + ke - n, 0)
+        before = tot // 2
+    else:
+        o = (n - ke) // stride + 1
+        before = tot = 0
+    pad = [(0, 0)] * x.ndim
+    pad[axis] = (before, tot - before)
+    xp = np.pad(x.astype(np.float64), pad)
+    out = 0
+    for t in range(w):
+        sl = [slice(None)] * x.ndim
+        st = t * dilation
+        sl[axis] = slice(st, st + (o - 1) * stride + 1, stride)
+        out = out + k[t] * xp[tuple(sl)]
+    return out.astype(x.dtype)
+
+
+def separable_conv(x, kernels, axis=None, batched=False, padding='SAME', strides=None, dilations=None):
+    """utils.py:665-751: the same 1-D filters across features, one pass per spatial axis."""
+    x = np.asarray(x)
+    if not batched:
+        x = x[None]
+    num_dim = x.ndim - 2
+    if np.isscalar(axis):
+        axis = [axis]
+    if axis is None:
+        axis = list(range(num_dim))
+    assert all(ax in range(num_dim) for ax in axis), 'non-spatial axis passed'
+
+    def conform(v):
+        v = np.ravel(1 if v is None else v).tolist()
+        return v * len(axis) if len(v) == 1 else v
+    strides, dilations = conform(strides), conform(dilations)
+    assert len(strides) == len(axis), 'number of strides and axes differ'
+    assert len(dilations) == len(axis), 'number of dilations and axes differ'
+    if not isinstance(kernels, (tuple, list)):
+        kernels = [kernels]
+    if len(kernels) == 1:
+        kernels = list(kernels) * len(axis)
+    assert len(kernels) == len(axis), 'number of kernels and axes differ'
+    for ax, k, s, d in zip(axis, kernels, strides, dilations):
+        x = conv1d_axis(x, k, ax + 1, padding, int(s), int(d))
+    return x if batched else x[0]
+
+
+def gaussian_blur(x, sigma):
+    """layers.GaussianBlur (non-random) on [B, *S, C]."""
+    nd = x.ndim - 2
+    sigma = np.ravel(sigma).tolist()
+    if len(sigma) == 1:
+        sigma = sigma * nd
+    if not any(s > 0 for s in sigma):
+        return x
+    return separable_conv(x, gaussian_kernel(sigma, separate=True) if nd > 1 else [gaussian_kernel(sigma, separate=True)],
+                          batched=True)
+
+
+def minmax_norm(x, axis=None):
+    """utils.py:953-968."""
+    x = np.asarray(x)
+    mn = x.min(axis=axis, keepdims=True)
+    mx = x.max(axis=axis, keepdims=True)
+    return divide_no_nan(x - mn, mx - mn)

@@ -266,7 +266,54 @@ def gen_lc3d():
     save('lc3d_small', **cases)
 
 
+def gen_filter():
+    """gaussian_kernel (utils.py:581-662), separable_conv (:665-751), minmax_norm (:953-968), layers.GaussianBlur (:251-364)."""
+    rng = np.random.default_rng(11)
+    cases = {}
+    # gaussian_kernel: joint and separated, explicit window, 'xy' indexing
+    for tag, kw in (('gk_iso3', dict(sigma=[1.5, 1.5, 1.5])), ('gk_aniso', dict(sigma=[0.7, 2.0])),
+                    ('gk_win', dict(sigma=[1.0, 2.0], windowsize=[5, 4])), ('gk_xy', dict(sigma=[1.0, 2.0], indexing='xy')),
+                    ('gk_tiny', dict(sigma=0))):
+        k = ne.utils.gaussian_kernel(**kw)
+        cases[tag + '__joint'] = A(k)
+        ks = ne.utils.gaussian_kernel(separate=True, **kw)
+        ks = ks if isinstance(ks, list) else [ks]
+        for i, kk in enumerate(ks):
+            cases[tag + '__sep%d' % i] = A(kk)
+    # separable_conv
+    x3 = rng.standard_normal((9, 8, 11, 3)).astype(F)
+    xb = rng.standard_normal((2, 7, 10, 6, 2)).astype(F)
+    x2 = rng.standard_normal((12, 9, 1)).astype(F)
+    k3 = [A(k).astype(F) for k in ne.utils.gaussian_kernel([1.0, 0.6, 1.4], separate=True)]
+    k5 = rng.standard_normal(5).astype(F)
+    k4 = rng.standard_normal(4).astype(F)
+    cases['sc_x3'] = x3; cases['sc_xb'] = xb; cases['sc_x2'] = x2
+    cases['sc_k3_0'], cases['sc_k3_1'], cases['sc_k3_2'] = k3
+    cases['sc_k5'] = k5; cases['sc_k4'] = k4
+    cases['sc_all_axes__out'] = A(ne.utils.separable_conv(T(x3), [T(k) for k in k3]))
+    cases['sc_single_kernel__out'] = A(ne.utils.separable_conv(T(x3), T(k5)))
+    cases['sc_axis1__out'] = A(ne.utils.separable_conv(T(x3), T(k5), axis=1))
+    cases['sc_axes02_valid__out'] = A(ne.utils.separable_conv(T(x3), [T(k5), T(k4)], axis=[0, 2], padding='VALID'))
+    cases['sc_even_same__out'] = A(ne.utils.separable_conv(T(x3), T(k4)))
+    cases['sc_stride2__out'] = A(ne.utils.separable_conv(T(x3), T(k5), strides=2))
+    cases['sc_stride_list__out'] = A(ne.utils.separable_conv(T(x3), [T(k5), T(k4)], axis=[1, 2], strides=[2, 3]))
+    cases['sc_dil2__out'] = A(ne.utils.separable_conv(T(x3), T(k5), dilations=2))
+    cases['sc_batched__out'] = A(ne.utils.separable_conv(T(xb), [T(k) for k in k3], batched=True))
+    cases['sc_2d__out'] = A(ne.utils.separable_conv(T(x2), T(k5)))
+    # GaussianBlur layer
+    cases['blur_sigma'] = np.array([1.0, 0.0, 2.0], F)
+    cases['blur__out'] = A(ne.layers.GaussianBlur(sigma=[1.0, 0.0, 2.0])(T(xb)))
+    cases['blur_iso__out'] = A(ne.layers.GaussianBlur(sigma=1.3)(T(xb)))
+    # minmax_norm
+    cases['mm_all__out'] = A(ne.utils.minmax_norm(T(xb)))
+    cases['mm_per_batch__out'] = A(ne.utils.minmax_norm(T(xb), axis=(1, 2, 3, 4)))
+    cases['mm_per_batch_feature__out'] = A(ne.utils.minmax_norm(T(xb), axis=(1, 2, 3)))
+    cases['mm_const__out'] = A(ne.utils.minmax_norm(T(np.full((3, 4, 2), 2.5, F))))
+    save('filter_small', **cases)
+
+
 if __name__ == '__main__':
+    gen_filter()
     gen_interpn()
     gen_resize()
     gen_index_helpers()

@@ -483,6 +483,55 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         _populate(module)
 
 
+def shape_(x, **kw): return Tensor(np.array(A(x).shape, np.int32))
+def transpose_(x, perm=None, **kw): return Tensor(np.transpose(A(x), None if perm is None else tuple(int(p) for p in A(perm))))
+
+
+def reduce_prod(x, axis=None, keepdims=False):
+    return Tensor(np.prod(A(x), axis=axis, keepdims=keepdims))
+
+
+def reduce_min(x, axis=None, keepdims=False):
+    return Tensor(np.min(A(x), axis=None if axis is None else tuple(np.ravel(axis)), keepdims=keepdims))
+
+
+def reduce_max(x, axis=None, keepdims=False):
+    return Tensor(np.max(A(x), axis=None if axis is None else tuple(np.ravel(axis)), keepdims=keepdims))
+
+
+def nn_convolution(x, filters, padding='VALID', strides=None, dilations=None, **kw):
+    """tf.nn.convolution for [N, *S, 1] inputs and [*k, 1, 1] filters (what separable_conv issues): cross-correlation,
+    TF SAME padding (total = max((out-1)*stride + (k-1)*dil + 1 - n, 0), before = total // 2), float32 accumulation."""
+    x = A(x)
+    f = A(filters)
+    nd = x.ndim - 2
+    assert x.shape[-1] == 1 and f.shape[-2:] == (1, 1), 'shim supports single-channel convolution only'
+    strides = [1] * nd if strides is None else [int(s) for s in np.ravel(strides)]
+    dil = [1] * nd if dilations is None else [int(d) for d in np.ravel(dilations)]
+    k = f.shape[:nd]
+    xs = x[..., 0]
+    outs, pads = [], []
+    for d in range(nd):
+        n, ke = xs.shape[1 + d], (k[d] - 1) * dil[d] + 1
+        if padding.upper() == 'SAME':
+            o = -(-n // strides[d])
+            tot = max((o - 1) * strides[d] + ke - n, 0)
+            pads.append((tot // 2, tot - tot // 2))
+        else:
+            o = (n - ke) // strides[d] + 1
+            pads.append((0, 0))
+        outs.append(o)
+    xp = np.pad(xs, [(0, 0)] + pads)
+    out = np.zeros((xs.shape[0],) + tuple(outs), x.dtype)
+    for tap in np.ndindex(*k):
+        sl = [slice(None)]
+        for d in range(nd):
+            st = tap[d] * dil[d]
+            sl.append(slice(st, st + (outs[d] - 1) * strides[d] + 1, strides[d]))
+        out = (out + f[tap + (0, 0)] * xp[tuple(sl)]).astype(x.dtype)
+    return Tensor(out[..., None])
+
+
 def _populate(m):
     n = m.__name__
     if n == 'pystrum':
@@ -497,6 +546,7 @@ def _populate(m):
             float32=DType(np.float32), float64=DType(np.float64), int32=DType(np.int32),
             int64=DType(np.int64), bool=DType(np.bool_), float16=DType(np.float16),
             expand_dims=lambda x, axis: k_expand_dims(x, axis),
+            shape=shape_, transpose=transpose_, reduce_prod=reduce_prod, reduce_min=reduce_min, reduce_max=reduce_max,
         )
         for k, v in d.items():
             setattr(m, k, v)
@@ -513,6 +563,9 @@ def _populate(m):
         m.InvalidArgumentError = InvalidArgumentError
     if n == 'tensorflow.compat.v1':
         m.Dimension = Dimension
+        m.div_no_nan = divide_no_nan
+    if n == 'tensorflow.nn':
+        m.convolution = nn_convolution
     if n == 'tensorflow.dtypes':
         m.as_dtype = lambda d: d if isinstance(d, DType) else DType(d)
     if n == 'tensorflow.keras.backend':
@@ -541,7 +594,7 @@ def install():
                  'tensorflow.keras.backend', 'tensorflow.keras.layers', 'tensorflow.keras.losses',
                  'tensorflow.keras.models', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
                  'tensorflow.python', 'tensorflow.python.keras', 'tensorflow.python.keras.utils',
-                 'tensorflow.python.ops', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
+                 'tensorflow.python.ops', 'tensorflow.nn', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
         mod = importlib.import_module(name)
         if '.' in name:
             parent, child = name.rsplit('.', 1)

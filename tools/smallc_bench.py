@@ -33,3 +33,16 @@ vi = ne.layers.VecInt(int_steps=7)
 ms = timeit(lambda: vi(flow), n=5)
 nbytes = 7 * B * S ** 3 * 36
 print(json.dumps({'op': 'VecInt 7 steps 160^3', 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
+# synthesis front-end: Gaussian blur (3 separable passes), min-max normalisation, Perlin-like noise
+img = torch.randn(B, S, S, S, 1, device=dev)
+for sigma in (1.0, 3.0):
+    blur = ne.layers.GaussianBlur(sigma=sigma)
+    ms = timeit(lambda: blur(img))
+    nbytes = 3 * 2 * img.numel() * 4
+    print(json.dumps({'op': 'GaussianBlur sigma=%g C=1 (3 passes)' % sigma, 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1),
+                      'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
+ms = timeit(lambda: ne.utils.minmax_norm(img, axis=(1, 2, 3, 4)))
+nbytes = 3 * img.numel() * 4
+print(json.dumps({'op': 'minmax_norm per batch entry', 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
+ms = timeit(lambda: ne.augment.draw_perlin((S, S, S, 1), scales=(8, 16, 32), max_std=1.0, seed=1), n=5)
+print(json.dumps({'op': 'draw_perlin 160^3 scales (8,16,32)', 'ms': round(ms, 4)}))
