@@ -309,6 +309,29 @@ int nrt_conv1d_axis_f32(const float *x, const float *kernel, float *y, long long
 size_t nrt_minmax_workspace_bytes(long long outer, int inner);
 int nrt_minmax_norm_f32(const float *x, float *y, long long outer, long long reduce_len, int inner, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* out2 = {min, max} of x[0..n) on the device (no host synchronisation); workspace >= 8 bytes */
+int nrt_minmax_f32(const float *x, long long n, float *out2, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Soft quantisation and mutual information (neurite/tf/utils/utils.py:1099-1172, neurite/tf/metrics.py:41-336)
+ *   nrt_soft_quantize_f32   out[v, b] = exp(-alpha (clip(x_v) - centers_b)^2)  (or its log)
+ *   nrt_mi_joint_f32        x, y [batch, nvox, channels]; per item (b, c): joint[i][j] += sum_v wx_i(v) wy_j(v),
+ *                           sum_x[i] += sum_v wx_i(v), sum_y likewise -- the contraction of MutualInformation.channelwise
+ *                           without the [V, nb] maps (fp32 MFMA, weights formed in registers); nb_bins <= 32;
+ *                           outputs are accumulated with float atomics and must be ZERO-FILLED by the caller
+ *   nrt_mi_joint_bwd_f32    gradient wrt x / y given d loss / d joint, d sum_x, d sum_y (bin centres held constant)
+ *   nrt_colsum_f32          out[item, c] += sum_r x[item, r, c]  (marginals of probability maps; zero-filled by the caller)
+ * ------------------------------------------------------------------------------------------ */
+int nrt_soft_quantize_f32(const float *x, const float *centers, float alpha, float min_clip, float max_clip, int return_log,
+                          float *out, long long n, int nb_bins, void *stream);
+int nrt_mi_joint_f32(const float *x, const float *y, const float *centers_x, const float *centers_y, float alpha, float min_clip,
+                     float max_clip, int batch, long long nvox, int channels, int nb_bins, float *joint, float *sum_x,
+                     float *sum_y, void *stream);
+int nrt_mi_joint_bwd_f32(const float *x, const float *y, const float *centers_x, const float *centers_y, float alpha,
+                         float min_clip, float max_clip, int batch, long long nvox, int channels, int nb_bins,
+                         const float *grad_joint, const float *grad_sum_x, const float *grad_sum_y, float *grad_x, float *grad_y,
+                         void *stream);
+int nrt_colsum_f32(const float *x, int items, long long rows, int cols, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or

@@ -60,6 +60,11 @@ _SIGNATURES = {
     'nrt_conv1d_axis_f32': (_i, [_vp, _vp, _vp, _ll, _i, _ll, _i, _i, _i, _i, _i, _vp]),
     'nrt_minmax_workspace_bytes': (_sz, [_ll, _i]),
     'nrt_minmax_norm_f32': (_i, [_vp, _vp, _ll, _ll, _i, _vp, _sz, _vp]),
+    'nrt_minmax_f32': (_i, [_vp, _ll, _vp, _vp, _sz, _vp]),
+    'nrt_soft_quantize_f32': (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _ll, _i, _vp]),
+    'nrt_mi_joint_f32': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _ll, _i, _i, _vp, _vp, _vp, _vp]),
+    'nrt_mi_joint_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'nrt_colsum_f32': (_i, [_vp, _i, _ll, _i, _vp, _vp]),
     'nrt_membench_l1_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'nrt_membench_copy_f32': (_i, [_vp, _vp, _ll, _i, _i, _vp]),
     'nrt_wcce': (_i, [_vp, _vp, _i, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),

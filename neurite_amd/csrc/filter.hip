@@ -107,6 +107,10 @@ __global__ __launch_bounds__(256) void minmax_apply(const float *__restrict__ x,
     }
 }
 
+__global__ void minmax_decode(const int *ws, float *out) {
+    if (threadIdx.x == 0) { out[0] = key2f(ws[0]); out[1] = key2f(ws[1]); }
+}
+
 unsigned fblocks(long long n) {
     long long b = (n + 255) / 256;
     if (b > 256ll * 16) b = 256ll * 16;
@@ -155,6 +159,20 @@ extern "C" int nrt_minmax_norm_f32(const float *x, float *y, long long outer, lo
     hipLaunchKernelGGL(minmax_reduce, dim3((unsigned)bx, (unsigned)outer), dim3(256), (size_t)inner * 2 * sizeof(int), st, x, ws,
                        reduce_len, inner);
     hipLaunchKernelGGL(minmax_apply, dim3(fblocks(reduce_len * inner), (unsigned)outer), dim3(256), 0, st, x, ws, y, reduce_len, inner);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_minmax_f32(const float *x, long long n, float *out2, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x || !out2 || n < 1) return NRT_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < 2 * sizeof(int)) return NRT_ERR_WORKSPACE;
+    hipStream_t st = nrt_stream(stream);
+    int *ws = (int *)workspace;
+    hipLaunchKernelGGL(minmax_init, dim3(1), dim3(256), 0, st, ws, 1ll);
+    long long bx = (n + 256 * 16 - 1) / (256 * 16);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(minmax_reduce, dim3((unsigned)bx, 1), dim3(256), 2 * sizeof(int), st, x, ws, n, 1);
+    hipLaunchKernelGGL(minmax_decode, dim3(1), dim3(64), 0, st, ws, out2);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

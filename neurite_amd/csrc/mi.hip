@@ -1,0 +1,231 @@
+// Soft quantisation and mutual information (neurite/tf/utils/utils.py:1099-1172,
+// neurite/tf/metrics.py:41-336), gfx950.
+//
+// MutualInformation.volumes / channelwise soft-quantise both images into nb bins (w_b(v) = exp(-alpha (x_v - c_b)^2)),
+// build the joint histogram J[i][j] = sum_v wx_i(v) wy_j(v) with a batched matmul over the [V, nb] maps, and reduce it to
+// one number per (batch, channel).  The [V, nb] maps are 16x the images and exist only to be contracted: here they never
+// do.  A wave computes the bin weights in registers in the layout of the fp32 MFMA operands -- lane l holds
+// wx[bin = l & 15][voxel = l >> 4] and wy[voxel = l >> 4][bin = l & 15] -- so one v_mfma_f32_16x16x4_f32 adds four voxels
+// to a 16 x 16 tile of J; the marginals are the lanes' running sums.  The kernel reads 8 bytes per voxel and writes nb^2
+// floats per item.  The [items, nb, nb]-sized arithmetic that follows (normalisation, log, sum) is host-side glue.
+// The backward recomputes the weights: dL/dx_v = sum_i (sum_j G_ij wy_j(v) + gx_i) * wx_i(v) * (-2 alpha (x_v - c_i)).
+
+#include "nrt_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MiArgs {
+    const float *x, *y;      // item (b, c) voxel v at [(b * V + v) * C + c]
+    const float *cx, *cy;    // bin centres [nb] (device)
+    float alpha, lo, hi;     // clip range
+    long long V;
+    int C, nb, items;        // items = B * C
+    float *joint, *sx, *sy;  // [items, nb, nb], [items, nb], [items, nb]; accumulated with atomics (zero-filled by the caller)
+};
+
+__device__ __forceinline__ float clipf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// NBT = ceil(nb / 16) tiles per side (1 or 2); grid (chunks, items)
+template <int NBT>
+__global__ __launch_bounds__(256) void mi_joint(MiArgs a) {
+    const int item = blockIdx.y, b = item / a.C, c = item % a.C;
+    const float *xb = a.x + ((long long)b * a.V) * a.C + c;
+    const float *yb = a.y + ((long long)b * a.V) * a.C + c;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    float cxv[NBT], cyv[NBT];
+    bool live[NBT];
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) {
+        live[t] = 16 * t + l15 < a.nb;
+        cxv[t] = live[t] ? a.cx[16 * t + l15] : 0.0f;
+        cyv[t] = live[t] ? a.cy[16 * t + l15] : 0.0f;
+    }
+    f32x4 acc[NBT][NBT];
+    float sx[NBT], sy[NBT];
+#pragma unroll
+    for (int i = 0; i < NBT; ++i) {
+        sx[i] = 0.0f; sy[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NBT; ++j) acc[i][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    // a wave takes 64 voxels at a time (one coalesced load), 16 MFMA steps of 4 voxels
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long v0 = ((long long)blockIdx.x * 4 + wv) * 64; v0 < a.V; v0 += nwaves * 64) {
+        const long long v = v0 + lane;
+        const bool in = v < a.V;
+        const float xl = in ? clipf(xb[v * a.C], a.lo, a.hi) : 0.0f;
+        const float yl = in ? clipf(yb[v * a.C], a.lo, a.hi) : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int src = 4 * s + l4;
+            const float xv = __shfl(xl, src, 64), yv = __shfl(yl, src, 64);
+            const bool vin = v0 + src < a.V;
+            float wa[NBT], wb[NBT];
+#pragma unroll
+            for (int t = 0; t < NBT; ++t) {
+                const float dx = xv - cxv[t], dy = yv - cyv[t];
+                wa[t] = (live[t] && vin) ? expf(-a.alpha * (dx * dx)) : 0.0f;
+                wb[t] = (live[t] && vin) ? expf(-a.alpha * (dy * dy)) : 0.0f;
+                sx[t] += wa[t]; sy[t] += wb[t];
+            }
+#pragma unroll
+            for (int i = 0; i < NBT; ++i)
+#pragma unroll
+                for (int j = 0; j < NBT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], wb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // marginals: sum the four voxel slots of a bin (lanes l, l^16, l^32, l^48)
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) {
+        sx[t] += __shfl_xor(sx[t], 16, 64); sx[t] += __shfl_xor(sx[t], 32, 64);
+        sy[t] += __shfl_xor(sy[t], 16, 64); sy[t] += __shfl_xor(sy[t], 32, 64);
+        if (l4 == 0 && live[t]) {
+            unsafeAtomicAdd(&a.sx[(long long)item * a.nb + 16 * t + l15], sx[t]);
+            unsafeAtomicAdd(&a.sy[(long long)item * a.nb + 16 * t + l15], sy[t]);
+        }
+    }
+    // joint: D row = 4 (l >> 4) + r (x bin), col = l & 15 (y bin)
+#pragma unroll
+    for (int i = 0; i < NBT; ++i)
+#pragma unroll
+        for (int j = 0; j < NBT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bi = 16 * i + 4 * l4 + r, bj = 16 * j + l15;
+                if (bi < a.nb && bj < a.nb) unsafeAtomicAdd(&a.joint[((long long)item * a.nb + bi) * a.nb + bj], acc[i][j][r]);
+            }
+}
+
+// backward: one thread per voxel of an item; G [items, nb, nb], gsx / gsy [items, nb]
+__global__ __launch_bounds__(256) void mi_joint_bwd(MiArgs a, const float *__restrict__ G, const float *__restrict__ gsx,
+                                                    const float *__restrict__ gsy, float *__restrict__ gx, float *__restrict__ gy) {
+    extern __shared__ float sm[];          // G [nb][nb], gsx [nb], gsy [nb], cx [nb], cy [nb]
+    const int item = blockIdx.y, b = item / a.C, c = item % a.C;
+    const int nb = a.nb;
+    float *sG = sm, *sgx = sm + nb * nb, *sgy = sgx + nb, *scx = sgy + nb, *scy = scx + nb;
+    for (int i = threadIdx.x; i < nb * nb; i += 256) sG[i] = G[(long long)item * nb * nb + i];
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        sgx[i] = gsx[(long long)item * nb + i]; sgy[i] = gsy[(long long)item * nb + i];
+        scx[i] = a.cx[i]; scy[i] = a.cy[i];
+    }
+    __syncthreads();
+    const long long base = ((long long)b * a.V) * a.C + c;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < a.V; v += (long long)gridDim.x * 256) {
+        const float xr = a.x[base + v * a.C], yr = a.y[base + v * a.C];
+        const float xv = clipf(xr, a.lo, a.hi), yv = clipf(yr, a.lo, a.hi);
+        const bool xin = xr >= a.lo && xr <= a.hi, yin = yr >= a.lo && yr <= a.hi;      // clip_by_value passes the gradient inside
+        float wy[32], dgx = 0.0f, dgy = 0.0f;
+        for (int j = 0; j < nb; ++j) { const float d = yv - scy[j]; wy[j] = expf(-a.alpha * d * d); }
+        float ty[32];
+        for (int j = 0; j < nb; ++j) ty[j] = sgy[j];
+        for (int i = 0; i < nb; ++i) {
+            const float d = xv - scx[i];
+            const float wx = expf(-a.alpha * d * d);
+            float t = sgx[i];
+            for (int j = 0; j < nb; ++j) { t += sG[i * nb + j] * wy[j]; ty[j] += sG[i * nb + j] * wx; }
+            dgx += t * wx * (-2.0f * a.alpha * d);
+        }
+        for (int j = 0; j < nb; ++j) dgy += ty[j] * wy[j] * (-2.0f * a.alpha * (yv - scy[j]));
+        if (gx) gx[base + v * a.C] = xin ? dgx : 0.0f;
+        if (gy) gy[base + v * a.C] = yin ? dgy : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void soft_quantize(const float *__restrict__ x, const float *__restrict__ centers, float alpha,
+                                                     float lo, float hi, int ret_log, float *__restrict__ out, long long n, int nb) {
+    const long long total = n * nb;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long v = e / nb;
+        const int bidx = (int)(e - v * nb);
+        const float d = clipf(x[v], lo, hi) - centers[bidx];
+        const float lg = -alpha * (d * d);
+        out[e] = ret_log ? lg : expf(lg);
+    }
+}
+
+// column sums of a [n, C] matrix per batch item: out[item][c] += sum_v x[item][v][c]  (atomics, zero-filled by the caller)
+__global__ __launch_bounds__(256) void colsum(const float *__restrict__ x, long long n, int C, float *__restrict__ out) {
+    extern __shared__ float sm[];
+    const int item = blockIdx.y;
+    for (int i = threadIdx.x; i < C; i += 256) sm[i] = 0.0f;
+    __syncthreads();
+    const float *xb = x + (long long)item * n * C;
+    const long long total = n * C;
+    // a thread keeps one column when 256 % C == 0 (the stride preserves e % C); otherwise LDS atomics per element
+    if (256 % C == 0) {
+        float s = 0.0f;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) s += xb[e];
+        atomicAdd(&sm[threadIdx.x % C], s);
+    } else {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+            atomicAdd(&sm[(int)(e % C)], xb[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) unsafeAtomicAdd(&out[(long long)item * C + i], sm[i]);
+}
+
+unsigned mblocks(long long n, int per) {
+    long long b = (n + per - 1) / per;
+    if (b > 256ll * 8) b = 256ll * 8;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int nrt_mi_joint_f32(const float *x, const float *y, const float *centers_x, const float *centers_y, float alpha,
+                                float min_clip, float max_clip, int batch, long long nvox, int channels, int nb_bins, float *joint,
+                                float *sum_x, float *sum_y, void *stream) {
+    if (!x || !y || !centers_x || !centers_y || !joint || !sum_x || !sum_y) return NRT_ERR_INVALID_ARG;
+    if (batch < 1 || nvox < 0 || channels < 1 || nb_bins < 1) return NRT_ERR_INVALID_ARG;
+    if (nb_bins > 32 || (long long)batch * channels > 65535) return NRT_ERR_UNSUPPORTED;
+    if (nvox == 0) return NRT_OK;
+    MiArgs a;
+    a.x = x; a.y = y; a.cx = centers_x; a.cy = centers_y; a.alpha = alpha; a.lo = min_clip; a.hi = max_clip;
+    a.V = nvox; a.C = channels; a.nb = nb_bins; a.items = batch * channels; a.joint = joint; a.sx = sum_x; a.sy = sum_y;
+    dim3 grid(mblocks(nvox, 256 * 16), (unsigned)a.items);
+    if (nb_bins <= 16) hipLaunchKernelGGL((mi_joint<1>), grid, dim3(256), 0, nrt_stream(stream), a);
+    else hipLaunchKernelGGL((mi_joint<2>), grid, dim3(256), 0, nrt_stream(stream), a);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_mi_joint_bwd_f32(const float *x, const float *y, const float *centers_x, const float *centers_y, float alpha,
+                                    float min_clip, float max_clip, int batch, long long nvox, int channels, int nb_bins,
+                                    const float *grad_joint, const float *grad_sum_x, const float *grad_sum_y, float *grad_x,
+                                    float *grad_y, void *stream) {
+    if (!x || !y || !centers_x || !centers_y || !grad_joint || !grad_sum_x || !grad_sum_y || (!grad_x && !grad_y)) return NRT_ERR_INVALID_ARG;
+    if (batch < 1 || nvox < 0 || channels < 1 || nb_bins < 1) return NRT_ERR_INVALID_ARG;
+    if (nb_bins > 32 || (long long)batch * channels > 65535) return NRT_ERR_UNSUPPORTED;
+    if (nvox == 0) return NRT_OK;
+    MiArgs a;
+    a.x = x; a.y = y; a.cx = centers_x; a.cy = centers_y; a.alpha = alpha; a.lo = min_clip; a.hi = max_clip;
+    a.V = nvox; a.C = channels; a.nb = nb_bins; a.items = batch * channels; a.joint = nullptr; a.sx = nullptr; a.sy = nullptr;
+    const size_t shm = (size_t)(nb_bins * nb_bins + 4 * nb_bins) * sizeof(float);
+    hipLaunchKernelGGL(mi_joint_bwd, dim3(mblocks(nvox, 256), (unsigned)a.items), dim3(256), shm, nrt_stream(stream), a, grad_joint,
+                       grad_sum_x, grad_sum_y, grad_x, grad_y);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_soft_quantize_f32(const float *x, const float *centers, float alpha, float min_clip, float max_clip,
+                                     int return_log, float *out, long long n, int nb_bins, void *stream) {
+    if (!x || !centers || !out || n < 0 || nb_bins < 1) return NRT_ERR_INVALID_ARG;
+    if (n == 0) return NRT_OK;
+    hipLaunchKernelGGL(soft_quantize, dim3(mblocks(n * nb_bins, 256)), dim3(256), 0, nrt_stream(stream), x, centers, alpha, min_clip,
+                       max_clip, return_log, out, n, nb_bins);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_colsum_f32(const float *x, int items, long long rows, int cols, float *out, void *stream) {
+    if (!x || !out || items < 1 || items > 65535 || rows < 0 || cols < 1 || cols > 4096) return NRT_ERR_INVALID_ARG;
+    if (rows == 0) return NRT_OK;
+    hipLaunchKernelGGL(colsum, dim3(mblocks(rows * cols, 256 * 32), (unsigned)items), dim3(256), (size_t)cols * sizeof(float),
+                       nrt_stream(stream), x, rows, cols, out);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

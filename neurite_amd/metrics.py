@@ -20,7 +20,7 @@ from . import utils
 from .errors import InvalidArgumentError
 
 __all__ = ['Dice', 'SoftDice', 'HardDice', 'CategoricalCrossentropy', 'WeightedCategoricalCrossentropy',
-           'dice_partial_sums']
+           'dice_partial_sums', 'MutualInformation']
 
 _INT_DTYPES = (torch.int8, torch.uint8, torch.int16, torch.int32, torch.int64, torch.bool)
 
@@ -359,3 +359,175 @@ class CategoricalCrossentropy:
 
 
 WeightedCategoricalCrossentropy = CategoricalCrossentropy
+
+
+# --------------------------------------------------------------------------------------
+# MutualInformation (neurite/tf/metrics.py:41-336)
+# --------------------------------------------------------------------------------------
+
+def _mi_from_joint(joint, sx, sy, eps=1e-7):
+    """metrics.py:262-281 on the [items, B, B] joint histogram and the [items, B] marginal sums (tiny tensors: glue;
+    differentiable, so autograd supplies d mi / d joint for the backward kernel)."""
+    pxy = joint / (joint.sum((1, 2), keepdim=True) + eps)
+    px = sx / (sx.sum(1, keepdim=True) + eps)
+    py = sy / (sy.sum(1, keepdim=True) + eps)
+    pxpy = px[:, :, None] * py[:, None, :] + eps
+    return (pxy * torch.log(pxy / pxpy + eps)).sum((1, 2))
+
+
+class _MiJointFn(torch.autograd.Function):
+    """joint soft histogram + marginals of two images [B, V, C] (csrc/mi.hip); backward wrt both images."""
+
+    @staticmethod
+    def forward(ctx, x, y, cx, cy, alpha, lo, hi):
+        lib = _lib.lib()
+        dev = x.device
+        B, V, C = x.shape
+        nb = cx.numel()
+        joint = torch.zeros((B * C, nb, nb), dtype=torch.float32, device=dev)
+        sx = torch.zeros((B * C, nb), dtype=torch.float32, device=dev)
+        sy = torch.zeros((B * C, nb), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_mi_joint_f32(_lib.ptr(x), _lib.ptr(y), _lib.ptr(cx), _lib.ptr(cy), float(alpha), float(lo), float(hi),
+                                      B, V, C, nb, _lib.ptr(joint), _lib.ptr(sx), _lib.ptr(sy), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_mi_joint_f32')
+        ctx.save_for_backward(x, y, cx, cy)
+        ctx.cfg = (float(alpha), float(lo), float(hi))
+        return joint, sx, sy
+
+    @staticmethod
+    def backward(ctx, gj, gsx, gsy):
+        x, y, cx, cy = ctx.saved_tensors
+        alpha, lo, hi = ctx.cfg
+        lib = _lib.lib()
+        dev = x.device
+        B, V, C = x.shape
+        nb = cx.numel()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if gx is None and gy is None:
+            return None, None, None, None, None, None, None
+        gj = torch.zeros((B * C, nb, nb), dtype=torch.float32, device=dev) if gj is None else gj.contiguous()
+        gsx = torch.zeros((B * C, nb), dtype=torch.float32, device=dev) if gsx is None else gsx.contiguous()
+        gsy = torch.zeros((B * C, nb), dtype=torch.float32, device=dev) if gsy is None else gsy.contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.nrt_mi_joint_bwd_f32(_lib.ptr(x), _lib.ptr(y), _lib.ptr(cx), _lib.ptr(cy), alpha, lo, hi, B, V, C, nb,
+                                          _lib.ptr(gj), _lib.ptr(gsx), _lib.ptr(gsy), _lib.ptr(gx), _lib.ptr(gy),
+                                          _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_mi_joint_bwd_f32')
+        return gx, gy, None, None, None, None, None
+
+
+class MutualInformation:
+    """
+    Soft mutual information for intensity volumes and probabilistic volumes (neurite/tf/metrics.py:41-336):
+    `volumes`, `segs`, `volume_seg`, `channelwise`, `maps`.  Same constructor arguments and defaults; like the reference
+    the constructor prints soft_bin_alpha when it derives it.  The image paths (`volumes`, `channelwise`) never build the
+    [V, nb_bins] soft maps: csrc/mi.hip forms the bin weights in registers and contracts them on the matrix cores; they
+    are differentiable wrt both images (bin centres held constant).  nb_bins <= 32 on those paths.
+    """
+
+    def __init__(self, bin_centers=None, nb_bins=None, soft_bin_alpha=None, min_clip=None, max_clip=None):
+        self.bin_centers = None
+        if bin_centers is not None:
+            self.bin_centers = torch.as_tensor(np.asarray(bin_centers, dtype=np.float32))
+            assert nb_bins is None, 'cannot provide both bin_centers and nb_bins'
+            nb_bins = self.bin_centers.shape[0]
+        self.nb_bins = nb_bins
+        if bin_centers is None and nb_bins is None:
+            self.nb_bins = 16
+        self.min_clip = -np.inf if min_clip is None else min_clip
+        self.max_clip = np.inf if max_clip is None else max_clip
+        self.soft_bin_alpha = soft_bin_alpha
+        if self.soft_bin_alpha is None:
+            sigma_ratio = 0.5
+            if self.bin_centers is None:
+                sigma = np.float32(sigma_ratio / (self.nb_bins - 1))
+            else:
+                sigma = np.float32(sigma_ratio * float(np.mean(np.diff(self.bin_centers.numpy()))))
+            self.soft_bin_alpha = float(np.float32(1) / (np.float32(2) * np.square(sigma)))       # tf.square works in float32
+            print(self.soft_bin_alpha)
+
+    # the reference passes both bin_centers and nb_bins to soft_quantize, which asserts (utils.py:1143); here given centres work
+    def _centers(self, t):
+        return utils._bin_centers(t, self.bin_centers, None if self.bin_centers is not None else self.nb_bins)
+
+    def _soft_sim_map(self, x):
+        return utils.soft_quantize(x, bin_centers=self.bin_centers, nb_bins=None if self.bin_centers is not None else self.nb_bins,
+                                   alpha=self.soft_bin_alpha, min_clip=self.min_clip, max_clip=self.max_clip, return_log=False)
+
+    def _soft_log_sim_map(self, x):
+        return utils.soft_quantize(x, bin_centers=self.bin_centers, nb_bins=None if self.bin_centers is not None else self.nb_bins,
+                                   alpha=self.soft_bin_alpha, min_clip=self.min_clip, max_clip=self.max_clip, return_log=True)
+
+    def volumes(self, x, y):
+        """MI for each item of a batch of single-channel volumes [bs, ..., 1] -> [bs]."""
+        msg = 'volume_mi requires two single-channel volumes. See channelwise().'
+        if x.shape[-1] != 1 or y.shape[-1] != 1:
+            raise InvalidArgumentError(msg)
+        return self.channelwise(x, y).reshape(-1)
+
+    def segs(self, x, y):
+        """MI between two probabilistic segmentation maps [bs, ..., nb_labels] -> [bs]."""
+        return self.maps(x, y)
+
+    def volume_seg(self, x, y):
+        """MI between a volume [bs, ..., 1] and a probabilistic segmentation [bs, ..., nb_labels] (either order) -> [bs]."""
+        cx_, cy_ = x.shape[-1], y.shape[-1]
+        if min(cx_, cy_) != 1:
+            raise InvalidArgumentError('volume_seg_mi requires one single-channel volume.')
+        if not max(cx_, cy_) > 1:
+            raise InvalidArgumentError('volume_seg_mi requires one multi-channel segmentation.')
+        if cx_ == 1:
+            x = self._soft_sim_map(x[..., 0])
+        else:
+            y = self._soft_sim_map(y[..., 0])
+        return self.maps(x, y)
+
+    def channelwise(self, x, y):
+        """MI for each channel of x and y [bs, ..., C] -> [bs, C] (bins spread between the extrema of each whole tensor)."""
+        _lib.require_device(x, y)
+        if tuple(x.shape) != tuple(y.shape):
+            raise InvalidArgumentError('volume shapes do not match')
+        if x.dtype != torch.float32 or y.dtype != torch.float32:
+            raise NotImplementedError('MutualInformation: float32 tensors')
+        nb = self.nb_bins
+        if nb > 32:
+            raise NotImplementedError('MutualInformation on images: nb_bins <= 32 on the HIP path, got %d' % nb)
+        bs, C = x.shape[0], x.shape[-1]
+        xf = x.reshape(bs, -1, C).contiguous()
+        yf = y.reshape(bs, -1, C).contiguous()
+        cx, cy = self._centers(xf.detach()), self._centers(yf.detach())
+        joint, sx, sy = _MiJointFn.apply(xf, yf, cx, cy, self.soft_bin_alpha, self.min_clip, self.max_clip)
+        return _mi_from_joint(joint, sx, sy).reshape(bs, C)
+
+    def maps(self, x, y):
+        """MI per batch entry of two probability / similarity maps [bs, ..., B] -> [bs]."""
+        lib = _lib.lib()
+        dev = _lib.require_device(x, y)
+        if tuple(x.shape) != tuple(y.shape):
+            raise InvalidArgumentError('')                                              # tf.debugging.assert_equal :249
+        if x.dtype != torch.float32 or y.dtype != torch.float32:
+            raise NotImplementedError('MutualInformation: float32 tensors')
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+            raise NotImplementedError('neurite_amd: backward of MutualInformation.maps is not implemented (use volumes/channelwise)')
+        bs, Bn = x.shape[0], x.shape[-1]
+        xf = x.reshape(bs, -1, Bn).contiguous()
+        yf = y.reshape(bs, -1, Bn).contiguous()
+        V = xf.shape[1]
+        mm = torch.stack([utils._device_minmax(xf), utils._device_minmax(yf)])
+        if not bool((mm[:, 0] >= 0).all()):                                             # assert_non_negative :250-251
+            raise InvalidArgumentError('')
+        joint = torch.zeros((bs, Bn, Bn), dtype=torch.float32, device=dev)
+        sx = torch.zeros((bs, Bn), dtype=torch.float32, device=dev)
+        sy = torch.zeros((bs, Bn), dtype=torch.float32, device=dev)
+        # joint[b] = x[b]^T y[b]: the 1x1x1 case of the conv weight-gradient contraction (MFMA over voxels); its bias output is sum_v y
+        shape = [V // 32, 4, 8] if V % 32 == 0 else [V, 1, 1]
+        with torch.cuda.device(dev):
+            for b in range(bs):
+                rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xf[b]), _lib.ptr(yf[b]), _lib.ptr(joint[b]), _lib.ptr(sy[b]), 1,
+                                              _lib.ints(shape), Bn, Bn, _lib.ints([1, 1, 1]), 1, _lib.stream_ptr(dev))
+                _lib.check(rc, 'nrt_conv3d_wgrad_f32')
+            rc = lib.nrt_colsum_f32(_lib.ptr(xf), bs, V, Bn, _lib.ptr(sx), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_colsum_f32')
+        return _mi_from_joint(joint, sx, sy)

@@ -20,7 +20,7 @@ import torch
 from . import _lib
 
 __all__ = ['interpn', 'resize', 'zoom', 'transform', 'affine_to_dense_shift', 'integrate_vec', 'compose',
-           'gaussian_kernel', 'separable_conv', 'minmax_norm',
+           'gaussian_kernel', 'separable_conv', 'minmax_norm', 'soft_quantize',
            'rescale_dense_transform', 'rescale_affine', 'is_affine_shape', 'validate_affine_shape', 'make_square_affine', 'volshape_to_ndgrid',
            'volshape_to_meshgrid', 'ndgrid', 'meshgrid', 'sub2ind2d', 'prod_n', 'batch_channel_flatten',
            'flatten_batch_channel', 'flatten_axes']
@@ -607,6 +607,58 @@ def minmax_norm(x, axis=None):
         rc = lib.nrt_minmax_norm_f32(_lib.ptr(x), _lib.ptr(y), outer, red, inner, _lib.ptr(ws), nws, _lib.stream_ptr(dev))
     _lib.check(rc, 'nrt_minmax_norm_f32')
     return y
+
+
+def _device_minmax(x):
+    """[min, max] of a float32 tensor as a 2-element device tensor (csrc/filter.hip; no host synchronisation)."""
+    lib = _lib.lib()
+    dev = x.device
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    ws = torch.empty((16,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_minmax_f32(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.ptr(ws), 16, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_minmax_f32')
+    return out
+
+
+def _bin_centers(x, bin_centers, nb_bins):
+    """bin centres of soft_quantize as a float32 device tensor: given, or tf.linspace(min(x), max(x), nb_bins) (:1152-1154)."""
+    dev = x.device
+    if bin_centers is not None:
+        assert nb_bins is None, 'cannot provide both bin_centers and nb_bins'
+        return torch.as_tensor(bin_centers, dtype=torch.float32).reshape(-1).to(dev).contiguous()
+    if nb_bins is None:
+        nb_bins = 16
+    mm = _device_minmax(x)
+    if nb_bins == 1:
+        return mm[:1].clone()
+    delta = (mm[1] - mm[0]) / float(nb_bins - 1)
+    c = mm[0] + delta * torch.arange(nb_bins, dtype=torch.float32, device=dev)      # nb_bins numbers: glue
+    c[0] = mm[0]
+    c[-1] = mm[1]                                                                  # tf.linspace ends exactly on `stop`
+    return c.contiguous()
+
+
+def soft_quantize(x, bin_centers=None, nb_bins=16, alpha=1, min_clip=-np.inf, max_clip=np.inf, return_log=False):
+    """
+    (Softly) quantise the values of a tensor with RBFs (utils.py:1099-1172): value v gets weight exp(-alpha (v - c)^2) for
+    every bin centre c.  Returns a tensor with one more dimension [..., B].  Specify bin_centers OR nb_bins (centres are then
+    spread between the extrema of x).
+    """
+    lib = _lib.lib()
+    dev = _lib.require_device(x)
+    if x.dtype != torch.float32:
+        raise NotImplementedError('soft_quantize: float32 tensors, got %s' % x.dtype)
+    x = x.contiguous()
+    centers = _bin_centers(x, bin_centers, nb_bins)
+    nb = centers.numel()
+    out = torch.empty(tuple(x.shape) + (nb,), dtype=torch.float32, device=dev)
+    if x.numel():
+        with torch.cuda.device(dev):
+            rc = lib.nrt_soft_quantize_f32(_lib.ptr(x), _lib.ptr(centers), float(alpha), float(min_clip), float(max_clip),
+                                           int(bool(return_log)), _lib.ptr(out), x.numel(), nb, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_soft_quantize_f32')
+    return out
 
 
 # --------------------------------------------------------------------------------------

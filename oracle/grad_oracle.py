@@ -107,3 +107,21 @@ def lc3d(x, kernel, bias=None, kernel_size=(3, 3, 3), strides=(1, 1, 1), activat
     elif activation == 'relu':
         y = torch.relu(y)
     return y
+
+
+def mi_channelwise(x, y, cx, cy, alpha, min_clip=float('-inf'), max_clip=float('inf'), eps=1e-7):
+    """MutualInformation.channelwise (neurite/tf/metrics.py:188-282) with GIVEN bin centres cx, cy [nb] (held constant, as the
+    HIP backward does): x, y [bs, ..., C] -> [bs, C]."""
+    bs, C = x.shape[0], x.shape[-1]
+    xf = torch.clamp(x.reshape(bs, -1, C), min_clip, max_clip)
+    yf = torch.clamp(y.reshape(bs, -1, C), min_clip, max_clip)
+    wx = torch.exp(-alpha * (xf[..., None] - cx) ** 2)             # [bs, V, C, nb]
+    wy = torch.exp(-alpha * (yf[..., None] - cy) ** 2)
+    joint = torch.einsum('bvci,bvcj->bcij', wx, wy)
+    pxy = joint / (joint.sum((2, 3), keepdim=True) + eps)
+    px = wx.sum(1)
+    px = px / (px.sum(-1, keepdim=True) + eps)
+    py = wy.sum(1)
+    py = py / (py.sum(-1, keepdim=True) + eps)
+    pxpy = px[..., :, None] * py[..., None, :] + eps
+    return (pxy * torch.log(pxy / pxpy + eps)).sum((2, 3))

@@ -640,3 +640,81 @@ def minmax_norm(x, axis=None):
     mn = x.min(axis=axis, keepdims=True)
     mx = x.max(axis=axis, keepdims=True)
     return divide_no_nan(x - mn, mx - mn)
+
+
+# --------------------------------------------------------------------------------------
+# soft quantisation and mutual information (neurite/tf/utils/utils.py:1099-1172, neurite/tf/metrics.py:41-336)
+# --------------------------------------------------------------------------------------
+
+def soft_quantize(x, bin_centers=None, nb_bins=16, alpha=1, min_clip=-np.inf, max_clip=np.inf, return_log=False):
+    """utils.py:1099-1172: weight exp(-alpha (v - c_b)^2) of every value for every bin, float32 like the reference."""
+    x = np.asarray(x, F32)
+    if bin_centers is not None:
+        bin_centers = np.asarray(bin_centers, F32)
+        assert nb_bins is None, 'cannot provide both bin_centers and nb_bins'
+    else:
+        if nb_bins is None:
+            nb_bins = 16
+        bin_centers = tf_linspace(x.min(), x.max(), nb_bins)                # :1152-1154
+    xc = np.clip(x[..., None], F32(min_clip), F32(max_clip))                # :1157-1158
+    log = (-F32(alpha) * np.square(xc - bin_centers)).astype(F32)           # :1166-1167
+    return log if return_log else np.exp(log).astype(F32)
+
+
+def mi_default_alpha(nb_bins=16):
+    """metrics.py:111-118: alpha = 1 / (2 sigma^2), sigma = 0.5 / (nb_bins - 1), evaluated in float32 as tf.square does."""
+    sigma = 0.5 / (nb_bins - 1)
+    return F32(1) / (F32(2) * np.square(F32(sigma)))
+
+
+def mi_maps(x, y, eps=1e-7):
+    """metrics.py:228-282: MI per batch entry of two maps [bs, ..., B] (float64 accumulation)."""
+    x = np.asarray(x)
+    y = np.asarray(y)
+    if x.shape != y.shape:
+        raise ValueError('maps: shapes differ')                              # tf.debugging.assert_equal :249
+    if (x < 0).any() or (y < 0).any():
+        raise ValueError('maps: negative values')                            # :250-251
+    bs, B = x.shape[0], x.shape[-1]
+    xf = x.reshape(bs, -1, B).astype(np.float64)
+    yf = y.reshape(bs, -1, B).astype(np.float64)
+    pxy = np.einsum('bvi,bvj->bij', xf, yf)
+    pxy = pxy / (pxy.sum((1, 2), keepdims=True) + eps)
+    px = xf.sum(1, keepdims=True)
+    px = px / (px.sum(2, keepdims=True) + eps)
+    py = yf.sum(1, keepdims=True)
+    py = py / (py.sum(2, keepdims=True) + eps)
+    pxpy = np.einsum('bki,bkj->bij', px, py) + eps
+    return (pxy * np.log(pxy / pxpy + eps)).sum((1, 2)).astype(F32)
+
+
+def mi_channelwise(x, y, nb_bins=16, alpha=None, min_clip=-np.inf, max_clip=np.inf):
+    """metrics.py:188-226: bins are placed between the extrema of the WHOLE tensor (all channels and batch entries)."""
+    x = np.asarray(x, F32)
+    y = np.asarray(y, F32)
+    assert x.shape == y.shape, 'volume shapes do not match'
+    alpha = mi_default_alpha(nb_bins) if alpha is None else alpha
+    bs, C = x.shape[0], x.shape[-1]
+    xq = soft_quantize(x.reshape(bs, -1, C), None, nb_bins, alpha, min_clip, max_clip)     # [bs, V, C, B]
+    yq = soft_quantize(y.reshape(bs, -1, C), None, nb_bins, alpha, min_clip, max_clip)
+    return np.stack([mi_maps(xq[:, :, c], yq[:, :, c]) for c in range(C)], 1)
+
+
+def mi_volumes(x, y, **kw):
+    """metrics.py:119-142."""
+    assert np.asarray(x).shape[-1] == 1 and np.asarray(y).shape[-1] == 1, 'volume_mi requires two single-channel volumes. See channelwise().'
+    return mi_channelwise(x, y, **kw).reshape(-1)
+
+
+def mi_volume_seg(x, y, nb_bins=16, alpha=None, min_clip=-np.inf, max_clip=np.inf):
+    """metrics.py:156-186."""
+    x = np.asarray(x, F32)
+    y = np.asarray(y, F32)
+    alpha = mi_default_alpha(nb_bins) if alpha is None else alpha
+    assert min(x.shape[-1], y.shape[-1]) == 1, 'volume_seg_mi requires one single-channel volume.'
+    assert max(x.shape[-1], y.shape[-1]) > 1, 'volume_seg_mi requires one multi-channel segmentation.'
+    if x.shape[-1] == 1:
+        x = soft_quantize(x[..., 0], None, nb_bins, alpha, min_clip, max_clip)
+    else:
+        y = soft_quantize(y[..., 0], None, nb_bins, alpha, min_clip, max_clip)
+    return mi_maps(x, y)

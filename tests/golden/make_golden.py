@@ -312,7 +312,43 @@ def gen_filter():
     save('filter_small', **cases)
 
 
+def gen_mi():
+    """metrics.MutualInformation (metrics.py:41-336) and utils.soft_quantize (utils.py:1099-1172)."""
+    import contextlib, io
+    rng = np.random.default_rng(13)
+    cases = {}
+    x = rng.random((2, 6, 5, 7, 1)).astype(F)
+    y = (0.7 * x + 0.3 * rng.random(x.shape)).astype(F)
+    p3 = rng.random((2, 6, 5, 7, 3)).astype(F)
+    q3 = (0.5 * p3 + 0.5 * rng.random(p3.shape)).astype(F)
+    p16 = rng.random((2, 6, 5, 7, 16)).astype(F)
+    p16 /= p16.sum(-1, keepdims=True)
+    q16 = rng.random((2, 6, 5, 7, 16)).astype(F)
+    q16 /= q16.sum(-1, keepdims=True)
+    cases.update(x=x, y=y, p3=p3, q3=q3, p16=p16, q16=q16)
+    with contextlib.redirect_stdout(io.StringIO()):                       # the constructor prints soft_bin_alpha
+        mi16 = ne.metrics.MutualInformation()
+        mi8 = ne.metrics.MutualInformation(nb_bins=8, min_clip=0.1, max_clip=0.9)
+        mia = ne.metrics.MutualInformation(nb_bins=16, soft_bin_alpha=50.0)
+    cases['alpha16'] = A(mi16.soft_bin_alpha).astype(F)
+    cases['volumes16__out'] = A(mi16.volumes(T(x), T(y)))
+    cases['volumes8clip__out'] = A(mi8.volumes(T(x), T(y)))
+    cases['volumes_alpha50__out'] = A(mia.volumes(T(x), T(y)))
+    cases['channelwise__out'] = A(mi16.channelwise(T(p3), T(q3)))
+    cases['segs__out'] = A(mi16.segs(T(p16), T(q16)))
+    cases['maps_self__out'] = A(mi16.maps(T(p16), T(p16)))
+    cases['volume_seg__out'] = A(mi16.volume_seg(T(x), T(p16)))
+    cases['seg_volume__out'] = A(mi16.volume_seg(T(p16), T(y)))
+    small = rng.random((3, 4)).astype(F)
+    cases['sq_in'] = small
+    cases['sq_nb5__out'] = A(ne.utils.soft_quantize(T(small), nb_bins=5, alpha=3.0))
+    cases['sq_centers__out'] = A(ne.utils.soft_quantize(T(small), bin_centers=np.array([0.1, 0.5, 0.9], F), nb_bins=None, alpha=2.0))
+    cases['sq_log_clip__out'] = A(ne.utils.soft_quantize(T(small), nb_bins=4, alpha=1.5, min_clip=0.2, max_clip=0.8, return_log=True))
+    save('mi_small', **cases)
+
+
 if __name__ == '__main__':
+    gen_mi()
     gen_filter()
     gen_interpn()
     gen_resize()

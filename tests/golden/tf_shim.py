@@ -161,6 +161,9 @@ class Tensor:
     def __le__(self, o): return self._bin(o, np.less_equal)
     def __gt__(self, o): return self._bin(o, np.greater)
     def __ge__(self, o): return self._bin(o, np.greater_equal)
+    def __eq__(self, o): return bool(np.all(self.a == A(o)))          # eager tensors compare by value (used in `if t == 1`)
+    def __ne__(self, o): return not self.__eq__(o)
+    __hash__ = object.__hash__
 
 
 def T(x, dtype=None):
@@ -218,7 +221,7 @@ def floor(x): return Tensor(np.floor(A(x)))
 def round_(x): return Tensor(np.rint(A(x)))                 # half-to-even
 def exp(x): return Tensor(np.exp(A(x)))
 def log(x): return Tensor(np.log(A(x)))
-def square(x): return Tensor(np.square(A(x)))
+def square(x): return Tensor(np.square(np.float32(x) if isinstance(x, (float, int)) else A(x)))     # python scalars become float32
 def less(x, y): return T(x) < y
 def greater(x, y): return T(x) > y
 def logical_not(x): return Tensor(np.logical_not(A(x)))
@@ -251,6 +254,7 @@ def reduce_any(x, axis=None, keepdims=False):
 
 def reduce_sum(x, axis=None, keepdims=False):
     a = A(x)
+    axis = tuple(axis) if isinstance(axis, list) else axis
     return Tensor(np.sum(a.astype(np.float64), axis=axis, keepdims=keepdims).astype(a.dtype))
 
 
@@ -337,6 +341,7 @@ def k_epsilon(): return 1e-7
 def k_sum(x, axis=None, keepdims=False):
     # TF's reduction order is unspecified; accumulate wide and round once
     a = A(x)
+    axis = tuple(axis) if isinstance(axis, list) else axis
     return Tensor(np.sum(a.astype(np.float64), axis=axis, keepdims=keepdims).astype(a.dtype))
 
 
@@ -547,6 +552,8 @@ def _populate(m):
             int64=DType(np.int64), bool=DType(np.bool_), float16=DType(np.float16),
             expand_dims=lambda x, axis: k_expand_dims(x, axis),
             shape=shape_, transpose=transpose_, reduce_prod=reduce_prod, reduce_min=reduce_min, reduce_max=reduce_max,
+            newaxis=None, minimum=lambda a, b: Tensor(np.minimum(A(a), A(b))), maximum=lambda a, b: Tensor(np.maximum(A(a), A(b))),
+            reduce_mean=lambda x, axis=None, keepdims=False: Tensor(np.mean(A(x), axis=axis, keepdims=keepdims)),
         )
         for k, v in d.items():
             setattr(m, k, v)
@@ -559,6 +566,9 @@ def _populate(m):
         m.assert_greater_equal = assert_greater_equal
         m.assert_less_equal = assert_less_equal
         m.assert_all_finite = assert_all_finite
+        m.assert_equal = lambda x, y, message='', **kw: _assert(np.all(A(x) == A(y)), message)
+        m.assert_non_negative = lambda x, message='', **kw: _assert(np.all(A(x) >= 0), message)
+        m.assert_greater = lambda x, y, message='', **kw: _assert(np.all(A(x) > A(y)), message)
     if n == 'tensorflow.errors':
         m.InvalidArgumentError = InvalidArgumentError
     if n == 'tensorflow.compat.v1':
@@ -566,6 +576,8 @@ def _populate(m):
         m.div_no_nan = divide_no_nan
     if n == 'tensorflow.nn':
         m.convolution = nn_convolution
+    if n == 'tensorflow.experimental.numpy':
+        m.diff = lambda x, **kw: Tensor(np.diff(A(x)))
     if n == 'tensorflow.dtypes':
         m.as_dtype = lambda d: d if isinstance(d, DType) else DType(d)
     if n == 'tensorflow.keras.backend':
@@ -573,7 +585,10 @@ def _populate(m):
                  mean=k_mean, square=k_square, argmax=k_argmax, one_hot=k_one_hot, reshape=reshape,
                  concatenate=k_concatenate, permute_dimensions=k_permute_dimensions, batch_dot=k_batch_dot,
                  bias_add=k_bias_add, epsilon=k_epsilon, floor=floor, exp=exp, log=log,
-                 cast=cast, stack=stack, clip=clip_by_value)
+                 cast=cast, stack=stack, clip=clip_by_value,
+                 min=lambda x, axis=None, keepdims=False: Tensor(np.min(A(x), axis=axis, keepdims=keepdims)),
+                 max=lambda x, axis=None, keepdims=False: Tensor(np.max(A(x), axis=axis, keepdims=keepdims)),
+                 flatten=lambda x: Tensor(A(x).reshape(-1)))
         for k, v in d.items():
             setattr(m, k, v)
     if n == 'tensorflow.keras.layers':
@@ -594,7 +609,7 @@ def install():
                  'tensorflow.keras.backend', 'tensorflow.keras.layers', 'tensorflow.keras.losses',
                  'tensorflow.keras.models', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
                  'tensorflow.python', 'tensorflow.python.keras', 'tensorflow.python.keras.utils',
-                 'tensorflow.python.ops', 'tensorflow.nn', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
+                 'tensorflow.python.ops', 'tensorflow.nn', 'tensorflow.experimental', 'tensorflow.experimental.numpy', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
         mod = importlib.import_module(name)
         if '.' in name:
             parent, child = name.rsplit('.', 1)

@@ -1,0 +1,120 @@
+"""
+GPU parity tests of soft_quantize / MutualInformation (csrc/mi.hip) against the golden vectors produced by the reference's
+own source (tests/golden/mi_small.npz), the oracle at larger sizes, and the float64 autograd oracle for the gradients.
+"""
+
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import neurite_amd as ne
+from conftest import load_golden
+from neurite_amd.errors import InvalidArgumentError
+from oracle import grad_oracle as go
+from oracle import np_oracle as npo
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+R = dict(rtol=5e-5, atol=5e-6)
+
+
+def G(a, dev, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.requires_grad_() if grad else t
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def MI(**kw):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return ne.metrics.MutualInformation(**kw)
+
+
+def test_mi_golden(dev):
+    g = load_golden('mi_small')
+    x, y, p3, q3, p16, q16 = [G(g[k], dev) for k in ('x', 'y', 'p3', 'q3', 'p16', 'q16')]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mi16 = ne.metrics.MutualInformation()
+    assert np.isclose(mi16.soft_bin_alpha, g['alpha16'], rtol=1e-6) and buf.getvalue().strip() != ''     # the reference prints alpha
+    np.testing.assert_allclose(N(mi16.volumes(x, y)), g['volumes16__out'], **R)
+    np.testing.assert_allclose(N(MI(nb_bins=8, min_clip=0.1, max_clip=0.9).volumes(x, y)), g['volumes8clip__out'], **R)
+    np.testing.assert_allclose(N(MI(nb_bins=16, soft_bin_alpha=50.0).volumes(x, y)), g['volumes_alpha50__out'], **R)
+    np.testing.assert_allclose(N(mi16.channelwise(p3, q3)), g['channelwise__out'], **R)
+    np.testing.assert_allclose(N(mi16.segs(p16, q16)), g['segs__out'], **R)
+    np.testing.assert_allclose(N(mi16.maps(p16, p16)), g['maps_self__out'], **R)
+    np.testing.assert_allclose(N(mi16.volume_seg(x, p16)), g['volume_seg__out'], **R)
+    np.testing.assert_allclose(N(mi16.volume_seg(p16, y)), g['seg_volume__out'], **R)
+    s = G(g['sq_in'], dev)
+    np.testing.assert_allclose(N(ne.utils.soft_quantize(s, nb_bins=5, alpha=3.0)), g['sq_nb5__out'], rtol=2e-6)
+    np.testing.assert_allclose(N(ne.utils.soft_quantize(s, bin_centers=np.array([0.1, 0.5, 0.9], F), nb_bins=None, alpha=2.0)),
+                               g['sq_centers__out'], rtol=2e-6)
+    np.testing.assert_allclose(N(ne.utils.soft_quantize(s, nb_bins=4, alpha=1.5, min_clip=0.2, max_clip=0.8, return_log=True)),
+                               g['sq_log_clip__out'], rtol=2e-6, atol=1e-7)
+    # error behaviour
+    with pytest.raises(InvalidArgumentError):
+        mi16.volumes(p3, q3)
+    with pytest.raises(InvalidArgumentError):
+        mi16.maps(p16, q16[..., :8])
+    with pytest.raises(InvalidArgumentError):
+        mi16.maps(p16 - 1.0, q16)
+    with pytest.raises(InvalidArgumentError):
+        mi16.volume_seg(x, y)
+    with pytest.raises(AssertionError):
+        ne.utils.soft_quantize(s, bin_centers=[0.1, 0.5], nb_bins=3)
+    with pytest.raises(AssertionError):
+        ne.metrics.MutualInformation(bin_centers=np.array([0., 1.], F), nb_bins=2)
+
+
+def test_mi_larger_vs_oracle(dev):
+    rng = np.random.default_rng(17)
+    x = rng.random((2, 33, 30, 35, 1)).astype(F)
+    y = (np.sin(3 * x) + 0.2 * rng.standard_normal(x.shape)).astype(F)
+    for nb in (16, 24, 32, 5):
+        got = N(MI(nb_bins=nb).volumes(G(x, dev), G(y, dev)))
+        np.testing.assert_allclose(got, npo.mi_volumes(x, y, nb_bins=nb), rtol=2e-4, atol=2e-5)
+    p = rng.random((2, 20, 16, 24, 3)).astype(F)
+    q = (0.6 * p + 0.4 * rng.random(p.shape)).astype(F)
+    np.testing.assert_allclose(N(MI(nb_bins=16).channelwise(G(p, dev), G(q, dev))), npo.mi_channelwise(p, q), rtol=2e-4, atol=2e-5)
+    # given bin centres (the reference's own constructor path asserts in soft_quantize; supported here)
+    cen = np.linspace(0, 1, 12).astype(F)
+    mi = MI(bin_centers=cen)
+    xq = npo.soft_quantize(x[..., 0], cen, None, mi.soft_bin_alpha)
+    yq = npo.soft_quantize(np.clip(y, 0, 1)[..., 0], cen, None, mi.soft_bin_alpha)
+    np.testing.assert_allclose(N(mi.volumes(G(x, dev), G(np.clip(y, 0, 1), dev))), npo.mi_maps(xq, yq), rtol=2e-4, atol=2e-5)
+    # probability maps with a voxel count that is not a multiple of 32 and an odd label count
+    pm = rng.random((2, 7, 9, 5, 11)).astype(F)
+    qm = rng.random((2, 7, 9, 5, 11)).astype(F)
+    np.testing.assert_allclose(N(MI().maps(G(pm, dev), G(qm, dev))), npo.mi_maps(pm, qm), rtol=2e-4, atol=2e-6)
+
+
+def test_mi_backward(dev):
+    """-MI as a registration loss: gradient wrt both images (bin centres constant) vs float64 autograd"""
+    rng = np.random.default_rng(23)
+    x = rng.random((2, 9, 8, 10, 2)).astype(F)
+    y = (0.5 * x + 0.5 * rng.random(x.shape)).astype(F)
+    for kw in (dict(nb_bins=16), dict(nb_bins=20, min_clip=0.15, max_clip=0.85)):
+        mi = MI(**kw)
+        xg, yg = G(x, dev, True), G(y, dev, True)
+        val = mi.channelwise(xg, yg)
+        w = rng.standard_normal(tuple(val.shape)).astype(F)
+        (-(val * G(w, dev)).sum()).backward()
+        nb = kw['nb_bins']
+        cx = torch.from_numpy(npo.tf_linspace(x.min(), x.max(), nb)).double()
+        cy = torch.from_numpy(npo.tf_linspace(y.min(), y.max(), nb)).double()
+        xo, yo = torch.from_numpy(x).double().requires_grad_(), torch.from_numpy(y).double().requires_grad_()
+        ref = go.mi_channelwise(xo, yo, cx, cy, float(mi.soft_bin_alpha), kw.get('min_clip', float('-inf')),
+                                kw.get('max_clip', float('inf')))
+        (-(ref * torch.from_numpy(w).double()).sum()).backward()
+        np.testing.assert_allclose(N(val), ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+        for got, want, nm in ((xg.grad, xo.grad, 'x'), (yg.grad, yo.grad, 'y')):
+            want = want.numpy()
+            err = np.abs(N(got) - want).max() / np.abs(want).max()
+            assert err < 2e-3, (nm, err)
+    with pytest.raises(NotImplementedError):
+        MI().maps(G(np.abs(x), dev, True), G(np.abs(y), dev))

@@ -46,3 +46,16 @@ nbytes = 3 * img.numel() * 4
 print(json.dumps({'op': 'minmax_norm per batch entry', 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
 ms = timeit(lambda: ne.augment.draw_perlin((S, S, S, 1), scales=(8, 16, 32), max_std=1.0, seed=1), n=5)
 print(json.dumps({'op': 'draw_perlin 160^3 scales (8,16,32)', 'ms': round(ms, 4)}))
+# mutual information of two images (registration loss), forward and forward + backward
+import contextlib, io
+with contextlib.redirect_stdout(io.StringIO()):
+    mi = ne.metrics.MutualInformation(nb_bins=16)
+ya = img * 0.7 + 0.3 * torch.randn_like(img)
+ms = timeit(lambda: mi.volumes(img, ya))
+print(json.dumps({'op': 'MutualInformation.volumes nb_bins=16', 'ms': round(ms, 4), 'GBs': round(2 * img.numel() * 4 / ms / 1e6, 1)}))
+xg = img.clone().requires_grad_()
+def mi_step():
+    xg.grad = None
+    (-mi.volumes(xg, ya).sum()).backward()
+ms = timeit(mi_step)
+print(json.dumps({'op': 'MutualInformation.volumes forward + backward', 'ms': round(ms, 4)}))
