@@ -334,6 +334,25 @@ int nrt_mi_joint_bwd_f32(const float *x, const float *y, const float *centers_x,
 int nrt_colsum_f32(const float *x, int items, long long rows, int cols, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Elementwise stages of the label-to-image synthesis model (neurite/tf/models.py:649-918); random numbers are inputs
+ *   nrt_synth_relabel_i32     out[i] = lut[labels[i]] (labels -> dense indices, :778-784)
+ *   nrt_synth_intensity_f32   labels, noise [B, V] (indices; one draw per voxel), out [B, V, C], mean/std [B, C, L], bg_zero [B, C] or NULL:
+ *                             out = noise * std[label] + mean[label], zeroed where label == 0 and bg_zero (:819-849)
+ *   nrt_synth_bias_clip_f32   out = clip(image * exp(bias), lo, hi); image [n, C], bias [n] or NULL (:860-874)
+ *   nrt_synth_gamma_dc_f32    out = image ^ exp(gamma[b, c]) + dc[b, c]; gamma / dc [B, C] or NULL (:877-888)
+ *   nrt_synth_labels_out      indices -> lut (int32 out) or its one-hot encoding [n, depth] (-1 = dropped label) (:890-918)
+ * ------------------------------------------------------------------------------------------ */
+int nrt_synth_relabel_i32(const int *labels, const float *lut, int lut_len, float *out, long long n, void *stream);
+int nrt_synth_intensity_f32(const float *labels, const float *noise, const float *mean, const float *stdv, const float *bg_zero,
+                            float *out, int batch, long long nvox, int channels, int nlabels, void *stream);
+int nrt_synth_bias_clip_f32(const float *image, const float *bias, float *out, long long n, int channels, float lo, float hi,
+                            void *stream);
+int nrt_synth_gamma_dc_f32(const float *image, const float *gamma, const float *dc, float *out, int batch, long long nvox,
+                           int channels, void *stream);
+int nrt_synth_labels_out(const float *idx, const int *lut, int lut_len, int depth, float *onehot, int *out_i32, long long n,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or
  * non-temporal; calibrates the achievable mixed read/write HBM rate next to the kernels above.
  * ------------------------------------------------------------------------------------------ */

@@ -25,6 +25,7 @@ from . import models  # noqa: F401
 from . import fused  # noqa: F401
 from . import distributed  # noqa: F401
 from . import augment  # noqa: F401
+from . import synthesis  # noqa: F401
 from . import synth  # noqa: F401
 
 backend = 'pytorch'

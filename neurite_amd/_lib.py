@@ -65,6 +65,11 @@ _SIGNATURES = {
     'nrt_mi_joint_f32': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _ll, _i, _i, _vp, _vp, _vp, _vp]),
     'nrt_mi_joint_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nrt_colsum_f32': (_i, [_vp, _i, _ll, _i, _vp, _vp]),
+    'nrt_synth_relabel_i32': (_i, [_vp, _vp, _i, _vp, _ll, _vp]),
+    'nrt_synth_intensity_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp]),
+    'nrt_synth_bias_clip_f32': (_i, [_vp, _vp, _vp, _ll, _i, _f, _f, _vp]),
+    'nrt_synth_gamma_dc_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
+    'nrt_synth_labels_out': (_i, [_vp, _vp, _i, _i, _vp, _vp, _ll, _vp]),
     'nrt_membench_l1_f32': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'nrt_membench_copy_f32': (_i, [_vp, _vp, _ll, _i, _i, _vp]),
     'nrt_wcce': (_i, [_vp, _vp, _i, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -718,3 +718,35 @@ def mi_volume_seg(x, y, nb_bins=16, alpha=None, min_clip=-np.inf, max_clip=np.in
     else:
         y = soft_quantize(y[..., 0], None, nb_bins, alpha, min_clip, max_clip)
     return mi_maps(x, y)
+
+
+# --------------------------------------------------------------------------------------
+# label-to-image synthesis, deterministic part given the random draws (neurite/tf/models.py:819-918)
+# --------------------------------------------------------------------------------------
+
+def synth_image(idx, noise, mean, std, bg_zero, blur_kernels, bias, normalize, gamma, dc):
+    """idx [B,*S,1] warped label indices (float), noise [B,*S], mean/std [B,C,L], bg_zero [B,C] or None, blur_kernels list of
+    1-D kernels or None, bias [B,*S,1] or None, gamma/dc [B,C] or None.  Returns the image [B,*S,C] (float32 semantics)."""
+    idx = np.asarray(idx)[..., 0].astype(np.int64)
+    B = idx.shape[0]
+    C = mean.shape[1]
+    nd = idx.ndim - 1
+    img = np.zeros(idx.shape + (C,), F32)
+    for b in range(B):
+        for c in range(C):
+            img[b, ..., c] = (noise[b] * std[b, c][idx[b]] + mean[b, c][idx[b]]).astype(F32)          # :831-839
+            if bg_zero is not None and bg_zero[b, c] != 0:
+                img[b, ..., c] = np.where(idx[b] == 0, F32(0), img[b, ..., c])                          # :842-849
+    if blur_kernels is not None:
+        img = separable_conv(img, list(blur_kernels), batched=True)                                    # :852-857
+    if bias is not None:
+        img = (img * np.exp(np.asarray(bias, F32))).astype(F32)                                        # :871
+    img = np.clip(img, 0, 255).astype(F32)                                                             # :874
+    if normalize:
+        img = np.stack([minmax_norm(img[b]) for b in range(B)], 0).astype(F32)                         # :875-876
+    sh = (B,) + (1,) * nd + (C,)
+    if gamma is not None:
+        img = np.power(img, np.exp(np.asarray(gamma, F32)).reshape(sh)).astype(F32)                    # :877-881
+    if dc is not None:
+        img = (img + np.asarray(dc, F32).reshape(sh)).astype(F32)                                      # :882-888
+    return img
