@@ -50,6 +50,36 @@ __global__ __launch_bounds__(256) void conv1d_axis(C1Args a) {
     }
 }
 
+// innermost-axis pass of single-channel tensors (inner == 1, stride == 1, dilation == 1): a thread produces 4 consecutive
+// outputs from W + 3 inputs instead of 4 W (same tap order per output => bit-identical to conv1d_axis<false>)
+__global__ __launch_bounds__(256) void conv1d_axis_run4(C1Args a) {
+    extern __shared__ float ks[];
+    for (int t = threadIdx.x; t < a.W; t += 256) ks[t] = a.k[t];
+    __syncthreads();
+    const long long nrun = (a.Aout + 3) / 4;
+    const long long total = a.outer * nrun;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long o = e / nrun;
+        const int a0 = (int)(e - o * nrun) * 4;
+        const float *xo = a.x + o * a.A;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < a.W + 3; ++t) {
+            const int ai = a0 - a.pad + t;
+            const float v = (ai >= 0 && ai < a.A) ? xo[ai] : 0.0f;
+            const bool inside = ai >= 0 && ai < a.A;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kt = t - r;
+                if (inside && kt >= 0 && kt < a.W) acc[r] = acc[r] + ks[kt] * v;
+            }
+        }
+        float *yo = a.y + o * a.Aout + a0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (a0 + r < a.Aout) yo[r] = acc[r];
+    }
+}
+
 __device__ __forceinline__ int f2key(float f) {
     const int b = __float_as_int(f);
     return b >= 0 ? b : b ^ 0x7fffffff;
@@ -130,7 +160,9 @@ extern "C" int nrt_conv1d_axis_f32(const float *x, const float *kernel, float *y
     a.dil = dilation; a.pad = pad_before; a.inner = inner;
     hipStream_t st = nrt_stream(stream);
     const bool vec = inner % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
-    if (vec) {
+    if (inner == 1 && stride == 1 && dilation == 1 && out_len >= 8 && width <= 1024) {
+        hipLaunchKernelGGL(conv1d_axis_run4, dim3(fblocks(outer * ((out_len + 3) / 4))), dim3(256), (size_t)width * sizeof(float), st, a);
+    } else if (vec) {
         a.inner = inner / 4;
         hipLaunchKernelGGL((conv1d_axis<true>), dim3(fblocks(outer * out_len * a.inner)), dim3(256), 0, st, a);
     } else {

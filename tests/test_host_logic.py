@@ -236,3 +236,23 @@ def test_convnet_weight_api_cpu(tmp_path):
         net.set_weights(new[:-1])
     with pytest.raises(ValueError, match='not compatible'):
         net.set_weights([new[1]] + new[1:])
+
+
+def test_gaussian_kernel_and_synthesis_tables_cpu():
+    """host-side pieces of the synthesis front-end: Gaussian kernels vs the reference's own output, label lookup tables"""
+    import warnings
+    import neurite_amd as ne
+    from conftest import load_golden
+    g = load_golden('filter_small')
+    for tag, kw in (('gk_iso3', dict(sigma=[1.5, 1.5, 1.5])), ('gk_aniso', dict(sigma=[0.7, 2.0])),
+                    ('gk_win', dict(sigma=[1.0, 2.0], windowsize=[5, 4])), ('gk_xy', dict(sigma=[1.0, 2.0], indexing='xy'))):
+        np.testing.assert_allclose(ne.utils.gaussian_kernel(**kw).numpy(), g[tag + '__joint'], rtol=2e-6, atol=1e-9)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = ne.models.labels_to_image((8, 8, 8), [0, 3, 3, 17, 5], out_label_list={3: 1, 17: 1, 5: 2})
+    c = m.cfg
+    assert c['num_in_labels'] == 4 and c['in_lut'][[0, 3, 5, 17]].tolist() == [0, 1, 2, 3]       # np.unique sorts: 0, 3, 5, 17
+    assert c['depth'] == 3 and c['out_lut'].tolist() == [0, 1, 2, 1]                                # one-hot over {0, 1, 2}
+    assert c['mean_min'] == [0, 25, 25, 25] and c['std_max'] == [25] * 4
+    with pytest.raises(NotImplementedError):
+        ne.models.labels_to_image((8, 8, 8), [0, 1], input_model=object())
