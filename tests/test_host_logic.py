@@ -252,7 +252,7 @@ def test_gaussian_kernel_and_synthesis_tables_cpu():
         m = ne.models.labels_to_image((8, 8, 8), [0, 3, 3, 17, 5], out_label_list={3: 1, 17: 1, 5: 2})
     c = m.cfg
     assert c['num_in_labels'] == 4 and c['in_lut'][[0, 3, 5, 17]].tolist() == [0, 1, 2, 3]       # np.unique sorts: 0, 3, 5, 17
-    assert c['depth'] == 3 and c['out_lut'].tolist() == [0, 1, 2, 1]                                # one-hot over {0, 1, 2}
+    assert c['depth'] == 2 and c['out_lut'].tolist() == [-1, 0, 1, 0]             # one-hot over {1, 2}; background dropped (-1)
     assert c['mean_min'] == [0, 25, 25, 25] and c['std_max'] == [25] * 4
     with pytest.raises(NotImplementedError):
         ne.models.labels_to_image((8, 8, 8), [0, 1], input_model=object())
