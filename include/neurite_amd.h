@@ -236,6 +236,11 @@ int nrt_add_act_affine_f32(const float *a, const float *b, const float *scale, c
 int nrt_act_bwd_f32(const float *grad_out, const float *y, int activation, float *grad_pre, long long n, void *stream);
 int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float *grad_weights, float *grad_bias, int batch,
                          const int *shape, int cin, int cout, const int *ksize, int dilation, void *stream);
+/* the same with the forward kernel's fused loader: the layer input was concat(x [.., c0], UpSampling3D(x_lo [.., c1])), which
+ * is read from its two sources and never materialised (c0 % 4 == 0; x_lo may be NULL with c1 = 0) */
+int nrt_conv3d_wgrad2_f32(const float *x, int c0, const float *x_lo, int c1, const int *up, const float *grad_pre,
+                          float *grad_weights, float *grad_bias, int batch, const int *shape, int cout, const int *ksize,
+                          int dilation, void *stream);
 int nrt_maxpool3d_bwd_f32(const float *x, const float *grad_out, float *grad_x, int batch, const int *shape,
                           int channels, const int *pool, int padding_same, void *stream);
 int nrt_upsample_sum_f32(const float *grad_up, int grad_channels, int channel_offset, float *grad_lo, int channels,

@@ -52,6 +52,7 @@ _SIGNATURES = {
     'nrt_add_act_affine_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     'nrt_act_bwd_f32': (_i, [_vp, _vp, _i, _vp, _ll, _vp]),
     'nrt_conv3d_wgrad_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ip, _i, _i, _ip, _i, _vp]),
+    'nrt_conv3d_wgrad2_f32': (_i, [_vp, _i, _vp, _i, _ip, _vp, _vp, _vp, _i, _ip, _i, _ip, _i, _vp]),
     'nrt_maxpool3d_bwd_f32': (_i, [_vp, _vp, _vp, _i, _ip, _i, _ip, _i, _vp]),
     'nrt_upsample_sum_f32': (_i, [_vp, _i, _i, _vp, _i, _i, _ip, _ip, _vp]),
     'nrt_softmax_bwd_f32': (_i, [_vp, _vp, _vp, _ll, _i, _vp]),

@@ -149,6 +149,8 @@ struct WgArgs {
     int kx, ky, kz, dil;
     int ntx, nty, ntz;       // voxel tiles per volume
     int ncic, ncoc;          // channel chunks
+    const float *x1;         // optional second source [B, X/ux, Y/uy, Z/uz, c1], nearest up-sampled and concatenated after the c0
+    int c0, c1, ux, uy, uz;  // channels of x (the layer saw concat(x, upsample(x1)), Cin = c0 + c1); c0 % 4 == 0 when x1 is given
     int im2col;              // single-channel input, 3x3x3 kernel: the 27 taps are staged as 27 "channels" of a 1x1x1 conv
                              // (Cin = 27, kx = ky = kz = 1 above; dW[tap][0][co] and dW[0][tap][co] are the same memory)
 };
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
         const long long tv = tile % tiles_per_vol;
         const int x0 = (int)(tv / ((long long)a.nty * a.ntz)) * WT_X, y0 = (int)((tv / a.ntz) % a.nty) * WT_Y,
                   z0 = (int)(tv % a.ntz) * WT_Z;
-        const float *xb = a.x + (long long)b * a.X * a.Y * a.Z * a.Cin;
+        const float *xb = a.x + (long long)b * a.X * a.Y * a.Z * (a.x1 ? a.c0 : a.Cin);
         const float *pb = a.dp + (long long)b * a.X * a.Y * a.Z * a.Cout;
         __syncthreads();                                        // previous tile fully consumed
         // ---- stage the x halo tile (zero outside the volume = SAME padding, zero beyond Cin) ---------------
@@ -221,11 +223,24 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
             const int gx = x0 + rx - hx, gy = y0 + ry - hy, gz = z0 + rz - hz;
             nrt_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
             if (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z) {
-                const float *src = xb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.Cin + ci0 + c4;
-                if (ci0 + c4 + 3 < a.Cin && (a.Cin & 3) == 0) v = *(const nrt_f4 *)src;
-                else {
+                const int ch = ci0 + c4;
+                if (a.x1 && ch >= a.c0) {
+                    // fused UpSampling3D + concatenate loader: the channel quad comes from the low-resolution tensor
+                    const int X1 = a.X / a.ux, Y1 = a.Y / a.uy, Z1 = a.Z / a.uz;
+                    const float *src = a.x1 + ((((long long)b * X1 + gx / a.ux) * Y1 + gy / a.uy) * Z1 + gz / a.uz) * a.c1 + (ch - a.c0);
+                    if (ch + 3 < a.Cin && (a.c1 & 3) == 0) v = *(const nrt_f4 *)src;
+                    else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (ci0 + c4 + k < a.Cin) v[k] = src[k];
+                        for (int k = 0; k < 4; ++k) if (ch + k < a.Cin) v[k] = src[k];
+                    }
+                } else {
+                    const int cs = a.x1 ? a.c0 : a.Cin;                // channel stride of the first source
+                    const float *src = xb + (((long long)gx * a.Y + gy) * a.Z + gz) * cs + ch;
+                    if (ch + 3 < cs && (cs & 3) == 0) v = *(const nrt_f4 *)src;
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (ch + k < cs) v[k] = src[k];
+                    }
                 }
             }
             *(nrt_f4 *)(la + r * RSA + c4) = v;
@@ -400,17 +415,24 @@ extern "C" int nrt_softmax_bwd_f32(const float *y, const float *grad_out, float 
     return NRT_OK;
 }
 
-extern "C" int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float *grad_weights, float *grad_bias, int batch,
-                                    const int *shape, int cin, int cout, const int *ksize, int dilation, void *stream) {
+extern "C" int nrt_conv3d_wgrad2_f32(const float *x, int c0, const float *x_lo, int c1, const int *up, const float *grad_pre,
+                                     float *grad_weights, float *grad_bias, int batch, const int *shape, int cout,
+                                     const int *ksize, int dilation, void *stream) {
     if (!x || !grad_pre || !grad_weights || !shape || !ksize) return NRT_ERR_INVALID_ARG;
-    if (batch < 1 || cin < 1 || cout < 1 || dilation < 1) return NRT_ERR_INVALID_ARG;
+    if (batch < 1 || c0 < 1 || c1 < 0 || cout < 1 || dilation < 1) return NRT_ERR_INVALID_ARG;
+    if (c1 > 0 && (!x_lo || !up)) return NRT_ERR_INVALID_ARG;
     for (int d = 0; d < 3; ++d) {
         if (shape[d] < 1 || ksize[d] < 1) return NRT_ERR_INVALID_ARG;
         if (ksize[d] != 1 && ksize[d] != 3) return NRT_ERR_UNSUPPORTED;           // the kernel sizes of the conv stacks
+        if (c1 > 0 && (up[d] < 1 || shape[d] % up[d])) return NRT_ERR_INVALID_ARG;
     }
     if (dilation > 2) return NRT_ERR_UNSUPPORTED;
+    if (c1 > 0 && (c0 % 4)) return NRT_ERR_UNSUPPORTED;                           // a staged channel quad must not straddle the sources
+    int cin = c0 + c1;
     WgArgs a;
     a.x = x; a.dp = grad_pre; a.dw = grad_weights; a.db = grad_bias;
+    a.x1 = c1 > 0 ? x_lo : nullptr; a.c0 = c0; a.c1 = c1;
+    a.ux = c1 > 0 ? up[0] : 1; a.uy = c1 > 0 ? up[1] : 1; a.uz = c1 > 0 ? up[2] : 1;
     a.B = batch; a.X = shape[0]; a.Y = shape[1]; a.Z = shape[2]; a.Cin = cin; a.Cout = cout;
     a.kx = ksize[0]; a.ky = ksize[1]; a.kz = ksize[2]; a.dil = dilation;
     a.ntx = (a.X + WT_X - 1) / WT_X; a.nty = (a.Y + WT_Y - 1) / WT_Y; a.ntz = (a.Z + WT_Z - 1) / WT_Z;
@@ -431,4 +453,10 @@ extern "C" int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float
         if (rc != NRT_ERR_UNSUPPORTED) return rc;
     }
     return NRT_ERR_UNSUPPORTED;
+}
+
+extern "C" int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float *grad_weights, float *grad_bias, int batch,
+                                    const int *shape, int cin, int cout, const int *ksize, int dilation, void *stream) {
+    return nrt_conv3d_wgrad2_f32(x, cin, nullptr, 0, nullptr, grad_pre, grad_weights, grad_bias, batch, shape, cout, ksize, dilation,
+                                 stream);
 }

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void mi_joint(MiArgs a) {
 #pragma unroll
             for (int t = 0; t < NBT; ++t) {
                 const float dx = xv - cxv[t], dy = yv - cyv[t];
-                wa[t] = (live[t] && vin) ? expf(-a.alpha * (dx * dx)) : 0.0f;
-                wb[t] = (live[t] && vin) ? expf(-a.alpha * (dy * dy)) : 0.0f;
+                wa[t] = (live[t] && vin) ? __expf(-a.alpha * (dx * dx)) : 0.0f;
+                wb[t] = (live[t] && vin) ? __expf(-a.alpha * (dy * dy)) : 0.0f;
                 sx[t] += wa[t]; sy[t] += wb[t];
             }
 #pragma unroll
@@ -118,12 +118,12 @@ __global__ __launch_bounds__(256) void mi_joint_bwd(MiArgs a, const float *__res
         const float xv = clipf(xr, a.lo, a.hi), yv = clipf(yr, a.lo, a.hi);
         const bool xin = xr >= a.lo && xr <= a.hi, yin = yr >= a.lo && yr <= a.hi;      // clip_by_value passes the gradient inside
         float wy[32], dgx = 0.0f, dgy = 0.0f;
-        for (int j = 0; j < nb; ++j) { const float d = yv - scy[j]; wy[j] = expf(-a.alpha * d * d); }
+        for (int j = 0; j < nb; ++j) { const float d = yv - scy[j]; wy[j] = __expf(-a.alpha * d * d); }
         float ty[32];
         for (int j = 0; j < nb; ++j) ty[j] = sgy[j];
         for (int i = 0; i < nb; ++i) {
             const float d = xv - scx[i];
-            const float wx = expf(-a.alpha * d * d);
+            const float wx = __expf(-a.alpha * d * d);
             float t = sgx[i];
             for (int j = 0; j < nb; ++j) { t += sG[i * nb + j] * wy[j]; ty[j] += sG[i * nb + j] * wx; }
             dgx += t * wx * (-2.0f * a.alpha * d);

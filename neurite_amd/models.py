@@ -297,15 +297,18 @@ class _ConvFn(torch.autograd.Function):
         dx = dlo = dw = db = None
         c0 = x.shape[-1]
         if need_w or need_b:
-            xin = x.contiguous() if lo is None else _upsample_concat(x, lo, up)
             dw = torch.zeros_like(kernel, dtype=torch.float32)
             db = torch.zeros(mod.cout, dtype=torch.float32, device=dev)
-            B, S = xin.shape[0], list(xin.shape[1:4])
+            xs = x.contiguous()
+            lo_c = None if lo is None else lo.contiguous()
+            if lo_c is not None and c0 % 4:
+                xs, lo_c = _upsample_concat(xs, lo_c, up), None          # a channel quad would straddle the two sources
+            B, S = xs.shape[0], list(xs.shape[1:4])
             with torch.cuda.device(dev):
-                rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xin), _lib.ptr(dpre), _lib.ptr(dw), _lib.ptr(db), B, _lib.ints(S),
-                                              mod.cin, mod.cout, _lib.ints(mod.ksize3), mod.dilation, _lib.stream_ptr(dev))
-            _lib.check(rc, 'nrt_conv3d_wgrad_f32')
-            del xin
+                rc = lib.nrt_conv3d_wgrad2_f32(_lib.ptr(xs), xs.shape[-1], _lib.ptr(lo_c), 0 if lo_c is None else lo_c.shape[-1],
+                                               _lib.ints(up) if lo_c is not None else None, _lib.ptr(dpre), _lib.ptr(dw), _lib.ptr(db),
+                                               B, _lib.ints(S), mod.cout, _lib.ints(mod.ksize3), mod.dilation, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_conv3d_wgrad2_f32')
         k5 = kernel.detach()
         if need_x:
             dx = _conv_dgrad(dpre, k5[..., :c0, :], mod.ksize3, mod.dilation)
