@@ -249,6 +249,28 @@ def sweep(args, dev, mov, fix, trf):
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
 
 
+def unet_fwd_ms(dev, size=160, labels=32, reps=20, warmup=5):
+    """median forward ms of the BASELINE config 3 unet on this rank's GPU (used for the N > 1 line of the metric)"""
+    import contextlib
+    import neurite_amd as ne
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = ne.models.unet(16, (size, size, size, 1), 3, 3, labels, feat_mult=2).to(dev)
+    x = torch.randn(1, size, size, size, 1, device=dev)
+    for _ in range(warmup):
+        model(x)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        model(x)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    return float(np.median(times))
+
+
 def unet_bench(dev, size=160, labels=32, nb_conv_per_level=1, reps=20, warmup=5):
     """BASELINE config 3: unet(16, (160,160,160,1), 3, 3, nb_labels, feat_mult=2) forward on one fp32 volume.
     Returns total forward ms (median) and per-conv-layer time / TFLOP/s / fraction of the fp32 MFMA peak."""
@@ -438,6 +460,18 @@ def main():
     # the other form of the same pipeline, shorter run, for the record
     o_elapsed, o_k0, o_k1, o_m = timed(step_unfused if fused else step_fused, max(5, args.steps // 5), 2)
     o_steps = max(5, args.steps // 5)
+    unet_multi = None
+    if world > 1 and not args.no_unet:
+        # "3D UNet fwd ms at 1/2/4/8 GPU": every rank runs the config-3 forward on its own volume (data parallel inference);
+        # the slowest rank's median is reported
+        try:
+            ms_un = unet_fwd_ms(dev)
+        except Exception as e:   # noqa
+            ms_un = float('inf')                 # every rank still joins the reduction below
+            log('unet forward at world %d failed on rank %d: %s' % (world, rank, e))
+        t_un = torch.tensor([ms_un], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_un, op=dist.ReduceOp.MAX)
+        unet_multi = float(t_un[0]) if np.isfinite(float(t_un[0])) else None
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -542,6 +576,9 @@ def main():
             out['lc3d_wcce'] = lc3d_bench(dev)
         except Exception as e:   # noqa
             out['lc3d_wcce'] = {'error': str(e)}
+    if unet_multi is not None:
+        out['unet_fwd'] = {'config': 'BASELINE config 3, one 160^3 volume per GPU (data-parallel inference)', 'n_gpus': world,
+                           'fwd_ms': round(unet_multi, 3), 'volumes_per_s': round(world / (unet_multi * 1e-3), 1)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
