@@ -24,6 +24,7 @@ struct InterpBwdArgs {
     const float *gout;            // [B, nout, C]
     float *gvol;                  // [B, nin, C]  zero-initialised by the caller, or null
     float *gloc;                  // [B, nout, D] or null
+    TileGeom tg;                  // x-march schedule (G == 8 kernels) when tg.x_march
 };
 
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
@@ -93,7 +94,13 @@ __global__ __launch_bounds__(256) void interpn_bwd_rows(InterpBwdArgs ba) {
     constexpr int D = 3;
     constexpr int NG = 256 / G;
     const InterpArgs &a = ba.f;
-    const int b = blockIdx.y;
+    // x-march schedule (G == 8): the block owns a 4 x 8 (y,z) patch of one batch entry and walks x, see interpn_core.h
+    const bool xm = G == 8 && ba.tg.x_march;
+    int b = blockIdx.y, xm_x0 = 0, xm_y0 = 0, xm_z0 = 0, xm_len = 0;
+    if (xm) {
+        unsigned prow;
+        if (!xmarch_block(ba.tg, a.O[0], b, prow, xm_x0, xm_y0, xm_z0, xm_len)) return;
+    }
     const nrt_f4 *vol = (const nrt_f4 *)((const float *)a.vol + (long long)b * a.vol_bs);
     const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
     const nrt_f4 *go = (const nrt_f4 *)(ba.gout + (long long)b * a.out_bs);
@@ -102,55 +109,85 @@ __global__ __launch_bounds__(256) void interpn_bwd_rows(InterpBwdArgs ba) {
     const int lg = threadIdx.x % G;
     const unsigned g = threadIdx.x / G;
     const int Y = a.S[1], Z = a.S[2];
+    // two voxels per lane-group in flight (all row loads of an iteration issued before the first use); every lane-group
+    // runs the same number of iterations so that the shuffles below are convergent
+    constexpr int U = 2;
     const unsigned ngroups = gridDim.x * NG;
-    // every lane-group runs the same number of iterations so that the shuffles below are convergent
-    const unsigned niter = (a.nout + ngroups - 1) / ngroups;
+    unsigned niter = (a.nout + ngroups * U - 1) / (ngroups * U);
+    if (xm) niter = ((unsigned)xm_len + U - 1) / U;
     for (unsigned it = 0; it < niter; ++it) {
-        const unsigned qq = blockIdx.x * NG + g + it * ngroups;
-        const bool live = qq < a.nout;
-        const unsigned q = live ? qq : a.nout - 1;
-        int qd[NRT_MAXD];
-        float p[NRT_MAXD];
-        decode<D>(a, q, qd);
-        load_loc<D, MODE>(a, locb, q, qd, p);
-        const bool oob = a.has_fill ? out_of_bounds<D>(a, p) : false;
-        int i0[3], i1[3];
-        float w0[3], w1[3], m[3];
+        unsigned q[U];
+        bool live[U], oob[U];
+        int i0[U][3], i1[U][3];
+        float w0[U][3], w1[U][3], m[U][3];
+        nrt_f4 gq[U], v[U][8];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
-            m[d] = (p[d] >= 0.0f && p[d] <= (float)(a.S[d] - 1)) ? 1.0f : 0.0f;
+        for (int u = 0; u < U; ++u) {
+            unsigned qq;
+            if (xm) {
+                const int x = xm_x0 + (int)(it * U + u), y = xm_y0 + (int)(g >> ba.tg.ltz), z = xm_z0 + (int)(g & ((1u << ba.tg.ltz) - 1u));
+                const bool in = x < xm_x0 + xm_len && y < a.O[1] && z < a.O[2];
+                qq = in ? ((unsigned)x * (unsigned)a.O[1] + (unsigned)y) * (unsigned)a.O[2] + (unsigned)z : 0xffffffffu;
+            } else {
+                qq = blockIdx.x * NG + g + (it * U + u) * ngroups;
+            }
+            live[u] = qq < a.nout;
+            q[u] = live[u] ? qq : a.nout - 1;
+            int qd[NRT_MAXD];
+            float p[NRT_MAXD];
+            decode<D>(a, q[u], qd);
+            load_loc<D, MODE>(a, locb, q[u], qd, p);
+            oob[u] = a.has_fill ? out_of_bounds<D>(a, p) : false;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                corner_1d(p[d], a.S[d], i0[u][d], i1[u][d], w0[u][d], w1[u][d]);
+                m[u][d] = (p[d] >= 0.0f && p[d] <= (float)(a.S[d] - 1)) ? 1.0f : 0.0f;
+            }
+            gq[u] = go[(long long)q[u] * G + lg];
+            if (gl) {
+#pragma unroll
+                for (int corner = 0; corner < 8; ++corner) {
+                    const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+                    const long long idx = ((long long)(bx ? i1[u][0] : i0[u][0]) * Y + (by ? i1[u][1] : i0[u][1])) * Z +
+                                          (bz ? i1[u][2] : i0[u][2]);
+                    v[u][corner] = vol[idx * G + lg];
+                }
+            }
         }
-        nrt_f4 gq = go[(long long)q * G + lg];
-        if (oob || !live) gq = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
-        float gacc[3] = {0.0f, 0.0f, 0.0f};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
-            const long long idx = ((long long)(bx ? i1[0] : i0[0]) * Y + (by ? i1[1] : i0[1])) * Z + (bz ? i1[2] : i0[2]);
-            const float wx = bx ? w1[0] : w0[0], wy = by ? w1[1] : w0[1], wz = bz ? w1[2] : w0[2];
-            if (gv && live && !oob) {
-                const float wt = wx * wy * wz;
-                float *dst = gv + (idx * G + lg) * 4;
+        for (int u = 0; u < U; ++u) {
+            if (oob[u] || !live[u]) gq[u] = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+            float gacc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) atomic_add_f32(dst + e, wt * gq[e]);
+            for (int corner = 0; corner < 8; ++corner) {
+                const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+                const float wx = bx ? w1[u][0] : w0[u][0], wy = by ? w1[u][1] : w0[u][1], wz = bz ? w1[u][2] : w0[u][2];
+                if (gv && live[u] && !oob[u]) {
+                    const long long idx = ((long long)(bx ? i1[u][0] : i0[u][0]) * Y + (by ? i1[u][1] : i0[u][1])) * Z +
+                                          (bz ? i1[u][2] : i0[u][2]);
+                    const float wt = wx * wy * wz;
+                    float *dst = gv + (idx * G + lg) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomic_add_f32(dst + e, wt * gq[u][e]);
+                }
+                if (gl) {
+                    const nrt_f4 c = v[u][corner];
+                    const float dot = gq[u][0] * c[0] + gq[u][1] * c[1] + gq[u][2] * c[2] + gq[u][3] * c[3];
+                    gacc[0] += dot * (bx ? m[u][0] : -m[u][0]) * wy * wz;
+                    gacc[1] += dot * wx * (by ? m[u][1] : -m[u][1]) * wz;
+                    gacc[2] += dot * wx * wy * (bz ? m[u][2] : -m[u][2]);
+                }
             }
             if (gl) {
-                const nrt_f4 v = vol[idx * G + lg];
-                const float dot = gq[0] * v[0] + gq[1] * v[1] + gq[2] * v[2] + gq[3] * v[3];
-                gacc[0] += dot * (bx ? m[0] : -m[0]) * wy * wz;
-                gacc[1] += dot * wx * (by ? m[1] : -m[1]) * wz;
-                gacc[2] += dot * wx * wy * (bz ? m[2] : -m[2]);
-            }
-        }
-        if (gl) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d)
+                for (int d = 0; d < 3; ++d)
 #pragma unroll
-                for (int off = 1; off < G; off <<= 1) gacc[d] += __shfl_xor(gacc[d], off, 64);
-            if (live && lg == 0) {
-                float *dst = gl + (long long)q * 3;
-                dst[0] = gacc[0]; dst[1] = gacc[1]; dst[2] = gacc[2];
+                    for (int off = 1; off < G; off <<= 1) gacc[d] += __shfl_xor(gacc[d], off, 64);
+                if (live[u] && lg == 0) {
+                    float *dst = gl + (long long)q[u] * 3;
+                    dst[0] = gacc[0]; dst[1] = gacc[1]; dst[2] = gacc[2];
+                }
             }
         }
     }
@@ -349,7 +386,13 @@ __global__ __launch_bounds__(256) void warp_dice_bwd_rows(InterpBwdArgs ba, cons
     constexpr int NG = 256 / G;
     constexpr int L = G * 4;
     const InterpArgs &a = ba.f;
-    const int b = blockIdx.y;
+    // x-march schedule (G == 8): the block owns a 4 x 8 (y,z) patch of one batch entry and walks x, see interpn_core.h
+    const bool xm = G == 8 && ba.tg.x_march;
+    int b = blockIdx.y, xm_x0 = 0, xm_y0 = 0, xm_z0 = 0, xm_len = 0;
+    if (xm) {
+        unsigned prow;
+        if (!xmarch_block(ba.tg, a.O[0], b, prow, xm_x0, xm_y0, xm_z0, xm_len)) return;
+    }
     const nrt_f4 *vol = (const nrt_f4 *)((const float *)a.vol + (long long)b * a.vol_bs);
     const float *locb = a.loc + (long long)b * a.loc_bs;
     const nrt_f4 *fix = (const nrt_f4 *)(fixed + (long long)b * a.out_bs);
@@ -369,61 +412,80 @@ __global__ __launch_bounds__(256) void warp_dice_bwd_rows(InterpBwdArgs ba, cons
             if (den != 0.0f) { ca[k] = 2.0f * gd / den; cb[k] = -2.0f * gd * num / (den * den); }
         }
     }
+    // two voxels per lane-group in flight: all 18 row loads of an iteration are issued before the first use
+    constexpr int U = 2;
     const unsigned ngroups = gridDim.x * NG;
-    const unsigned niter = (a.nout + ngroups - 1) / ngroups;
+    unsigned niter = (a.nout + ngroups * U - 1) / (ngroups * U);
+    if (xm) niter = ((unsigned)xm_len + U - 1) / U;
     for (unsigned it = 0; it < niter; ++it) {
-        const unsigned qq = blockIdx.x * NG + g + it * ngroups;
-        const bool live = qq < a.nout;
-        const unsigned q = live ? qq : a.nout - 1;
-        int qd[NRT_MAXD];
-        float p[NRT_MAXD];
-        decode<D>(a, q, qd);
-        load_loc<D, MODE>(a, locb, q, qd, p);
-        const bool oob = a.has_fill ? out_of_bounds<D>(a, p) : false;
-        int i0[3], i1[3];
-        float w0[3], w1[3], m[3];
+        unsigned q[U];
+        bool live[U], oob[U];
+        float w0[U][3], w1[U][3], m[U][3];
+        nrt_f4 t[U], v[U][8];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
-            m[d] = (p[d] >= 0.0f && p[d] <= (float)(a.S[d] - 1)) ? 1.0f : 0.0f;
+        for (int u = 0; u < U; ++u) {
+            unsigned qq;
+            if (xm) {
+                const int x = xm_x0 + (int)(it * U + u), y = xm_y0 + (int)(g >> ba.tg.ltz), z = xm_z0 + (int)(g & ((1u << ba.tg.ltz) - 1u));
+                const bool in = x < xm_x0 + xm_len && y < a.O[1] && z < a.O[2];
+                qq = in ? ((unsigned)x * (unsigned)a.O[1] + (unsigned)y) * (unsigned)a.O[2] + (unsigned)z : 0xffffffffu;
+            } else {
+                qq = blockIdx.x * NG + g + (it * U + u) * ngroups;
+            }
+            live[u] = qq < a.nout;
+            q[u] = live[u] ? qq : a.nout - 1;
+            int qd[NRT_MAXD];
+            float p[NRT_MAXD];
+            decode<D>(a, q[u], qd);
+            load_loc<D, MODE>(a, locb, q[u], qd, p);
+            oob[u] = a.has_fill ? out_of_bounds<D>(a, p) : false;
+            int i0[3], i1[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                corner_1d(p[d], a.S[d], i0[d], i1[d], w0[u][d], w1[u][d]);
+                m[u][d] = (p[d] >= 0.0f && p[d] <= (float)(a.S[d] - 1)) ? 1.0f : 0.0f;
+            }
+            t[u] = fix[(long long)q[u] * G + lg];
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+                const long long idx = ((long long)(bx ? i1[0] : i0[0]) * Y + (by ? i1[1] : i0[1])) * Z + (bz ? i1[2] : i0[2]);
+                v[u][corner] = vol[idx * G + lg];
+            }
         }
-        const nrt_f4 t = fix[(long long)q * G + lg];
-        nrt_f4 v[8];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
-            const long long idx = ((long long)(bx ? i1[0] : i0[0]) * Y + (by ? i1[1] : i0[1])) * Z + (bz ? i1[2] : i0[2]);
-            v[corner] = vol[idx * G + lg];
-        }
-        nrt_f4 wp = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+        for (int u = 0; u < U; ++u) {
+            nrt_f4 wp = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
-            const float wt = (bx ? w1[0] : w0[0]) * (by ? w1[1] : w0[1]) * (bz ? w1[2] : w0[2]);
+            for (int corner = 0; corner < 8; ++corner) {
+                const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+                const float wt = (bx ? w1[u][0] : w0[u][0]) * (by ? w1[u][1] : w0[u][1]) * (bz ? w1[u][2] : w0[u][2]);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wp[k] += wt * v[corner][k];
-        }
-        nrt_f4 gq;
+                for (int k = 0; k < 4; ++k) wp[k] += wt * v[u][corner][k];
+            }
+            nrt_f4 gq;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) gq[k] = (oob || !live) ? 0.0f : ca[k] * t[k] + cb[k] * wp[k];
-        float gacc[3] = {0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < 4; ++k) gq[k] = (oob[u] || !live[u]) ? 0.0f : ca[k] * t[u][k] + cb[k] * wp[k];
+            float gacc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
-            const float wx = bx ? w1[0] : w0[0], wy = by ? w1[1] : w0[1], wz = bz ? w1[2] : w0[2];
-            const nrt_f4 c = v[corner];
-            const float dot = gq[0] * c[0] + gq[1] * c[1] + gq[2] * c[2] + gq[3] * c[3];
-            gacc[0] += dot * (bx ? m[0] : -m[0]) * wy * wz;
-            gacc[1] += dot * wx * (by ? m[1] : -m[1]) * wz;
-            gacc[2] += dot * wx * wy * (bz ? m[2] : -m[2]);
-        }
+            for (int corner = 0; corner < 8; ++corner) {
+                const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+                const float wx = bx ? w1[u][0] : w0[u][0], wy = by ? w1[u][1] : w0[u][1], wz = bz ? w1[u][2] : w0[u][2];
+                const nrt_f4 c = v[u][corner];
+                const float dot = gq[0] * c[0] + gq[1] * c[1] + gq[2] * c[2] + gq[3] * c[3];
+                gacc[0] += dot * (bx ? m[u][0] : -m[u][0]) * wy * wz;
+                gacc[1] += dot * wx * (by ? m[u][1] : -m[u][1]) * wz;
+                gacc[2] += dot * wx * wy * (bz ? m[u][2] : -m[u][2]);
+            }
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+            for (int d = 0; d < 3; ++d)
 #pragma unroll
-            for (int off = 1; off < G; off <<= 1) gacc[d] += __shfl_xor(gacc[d], off, 64);
-        if (live && lg == 0) {
-            float *dst = gl + (long long)q * 3;
-            dst[0] = gacc[0]; dst[1] = gacc[1]; dst[2] = gacc[2];
+                for (int off = 1; off < G; off <<= 1) gacc[d] += __shfl_xor(gacc[d], off, 64);
+            if (live[u] && lg == 0) {
+                float *dst = gl + (long long)q[u] * 3;
+                dst[0] = gacc[0]; dst[1] = gacc[1]; dst[2] = gacc[2];
+            }
         }
     }
 }
@@ -443,6 +505,7 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
     if (rc != NRT_OK) return rc;
     ba.f.out = nullptr;
     ba.gout = grad_out; ba.gvol = grad_vol; ba.gloc = grad_loc;
+    ba.tg.x_march = 0;
     if (ba.f.nout == 0) return NRT_OK;
     hipStream_t st = nrt_stream(stream);
     const int G = channels / 4;
@@ -459,6 +522,13 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
         unsigned blocks = (ba.f.nout + ng - 1) / ng;
         if (blocks > 256u * 16u) blocks = 256u * 16u;
         dim3 grid(blocks, batch);
+        if (G == 8 && xmarch_applies(out_shape, batch)) {         // same block schedule as the fused forward (interpn_core.h)
+            unsigned nt;
+            const int t = xmarch_default_tune();
+            tile_geometry(out_shape, G, t, t, ba.tg, nt);
+            const unsigned per_batch = xmarch_setup(out_shape, batch, t, ba.tg);
+            grid = dim3(nrt_xcd_grid(per_batch * (unsigned)batch), 1);
+        }
         switch (G) {
             case 1: NRT_BWD_MODE(interpn_bwd_rows, 1) break;
             case 2: NRT_BWD_MODE(interpn_bwd_rows, 2) break;
@@ -568,12 +638,20 @@ extern "C" int nrt_warp_dice_bwd_f32(const float *moving, const float *loc, cons
     if (rc != NRT_OK) return rc;
     ba.f.out = nullptr;
     ba.gout = nullptr; ba.gvol = nullptr; ba.gloc = grad_loc;
+    ba.tg.x_march = 0;
     if (ba.f.nout == 0) return NRT_OK;
     hipStream_t st = nrt_stream(stream);
     const unsigned ng = 256 / G;
     unsigned blocks = (ba.f.nout + ng - 1) / ng;
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     dim3 grid(blocks, batch);
+    if (G == 8 && xmarch_applies(out_shape, batch)) {             // same block schedule as the fused forward (interpn_core.h)
+        unsigned nt;
+        const int t = xmarch_default_tune();
+        tile_geometry(out_shape, G, t, t, ba.tg, nt);
+        const unsigned per_batch = xmarch_setup(out_shape, batch, t, ba.tg);
+        grid = dim3(nrt_xcd_grid(per_batch * (unsigned)batch), 1);
+    }
 #define NRT_WDB(GG)                                                                                              \
     if (loc_mode == NRT_LOC_SHIFT)                                                                               \
         hipLaunchKernelGGL((warp_dice_bwd_rows<GG, NRT_LOC_SHIFT>), grid, dim3(256), 0, st, ba, fixed, sums,     \

@@ -232,34 +232,14 @@ void fused_geom(const int *out_shape, int G, int batch, int tune, TileGeom &tg, 
     tile_geometry(out_shape, G, tune, 3 | (3 << 4) | (4 << 8), tg, nblocks);   // default 8 x 8 x 16 tiles (profiles/r01)
     if (nblocks > (unsigned)DICE_MAX_BLOCKS) nblocks = DICE_MAX_BLOCKS;        // multiple of 8; blocks loop over tiles
     int t = tune <= 0 ? 0 : tune;
-    if (t == 0 && G == 8) {
+    if (t == 0 && G == 8 && xmarch_applies(out_shape, batch)) {
         // default for 32 labels: x-march over 4 x 8 (y,z) patches, blocks dealt to the XCDs region by region
         // (8 x 4 patches = 32 x 32 voxels).  Same speed as the 8 x 8 x 16 tiles (both sit on the L1-miss path, see
         // DESIGN.md 4.3) but 0.69x their L2-miss traffic: 1.11x instead of 1.61x the algorithmic bytes (profiles/).
-        const unsigned cols = ((unsigned)(out_shape[1] + 3) / 4) * ((unsigned)(out_shape[2] + 7) / 8);
-        if (out_shape[0] >= 16 && cols * (unsigned)batch >= 512) {
-            t = 3 | (2 << 4) | (3 << 8) | (1 << 14) | (3 << 24) | (2 << 27);
-            tile_geometry(out_shape, G, t, t, tg, nblocks);
-        }
+        t = xmarch_default_tune();
+        tile_geometry(out_shape, G, t, t, tg, nblocks);
     }
-    if (((t >> 14) & 1) && !tg.plane_major && out_shape[0] > 0) {
-        tg.x_march = 1;
-        tg.nbatch = (unsigned)batch;
-        tg.lry = (t >> 24) & 7; tg.lrz = (t >> 27) & 7;
-        {   // regions are padded to full size; out-of-range patches are empty blocks
-            const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
-            tg.ncol = ((tg.nTy + RY - 1) / RY) * ((tg.nTz + RZ - 1) / RZ) * RY * RZ;
-        }
-        unsigned nseg = (unsigned)(t >> 16) & 0xffu;
-        if (nseg == 0) {                                       // auto: at least two blocks per CU over the launch
-            nseg = (512u + tg.ncol * batch - 1) / (tg.ncol * batch);
-            if (nseg < 1) nseg = 1;
-        }
-        if (nseg > (unsigned)out_shape[0]) nseg = (unsigned)out_shape[0];
-        tg.seglen = ((unsigned)out_shape[0] + nseg - 1) / nseg;
-        tg.nseg = ((unsigned)out_shape[0] + tg.seglen - 1) / tg.seglen;
-        nblocks = tg.ncol * tg.nseg;
-    }
+    if (((t >> 14) & 1) && !tg.plane_major && out_shape[0] > 0) nblocks = xmarch_setup(out_shape, batch, t, tg);
 }
 
 template <int G>

@@ -138,6 +138,55 @@ __device__ __forceinline__ void tile_voxel(const TileGeom &tg, int NG, int pass,
     }
 }
 
+
+// ---- x-march schedule shared by the fused forward and the backward gathers ---------------------------------------
+// host: fill the x-march fields of tg for `tune` (lty/ltz = patch, bits 16-23 segments, 24-26 lry, 27-29 lrz); returns the
+// number of blocks per batch entry
+inline unsigned xmarch_setup(const int *out_shape, int batch, int t, TileGeom &tg) {
+    tg.x_march = 1;
+    tg.nbatch = (unsigned)batch;
+    tg.lry = (t >> 24) & 7; tg.lrz = (t >> 27) & 7;
+    const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;             // regions are padded; out-of-range patches are empty blocks
+    tg.ncol = ((tg.nTy + RY - 1) / RY) * ((tg.nTz + RZ - 1) / RZ) * RY * RZ;
+    unsigned nseg = (unsigned)(t >> 16) & 0xffu;
+    if (nseg == 0) {                                                 // auto: at least two blocks per CU over the launch
+        nseg = (512u + tg.ncol * batch - 1) / (tg.ncol * batch);
+        if (nseg < 1) nseg = 1;
+    }
+    if (nseg > (unsigned)out_shape[0]) nseg = (unsigned)out_shape[0];
+    tg.seglen = ((unsigned)out_shape[0] + nseg - 1) / nseg;
+    tg.nseg = ((unsigned)out_shape[0] + tg.seglen - 1) / tg.seglen;
+    return tg.ncol * tg.nseg;
+}
+
+// default x-march tune for 32-channel volumes: 4 x 8 (y,z) patches, regions of 8 x 4 patches
+inline int xmarch_default_tune() { return 3 | (2 << 4) | (3 << 8) | (1 << 14) | (3 << 24) | (2 << 27); }
+inline bool xmarch_applies(const int *out_shape, int batch) {
+    const unsigned cols = ((unsigned)(out_shape[1] + 3) / 4) * ((unsigned)(out_shape[2] + 7) / 8);
+    return out_shape[0] >= 16 && cols * (unsigned)batch >= 512;
+}
+
+// device: which (batch, patch, x segment) does this block own?  false = nothing (padding block)
+__device__ __forceinline__ bool xmarch_block(const TileGeom &tg, int O0, int &b, unsigned &prow, int &x0, int &y0, int &z0, int &xlen) {
+    const unsigned k = blockIdx.x % NRT_NXCD, jb = blockIdx.x / NRT_NXCD;
+    const unsigned per_batch = tg.ncol * tg.nseg, U = per_batch * tg.nbatch;
+    const unsigned perU = gridDim.x / NRT_NXCD;
+    const unsigned u = k * perU + jb;
+    if (jb >= perU || u >= U) return false;
+    b = (int)(u / per_batch);
+    prow = u % per_batch;
+    const unsigned useg = prow / tg.ncol, ucol = prow % tg.ncol;
+    const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
+    const unsigned nRz = (tg.nTz + RZ - 1) / RZ;
+    const unsigned reg = ucol / (RY * RZ), w = ucol % (RY * RZ);
+    const unsigned cy = (reg / nRz) * RY + w / RZ, cz = (reg % nRz) * RZ + w % RZ;
+    x0 = (int)(useg * tg.seglen);
+    y0 = (int)cy << tg.lty;
+    z0 = (int)cz << tg.ltz;
+    xlen = min((int)tg.seglen, O0 - x0);
+    return cy < tg.nTy && cz < tg.nTz && xlen > 0;
+}
+
 struct TileMeta {
     float w0[3], w1[3];
     unsigned q;
