@@ -310,11 +310,17 @@ class _ConvFn(torch.autograd.Function):
                                                B, _lib.ints(S), mod.cout, _lib.ints(mod.ksize3), mod.dilation, _lib.stream_ptr(dev))
             _lib.check(rc, 'nrt_conv3d_wgrad2_f32')
         k5 = kernel.detach()
-        if need_x:
-            dx = _conv_dgrad(dpre, k5[..., :c0, :], mod.ksize3, mod.dilation)
-        if lo is not None and need_lo:
-            full = _conv_dgrad(dpre, k5[..., c0:, :], mod.ksize3, mod.dilation)
-            dlo = _upsample_sum(full, 0, full.shape[-1], list(lo.shape[1:4]), up)
+        if lo is not None and need_x and need_lo and mod.cin <= 64:
+            # one dgrad for both sources of the fused loader (dpre is staged once, three N-tiles per A fragment)
+            full = _conv_dgrad(dpre, k5, mod.ksize3, mod.dilation)
+            dx = full[..., :c0]
+            dlo = _upsample_sum(full, c0, mod.cin - c0, list(lo.shape[1:4]), up)
+        else:
+            if need_x:
+                dx = _conv_dgrad(dpre, k5[..., :c0, :], mod.ksize3, mod.dilation)
+            if lo is not None and need_lo:
+                full = _conv_dgrad(dpre, k5[..., c0:, :], mod.ksize3, mod.dilation)
+                dlo = _upsample_sum(full, 0, full.shape[-1], list(lo.shape[1:4]), up)
         return dx, dlo, dw if need_w else None, db if need_b else None, None, None, None, None
 
 
