@@ -325,3 +325,26 @@ def test_fused_warp_dice_backward(dev, L, fill, eps):
     close(N(f1.grad), N(f3.grad), 'single/xy')
     with pytest.raises(NotImplementedError):
         ne.fused.warp_dice(G(mov, dev, True), f1, G(fix, dev), single_transform=True)
+
+
+def test_backward_x_march_schedule_ragged(dev):
+    """The backward gathers take the forward's x-march block schedule for 32 channels above ~500 patches: a ragged shape"""
+    rng = np.random.default_rng(31)
+    B, S, L = 6, (20, 50, 61), 32
+    mov = rng.random((B,) + S + (L,)).astype(F)
+    fix = rng.random((B,) + S + (L,)).astype(F)
+    flow = (rng.standard_normal((B,) + S + (3,)) * 2.0).astype(F)
+    wl = rng.uniform(0.5, 1.5, (B, L)).astype(F)
+    f = G(flow, dev, True)
+    d = ne.fused.warp_dice(G(mov, dev), f, G(fix, dev))
+    (-(d * G(wl, dev)).mean()).backward()
+    f2 = G(flow, dev, True)
+    warped = ne.layers.SpatialTransformer()([G(mov, dev), f2])
+    d2 = ne.metrics.Dice(check_input_limits=False).dice(G(fix, dev), warped)
+    (-(d2 * G(wl, dev)).mean()).backward()
+    close(N(f.grad), N(f2.grad), 'fused vs unfused')
+    for b in (0, B - 1):
+        ref, vo, lo = _shift_oracle(mov[b], flow[b])
+        dd = go.soft_dice(D64(fix[b:b + 1]), ref[None])
+        (-(dd * D64(wl[b:b + 1])).sum() / (B * L)).backward()
+        close(N(f.grad[b]), lo.grad.numpy(), 'grad_flow b%d' % b)

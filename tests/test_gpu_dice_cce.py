@@ -255,3 +255,28 @@ def test_cce_cfg5_size_bf16(dev):
     np.testing.assert_allclose(got, want, rtol=1e-4)
     got32 = float(ne.metrics.CategoricalCrossentropy(label_weights=w)(t, p))
     np.testing.assert_allclose(got32, co.wcce(N(t), N(p), w), rtol=RTOL)
+
+
+def test_fused_x_march_schedule_ragged(dev):
+    """The x-march block schedule (default for 32 labels above ~500 patches) on shapes that are not multiples of the 4 x 8
+    patch, the 8 x 4 patch region or the x segment: bit-identical `warped`, Dice equal to the tile schedule and the oracle."""
+    rng = np.random.default_rng(77)
+    B, S, L = 6, (36, 50, 61), 32
+    mov = rng.random((B,) + S + (L,)).astype(F)
+    fix = rng.random((B,) + S + (L,)).astype(F)
+    trf = rng.normal(0, 2.0, (B,) + S + (3,)).astype(F)
+    w_ref = npo.spatial_transformer(mov, trf, fill_value=0.0)
+    d_ref = npo.dice(fix, w_ref, check_input_limits=False)
+    xm = 3 | (2 << 4) | (3 << 8) | (1 << 14)
+    tunes = (0,                                  # auto -> x-march (13 x 8 patches x 6 volumes >= 512)
+             3 | (3 << 4) | (4 << 8),            # 8 x 8 x 16 tiles
+             xm,                                 # x-march, no regions, one segment
+             xm | (3 << 16),                     # three x segments (36 = 3 x 12)
+             xm | (5 << 16) | (2 << 24) | (1 << 27),     # five segments (ragged last), 4 x 2 regions
+             3 | (3 << 4) | (3 << 8) | (1 << 14) | (1 << 24) | (3 << 27))        # 8 x 8 patches (two passes per plane), 2 x 8 regions
+    for tune in tunes:
+        d, w = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=0.0, return_warped=True, _tune=tune)
+        assert bits_equal(N(w), w_ref), tune
+        np.testing.assert_allclose(N(d), d_ref, rtol=RTOL, err_msg=str(tune))
+        d2 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=0.0, _tune=tune)
+        assert bits_equal(N(d2), N(d)), tune
