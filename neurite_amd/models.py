@@ -405,6 +405,36 @@ class _HeadFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _ChannelScaleFn(torch.autograd.Function):
+    """y[b, ..., c] = x[b, ..., c] * scale[b, c]: Keras Dropout with noise_shape [None, 1, .., 1, C] (whole feature maps are
+    dropped, models.py:1390-1399) once the mask is drawn; the backward is the same scaling of the gradient."""
+
+    @staticmethod
+    def _apply(x, scale):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        lib = _lib.lib()
+        dev = x.device
+        zero = torch.zeros(x.shape[-1], dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            for b in range(x.shape[0]):
+                rc = lib.nrt_add_act_affine_f32(_lib.ptr(x[b]), None, _lib.ptr(scale[b]), _lib.ptr(zero), _lib.ptr(y[b]), x[b].numel(),
+                                                x.shape[-1], 0, _lib.stream_ptr(dev))
+                _lib.check(rc, 'nrt_add_act_affine_f32')
+        return y
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(scale)
+        with torch.no_grad():
+            return _ChannelScaleFn._apply(x, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return _ChannelScaleFn._apply(g, scale), None
+
+
 class _SoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z):
@@ -582,6 +612,7 @@ class ConvNet(nn.Module):
         and the softmax run unfused so that the logits are available to the backward."""
         nd = self.ndims
         t = {}
+        self.last_dropout_scales = {}
         for op in self.ops:
             kind, name = op['kind'], op['name']
             if kind == 'input':
@@ -593,9 +624,15 @@ class ConvNet(nn.Module):
                 m = self.layers_by_name[name]
                 t[name] = _ConvFn.apply(t[op['src']], lo, m.kernel, m.bias, m, op.get('up'), self.conv_variant, False)
             elif kind == 'dropout':
-                if op.get('rate', 0):
-                    raise NotImplementedError('neurite_amd: training-mode Dropout is not implemented')
-                t[name] = t[op['src']]
+                rate = float(op.get('rate', 0))
+                if rate > 0:
+                    src = t[op['src']]
+                    kept = (torch.rand((src.shape[0], src.shape[-1]), device=src.device) >= rate).to(torch.float32)
+                    scale = (kept / (1.0 - rate)).contiguous()          # [B, C] numbers: the draw is plumbing, the scaling a kernel
+                    self.last_dropout_scales[name] = scale
+                    t[name] = _ChannelScaleFn.apply(src, scale)
+                else:
+                    t[name] = t[op['src']]
             elif kind == 'maxpool':
                 t[name] = _MaxPoolFn.apply(t[op['src']], op['pool'], op['padding'])
             elif kind == 'upsample':

@@ -51,7 +51,7 @@ def upsample(x, up):
     return x
 
 
-def forward(net, x, params=None, return_tensors=None):
+def forward(net, x, params=None, return_tensors=None, dropout_scales=None):
     """Run a neurite_amd.models.ConvNet graph (3-D nets) in float64 on the CPU.  params: {layer: (kernel, bias)} of
     float64 tensors (requires_grad as the caller likes); default: copies of the model's weights."""
     if params is None:
@@ -71,6 +71,9 @@ def forward(net, x, params=None, return_tensors=None):
             t[name] = conv3d_same(src, k, b, m.dilation, m.activation)
         elif kind == 'dropout':
             t[name] = t[op['src']]
+            if dropout_scales and name in dropout_scales:             # training mode: the recorded [B, C] keep / (1 - rate) factors
+                sc = dropout_scales[name]
+                t[name] = t[name] * sc.reshape(sc.shape[0], 1, 1, 1, sc.shape[1])
         elif kind == 'maxpool':
             t[name] = maxpool_same(t[op['src']], op['pool'])
         elif kind == 'upsample':

@@ -185,3 +185,30 @@ def test_unet_training_step_gradients(dev, kw, ishape):
     assert float(loss2.detach()) < float(loss.detach())
     net.eval()
     assert net(G(x, dev)).requires_grad is False
+
+
+def test_unet_training_with_feature_dropout(dev):
+    """conv_dropout > 0: Keras Dropout with noise_shape [None, 1, 1, 1, C] (models.py:1390-1399) in training mode; gradients vs
+    the oracle run with the recorded masks; eval mode ignores it"""
+    rng = np.random.default_rng(43)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ne.models.unet(8, (8, 8, 16, 1), 2, 3, 3, conv_dropout=0.4).to(dev)
+    for m in net.layers_by_name.values():
+        with torch.no_grad():
+            m.kernel.copy_(G((rng.standard_normal(tuple(m.kernel.shape)) * 0.2).astype(F), dev))
+    x = rng.standard_normal((3, 8, 8, 16, 1)).astype(F)
+    y_eval = net(G(x, dev))
+    net.train()
+    y = net(G(x, dev))
+    scales = {k: v.detach().cpu().double() for k, v in net.last_dropout_scales.items()}
+    assert scales and all(set(np.unique(v.numpy().round(4))) <= {0.0, round(1 / 0.6, 4)} for v in scales.values())
+    assert not np.allclose(N(y), N(y_eval))
+    w = rng.standard_normal(tuple(y.shape)).astype(F)
+    (y * G(w, dev)).sum().backward()
+    params = {k: (m.kernel.detach().cpu().double().requires_grad_(), m.bias.detach().cpu().double().requires_grad_())
+              for k, m in net.layers_by_name.items()}
+    yo = tuo.forward(net, torch.from_numpy(x).double(), params, dropout_scales=scales)
+    (yo * torch.from_numpy(w).double()).sum().backward()
+    close(N(y), yo.detach().numpy(), 'forward with dropout', 1e-4)
+    for k, m in net.layers_by_name.items():
+        close(N(m.kernel.grad), params[k][0].grad.numpy(), k + ' kernel', 5e-4)
