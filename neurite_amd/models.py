@@ -435,6 +435,25 @@ class _ChannelScaleFn(torch.autograd.Function):
         return _ChannelScaleFn._apply(g, scale), None
 
 
+class _AddActFn(torch.autograd.Function):
+    """y = act(a [+ b]): the residual merge (`KL.add`, models.py:1426) and the stand-alone Activation layers"""
+
+    @staticmethod
+    def forward(ctx, a, b, act):
+        with torch.no_grad():
+            y = _elementwise(a, b, act=act)
+        ctx.act = act
+        ctx.has_b = b is not None
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        d = _act_bwd(g, y, ctx.act)
+        return d, (d if ctx.has_b else None), None
+
+
 class _SoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z):
@@ -642,6 +661,10 @@ class ConvNet(nn.Module):
                     t[name] = None
                 else:
                     t[name] = _MergeFn.apply(t[op['skip']], t[op['lo']], op['up'])
+            elif kind == 'add':
+                t[name] = _AddActFn.apply(t[op['a']], t[op['b']], 0)
+            elif kind == 'activation':
+                t[name] = _AddActFn.apply(t[op['src']], None, _act_code(op['activation']))
             elif kind == 'likelihood':
                 m = self.layers_by_name[name]
                 if op.get('fuse_softmax') and name not in keep and m.cout <= 64 and tuple(m.ksize3) == (1, 1, 1):

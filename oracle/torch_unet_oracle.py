@@ -80,6 +80,15 @@ def forward(net, x, params=None, return_tensors=None, dropout_scales=None):
             t[name] = upsample(t[op['src']], op['up'])
         elif kind == 'merge':
             t[name] = torch.cat([t[op['skip']], upsample(t[op['lo']], op['up'])], -1)
+        elif kind == 'add':
+            t[name] = t[op['a']] + t[op['b']]
+        elif kind == 'activation':
+            y = t[op['src']]
+            if op['activation'] == 'elu':
+                y = torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0.0)) - 1)
+            elif op['activation'] == 'relu':
+                y = torch.relu(y)
+            t[name] = y
         elif kind == 'likelihood':
             k, b = params[name]
             t[name] = conv3d_same(t[op['src']], k, b, 1, None)

@@ -141,6 +141,7 @@ def test_small_layer_backward(dev):
 @pytest.mark.parametrize('kw,ishape', [
     (dict(nb_features=8, nb_levels=3, conv_size=3, nb_labels=4, feat_mult=2), (16, 8, 16, 1)),
     (dict(nb_features=8, nb_levels=2, conv_size=3, nb_labels=3, nb_conv_per_level=2), (8, 12, 8, 2)),
+    (dict(nb_features=8, nb_levels=2, conv_size=3, nb_labels=3, nb_conv_per_level=2, use_residuals=True, feat_mult=2), (8, 8, 8, 2)),
 ])
 def test_unet_training_step_gradients(dev, kw, ishape):
     """model.train(): loss = weighted CCE(one-hot, unet(x)) - mean Dice; every parameter gradient vs the float64 oracle"""
