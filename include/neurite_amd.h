@@ -246,6 +246,11 @@ int nrt_maxpool3d_bwd_f32(const float *x, const float *grad_out, float *grad_x, 
 int nrt_upsample_sum_f32(const float *grad_up, int grad_channels, int channel_offset, float *grad_lo, int channels,
                          int batch, const int *lo_shape, const int *up, void *stream);
 int nrt_softmax_bwd_f32(const float *y, const float *grad_out, float *grad_in, long long nvox, int channels, void *stream);
+/* BatchNormalization in training mode (Keras axis -1; models.py:1431-1434, 1585-1588): per-channel sums over [rows, channels],
+ * out[c] += sum_r a[r][c] * (b ? b[r][c] : 1)  (ZERO-FILLED by the caller), and y = coef_a[c] a + coef_b[c] b + coef_c[c] */
+int nrt_channel_sums_f32(const float *a, const float *b, long long rows, int channels, float *out, void *stream);
+int nrt_channel_axpby_f32(const float *a, const float *b, const float *coef_a, const float *coef_b, const float *coef_c, float *y,
+                          long long n, int channels, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * LocallyConnected3D, implementation 1 ('valid' padding, channels-last)

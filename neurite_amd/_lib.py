@@ -56,6 +56,8 @@ _SIGNATURES = {
     'nrt_maxpool3d_bwd_f32': (_i, [_vp, _vp, _vp, _i, _ip, _i, _ip, _i, _vp]),
     'nrt_upsample_sum_f32': (_i, [_vp, _i, _i, _vp, _i, _i, _ip, _ip, _vp]),
     'nrt_softmax_bwd_f32': (_i, [_vp, _vp, _vp, _ll, _i, _vp]),
+    'nrt_channel_sums_f32': (_i, [_vp, _vp, _ll, _i, _vp, _vp]),
+    'nrt_channel_axpby_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
     'nrt_lc3d_f': (_i, [_vp, _vp, _vp, _vp, _i, _i, _ip, _i, _ip, _ip, _i, _i, _i, _vp]),
     'nrt_lc3d_bwd_f': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ip, _i, _ip, _ip, _i, _i, _vp]),
     'nrt_conv1d_axis_f32': (_i, [_vp, _vp, _vp, _ll, _i, _ll, _i, _i, _i, _i, _i, _vp]),

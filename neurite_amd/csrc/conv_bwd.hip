@@ -333,6 +333,40 @@ int launch_wgrad(WgArgs &a, hipStream_t st) {
     return NRT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// BatchNormalization in training mode (Keras, axis = -1): per-channel statistics over [rows, C]
+//   channel_sums:   out[c] += sum_r a[r][c] * (b ? b[r][c] : 1)      (sum x, sum x^2 = a = b = x, sum g, sum g x)
+//   channel_axpby:  y[r][c] = A[c] * a[r][c] + B[c] * b[r][c] + C0[c]    (the backward: dx = A g + B x + C0)
+// float atomics across blocks; the caller zero-fills `out`
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_sums(const float *__restrict__ a, const float *__restrict__ b, long long rows, int C,
+                                                    float *__restrict__ out) {
+    extern __shared__ float sm[];
+    for (int i = threadIdx.x; i < C; i += 256) sm[i] = 0.0f;
+    __syncthreads();
+    const long long total = rows * C;
+    if (256 % C == 0) {                    // the grid stride keeps e % C: a thread owns one channel
+        float s = 0.0f;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+            s += b ? a[e] * b[e] : a[e];
+        atomicAdd(&sm[threadIdx.x % C], s);
+    } else {
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+            atomicAdd(&sm[(int)(e % C)], b ? a[e] * b[e] : a[e]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) unsafeAtomicAdd(&out[i], sm[i]);
+}
+
+__global__ __launch_bounds__(256) void channel_axpby(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ A,
+                                                     const float *__restrict__ B, const float *__restrict__ C0, float *__restrict__ y,
+                                                     long long n, int C) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        y[e] = A[c] * a[e] + B[c] * b[e] + C0[c];
+    }
+}
+
 unsigned ew_blocks(long long n, int per) {
     long long b = (n + per - 1) / per;
     if (b > 256ll * 16) b = 256ll * 16;
@@ -459,4 +493,26 @@ extern "C" int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float
                                     const int *shape, int cin, int cout, const int *ksize, int dilation, void *stream) {
     return nrt_conv3d_wgrad2_f32(x, cin, nullptr, 0, nullptr, grad_pre, grad_weights, grad_bias, batch, shape, cout, ksize, dilation,
                                  stream);
+}
+
+extern "C" int nrt_channel_sums_f32(const float *a, const float *b, long long rows, int channels, float *out, void *stream) {
+    if (!a || !out || rows < 0 || channels < 1 || channels > 4096) return NRT_ERR_INVALID_ARG;
+    if (rows == 0) return NRT_OK;
+    long long bx = (rows * channels + 256 * 32 - 1) / (256 * 32);
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(channel_sums, dim3((unsigned)bx), dim3(256), (size_t)channels * sizeof(float), nrt_stream(stream), a, b, rows,
+                       channels, out);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_channel_axpby_f32(const float *a, const float *b, const float *coef_a, const float *coef_b, const float *coef_c,
+                                     float *y, long long n, int channels, void *stream) {
+    if (!a || !b || !coef_a || !coef_b || !coef_c || !y || n < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (n == 0) return NRT_OK;
+    hipLaunchKernelGGL(channel_axpby, dim3(ew_blocks(n, 256)), dim3(256), 0, nrt_stream(stream), a, b, coef_a, coef_b, coef_c, y, n,
+                       channels);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
 }

@@ -135,12 +135,15 @@ class _Conv(nn.Module):
 
 
 class _BatchNorm(nn.Module):
-    """Keras BatchNormalization at inference: gamma, beta, moving_mean, moving_variance, epsilon = 1e-3."""
+    """Keras BatchNormalization (axis -1): gamma, beta, moving_mean, moving_variance, epsilon = 1e-3, momentum = 0.99.
+    Inference uses the moving statistics; in training mode (`_BatchNormFn`) the batch statistics, and the moving ones are
+    updated as moving * momentum + batch * (1 - momentum) with the biased batch variance."""
 
-    def __init__(self, name, channels, epsilon=1e-3):
+    def __init__(self, name, channels, epsilon=1e-3, momentum=0.99):
         super().__init__()
         self.layer_name = name
         self.epsilon = epsilon
+        self.momentum = momentum
         self.gamma = nn.Parameter(torch.ones(channels))
         self.beta = nn.Parameter(torch.zeros(channels))
         self.register_buffer('moving_mean', torch.zeros(channels))
@@ -454,6 +457,64 @@ class _AddActFn(torch.autograd.Function):
         return d, (d if ctx.has_b else None), None
 
 
+def _channel_sums(a, b=None):
+    lib = _lib.lib()
+    dev = a.device
+    C = a.shape[-1]
+    out = torch.zeros(C, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_channel_sums_f32(_lib.ptr(a), _lib.ptr(b), a.numel() // C, C, _lib.ptr(out), _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_channel_sums_f32')
+    return out
+
+
+class _BatchNormFn(torch.autograd.Function):
+    """training-mode BatchNormalization over all axes but the last; [C]-sized arithmetic is glue, volume passes are kernels"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod):
+        with torch.no_grad():
+            x = x.contiguous()
+            C = x.shape[-1]
+            n = x.numel() // C
+            mean = _channel_sums(x) / n
+            var = torch.clamp(_channel_sums(x, x) / n - mean * mean, min=0.0)
+            inv = torch.rsqrt(var + mod.epsilon)
+            scale = (gamma * inv).contiguous()
+            shift = (beta - mean * scale).contiguous()
+            y = _elementwise(x, scale=scale, shift=shift)
+            mod.moving_mean.mul_(mod.momentum).add_(mean * (1 - mod.momentum))
+            mod.moving_variance.mul_(mod.momentum).add_(var * (1 - mod.momentum))
+        ctx.save_for_backward(x, gamma, mean, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, inv = ctx.saved_tensors
+        lib = _lib.lib()
+        dev = g.device
+        g = g.contiguous()
+        C = x.shape[-1]
+        n = x.numel() // C
+        sg = _channel_sums(g)
+        sgx = _channel_sums(g, x)
+        sgxh = (sgx - mean * sg) * inv                         # sum g * xhat
+        dgamma, dbeta = sgxh, sg
+        dx = None
+        if ctx.needs_input_grad[0]:
+            scale = gamma * inv
+            m1, m2 = sg / n, sgxh / n
+            A = scale.contiguous()
+            B = (-scale * inv * m2).contiguous()
+            C0 = (-scale * m1 + scale * inv * m2 * mean).contiguous()
+            dx = torch.empty_like(x)
+            with torch.cuda.device(dev):
+                rc = lib.nrt_channel_axpby_f32(_lib.ptr(g), _lib.ptr(x), _lib.ptr(A), _lib.ptr(B), _lib.ptr(C0), _lib.ptr(dx),
+                                               x.numel(), C, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_channel_axpby_f32')
+        return dx, dgamma, dbeta, None
+
+
 class _SoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z):
@@ -661,6 +722,9 @@ class ConvNet(nn.Module):
                     t[name] = None
                 else:
                     t[name] = _MergeFn.apply(t[op['skip']], t[op['lo']], op['up'])
+            elif kind == 'bn':
+                m = self.layers_by_name[name]
+                t[name] = _BatchNormFn.apply(t[op['src']], m.gamma, m.beta, m)
             elif kind == 'add':
                 t[name] = _AddActFn.apply(t[op['a']], t[op['b']], 0)
             elif kind == 'activation':

@@ -51,12 +51,14 @@ def upsample(x, up):
     return x
 
 
-def forward(net, x, params=None, return_tensors=None, dropout_scales=None):
+def forward(net, x, params=None, return_tensors=None, dropout_scales=None, bn_train=False):
     """Run a neurite_amd.models.ConvNet graph (3-D nets) in float64 on the CPU.  params: {layer: (kernel, bias)} of
     float64 tensors (requires_grad as the caller likes); default: copies of the model's weights."""
     if params is None:
         params = {k: (m.kernel.detach().cpu().double(), m.bias.detach().cpu().double())
                   for k, m in net.layers_by_name.items() if hasattr(m, 'kernel')}
+        params.update({k: (m.gamma.detach().cpu().double(), m.beta.detach().cpu().double())
+                       for k, m in net.layers_by_name.items() if hasattr(m, 'gamma')})
     t = {}
     for op in net.ops:
         kind, name = op['kind'], op['name']
@@ -80,6 +82,16 @@ def forward(net, x, params=None, return_tensors=None, dropout_scales=None):
             t[name] = upsample(t[op['src']], op['up'])
         elif kind == 'merge':
             t[name] = torch.cat([t[op['skip']], upsample(t[op['lo']], op['up'])], -1)
+        elif kind == 'bn':
+            m = net.layers_by_name[name]
+            gamma, beta = params[name]
+            v = t[op['src']]
+            if bn_train:                                              # Keras training mode: biased batch statistics
+                mean = v.mean(dim=(0, 1, 2, 3))
+                var = v.var(dim=(0, 1, 2, 3), unbiased=False)
+            else:
+                mean, var = m.moving_mean.detach().cpu().double(), m.moving_variance.detach().cpu().double()
+            t[name] = (v - mean) / torch.sqrt(var + m.epsilon) * gamma + beta
         elif kind == 'add':
             t[name] = t[op['a']] + t[op['b']]
         elif kind == 'activation':

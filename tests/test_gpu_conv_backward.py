@@ -213,3 +213,41 @@ def test_unet_training_with_feature_dropout(dev):
     close(N(y), yo.detach().numpy(), 'forward with dropout', 1e-4)
     for k, m in net.layers_by_name.items():
         close(N(m.kernel.grad), params[k][0].grad.numpy(), k + ' kernel', 5e-4)
+
+
+def test_unet_training_with_batch_norm(dev):
+    """batch_norm=-1: training-mode BatchNormalization (batch statistics, moving averages updated) forward and gradients"""
+    rng = np.random.default_rng(47)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ne.models.unet(8, (8, 8, 8, 2), 2, 3, 3, batch_norm=-1, nb_conv_per_level=2).to(dev)
+    conv = {k: m for k, m in net.layers_by_name.items() if hasattr(m, 'kernel')}
+    bns = {k: m for k, m in net.layers_by_name.items() if hasattr(m, 'gamma')}
+    assert bns
+    for m in conv.values():
+        with torch.no_grad():
+            m.kernel.copy_(G((rng.standard_normal(tuple(m.kernel.shape)) * 0.3).astype(F), dev))
+            m.bias.copy_(G((rng.standard_normal(tuple(m.bias.shape)) * 0.2).astype(F), dev))
+    for m in bns.values():
+        with torch.no_grad():
+            m.gamma.copy_(G((1 + 0.2 * rng.standard_normal(tuple(m.gamma.shape))).astype(F), dev))
+            m.beta.copy_(G((0.2 * rng.standard_normal(tuple(m.beta.shape))).astype(F), dev))
+    x = rng.standard_normal((3, 8, 8, 8, 2)).astype(F)
+    net.train()
+    y = net(G(x, dev))
+    w = rng.standard_normal(tuple(y.shape)).astype(F)
+    (y * G(w, dev)).sum().backward()
+    params = {k: (m.kernel.detach().cpu().double().requires_grad_(), m.bias.detach().cpu().double().requires_grad_()) for k, m in conv.items()}
+    params.update({k: (m.gamma.detach().cpu().double().requires_grad_(), m.beta.detach().cpu().double().requires_grad_()) for k, m in bns.items()})
+    yo = tuo.forward(net, torch.from_numpy(x).double(), params, bn_train=True)
+    (yo * torch.from_numpy(w).double()).sum().backward()
+    close(N(y), yo.detach().numpy(), 'forward (batch statistics)', 2e-4)
+    for k, m in conv.items():
+        close(N(m.kernel.grad), params[k][0].grad.numpy(), k + ' kernel', 2e-3)
+    for k, m in bns.items():
+        close(N(m.gamma.grad), params[k][0].grad.numpy(), k + ' gamma', 2e-3)
+        close(N(m.beta.grad), params[k][1].grad.numpy(), k + ' beta', 2e-3)
+        assert float((m.moving_mean != 0).sum()) > 0 and float((m.moving_variance != 1).sum()) > 0      # moving statistics moved
+    net.eval()
+    y_eval = net(G(x, dev))
+    yo_eval = tuo.forward(net, torch.from_numpy(x).double())
+    close(N(y_eval), yo_eval.numpy(), 'eval uses the moving statistics', 2e-4)
