@@ -17,6 +17,7 @@ Inference only: Dropout is the identity, BatchNormalization uses its moving stat
 """
 
 import math
+import sys
 import warnings
 
 import numpy as np
@@ -1022,8 +1023,9 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
     model_name = name
     if prefix is None:
         prefix = model_name
-    if add_prior_layer:
-        raise NotImplementedError('add_prior_layer (models.add_prior, models.py:378) is outside the hot path')
+    if add_prior_layer and not use_logp:
+        raise NotImplementedError('add_prior_layer with use_logp=False (sigmoid likelihood x prior, models.py:408-414) is not '
+                                  'implemented; the log-prior form is')
     multi = isinstance(input_shape[0], (tuple, list, np.ndarray))
     if multi:                                                                    # :155-170
         shapes = [tuple(int(v) for v in s) for s in input_shape]
@@ -1067,9 +1069,25 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
     if isinstance(nb_features, list):
         enc_ncpl = [len(f) for f in nb_features]
     last = _decoder(bld, nb_features, nb_levels, conv_size, nb_labels, prefix, feat_mult, pool_size, 1, padding,
-                    dilation_rate_mult, activation, use_residuals, final_pred_activation, nb_conv_per_level, lnf,
-                    batch_norm, conv_dropout, last, enc_ncpl)
+                    dilation_rate_mult, activation, use_residuals, 'linear' if add_prior_layer else final_pred_activation,
+                    nb_conv_per_level, lnf, batch_norm, conv_dropout, last, enc_ncpl)
     _fix_residual_adds(bld)
+    if add_prior_layer:                                                          # models.add_prior, :378-436 (log-prior form)
+        pname = model_name + '_prior'
+        prior_shape = tuple(first[:-1]) + (int(nb_labels),)
+        sp = (1,) * (3 - ndims) + tuple(first[:-1])
+        print("Breaking change: use_logp option now requires log input!", file=sys.stderr)
+        prior = bld.add({'kind': 'input', 'name': '%s-input' % pname, 'index': len(shapes)}, (sp, int(nb_labels)))
+        post = bld.add({'kind': 'add', 'name': '%s_posterior' % pname, 'a': prior, 'b': last}, (sp, int(nb_labels)))
+        if final_pred_activation == 'softmax':
+            print("using final_pred_activation %s for %s" % (final_pred_activation, pname))
+            last = bld.add({'kind': 'prediction', 'name': '%s_prediction' % pname, 'src': post, 'activation': 'softmax'},
+                           (sp, int(nb_labels)))
+        else:
+            last = bld.add({'kind': 'prediction', 'name': '%s_prediction' % pname, 'src': post, 'activation': 'linear'},
+                           (sp, int(nb_labels)))
+        shapes = shapes + [prior_shape]
+        model_name = pname
     net = ConvNet(model_name, ndims, shapes, bld.ops, last, bld.modules)
     net._builder_state = dict(shapes=bld.shapes)
     return net

@@ -63,7 +63,7 @@ def forward(net, x, params=None, return_tensors=None, dropout_scales=None, bn_tr
     for op in net.ops:
         kind, name = op['kind'], op['name']
         if kind == 'input':
-            t[name] = x
+            t[name] = x[op['index']] if isinstance(x, (list, tuple)) else x
         elif kind == 'conv':
             src = t[op['src']]
             if op.get('lo'):

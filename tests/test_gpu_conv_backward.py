@@ -251,3 +251,36 @@ def test_unet_training_with_batch_norm(dev):
     y_eval = net(G(x, dev))
     yo_eval = tuo.forward(net, torch.from_numpy(x).double())
     close(N(y_eval), yo_eval.numpy(), 'eval uses the moving statistics', 2e-4)
+
+
+def test_unet_add_prior_layer(dev):
+    """unet(add_prior_layer=True) = models.add_prior (models.py:378-436, log-prior form): softmax(log prior + likelihood);
+    inference and training-mode gradients (incl. wrt the prior input) vs the oracle"""
+    rng = np.random.default_rng(53)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        net = ne.models.unet(8, (8, 8, 8, 1), 2, 3, 4, add_prior_layer=True).to(dev)
+    assert net.name == 'unet_prior' and net.input_shapes == [(8, 8, 8, 1), (8, 8, 8, 4)]
+    assert net.layer_names[-3:] == ['unet_prior-input', 'unet_prior_posterior', 'unet_prior_prediction']
+    for m in net.layers_by_name.values():
+        with torch.no_grad():
+            m.kernel.copy_(G((rng.standard_normal(tuple(m.kernel.shape)) * 0.3).astype(F), dev))
+    x = rng.standard_normal((2, 8, 8, 8, 1)).astype(F)
+    prior = np.log(rng.dirichlet(np.ones(4), (2, 8, 8, 8))).astype(F)
+    y = net([G(x, dev), G(prior, dev)])
+    yo = tuo.forward(net, [torch.from_numpy(x).double(), torch.from_numpy(prior).double()])
+    close(N(y), yo.numpy(), 'posterior', 1e-4)
+    np.testing.assert_allclose(N(y).sum(-1), 1.0, rtol=1e-5)
+    net.train()
+    pg = G(prior, dev, True)
+    yt = net([G(x, dev), pg])
+    w = rng.standard_normal(tuple(yt.shape)).astype(F)
+    (yt * G(w, dev)).sum().backward()
+    params = {k: (m.kernel.detach().cpu().double().requires_grad_(), m.bias.detach().cpu().double().requires_grad_())
+              for k, m in net.layers_by_name.items()}
+    po = torch.from_numpy(prior).double().requires_grad_()
+    (tuo.forward(net, [torch.from_numpy(x).double(), po], params) * torch.from_numpy(w).double()).sum().backward()
+    close(N(pg.grad), po.grad.numpy(), 'grad wrt the log prior', 2e-4)
+    for k, m in net.layers_by_name.items():
+        close(N(m.kernel.grad), params[k][0].grad.numpy(), k + ' kernel', 5e-4)
+    with pytest.raises(NotImplementedError):
+        ne.models.unet(8, (8, 8, 8, 1), 2, 3, 4, add_prior_layer=True, use_logp=False)
