@@ -474,6 +474,34 @@ __global__ __launch_bounds__(256) void conv3d_c1_mfma(ConvArgs a, const float *_
     }
 }
 
+// G = C/4 lanes per voxel: coalesced 16-byte loads / stores, channel max and sum by xor-shuffles inside the lane-group
+template <int G>
+__global__ __launch_bounds__(256) void softmax_lastdim_vec(const f32x4 *__restrict__ x, f32x4 *__restrict__ y, long long n) {
+    constexpr int NG = 256 / G;
+    const int lg = threadIdx.x % G;
+    const long long ngroups = (long long)gridDim.x * NG;
+    const long long niter = (n + ngroups - 1) / ngroups;
+    for (long long it = 0; it < niter; ++it) {
+        const long long vv = (long long)blockIdx.x * NG + threadIdx.x / G + it * ngroups;
+        const bool live = vv < n;
+        const long long v = live ? vv : n - 1;
+        const f32x4 xv = x[v * G + lg];
+        float m = fmaxf(fmaxf(xv[0], xv[1]), fmaxf(xv[2], xv[3]));
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        f32x4 e;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = expf(xv[k] - m);
+        float s = (e[0] + e[1]) + (e[2] + e[3]);
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) s += __shfl_xor(s, off, 64);
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] *= inv;
+        if (live) y[v * G + lg] = e;
+    }
+}
+
 __global__ __launch_bounds__(256) void softmax_lastdim(const float *__restrict__ x, float *__restrict__ y, long long n, int C) {
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
         const float *xp = x + q * C;
@@ -720,6 +748,22 @@ extern "C" int nrt_conv1x1_softmax_f32(const float *x, const float *weights, con
 extern "C" int nrt_softmax_lastdim_f32(const float *x, float *y, long long n, int channels, void *stream) {
     if (!x || !y || n < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
     if (n == 0) return NRT_OK;
+    const int G = channels / 4;
+    if (channels % 4 == 0 && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0)) {
+        const long long per = 256 / G;
+        unsigned vb = (unsigned)((n + per - 1) / per);
+        if (vb > 256u * 16u) vb = 256u * 16u;
+        hipStream_t st = nrt_stream(stream);
+        switch (G) {
+            case 1: hipLaunchKernelGGL((softmax_lastdim_vec<1>), dim3(vb), dim3(256), 0, st, (const f32x4 *)x, (f32x4 *)y, n); break;
+            case 2: hipLaunchKernelGGL((softmax_lastdim_vec<2>), dim3(vb), dim3(256), 0, st, (const f32x4 *)x, (f32x4 *)y, n); break;
+            case 4: hipLaunchKernelGGL((softmax_lastdim_vec<4>), dim3(vb), dim3(256), 0, st, (const f32x4 *)x, (f32x4 *)y, n); break;
+            case 8: hipLaunchKernelGGL((softmax_lastdim_vec<8>), dim3(vb), dim3(256), 0, st, (const f32x4 *)x, (f32x4 *)y, n); break;
+            default: hipLaunchKernelGGL((softmax_lastdim_vec<16>), dim3(vb), dim3(256), 0, st, (const f32x4 *)x, (f32x4 *)y, n); break;
+        }
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     hipLaunchKernelGGL(softmax_lastdim, dim3(blocks), dim3(256), 0, nrt_stream(stream), x, y, n, channels);
