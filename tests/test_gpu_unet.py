@@ -196,7 +196,7 @@ def test_unet_layer_names_and_errors(dev):
     with pytest.raises(AssertionError, match='list of lists'):
         ne.models.unet([4, 8], (8, 8, 8, 1), None, 3, 2, feat_mult=None)
     with pytest.raises(NotImplementedError):
-        ne.models.unet(4, (8, 8, 8, 1), 2, 3, 2, add_prior_layer=True)
+        ne.models.unet(4, (8, 8, 8, 1), 2, 3, 2, add_prior_layer=True, use_logp=False)
     # multi-input and intermediate tensors
     mi = ne.models.unet(4, [(8, 8, 8, 1), (8, 8, 8, 2)], 2, 3, 2).to(dev)
     out = mi([torch.randn(1, 8, 8, 8, 1, device=dev), torch.randn(1, 8, 8, 8, 2, device=dev)],
