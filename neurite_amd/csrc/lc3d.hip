@@ -254,8 +254,10 @@ __device__ __forceinline__ float lc_dpre(float g, float y, int act) {
     return g;
 }
 
-template <typename T, int MAXIT>
-__global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba) {
+// NB batch entries per pass (the first pass writes dK, later passes add to it: a lane owns its 16-byte slices exclusively);
+// HAS_DX: also stream the weights and scatter the input gradient.  Buffer addressing as in the forward kernel.
+template <typename T, int MAXIT, int NB, bool HAS_DX>
+__global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb) {
     const LcArgs &a = ba.f;
     constexpr int VEC = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
@@ -267,14 +269,14 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba) {
     const int sl = lane % LPR, row0 = lane / LPR;
     const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
     const T *xb = (const T *)a.x;
-    int xoff[MAXIT];
+    unsigned xvoff[MAXIT];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int f = it * RPW + row0;
         const int ff = ((it < nit) && (f < F)) ? f : F - 1;
         const int ci = ff % a.Cin, tap = ff / a.Cin;
         const int dz = tap % a.kz, dc = (tap / a.kz) % a.kc, dr = tap / (a.kz * a.kc);
-        xoff[it] = ((dr * a.C + dc) * a.Z + dz) * a.Cin + ci;
+        xvoff[it] = (unsigned)((((dr * a.C + dc) * a.Z + dz) * a.Cin + ci) * (int)sizeof(T));
     }
     const unsigned w0 = (unsigned)lane * 16u;
     const unsigned wbytes = (unsigned)F * (unsigned)a.Cout * (unsigned)sizeof(T);
@@ -282,72 +284,105 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (long long o = (long long)blockIdx.x * (blockDim.x >> 6) + wave; o < O; o += nwaves) {
         const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
-        const long long xbase = (((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin;
-        const char *kp = (const char *)((const T *)a.k + o * (long long)F * a.Cout);
-        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)kp, 0, (int)wbytes, 0x00020000);
-        vec_t w[MAXIT];
-        if (ba.dx) {
+        const long long xbase_e = (((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin;
+        const unsigned xbase = (unsigned)(xbase_e * (long long)sizeof(T));
+        // ---- issue the loads: patch elements of the NB batch entries, the weight slices if dx is wanted ----------------
+        T xr[NB][MAXIT];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) xr[b][it] = buf_load_elem<T>(xres, xvoff[it], xbase);
+        }
+        vec_t w[HAS_DX ? MAXIT : 1];
+        if (HAS_DX) {
+            const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)((const char *)a.k + o * (long long)wbytes), 0, (int)wbytes, 0x00020000);
 #pragma unroll
             for (int it = 0; it < MAXIT; ++it)
-                w[it] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(wr, w0, it * 1024, 2));
+                w[HAS_DX ? it : 0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(wr, w0, it * 1024, 2));
         }
-        float dk[MAXIT][VEC];
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) dk[it][e] = 0.0f;
-        float db[VEC];
+        // ---- this lane's cout slice of dpre[b][o] -------------------------------------------------------------------------
+        float dp[NB][VEC], db[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) db[e] = 0.0f;
-        for (int b = 0; b < a.B; ++b) {
-            // this lane's cout slice of dpre[b][o]
-            const long long go = ((long long)b * O + o) * a.Cout + sl * VEC;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const long long go = ((long long)(b0 + (b < nb ? b : 0)) * O + o) * a.Cout + sl * VEC;
             const vec_t gv = *(const vec_t *)((const T *)ba.g + go);
-            float dp[VEC];
             if (a.act != 0) {
                 const vec_t yv = *(const vec_t *)((const T *)a.y + go);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) dp[e] = lc_dpre<T>(to_f32(gv[e]), to_f32(yv[e]), a.act);
+                for (int e = 0; e < VEC; ++e) dp[b][e] = b < nb ? lc_dpre<T>(to_f32(gv[e]), to_f32(yv[e]), a.act) : 0.0f;
             } else {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) dp[e] = to_f32(gv[e]);
+                for (int e = 0; e < VEC; ++e) dp[b][e] = b < nb ? to_f32(gv[e]) : 0.0f;
             }
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) db[e] += dp[e];
-            const T *xp = xb + (long long)b * xbs + xbase;
+            for (int e = 0; e < VEC; ++e) db[e] += dp[b][e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        char *dkp = ba.dk ? (char *)ba.dk + o * (long long)wbytes : nullptr;
 #pragma unroll
-            for (int it = 0; it < MAXIT; ++it) {
-                const bool live = (it < nit) && (it * RPW + row0 < F);
-                if (ba.dk) {
-                    const float xv = live ? to_f32(xp[xoff[it]]) : 0.0f;
+        for (int it = 0; it < MAXIT; ++it) {
+            const bool live = (it < nit) && (it * RPW + row0 < F);
+            const unsigned off = w0 + (unsigned)it * 1024u;
+            if (dkp && off < wbytes) {
+                float acc[VEC];
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) dk[it][e] = fmaf(xv, dp[e], dk[it][e]);
+                for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const float xv = live ? to_f32(xr[b][it]) : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] = fmaf(xv, dp[b][e], acc[e]);
                 }
-                if (ba.dx) {
+                vec_t *dst = (vec_t *)(dkp + off);
+                if (b0 > 0) {                                   // later batch chunk: add to what the first chunk wrote
+                    const vec_t old = *dst;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[e] += to_f32(old[e]);
+                }
+                vec_t ov;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { T tmp; store_out(&tmp, acc[e]); ov[e] = tmp; }
+                __builtin_nontemporal_store(ov, dst);
+            }
+            if (HAS_DX) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
                     float t = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) t = fmaf(to_f32(w[it][e]), dp[e], t);
-                    for (int off = 1; off < LPR; off <<= 1) t += __shfl_xor(t, off, 64);     // over the cout slices of row f
-                    if (live && sl == 0) unsafeAtomicAdd(ba.dx + (long long)b * xbs + xbase + xoff[it], t);
-                }
-            }
-        }
-        if (ba.dk) {
-#pragma unroll
-            for (int it = 0; it < MAXIT; ++it) {
-                const unsigned off = w0 + (unsigned)it * 1024u;
-                if (off < wbytes) {
-                    vec_t ov;
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) { T tmp; store_out(&tmp, dk[it][e]); ov[e] = tmp; }
-                    __builtin_nontemporal_store(ov, (vec_t *)((char *)ba.dk + o * (long long)wbytes + off));
+                    for (int e = 0; e < VEC; ++e) t = fmaf(to_f32(w[HAS_DX ? it : 0][e]), dp[b][e], t);
+                    for (int off2 = 1; off2 < LPR; off2 <<= 1) t += __shfl_xor(t, off2, 64);      // over the cout slices of row f
+                    if (live && sl == 0 && b < nb)
+                        unsafeAtomicAdd(ba.dx + (long long)(b0 + b) * xbs + xbase_e + (long long)(xvoff[it] / (unsigned)sizeof(T)), t);
                 }
             }
         }
         if (ba.dbias && lane < LPR) {
+            T *dbp = (T *)ba.dbias + o * a.Cout + sl * VEC;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) store_out((T *)ba.dbias + o * a.Cout + sl * VEC + e, db[e]);
+            for (int e = 0; e < VEC; ++e) {
+                float v = db[e];
+                if (b0 > 0) v += to_f32(dbp[e]);
+                store_out(dbp + e, v);
+            }
         }
+    }
+}
+
+template <typename T, int MAXIT>
+void launch_bwd_it(const LcBwdArgs &ba, unsigned blocks, hipStream_t st) {
+    const int B = ba.f.B;
+    for (int b0 = 0; b0 < B; b0 += 4) {
+        const int nb = B - b0 < 4 ? B - b0 : 4;
+#define NRT_LCB(NBV)                                                                                               \
+        if (ba.dx) hipLaunchKernelGGL((lc3d_bwd<T, MAXIT, NBV, true>), dim3(blocks), dim3(256), 0, st, ba, b0, nb); \
+        else hipLaunchKernelGGL((lc3d_bwd<T, MAXIT, NBV, false>), dim3(blocks), dim3(256), 0, st, ba, b0, nb)
+        if (nb == 1) { NRT_LCB(1); } else if (nb == 2) { NRT_LCB(2); } else { NRT_LCB(4); }
+#undef NRT_LCB
     }
 }
 
@@ -364,11 +399,12 @@ int launch_bwd(const LcBwdArgs &ba, hipStream_t st) {
     if ((((uintptr_t)a.k | (uintptr_t)ba.g | (uintptr_t)a.y | (uintptr_t)ba.dk) & 15) != 0) return NRT_ERR_UNSUPPORTED;
     const long long O = (long long)a.orr * a.occ * a.ozz;
     unsigned blocks = (unsigned)((O + 3) / 4);
-    if (blocks > 256u * 8u) blocks = 256u * 8u;
-    if (nit <= 8) hipLaunchKernelGGL((lc3d_bwd<T, 8>), dim3(blocks), dim3(256), 0, st, ba);
-    else if (nit <= 14) hipLaunchKernelGGL((lc3d_bwd<T, 14>), dim3(blocks), dim3(256), 0, st, ba);
-    else if (nit <= 16) hipLaunchKernelGGL((lc3d_bwd<T, 16>), dim3(blocks), dim3(256), 0, st, ba);
-    else hipLaunchKernelGGL((lc3d_bwd<T, 32>), dim3(blocks), dim3(256), 0, st, ba);
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    if ((long long)a.R * a.C * a.Z * a.Cin * (long long)sizeof(T) >= (1ll << 31)) return NRT_ERR_UNSUPPORTED;       // 32-bit buffer offsets
+    if (nit <= 8) launch_bwd_it<T, 8>(ba, blocks, st);
+    else if (nit <= 14) launch_bwd_it<T, 14>(ba, blocks, st);
+    else if (nit <= 16) launch_bwd_it<T, 16>(ba, blocks, st);
+    else launch_bwd_it<T, 32>(ba, blocks, st);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
