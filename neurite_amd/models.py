@@ -16,6 +16,9 @@ with the channel softmax.  1-D / 2-D nets are lifted to 3-D with unit leading di
 Inference only: Dropout is the identity, BatchNormalization uses its moving statistics.
 """
 
+import functools
+import inspect
+import json
 import math
 import sys
 import warnings
@@ -27,7 +30,7 @@ from torch import nn
 from . import _lib
 from . import utils
 
-__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image']
+__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'load', 'load_config']
 
 _ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}
 
@@ -59,6 +62,64 @@ def _unlift(x, ndims):
     for _ in range(3 - ndims):
         x = x.squeeze(1)
     return x
+
+
+def _jsonable(v):
+    if isinstance(v, np.ndarray):
+        return v.tolist()
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.floating,)):
+        return float(v)
+    if isinstance(v, tuple):
+        return [_jsonable(x) for x in v]
+    if isinstance(v, list):
+        return [_jsonable(x) for x in v]
+    return v
+
+
+def _store_config(func):
+    """
+    The builders' counterpart of modelio.store_config_args (neurite/tf/modelio.py:8-45): every argument the network was
+    built with (defaults, positionals, keywords) is kept on the returned model as `model.config`, so that
+    `model.save(path)` / `models.load(path)` rebuild the same architecture without the caller restating it
+    (LoadableModel, modelio.py:78-143).  Graph-valued arguments (input_model, convL, src ...) are not recorded.
+    """
+    sig = inspect.signature(func)
+
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+        net = func(*args, **kwargs)
+        bound = sig.bind(*args, **kwargs)
+        bound.apply_defaults()
+        params = {}
+        loadable = True
+        for k, v in bound.arguments.items():
+            if k in ('convL', 'src', 'src_input', 'input_model'):
+                loadable = loadable and v is None
+                continue
+            params[k] = _jsonable(v)
+        params['metadata'] = {}
+        net.config = {'builder': func.__name__, 'params': params, 'loadable': loadable}
+        return net
+    return wrapper
+
+
+def _h5py():
+    try:
+        import h5py
+    except ImportError as e:                # noqa
+        raise ImportError('reading / writing Keras HDF5 files needs h5py, which is not installed; export the weights with '
+                          'np.savez(path, *model.get_weights()) on the TensorFlow side or use the .npz format') from e
+    return h5py
+
+
+def _is_h5(path):
+    return str(path).lower().endswith(('.h5', '.hdf5', '.keras.h5'))
+
+
+def _h5_str(v):
+    return v.decode('utf-8') if isinstance(v, bytes) else str(v)
 
 
 class _Conv(nn.Module):
@@ -599,13 +660,117 @@ class ConvNet(nn.Module):
                                      % (tuple(t.shape), tuple(w.shape), name))
                 t.copy_(torch.from_numpy(w))
 
-    def save_weights(self, path):
-        """np.savez archive keyed by `layer/variable` (h5py is not a dependency of this package)."""
-        np.savez(path, **{name: a for (name, _, _), a in zip(self._weight_tensors(), self.get_weights())})
+    def _weights_by_layer(self):
+        """[(layer name, [(variable name, tensor, conv ndims or None), ...])] in Keras layer order"""
+        groups = []
+        for name, t, nd in self._weight_tensors():
+            layer, var = name.rsplit('/', 1)
+            if not groups or groups[-1][0] != layer:
+                groups.append((layer, []))
+            groups[-1][1].append((var, t, nd))
+        return groups
 
-    def load_weights(self, path):
-        with np.load(path) as z:
-            self.set_weights([z[name] for name, _, _ in self._weight_tensors()])
+    def save_weights(self, path):
+        """
+        `.npz` (default; np.savez archive keyed by `layer/variable`) or, for a path ending in .h5 / .hdf5 and with h5py
+        installed, the Keras `save_weights` HDF5 layout (root attrs `layer_names`; per layer a group with attr `weight_names`
+        and one dataset per variable, `layer/kernel:0` ...) so that the file loads into the Keras-built neurite unet.
+        """
+        if _is_h5(path):
+            h5py = _h5py()
+            with h5py.File(path, 'w') as f:
+                self._write_h5_weights(f)
+            return
+        np.savez(path, **self._npz_dict())
+
+    def _npz_dict(self):
+        return {name: a for (name, _, _), a in zip(self._weight_tensors(), self.get_weights())}
+
+    def _write_h5_weights(self, f):
+        arrays = dict(zip([n for n, _, _ in self._weight_tensors()], self.get_weights()))
+        groups = self._weights_by_layer()
+        f.attrs['layer_names'] = [l.encode('utf8') for l, _ in groups]
+        f.attrs['backend'] = b'neurite_amd'
+        for layer, vs in groups:
+            g = f.create_group(layer)
+            names = ['%s/%s:0' % (layer, var) for var, _, _ in vs]
+            g.attrs['weight_names'] = [n.encode('utf8') for n in names]
+            for n, (var, _, _) in zip(names, vs):
+                g.create_dataset(n, data=arrays[layer + '/' + var])
+
+    def _read_h5_weights(self, f, by_name):
+        """Keras HDF5 weights (the file itself for `save_weights`, its `model_weights` group for `model.save`):
+        layers are matched by name when every layer of this model is present (or by_name), else in order, as Keras does."""
+        if 'layer_names' not in f.attrs and 'model_weights' in f:
+            f = f['model_weights']
+        stored = [_h5_str(n) for n in f.attrs['layer_names']]
+        with_w = [n for n in stored if len(f[n].attrs['weight_names'])]
+        groups = self._weights_by_layer()
+        mine = [l for l, _ in groups]
+        if by_name:
+            pairs = [(g, g[0]) for g in groups if g[0] in with_w]
+        elif all(l in with_w for l in mine):
+            pairs = [(g, g[0]) for g in groups]
+        else:
+            if len(with_w) != len(mine):
+                raise ValueError('You are trying to load a weight file containing %d layers into a model with %d layers.'
+                                 % (len(with_w), len(mine)))
+            pairs = list(zip(groups, with_w))
+        out = {}
+        for (layer, vs), src in pairs:
+            g = f[src]
+            wn = [_h5_str(n) for n in g.attrs['weight_names']]
+            if len(wn) != len(vs):
+                raise ValueError('Layer %s expects %d weights, the file holds %d for %s' % (layer, len(vs), len(wn), src))
+            for (var, _, _), n in zip(vs, wn):
+                out[layer + '/' + var] = np.asarray(g[n])
+        return out
+
+    def load_weights(self, path, by_name=False):
+        """counterpart of `save_weights`; also reads HDF5 files written by Keras (`model.save_weights` / `model.save`) when
+        h5py is installed.  by_name=True loads only the layers found in the file (Keras semantics)."""
+        if _is_h5(path):
+            h5py = _h5py()
+            with h5py.File(path, 'r') as f:
+                found = self._read_h5_weights(f, by_name)
+        else:
+            with np.load(path) as z:
+                found = {name: z[name] for name, _, _ in self._weight_tensors() if name in z.files}
+        slots = self._weight_tensors()
+        if not by_name:
+            missing = [n for n, _, _ in slots if n not in found]
+            if missing:
+                raise ValueError('weight file %s has no entry for %s' % (path, missing))
+            self.set_weights([found[n] for n, _, _ in slots])
+            return
+        current = dict(zip([n for n, _, _ in slots], self.get_weights()))
+        current.update(found)
+        self.set_weights([current[n] for n, _, _ in slots])
+
+    # ---- LoadableModel (neurite/tf/modelio.py:78-143): architecture arguments travel with the weights ----
+    def get_config(self):
+        if not hasattr(self, 'config'):
+            raise RuntimeError('this network was not built through unet / conv_enc / conv_dec, so it has no stored config')
+        return self.config['params']
+
+    @property
+    def metadata(self):
+        return self.get_config()['metadata']
+
+    def save(self, path):
+        """weights + the builder arguments (`model_config`), reloadable with `neurite_amd.models.load(path)`"""
+        cfg = json.dumps({'class_name': self.config['builder'] if hasattr(self, 'config') else None,
+                          'config': self.get_config()})
+        if hasattr(self, 'config') and not self.config['loadable']:
+            raise RuntimeError('networks assembled from an input_model are saved part by part (save the encoder and the '
+                               'decoder arguments), as their config cannot name the graph they were grafted on')
+        if _is_h5(path):
+            h5py = _h5py()
+            with h5py.File(path, 'w') as f:
+                f.attrs['model_config'] = cfg
+                self._write_h5_weights(f.create_group('model_weights'))
+            return
+        np.savez(path, __model_config__=np.array(cfg), **self._npz_dict())
 
     def get_layer(self, name):
         if name in self.layers_by_name:
@@ -943,6 +1108,7 @@ def _fix_residual_adds(bld):
             raise RuntimeError('degenerate residual add in ' + op['name'])
 
 
+@_store_config
 def conv_enc(nb_features, input_shape, nb_levels, conv_size, name=None, prefix=None, feat_mult=1, pool_size=2,
              dilation_rate_mult=1, padding='same', activation='elu', layer_nb_feats=None, use_residuals=False,
              nb_conv_per_level=2, conv_dropout=0, batch_norm=None, convL=None, src=None, src_input=None):
@@ -973,6 +1139,7 @@ def conv_enc(nb_features, input_shape, nb_levels, conv_size, name=None, prefix=N
 conv_block = conv_enc
 
 
+@_store_config
 def conv_dec(nb_features, input_shape, nb_levels, conv_size, nb_labels, name=None, prefix=None, feat_mult=1,
              pool_size=2, use_skip_connections=False, padding='same', dilation_rate_mult=1, activation='elu',
              use_residuals=False, final_pred_activation='softmax', nb_conv_per_level=2, layer_nb_feats=None,
@@ -1015,6 +1182,7 @@ def conv_dec(nb_features, input_shape, nb_levels, conv_size, nb_labels, name=Non
     return net
 
 
+@_store_config
 def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None, feat_mult=1,
          pool_size=2, use_logp=True, padding='same', dilation_rate_mult=1, activation='elu', use_residuals=False,
          final_pred_activation='softmax', nb_conv_per_level=1, add_prior_layer=False, add_prior_layer_reg=0,
@@ -1091,6 +1259,38 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
     net = ConvNet(model_name, ndims, shapes, bld.ops, last, bld.modules)
     net._builder_state = dict(shapes=bld.shapes)
     return net
+
+
+def load_config(path):
+    """builder name and arguments stored by `ConvNet.save` (LoadableModel.load_config, neurite/tf/modelio.py:125-143)"""
+    if _is_h5(path):
+        h5py = _h5py()
+        with h5py.File(path, 'r') as f:
+            cfg = f.attrs['model_config']
+    else:
+        with np.load(path) as z:
+            if '__model_config__' not in z.files:
+                raise ValueError('%s holds weights only (written by save_weights); build the model and call load_weights' % path)
+            cfg = z['__model_config__'].item()
+    cfg = json.loads(_h5_str(cfg))
+    return cfg['class_name'], cfg['config']
+
+
+def load(path, by_name=False, **kwargs):
+    """
+    LoadableModel.load (neurite/tf/modelio.py:111-123): rebuild the network from the arguments saved with it (keyword
+    arguments override them), then load its weights.
+    """
+    builder, config = load_config(path)
+    builders = {'unet': unet, 'conv_enc': conv_enc, 'conv_dec': conv_dec}
+    if builder not in builders:
+        raise ValueError('%s was not saved from a unet / conv_enc / conv_dec network (class_name %r)' % (path, builder))
+    config.update(kwargs)
+    metadata = config.pop('metadata', {})
+    model = builders[builder](**config)
+    model.metadata.update(metadata)
+    model.load_weights(path, by_name=by_name)
+    return model
 
 
 def labels_to_image(*args, **kwargs):

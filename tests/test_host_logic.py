@@ -238,6 +238,130 @@ def test_convnet_weight_api_cpu(tmp_path):
         net.set_weights([new[1]] + new[1:])
 
 
+class _FakeH5Node(dict):
+    """dict-backed stand-in for h5py.File / Group (h5py is absent from this image): attrs, create_group, create_dataset,
+    item access by (possibly nested) name, `in`"""
+
+    def __init__(self):
+        super().__init__()
+        self.attrs = {}
+
+    def create_group(self, name):
+        g = _FakeH5Node()
+        dict.__setitem__(self, name, g)
+        return g
+
+    def create_dataset(self, name, data):
+        dict.__setitem__(self, name, np.array(data))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _fake_h5py(store):
+    import types
+    mod = types.ModuleType('h5py')
+
+    def File(path, mode='r'):
+        if mode == 'w':
+            store[path] = _FakeH5Node()
+        return store[path]
+    mod.File = File
+    return mod
+
+
+def test_loadable_model_cpu(tmp_path, monkeypatch):
+    """LoadableModel behaviour (neurite/tf/modelio.py:78-143): the builder arguments travel with the weights; Keras HDF5
+    layouts (save_weights and model.save) read back by layer name, in order, and by_name"""
+    import contextlib, io, sys
+    import neurite_amd as ne
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ne.models.unet(4, (12, 12, 12, 2), 2, 3, 5, name='seg', feat_mult=2, nb_conv_per_level=2, batch_norm=-1)
+    cfg = net.get_config()
+    assert cfg['nb_features'] == 4 and cfg['input_shape'] == [12, 12, 12, 2] and cfg['feat_mult'] == 2
+    assert cfg['activation'] == 'elu' and cfg['metadata'] == {}                  # defaults recorded too
+    net.metadata['trained_on'] = 'synthetic'
+    rng = np.random.default_rng(1)
+    new = [rng.standard_normal(a.shape).astype(np.float32) for a in net.get_weights()]
+    net.set_weights(new)
+    p = str(tmp_path / 'model.npz')
+    net.save(p)
+    assert ne.models.load_config(p)[0] == 'unet'
+    with contextlib.redirect_stdout(io.StringIO()):
+        back = ne.models.load(p)
+    assert back.layer_names == net.layer_names and back.metadata == {'trained_on': 'synthetic'}
+    assert all(np.array_equal(a, b) for a, b in zip(back.get_weights(), new))
+    with contextlib.redirect_stdout(io.StringIO()), pytest.raises(ValueError):
+        ne.models.load(p, nb_labels=7)                                           # override changes the head -> shape mismatch
+    wp = str(tmp_path / 'w.npz')
+    net.save_weights(wp)
+    with pytest.raises(ValueError, match='weights only'):
+        ne.models.load_config(wp)
+    with pytest.raises(ImportError, match='h5py'):
+        net.save_weights(str(tmp_path / 'w.h5'))
+    # an encoder grafted into a decoder has no self-contained config
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc = ne.models.conv_enc(4, (8, 8, 1), 2, 3, name='e')
+        dec = ne.models.conv_dec(4, None, 2, 3, 2, name='d', prefix='e', input_model=enc, use_skip_connections=True)
+    assert enc.get_config()['nb_levels'] == 2
+    with pytest.raises(RuntimeError, match='part by part'):
+        dec.save(str(tmp_path / 'dec.npz'))
+
+    store = {}
+    monkeypatch.setitem(sys.modules, 'h5py', _fake_h5py(store))
+    net.save_weights('w.h5')
+    f = store['w.h5']
+    names = [n.decode() for n in f.attrs['layer_names']]
+    assert names[0] == 'seg_conv_downarm_0_0' and f[names[0]].attrs['weight_names'][0] == b'seg_conv_downarm_0_0/kernel:0'
+    assert f[names[0]]['seg_conv_downarm_0_0/kernel:0'].shape == (3, 3, 3, 2, 4)  # Keras layout
+    with contextlib.redirect_stdout(io.StringIO()):
+        other = ne.models.unet(4, (12, 12, 12, 2), 2, 3, 5, name='seg', feat_mult=2, nb_conv_per_level=2, batch_norm=-1)
+    other.load_weights('w.h5')
+    assert all(np.array_equal(a, b) for a, b in zip(other.get_weights(), new))
+    # a Keras file also lists weight-less layers (inputs, pooling ...) and may use other layer names: order-based load
+    k = _FakeH5Node()
+    knames = []
+    for i, n in enumerate(names):
+        for extra in ('in%d' % i,):
+            k.create_group(extra).attrs['weight_names'] = []
+            knames.append(extra)
+        g = k.create_group('L%d' % i)
+        wn = [w.decode().replace(n, 'L%d' % i) for w in f[n].attrs['weight_names']]
+        g.attrs['weight_names'] = [w.encode() for w in wn]
+        for w_old, w_new in zip(f[n].attrs['weight_names'], wn):
+            g.create_dataset(w_new, f[n][w_old.decode()])
+        knames.append('L%d' % i)
+    full = _FakeH5Node()
+    dict.__setitem__(full, 'model_weights', k)
+    k.attrs['layer_names'] = [n.encode() for n in knames]
+    store['keras_model.h5'] = full
+    with contextlib.redirect_stdout(io.StringIO()):
+        third = ne.models.unet(4, (12, 12, 12, 2), 2, 3, 5, name='seg', feat_mult=2, nb_conv_per_level=2, batch_norm=-1)
+    third.load_weights('keras_model.h5')
+    assert all(np.array_equal(a, b) for a, b in zip(third.get_weights(), new))
+    # by_name: only layers present in the file change
+    part = _FakeH5Node()
+    part.attrs['layer_names'] = [names[0].encode()]
+    dict.__setitem__(part, names[0], f[names[0]])
+    store['part.h5'] = part
+    with contextlib.redirect_stdout(io.StringIO()):
+        fourth = ne.models.unet(4, (12, 12, 12, 2), 2, 3, 5, name='seg', feat_mult=2, nb_conv_per_level=2, batch_norm=-1)
+    before = fourth.get_weights()
+    fourth.load_weights('part.h5', by_name=True)
+    after = fourth.get_weights()
+    assert np.array_equal(after[0], new[0]) and np.array_equal(after[1], new[1])
+    assert all(np.array_equal(a, b) for a, b in zip(after[2:], before[2:]))
+    with pytest.raises(ValueError):
+        fourth.load_weights('part.h5')
+    net.save('m.h5')
+    with contextlib.redirect_stdout(io.StringIO()):
+        fifth = ne.models.load('m.h5')
+    assert all(np.array_equal(a, b) for a, b in zip(fifth.get_weights(), new))
+
+
 def test_gaussian_kernel_and_synthesis_tables_cpu():
     """host-side pieces of the synthesis front-end: Gaussian kernels vs the reference's own output, label lookup tables"""
     import warnings
