@@ -183,7 +183,9 @@ int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *lab
  * (:1601-1605) and the residual add / activation / BatchNormalization (:1401-1433).
  * All tensors channels-last float32 [batch, X, Y, Z, C]; `shape`, `ksize`, `pool`, `up` are host int[3].
  * ------------------------------------------------------------------------------------------ */
-typedef enum { NRT_ACT_NONE = 0, NRT_ACT_ELU = 1, NRT_ACT_RELU = 2 } nrt_activation;
+typedef enum { NRT_ACT_NONE = 0, NRT_ACT_ELU = 1, NRT_ACT_RELU = 2, NRT_ACT_SIGMOID = 3 } nrt_activation;
+/* nrt_add_act_affine_f32 only: or-ed into `activation`, y = act(a) * b instead of act(a + b) (models.add_prior, use_logp=False) */
+#define NRT_ACT_MUL_B 0x100
 
 /* Weights re-ordered for the MFMA kernel ("packed"): query the size, pack once per layer. */
 size_t nrt_conv3d_packed_weight_floats(const int *ksize, int cin, int cout);

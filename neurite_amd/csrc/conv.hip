@@ -27,12 +27,18 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_MUL_B = 0x100 };
 
 __device__ __forceinline__ float activate(float v, int act) {
     if (act == ACT_ELU) return v > 0.0f ? v : (expf(v) - 1.0f);      // Keras elu, alpha = 1
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
     return v;
+}
+
+// stand-alone Activation layers also know the sigmoid (models.py:409-411); the conv epilogues do not need it
+__device__ __forceinline__ float activate_ew(float v, int act) {
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return activate(v, act);
 }
 
 struct ConvArgs {
@@ -559,14 +565,19 @@ __global__ __launch_bounds__(256) void upsample_concat(const float *__restrict__
     }
 }
 
-// y = act(a + b) [+ per-channel affine]: residual merges (models.py:1423-1429) and inference BatchNorm
+// y = act(a + b) [+ per-channel affine]: residual merges (models.py:1423-1429) and inference BatchNorm;
+// with ACT_MUL_B in the activation word y = act(a) * b: the likelihood x prior merge of models.add_prior (models.py:408-414)
 __global__ __launch_bounds__(256) void add_act_affine(const float *__restrict__ a, const float *__restrict__ bsrc,
                                                       const float *__restrict__ scale, const float *__restrict__ shift,
                                                       float *__restrict__ y, long long n, int C, int act) {
+    const bool mul = (act & ACT_MUL_B) != 0;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
         float v = a[e];
-        if (bsrc) v += bsrc[e];
-        v = activate(v, act);
+        if (mul) v = activate_ew(v, act & 0xff) * bsrc[e];
+        else {
+            if (bsrc) v += bsrc[e];
+            v = activate_ew(v, act);
+        }
         if (scale) v = v * scale[e % C] + shift[e % C];
         y[e] = v;
     }
@@ -805,6 +816,8 @@ extern "C" int nrt_add_act_affine_f32(const float *a, const float *b, const floa
                                       long long n, int channels, int activation, void *stream) {
     if (!a || !y || n < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
     if ((scale == nullptr) != (shift == nullptr)) return NRT_ERR_INVALID_ARG;
+    if ((activation & 0xff) > ACT_SIGMOID || (activation & ~(0xff | ACT_MUL_B)) || activation < 0) return NRT_ERR_INVALID_ARG;
+    if ((activation & ACT_MUL_B) && !b) return NRT_ERR_INVALID_ARG;
     if (n == 0) return NRT_OK;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 256u * 32u) blocks = 256u * 32u;

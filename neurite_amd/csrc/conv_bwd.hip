@@ -1,7 +1,7 @@
 // Backward kernels of the unet layer set (conv3d dgrad / wgrad and the small Keras layers), gfx950.
 //
 // Keras Conv3D (neurite/tf/models.py:1345-1347, 1506-1508), stride 1, SAME padding, y = act(conv(x, W) + b):
-//   dpre = g * act'(y)                         nrt_act_bwd_f32   (ELU: y > 0 ? 1 : y + 1; ReLU: y > 0)
+//   dpre = g * act'(y)                         nrt_act_bwd_f32   (ELU: y > 0 ? 1 : y + 1; ReLU: y > 0; sigmoid: y (1 - y))
 //   dX   = conv(dpre, flip(W)^T)               the forward MFMA kernel with transformed weights (host side)
 //   dW[t][ci][co] = sum_v x[v + off(t)][ci] * dpre[v][co],  db[co] = sum_v dpre[v][co]       nrt_conv3d_wgrad_f32
 // MaxPooling3D (:1438), UpSampling3D (:1531, nearest) and the channel softmax (:1604) have the elementwise backward
@@ -21,7 +21,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_bwd(const nrt_f4 *__restrict__ g, const nrt_f4 *__restrict__ y, int act,
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void act_bwd(const nrt_f4 *__restrict__ g, con
             float s = 1.0f;
             if (act == ACT_ELU) s = yv[k] > 0.0f ? 1.0f : yv[k] + 1.0f;
             else if (act == ACT_RELU) s = yv[k] > 0.0f ? 1.0f : 0.0f;
+            else if (act == ACT_SIGMOID) s = yv[k] * (1.0f - yv[k]);
             o[k] = gv[k] * s;
         }
         d[i] = o;
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void act_bwd_tail(const float *__restrict__ g,
         float s = 1.0f;
         if (act == ACT_ELU) s = y[i] > 0.0f ? 1.0f : y[i] + 1.0f;
         else if (act == ACT_RELU) s = y[i] > 0.0f ? 1.0f : 0.0f;
+        else if (act == ACT_SIGMOID) s = y[i] * (1.0f - y[i]);
         d[i] = g[i] * s;
     }
 }
@@ -379,7 +381,7 @@ unsigned ew_blocks(long long n, int per) {
 extern "C" int nrt_act_bwd_f32(const float *grad_out, const float *y, int activation, float *grad_pre, long long n,
                                void *stream) {
     if (!grad_out || !y || !grad_pre || n < 0) return NRT_ERR_INVALID_ARG;
-    if (activation < ACT_NONE || activation > ACT_RELU) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_SIGMOID) return NRT_ERR_INVALID_ARG;
     if (n == 0) return NRT_OK;
     hipStream_t st = nrt_stream(stream);
     const bool al = ((((uintptr_t)grad_out | (uintptr_t)y | (uintptr_t)grad_pre) & 15) == 0);

@@ -33,6 +33,8 @@ from . import utils
 __all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'load', 'load_config']
 
 _ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}
+_EW_ACTS = dict(_ACTS, sigmoid=3)            # stand-alone Activation layers only (nrt_add_act_affine_f32)
+_ACT_MUL_B = 0x100
 
 
 def _act_code(activation):
@@ -212,7 +214,10 @@ class _BatchNorm(nn.Module):
         self.register_buffer('moving_variance', torch.ones(channels))
 
 
-def _elementwise(a, b=None, scale=None, shift=None, act=0):
+def _elementwise(a, b=None, scale=None, shift=None, act=0, mul=False):
+    """act(a + b) * scale + shift, or with mul act(a) * b"""
+    if mul:
+        act = int(act) | _ACT_MUL_B
     lib = _lib.lib()
     dev = _lib.require_device(a, b)
     a = a.contiguous()
@@ -517,6 +522,24 @@ class _AddActFn(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         d = _act_bwd(g, y, ctx.act)
         return d, (d if ctx.has_b else None), None
+
+
+class _MulFn(torch.autograd.Function):
+    """y = a * b (`KL.multiply` of the prior and the sigmoid likelihood, models.py:412-417)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        with torch.no_grad():
+            y = _elementwise(a, b, mul=True)
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = _elementwise(g, b, mul=True) if ctx.needs_input_grad[0] else None
+        db = _elementwise(g, a, mul=True) if ctx.needs_input_grad[1] else None
+        return da, db
 
 
 def _channel_sums(a, b=None):
@@ -827,7 +850,9 @@ class ConvNet(nn.Module):
                 elif kind == 'add':
                     t[name] = _elementwise(t[op['a']], t[op['b']])
                 elif kind == 'activation':
-                    t[name] = _elementwise(t[op['src']], act=_act_code(op['activation']))
+                    t[name] = _elementwise(t[op['src']], act=_EW_ACTS[op['activation']])
+                elif kind == 'multiply':
+                    t[name] = _elementwise(t[op['a']], t[op['b']], mul=True)
                 elif kind == 'bn':
                     scale, shift = self._affine(self.layers_by_name[name])
                     t[name] = _elementwise(t[op['src']], scale=scale, shift=shift)
@@ -894,7 +919,9 @@ class ConvNet(nn.Module):
             elif kind == 'add':
                 t[name] = _AddActFn.apply(t[op['a']], t[op['b']], 0)
             elif kind == 'activation':
-                t[name] = _AddActFn.apply(t[op['src']], None, _act_code(op['activation']))
+                t[name] = _AddActFn.apply(t[op['src']], None, _EW_ACTS[op['activation']])
+            elif kind == 'multiply':
+                t[name] = _MulFn.apply(t[op['a']], t[op['b']])
             elif kind == 'likelihood':
                 m = self.layers_by_name[name]
                 if op.get('fuse_softmax') and name not in keep and m.cout <= 64 and tuple(m.ksize3) == (1, 1, 1):
@@ -1191,9 +1218,8 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
     model_name = name
     if prefix is None:
         prefix = model_name
-    if add_prior_layer and not use_logp:
-        raise NotImplementedError('add_prior_layer with use_logp=False (sigmoid likelihood x prior, models.py:408-414) is not '
-                                  'implemented; the log-prior form is')
+    if add_prior_layer and not use_logp:                                         # models.py:423
+        assert final_pred_activation != 'softmax', 'cannot do softmax when adding prior via P()'
     multi = isinstance(input_shape[0], (tuple, list, np.ndarray))
     if multi:                                                                    # :155-170
         shapes = [tuple(int(v) for v in s) for s in input_shape]
@@ -1244,9 +1270,14 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
         pname = model_name + '_prior'
         prior_shape = tuple(first[:-1]) + (int(nb_labels),)
         sp = (1,) * (3 - ndims) + tuple(first[:-1])
-        print("Breaking change: use_logp option now requires log input!", file=sys.stderr)
         prior = bld.add({'kind': 'input', 'name': '%s-input' % pname, 'index': len(shapes)}, (sp, int(nb_labels)))
-        post = bld.add({'kind': 'add', 'name': '%s_posterior' % pname, 'a': prior, 'b': last}, (sp, int(nb_labels)))
+        if use_logp:                                                             # :401-406
+            print("Breaking change: use_logp option now requires log input!", file=sys.stderr)
+            post = bld.add({'kind': 'add', 'name': '%s_posterior' % pname, 'a': prior, 'b': last}, (sp, int(nb_labels)))
+        else:                                                                    # :408-414: sigmoid likelihood x prior
+            like = bld.add({'kind': 'activation', 'name': '%s_likelihood_sigmoid' % pname, 'src': last,
+                            'activation': 'sigmoid'}, (sp, int(nb_labels)))
+            post = bld.add({'kind': 'multiply', 'name': '%s_posterior' % pname, 'a': prior, 'b': like}, (sp, int(nb_labels)))
         if final_pred_activation == 'softmax':
             print("using final_pred_activation %s for %s" % (final_pred_activation, pname))
             last = bld.add({'kind': 'prediction', 'name': '%s_prediction' % pname, 'src': post, 'activation': 'softmax'},

@@ -100,7 +100,11 @@ def forward(net, x, params=None, return_tensors=None, dropout_scales=None, bn_tr
                 y = torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0.0)) - 1)
             elif op['activation'] == 'relu':
                 y = torch.relu(y)
+            elif op['activation'] == 'sigmoid':
+                y = torch.sigmoid(y)
             t[name] = y
+        elif kind == 'multiply':                      # KL.multiply (models.py:412-417)
+            t[name] = t[op['a']] * t[op['b']]
         elif kind == 'likelihood':
             k, b = params[name]
             t[name] = conv3d_same(t[op['src']], k, b, 1, None)

@@ -282,5 +282,39 @@ def test_unet_add_prior_layer(dev):
     close(N(pg.grad), po.grad.numpy(), 'grad wrt the log prior', 2e-4)
     for k, m in net.layers_by_name.items():
         close(N(m.kernel.grad), params[k][0].grad.numpy(), k + ' kernel', 5e-4)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match='cannot do softmax'):               # models.py:423
         ne.models.unet(8, (8, 8, 8, 1), 2, 3, 4, add_prior_layer=True, use_logp=False)
+
+
+def test_unet_add_prior_layer_probability_form(dev):
+    """add_prior with use_logp=False (models.py:408-417): prior * sigmoid(likelihood), linear prediction; inference and
+    training-mode gradients vs the oracle"""
+    rng = np.random.default_rng(54)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        net = ne.models.unet(8, (8, 8, 8, 1), 2, 3, 4, add_prior_layer=True, use_logp=False,
+                             final_pred_activation='linear').to(dev)
+    assert net.layer_names[-4:] == ['unet_prior-input', 'unet_prior_likelihood_sigmoid', 'unet_prior_posterior',
+                                    'unet_prior_prediction']
+    for m in net.layers_by_name.values():
+        with torch.no_grad():
+            m.kernel.copy_(G((rng.standard_normal(tuple(m.kernel.shape)) * 0.3).astype(F), dev))
+    x = rng.standard_normal((2, 8, 8, 8, 1)).astype(F)
+    prior = rng.dirichlet(np.ones(4), (2, 8, 8, 8)).astype(F)
+    y = net([G(x, dev), G(prior, dev)])
+    yo = tuo.forward(net, [torch.from_numpy(x).double(), torch.from_numpy(prior).double()])
+    close(N(y), yo.numpy(), 'posterior', 1e-4)
+    assert (N(y) >= 0).all() and (N(y) <= prior + 1e-7).all()                     # sigmoid in (0, 1) scales the prior down
+    net.train()
+    pg = G(prior, dev, True)
+    yt = net([G(x, dev), pg])
+    close(N(yt), yo.numpy(), 'training-mode forward', 1e-4)
+    w = rng.standard_normal(tuple(yt.shape)).astype(F)
+    (yt * G(w, dev)).sum().backward()
+    params = {k: (m.kernel.detach().cpu().double().requires_grad_(), m.bias.detach().cpu().double().requires_grad_())
+              for k, m in net.layers_by_name.items()}
+    po = torch.from_numpy(prior).double().requires_grad_()
+    (tuo.forward(net, [torch.from_numpy(x).double(), po], params) * torch.from_numpy(w).double()).sum().backward()
+    close(N(pg.grad), po.grad.numpy(), 'grad wrt the prior', 2e-4)
+    for k, m in net.layers_by_name.items():
+        close(N(m.kernel.grad), params[k][0].grad.numpy(), k + ' kernel', 5e-4)
+        close(N(m.bias.grad), params[k][1].grad.numpy(), k + ' bias', 5e-4)

@@ -195,7 +195,7 @@ def test_unet_layer_names_and_errors(dev):
         ne.models.unet(4, [(8, 8, 8, 1), (8, 8, 4, 1)], 2, 3, 2)
     with pytest.raises(AssertionError, match='list of lists'):
         ne.models.unet([4, 8], (8, 8, 8, 1), None, 3, 2, feat_mult=None)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match='cannot do softmax'):
         ne.models.unet(4, (8, 8, 8, 1), 2, 3, 2, add_prior_layer=True, use_logp=False)
     # multi-input and intermediate tensors
     mi = ne.models.unet(4, [(8, 8, 8, 1), (8, 8, 8, 2)], 2, 3, 2).to(dev)
