@@ -418,6 +418,57 @@ class _MiJointFn(torch.autograd.Function):
         return gx, gy, None, None, None, None, None
 
 
+class _MiMapsFn(torch.autograd.Function):
+    """joint[b] = x[b]^T y[b] and the column sums of two maps [bs, V, Bn] (metrics.py:256-269).  Forward: the 1x1x1 case of the
+    conv weight-gradient contraction (MFMA over voxels; its bias output is sum_v y).  Backward: dx = y gJ^T + gsx and
+    dy = x gJ + gsy, i.e. 1x1 convolutions with the [Bn, Bn] histogram gradient as weights."""
+
+    @staticmethod
+    def forward(ctx, xf, yf):
+        lib = _lib.lib()
+        dev = xf.device
+        bs, V, Bn = xf.shape
+        joint = torch.zeros((bs, Bn, Bn), dtype=torch.float32, device=dev)
+        sx = torch.zeros((bs, Bn), dtype=torch.float32, device=dev)
+        sy = torch.zeros((bs, Bn), dtype=torch.float32, device=dev)
+        shape = [V // 32, 4, 8] if V % 32 == 0 else [V, 1, 1]
+        with torch.cuda.device(dev):
+            for b in range(bs):
+                rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xf[b]), _lib.ptr(yf[b]), _lib.ptr(joint[b]), _lib.ptr(sy[b]), 1,
+                                              _lib.ints(shape), Bn, Bn, _lib.ints([1, 1, 1]), 1, _lib.stream_ptr(dev))
+                _lib.check(rc, 'nrt_conv3d_wgrad_f32')
+            rc = lib.nrt_colsum_f32(_lib.ptr(xf), bs, V, Bn, _lib.ptr(sx), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_colsum_f32')
+        ctx.save_for_backward(xf, yf)
+        return joint, sx, sy
+
+    @staticmethod
+    def backward(ctx, gj, gsx, gsy):
+        xf, yf = ctx.saved_tensors
+        lib = _lib.lib()
+        dev = xf.device
+        bs, V, Bn = xf.shape
+        if Bn > 64:
+            raise NotImplementedError('neurite_amd: backward of MutualInformation.maps with more than 64 bins')
+        gj = torch.zeros((bs, Bn, Bn), dtype=torch.float32, device=dev) if gj is None else gj.contiguous()
+        gsx = torch.zeros((bs, Bn), dtype=torch.float32, device=dev) if gsx is None else gsx.contiguous()
+        gsy = torch.zeros((bs, Bn), dtype=torch.float32, device=dev) if gsy is None else gsy.contiguous()
+        gx = torch.empty_like(xf) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(yf) if ctx.needs_input_grad[1] else None
+        gjt = gj.transpose(1, 2).contiguous()
+        with torch.cuda.device(dev):
+            for b in range(bs):
+                if gx is not None:          # dx[v, i] = sum_j y[v, j] gJ[i, j] + gsx[i]: weights [cin = j][cout = i] = gJ^T
+                    rc = lib.nrt_conv1x1_softmax_f32(_lib.ptr(yf[b]), _lib.ptr(gjt[b]), _lib.ptr(gsx[b]), _lib.ptr(gx[b]), V, Bn, Bn,
+                                                     0, 0, _lib.stream_ptr(dev))
+                    _lib.check(rc, 'nrt_conv1x1_softmax_f32')
+                if gy is not None:          # dy[v, j] = sum_i x[v, i] gJ[i, j] + gsy[j]
+                    rc = lib.nrt_conv1x1_softmax_f32(_lib.ptr(xf[b]), _lib.ptr(gj[b]), _lib.ptr(gsy[b]), _lib.ptr(gy[b]), V, Bn, Bn,
+                                                     0, 0, _lib.stream_ptr(dev))
+                    _lib.check(rc, 'nrt_conv1x1_softmax_f32')
+        return gx, gy
+
+
 class MutualInformation:
     """
     Soft mutual information for intensity volumes and probabilistic volumes (neurite/tf/metrics.py:41-336):
@@ -502,32 +553,17 @@ class MutualInformation:
         return _mi_from_joint(joint, sx, sy).reshape(bs, C)
 
     def maps(self, x, y):
-        """MI per batch entry of two probability / similarity maps [bs, ..., B] -> [bs]."""
-        lib = _lib.lib()
-        dev = _lib.require_device(x, y)
+        """MI per batch entry of two probability / similarity maps [bs, ..., B] -> [bs]; differentiable wrt both maps."""
+        _lib.require_device(x, y)
         if tuple(x.shape) != tuple(y.shape):
             raise InvalidArgumentError('')                                              # tf.debugging.assert_equal :249
         if x.dtype != torch.float32 or y.dtype != torch.float32:
             raise NotImplementedError('MutualInformation: float32 tensors')
-        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
-            raise NotImplementedError('neurite_amd: backward of MutualInformation.maps is not implemented (use volumes/channelwise)')
         bs, Bn = x.shape[0], x.shape[-1]
         xf = x.reshape(bs, -1, Bn).contiguous()
         yf = y.reshape(bs, -1, Bn).contiguous()
-        V = xf.shape[1]
-        mm = torch.stack([utils._device_minmax(xf), utils._device_minmax(yf)])
+        mm = torch.stack([utils._device_minmax(xf.detach()), utils._device_minmax(yf.detach())])
         if not bool((mm[:, 0] >= 0).all()):                                             # assert_non_negative :250-251
             raise InvalidArgumentError('')
-        joint = torch.zeros((bs, Bn, Bn), dtype=torch.float32, device=dev)
-        sx = torch.zeros((bs, Bn), dtype=torch.float32, device=dev)
-        sy = torch.zeros((bs, Bn), dtype=torch.float32, device=dev)
-        # joint[b] = x[b]^T y[b]: the 1x1x1 case of the conv weight-gradient contraction (MFMA over voxels); its bias output is sum_v y
-        shape = [V // 32, 4, 8] if V % 32 == 0 else [V, 1, 1]
-        with torch.cuda.device(dev):
-            for b in range(bs):
-                rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xf[b]), _lib.ptr(yf[b]), _lib.ptr(joint[b]), _lib.ptr(sy[b]), 1,
-                                              _lib.ints(shape), Bn, Bn, _lib.ints([1, 1, 1]), 1, _lib.stream_ptr(dev))
-                _lib.check(rc, 'nrt_conv3d_wgrad_f32')
-            rc = lib.nrt_colsum_f32(_lib.ptr(xf), bs, V, Bn, _lib.ptr(sx), _lib.stream_ptr(dev))
-        _lib.check(rc, 'nrt_colsum_f32')
+        joint, sx, sy = _MiMapsFn.apply(xf, yf)
         return _mi_from_joint(joint, sx, sy)

@@ -649,6 +649,9 @@ def soft_quantize(x, bin_centers=None, nb_bins=16, alpha=1, min_clip=-np.inf, ma
     dev = _lib.require_device(x)
     if x.dtype != torch.float32:
         raise NotImplementedError('soft_quantize: float32 tensors, got %s' % x.dtype)
+    if torch.is_grad_enabled() and x.requires_grad:
+        raise NotImplementedError('neurite_amd: soft_quantize has no backward (MutualInformation.volumes / channelwise '
+                                  'differentiate through the fused histogram kernel instead)')
     x = x.contiguous()
     centers = _bin_centers(x, bin_centers, nb_bins)
     nb = centers.numel()

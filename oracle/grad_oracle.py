@@ -125,3 +125,18 @@ def mi_channelwise(x, y, cx, cy, alpha, min_clip=float('-inf'), max_clip=float('
     py = py / (py.sum(-1, keepdim=True) + eps)
     pxpy = px[..., :, None] * py[..., None, :] + eps
     return (pxy * torch.log(pxy / pxpy + eps)).sum((2, 3))
+
+
+def mi_maps(x, y, eps=1e-7):
+    """MutualInformation.maps (neurite/tf/metrics.py:228-282): x, y [bs, ..., B] non-negative maps -> [bs]."""
+    bs, B = x.shape[0], x.shape[-1]
+    xf = x.reshape(bs, -1, B)
+    yf = y.reshape(bs, -1, B)
+    joint = torch.einsum('bvi,bvj->bij', xf, yf)                   # :256-259
+    pxy = joint / (joint.sum((1, 2), keepdim=True) + eps)          # :262
+    px = xf.sum(1)
+    px = px / (px.sum(1, keepdim=True) + eps)                      # :265-266
+    py = yf.sum(1)
+    py = py / (py.sum(1, keepdim=True) + eps)                      # :267-268
+    pxpy = px[:, :, None] * py[:, None, :] + eps                   # :271-274
+    return (pxy * torch.log(pxy / pxpy + eps)).sum((1, 2))         # :277-281

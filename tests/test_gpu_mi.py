@@ -116,5 +116,33 @@ def test_mi_backward(dev):
             want = want.numpy()
             err = np.abs(N(got) - want).max() / np.abs(want).max()
             assert err < 2e-3, (nm, err)
-    with pytest.raises(NotImplementedError):
-        MI().maps(G(np.abs(x), dev, True), G(np.abs(y), dev))
+    with pytest.raises(NotImplementedError, match='soft_quantize has no backward'):
+        MI().volume_seg(G(x[..., :1], dev, True), G(np.abs(y), dev))
+
+
+def test_mi_maps_backward(dev):
+    """-MI between probability maps (segs / maps) as a loss: gradient wrt both maps vs float64 autograd; voxel counts that
+    are / are not multiples of 32, odd label counts"""
+    rng = np.random.default_rng(29)
+    for shape in ((2, 8, 8, 8, 16), (1, 7, 9, 5, 5), (3, 33, 40)):
+        p = rng.dirichlet(np.ones(shape[-1]), shape[:-1]).astype(F)
+        q = (0.6 * p + 0.4 * rng.dirichlet(np.ones(shape[-1]), shape[:-1])).astype(F)
+        pg, qg = G(p, dev, True), G(q, dev, True)
+        val = MI().maps(pg, qg)
+        w = rng.standard_normal(tuple(val.shape)).astype(F)
+        (-(val * G(w, dev)).sum()).backward()
+        po, qo = torch.from_numpy(p).double().requires_grad_(), torch.from_numpy(q).double().requires_grad_()
+        ref = go.mi_maps(po, qo)
+        (-(ref * torch.from_numpy(w).double()).sum()).backward()
+        np.testing.assert_allclose(N(val), ref.detach().numpy(), rtol=2e-4, atol=2e-6)
+        for got, want, nm in ((pg.grad, po.grad, 'x'), (qg.grad, qo.grad, 'y')):
+            want = want.numpy()
+            assert got.shape == want.shape
+            err = np.abs(N(got) - want).max() / np.abs(want).max()
+            assert err < 5e-4, (shape, nm, err)
+    # only one side needs a gradient (a fixed atlas prior against a predicted segmentation)
+    pg = G(p, dev, True)
+    MI().segs(pg, G(q, dev)).sum().backward()
+    po = torch.from_numpy(p).double().requires_grad_()
+    go.mi_maps(po, torch.from_numpy(q).double()).sum().backward()
+    assert np.abs(N(pg.grad) - po.grad.numpy()).max() / np.abs(po.grad.numpy()).max() < 5e-4
