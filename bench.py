@@ -425,7 +425,12 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     dist = None
+    real_stdout = None
     if world > 1 or (os.environ.get('NRT_FORCE_DIST') and 'RANK' in os.environ):
+        # RCCL prints its version banner on the process's stdout at communicator creation: keep fd 1 for the one JSON line
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
@@ -468,7 +473,7 @@ def main():
         d = dice.dice(fix, warped)                      # [B, L]
         if events is not None:
             events[2].record()
-        return nd.all_reduce_mean_dice(d)               # one all-reduce of 2 floats when world > 1
+        return nd.all_reduce_mean_dice(d, async_op=True)    # one all-reduce of 2 floats when world > 1
 
     def step_fused(events=None):
         if events is not None:
@@ -477,11 +482,20 @@ def main():
         if events is not None:
             events[1].record()
             events[2].record()
-        return nd.all_reduce_mean_dice(d)
+        return nd.all_reduce_mean_dice(d, async_op=True)
 
     def timed(step, steps, warmup):
+        # the all-reduce of step k runs on RCCL's stream while step k + 1's kernels run on the compute stream: a step's
+        # global mean is collected (a stream-level wait, no host sync) after the next step has been enqueued; every mean
+        # is complete before the closing synchronize, so all K steps' work lies inside the timed region
+        pending = None
         for _ in range(warmup):
-            m = step()
+            nxt = step()
+            if pending is not None:
+                pending.result()
+            pending = nxt
+        m = pending.result() if pending is not None else None
+        pending = None
         torch.cuda.synchronize()
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
         if dist is not None:
@@ -489,7 +503,11 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(steps):
-            m = step(evs[k])
+            nxt = step(evs[k])
+            if pending is not None:
+                m = pending.result()
+            pending = nxt
+        m = pending.result()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -632,8 +650,14 @@ def main():
     if unet_multi is not None:
         out['unet_fwd'] = {'config': 'BASELINE config 3, one 160^3 volume per GPU (data-parallel inference)', 'n_gpus': world,
                            'fwd_ms': round(unet_multi, 3), 'volumes_per_s': round(world / (unet_multi * 1e-3), 1)}
+    if real_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     print(json.dumps(out), flush=True)
     if dist is not None:
+        sys.stdout.flush()
+        os.dup2(2, 1)                       # anything RCCL says at teardown goes to stderr as well
         dist.destroy_process_group()
 
 

@@ -20,7 +20,7 @@ single-process tower replication; nothing of it is reproduced here.
 import torch
 import torch.distributed as dist
 
-__all__ = ['shard_range', 'all_reduce_mean_dice', 'all_reduce_mean', 'reduce_dice_sums', 'dice_from_sums',
+__all__ = ['shard_range', 'PendingMean', 'all_reduce_mean_dice', 'all_reduce_mean', 'reduce_dice_sums', 'dice_from_sums',
            'all_reduce_gradients']
 
 
@@ -52,20 +52,43 @@ def shard_range(n_items, rank=None, world_size=None):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_reduce_mean_dice(local_dice, weights=None, group=None):
+class PendingMean:
+    """
+    A mean whose all-reduce is in flight on RCCL's own stream.  `result()` makes the CURRENT stream wait for it (no host
+    sync) and returns the 0-d tensor: call it after the next step's kernels have been enqueued and the collective's
+    latency hides behind them.
+    """
+
+    def __init__(self, buf, work, value=None):
+        self._buf, self._work, self._value = buf, work, value
+
+    def result(self):
+        if self._value is not None:
+            return self._value
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._buf[0] / self._buf[1]
+
+
+def all_reduce_mean_dice(local_dice, weights=None, group=None, async_op=False):
     """
     local_dice [B_local, L] (this rank's batch entries).  Returns the global mean over all ranks'
     entries of dice*weights -- what Dice.mean_dice would return on the gathered batch.  One all-reduce
-    of 2 floats.
+    of 2 floats.  With async_op a PendingMean is returned instead (also when there is nothing to reduce).
     """
     d = local_dice
     if weights is not None:
         d = d * torch.as_tensor(weights, dtype=d.dtype, device=d.device)
     _, w = _world(group)
     if w == 1 and not (dist.is_available() and dist.is_initialized()):
+        if async_op:
+            return PendingMean(None, None, d.mean(dtype=torch.float32))
         return d.mean(dtype=torch.float32)
     # [sum, count] in one device buffer; the count constant is cached per (device, value): no H2D copy per step
     buf = torch.cat([d.sum(dtype=torch.float32).reshape(1), _count_tensor(d.numel(), d.device)])
+    if async_op:
+        return PendingMean(buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf[0] / buf[1]
 

@@ -34,6 +34,9 @@ def _worker(rank, world, port, q):
         assert (lo, hi) == nd.shard_range(B, rank, world)
         local = torch.from_numpy(npo.dice(t[lo:hi], p[lo:hi]))
         got = nd.all_reduce_mean_dice(local, weights=w)
+        pend = nd.all_reduce_mean_dice(local, weights=w, async_op=True)        # collective in flight; collected later
+        assert isinstance(pend, nd.PendingMean)
+        assert float(pend.result()) == float(got) and float(pend.result()) == float(got)
         want = npo.mean_dice(t, p, weights=w)
         # spatially split batch entry: all-reduce the numerator/denominator partials, then divide
         half = S[0] // 2
@@ -86,6 +89,7 @@ def test_world1_is_identity():
     from neurite_amd import distributed as nd
     d = torch.rand(3, 4)
     assert torch.allclose(nd.all_reduce_mean_dice(d), d.mean())
+    assert torch.allclose(nd.all_reduce_mean_dice(d, async_op=True).result(), d.mean())
     s = torch.rand(2, 3, 4)
     assert nd.reduce_dice_sums(s) is s
     assert nd.shard_range(10) == (0, 10)
