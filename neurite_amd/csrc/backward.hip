@@ -159,6 +159,20 @@ __global__ __launch_bounds__(256) void interpn_bwd_rows(InterpBwdArgs ba) {
         for (int u = 0; u < U; ++u) {
             if (oob[u] || !live[u]) gq[u] = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
             float gacc[3] = {0.0f, 0.0f, 0.0f};
+            // scatter layout: atomic e of lane lg adds channel G * e + lg, so the G lanes of a voxel hit G consecutive
+            // dwords per instruction (the row-load layout, channel 4 lg + e, would spread them 16 B apart); the value
+            // lives in component (G e + lg) & 3 of lane (G e + lg) >> 2 of the group
+            float gs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (gv) {
+                const int base = (int)(threadIdx.x & 63u) - lg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ch = G * e + lg, src = base + (ch >> 2);
+                    const float c0 = __shfl(gq[u][0], src, 64), c1 = __shfl(gq[u][1], src, 64);
+                    const float c2 = __shfl(gq[u][2], src, 64), c3 = __shfl(gq[u][3], src, 64);
+                    gs[e] = (ch & 2) ? ((ch & 1) ? c3 : c2) : ((ch & 1) ? c1 : c0);
+                }
+            }
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
                 const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
@@ -167,9 +181,9 @@ __global__ __launch_bounds__(256) void interpn_bwd_rows(InterpBwdArgs ba) {
                     const long long idx = ((long long)(bx ? i1[u][0] : i0[u][0]) * Y + (by ? i1[u][1] : i0[u][1])) * Z +
                                           (bz ? i1[u][2] : i0[u][2]);
                     const float wt = wx * wy * wz;
-                    float *dst = gv + (idx * G + lg) * 4;
+                    float *dst = gv + idx * (4 * G) + lg;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) atomic_add_f32(dst + e, wt * gq[u][e]);
+                    for (int e = 0; e < 4; ++e) atomic_add_f32(dst + G * e, wt * gs[e]);
                 }
                 if (gl) {
                     const nrt_f4 c = v[u][corner];
