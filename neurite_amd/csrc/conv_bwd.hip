@@ -15,6 +15,8 @@
 // D tiles stay in registers over all the voxel tiles a (persistent) block visits; one float atomic per weight and
 // block at the end.  x is read once per (cin chunk, cout chunk) pair, weights never.
 
+#include <type_traits>
+
 #include "nrt_common.h"
 
 namespace {
@@ -161,18 +163,20 @@ constexpr int WT_X = 4, WT_Y = 4, WT_Z = 8;     // voxel tile: 128 voxels = 32 k
 constexpr int WG_MAXT = 7;                       // taps per wave: ceil(27 / 4)
 
 // NA, NB: 16-channel blocks of the cin / cout chunk handled by one block
-template <int NA, int NB>
+// K3: 3x3x3 kernel, dilation 1 -- the halo geometry is a compile-time constant, which turns the staging loop's row
+// decode (two runtime divisions per 16-byte load) into multiply-shifts
+template <int NA, int NB, bool K3>
 __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CC = 16 * NA, CO = 16 * NB;
     constexpr int RSA = (CC % 32 == 0) ? CC + 16 : CC;          // row strides: 16 mod 32 floats
     constexpr int RSB = (CO % 32 == 0) ? CO + 16 : CO;
-    const int hx = a.kx > 1 ? a.dil : 0, hy = a.ky > 1 ? a.dil : 0, hz = a.kz > 1 ? a.dil : 0;
+    const int hx = K3 ? 1 : (a.kx > 1 ? a.dil : 0), hy = K3 ? 1 : (a.ky > 1 ? a.dil : 0), hz = K3 ? 1 : (a.kz > 1 ? a.dil : 0);
     const int HX = WT_X + 2 * hx, HY = WT_Y + 2 * hy, HZ = WT_Z + 2 * hz;
     const int nrowsA = HX * HY * HZ;
     float *la = lds;                                            // [nrowsA][RSA]
     float *lb = lds + nrowsA * RSA;                             // [128][RSB]
-    const int ntap = a.kx * a.ky * a.kz;
+    const int ntap = K3 ? 27 : a.kx * a.ky * a.kz;
     const int cic = blockIdx.y % a.ncic, coc = blockIdx.y / a.ncic;
     const int ci0 = cic * CC, co0 = coc * CO;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -192,8 +196,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < WG_MAXT; ++i) {
         const int t = min(wv + 4 * i, ntap - 1);
-        const int dz = t % a.kz, dy = (t / a.kz) % a.ky, dx = t / (a.kz * a.ky);
-        toff[i] = ((dx * a.dil) * HY + dy * a.dil) * HZ + dz * a.dil;
+        const int kz = K3 ? 3 : a.kz, ky = K3 ? 3 : a.ky, dil = K3 ? 1 : a.dil;
+        const int dz = t % kz, dy = (t / kz) % ky, dx = t / (kz * ky);
+        toff[i] = ((dx * dil) * HY + dy * dil) * HZ + dz * dil;
     }
 
     const long long tiles_per_vol = (long long)a.ntx * a.nty * a.ntz;
@@ -207,6 +212,73 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
         const float *pb = a.dp + (long long)b * a.X * a.Y * a.Z * a.Cout;
         __syncthreads();                                        // previous tile fully consumed
         // ---- stage the x halo tile (zero outside the volume = SAME padding, zero beyond Cin) ---------------
+        if (K3) {
+            // channel counts are multiples of 4 here (launch_wgrad): every element is one unconditional 16-byte load from
+            // a clamped address, six (two for dpre) in flight per thread, zeroed by select afterwards
+            constexpr int QA = CC / 4, TOTA = (WT_X + 2) * (WT_Y + 2) * (WT_Z + 2) * QA, UB = 6;
+            const int cs = a.x1 ? a.c0 : a.Cin;
+            auto stage_x = [&](auto has_x1) {
+                constexpr bool X1SRC = decltype(has_x1)::value;
+                // up-sampling factors are powers of two on this path (launch_wgrad)
+                const int shx = X1SRC ? __ffs(a.ux) - 1 : 0, shy = X1SRC ? __ffs(a.uy) - 1 : 0, shz = X1SRC ? __ffs(a.uz) - 1 : 0;
+                // element offsets fit 32 bits and the strides 24 bits on this path (launch_wgrad): full-rate multiplies
+                const unsigned sZ = (unsigned)cs, sY = (unsigned)a.Z * sZ, sX = (unsigned)a.Y * sY;
+                const unsigned Y1 = X1SRC ? a.Y >> shy : 1, Z1 = X1SRC ? a.Z >> shz : 1;
+                const unsigned tZ = X1SRC ? (unsigned)a.c1 : 0, tY = Z1 * tZ, tX = Y1 * tY;
+                const float *xlo = X1SRC ? a.x1 + (long long)b * (a.X >> shx) * tX : nullptr;
+                for (int e0 = threadIdx.x; e0 < TOTA; e0 += 256 * UB) {
+                    nrt_f4 v[UB];
+                    bool ok[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int e = e0 + 256 * u, ee = e < TOTA ? e : 0;
+                        const int r = ee / QA, c4 = (ee % QA) * 4;
+                        const int rz = r % HZ, ry = (r / HZ) % HY, rx = r / (HZ * HY);
+                        const int gx = x0 + rx - 1, gy = y0 + ry - 1, gz = z0 + rz - 1, ch = ci0 + c4;
+                        ok[u] = (e < TOTA) & (gx >= 0) & (gx < a.X) & (gy >= 0) & (gy < a.Y) & (gz >= 0) & (gz < a.Z) & (ch < a.Cin);
+                        unsigned off = __umul24((unsigned)gx, sX) + __umul24((unsigned)gy, sY) + __umul24((unsigned)gz, sZ) + (unsigned)ch;
+                        const float *base = xb;
+                        if (X1SRC) {
+                            const unsigned off1 = __umul24((unsigned)(gx >> shx), tX) + __umul24((unsigned)(gy >> shy), tY) +
+                                                  __umul24((unsigned)(gz >> shz), tZ) + (unsigned)(ch - a.c0);
+                            const bool lo = ch >= a.c0;
+                            off = lo ? off1 : off;
+                            base = lo ? xlo : xb;
+                        }
+                        off = ok[u] ? off : 0u;
+                        v[u] = *(const nrt_f4 *)(base + off);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const int e = e0 + 256 * u;
+                        if (e < TOTA) {
+                            const int r = e / QA, c4 = (e % QA) * 4;
+                            *(nrt_f4 *)(la + r * RSA + c4) = ok[u] ? v[u] : (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+                        }
+                    }
+                }
+            };
+            if (a.x1) stage_x(std::true_type{});
+            else stage_x(std::false_type{});
+            constexpr int QB = CO / 4, TOTB = 128 * QB, UBB = (TOTB + 255) / 256;
+            nrt_f4 vb[UBB];
+            bool okb[UBB];
+#pragma unroll
+            for (int u = 0; u < UBB; ++u) {
+                const int e = threadIdx.x + 256 * u, ee = e < TOTB ? e : 0;
+                const int r = ee / QB, c4 = (ee % QB) * 4;
+                const int rz = r % WT_Z, ry = (r / WT_Z) % WT_Y, rx = r / (WT_Z * WT_Y);
+                const int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
+                okb[u] = e < TOTB && gx < a.X && gy < a.Y && gz < a.Z && co0 + c4 < a.Cout;
+                const float *src = okb[u] ? pb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.Cout + co0 + c4 : a.dp;
+                vb[u] = *(const nrt_f4 *)src;
+            }
+#pragma unroll
+            for (int u = 0; u < UBB; ++u) {
+                const int e = threadIdx.x + 256 * u;
+                if (e < TOTB) *(nrt_f4 *)(lb + (e / QB) * RSB + (e % QB) * 4) = okb[u] ? vb[u] : (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        } else {
         if (a.im2col) {
             const float *x1 = a.x + (long long)b * a.X * a.Y * a.Z;
             for (int e = threadIdx.x; e < 128 * CC; e += 256) {
@@ -263,6 +335,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
             }
             *(nrt_f4 *)(lb + r * RSB + c4) = v;
         }
+        }
         __syncthreads();
         // ---- bias gradient: column sums of the dpre tile (cin chunk 0 only) --------------------------------
         if (a.db && cic == 0 && threadIdx.x < CO) {
@@ -271,6 +344,47 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
             bsum += s;
         }
         // ---- 32 k-steps of 4 consecutive-z voxels --------------------------------------------------------------
+        if (K3) {
+            // fully unrolled and double-buffered: every LDS address is a per-tap base register plus an immediate, the
+            // operands of step ks + 1 are read while the matrix pipe works on step ks, no tap conditionals (wave 3's
+            // seventh tap repeats tap 26 and is dropped at the end)
+            const float *pbl = lb + l4 * RSB + l15;
+            const float *pal[WG_MAXT];
+#pragma unroll
+            for (int i = 0; i < WG_MAXT; ++i) pal[i] = la + (toff[i] + l4) * RSA + l15;
+            auto frag = [&](int ks, float (&af)[WG_MAXT][NA], float (&bf)[NB]) {
+                const int zh = ks & 1, yy = (ks >> 1) & 3, xx = ks >> 3;
+                const int vrow = (xx * WT_Y + yy) * WT_Z + zh * 4, arow = (xx * HY + yy) * HZ + zh * 4;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bf[nb] = pbl[vrow * RSB + nb * 16];
+#pragma unroll
+                for (int i = 0; i < WG_MAXT; ++i)
+#pragma unroll
+                    for (int na = 0; na < NA; ++na) af[i][na] = pal[i][arow * RSA + na * 16];
+            };
+            auto mma = [&](const float (&af)[WG_MAXT][NA], const float (&bf)[NB]) {
+#pragma unroll
+                for (int i = 0; i < WG_MAXT; ++i)
+#pragma unroll
+                    for (int na = 0; na < NA; ++na)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[i][na][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][na], bf[nb], acc[i][na][nb], 0, 0, 0);
+            };
+            float afA[WG_MAXT][NA], afB[WG_MAXT][NA], bfA[NB], bfB[NB];
+            frag(0, afA, bfA);
+#pragma unroll
+            for (int ks = 0; ks < 32; ks += 2) {
+                __builtin_amdgcn_sched_barrier(0);          // keep the reads of the next step ahead of this step's MFMAs
+                frag(ks + 1, afB, bfB);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(afA, bfA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < 32) frag(ks + 2, afA, bfA);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(afB, bfB);
+            }
+        } else
         for (int ks = 0; ks < 32; ++ks) {
             const int zh = ks & 1, yy = (ks >> 1) & 3, xx = ks >> 3;
             const int vrow = (xx * WT_Y + yy) * WT_Z + zh * 4 + l4;                       // row in the dpre tile
@@ -328,9 +442,19 @@ int launch_wgrad(WgArgs &a, hipStream_t st) {
     long long bx = 256ll * per_cu / (a.ncic * a.ncoc);           // about one resident wave of blocks
     if (bx < 64) bx = 64;
     if (bx > ntiles) bx = ntiles;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)conv3d_wgrad<NA, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv3d_wgrad<NA, NB>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);
+    const bool k3 = a.kx == 3 && a.ky == 3 && a.kz == 3 && a.dil == 1 && !a.im2col && (a.Cin & 3) == 0 && (a.Cout & 3) == 0 &&
+                    (!a.x1 || ((a.c0 & 3) == 0 && (a.c1 & 3) == 0 && (a.ux & (a.ux - 1)) == 0 && (a.uy & (a.uy - 1)) == 0 &&
+                               (a.uz & (a.uz - 1)) == 0)) &&
+                    (long long)a.X * a.Y * a.Z * (a.x1 ? a.c0 : a.Cin) < (1ll << 31) && (long long)a.Y * a.Z * a.Cin < (1ll << 24);
+    if (k3) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)conv3d_wgrad<NA, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3d_wgrad<NA, NB, true>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);
+    } else {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)conv3d_wgrad<NA, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3d_wgrad<NA, NB, false>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);
+    }
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
