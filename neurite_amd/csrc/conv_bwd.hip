@@ -165,18 +165,22 @@ constexpr int WG_MAXT = 7;                       // taps per wave: ceil(27 / 4)
 // NA, NB: 16-channel blocks of the cin / cout chunk handled by one block
 // K3: 3x3x3 kernel, dilation 1 -- the halo geometry is a compile-time constant, which turns the staging loop's row
 // decode (two runtime divisions per 16-byte load) into multiply-shifts
-template <int NA, int NB, bool K3>
+// KM = 1: 1x1x1 kernel (also the im2col form of the first layer) -- same staging; the four waves split the 32 k-steps
+// instead of the taps and each adds its partial sums at the end
+template <int NA, int NB, int KM>
 __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
+    constexpr bool K3 = KM == 3, K1 = KM == 1, KF = K3 || K1;
+    constexpr int HALO = K3 ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CC = 16 * NA, CO = 16 * NB;
     constexpr int RSA = (CC % 32 == 0) ? CC + 16 : CC;          // row strides: 16 mod 32 floats
     constexpr int RSB = (CO % 32 == 0) ? CO + 16 : CO;
-    const int hx = K3 ? 1 : (a.kx > 1 ? a.dil : 0), hy = K3 ? 1 : (a.ky > 1 ? a.dil : 0), hz = K3 ? 1 : (a.kz > 1 ? a.dil : 0);
+    const int hx = KF ? HALO : (a.kx > 1 ? a.dil : 0), hy = KF ? HALO : (a.ky > 1 ? a.dil : 0), hz = KF ? HALO : (a.kz > 1 ? a.dil : 0);
     const int HX = WT_X + 2 * hx, HY = WT_Y + 2 * hy, HZ = WT_Z + 2 * hz;
     const int nrowsA = HX * HY * HZ;
     float *la = lds;                                            // [nrowsA][RSA]
     float *lb = lds + nrowsA * RSA;                             // [128][RSB]
-    const int ntap = K3 ? 27 : a.kx * a.ky * a.kz;
+    const int ntap = K3 ? 27 : K1 ? 1 : a.kx * a.ky * a.kz;
     const int cic = blockIdx.y % a.ncic, coc = blockIdx.y / a.ncic;
     const int ci0 = cic * CC, co0 = coc * CO;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < WG_MAXT; ++i) {
         const int t = min(wv + 4 * i, ntap - 1);
-        const int kz = K3 ? 3 : a.kz, ky = K3 ? 3 : a.ky, dil = K3 ? 1 : a.dil;
+        const int kz = K3 ? 3 : K1 ? 1 : a.kz, ky = K3 ? 3 : K1 ? 1 : a.ky, dil = KF ? 1 : a.dil;
         const int dz = t % kz, dy = (t / kz) % ky, dx = t / (kz * ky);
         toff[i] = ((dx * dil) * HY + dy * dil) * HZ + dz * dil;
     }
@@ -212,10 +216,10 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
         const float *pb = a.dp + (long long)b * a.X * a.Y * a.Z * a.Cout;
         __syncthreads();                                        // previous tile fully consumed
         // ---- stage the x halo tile (zero outside the volume = SAME padding, zero beyond Cin) ---------------
-        if (K3) {
+        if (KF) {
             // channel counts are multiples of 4 here (launch_wgrad): every element is one unconditional 16-byte load from
             // a clamped address, six (two for dpre) in flight per thread, zeroed by select afterwards
-            constexpr int QA = CC / 4, TOTA = (WT_X + 2) * (WT_Y + 2) * (WT_Z + 2) * QA, UB = 6;
+            constexpr int QA = CC / 4, TOTA = (WT_X + 2 * HALO) * (WT_Y + 2 * HALO) * (WT_Z + 2 * HALO) * QA, UB = 6;
             const int cs = a.x1 ? a.c0 : a.Cin;
             auto stage_x = [&](auto has_x1) {
                 constexpr bool X1SRC = decltype(has_x1)::value;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
                         const int e = e0 + 256 * u, ee = e < TOTA ? e : 0;
                         const int r = ee / QA, c4 = (ee % QA) * 4;
                         const int rz = r % HZ, ry = (r / HZ) % HY, rx = r / (HZ * HY);
-                        const int gx = x0 + rx - 1, gy = y0 + ry - 1, gz = z0 + rz - 1, ch = ci0 + c4;
+                        const int gx = x0 + rx - HALO, gy = y0 + ry - HALO, gz = z0 + rz - HALO, ch = ci0 + c4;
                         ok[u] = (e < TOTA) & (gx >= 0) & (gx < a.X) & (gy >= 0) & (gy < a.Y) & (gz >= 0) & (gz < a.Z) & (ch < a.Cin);
                         unsigned off = __umul24((unsigned)gx, sX) + __umul24((unsigned)gy, sY) + __umul24((unsigned)gz, sZ) + (unsigned)ch;
                         const float *base = xb;
@@ -258,7 +262,32 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
                     }
                 }
             };
-            if (a.x1) stage_x(std::true_type{});
+            if (K1 && a.im2col) {
+                // first layer: the 27 taps of the single-channel input are the "channels" of this tile's rows; eight
+                // clamped scalar loads in flight per thread
+                constexpr int TOTI = 128 * CC, UI = 8;
+                const float *x1 = a.x + (long long)b * a.X * a.Y * a.Z;
+                const unsigned sY = (unsigned)a.Z, sX = (unsigned)a.Y * sY;
+                for (int e0 = threadIdx.x; e0 < TOTI; e0 += 256 * UI) {
+                    float v[UI];
+                    bool ok[UI];
+#pragma unroll
+                    for (int u = 0; u < UI; ++u) {
+                        const int e = e0 + 256 * u, ee = e < TOTI ? e : 0;
+                        const int r = ee / CC, t = ci0 + ee % CC;
+                        const int rz = r % WT_Z, ry = (r / WT_Z) % WT_Y, rx = r / (WT_Z * WT_Y);
+                        const int gx = x0 + rx + (t / 9 - 1) * a.dil, gy = y0 + ry + ((t / 3) % 3 - 1) * a.dil, gz = z0 + rz + (t % 3 - 1) * a.dil;
+                        ok[u] = (e < TOTI) & (t < 27) & (gx >= 0) & (gx < a.X) & (gy >= 0) & (gy < a.Y) & (gz >= 0) & (gz < a.Z);
+                        const unsigned off = __umul24((unsigned)gx, sX) + __umul24((unsigned)gy, sY) + (unsigned)gz;
+                        v[u] = x1[ok[u] ? off : 0u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UI; ++u) {
+                        const int e = e0 + 256 * u;
+                        if (e < TOTI) la[(e / CC) * RSA + e % CC] = ok[u] ? v[u] : 0.0f;
+                    }
+                }
+            } else if (a.x1) stage_x(std::true_type{});
             else stage_x(std::false_type{});
             constexpr int QB = CO / 4, TOTB = 128 * QB, UBB = (TOTB + 255) / 256;
             nrt_f4 vb[UBB];
@@ -344,7 +373,25 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
             bsum += s;
         }
         // ---- 32 k-steps of 4 consecutive-z voxels --------------------------------------------------------------
-        if (K3) {
+        if (K1) {
+            // one tap: wave w takes k-steps w, w + 4, ... (tile row 4 ks + lane / 16), all reads first, then the MFMAs
+            const float *pa0 = la + (4 * wv + l4) * RSA + l15, *pb0 = lb + (4 * wv + l4) * RSB + l15;
+            float af[8][NA], bf[8][NB];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int na = 0; na < NA; ++na) af[j][na] = pa0[j * 16 * RSA + na * 16];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bf[j][nb] = pb0[j * 16 * RSB + nb * 16];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int na = 0; na < NA; ++na)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[0][na][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][na], bf[j][nb], acc[0][na][nb], 0, 0, 0);
+        } else if (K3) {
             // fully unrolled and double-buffered: every LDS address is a per-tap base register plus an immediate, the
             // operands of step ks + 1 are read while the matrix pipe works on step ks, no tap conditionals (wave 3's
             // seventh tap repeats tap 26 and is dropped at the end)
@@ -409,8 +456,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
     // ---- accumulate into global memory: D row = 4 (lane >> 4) + r (ci), col = lane & 15 (co) -----------------------
 #pragma unroll
     for (int i = 0; i < WG_MAXT; ++i) {
-        const int t = wv + 4 * i;
-        if (t < ntap) {
+        const int t = K1 ? 0 : wv + 4 * i;
+        if (K1 ? i == 0 : t < ntap) {
 #pragma unroll
             for (int na = 0; na < NA; ++na)
 #pragma unroll
@@ -442,19 +489,24 @@ int launch_wgrad(WgArgs &a, hipStream_t st) {
     long long bx = 256ll * per_cu / (a.ncic * a.ncoc);           // about one resident wave of blocks
     if (bx < 64) bx = 64;
     if (bx > ntiles) bx = ntiles;
-    const bool k3 = a.kx == 3 && a.ky == 3 && a.kz == 3 && a.dil == 1 && !a.im2col && (a.Cin & 3) == 0 && (a.Cout & 3) == 0 &&
-                    (!a.x1 || ((a.c0 & 3) == 0 && (a.c1 & 3) == 0 && (a.ux & (a.ux - 1)) == 0 && (a.uy & (a.uy - 1)) == 0 &&
-                               (a.uz & (a.uz - 1)) == 0)) &&
-                    (long long)a.X * a.Y * a.Z * (a.x1 ? a.c0 : a.Cin) < (1ll << 31) && (long long)a.Y * a.Z * a.Cin < (1ll << 24);
-    if (k3) {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)conv3d_wgrad<NA, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv3d_wgrad<NA, NB, true>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);
-    } else {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)conv3d_wgrad<NA, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv3d_wgrad<NA, NB, false>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);
-    }
+    const bool quads = (a.Cout & 3) == 0 && (a.im2col || ((a.Cin & 3) == 0 &&
+                       (!a.x1 || ((a.c0 & 3) == 0 && (a.c1 & 3) == 0 && (a.ux & (a.ux - 1)) == 0 && (a.uy & (a.uy - 1)) == 0 &&
+                                  (a.uz & (a.uz - 1)) == 0))));
+    const bool small = (long long)a.X * a.Y * a.Z * (a.im2col ? 1 : (a.x1 ? a.c0 : a.Cin)) < (1ll << 31) &&
+                       (long long)a.Y * a.Z * (a.im2col ? 1 : a.Cin) < (1ll << 24);
+    const int km = !(quads && small) ? 0 : (a.kx == 3 && a.ky == 3 && a.kz == 3 && a.dil == 1 && !a.im2col) ? 3
+                   : (a.kx == 1 && a.ky == 1 && a.kz == 1) ? 1 : 0;
+#define NRT_WG_LAUNCH(KM)                                                                                                   \
+    do {                                                                                                                    \
+        if (lds > 48 * 1024)                                                                                                \
+            (void)hipFuncSetAttribute((const void *)conv3d_wgrad<NA, NB, KM>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      (int)lds);                                                                            \
+        hipLaunchKernelGGL((conv3d_wgrad<NA, NB, KM>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);         \
+    } while (0)
+    if (km == 3) NRT_WG_LAUNCH(3);
+    else if (km == 1) NRT_WG_LAUNCH(1);
+    else NRT_WG_LAUNCH(0);
+#undef NRT_WG_LAUNCH
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
