@@ -21,6 +21,8 @@
 // conv1x1_softmax_f32 -- the likelihood conv with the channel softmax fused (one pass, no logits tensor).
 // maxpool3d_f32, upsample_concat_f32, softmax_lastdim_f32 -- the remaining Keras layers.
 
+#include <type_traits>
+
 #include "nrt_common.h"
 
 namespace {
@@ -118,14 +120,54 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
     constexpr int PF = 11;                                    // 64 * 11 = 704 >= 648 rows (3x3x3, dilation 1)
     const bool prefetch = nrows <= 64 * PF;
     f32x4 stage[PF];
-    if (prefetch) {
+    unsigned okbits = 0;
+    // FAST (launch_mfma guarantees quad-aligned channel counts, power-of-two up-sampling, 32-bit offsets, 24-bit
+    // strides): a row is ONE unconditional 16-byte load from a clamped address, zeroed by select when it is written to
+    // LDS -- the eleven loads of a chunk leave back to back and are only waited for after the chunk's MFMAs
+    const unsigned sZ0 = (unsigned)a.c0, sY0 = (unsigned)a.Z * sZ0, sX0 = (unsigned)a.Y * sY0;
+    const int shx = FAST && a.c1 ? __ffs(a.ux) - 1 : 0, shy = FAST && a.c1 ? __ffs(a.uy) - 1 : 0, shz = FAST && a.c1 ? __ffs(a.uz) - 1 : 0;
+    const unsigned tZ = (unsigned)a.c1, tY = (unsigned)a.Z1 * tZ, tX = (unsigned)a.Y1 * tY;
+    auto fetch_fast = [&](int cbase, auto two_sources) {
+        constexpr bool TWO = decltype(two_sources)::value;
+        okbits = 0;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int r = (threadIdx.x >> 2) + 64 * i;
+            const int rz = r % HZ, ry = (r / HZ) % HY, rx = r / (HZ * HY);
+            const int x = x0 - 1 + rx, y = y0 - 1 + ry, z = z0 - 1 + rz, c = cbase + 4 * q4;
+            const bool ok = (r < nrows) & (x >= 0) & (x < a.X) & (y >= 0) & (y < a.Y) & (z >= 0) & (z < a.Z) & (c < Cin);
+            unsigned off = __umul24((unsigned)x, sX0) + __umul24((unsigned)y, sY0) + __umul24((unsigned)z, sZ0) + (unsigned)c;
+            const float *base = s0;
+            if (TWO) {
+                const unsigned off1 = __umul24((unsigned)(x >> shx), tX) + __umul24((unsigned)(y >> shy), tY) +
+                                      __umul24((unsigned)(z >> shz), tZ) + (unsigned)(c - a.c0);
+                const bool lo = c >= a.c0;
+                off = lo ? off1 : off;
+                base = lo ? s1 : s0;
+            }
+            off = ok ? off : 0u;
+            okbits |= (ok ? 1u : 0u) << i;
+            stage[i] = *(const f32x4 *)(base + off);
+        }
+    };
+    if (FAST) {
+        if (a.c1) fetch_fast(0, std::true_type{});
+        else fetch_fast(0, std::false_type{});
+    } else if (prefetch) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) stage[i] = load_row((threadIdx.x >> 2) + 64 * i, 0);
     }
     for (int ch = 0; ch < nchunk; ++ch) {
         __syncthreads();                                   // previous chunk fully consumed
         const int cbase = ch * 16;
-        if (prefetch) {
+        if (FAST) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int r = (threadIdx.x >> 2) + 64 * i;
+                if (r < nrows)
+                    *(f32x4 *)&lds[r * LDS_ROW + 4 * q4] = ((okbits >> i) & 1u) ? stage[i] : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        } else if (prefetch) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int r = (threadIdx.x >> 2) + 64 * i;
@@ -135,15 +177,29 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
             for (int r = threadIdx.x >> 2; r < nrows; r += 64) *(f32x4 *)&lds[r * LDS_ROW + 4 * q4] = load_row(r, cbase);
         }
         __syncthreads();
-        if (prefetch && ch + 1 < nchunk) {
+        const f32x4 *wp = (const f32x4 *)wpacked + ((long long)ch * ntap) * NT * 64 + lane;
+        // vmcnt retires in order: a weight load issued after the halo prefetch can only be waited for together with it.
+        // So the weights of the first WPRE taps are requested first, then the next chunk's halo rows, and the first
+        // weight load behind them is not needed before WPRE taps (WPRE * 16 NT MFMAs, ~3-4 k cycles) have run
+        constexpr int WPRE = FAST ? (NT == 1 ? 6 : NT == 2 ? 4 : NT == 3 ? 3 : 2) : 1;
+        f32x4 bpre[WPRE][NT];
+#pragma unroll
+        for (int t = 0; t < WPRE; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bpre[t][nt] = wp[(t * NT + nt) * 64];
+        if (FAST) {
+            if (ch + 1 < nchunk) {
+                if (a.c1) fetch_fast(cbase + 16, std::true_type{});
+                else fetch_fast(cbase + 16, std::false_type{});
+            }
+        } else if (prefetch && ch + 1 < nchunk) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) stage[i] = load_row((threadIdx.x >> 2) + 64 * i, cbase + 16);
         }
         // ---- taps ------------------------------------------------------------------------------
-        const f32x4 *wp = (const f32x4 *)wpacked + ((long long)ch * ntap) * NT * 64 + lane;
         f32x4 bfrag[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bfrag[nt] = wp[nt * 64];
+        for (int nt = 0; nt < NT; ++nt) bfrag[nt] = bpre[0][nt];
         if (FAST) {
             constexpr int FHY = CT_Y + 2, FHZ = CT_Z + 2;
             const float *abase = &lds[((w * FHY) * FHZ + li) * LDS_ROW + 4 * kq];
@@ -152,7 +208,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
                 f32x4 bnext[NT];
                 const int tn = (t + 1 < 27) ? t + 1 : t;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bnext[nt] = wp[(tn * NT + nt) * 64];
+                for (int nt = 0; nt < NT; ++nt) bnext[nt] = (tn < WPRE) ? bpre[tn][nt] : wp[(tn * NT + nt) * 64];
                 const int dz = t % 3, dy = (t / 3) % 3, dx = t / 9;
                 f32x4 av[4];
 #pragma unroll
@@ -630,7 +686,9 @@ int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t 
     const unsigned nbx = (a.OX + CT_X - 1) / CT_X, nby = (a.OY + CT_Y - 1) / CT_Y, nbz = (a.OZ + CT_Z - 1) / CT_Z;
     const unsigned nblk = nbx * nby * nbz;
     const size_t shm = mfma_lds_bytes(a);
-    const bool fast = a.kx == 3 && a.ky == 3 && a.kz == 3 && a.dil == 1;
+    const bool pow2 = a.c1 == 0 || ((a.ux & (a.ux - 1)) == 0 && (a.uy & (a.uy - 1)) == 0 && (a.uz & (a.uz - 1)) == 0);
+    const bool fast = a.kx == 3 && a.ky == 3 && a.kz == 3 && a.dil == 1 && (a.c0 & 3) == 0 && (a.c1 & 3) == 0 && pow2 &&
+                      (long long)a.X * a.Y * a.Z * a.c0 < (1ll << 31) && (long long)a.Y * a.Z * (a.c0 > a.c1 ? a.c0 : a.c1) < (1ll << 24);
     if (shm > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)conv3d_mfma<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return NRT_ERR_LAUNCH;
