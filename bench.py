@@ -367,33 +367,36 @@ def lc3d_bench(dev, reps=10):
             'wcce_ms': round(ms2, 4), 'wcce_GBs': round(2 * 2 * 16 * 94 ** 3 / ms2 / 1e6, 1), 'loss': round(float(l), 5)}
 
 
-def training_bench(dev, size=160, labels=32, reps=5):
-    """forward + backward of the two training uses of the path: a registration step (-mean Dice of a warped one-hot map wrt
-    the displacement field, fused kernels) and a unet segmentation step (CCE - Dice, SGD update), BASELINE sizes."""
-    import contextlib
-    import neurite_amd as ne
-    from neurite_amd import synth
-
-    def timeit(fn, n):
+def _timeit(fn, n):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(n):
         fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
 
-    B = 2
-    mov, fix, trf = synth.cfg2_batch(B, size, labels, device=dev, seed0=7)
+
+def registration_bench(mov, fix, trf, reps=5):
+    """forward + backward of a registration step (-mean Dice of a warped one-hot map wrt the displacement field, fused
+    kernels) on the bench's own volumes, so that its forward launches are the same launches as the timed ones."""
+    import neurite_amd as ne
+    B, size, labels = mov.shape[0], mov.shape[1], mov.shape[-1]
 
     def reg_step():
         f = trf.clone().requires_grad_()
         (-ne.fused.warp_dice(mov, f, fix).mean()).backward()
-    reg_ms = timeit(reg_step, reps)
-    del mov, fix, trf
-    torch.cuda.empty_cache()
+    reg_ms = _timeit(reg_step, reps)
+    return {'what': 'fused warp+Dice forward + backward wrt the field, %d x %d^3 x %d' % (B, size, labels),
+            'ms': round(reg_ms, 3), 'Mvoxels_per_s': round(B * size ** 3 / reg_ms / 1e3, 1)}
+
+
+def unet_train_bench(dev, size=160, labels=32, reps=3):
+    """unet segmentation training step (CCE - Dice, SGD update) at BASELINE config 3."""
+    import contextlib
+    import neurite_amd as ne
     with contextlib.redirect_stdout(sys.stderr):
         net = ne.models.unet(16, (size, size, size, 1), 3, 3, labels, feat_mult=2).to(dev)
     net.train()
@@ -409,10 +412,8 @@ def training_bench(dev, size=160, labels=32, reps=5):
             for p in params:
                 p -= 1e-4 * p.grad
                 p.grad = None
-    seg_ms = timeit(seg_step, max(2, reps // 2))
-    return {'registration_step': {'what': 'fused warp+Dice forward + backward wrt the field, %d x %d^3 x %d' % (B, size, labels),
-                                  'ms': round(reg_ms, 3), 'Mvoxels_per_s': round(B * size ** 3 / reg_ms / 1e3, 1)},
-            'unet_train_step': {'what': 'BASELINE config 3 unet, forward + backward + SGD, batch 1', 'ms': round(seg_ms, 3)}}
+    seg_ms = _timeit(seg_step, reps)
+    return {'what': 'BASELINE config 3 unet, forward + backward + SGD, batch 1', 'ms': round(seg_ms, 3)}
 
 
 def main():
@@ -632,6 +633,11 @@ def main():
             out['cpu_baseline'] = {'value': None, 'unit': 'Mvoxels/s', 'cores': 0, 'kind': 'port',
                                    'sample': 'failed: %s' % e}
     if world == 1 and not args.no_unet:
+        out['training'] = {}
+        try:
+            out['training']['registration_step'] = registration_bench(mov, fix, trf)
+        except Exception as e:   # noqa
+            out['training']['registration_step'] = {'error': str(e)}
         try:
             del mov, fix, trf
             torch.cuda.empty_cache()
@@ -644,9 +650,9 @@ def main():
             out['lc3d_wcce'] = {'error': str(e)}
         try:
             torch.cuda.empty_cache()
-            out['training'] = training_bench(dev, size=S, labels=L)
+            out['training']['unet_train_step'] = unet_train_bench(dev, size=S, labels=L)
         except Exception as e:   # noqa
-            out['training'] = {'error': str(e)}
+            out['training']['unet_train_step'] = {'error': str(e)}
     if unet_multi is not None:
         out['unet_fwd'] = {'config': 'BASELINE config 3, one 160^3 volume per GPU (data-parallel inference)', 'n_gpus': world,
                            'fwd_ms': round(unet_multi, 3), 'volumes_per_s': round(world / (unet_multi * 1e-3), 1)}
