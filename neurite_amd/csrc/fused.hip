@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
     int npass = tg.plane_major ? tg.tz : (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
     const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
 
-    nrt_f4 stp = {0, 0, 0, 0}, stt = {0, 0, 0, 0}, spp = {0, 0, 0, 0};
+    // sums as float2 halves: the blend and the Dice accumulation run on v_pk_mul_f32 / v_pk_add_f32 (two IEEE fp32 operations
+    // per issue slot, no fusion -> bit-identical to the scalar sequence); the kernel is bound by VALU issue, not by memory
+    nrt_f2 stp_l = {0, 0}, stp_h = {0, 0}, stt_l = {0, 0}, stt_h = {0, 0}, spp_l = {0, 0}, spp_h = {0, 0};
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
 
     for (unsigned j = jb; j < per; j += nb) {
@@ -89,16 +91,22 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
         auto fetch_loc = [&](int pass, float (&p)[NRT_MAXD]) {
             int qd[NRT_MAXD]; bool valid;
             voxel(pass, qd, valid);
-            const unsigned q = ((unsigned)qd[0] * (unsigned)a.O[1] + (unsigned)qd[1]) * (unsigned)a.O[2] + (unsigned)qd[2];
+            // operands below 2^24 (checked by the C entry): full-rate 24-bit multiplies, 32-bit byte offsets from a uniform base
+            const unsigned q = nrt_mad24(nrt_mad24((unsigned)qd[0], (unsigned)a.O[1], (unsigned)qd[1]), (unsigned)a.O[2], (unsigned)qd[2]);
             if (MODE != NRT_LOC_LINSPACE) {
-                const float *lp = locb + (long long)q * 3;
+                const float *lp = (const float *)((const char *)locb + (size_t)(nrt_times3(q) << 2));
                 p[0] = lp[0]; p[1] = lp[1]; p[2] = lp[2];
             }
         };
-        auto prepare = [&](int pass, const float (&praw)[NRT_MAXD], TileMeta &m, unsigned (&off)[8]) {
+        // the per-voxel state that travels from prepare() to finish() is passed as separate scalars: as members of one struct
+        // the three lower weights were re-loaded pairwise, which kept the struct in memory (= in LDS, 24 B per thread)
+        struct FM { float w0x, w0y, w0z, w1x, w1y, w1z; unsigned q; bool oob, valid; };
+        auto prepare = [&](int pass, const float (&praw)[NRT_MAXD], float &W0x, float &W0y, float &W0z, unsigned &Q, bool &VALID,
+                           bool &OOB, unsigned (&off)[8]) {
+            FM m;
             int qd[NRT_MAXD];
             voxel(pass, qd, m.valid);
-            m.q = ((unsigned)qd[0] * (unsigned)a.O[1] + (unsigned)qd[1]) * (unsigned)a.O[2] + (unsigned)qd[2];
+            m.q = nrt_mad24(nrt_mad24((unsigned)qd[0], (unsigned)a.O[1], (unsigned)qd[1]), (unsigned)a.O[2], (unsigned)qd[2]);
             float p[NRT_MAXD];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -107,43 +115,58 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
                 else p[d] = (qd[d] == 0) ? 0.0f
                           : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
             }
-            int i0[3], i1[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], m.w0[d], m.w1[d]);
+            int i0x, i1x, i0y, i1y, i0z, i1z;              // scalars, not arrays: an array here ends up in LDS
+            corner_1d(p[0], a.S[0], i0x, i1x, m.w0x, m.w1x);
+            corner_1d(p[1], a.S[1], i0y, i1y, m.w0y, m.w1y);
+            corner_1d(p[2], a.S[2], i0z, i1z, m.w0z, m.w1z);
             m.oob = a.has_fill ? out_of_bounds<3>(a, p) : false;
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
-                const unsigned ix = (corner & 4) ? i1[0] : i0[0];
-                const unsigned iy = (corner & 2) ? i1[1] : i0[1];
-                const unsigned iz = (corner & 1) ? i1[2] : i0[2];
-                off[corner] = (((ix * SY + iy) * SZ + iz) * (unsigned)G + (unsigned)lg) * 16u;
+                const unsigned ix = (corner & 4) ? i1x : i0x;
+                const unsigned iy = (corner & 2) ? i1y : i0y;
+                const unsigned iz = (corner & 1) ? i1z : i0z;
+                off[corner] = (nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz) * (unsigned)G + (unsigned)lg) * 16u;
             }
+            W0x = m.w0x; W0y = m.w0y; W0z = m.w0z; Q = m.q; VALID = m.valid; OOB = m.oob;
         };
         auto load_rows = [&](const unsigned (&off)[8], unsigned q, nrt_f4 (&R)[8], nrt_f4 &T) {
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) R[corner] = *(const nrt_f4 *)(volb + (size_t)off[corner]);
-            T = __builtin_nontemporal_load(&fix[(long long)q * G + lg]);
+            T = __builtin_nontemporal_load((const nrt_f4 *)((const char *)fix + (size_t)((q * (unsigned)G + (unsigned)lg) * 16u)));
         };
-        auto finish = [&](const TileMeta &m, const nrt_f4 (&R)[8], const nrt_f4 &T) {
-            nrt_f4 acc = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+        auto finish = [&](float W0x, float W0y, float W0z, unsigned Q, bool VALID, bool OOB, const nrt_f4 (&R)[8], const nrt_f4 &T) {
+            FM m;
+            m.w0x = W0x; m.w0y = W0y; m.w0z = W0z; m.q = Q; m.valid = VALID; m.oob = OOB;
+            m.w1x = nrt_sub(1.0f, W0x); m.w1y = nrt_sub(1.0f, W0y); m.w1z = nrt_sub(1.0f, W0z);      // corner_1d's w1
+            // corner weights (wx * wy) * wz in the reference's order, two corners per packed multiply
+            const nrt_f2 wy2 = {m.w0y, m.w1y}, wz2 = {m.w0z, m.w1z};
+            const nrt_f2 wxy0 = (nrt_f2){m.w0x, m.w0x} * wy2, wxy1 = (nrt_f2){m.w1x, m.w1x} * wy2;
+            nrt_f2 wt2[4];
+            wt2[0] = (nrt_f2){wxy0[0], wxy0[0]} * wz2;          // corners 0, 1
+            wt2[1] = (nrt_f2){wxy0[1], wxy0[1]} * wz2;          // corners 2, 3
+            wt2[2] = (nrt_f2){wxy1[0], wxy1[0]} * wz2;          // corners 4, 5
+            wt2[3] = (nrt_f2){wxy1[1], wxy1[1]} * wz2;          // corners 6, 7
+            nrt_f2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) {
-                const float wt = nrt_mul(nrt_mul((corner & 4) ? m.w1[0] : m.w0[0], (corner & 2) ? m.w1[1] : m.w0[1]),
-                                         (corner & 1) ? m.w1[2] : m.w0[2]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, R[corner][c]));
+                const float wt = wt2[corner >> 1][corner & 1];
+                const nrt_f2 w2 = {wt, wt};
+                al = al + w2 * (nrt_f2){R[corner][0], R[corner][1]};
+                ah = ah + w2 * (nrt_f2){R[corner][2], R[corner][3]};
             }
+            nrt_f4 acc = {al[0], al[1], ah[0], ah[1]};
             if (a.has_fill) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], m.oob, a.fill_f);
             }
             if (m.valid) {
-                if (STORE) __builtin_nontemporal_store(acc, &out[(long long)m.q * G + lg]);
+                if (STORE) __builtin_nontemporal_store(acc, (nrt_f4 *)((char *)out + (size_t)((m.q * (unsigned)G + (unsigned)lg) * 16u)));
+                const nrt_f2 pl = {acc[0], acc[1]}, ph = {acc[2], acc[3]}, tl = {T[0], T[1]}, th = {T[2], T[3]};
+                stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
+                stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
+                spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    stp[c] += T[c] * acc[c];
-                    stt[c] += T[c] * T[c];
-                    spp[c] += acc[c] * acc[c];
                     mnt = fminf(mnt, T[c]); mxt = fmaxf(mxt, T[c]);
                     mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
                 }
@@ -151,36 +174,40 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
         };
 
         nrt_f4 Ra[8], Rb[8], Ta, Tb;
-        TileMeta Ma, Mb;
+        float Ax, Ay, Az, Bx, By, Bz;
+        unsigned Aq, Bq;
+        bool Av, Ao, Bv, Bo;
         unsigned off[8];
         float pn[NRT_MAXD] = {0.0f, 0.0f, 0.0f};
         const int last = npass - 1;
         fetch_loc(0, pn);
-        prepare(0, pn, Ma, off);
+        prepare(0, pn, Ax, Ay, Az, Aq, Av, Ao, off);
         fetch_loc(min(1, last), pn);
         __builtin_amdgcn_sched_barrier(0);
-        load_rows(off, Ma.q, Ra, Ta);
+        load_rows(off, Aq, Ra, Ta);
         __builtin_amdgcn_sched_barrier(0);
         for (int pass = 0; pass < npass; pass += 2) {
-            prepare(min(pass + 1, last), pn, Mb, off);
-            Mb.valid = Mb.valid && (pass + 1 < npass);
+            prepare(min(pass + 1, last), pn, Bx, By, Bz, Bq, Bv, Bo, off);
+            Bv = Bv && (pass + 1 < npass);
             __builtin_amdgcn_sched_barrier(0);
             fetch_loc(min(pass + 2, last), pn);
-            load_rows(off, Mb.q, Rb, Tb);
+            load_rows(off, Bq, Rb, Tb);
             __builtin_amdgcn_sched_barrier(0);
-            finish(Ma, Ra, Ta);
+            finish(Ax, Ay, Az, Aq, Av, Ao, Ra, Ta);
             __builtin_amdgcn_sched_barrier(0);
-            prepare(min(pass + 2, last), pn, Ma, off);
-            Ma.valid = Ma.valid && (pass + 2 < npass);
+            prepare(min(pass + 2, last), pn, Ax, Ay, Az, Aq, Av, Ao, off);
+            Av = Av && (pass + 2 < npass);
             __builtin_amdgcn_sched_barrier(0);
             fetch_loc(min(pass + 3, last), pn);
-            load_rows(off, Ma.q, Ra, Ta);
+            load_rows(off, Aq, Ra, Ta);
             __builtin_amdgcn_sched_barrier(0);
-            finish(Mb, Rb, Tb);
+            finish(Bx, By, Bz, Bq, Bv, Bo, Rb, Tb);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    nrt_f4 stp = {stp_l[0], stp_l[1], stp_h[0], stp_h[1]}, stt = {stt_l[0], stt_l[1], stt_h[0], stt_h[1]},
+           spp = {spp_l[0], spp_l[1], spp_h[0], spp_h[1]};
     // ---- block reduction (identical tree to dice_soft_vec) -------------------------------------
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -317,6 +344,10 @@ extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, con
     if (!warped) a.out = nullptr;
     a.fill_f = fill_value;
     if ((unsigned long long)vol_bs * 4ull >= (1ull << 32)) return NRT_ERR_UNSUPPORTED;
+    // the kernel addresses `fixed` / `warped` / `loc` rows with 32-bit byte offsets and forms row indices with 24-bit multiplies
+    if ((unsigned long long)a.nout * (unsigned long long)nlabels * 4ull >= (1ull << 32)) return NRT_ERR_UNSUPPORTED;
+    if ((long long)vol_shape[0] * vol_shape[1] >= (1 << 24) || vol_shape[2] >= (1 << 24) ||
+        (long long)out_shape[0] * out_shape[1] >= (1 << 24) || out_shape[2] >= (1 << 24)) return NRT_ERR_UNSUPPORTED;
     if ((((uintptr_t)moving | (uintptr_t)fixed | (uintptr_t)warped) & 15) != 0) return NRT_ERR_INVALID_ARG;
     if (a.nout == 0) return NRT_ERR_INVALID_ARG;
     TileGeom tg;

@@ -24,6 +24,20 @@ typedef int nrt_i4 __attribute__((ext_vector_type(4)));
 // the reference's one-rounding-per-op sequence explicit where bit-parity depends on it.
 __device__ __forceinline__ float nrt_mul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float nrt_add(float a, float b) { return __fadd_rn(a, b); }
+
+// a * b + c with 24-bit operands (full-rate v_mad_u32_u24; v_mul_lo_u32 / v_mad_u64_u32 issue at a quarter of the rate).
+// As inline asm because LLVM demotes a __umul24 whose result only feeds another 24-bit multiply back to a 32-bit one.
+__device__ __forceinline__ unsigned nrt_mad24(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// 3 * q without a multiplier (the compiler folds shift-add forms back into v_mul_lo_u32)
+__device__ __forceinline__ unsigned nrt_times3(unsigned q) {
+    unsigned r;
+    asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r) : "v"(q));
+    return r;
+}
 __device__ __forceinline__ float nrt_sub(float a, float b) { return __fsub_rn(a, b); }
 
 // tf.clip_by_value(v, lo, hi) = min(max(v, lo), hi).  fmaxf/fminf also squash NaN to a finite
