@@ -528,7 +528,7 @@ def main():
     o_elapsed, o_k0, o_k1, o_m = timed(step_unfused if fused else step_fused, max(5, args.steps // 5), 2)
     o_steps = max(5, args.steps // 5)
     unet_multi = None
-    if world > 1 and not args.no_unet:
+    if dist is not None and not args.no_unet:
         # "3D UNet fwd ms at 1/2/4/8 GPU": every rank runs the config-3 forward on its own volume (data parallel inference);
         # the slowest rank's median is reported
         try:

@@ -73,7 +73,18 @@ __global__ __launch_bounds__(256) void gamma_dc(const float *__restrict__ image,
 // idx [N] float indices -> lut[idx]; one_hot: out [N, depth] float32 (all zero for lut value < 0 or >= depth); else out_i32 [N]
 __global__ __launch_bounds__(256) void labels_out(const float *__restrict__ idx, const int *__restrict__ lut, int lut_len, int depth,
                                                   float *__restrict__ onehot, int *__restrict__ out_i32, long long n) {
-    if (onehot) {
+    if (onehot && (depth & 3) == 0 && n * depth < (1ll << 32) && (((uintptr_t)onehot) & 15) == 0) {
+        // one 16-byte store per thread and iteration, 32-bit index arithmetic (the scalar form below spends its time in a
+        // 64-bit division per element)
+        const unsigned q = (unsigned)depth >> 2, total = (unsigned)((n * depth) >> 2);
+        nrt_f4 *o4 = (nrt_f4 *)onehot;
+        for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+            const unsigned v = e / q;
+            const int d0 = (int)(e - v * q) * 4;
+            const int l = lut[min(max((int)idx[v], 0), lut_len - 1)];
+            o4[e] = (nrt_f4){l == d0 ? 1.0f : 0.0f, l == d0 + 1 ? 1.0f : 0.0f, l == d0 + 2 ? 1.0f : 0.0f, l == d0 + 3 ? 1.0f : 0.0f};
+        }
+    } else if (onehot) {
         for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n * depth; e += (long long)gridDim.x * 256) {
             const long long v = e / depth;
             const int d = (int)(e - v * depth);

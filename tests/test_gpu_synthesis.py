@@ -99,3 +99,25 @@ def test_options_and_label_conversion(dev):
         assert lo - 0.5 < m < lo + 1.5, (l, m)
     with pytest.raises(ValueError):
         model(lab[:, :-1])
+
+
+def test_one_hot_output_vector_path(dev):
+    """label counts that are multiples of 4 take the 16-byte-store form of the one-hot kernel: same result as the lookup"""
+    labels = [0, 3, 4, 7, 9, 12, 20, 31]
+    S, B = 16, 2
+    lab = label_map(dev, B, S, labels)
+    model = make((S, S, S), labels, out_label_list={3: 3, 4: 3, 7: 7, 9: 9, 12: 12, 20: 20, 31: 31, 0: 0}, seeds=dict(warp=1))
+    image, oh = model(lab)
+    oh = N(oh)
+    d = model.last_draws
+    idx = N(d['labels_warped'])[..., 0].astype(int)
+    hot = sorted({0, 3, 7, 9, 12, 20, 31})                                     # merged labels 3 and 4 -> 7 output classes: scalar path
+    assert oh.shape[-1] == len(hot)
+    model8 = make((S, S, S), labels, seeds=dict(warp=1))
+    _, oh8 = model8(lab)
+    oh8 = N(oh8)
+    idx8 = N(model8.last_draws['labels_warped'])[..., 0].astype(int)
+    assert oh8.shape[-1] == 8 and np.array_equal(oh8.argmax(-1), idx8) and np.all(oh8.sum(-1) == 1)
+    assert set(np.unique(oh8)) <= {0.0, 1.0}
+    lut7 = np.array([hot.index({0: 0, 3: 3, 4: 3, 7: 7, 9: 9, 12: 12, 20: 20, 31: 31}[l]) for l in labels])
+    assert np.array_equal(oh.argmax(-1), lut7[idx]) and np.all(oh.sum(-1) == 1)

@@ -59,3 +59,13 @@ def mi_step():
     (-mi.volumes(xg, ya).sum()).backward()
 ms = timeit(mi_step)
 print(json.dumps({'op': 'MutualInformation.volumes forward + backward', 'ms': round(ms, 4)}))
+# labels_to_image (neurite/tf/models.py:649-918): 160^3 label map with 32 labels -> warped labels (one-hot) + synthetic image
+import warnings
+lab = synth.one_hot_volume(1, S, 32, dev).argmax(-1)[None, ..., None].to(torch.int32).repeat(B, 1, 1, 1, 1)
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    gen = ne.models.labels_to_image((S, S, S), list(range(32)))
+gen = gen.to(dev) if hasattr(gen, 'to') else gen
+ms = timeit(lambda: gen(lab), n=5)
+print(json.dumps({'op': 'labels_to_image 160^3, 32 labels, batch %d (image + one-hot labels)' % B, 'ms': round(ms, 3),
+                  'ms_per_volume': round(ms / B, 3)}))
