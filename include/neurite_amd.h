@@ -147,6 +147,9 @@ int nrt_dice_from_sums_f32(const float *sums, int nlabels, int batch, float lapl
  *   fixed  [batch, out_shape, nlabels];  warped [batch, out_shape, nlabels] or NULL (not written).
  *   sums / dice / minmax as nrt_dice_soft_f32 with y_true = fixed, y_pred = warped.
  * 3-D only, nlabels in {4, 8, 16, 32, 64, 128, 256}.  tune: tile shape knob (0 = default).
+ * Size limits (NRT_ERR_UNSUPPORTED beyond them; use nrt_interpn_f32 + nrt_dice_soft_f32): one batch entry of moving /
+ * fixed / warped below 4 GiB, shape[0] * shape[1] and shape[2] below 2^24 for both shapes (32-bit row offsets, 24-bit
+ * index multiplies).
  * ------------------------------------------------------------------------------------------ */
 size_t nrt_warp_dice_workspace_bytes(const int *out_shape, int nlabels, int batch, int tune);
 int nrt_warp_dice_soft_f32(const float *moving, const float *loc, const float *fixed, float *warped,
