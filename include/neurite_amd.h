@@ -366,6 +366,19 @@ int nrt_synth_gamma_dc_f32(const float *image, const float *gamma, const float *
                            int channels, void *stream);
 int nrt_synth_labels_out(const float *idx, const int *lut, int lut_len, int depth, float *onehot, int *out_i32, long long n,
                          void *stream);
+/* Stages of labels_to_image_new (neurite/tf/models.py:920-1300) and of the augmentation layers it instantiates:
+ *   nrt_synth_axis_mask_f32    x viewed [outer, axis_len, inner]: y = x * mask[a]   (layers.RandomCrop, layers.py:446-519)
+ *   nrt_synth_axis_gather_f32  y[o, j, i] = x[o, index[j], i], j < out_len        (layers.Subsample, layers.py:367-443)
+ *   nrt_synth_noise_add_f32    y[b, v, c] = x + sd[b * sd_batch_stride + c * sd_channel_stride] * noise   (layers.GaussianNoise, :2305-2403)
+ *   nrt_synth_bg_clear_f32     y[b, v, c] = image * (labels[b, v] == 0 && flag[b] ? 0 : 1)   (models.py:1213-1223) */
+int nrt_synth_axis_mask_f32(const float *x, const float *mask, float *y, long long outer, int axis_len, long long inner,
+                            void *stream);
+int nrt_synth_axis_gather_f32(const float *x, const int *index, float *y, long long outer, int axis_len, int out_len,
+                              long long inner, void *stream);
+int nrt_synth_noise_add_f32(const float *x, const float *noise, const float *sd, float *y, int batch, long long nvox,
+                            int channels, int sd_batch_stride, int sd_channel_stride, void *stream);
+int nrt_synth_bg_clear_f32(const float *image, const float *labels, const float *flag, float *y, int batch, long long nvox,
+                           int channels, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or

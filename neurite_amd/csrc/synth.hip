@@ -99,6 +99,53 @@ __global__ __launch_bounds__(256) void labels_out(const float *__restrict__ idx,
     }
 }
 
+
+// ---- stages of labels_to_image_new (neurite/tf/models.py:920-1300) and of the augmentation layers it instantiates ------
+// x viewed as [outer, A, inner]: y = x * mask[a]   (RandomCrop, layers.py:446-519 / augment.draw_crop_mask)
+__global__ __launch_bounds__(256) void axis_mask(const float *__restrict__ x, const float *__restrict__ mask, float *__restrict__ y,
+                                                 long long total, int A, long long inner) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int a = (int)((e / inner) % A);
+        y[e] = x[e] * mask[a];
+    }
+}
+
+// y[o, j, i] = x[o, idx[j], i]   (Subsample, layers.py:367-443 / utils.subsample_axis: tf.gather along one axis)
+__global__ __launch_bounds__(256) void axis_gather(const float *__restrict__ x, const int *__restrict__ idx, float *__restrict__ y,
+                                                   long long total, int A, int J, long long inner) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e % inner, r = e / inner;
+        const int j = (int)(r % J);
+        const long long o = r / J;
+        y[e] = x[(o * A + idx[j]) * inner + i];
+    }
+}
+
+// y[b, v, c] = x[b, v, c] + sd[b * sdb + c * sdc] * noise[b, v, c]   (GaussianNoise, layers.py:2305-2403)
+__global__ __launch_bounds__(256) void noise_add(const float *__restrict__ x, const float *__restrict__ noise, const float *__restrict__ sd,
+                                                 float *__restrict__ y, long long V, int C, int sdb, int sdc) {
+    const int b = blockIdx.y;
+    const long long n = V * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long long g = (long long)b * n + e;
+        y[g] = x[g] + sd[b * sdb + c * sdc] * noise[g];
+    }
+}
+
+// y[b, v, c] = image[b, v, c] * (labels[b, v] == 0 && flag[b] ? 0 : 1)   (background clearing, models.py:1213-1223)
+__global__ __launch_bounds__(256) void bg_clear(const float *__restrict__ image, const float *__restrict__ labels,
+                                                const float *__restrict__ flag, float *__restrict__ y, long long V, int C) {
+    const int b = blockIdx.y;
+    const long long n = V * C;
+    const bool on = flag[b] != 0.0f;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const long long g = (long long)b * n + e;
+        const float keep = (on && labels[(long long)b * V + e / C] == 0.0f) ? 0.0f : 1.0f;
+        y[g] = image[g] * keep;
+    }
+}
+
 }  // namespace
 
 extern "C" int nrt_synth_relabel_i32(const int *labels, const float *lut, int lut_len, float *out, long long n, void *stream) {
@@ -146,6 +193,45 @@ extern "C" int nrt_synth_labels_out(const float *idx, const int *lut, int lut_le
     if (n == 0) return NRT_OK;
     hipLaunchKernelGGL(labels_out, dim3(sblocks(onehot ? n * depth : n)), dim3(256), 0, nrt_stream(stream), idx, lut, lut_len, depth,
                        onehot, out_i32, n);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_synth_axis_mask_f32(const float *x, const float *mask, float *y, long long outer, int axis_len, long long inner,
+                                       void *stream) {
+    if (!x || !mask || !y || outer < 0 || axis_len < 1 || inner < 1) return NRT_ERR_INVALID_ARG;
+    const long long total = outer * axis_len * inner;
+    if (total == 0) return NRT_OK;
+    hipLaunchKernelGGL(axis_mask, dim3(sblocks(total)), dim3(256), 0, nrt_stream(stream), x, mask, y, total, axis_len, inner);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_synth_axis_gather_f32(const float *x, const int *index, float *y, long long outer, int axis_len, int out_len,
+                                         long long inner, void *stream) {
+    if (!x || !index || !y || outer < 0 || axis_len < 1 || out_len < 0 || inner < 1) return NRT_ERR_INVALID_ARG;
+    const long long total = outer * out_len * inner;
+    if (total == 0) return NRT_OK;
+    hipLaunchKernelGGL(axis_gather, dim3(sblocks(total)), dim3(256), 0, nrt_stream(stream), x, index, y, total, axis_len, out_len, inner);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_synth_noise_add_f32(const float *x, const float *noise, const float *sd, float *y, int batch, long long nvox,
+                                       int channels, int sd_batch_stride, int sd_channel_stride, void *stream) {
+    if (!x || !noise || !sd || !y || batch < 1 || batch > 65535 || nvox < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (nvox == 0) return NRT_OK;
+    hipLaunchKernelGGL(noise_add, dim3(sblocks(nvox * channels), batch), dim3(256), 0, nrt_stream(stream), x, noise, sd, y, nvox, channels,
+                       sd_batch_stride, sd_channel_stride);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_synth_bg_clear_f32(const float *image, const float *labels, const float *flag, float *y, int batch, long long nvox,
+                                      int channels, void *stream) {
+    if (!image || !labels || !flag || !y || batch < 1 || batch > 65535 || nvox < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (nvox == 0) return NRT_OK;
+    hipLaunchKernelGGL(bg_clear, dim3(sblocks(nvox * channels), batch), dim3(256), 0, nrt_stream(stream), image, labels, flag, y, nvox, channels);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

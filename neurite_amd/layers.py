@@ -16,10 +16,11 @@ import torch
 from torch import nn
 
 from . import _lib
+from . import augment
 from . import utils
 
 __all__ = ['Resize', 'Zoom', 'SpatialTransformer', 'LocallyConnected3D', 'VecInt', 'RescaleTransform',
-           'ComposeTransform', 'AffineToDenseShift', 'GaussianBlur']
+           'ComposeTransform', 'AffineToDenseShift', 'GaussianBlur', 'Subsample', 'RandomCrop', 'GaussianNoise', 'PerlinNoise']
 
 
 class _Layer(nn.Module):
@@ -410,6 +411,198 @@ class GaussianBlur(_Layer):
         kernel = utils.gaussian_kernel(sigma=self.sigma, random=self.random, min_sigma=self.min_sigma, separate=True,
                                        dtype=x.dtype, seed=self.seed)
         return utils.separable_conv(x, kernel, batched=True)
+
+
+class Subsample(_Layer):
+    """
+    Symmetrically subsample a tensor [B, *S, C] by a random stride along one random spatial axis with nearest-neighbour
+    interpolation and (by default) up-sample it again, to create thick slices (layers.py:367-443).
+    """
+
+    def __init__(self, stride_min=1, stride_max=8, axes=None, prob=1, upsample=True, seed=None, **kwargs):
+        self.stride_min = stride_min
+        self.stride_max = stride_max
+        self.axes = axes
+        self.prob = prob
+        self.upsample = upsample
+        self.seed = seed
+        super().__init__(**kwargs)
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'stride_min': self.stride_min, 'stride_max': self.stride_max, 'axes': self.axes, 'prob': self.prob,
+                       'upsample': self.upsample, 'seed': self.seed})
+        return config
+
+    def build(self, input_shape):
+        ndims = len(input_shape) - 2
+        assert ndims in (1, 2, 3), 'only 1D, 2D, or 3D supported'
+        self.axes = augment.normalize_axes(self.axes, input_shape, range(1, ndims + 1), none_means_all=True)
+        self._rand = np.random.default_rng(self.seed)
+        self.built = True
+
+    def call(self, x):
+        if self.prob == 0 or self.stride_max == 1:
+            return x
+        return utils.subsample_axis(x, stride_min=self.stride_min, stride_max=self.stride_max, axes=self.axes, prob=self.prob,
+                                    upsample=self.upsample, seed=int(self._rand.integers(2 ** 31 - 1)))
+
+
+class RandomCrop(_Layer):
+    """Randomly crop the content of a tensor [B, *S, C] along a spatial axis by multiplying with a binary mask
+    (layers.py:446-519)."""
+
+    def __init__(self, crop_min=0, crop_max=0.5, axis=None, prob=1, bilateral=False, seed=None, **kwargs):
+        self.crop_min = crop_min
+        self.crop_max = crop_max
+        self.axis = axis
+        self.prob = prob
+        self.bilateral = bilateral
+        self.seed = seed
+        super().__init__(**kwargs)
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'crop_min': self.crop_min, 'crop_max': self.crop_max, 'axis': self.axis, 'prob': self.prob,
+                       'bilateral': self.bilateral, 'seed': self.seed})
+        return config
+
+    def build(self, input_shape):
+        ndims = len(input_shape) - 2
+        self.axis = augment.normalize_axes(self.axis, input_shape, range(1, ndims + 1), none_means_all=True)
+        self._rand = np.random.default_rng(self.seed)
+        self.built = True
+
+    def call(self, x):
+        if self.prob == 0:
+            return x
+        lib = _lib.lib()
+        dev = _lib.require_device(x)
+        if x.dtype != torch.float32:
+            raise NotImplementedError('RandomCrop: float32 tensors, got %s' % x.dtype)
+        mask = augment.draw_crop_mask(x, crop_min=self.crop_min, crop_max=self.crop_max, axis=self.axis, prob=self.prob,
+                                      bilateral=self.bilateral, seed=int(self._rand.integers(2 ** 31 - 1)))
+        self.last_mask = mask
+        ax = int(np.argmax([m > 1 for m in mask.shape])) if max(mask.shape) > 1 else self.axis[0]
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        outer = int(np.prod(x.shape[:ax])) if ax else 1
+        inner = int(np.prod(x.shape[ax + 1:]))
+        with torch.cuda.device(dev):
+            rc = lib.nrt_synth_axis_mask_f32(_lib.ptr(x), _lib.ptr(mask.reshape(-1).contiguous()), _lib.ptr(y), outer, x.shape[ax],
+                                             inner, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_synth_axis_mask_f32')
+        return y
+
+
+class GaussianNoise(_Layer):
+    """
+    Sample and add (or return) Gaussian noise whose SD is drawn uniformly from [noise_min, noise_max) times the absolute
+    maximum of the input (unless `absolute`), separately along `axes` (layers.py:2305-2403).  float32 [B, *S, C].
+    """
+
+    def __init__(self, noise_min=0.01, noise_max=0.10, noise_only=False, absolute=False, axes=(0, -1), seed=None, **kwargs):
+        self.noise_min = noise_min
+        self.noise_max = noise_max
+        self.noise_only = noise_only
+        self.absolute = absolute
+        self.axes = axes
+        self.seed = seed
+        super().__init__(**kwargs)
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'noise_min': self.noise_min, 'noise_max': self.noise_max, 'noise_only': self.noise_only,
+                       'absolute': self.absolute, 'axes': self.axes, 'seed': self.seed})
+        return config
+
+    def build(self, in_shape):
+        num_dim = len(in_shape)
+        self.axes = [int(ax) + num_dim if ax < 0 else int(ax) for ax in np.ravel(self.axes)]
+        assert all(0 <= ax < num_dim for ax in self.axes), 'invalid axes'
+        if any(ax not in (0, num_dim - 1) for ax in self.axes):
+            raise NotImplementedError('neurite_amd GaussianNoise: a separate SD along the batch and / or feature axis only')
+        self._gen = None
+        self.built = True
+
+    def call(self, x):
+        if self.noise_max == 0 and not self.noise_only:
+            return x
+        lib = _lib.lib()
+        dev = _lib.require_device(x)
+        if x.dtype != torch.float32:
+            raise NotImplementedError('GaussianNoise: float32 tensors, got %s' % x.dtype)
+        if self._gen is None:
+            self._gen = torch.Generator(device=dev)
+            if self.seed is None:
+                self._gen.seed()
+            else:
+                self._gen.manual_seed(int(self.seed))
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        nb = B if 0 in self.axes else 1
+        nc = C if (x.dim() - 1) in self.axes else 1
+        lo = torch.as_tensor(self.noise_min, dtype=torch.float32, device=dev)
+        hi = torch.as_tensor(self.noise_max, dtype=torch.float32, device=dev)
+        sd = lo + (hi - lo) * torch.rand((nb, nc), generator=self._gen, device=dev)
+        if not self.absolute:
+            mm = utils._device_minmax(x)
+            sd = sd * torch.maximum(mm[0].abs(), mm[1].abs())
+        sd = sd.contiguous()
+        noise = torch.randn(x.shape, generator=self._gen, device=dev)
+        self.last_draws = dict(sd=sd, noise=noise)
+        base = torch.zeros_like(x) if self.noise_only else x
+        y = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_synth_noise_add_f32(_lib.ptr(base), _lib.ptr(noise), _lib.ptr(sd), _lib.ptr(y), B, x[0].numel() // C, C,
+                                             nc if nb > 1 else 0, 1 if nc > 1 else 0, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_synth_noise_add_f32')
+        return y
+
+
+class PerlinNoise(_Layer):
+    """
+    Sample Perlin noise of the input's shape (or `shape`, excluding the batch dimension) by drawing noise at full resolution
+    and smoothing it randomly at several scales (layers.py:2406-2508); `reduce` is 'std' or 'max' (or tf / torch functions
+    of those names).  Only the batch size (and possibly the shape) of the input is used.
+    """
+
+    def __init__(self, shape=None, noise_min=0.01, noise_max=1, fwhm_min=4, fwhm_max=32, isotropic=False, reduce='std',
+                 out_type=torch.float32, axes=None, seed=None, **kwargs):
+        self.shape = shape
+        self.noise_min = noise_min
+        self.noise_max = noise_max
+        self.fwhm_min = fwhm_min
+        self.fwhm_max = fwhm_max
+        self.isotropic = isotropic
+        self.reduce = reduce
+        self.out_type = out_type
+        self.axes = axes
+        self.seed = seed
+        super().__init__(**kwargs)
+
+    def get_config(self):
+        config = super().get_config().copy()
+        config.update({'shape': self.shape, 'noise_min': self.noise_min, 'noise_max': self.noise_max, 'fwhm_min': self.fwhm_min,
+                       'fwhm_max': self.fwhm_max, 'isotropic': self.isotropic, 'reduce': self.reduce, 'out_type': self.out_type,
+                       'axes': self.axes, 'seed': self.seed})
+        return config
+
+    def build(self, input_shape):
+        self._rand = np.random.default_rng(self.seed)
+        shape = input_shape if self.shape is None else (input_shape[0],) + tuple(self.shape)
+        self.axes = augment.normalize_axes(self.axes, shape, range(1, len(shape)), none_means_all=False)
+        self.built = True
+
+    def call(self, x):
+        dev = _lib.require_device(x)
+        shape = tuple(x.shape[1:]) if self.shape is None else tuple(int(s) for s in self.shape)
+        return torch.stack([
+            augment.draw_perlin_full(shape, noise_min=self.noise_min, noise_max=self.noise_max, isotropic=self.isotropic,
+                                     fwhm_min=self.fwhm_min, fwhm_max=self.fwhm_max, batched=False, featured=True,
+                                     dtype=torch.float32, seed=int(self._rand.integers(2 ** 31 - 1)),
+                                     axes=[ax - 1 for ax in self.axes], reduce=self.reduce, device=dev)
+            for _ in range(x.shape[0])], 0)
 
 
 def _normalize_tuple(value, n, name):

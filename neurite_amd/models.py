@@ -30,7 +30,7 @@ from torch import nn
 from . import _lib
 from . import utils
 
-__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'load', 'load_config']
+__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'labels_to_image_new', 'load', 'load_config']
 
 _ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}
 _EW_ACTS = dict(_ACTS, sigmoid=3)            # stand-alone Activation layers only (nrt_add_act_affine_f32)
@@ -1328,3 +1328,9 @@ def labels_to_image(*args, **kwargs):
     """neurite/tf/models.py:649-918; implemented in neurite_amd.synthesis."""
     from . import synthesis
     return synthesis.labels_to_image(*args, **kwargs)
+
+
+def labels_to_image_new(*args, **kwargs):
+    """neurite/tf/models.py:920-1300; implemented in neurite_amd.synthesis."""
+    from . import synthesis
+    return synthesis.labels_to_image_new(*args, **kwargs)

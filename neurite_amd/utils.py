@@ -740,3 +740,194 @@ def flatten_axes(x, axes):
     if axes[-1] < x.dim() - 1 and not (axes[-1] == -1):
         new += shp[axes[-1] + 1:]
     return x.reshape(new)
+
+
+# --------------------------------------------------------------------------------------
+# affine sampling helpers of voxelmorph that neurite's labels_to_image_new instantiates (neurite/tf/models.py:1068-1112:
+# vxm.layers.DrawAffineParams, ParamsToAffineMatrix, vxm.utils.draw_flip_matrix / draw_swap_matrix).  voxelmorph is not
+# vendored in the reference tree; these follow its published interface.  Host-side: a handful of numbers per batch entry.
+# --------------------------------------------------------------------------------------
+
+def _host_generator(seed):
+    g = torch.Generator(device='cpu')
+    if seed is None:
+        g.seed()
+    else:
+        g.manual_seed(int(seed) % (2 ** 63 - 1))
+    return g
+
+
+def draw_affine_params(shift=None, rot=None, scale=None, shear=None, normal_shift=False, normal_rot=False,
+                       normal_scale=False, normal_shear=False, shift_scale=False, ndims=3, batch_shape=None, concat=True,
+                       dtype=torch.float32, seeds={}):
+    """
+    Draw translation, rotation, scaling and shearing parameters: uniformly in [-bound, bound] or, with normal_*, normally
+    with the bound as SD (scaling: truncated at two SDs).  Returns [*batch_shape, M] with M = 12 (3-D) or 6 (2-D), ordered
+    shift, rot, scale, shear; scaling parameters are deviations from 1 unless shift_scale.
+    """
+    assert ndims in (2, 3), 'only 2D and 3D supported'
+    splits = dict(shift=ndims, rot=3 if ndims == 3 else 1, scale=ndims, shear=3 if ndims == 3 else 1)
+    bounds = dict(shift=shift, rot=rot, scale=scale, shear=shear)
+    normal = dict(shift=normal_shift, rot=normal_rot, scale=normal_scale, shear=normal_shear)
+    batch_shape = [] if batch_shape is None else [int(b) for b in np.ravel(batch_shape)]
+    par = {}
+    for key, n in splits.items():
+        lim = np.ravel(0 if bounds[key] is None else bounds[key]).astype(np.float64)
+        if lim.size == 1:
+            lim = np.repeat(lim, n)
+        assert lim.size == n, f'unexpected number of {key} bounds {lim.size}, expected 1 or {n}'
+        lim = torch.as_tensor(lim, dtype=torch.float64)
+        gen = _host_generator(seeds.get(key) if isinstance(seeds, dict) else None)
+        shp = batch_shape + [n]
+        if normal[key]:
+            draw = torch.randn(shp, generator=gen, dtype=torch.float64)
+            if key == 'scale':                                  # tf.random.truncated_normal: re-draw beyond two SDs
+                for _ in range(64):
+                    bad = draw.abs() > 2
+                    if not bool(bad.any()):
+                        break
+                    draw = torch.where(bad, torch.randn(shp, generator=gen, dtype=torch.float64), draw)
+                draw = draw.clamp(-2, 2)
+            draw = draw * lim
+        else:
+            draw = (torch.rand(shp, generator=gen, dtype=torch.float64) * 2 - 1) * lim
+        par[key] = draw.to(dtype)
+    if shift_scale:
+        par['scale'] = par['scale'] + 1
+    return torch.cat(list(par.values()), -1) if concat else par
+
+
+def angles_to_rotation_matrix(ang, deg=True, ndims=3):
+    """Rotation matrices [..., N, N] from angles [..., 1] (2-D) or [..., 3] (3-D, intrinsic R = Rx @ Ry @ Rz)."""
+    assert ndims in (2, 3), 'only 2D and 3D supported'
+    ang = torch.as_tensor(ang)
+    if ang.dim() == 0:
+        ang = ang.reshape(1)
+    n = 1 if ndims == 2 else 3
+    if ang.shape[-1] < n:
+        ang = torch.cat([ang, ang.new_zeros(ang.shape[:-1] + (n - ang.shape[-1],))], -1)
+    ang = ang[..., :n]
+    if deg:
+        ang = ang * (np.pi / 180)
+    c, s = torch.cos(ang), torch.sin(ang)
+    one, zero = torch.ones_like(c[..., 0]), torch.zeros_like(c[..., 0])
+
+    def mat(rows):
+        return torch.stack([torch.stack(r, -1) for r in rows], -2)
+    if ndims == 2:
+        return mat([[c[..., 0], -s[..., 0]], [s[..., 0], c[..., 0]]])
+    rx = mat([[one, zero, zero], [zero, c[..., 0], -s[..., 0]], [zero, s[..., 0], c[..., 0]]])
+    ry = mat([[c[..., 1], zero, s[..., 1]], [zero, one, zero], [-s[..., 1], zero, c[..., 1]]])
+    rz = mat([[c[..., 2], -s[..., 2], zero], [s[..., 2], c[..., 2], zero], [zero, zero, one]])
+    return rx @ ry @ rz
+
+
+def params_to_affine_matrix(par, deg=True, shift_scale=False, last_row=False, ndims=3):
+    """
+    Affine matrices [..., N, N+1] (N+1 rows with last_row) from parameter vectors ordered shift, rot, scale, shear
+    (missing trailing parameters are neutral): T @ R @ diag(scale) @ shear with an upper-triangular shear matrix.
+    """
+    assert ndims in (2, 3), 'only 2D and 3D supported'
+    par = torch.as_tensor(par)
+    if not par.dtype.is_floating_point:
+        par = par.to(torch.float32)
+    nrot = 3 if ndims == 3 else 1
+    widths = (ndims, nrot, ndims, nrot)
+    total = sum(widths)
+    if par.shape[-1] > total:
+        raise ValueError(f'number of params exceeds value {total} expected for dimensionality')
+    if par.shape[-1] < total:
+        pad = par.new_zeros(par.shape[:-1] + (total - par.shape[-1],))
+        if par.shape[-1] <= ndims + nrot and not shift_scale:      # scaling parameters were not given at all: neutral = 1
+            pad[..., ndims + nrot - par.shape[-1]:2 * ndims + nrot - par.shape[-1]] = 1
+        par = torch.cat([par, pad], -1)
+    shift, rot, scale, shear = torch.split(par, widths, -1)
+    if shift_scale:
+        scale = scale + 1
+    m_rot = angles_to_rotation_matrix(rot, deg=deg, ndims=ndims)
+    m_scale = torch.diag_embed(scale)
+    m_shear = torch.eye(ndims, dtype=par.dtype, device=par.device).expand(par.shape[:-1] + (ndims, ndims)).clone()
+    iu = np.triu_indices(ndims, k=1)
+    for k, (i, j) in enumerate(zip(*iu)):
+        m_shear[..., i, j] = shear[..., k]
+    out = torch.cat([m_rot @ m_scale @ m_shear, shift[..., None]], -1)
+    if last_row:
+        row = out.new_zeros(out.shape[:-2] + (1, ndims + 1))
+        row[..., -1] = 1
+        out = torch.cat([out, row], -2)
+    return out
+
+
+def draw_flip_matrix(grid_shape, shift_center=True, last_row=True, dtype=torch.float32, seed=None):
+    """Matrix that flips each axis of an N-D grid with probability 1/2 (about the grid centre unless shift_center)."""
+    ndims = len(grid_shape)
+    bit = (torch.randn(ndims, generator=_host_generator(seed)) > 0).to(dtype)
+    out = torch.zeros(ndims, ndims + 1, dtype=dtype)
+    out[:, :ndims] = torch.diag(1 - 2 * bit)
+    if not shift_center:
+        out[:, -1] = (torch.as_tensor(np.asarray(grid_shape), dtype=dtype) - 1) * bit
+    if last_row:
+        out = torch.cat([out, torch.tensor([[0.] * ndims + [1.]], dtype=dtype)], 0)
+    return out
+
+
+def draw_swap_matrix(ndims, last_row=True, dtype=torch.float32, seed=None):
+    """Matrix that randomly permutes the axes of N-D space."""
+    perm = torch.randperm(ndims, generator=_host_generator(seed))
+    out = torch.zeros(ndims, ndims + 1, dtype=dtype)
+    out[torch.arange(ndims), perm] = 1
+    if last_row:
+        out = torch.cat([out, torch.tensor([[0.] * ndims + [1.]], dtype=dtype)], 0)
+    return out
+
+
+def _axis_gather(x, index, ax):
+    """y = tf.gather(x, index, axis=ax) of a float32 device tensor (csrc/synth.hip)."""
+    lib = _lib.lib()
+    dev = _lib.require_device(x)
+    x = x.contiguous()
+    idx = torch.as_tensor(np.asarray(index, dtype=np.int32)).to(dev)
+    outer = int(np.prod(x.shape[:ax])) if ax else 1
+    inner = int(np.prod(x.shape[ax + 1:]))
+    y = torch.empty(tuple(x.shape[:ax]) + (idx.numel(),) + tuple(x.shape[ax + 1:]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_synth_axis_gather_f32(_lib.ptr(x), _lib.ptr(idx), _lib.ptr(y), outer, x.shape[ax], idx.numel(), inner,
+                                           _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_synth_axis_gather_f32')
+    return y
+
+
+def subsample_axis_indices(width, thick):
+    """index lists of utils.subsample_axis (utils.py:815-824): slices kept, and the map back to `width` samples"""
+    num_slice = int(np.float32(width) / np.float32(thick) + np.float32(0.5))
+    down = (np.linspace(0, width - 1, num_slice).astype(np.float32) + np.float32(0.5)).astype(np.int32)
+    up = (np.linspace(0, num_slice - 1, width).astype(np.float32) + np.float32(0.5)).astype(np.int32)
+    return down, up
+
+
+def subsample_axis(x, stride_min=1, stride_max=8, axes=None, prob=1, upsample=True, seed=None):
+    """
+    Symmetrically subsample a tensor by a random factor (stride) along one randomly drawn axis with nearest-neighbour
+    interpolation and optionally up-sample it again (utils.py:754-826).  float32 device tensors.
+    """
+    if x.dtype != torch.float32:
+        raise NotImplementedError('subsample_axis: float32 tensors, got %s' % x.dtype)
+    num_dim = x.dim()
+    if axes is None:
+        axes = range(num_dim)
+    if np.isscalar(axes):
+        axes = [axes]
+    axes = list(axes)
+    assert all(i in range(num_dim) for i in axes), 'invalid axis passed'
+    assert 0 < stride_min and stride_min <= stride_max, 'invalid strides'
+    gen = _host_generator(seed)
+    ax = axes[int(torch.randint(len(axes), (), generator=gen))]
+    width = x.shape[ax]
+    thick = float(stride_min + (stride_max - stride_min) * torch.rand((), generator=gen))
+    assert 0 <= prob <= 1, f'{prob} not a probability'
+    if prob < 1 and not bool(torch.rand((), generator=gen) < prob):
+        thick = 1.0
+    down, up = subsample_axis_indices(width, thick)
+    if upsample:
+        return _axis_gather(x, down[up], ax)                 # the two gathers of the reference composed into one
+    return _axis_gather(x, down, ax)

@@ -380,3 +380,68 @@ def test_gaussian_kernel_and_synthesis_tables_cpu():
     assert c['mean_min'] == [0, 25, 25, 25] and c['std_max'] == [25] * 4
     with pytest.raises(NotImplementedError):
         ne.models.labels_to_image((8, 8, 8), [0, 1], input_model=object())
+
+
+def test_affine_sampling_helpers_cpu():
+    """vxm-style helpers behind labels_to_image_new (host-side): parameter layout, matrix composition, flips, swaps"""
+    from neurite_amd import augment, utils
+    p = utils.draw_affine_params(shift=5, rot=10, scale=0.1, shear=0.05, ndims=3, batch_shape=[6], seeds=dict(shift=1, rot=2))
+    assert p.shape == (6, 12)
+    assert (p[:, :3].abs() <= 5).all() and (p[:, 3:6].abs() <= 10).all() and (p[:, 6:9].abs() <= 0.1).all()
+    again = utils.draw_affine_params(shift=5, rot=10, scale=0.1, shear=0.05, ndims=3, batch_shape=[6], seeds=dict(shift=1, rot=2))
+    assert torch.equal(p[:, :6], again[:, :6])                               # seeded components reproduce
+    t = utils.draw_affine_params(scale=0.2, normal_scale=True, ndims=2, batch_shape=[500])
+    assert t.shape == (500, 6) and (t[:, 3:5].abs() <= 0.4 + 1e-6).all()     # truncated at two SDs
+    eye = utils.params_to_affine_matrix(torch.zeros(12), shift_scale=True, last_row=True)
+    assert torch.equal(eye, torch.eye(4))
+    m = utils.params_to_affine_matrix(torch.tensor([1., 2., 3., 90., 0., 0., 2., 3., 4., 0.5, 0., 0.]))
+    want = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], np.float64) @ np.diag([2., 3., 4.]) @ np.array([[1, .5, 0], [0, 1, 0], [0, 0, 1]])
+    np.testing.assert_allclose(m[:, :3].numpy(), want, atol=1e-6)
+    np.testing.assert_allclose(m[:, 3].numpy(), [1, 2, 3])
+    r = utils.angles_to_rotation_matrix(torch.tensor([[10., 20., 30.], [0., 0., 45.]]))
+    np.testing.assert_allclose((r @ r.transpose(1, 2)).numpy(), np.broadcast_to(np.eye(3), (2, 3, 3)), atol=1e-6)
+    np.testing.assert_allclose(torch.linalg.det(r).numpy(), 1.0, atol=1e-6)
+    r2 = utils.params_to_affine_matrix(torch.tensor([0., 0., 90.]), ndims=2)
+    np.testing.assert_allclose(r2.numpy(), [[0, -1, 0], [1, 0, 0]], atol=1e-6)
+    with pytest.raises(ValueError, match='exceeds'):
+        utils.params_to_affine_matrix(torch.zeros(13))
+    f = utils.draw_flip_matrix((8, 9, 10), shift_center=False, seed=3)
+    assert f.shape == (4, 4) and set(torch.diag(f)[:3].tolist()) <= {1.0, -1.0}
+    for d in range(3):                                                          # a flipped axis maps index i to (n - 1) - i
+        if f[d, d] < 0:
+            assert f[d, 3] == (8, 9, 10)[d] - 1
+        else:
+            assert f[d, 3] == 0
+    s = utils.draw_swap_matrix(3, seed=1)
+    assert sorted(s[:3, :3].sum(0).tolist()) == [1, 1, 1] and sorted(s[:3, :3].sum(1).tolist()) == [1, 1, 1] and s[3, 3] == 1
+    down, up = utils.subsample_axis_indices(16, 3.3)
+    assert down.tolist() == [0, 4, 8, 11, 15] and len(up) == 16 and up[0] == 0 and up[-1] == 4
+    assert augment.normalize_axes(-1, (2, 3, 4)) == (2,) and augment.normalize_axes(None, (2, 3, 4), (1, 2), True) == (1, 2)
+    with pytest.raises(IndexError):
+        augment.normalize_axes(0, (2, 3, 4), allowed=(1, 2))
+    x = torch.zeros(2, 10, 6, 1)
+    mask = augment.draw_crop_mask(x, crop_min=0.3, crop_max=0.3, axis=1, prob=1, seed=5)
+    assert mask.shape == (1, 10, 1, 1) and mask.sum() == 7 and (mask[0, :3, 0, 0].sum() == 0 or mask[0, 7:, 0, 0].sum() == 0)
+    both = augment.draw_crop_mask(x, crop_min=0.4, crop_max=0.4, axis=(1, 2), bilateral=True, seed=6)
+    assert sorted(both.shape)[-1] in (10, 6) and int(both.sum()) in (6, 3, 4)
+    assert augment.draw_crop_mask(x, crop_max=0.5, prob=0, axis=1).sum() == 10
+
+
+def test_labels_to_image_new_tables_cpu():
+    """label look-up tables of labels_to_image_new (models.py:1145-1153, 1243-1258) and its argument checks"""
+    import neurite_amd as ne
+    m = ne.models.labels_to_image_new([0, 1, 2, 3], in_shape=(16, 16, 16))
+    assert m.cfg['depth'] == 4 and m.cfg['gen_lut'].tolist() == [0, 1, 2, 3] and m.cfg['out_lut'].tolist() == [0, 1, 2, 3]
+    m = ne.models.labels_to_image_new({0: 0, 3: 'a', 4: 'a', 9: 'b'}, labels_out={3: 1, 4: 1, 9: 2}, in_shape=(16, 16, 16))
+    g = m.cfg['gen_lut']
+    assert g[3] == g[4] and len({g[0], g[3], g[9]}) == 3 and m.cfg['num_label'] == 3        # left / right share an intensity
+    assert m.cfg['out_lut'].tolist() == [-1, -1, -1, 0, 0, -1, -1, -1, -1, 1] and m.cfg['depth'] == 2
+    m = ne.models.labels_to_image_new([0, 5], labels_out=[5], in_shape=(8, 8), one_hot=False)
+    assert m.cfg['out_lut'].tolist() == [0, 0, 0, 0, 0, 5]
+    with pytest.raises(AssertionError, match='unknown seeds'):
+        ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), seeds=dict(nonsense=1))
+    with pytest.raises(AssertionError, match='gamma value'):
+        ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), gamma=1.5)
+    with pytest.raises(NotImplementedError):
+        ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), input_model=object())
+    assert ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), out_shape=(8, 8, 8), half_res=True).cfg['out_shape'].tolist() == [4, 4, 4]
