@@ -69,3 +69,10 @@ gen = gen.to(dev) if hasattr(gen, 'to') else gen
 ms = timeit(lambda: gen(lab), n=5)
 print(json.dumps({'op': 'labels_to_image 160^3, 32 labels, batch %d (image + one-hot labels)' % B, 'ms': round(ms, 3),
                   'ms_per_volume': round(ms / B, 3)}))
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    gen2 = ne.models.labels_to_image_new(list(range(32)), in_shape=(S, S, S), aff_shift=10, aff_rotate=10, aff_scale=0.1, aff_shear=0.05)
+labf = lab.to(torch.float32)
+ms = timeit(lambda: gen2(labf), n=5)
+print(json.dumps({'op': 'labels_to_image_new 160^3, 32 labels, batch %d, affine + warp + bias + noise + blur (defaults)' % B,
+                  'ms': round(ms, 3), 'ms_per_volume': round(ms / B, 3)}))
