@@ -30,7 +30,7 @@ from torch import nn
 from . import _lib
 from . import utils
 
-__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'labels_to_image_new', 'load', 'load_config']
+__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'labels_to_image_new', 'SynthStrip', 'load', 'load_config']
 
 _ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}
 _EW_ACTS = dict(_ACTS, sigmoid=3)            # stand-alone Activation layers only (nrt_add_act_affine_f32)
@@ -1334,3 +1334,72 @@ def labels_to_image_new(*args, **kwargs):
     """neurite/tf/models.py:920-1300; implemented in neurite_amd.synthesis."""
     from . import synthesis
     return synthesis.labels_to_image_new(*args, **kwargs)
+
+
+class SynthStrip(nn.Module):
+    """
+    SynthStrip (neurite/tf/models.py:1888-1967): a label map is turned into a synthetic image by `labels_to_image`
+    (integer output labels), a unet with one linear output channel is applied to it, and the model returns the unet output
+    concatenated with the warped label map, [B, *inshape, 2], for a brain / non-brain loss.  Constructor arguments are
+    recorded as `modelio.store_config_args` does (`get_config`, `save`, `SynthStrip.load`).
+    """
+
+    def __init__(self, inshape, labels_in, labels_out, nb_unet_features=None, nb_unet_levels=None, unet_feat_mult=1,
+                 nb_unet_conv_per_level=1, src_feats=1, gen_args={}):
+        super().__init__()
+        ndims = len(inshape)
+        assert ndims in [1, 2, 3], 'ndims should be one of 1, 2, or 3. found: %d' % ndims
+        inshape = tuple(int(s) for s in inshape)
+        self.config = {'builder': 'SynthStrip', 'loadable': True,
+                       'params': dict(inshape=list(inshape), labels_in=_jsonable(labels_in), labels_out=_jsonable(labels_out),
+                                      nb_unet_features=_jsonable(nb_unet_features), nb_unet_levels=nb_unet_levels,
+                                      unet_feat_mult=unet_feat_mult, nb_unet_conv_per_level=nb_unet_conv_per_level,
+                                      src_feats=src_feats, gen_args=_jsonable(dict(gen_args)), metadata={})}
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')                       # the reference builds the deprecated generator here too
+            self.gen_model = labels_to_image(inshape, labels_in, labels_out, id=0, return_def=False, one_hot=False, **gen_args)
+        self.unet = unet(nb_unet_features, (*inshape, 1), nb_unet_levels, ndims * (3,), 1, feat_mult=unet_feat_mult,
+                         nb_conv_per_level=nb_unet_conv_per_level, final_pred_activation='linear')
+        self.name = 'synthstrip'
+
+    def get_config(self):
+        return self.config['params']
+
+    @property
+    def metadata(self):
+        return self.config['params']['metadata']
+
+    def get_strip_model(self):
+        """the stripping model (just the U-Net)"""
+        return self.unet
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.unet.train(mode)                                    # ConvNet defaults to eval(); follow the wrapper's mode
+        return self
+
+    def forward(self, labels):
+        synth_image, synth_labels = self.gen_model(labels)[:2]
+        self.synth_image = synth_image
+        out = self.unet(synth_image)
+        return torch.cat([out, synth_labels.to(torch.float32)], -1)
+
+    def save(self, path):
+        """unet weights + constructor arguments (npz), reloadable with SynthStrip.load"""
+        cfg = json.dumps({'class_name': 'SynthStrip', 'config': self.get_config()})
+        np.savez(path, __model_config__=np.array(cfg), **self.unet._npz_dict())
+
+    @classmethod
+    def load(cls, path, **kwargs):
+        builder, config = load_config(path)
+        if builder != 'SynthStrip':
+            raise ValueError('%s was not saved from a SynthStrip model (class_name %r)' % (path, builder))
+        config.update(kwargs)
+        metadata = config.pop('metadata', {})
+        for key in ('labels_in', 'labels_out'):               # JSON turned integer label keys into strings
+            if isinstance(config.get(key), dict):
+                config[key] = {(int(k) if isinstance(k, str) and k.lstrip('-').isdigit() else k): v for k, v in config[key].items()}
+        model = cls(**config)
+        model.metadata.update(metadata)
+        model.unet.load_weights(path)
+        return model

@@ -121,3 +121,29 @@ def test_one_hot_output_vector_path(dev):
     assert set(np.unique(oh8)) <= {0.0, 1.0}
     lut7 = np.array([hot.index({0: 0, 3: 3, 4: 3, 7: 7, 9: 9, 12: 12, 20: 20, 31: 31}[l]) for l in labels])
     assert np.array_equal(oh.argmax(-1), lut7[idx]) and np.all(oh.sum(-1) == 1)
+
+
+def test_synthstrip_forward_and_training_step(dev):
+    """SynthStrip (models.py:1888-1967): generator -> unet -> concat([logit, warped labels]); one SGD step through the unet"""
+    import contextlib
+    import io
+    labels = [0, 1, 2, 3]
+    S, B = 16, 2
+    lab = label_map(dev, B, S, labels)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ne.models.SynthStrip((S, S, S), labels, {1: 1, 2: 1, 3: 1}, nb_unet_features=4, nb_unet_levels=2,
+                                     gen_args=dict(seeds=dict(warp=2, mean=3)))
+    model = model.to(dev)
+    out = model(lab)
+    assert out.shape == (B, S, S, S, 2)
+    seg = N(out[..., 1])
+    assert set(np.unique(seg)) <= {0.0, 1.0}                                        # brain / non-brain after the output look-up
+    want = N(model.get_strip_model()(model.synth_image))
+    assert np.array_equal(N(out[..., :1]), want)                                    # channel 0 is the unet applied to the synthetic image
+    model.train()
+    out = model(lab)
+    target = out[..., 1:].detach()
+    loss = ((out[..., :1] - target) ** 2).mean()
+    loss.backward()
+    grads = [p.grad for p in model.unet.parameters()]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads) and any(float(g.abs().max()) > 0 for g in grads)

@@ -445,3 +445,34 @@ def test_labels_to_image_new_tables_cpu():
     with pytest.raises(NotImplementedError):
         ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), input_model=object())
     assert ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), out_shape=(8, 8, 8), half_res=True).cfg['out_shape'].tolist() == [4, 4, 4]
+
+
+def test_synthstrip_config_roundtrip_cpu(tmp_path):
+    """SynthStrip (models.py:1888-1967) records its constructor arguments and reloads them with the unet weights"""
+    import contextlib, io
+    import neurite_amd as ne
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ne.models.SynthStrip((16, 16, 16), [0, 1, 2, 3], {1: 1, 2: 1, 3: 1}, nb_unet_features=4, nb_unet_levels=2,
+                                 gen_args=dict(warp_std=0.5))
+    assert m.get_strip_model() is m.unet and m.unet.layer_names[-1] == 'unet_prediction'
+    assert m.unet.output_shape[-1] == 1 and m.gen_model.cfg['one_hot'] is False
+    assert m.gen_model.cfg['out_lut'].tolist() == [0, 1, 1, 1]
+    rng = np.random.default_rng(0)
+    new = [rng.standard_normal(a.shape).astype(np.float32) for a in m.unet.get_weights()]
+    m.unet.set_weights(new)
+    m.metadata['note'] = 'x'
+    p = str(tmp_path / 'ss.npz')
+    m.save(p)
+    with contextlib.redirect_stdout(io.StringIO()):
+        back = ne.models.SynthStrip.load(p)
+    assert back.get_config()['labels_out'] == {1: 1, 2: 1, 3: 1} and back.metadata == {'note': 'x'}
+    assert back.gen_model.cfg['out_lut'].tolist() == [0, 1, 1, 1] and back.gen_model.cfg['warp_std'] == 0.5
+    assert all(np.array_equal(a, b) for a, b in zip(back.unet.get_weights(), new))
+    assert back.unet.training is False
+    back.train()
+    assert back.unet.training is True
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ne.models.unet(4, (16, 16, 16, 1), 2, 3, 2)
+    net.save(str(tmp_path / 'u.npz'))
+    with pytest.raises(ValueError, match='not saved from a SynthStrip'):
+        ne.models.SynthStrip.load(str(tmp_path / 'u.npz'))
