@@ -30,7 +30,7 @@ from torch import nn
 from . import _lib
 from . import utils
 
-__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'labels_to_image_new', 'SynthStrip', 'load', 'load_config']
+__all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'labels_to_image_new', 'SynthStrip', 'add_prior', 'dilation_net', 'load', 'load_config']
 
 _ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}
 _EW_ACTS = dict(_ACTS, sigmoid=3)            # stand-alone Activation layers only (nrt_add_act_affine_f32)
@@ -1135,6 +1135,63 @@ def _fix_residual_adds(bld):
             raise RuntimeError('degenerate residual add in ' + op['name'])
 
 
+def _append_prior(bld, last, model_name, prefix, spatial, nb_labels, ndims, input_index, use_logp, final_pred_activation):
+    """the layers of models.add_prior (models.py:378-436) appended to a graph under construction; returns the output name"""
+    sp = (1,) * (3 - ndims) + tuple(spatial)
+    prior = bld.add({'kind': 'input', 'name': '%s-input' % prefix, 'index': input_index}, (sp, nb_labels))
+    if use_logp:                                                                 # :401-406
+        print("Breaking change: use_logp option now requires log input!", file=sys.stderr)
+        post = bld.add({'kind': 'add', 'name': '%s_posterior' % prefix, 'a': prior, 'b': last}, (sp, nb_labels))
+    else:                                                                        # :408-414: sigmoid likelihood x prior
+        like = bld.add({'kind': 'activation', 'name': '%s_likelihood_sigmoid' % prefix, 'src': last, 'activation': 'sigmoid'},
+                       (sp, nb_labels))
+        post = bld.add({'kind': 'multiply', 'name': '%s_posterior' % prefix, 'a': prior, 'b': like}, (sp, nb_labels))
+    if final_pred_activation == 'softmax':
+        assert use_logp, 'cannot do softmax when adding prior via P()'
+        print("using final_pred_activation %s for %s" % (final_pred_activation, model_name))
+        return bld.add({'kind': 'prediction', 'name': '%s_prediction' % prefix, 'src': post, 'activation': 'softmax'}, (sp, nb_labels))
+    return bld.add({'kind': 'prediction', 'name': '%s_prediction' % prefix, 'src': post, 'activation': 'linear'}, (sp, nb_labels))
+
+
+def add_prior(input_model, prior_shape, name='prior_model', prefix=None, use_logp=True, final_pred_activation='softmax',
+              add_prior_layer_reg=0):
+    """
+    Append the post-prior layers to a built network (models.py:378-436): a second input `prior` [B, *prior_shape] is added
+    to (use_logp: log-prior + log-likelihood, then softmax) or multiplied with (prior x sigmoid(likelihood)) the model output.
+    """
+    if not isinstance(input_model, ConvNet):
+        raise TypeError('add_prior expects a network built by unet / conv_enc / conv_dec')
+    model_name = name
+    if prefix is None:
+        prefix = model_name
+    prior_shape = tuple(int(s) for s in prior_shape)
+    ndims = input_model.ndims
+    out_sp, out_c = input_model._builder_state['shapes'][input_model.output_name]
+    if tuple(out_sp[3 - ndims:]) != prior_shape[:-1] or out_c != prior_shape[-1]:
+        raise ValueError('prior shape %s does not match the model output %s' % (prior_shape, tuple(out_sp[3 - ndims:]) + (out_c,)))
+    bld = _Builder(ndims)
+    bld.ops = list(input_model.ops)
+    bld.modules = dict(input_model.layers_by_name.items())
+    bld.shapes = dict(input_model._builder_state['shapes'])
+    last = _append_prior(bld, input_model.output_name, model_name, prefix, prior_shape[:-1], prior_shape[-1], ndims,
+                         len(input_model.input_shapes), use_logp, final_pred_activation)
+    net = ConvNet(model_name, ndims, list(input_model.input_shapes) + [prior_shape], bld.ops, last, bld.modules)
+    net._builder_state = dict(shapes=bld.shapes)
+    return net
+
+
+def dilation_net(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='dilation_net', prefix=None, feat_mult=1,
+                 pool_size=2, use_logp=True, padding='same', dilation_rate_mult=1, activation='elu', use_residuals=False,
+                 final_pred_activation='softmax', nb_conv_per_level=1, add_prior_layer=False, add_prior_layer_reg=0,
+                 layer_nb_feats=None, batch_norm=None):
+    """models.py:45-85: as the reference, a unet that takes only `dilation_rate_mult` from these arguments (every other
+    option is passed to unet at its default)."""
+    return unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet', prefix=None, feat_mult=1, pool_size=2,
+                use_logp=True, padding='same', activation='elu', use_residuals=False, dilation_rate_mult=dilation_rate_mult,
+                final_pred_activation='softmax', nb_conv_per_level=1, add_prior_layer=False, add_prior_layer_reg=0,
+                layer_nb_feats=None, batch_norm=None)
+
+
 @_store_config
 def conv_enc(nb_features, input_shape, nb_levels, conv_size, name=None, prefix=None, feat_mult=1, pool_size=2,
              dilation_rate_mult=1, padding='same', activation='elu', layer_nb_feats=None, use_residuals=False,
@@ -1266,26 +1323,11 @@ def unet(nb_features, input_shape, nb_levels, conv_size, nb_labels, name='unet',
                     dilation_rate_mult, activation, use_residuals, 'linear' if add_prior_layer else final_pred_activation,
                     nb_conv_per_level, lnf, batch_norm, conv_dropout, last, enc_ncpl)
     _fix_residual_adds(bld)
-    if add_prior_layer:                                                          # models.add_prior, :378-436 (log-prior form)
+    if add_prior_layer:                                                          # models.add_prior, :378-436
         pname = model_name + '_prior'
-        prior_shape = tuple(first[:-1]) + (int(nb_labels),)
-        sp = (1,) * (3 - ndims) + tuple(first[:-1])
-        prior = bld.add({'kind': 'input', 'name': '%s-input' % pname, 'index': len(shapes)}, (sp, int(nb_labels)))
-        if use_logp:                                                             # :401-406
-            print("Breaking change: use_logp option now requires log input!", file=sys.stderr)
-            post = bld.add({'kind': 'add', 'name': '%s_posterior' % pname, 'a': prior, 'b': last}, (sp, int(nb_labels)))
-        else:                                                                    # :408-414: sigmoid likelihood x prior
-            like = bld.add({'kind': 'activation', 'name': '%s_likelihood_sigmoid' % pname, 'src': last,
-                            'activation': 'sigmoid'}, (sp, int(nb_labels)))
-            post = bld.add({'kind': 'multiply', 'name': '%s_posterior' % pname, 'a': prior, 'b': like}, (sp, int(nb_labels)))
-        if final_pred_activation == 'softmax':
-            print("using final_pred_activation %s for %s" % (final_pred_activation, pname))
-            last = bld.add({'kind': 'prediction', 'name': '%s_prediction' % pname, 'src': post, 'activation': 'softmax'},
-                           (sp, int(nb_labels)))
-        else:
-            last = bld.add({'kind': 'prediction', 'name': '%s_prediction' % pname, 'src': post, 'activation': 'linear'},
-                           (sp, int(nb_labels)))
-        shapes = shapes + [prior_shape]
+        last = _append_prior(bld, last, pname, pname, tuple(first[:-1]), int(nb_labels), ndims, len(shapes), use_logp,
+                             final_pred_activation)
+        shapes = shapes + [tuple(first[:-1]) + (int(nb_labels),)]
         model_name = pname
     net = ConvNet(model_name, ndims, shapes, bld.ops, last, bld.modules)
     net._builder_state = dict(shapes=bld.shapes)

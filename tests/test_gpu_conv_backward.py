@@ -284,6 +284,13 @@ def test_unet_add_prior_layer(dev):
         close(N(m.kernel.grad), params[k][0].grad.numpy(), k + ' kernel', 5e-4)
     with pytest.raises(AssertionError, match='cannot do softmax'):               # models.py:423
         ne.models.unet(8, (8, 8, 8, 1), 2, 3, 4, add_prior_layer=True, use_logp=False)
+    # the stand-alone builder gives the same network: models.add_prior(unet(..., final 'linear'), prior_shape)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        base = ne.models.unet(8, (8, 8, 8, 1), 2, 3, 4, final_pred_activation='linear').to(dev)
+        alone = ne.models.add_prior(base, (8, 8, 8, 4), name='unet_prior')
+    alone.set_weights(net.get_weights())
+    net.eval()
+    assert torch.equal(alone([G(x, dev), G(prior, dev)]), net([G(x, dev), G(prior, dev)]))
 
 
 def test_unet_add_prior_layer_probability_form(dev):

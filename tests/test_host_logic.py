@@ -476,3 +476,27 @@ def test_synthstrip_config_roundtrip_cpu(tmp_path):
     net.save(str(tmp_path / 'u.npz'))
     with pytest.raises(ValueError, match='not saved from a SynthStrip'):
         ne.models.SynthStrip.load(str(tmp_path / 'u.npz'))
+
+
+def test_add_prior_and_dilation_net_graphs_cpu():
+    """models.add_prior as a stand-alone builder (models.py:378-436) and the dilation_net wrapper (:45-85)"""
+    import contextlib, io
+    import neurite_amd as ne
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        ref = ne.models.unet(4, (8, 8, 8, 1), 2, 3, 3, add_prior_layer=True)
+        base = ne.models.unet(4, (8, 8, 8, 1), 2, 3, 3, final_pred_activation='linear')
+        post = ne.models.add_prior(base, (8, 8, 8, 3), name='unet_prior')
+        prob = ne.models.add_prior(base, (8, 8, 8, 3), name='p', use_logp=False, final_pred_activation='linear')
+        dil = ne.models.dilation_net(4, (8, 8, 8, 1), 2, 3, 3, dilation_rate_mult=2, feat_mult=7, nb_conv_per_level=3)
+        plain = ne.models.unet(4, (8, 8, 8, 1), 2, 3, 3, dilation_rate_mult=2)
+    assert post.layer_names == ref.layer_names and post.input_shapes == ref.input_shapes and post.name == 'unet_prior'
+    assert prob.layer_names[-4:] == ['p-input', 'p_likelihood_sigmoid', 'p_posterior', 'p_prediction']
+    assert [tuple(w.shape) for w in post.get_weights()] == [tuple(w.shape) for w in base.get_weights()]
+    assert dil.layer_names == plain.layer_names and dil.name == 'unet'             # every other argument is ignored, as upstream
+    assert [tuple(w.shape) for w in dil.get_weights()] == [tuple(w.shape) for w in plain.get_weights()]
+    with pytest.raises(ValueError, match='does not match'):
+        ne.models.add_prior(base, (8, 8, 8, 4))
+    with pytest.raises(AssertionError, match='cannot do softmax'):
+        ne.models.add_prior(base, (8, 8, 8, 3), use_logp=False)
+    with pytest.raises(TypeError):
+        ne.models.add_prior(object(), (8, 8, 8, 3))
