@@ -900,8 +900,9 @@ def _axis_gather(x, index, ax):
 def subsample_axis_indices(width, thick):
     """index lists of utils.subsample_axis (utils.py:815-824): slices kept, and the map back to `width` samples"""
     num_slice = int(np.float32(width) / np.float32(thick) + np.float32(0.5))
-    down = (np.linspace(0, width - 1, num_slice).astype(np.float32) + np.float32(0.5)).astype(np.int32)
-    up = (np.linspace(0, num_slice - 1, width).astype(np.float32) + np.float32(0.5)).astype(np.int32)
+    # tf.linspace re-casts integer end points to the dtype of its step, float64: the indices are truncations of doubles
+    down = (np.linspace(0, width - 1, num_slice, dtype=np.float64) + 0.5).astype(np.int32)
+    up = (np.linspace(0, num_slice - 1, width, dtype=np.float64) + 0.5).astype(np.int32)
     return down, up
 
 
