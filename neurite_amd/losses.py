@@ -8,7 +8,7 @@ import numpy as np
 from . import metrics
 
 __all__ = ['Dice', 'SoftDice', 'HardDice', 'CategoricalCrossentropy', 'WeightedCategoricalCrossentropy',
-           'multiple_losses_decorator']
+           'MeanSquaredErrorProb', 'multiple_losses_decorator']
 
 
 class _DiceLossMixin:
@@ -47,6 +47,16 @@ class CategoricalCrossentropy(metrics.CategoricalCrossentropy):
 
 
 WeightedCategoricalCrossentropy = CategoricalCrossentropy
+
+
+class MeanSquaredErrorProb(metrics.MeanSquaredErrorProb):
+    """neurite/tf/losses.py:208-220."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+
+    def loss(self, *args, **kwargs):
+        return self.mse(*args, **kwargs)
 
 
 def multiple_losses_decorator(losses, weights=None):

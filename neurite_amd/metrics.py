@@ -20,7 +20,7 @@ from . import utils
 from .errors import InvalidArgumentError
 
 __all__ = ['Dice', 'SoftDice', 'HardDice', 'CategoricalCrossentropy', 'WeightedCategoricalCrossentropy',
-           'dice_partial_sums', 'MutualInformation']
+           'dice_partial_sums', 'MutualInformation', 'MeanSquaredErrorProb']
 
 _INT_DTYPES = (torch.int8, torch.uint8, torch.int16, torch.int32, torch.int64, torch.bool)
 
@@ -359,6 +359,94 @@ class CategoricalCrossentropy:
 
 
 WeightedCategoricalCrossentropy = CategoricalCrossentropy
+
+
+# --------------------------------------------------------------------------------------
+# MeanSquaredErrorProb (neurite/tf/metrics.py:653-692)
+# --------------------------------------------------------------------------------------
+
+class _MseProbFn(torch.autograd.Function):
+    """sum over everything of w_l (t - p)^2 from the Dice kernel's per-(batch, label) sums (sum t p, sum t^2, sum p^2 -- the
+    second reduction stage is in float64); backward dp = 2 w_l (p - t) g on the per-channel a x + b y kernel."""
+
+    @staticmethod
+    def forward(ctx, t, p, w):
+        sums, _, _ = dice_partial_sums(t, p)
+        per_label = (sums[:, 1].double() - 2.0 * sums[:, 0].double() + sums[:, 2].double()).sum(0)        # [L]
+        ctx.save_for_backward(t, p, w)
+        return (per_label * w.double()).sum().to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        t, p, w = ctx.saved_tensors
+        lib = _lib.lib()
+        dev = p.device
+        L = p.shape[-1]
+        ca = (2.0 * w * g).to(torch.float32).contiguous()
+        cb = (-ca).contiguous()
+        zero = torch.zeros(L, dtype=torch.float32, device=dev)
+        dp = dt = None
+        pc, tc = p.contiguous(), t.contiguous()
+        if ctx.needs_input_grad[1]:
+            dp = torch.empty_like(pc)
+            with torch.cuda.device(dev):
+                rc = lib.nrt_channel_axpby_f32(_lib.ptr(pc), _lib.ptr(tc), _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(zero), _lib.ptr(dp),
+                                               pc.numel(), L, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_channel_axpby_f32')
+        if ctx.needs_input_grad[0]:
+            dt = torch.empty_like(tc)
+            with torch.cuda.device(dev):
+                rc = lib.nrt_channel_axpby_f32(_lib.ptr(tc), _lib.ptr(pc), _lib.ptr(ca), _lib.ptr(cb), _lib.ptr(zero), _lib.ptr(dt),
+                                               tc.numel(), L, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_channel_axpby_f32')
+        return dt, dp, None
+
+
+class MeanSquaredErrorProb:
+    """
+    tf.keras.losses.MeanSquaredError over label (log-)probability maps with label weights along the last axis
+    (neurite/tf/metrics.py:653-692): mean over all elements of w_l (y_true - y_pred)^2 (without label weights Keras averages
+    over the label axis first -- the same number).  Keras keyword arguments honoured: reduction ('auto' /
+    'sum_over_batch_size' / 'sum'), name.  sample_weight: None or a scalar.  float32 [B, ..., L]; differentiable.
+    """
+
+    def __init__(self, label_weights=None, **kwargs):
+        self.label_weights = None
+        if label_weights is not None:
+            self.label_weights = torch.as_tensor(np.asarray(label_weights, dtype=np.float32)
+                                                 if not isinstance(label_weights, torch.Tensor) else label_weights)
+        self.reduction = kwargs.pop('reduction', 'auto')
+        self.name = kwargs.pop('name', 'mean_squared_error')
+        if kwargs:
+            raise TypeError('unexpected keyword arguments: %s' % sorted(kwargs))
+        if self.reduction not in ('auto', 'sum_over_batch_size', 'sum', 'none'):
+            raise ValueError('Invalid Reduction Key: %s' % self.reduction)
+        if self.reduction == 'none':
+            raise NotImplementedError("MeanSquaredErrorProb: reduction='none' is not implemented")
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        return self.mse(y_true, y_pred, sample_weight=sample_weight)
+
+    def mse(self, y_true, y_pred, sample_weight=None):
+        yf = y_pred.shape[-1]
+        if self.label_weights is not None:
+            lf = self.label_weights.shape[0]
+            if yf != lf:                                                                  # metrics.py:679-680
+                raise ValueError(f'Label weights must be of len {yf}, but got {lf}.')
+        dev = _lib.require_device(y_true, y_pred)
+        if y_true.shape != y_pred.shape:
+            raise ValueError('y_true and y_pred must have the same shape')
+        if sample_weight is not None and np.ndim(sample_weight) != 0:
+            raise NotImplementedError('MeanSquaredErrorProb: scalar sample_weight only')
+        w = torch.ones(yf, dtype=torch.float32, device=dev) if self.label_weights is None \
+            else self.label_weights.to(dev, torch.float32).contiguous()
+        total = _MseProbFn.apply(_as_f32(y_true, 'y_true'), _as_f32(y_pred, 'y_pred'), w)
+        if sample_weight is not None:
+            total = total * float(sample_weight)
+        if self.reduction == 'sum':
+            # Keras sums the per-sample losses: with label weights those are per element, without them per voxel (mean over labels)
+            return total if self.label_weights is not None else total / yf
+        return total / y_pred.numel()
 
 
 # --------------------------------------------------------------------------------------

@@ -280,3 +280,40 @@ def test_fused_x_march_schedule_ragged(dev):
         np.testing.assert_allclose(N(d), d_ref, rtol=RTOL, err_msg=str(tune))
         d2 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=0.0, _tune=tune)
         assert bits_equal(N(d2), N(d)), tune
+
+
+def test_mean_squared_error_prob(dev):
+    """metrics.MeanSquaredErrorProb (neurite/tf/metrics.py:653-692): Keras MSE with label weights as per-element sample weights;
+    value and gradients against float64 NumPy / torch"""
+    import torch
+    rng = np.random.default_rng(71)
+    for shape in ((2, 9, 8, 7, 8), (3, 33, 5), (1, 6, 5, 4, 32)):
+        L = shape[-1]
+        t = rng.random(shape).astype(np.float32)
+        p = (t + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+        w = rng.random(L).astype(np.float32) + 0.5
+        tg = torch.from_numpy(t).to(dev)
+        pg = torch.from_numpy(p).to(dev).requires_grad_()
+        d2 = (t.astype(np.float64) - p.astype(np.float64)) ** 2
+        # no label weights: mean over the label axis, then over the rest (:692 -> keras MSE, SUM_OVER_BATCH_SIZE)
+        got = ne.metrics.MeanSquaredErrorProb()(tg, pg)
+        np.testing.assert_allclose(float(got.detach()), d2.mean(-1).mean(), rtol=2e-5)
+        got.backward()
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), 2 * (p.astype(np.float64) - t) / d2.size, rtol=1e-4, atol=1e-9)
+        # label weights become sample weights of the per-element losses (:676-690)
+        pg.grad = None
+        lw = ne.losses.MeanSquaredErrorProb(label_weights=w)
+        got = lw.loss(tg, pg)
+        np.testing.assert_allclose(float(got.detach()), (d2 * w).mean(), rtol=2e-5)
+        got.backward()
+        np.testing.assert_allclose(pg.grad.cpu().numpy(), 2 * w * (p.astype(np.float64) - t) / d2.size, rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(float(ne.metrics.MeanSquaredErrorProb(label_weights=w, reduction='sum')(tg, pg.detach())),
+                                   (d2 * w).sum(), rtol=2e-5)
+        np.testing.assert_allclose(float(ne.metrics.MeanSquaredErrorProb(reduction='sum')(tg, pg.detach(), sample_weight=0.5)),
+                                   0.5 * d2.mean(-1).sum(), rtol=2e-5)
+    with pytest.raises(ValueError, match='Label weights must be of len'):
+        ne.metrics.MeanSquaredErrorProb(label_weights=[1.0, 2.0])(tg, pg)
+    with pytest.raises(NotImplementedError):
+        ne.metrics.MeanSquaredErrorProb()(tg, pg, sample_weight=[1.0, 2.0])
+    with pytest.raises(ValueError, match='Invalid Reduction'):
+        ne.metrics.MeanSquaredErrorProb(reduction='mean')
