@@ -500,3 +500,22 @@ def test_add_prior_and_dilation_net_graphs_cpu():
         ne.models.add_prior(base, (8, 8, 8, 3), use_logp=False)
     with pytest.raises(TypeError):
         ne.models.add_prior(object(), (8, 8, 8, 3))
+
+
+def test_header_is_c99_and_a_c_program_links(tmp_path):
+    """include/neurite_amd.h is a plain C header: examples/c_abi_example.c builds with gcc -std=c99 -pedantic, links against the
+    shared library and (query mode, no GPU needed) runs"""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None or not os.path.isdir('/opt/rocm/lib'):
+        pytest.skip('gcc / ROCm runtime not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(ne.library_path())
+    exe = str(tmp_path / 'c_abi_example')
+    cmd = ['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(root, 'include'),
+           os.path.join(root, 'examples', 'c_abi_example.c'), '-L', libdir, '-lneurite_amd', '-L', '/opt/rocm/lib', '-lamdhip64',
+           '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'C ABI 1 for gfx950' in out.stdout and '"ok"' in out.stdout
