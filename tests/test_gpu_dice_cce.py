@@ -5,6 +5,7 @@ Tolerances: hard / one-hot Dice BIT-EXACT (integer counting); soft Dice and CCE 
 (float32 reduction order is unspecified in TensorFlow; the oracle accumulates in float64).
 """
 
+import os
 import warnings
 
 import numpy as np
@@ -317,3 +318,24 @@ def test_mean_squared_error_prob(dev):
         ne.metrics.MeanSquaredErrorProb()(tg, pg, sample_weight=[1.0, 2.0])
     with pytest.raises(ValueError, match='Invalid Reduction'):
         ne.metrics.MeanSquaredErrorProb(reduction='mean')
+
+
+@pytest.mark.skipif(os.environ.get('NRT_TEST_EXPERIMENTAL') != '1',
+                    reason='warp_dice_dedup (tune bit 30) is experimental and not yet validated on hardware; '
+                           'set NRT_TEST_EXPERIMENTAL=1 to run')
+def test_fused_dedup_schedule_experimental(dev):
+    """The de-duplicating x-march schedule (tune bit 30) must give the Dice of the default schedule to the last bit of
+    every blended value (same arithmetic; only the summation order of the block partials is shared too), on ragged shapes,
+    several x segments, a smooth and an incoherent field (hash overflow -> direct reads), with and without fill."""
+    rng = np.random.default_rng(91)
+    L = 32
+    for B, S, sigma in ((6, (36, 50, 61), 2.0), (2, (40, 64, 128), 30.0), (1, (19, 128, 131), 0.3)):
+        mov = rng.random((B,) + S + (L,)).astype(F)
+        fix = rng.random((B,) + S + (L,)).astype(F)
+        trf = rng.normal(0, sigma, (B,) + S + (3,)).astype(F)
+        for fill in (None, 0.0):
+            for seg in (0, 3 << 16):
+                base = 0 if seg == 0 else (3 | (2 << 4) | (3 << 8) | (1 << 14) | seg)
+                d0 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, _tune=base)
+                d1 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, _tune=base | (1 << 30))
+                np.testing.assert_allclose(N(d1), N(d0), rtol=2e-6, err_msg=str((B, S, sigma, fill, seg)))
