@@ -5,7 +5,8 @@ bench.py -- headline benchmark of the neurite hot path on MI355X.
 Metric (BASELINE.json): Mvoxels/sec of interpn+Dice on 160^3 x 32-label volumes.
 A step = one pass of the hot path over one batch of synthetic volumes already resident in HBM:
     dice = SpatialTransformer('linear')([moving, trf])  ->  Dice(fixed, warped)   [B, L]
-    N > 1: one RCCL all-reduce of [sum of dice, count] (mean Dice over the global batch)
+    N > 1: one RCCL all-reduce of [sum of dice, count] (mean Dice over the global batch); the collective of step k runs
+           on RCCL's stream while step k + 1's kernels run, every mean is collected before the closing synchronize
 computed by default with the fused kernel (neurite_amd.fused.warp_dice: the warped volume is consumed in
 registers, never written -- SURVEY.md 8d anticipates exactly this), or with --unfused by the drop-in
 two-kernel pipeline (layers.SpatialTransformer -> metrics.Dice).  The JSON line always carries the other
@@ -23,6 +24,9 @@ launch / its average duration measured with HIP events inside the timed region. 
 voxel (DESIGN.md 4): fused kernel 4C (moving row) + 12 (shift) + 4L (fixed row) = 268 B at C=L=32;
 unfused interpn 4C + 12 + 4C = 268 B, Dice 2*4L = 256 B.  `cpu_baseline` is the C oracle (a port of the
 reference algorithm, oracle/oracle.c) on the host cores over a bounded sample -- reported, not a target.
+At N = 1 the line also carries `unet_fwd` (BASELINE config 3 forward, per-layer fraction of the fp32 MFMA peak), `lc3d_wcce`
+(config 5) and `training` (registration step = fused warp+Dice forward + backward on the bench volumes; unet training step);
+at N > 1 `unet_fwd` is the slowest rank's forward with one volume per GPU.
 """
 
 import argparse
