@@ -253,12 +253,16 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
 // distinct on the benchmark's field.
 //   phase 1  lane c of every 8-lane group files the row index of corner c of each of its DD_W voxels in an open-addressing
 //            hash (ds_cmpswap); the slot number is the row's place in the LDS row buffer
-//   barrier
+//   barrier A
 //   phase 2  group g loads the rows of slots g, g + 32, ... (one 128-byte row per 8 lanes and instruction; empty slots use an
 //            out-of-range buffer offset: no memory access), the loads stay in flight during
-//   phase 3  the blend of the PREVIOUS window from the other buffer: corner rows come from LDS (slot broadcast by shuffle),
-//            the arithmetic is the one of warp_dice_tile; then the rows of phase 2 are written to LDS
-//   barrier
+//   phase 3  the blend of the PREVIOUS window from the row buffer: corner rows come from LDS (slot broadcast by shuffle),
+//            the arithmetic is the one of warp_dice_tile
+//   barrier B  (everyone is done with the buffer and the table)
+//   phase 4  the rows of phase 2 go to the row buffer, the table is emptied
+//   barrier C
+// One row buffer (64 KB) + one table (2 KB): two blocks per CU, i.e. two waves per SIMD to hide the latencies of a window's
+// dependency chain (hash -> loads -> LDS), which one block per CU leaves exposed.
 // Rows whose probe sequence fails (table full: incoherent fields) are read from memory directly.
 // ---------------------------------------------------------------------------------------------
 constexpr int DD_W = 4;
@@ -267,7 +271,7 @@ constexpr int DD_LOGH = 9;
 constexpr unsigned DD_EMPTY = 0xffffffffu;
 constexpr unsigned DD_DIRECT = 0xffffu;
 constexpr int DD_PROBES = 32;
-constexpr size_t DD_LDS_BYTES = (size_t)2 * DD_H * 128 + (size_t)2 * DD_H * sizeof(unsigned);
+constexpr size_t DD_LDS_BYTES = (size_t)DD_H * 128 + (size_t)DD_H * sizeof(unsigned);
 
 struct DdState {                 // per lane: its group's DD_W voxels of one window
     unsigned slot[DD_W];         // LDS slot of corner `lane % 8` (DD_DIRECT: read from memory)
@@ -278,12 +282,12 @@ struct DdState {                 // per lane: its group's DD_W voxels of one win
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void warp_dice_dedup(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
+__global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
                                                           float *__restrict__ fpart, float *__restrict__ mpart) {
     constexpr int G = 8, L = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char dd_smem[];
-    nrt_f4 *rowbuf = (nrt_f4 *)dd_smem;                                   // [2][DD_H][G]
-    unsigned *table = (unsigned *)(dd_smem + (size_t)2 * DD_H * 128);     // [2][DD_H]
+    nrt_f4 *rowbuf = (nrt_f4 *)dd_smem;                                   // [DD_H][G]
+    unsigned *table = (unsigned *)(dd_smem + (size_t)DD_H * 128);         // [DD_H]
     __shared__ float red[4][3 * L + 4];
     int b, x0, y0, z0, xlen;
     unsigned prow;
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(256, 1) void warp_dice_dedup(InterpArgs a, TileGeom
     };
     // phase 1
     auto index_window = [&](int win, const float (&pn)[DD_W][3], unsigned *tbl, DdState &st) {
+        unsigned hs[DD_W], old[DD_W];
 #pragma unroll
         for (int w = 0; w < DD_W; ++w) {
             const int x = x0 + win * DD_W + w;
@@ -346,16 +351,22 @@ __global__ __launch_bounds__(256, 1) void warp_dice_dedup(InterpArgs a, TileGeom
             corner_1d(p[2], a.S[2], i0z, i1z, st.w0z[w], w1z);
             st.oob[w] = a.has_fill ? out_of_bounds<3>(a, p) : false;
             const unsigned ix = (lg & 4) ? i1x : i0x, iy = (lg & 2) ? i1y : i0y, iz = (lg & 1) ? i1z : i0z;
-            const unsigned row = nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz);
-            st.rowc[w] = row;
-            unsigned res = 0;                                              // invalid voxels: any slot, never accumulated
-            if (st.valid[w]) {
+            st.rowc[w] = nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz);
+            hs[w] = (st.rowc[w] * 2654435761u) >> (32 - DD_LOGH);
+        }
+        // first probes of the DD_W voxels back to back (independent LDS atomics), then the rare longer probe sequences
+#pragma unroll
+        for (int w = 0; w < DD_W; ++w) old[w] = st.valid[w] ? atomicCAS(&tbl[hs[w]], DD_EMPTY, st.rowc[w]) : st.rowc[w];
+#pragma unroll
+        for (int w = 0; w < DD_W; ++w) {
+            unsigned res = hs[w];                                          // invalid voxels: any slot, never accumulated
+            if (st.valid[w] && old[w] != DD_EMPTY && old[w] != st.rowc[w]) {
                 res = DD_DIRECT;
-                unsigned s = (row * 2654435761u) >> (32 - DD_LOGH);
-                for (int t = 0; t < DD_PROBES; ++t) {
-                    const unsigned old = atomicCAS(&tbl[s], DD_EMPTY, row);
-                    if (old == DD_EMPTY || old == row) { res = s; break; }
-                    s = (s + 1) & (DD_H - 1);
+                unsigned sl = (hs[w] + 1) & (DD_H - 1);
+                for (int t = 1; t < DD_PROBES; ++t) {
+                    const unsigned o = atomicCAS(&tbl[sl], DD_EMPTY, st.rowc[w]);
+                    if (o == DD_EMPTY || o == st.rowc[w]) { res = sl; break; }
+                    sl = (sl + 1) & (DD_H - 1);
                 }
             }
             st.slot[w] = res;
@@ -421,8 +432,8 @@ __global__ __launch_bounds__(256, 1) void warp_dice_dedup(InterpArgs a, TileGeom
         }
     };
 
-    // ---- prologue: both tables empty, window 0 indexed and staged ----------------------------------------------
-    for (int i = threadIdx.x; i < 2 * DD_H; i += 256) table[i] = DD_EMPTY;
+    // ---- prologue: table empty, window 0 indexed and staged ---------------------------------------------------
+    for (int i = threadIdx.x; i < DD_H; i += 256) table[i] = DD_EMPTY;
     __syncthreads();
     float pn[DD_W][3];
     DdState sa, sb;
@@ -433,25 +444,27 @@ __global__ __launch_bounds__(256, 1) void warp_dice_dedup(InterpArgs a, TileGeom
     __syncthreads();
     issue_loads(table, R);
     load_fixed(0, Ta);
+    __syncthreads();                                                       // table read by everyone
+    for (int i = threadIdx.x; i < DD_H; i += 256) table[i] = DD_EMPTY;
     store_rows(rowbuf, R);
     __syncthreads();
     for (int i = 0; i < nwin; ++i) {
-        const int P = i & 1, Q = P ^ 1;
         const bool more = i + 1 < nwin;
         if (more) {
-            index_window(i + 1, pn, table + Q * DD_H, sb);
+            index_window(i + 1, pn, table, sb);
             load_loc(min(i + 2, nwin - 1), pn);
         }
-        __syncthreads();                                                   // inserts of window i + 1 are complete
+        __syncthreads();                                                   // A: inserts of window i + 1 are complete
         if (more) {
-            issue_loads(table + Q * DD_H, R);
+            issue_loads(table, R);
             load_fixed(i + 1, Tb);
         }
         __builtin_amdgcn_sched_barrier(0);
-        blend_window(rowbuf + (size_t)P * DD_H * G, sa, Ta);
-        for (int k = threadIdx.x; k < DD_H; k += 256) table[P * DD_H + k] = DD_EMPTY;     // ready for window i + 2
-        if (more) store_rows(rowbuf + (size_t)Q * DD_H * G, R);
-        __syncthreads();                                                   // buffer Q staged, buffer / table P free
+        blend_window(rowbuf, sa, Ta);
+        __syncthreads();                                                   // B: buffer and table no longer needed
+        for (int k = threadIdx.x; k < DD_H; k += 256) table[k] = DD_EMPTY;
+        if (more) store_rows(rowbuf, R);
+        __syncthreads();                                                   // C: window i + 1 staged, table empty
         sa = sb;
 #pragma unroll
         for (int w = 0; w < DD_W; ++w) Ta[w] = Tb[w];
