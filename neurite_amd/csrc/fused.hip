@@ -17,6 +17,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dice_reduce.h"
 #include "interpn_core.h"
 
@@ -263,13 +265,14 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
 //   barrier C
 // One row buffer (64 KB) + one table (2 KB): two blocks per CU, i.e. two waves per SIMD to hide the latencies of a window's
 // dependency chain (hash -> loads -> LDS), which one block per CU leaves exposed.
-// Rows whose probe sequence fails (table full: incoherent fields) are read from memory directly.
+// A window whose hash overflows (incoherent fields) is blended from memory directly by the whole block (block-uniform
+// branch): a conditional global load inside the LDS blend would make the compiler wait for all loads in flight
+// (vmcnt retires in order) and undo the overlap of phases 2 and 3.
 // ---------------------------------------------------------------------------------------------
 constexpr int DD_W = 4;
 constexpr int DD_H = 512;
 constexpr int DD_LOGH = 9;
 constexpr unsigned DD_EMPTY = 0xffffffffu;
-constexpr unsigned DD_DIRECT = 0xffffu;
 constexpr int DD_PROBES = 32;
 constexpr size_t DD_LDS_BYTES = (size_t)DD_H * 128 + (size_t)DD_H * sizeof(unsigned);
 
@@ -277,7 +280,6 @@ struct DdState {                 // per lane: its group's DD_W voxels of one win
     unsigned slot[DD_W];         // LDS slot of corner `lane % 8` (DD_DIRECT: read from memory)
     unsigned rowc[DD_W];         // its row index
     float w0x[DD_W], w0y[DD_W], w0z[DD_W];
-    unsigned q[DD_W];
     bool valid[DD_W], oob[DD_W];
 };
 
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom
     nrt_f4 *rowbuf = (nrt_f4 *)dd_smem;                                   // [DD_H][G]
     unsigned *table = (unsigned *)(dd_smem + (size_t)DD_H * 128);         // [DD_H]
     __shared__ float red[4][3 * L + 4];
+    __shared__ int dd_over;                                               // the window being indexed did not fit the table
     int b, x0, y0, z0, xlen;
     unsigned prow;
     if (!xmarch_block(tg, a.O[0], b, prow, x0, y0, z0, xlen)) return;
@@ -336,7 +339,6 @@ __global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom
             const int x = x0 + win * DD_W + w;
             st.valid[w] = yz_ok && x < xend;
             const int qd[3] = {min(x, a.O[0] - 1), yc, zc};
-            st.q[w] = voxel_q(x);
             float p[NRT_MAXD];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -361,13 +363,14 @@ __global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom
         for (int w = 0; w < DD_W; ++w) {
             unsigned res = hs[w];                                          // invalid voxels: any slot, never accumulated
             if (st.valid[w] && old[w] != DD_EMPTY && old[w] != st.rowc[w]) {
-                res = DD_DIRECT;
+                bool found = false;
                 unsigned sl = (hs[w] + 1) & (DD_H - 1);
                 for (int t = 1; t < DD_PROBES; ++t) {
                     const unsigned o = atomicCAS(&tbl[sl], DD_EMPTY, st.rowc[w]);
-                    if (o == DD_EMPTY || o == st.rowc[w]) { res = sl; break; }
+                    if (o == DD_EMPTY || o == st.rowc[w]) { res = sl; found = true; break; }
                     sl = (sl + 1) & (DD_H - 1);
                 }
+                if (!found) dd_over = 1;                                   // the block blends this window from memory
             }
             st.slot[w] = res;
         }
@@ -389,9 +392,23 @@ __global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom
         for (int k = 0; k < DD_H / 32; ++k) buf[(g + 32 * k) * G + lg] = R[k];
     };
     // phase 3
-    auto blend_window = [&](const nrt_f4 *buf, const DdState &st, const nrt_f4 (&T)[DD_W]) {
+    auto blend_window = [&](const nrt_f4 *buf, const DdState &st, const nrt_f4 (&T)[DD_W], auto from_lds) {
+        constexpr bool LDS = decltype(from_lds)::value;
 #pragma unroll
         for (int w = 0; w < DD_W; ++w) {
+            auto fetch_half = [&](int half, nrt_f4 (&rows)[4]) {            // four corner rows at a time (register budget)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int corner = 4 * half + k;
+                    if (LDS) {
+                        const unsigned sc = (unsigned)__shfl((int)st.slot[w], gbase + corner, 64);
+                        rows[k] = buf[sc * G + lg];
+                    } else {
+                        const unsigned rc = (unsigned)__shfl((int)st.rowc[w], gbase + corner, 64);
+                        rows[k] = *(const nrt_f4 *)(volb + (size_t)(rc * 128u + (unsigned)lg * 16u));
+                    }
+                }
+            };
             const float w1x = nrt_sub(1.0f, st.w0x[w]), w1y = nrt_sub(1.0f, st.w0y[w]), w1z = nrt_sub(1.0f, st.w0z[w]);
             const nrt_f2 wy2 = {st.w0y[w], w1y}, wz2 = {st.w0z[w], w1z};
             const nrt_f2 wxy0 = (nrt_f2){st.w0x[w], st.w0x[w]} * wy2, wxy1 = (nrt_f2){w1x, w1x} * wy2;
@@ -402,16 +419,17 @@ __global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom
             wt2[3] = (nrt_f2){wxy1[1], wxy1[1]} * wz2;
             nrt_f2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const unsigned sc = (unsigned)__shfl((int)st.slot[w], gbase + corner, 64);
-                const unsigned rc = (unsigned)__shfl((int)st.rowc[w], gbase + corner, 64);
-                nrt_f4 r;
-                if (sc != DD_DIRECT) r = buf[sc * G + lg];
-                else r = *(const nrt_f4 *)(volb + (size_t)(rc * 128u + (unsigned)lg * 16u));
-                const float wt = wt2[corner >> 1][corner & 1];
-                const nrt_f2 w2 = {wt, wt};
-                al = al + w2 * (nrt_f2){r[0], r[1]};
-                ah = ah + w2 * (nrt_f2){r[2], r[3]};
+            for (int half = 0; half < 2; ++half) {
+                nrt_f4 rows[4];
+                fetch_half(half, rows);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int corner = 4 * half + k;
+                    const float wt = wt2[corner >> 1][corner & 1];
+                    const nrt_f2 w2 = {wt, wt};
+                    al = al + w2 * (nrt_f2){rows[k][0], rows[k][1]};
+                    ah = ah + w2 * (nrt_f2){rows[k][2], rows[k][3]};
+                }
             }
             nrt_f4 acc = {al[0], al[1], ah[0], ah[1]};
             if (a.has_fill) {
@@ -434,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom
 
     // ---- prologue: table empty, window 0 indexed and staged ---------------------------------------------------
     for (int i = threadIdx.x; i < DD_H; i += 256) table[i] = DD_EMPTY;
+    if (threadIdx.x == 0) dd_over = 0;
     __syncthreads();
     float pn[DD_W][3];
     DdState sa, sb;
@@ -442,11 +461,13 @@ __global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom
     index_window(0, pn, table, sa);
     load_loc(min(1, nwin - 1), pn);
     __syncthreads();
-    issue_loads(table, R);
+    bool direct_a = dd_over != 0, direct_b = false;                        // block-uniform
+    if (!direct_a) issue_loads(table, R);
     load_fixed(0, Ta);
-    __syncthreads();                                                       // table read by everyone
+    __syncthreads();                                                       // table and flag read by everyone
     for (int i = threadIdx.x; i < DD_H; i += 256) table[i] = DD_EMPTY;
-    store_rows(rowbuf, R);
+    if (threadIdx.x == 0) dd_over = 0;
+    if (!direct_a) store_rows(rowbuf, R);
     __syncthreads();
     for (int i = 0; i < nwin; ++i) {
         const bool more = i + 1 < nwin;
@@ -455,17 +476,21 @@ __global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom
             load_loc(min(i + 2, nwin - 1), pn);
         }
         __syncthreads();                                                   // A: inserts of window i + 1 are complete
+        direct_b = more && dd_over != 0;
         if (more) {
-            issue_loads(table, R);
+            if (!direct_b) issue_loads(table, R);
             load_fixed(i + 1, Tb);
         }
         __builtin_amdgcn_sched_barrier(0);
-        blend_window(rowbuf, sa, Ta);
-        __syncthreads();                                                   // B: buffer and table no longer needed
+        if (direct_a) blend_window(rowbuf, sa, Ta, std::false_type{});
+        else blend_window(rowbuf, sa, Ta, std::true_type{});
+        __syncthreads();                                                   // B: buffer, table and flag no longer needed
         for (int k = threadIdx.x; k < DD_H; k += 256) table[k] = DD_EMPTY;
-        if (more) store_rows(rowbuf, R);
+        if (threadIdx.x == 0) dd_over = 0;
+        if (more && !direct_b) store_rows(rowbuf, R);
         __syncthreads();                                                   // C: window i + 1 staged, table empty
         sa = sb;
+        direct_a = direct_b;
 #pragma unroll
         for (int w = 0; w < DD_W; ++w) Ta[w] = Tb[w];
     }
