@@ -176,27 +176,32 @@ def draw_perlin_full(shape, noise_min=0.01, noise_max=1, fwhm_min=4, fwhm_max=32
     return out
 
 
-def draw_crop_mask(x, crop_min=0, crop_max=0.5, axis=None, prob=1, bilateral=False, seed=None):
+def draw_crop_mask(x, crop_min=0, crop_max=0.5, axis=None, prob=1, bilateral=False, seed=None, _draws=None):
     """
     Mask that multiplicatively crops the field of view of an N-D tensor along one (randomly drawn) axis
     (augment.py:218-290): float32 tensor on x's device with singleton dimensions except along that axis.
+    `_draws` (tests): the uniform [0, 1) numbers to use instead of the generator's, in the reference's order of draws.
     """
     shape = tuple(x.shape)
     axis = list(normalize_axes(axis, shape, none_means_all=True))
     assert 0 <= crop_min <= crop_max <= 1, f'invalid proportions {crop_min}, {crop_max}'
     gen = utils._host_generator(seed)
+    draws = None if _draws is None else list(_draws)
+
+    def uniform():
+        return np.float32(draws.pop(0)) if draws is not None else np.float32(float(torch.rand((), generator=gen)))
     prop_cut = np.float32(crop_max)
-    if crop_min < crop_max:
-        prop_cut = np.float32(crop_min + (crop_max - crop_min) * float(torch.rand((), generator=gen)))
+    if crop_min < crop_max:                                   # tf.random.uniform: u * (maxval - minval) + minval in float32
+        prop_cut = uniform() * np.float32(np.float32(crop_max) - np.float32(crop_min)) + np.float32(crop_min)
     assert 0 <= prob <= 1, f'{prob} not a probability'
     if prob < 1:
-        prop_cut = prop_cut * np.float32(float(torch.rand((), generator=gen)) < prob)
-    rand_prop = np.float32(float(torch.rand((), generator=gen)))
+        prop_cut = prop_cut * np.float32(uniform() < np.float32(prob))
+    rand_prop = uniform()
     if not bilateral:
-        rand_prop = np.float32(rand_prop < 0.5)
+        rand_prop = np.float32(rand_prop < np.float32(0.5))
     prop_low = prop_cut * rand_prop
     prop_cen = np.float32(1) - prop_cut
-    ax = axis[int(torch.randint(len(axis), (), generator=gen))]
+    ax = axis[int(np.floor(np.float64(uniform()) * len(axis)))]
     width = shape[ax]
     prop = (np.arange(width, dtype=np.float32) * (np.float32(1) / np.float32(width))).astype(np.float32)   # tf.range(1, delta=1/width)
     mask = np.logical_and(prop >= prop_low, prop < prop_low + prop_cen).astype(np.float32)

@@ -911,7 +911,24 @@ def subsample_axis_indices(width, thick):
     return down, up
 
 
-def subsample_axis(x, stride_min=1, stride_max=8, axes=None, prob=1, upsample=True, seed=None):
+def _subsample_draws(num_axes, stride_min, stride_max, prob, seed, draws=None):
+    """(index into the axis list, slice thickness) of utils.subsample_axis (utils.py:801-813), in the reference's order of
+    draws; `draws` (tests): uniform [0, 1) numbers to use instead of the generator's"""
+    gen = _host_generator(seed)
+    draws = None if draws is None else list(draws)
+
+    def uniform():
+        return np.float32(draws.pop(0)) if draws is not None else np.float32(float(torch.rand((), generator=gen)))
+    ax = int(np.floor(np.float64(uniform()) * num_axes))
+    thick = uniform() * np.float32(np.float32(stride_max) - np.float32(stride_min)) + np.float32(stride_min)
+    assert 0 <= prob <= 1, f'{prob} not a probability'
+    if prob < 1:
+        bit = np.float32(uniform() < np.float32(prob))
+        thick = thick * bit + (np.float32(1) - bit)
+    return ax, thick
+
+
+def subsample_axis(x, stride_min=1, stride_max=8, axes=None, prob=1, upsample=True, seed=None, _draws=None):
     """
     Symmetrically subsample a tensor by a random factor (stride) along one randomly drawn axis with nearest-neighbour
     interpolation and optionally up-sample it again (utils.py:754-826).  float32 device tensors.
@@ -926,13 +943,9 @@ def subsample_axis(x, stride_min=1, stride_max=8, axes=None, prob=1, upsample=Tr
     axes = list(axes)
     assert all(i in range(num_dim) for i in axes), 'invalid axis passed'
     assert 0 < stride_min and stride_min <= stride_max, 'invalid strides'
-    gen = _host_generator(seed)
-    ax = axes[int(torch.randint(len(axes), (), generator=gen))]
+    ax, thick = _subsample_draws(len(axes), stride_min, stride_max, prob, seed, _draws)
+    ax = axes[ax]
     width = x.shape[ax]
-    thick = float(stride_min + (stride_max - stride_min) * torch.rand((), generator=gen))
-    assert 0 <= prob <= 1, f'{prob} not a probability'
-    if prob < 1 and not bool(torch.rand((), generator=gen) < prob):
-        thick = 1.0
     down, up = subsample_axis_indices(width, thick)
     if upsample:
         return _axis_gather(x, down[up], ax)                 # the two gathers of the reference composed into one

@@ -347,6 +347,52 @@ def gen_mi():
     save('mi_small', **cases)
 
 
+
+def gen_augment():
+    """augment.draw_crop_mask (augment.py:218-290) and utils.subsample_axis (utils.py:754-826) with scripted uniform draws:
+    the reference's own control flow decides how many draws are taken and in which order."""
+    rng = np.random.default_rng(21)
+    cases = {}
+    n = 0
+    for shape, kw in (((2, 10, 6, 1), dict(crop_min=0.1, crop_max=0.5, axis=(1, 2))),
+                      ((2, 10, 6, 1), dict(crop_min=0.3, crop_max=0.3, axis=1)),
+                      ((1, 17, 9, 12, 2), dict(crop_min=0.0, crop_max=0.8, axis=None, bilateral=True)),
+                      ((3, 32, 2), dict(crop_min=0.2, crop_max=0.6, axis=1, prob=0.5)),
+                      ((3, 32, 2), dict(crop_min=0.2, crop_max=0.6, axis=(0, 1, 2), prob=0.5, bilateral=True)),
+                      ((1, 64, 64, 1), dict(crop_min=0.05, crop_max=0.95, axis=(1, 2)))):
+        for rep in range(4):
+            draws = rng.random(6).astype(F)
+            tf_shim.RANDOM_SCRIPT[:] = [float(d) for d in draws]
+            mask = A(ne.utils.augment.draw_crop_mask(T(np.zeros(shape, F)), seed=1, **kw))
+            used = 6 - len(tf_shim.RANDOM_SCRIPT)
+            cases['crop%d__shape' % n] = np.asarray(shape)
+            cases['crop%d__draws' % n] = draws[:used]
+            cases['crop%d__mask' % n] = mask
+            for k, v in kw.items():
+                cases['crop%d__%s' % (n, k)] = np.asarray(-1 if v is None else v)
+            n += 1
+    cases['ncrop'] = np.asarray(n)
+    n = 0
+    for shape, kw in (((2, 12, 3), dict(stride_min=2, stride_max=5, axes=(1,))),
+                      ((1, 33, 20, 2), dict(stride_min=1, stride_max=8, axes=(1, 2))),
+                      ((1, 33, 20, 2), dict(stride_min=1, stride_max=8, axes=(1, 2), prob=0.5)),
+                      ((2, 16, 16, 16, 1), dict(stride_min=3, stride_max=3, axes=(1, 2, 3), upsample=False)),
+                      ((1, 160, 1), dict(stride_min=1.5, stride_max=6.5, axes=1))):
+        for rep in range(4):
+            draws = rng.random(4).astype(F)
+            tf_shim.RANDOM_SCRIPT[:] = [float(d) for d in draws]
+            x = rng.standard_normal(shape).astype(F)
+            y = A(ne.utils.subsample_axis(T(x), seed=1, **kw))
+            used = 4 - len(tf_shim.RANDOM_SCRIPT)
+            cases['sub%d__x' % n] = x
+            cases['sub%d__draws' % n] = draws[:used]
+            cases['sub%d__out' % n] = y
+            for k, v in kw.items():
+                cases['sub%d__%s' % (n, k)] = np.asarray(v)
+            n += 1
+    cases['nsub'] = np.asarray(n)
+    save('augment_small', **cases)
+
 if __name__ == '__main__':
     gen_mi()
     gen_filter()
@@ -356,3 +402,4 @@ if __name__ == '__main__':
     gen_dice()
     gen_cce()
     gen_lc3d()
+    gen_augment()

@@ -213,6 +213,8 @@ def stack(values, axis=0, **kw):
 
 
 def concat(values, axis, **kw):
+    if isinstance(values, Tensor):
+        return values                        # tf.concat of a single tensor is the tensor
     arrs = [A(convert_to_tensor(v)) for v in values]
     return Tensor(np.concatenate(arrs, axis))
 
@@ -245,7 +247,9 @@ def reshape(x, shape, **kw):
 
 
 def gather(params, indices, axis=0, **kw):
-    return Tensor(np.take(A(params), A(indices), axis=axis))
+    if isinstance(params, (list, tuple, range)):
+        params = np.asarray(list(params))
+    return Tensor(np.take(A(params), A(indices), axis=int(A(axis))))
 
 
 def reduce_any(x, axis=None, keepdims=False):
@@ -260,7 +264,11 @@ def reduce_sum(x, axis=None, keepdims=False):
 
 def linspace(start, stop, num, **kw):
     """tf.linspace in float32 for python-float endpoints (TF semantics restated)."""
-    f = np.float32
+    start, stop, num = (A(v) if isinstance(v, Tensor) else v for v in (start, stop, num))
+    ints = all(isinstance(v, (int, np.integer)) or (isinstance(v, np.ndarray) and np.issubdtype(v.dtype, np.integer))
+               for v in (start, stop))
+    # integer end points: TF's linspace divides with truediv (float64) and re-casts start / stop to that dtype
+    f = np.float64 if ints else np.float32
     start, stop, num = f(start), f(stop), int(num)
     if num == 1:
         return Tensor(np.array([start], f))
@@ -272,6 +280,15 @@ def linspace(start, stop, num, **kw):
 def range_(start, limit=None, delta=1, dtype=None, **kw):
     if limit is None:
         start, limit = 0, start
+    start, limit, delta = (A(v) if isinstance(v, Tensor) else v for v in (start, limit, delta))
+    if any(isinstance(v, (float, np.floating)) or (isinstance(v, np.ndarray) and np.issubdtype(v.dtype, np.floating))
+           for v in (start, limit, delta)):
+        # float range: size = ceil((limit - start) / delta), element i = start + i * delta, all in float32
+        f = np.float32
+        start, limit, delta = f(start), f(limit), f(delta)
+        n = int(np.ceil(np.abs((limit - start) / delta)))
+        a = (start + np.arange(n).astype(f) * delta).astype(f)
+        return Tensor(a if dtype is None else a.astype(as_np_dtype(dtype)))
     a = np.arange(start, limit, delta)
     if dtype is not None:
         a = a.astype(as_np_dtype(dtype))
@@ -537,6 +554,34 @@ def nn_convolution(x, filters, padding='VALID', strides=None, dilations=None, **
     return Tensor(out[..., None])
 
 
+# ---- scripted randomness: tf.random.uniform returns minval + u * (maxval - minval) for the next u of RANDOM_SCRIPT -------
+# (float32 arithmetic as TensorFlow's random_uniform; integer dtypes: minval + floor(u * (maxval - minval)))
+RANDOM_SCRIPT = []
+
+
+def random_uniform(shape=(), minval=0, maxval=None, dtype=np.float32, seed=None, **kw):
+    dt = as_np_dtype(dtype)
+    shp = tuple(int(v) for v in np.ravel(A(shape))) if not isinstance(shape, (list, tuple)) or len(shape) else ()
+    n = int(np.prod(shp)) if shp else 1
+    if len(RANDOM_SCRIPT) < n:
+        raise RuntimeError('tf_shim.RANDOM_SCRIPT exhausted')
+    u = np.array([RANDOM_SCRIPT.pop(0) for _ in range(n)], np.float32).reshape(shp)
+    if np.issubdtype(dt, np.integer):
+        if maxval is None:
+            raise ValueError('maxval is required for integer dtypes')
+        lo, hi = int(A(minval)), int(A(maxval))
+        return Tensor((lo + np.floor(u.astype(np.float64) * (hi - lo))).astype(dt))
+    hi = np.float32(1.0 if maxval is None else A(maxval))
+    lo = np.float32(A(minval))
+    return Tensor((u * (hi - lo) + lo).astype(dt))
+
+
+def roll_(x, shift, axis, **kw):
+    if isinstance(x, (list, tuple)):         # a python sequence mixing tensors and numbers is packed like tf.stack
+        x = np.array([np.asarray(A(v)).reshape(()) for v in x])
+    return Tensor(np.roll(A(x), int(A(shift)), int(A(axis))))
+
+
 def _populate(m):
     n = m.__name__
     if n == 'pystrum':
@@ -554,10 +599,14 @@ def _populate(m):
             shape=shape_, transpose=transpose_, reduce_prod=reduce_prod, reduce_min=reduce_min, reduce_max=reduce_max,
             newaxis=None, minimum=lambda a, b: Tensor(np.minimum(A(a), A(b))), maximum=lambda a, b: Tensor(np.maximum(A(a), A(b))),
             reduce_mean=lambda x, axis=None, keepdims=False: Tensor(np.mean(A(x), axis=axis, keepdims=keepdims)),
+            logical_and=lambda a, b: Tensor(np.logical_and(A(a), A(b))), greater_equal=lambda a, b: T(a) >= b,
+            is_tensor=lambda x: isinstance(x, Tensor), roll=roll_,
         )
         for k, v in d.items():
             setattr(m, k, v)
         m.__version__ = '2.99.shim'
+    if n == 'tensorflow.random':
+        m.uniform = random_uniform
     if n == 'tensorflow.math':
         m.divide_no_nan = divide_no_nan
         m.log = log
@@ -609,7 +658,7 @@ def install():
                  'tensorflow.keras.backend', 'tensorflow.keras.layers', 'tensorflow.keras.losses',
                  'tensorflow.keras.models', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
                  'tensorflow.python', 'tensorflow.python.keras', 'tensorflow.python.keras.utils',
-                 'tensorflow.python.ops', 'tensorflow.nn', 'tensorflow.experimental', 'tensorflow.experimental.numpy', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
+                 'tensorflow.python.ops', 'tensorflow.nn', 'tensorflow.random', 'tensorflow.experimental', 'tensorflow.experimental.numpy', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
         mod = importlib.import_module(name)
         if '.' in name:
             parent, child = name.rsplit('.', 1)

@@ -519,3 +519,37 @@ def test_header_is_c99_and_a_c_program_links(tmp_path):
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and 'C ABI 1 for gfx950' in out.stdout and '"ok"' in out.stdout
+
+
+def test_augment_golden_cpu():
+    """draw_crop_mask and the index logic of subsample_axis against the REFERENCE'S OWN SOURCE run on scripted uniform draws
+    (tests/golden/augment_small.npz): same number of draws in the same order, same masks / slices"""
+    from neurite_amd import augment, utils
+    g = load_golden('augment_small')
+    for n in range(int(g['ncrop'])):
+        kw = {}
+        for k in ('crop_min', 'crop_max', 'prob'):
+            if 'crop%d__%s' % (n, k) in g:
+                kw[k] = float(g['crop%d__%s' % (n, k)])
+        if 'crop%d__bilateral' % n in g:
+            kw['bilateral'] = bool(g['crop%d__bilateral' % n])
+        ax = g['crop%d__axis' % n]
+        kw['axis'] = None if ax.ndim == 0 and int(ax) == -1 else (int(ax) if ax.ndim == 0 else tuple(int(v) for v in ax))
+        draws = [float(d) for d in g['crop%d__draws' % n]]
+        x = torch.zeros(tuple(int(v) for v in g['crop%d__shape' % n]))
+        mask = augment.draw_crop_mask(x, _draws=draws, **kw).numpy()
+        want = g['crop%d__mask' % n]
+        assert mask.shape == want.shape and np.array_equal(mask, want), (n, kw, draws)
+    for n in range(int(g['nsub'])):
+        x, want = g['sub%d__x' % n], g['sub%d__out' % n]
+        axes = g['sub%d__axes' % n]
+        axes = [int(axes)] if axes.ndim == 0 else [int(v) for v in axes]
+        prob = float(g['sub%d__prob' % n]) if 'sub%d__prob' % n in g else 1
+        upsample = bool(g['sub%d__upsample' % n]) if 'sub%d__upsample' % n in g else True
+        draws = [float(d) for d in g['sub%d__draws' % n]]
+        ai, thick = utils._subsample_draws(len(axes), float(g['sub%d__stride_min' % n]), float(g['sub%d__stride_max' % n]), prob,
+                                           None, draws)
+        ax = axes[ai]
+        down, up = utils.subsample_axis_indices(x.shape[ax], thick)
+        got = np.take(x, down[up] if upsample else down, axis=ax)
+        assert got.shape == want.shape and np.array_equal(got, want), (n, ax, float(thick))
