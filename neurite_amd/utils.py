@@ -484,7 +484,7 @@ def compose(transforms, interp_method='linear', shift_center=True, indexing='ij'
 # --------------------------------------------------------------------------------------
 
 def gaussian_kernel(sigma, windowsize=None, indexing='ij', separate=False, random=False, min_sigma=0,
-                    dtype=torch.float32, seed=None, device=None):
+                    dtype=torch.float32, seed=None, device=None, _draws=None):
     """
     N-dimensional Gaussian kernel (utils.py:581-662), or a list of N 1-D kernels with separate=True.  Host-side: the
     kernels are a few dozen numbers.  random=True draws each SD uniformly from [min_sigma, sigma) with torch's RNG
@@ -514,7 +514,12 @@ def gaussian_kernel(sigma, windowsize=None, indexing='ij', separate=False, rando
     if random:
         gen = torch.Generator(device='cpu')
         gen.manual_seed(int(np.random.default_rng(seed).integers(2 ** 31 - 1)))
-        sigma = [float(a + (b - a) * torch.rand((), generator=gen)) for a, b in zip(min_sigma, sigma)]
+        draws = None if _draws is None else list(_draws)         # tests: the uniform [0, 1) numbers to use
+
+        def uniform():
+            return np.float32(draws.pop(0)) if draws is not None else np.float32(float(torch.rand((), generator=gen)))
+        # tf.random.uniform(minval=a, maxval=b) = u * (b - a) + a in float32
+        sigma = [float(uniform() * np.float32(np.float32(b) - np.float32(a)) + np.float32(a)) for a, b in zip(min_sigma, sigma)]
     exponent = [m / torch.tensor(s, dtype=dtype) ** 2 for m, s in zip(mesh, sigma)]
     if not separate:
         exponent = [torch.stack(exponent).sum(0)]

@@ -391,6 +391,22 @@ def gen_augment():
                 cases['sub%d__%s' % (n, k)] = np.asarray(v)
             n += 1
     cases['nsub'] = np.asarray(n)
+    # gaussian_kernel(random=True) (utils.py:643-650): one uniform draw per axis for the SD
+    n = 0
+    for kw in (dict(sigma=[2.0, 3.0, 1.0], min_sigma=[0.5, 0.5, 0.5]), dict(sigma=4.0, min_sigma=1.0), dict(sigma=[1.5, 1.5], min_sigma=0)):
+        for rep in range(3):
+            nsig = len(kw['sigma']) if isinstance(kw['sigma'], list) else 1
+            draws = rng.random(nsig).astype(F)
+            tf_shim.RANDOM_SCRIPT[:] = [float(d) for d in draws]
+            ks = ne.utils.gaussian_kernel(separate=True, random=True, seed=5, **kw)
+            ks = ks if isinstance(ks, list) else [ks]
+            cases['gk%d__draws' % n] = draws
+            cases['gk%d__sigma' % n] = np.asarray(kw['sigma'], F)
+            cases['gk%d__min_sigma' % n] = np.asarray(kw['min_sigma'], F)
+            for i, k in enumerate(ks):
+                cases['gk%d__k%d' % (n, i)] = A(k)
+            n += 1
+    cases['ngk'] = np.asarray(n)
     save('augment_small', **cases)
 
 if __name__ == '__main__':

@@ -157,6 +157,8 @@ class Tensor:
     def __truediv__(self, o): return self._bin(o, np.divide)
     def __rtruediv__(self, o): return self._bin(o, np.divide, True)
     def __neg__(self): return Tensor(-self.a)
+    def __pow__(self, o): return self._bin(o, np.power)
+    def __rpow__(self, o): return self._bin(o, np.power, True)
     def __lt__(self, o): return self._bin(o, np.less)
     def __le__(self, o): return self._bin(o, np.less_equal)
     def __gt__(self, o): return self._bin(o, np.greater)

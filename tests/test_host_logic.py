@@ -553,3 +553,11 @@ def test_augment_golden_cpu():
         down, up = utils.subsample_axis_indices(x.shape[ax], thick)
         got = np.take(x, down[up] if upsample else down, axis=ax)
         assert got.shape == want.shape and np.array_equal(got, want), (n, ax, float(thick))
+    for n in range(int(g['ngk'])):                         # gaussian_kernel(random=True): one uniform draw per axis
+        sig, mn = g['gk%d__sigma' % n], g['gk%d__min_sigma' % n]
+        sig = float(sig) if sig.ndim == 0 else [float(v) for v in sig]
+        mn = float(mn) if mn.ndim == 0 else [float(v) for v in mn]
+        ks = utils.gaussian_kernel(sig, separate=True, random=True, min_sigma=mn, _draws=[float(d) for d in g['gk%d__draws' % n]])
+        ks = ks if isinstance(ks, list) else [ks]
+        for i, k in enumerate(ks):
+            np.testing.assert_allclose(k.numpy(), g['gk%d__k%d' % (n, i)], rtol=2e-6, atol=1e-9)
