@@ -674,6 +674,11 @@ def soft_quantize(x, bin_centers=None, nb_bins=16, alpha=1, min_clip=-np.inf, ma
     return out
 
 
+def soft_digitize(*args, **kwargs):
+    """alias of soft_quantize (utils.py:1095-1096)"""
+    return soft_quantize(*args, **kwargs)
+
+
 # --------------------------------------------------------------------------------------
 # index / grid helpers (host-side; the kernels never need the materialised grids)
 # --------------------------------------------------------------------------------------
