@@ -21,6 +21,7 @@
 
 #include "dice_reduce.h"
 #include "interpn_core.h"
+#include "wdd.h"
 
 namespace {
 
@@ -248,291 +249,6 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// EXPERIMENTAL -- selected only by tune bit 30, never by default, and NOT YET VALIDATED ON HARDWARE (written after the
-// round's GPU budget was spent).  x-march schedule with exact de-duplication of the corner
-// rows of a window of DD_W x-planes in LDS: the 128 voxels of a 4 x 8 x DD_W window request 1024 rows of which ~320 are
-// distinct on the benchmark's field.
-//   phase 1  lane c of every 8-lane group files the row index of corner c of each of its DD_W voxels in an open-addressing
-//            hash (ds_cmpswap); the slot number is the row's place in the LDS row buffer
-//   barrier A
-//   phase 2  group g loads the rows of slots g, g + 32, ... (one 128-byte row per 8 lanes and instruction; empty slots use an
-//            out-of-range buffer offset: no memory access), the loads stay in flight during
-//   phase 3  the blend of the PREVIOUS window from the row buffer: corner rows come from LDS (slot broadcast by shuffle),
-//            the arithmetic is the one of warp_dice_tile
-//   barrier B  (everyone is done with the buffer and the table)
-//   phase 4  the rows of phase 2 go to the row buffer, the table is emptied
-//   barrier C
-// One row buffer (64 KB) + one table (2 KB): two blocks per CU, i.e. two waves per SIMD to hide the latencies of a window's
-// dependency chain (hash -> loads -> LDS), which one block per CU leaves exposed.
-// A window whose hash overflows (incoherent fields) is blended from memory directly by the whole block (block-uniform
-// branch): a conditional global load inside the LDS blend would make the compiler wait for all loads in flight
-// (vmcnt retires in order) and undo the overlap of phases 2 and 3.
-// ---------------------------------------------------------------------------------------------
-constexpr int DD_W = 4;
-constexpr int DD_H = 512;
-constexpr int DD_LOGH = 9;
-constexpr unsigned DD_EMPTY = 0xffffffffu;
-constexpr int DD_PROBES = 32;
-constexpr size_t DD_LDS_BYTES = (size_t)DD_H * 128 + (size_t)DD_H * sizeof(unsigned);
-
-struct DdState {                 // per lane: its group's DD_W voxels of one window
-    unsigned slot[DD_W];         // LDS slot of corner `lane % 8` (DD_DIRECT: read from memory)
-    unsigned rowc[DD_W];         // its row index
-    float w0x[DD_W], w0y[DD_W], w0z[DD_W];
-    bool valid[DD_W], oob[DD_W];
-};
-
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void warp_dice_dedup(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
-                                                          float *__restrict__ fpart, float *__restrict__ mpart) {
-    constexpr int G = 8, L = 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dd_smem[];
-    nrt_f4 *rowbuf = (nrt_f4 *)dd_smem;                                   // [DD_H][G]
-    unsigned *table = (unsigned *)(dd_smem + (size_t)DD_H * 128);         // [DD_H]
-    __shared__ float red[4][3 * L + 4];
-    __shared__ int dd_over;                                               // the window being indexed did not fit the table
-    int b, x0, y0, z0, xlen;
-    unsigned prow;
-    if (!xmarch_block(tg, a.O[0], b, prow, x0, y0, z0, xlen)) return;
-    const char *volb = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
-    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
-    const char *fixb = (const char *)(fixed + (long long)b * a.out_bs);
-    const int lg = threadIdx.x & 7, g = threadIdx.x >> 3;
-    const int gbase = (int)(threadIdx.x & 63u) - lg;                       // first lane of this group inside its wave
-    const int yv = y0 + (g >> 3), zv = z0 + (g & 7);                       // 4 x 8 patch (checked by the launcher)
-    const bool yz_ok = yv < a.O[1] && zv < a.O[2];
-    const int yc = min(yv, a.O[1] - 1), zc = min(zv, a.O[2] - 1);
-    const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
-    const unsigned vol_bytes = (unsigned)a.S[0] * SY * SZ * 128u;          // < 2^32 - 256 (launcher)
-    __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc((void *)volb, 0, (int)vol_bytes, 0x00020000);
-    const int xend = x0 + xlen;
-    const int nwin = (xlen + DD_W - 1) / DD_W;
-
-    nrt_f2 stp_l = {0, 0}, stp_h = {0, 0}, stt_l = {0, 0}, stt_h = {0, 0}, spp_l = {0, 0}, spp_h = {0, 0};
-    float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
-
-    auto voxel_q = [&](int x) { return nrt_mad24(nrt_mad24((unsigned)min(x, a.O[0] - 1), (unsigned)a.O[1], (unsigned)yc), (unsigned)a.O[2], (unsigned)zc); };
-    auto load_loc = [&](int win, float (&pn)[DD_W][3]) {
-#pragma unroll
-        for (int w = 0; w < DD_W; ++w) {
-            pn[w][0] = pn[w][1] = pn[w][2] = 0.0f;
-            if (MODE != NRT_LOC_LINSPACE) {
-                const unsigned q = voxel_q(x0 + win * DD_W + w);
-                const float *lp = (const float *)((const char *)locb + (size_t)(nrt_times3(q) << 2));
-                pn[w][0] = lp[0]; pn[w][1] = lp[1]; pn[w][2] = lp[2];
-            }
-        }
-    };
-    auto load_fixed = [&](int win, nrt_f4 (&T)[DD_W]) {
-#pragma unroll
-        for (int w = 0; w < DD_W; ++w) {
-            const unsigned q = voxel_q(x0 + win * DD_W + w);
-            T[w] = __builtin_nontemporal_load((const nrt_f4 *)(fixb + (size_t)((q * 8u + (unsigned)lg) * 16u)));
-        }
-    };
-    // phase 1
-    auto index_window = [&](int win, const float (&pn)[DD_W][3], unsigned *tbl, DdState &st) {
-        unsigned hs[DD_W], old[DD_W];
-#pragma unroll
-        for (int w = 0; w < DD_W; ++w) {
-            const int x = x0 + win * DD_W + w;
-            st.valid[w] = yz_ok && x < xend;
-            const int qd[3] = {min(x, a.O[0] - 1), yc, zc};
-            float p[NRT_MAXD];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                if (MODE == NRT_LOC_ABSOLUTE) p[d] = pn[w][d];
-                else if (MODE == NRT_LOC_SHIFT) p[d] = nrt_add((float)qd[d], pn[w][d]);
-                else p[d] = (qd[d] == 0) ? 0.0f : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
-            }
-            int i0x, i1x, i0y, i1y, i0z, i1z;
-            float w1x, w1y, w1z;
-            corner_1d(p[0], a.S[0], i0x, i1x, st.w0x[w], w1x);
-            corner_1d(p[1], a.S[1], i0y, i1y, st.w0y[w], w1y);
-            corner_1d(p[2], a.S[2], i0z, i1z, st.w0z[w], w1z);
-            st.oob[w] = a.has_fill ? out_of_bounds<3>(a, p) : false;
-            const unsigned ix = (lg & 4) ? i1x : i0x, iy = (lg & 2) ? i1y : i0y, iz = (lg & 1) ? i1z : i0z;
-            st.rowc[w] = nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz);
-            hs[w] = (st.rowc[w] * 2654435761u) >> (32 - DD_LOGH);
-        }
-        // first probes of the DD_W voxels back to back (independent LDS atomics), then the rare longer probe sequences
-#pragma unroll
-        for (int w = 0; w < DD_W; ++w) old[w] = st.valid[w] ? atomicCAS(&tbl[hs[w]], DD_EMPTY, st.rowc[w]) : st.rowc[w];
-#pragma unroll
-        for (int w = 0; w < DD_W; ++w) {
-            unsigned res = hs[w];                                          // invalid voxels: any slot, never accumulated
-            if (st.valid[w] && old[w] != DD_EMPTY && old[w] != st.rowc[w]) {
-                bool found = false;
-                unsigned sl = (hs[w] + 1) & (DD_H - 1);
-                for (int t = 1; t < DD_PROBES; ++t) {
-                    const unsigned o = atomicCAS(&tbl[sl], DD_EMPTY, st.rowc[w]);
-                    if (o == DD_EMPTY || o == st.rowc[w]) { res = sl; found = true; break; }
-                    sl = (sl + 1) & (DD_H - 1);
-                }
-                if (!found) dd_over = 1;                                   // the block blends this window from memory
-            }
-            st.slot[w] = res;
-        }
-    };
-    // phase 2: slots g, g + 32, ... of the table -> registers
-    auto issue_loads = [&](const unsigned *tbl, nrt_f4 (&R)[DD_H / 32]) {
-        unsigned rows[DD_H / 32];
-#pragma unroll
-        for (int k = 0; k < DD_H / 32; ++k) rows[k] = tbl[g + 32 * k];
-#pragma unroll
-        for (int k = 0; k < DD_H / 32; ++k) {
-            const unsigned off = rows[k] == DD_EMPTY ? 0xfffffff0u : rows[k] * 128u + (unsigned)lg * 16u;
-            const nrt_i4 v = __builtin_bit_cast(nrt_i4, __builtin_amdgcn_raw_buffer_load_b128(vr, off, 0, 0));
-            R[k] = __builtin_bit_cast(nrt_f4, v);
-        }
-    };
-    auto store_rows = [&](nrt_f4 *buf, const nrt_f4 (&R)[DD_H / 32]) {
-#pragma unroll
-        for (int k = 0; k < DD_H / 32; ++k) buf[(g + 32 * k) * G + lg] = R[k];
-    };
-    // phase 3
-    auto blend_window = [&](const nrt_f4 *buf, const DdState &st, const nrt_f4 (&T)[DD_W], auto from_lds) {
-        constexpr bool LDS = decltype(from_lds)::value;
-#pragma unroll
-        for (int w = 0; w < DD_W; ++w) {
-            auto fetch_half = [&](int half, nrt_f4 (&rows)[4]) {            // four corner rows at a time (register budget)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int corner = 4 * half + k;
-                    if (LDS) {
-                        const unsigned sc = (unsigned)__shfl((int)st.slot[w], gbase + corner, 64);
-                        rows[k] = buf[sc * G + lg];
-                    } else {
-                        const unsigned rc = (unsigned)__shfl((int)st.rowc[w], gbase + corner, 64);
-                        rows[k] = *(const nrt_f4 *)(volb + (size_t)(rc * 128u + (unsigned)lg * 16u));
-                    }
-                }
-            };
-            const float w1x = nrt_sub(1.0f, st.w0x[w]), w1y = nrt_sub(1.0f, st.w0y[w]), w1z = nrt_sub(1.0f, st.w0z[w]);
-            const nrt_f2 wy2 = {st.w0y[w], w1y}, wz2 = {st.w0z[w], w1z};
-            const nrt_f2 wxy0 = (nrt_f2){st.w0x[w], st.w0x[w]} * wy2, wxy1 = (nrt_f2){w1x, w1x} * wy2;
-            nrt_f2 wt2[4];
-            wt2[0] = (nrt_f2){wxy0[0], wxy0[0]} * wz2;
-            wt2[1] = (nrt_f2){wxy0[1], wxy0[1]} * wz2;
-            wt2[2] = (nrt_f2){wxy1[0], wxy1[0]} * wz2;
-            wt2[3] = (nrt_f2){wxy1[1], wxy1[1]} * wz2;
-            nrt_f2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                nrt_f4 rows[4];
-                fetch_half(half, rows);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int corner = 4 * half + k;
-                    const float wt = wt2[corner >> 1][corner & 1];
-                    const nrt_f2 w2 = {wt, wt};
-                    al = al + w2 * (nrt_f2){rows[k][0], rows[k][1]};
-                    ah = ah + w2 * (nrt_f2){rows[k][2], rows[k][3]};
-                }
-            }
-            nrt_f4 acc = {al[0], al[1], ah[0], ah[1]};
-            if (a.has_fill) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], st.oob[w], a.fill_f);
-            }
-            if (st.valid[w]) {
-                const nrt_f2 pl = {acc[0], acc[1]}, ph = {acc[2], acc[3]}, tl = {T[w][0], T[w][1]}, th = {T[w][2], T[w][3]};
-                stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
-                stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
-                spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    mnt = fminf(mnt, T[w][c]); mxt = fmaxf(mxt, T[w][c]);
-                    mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
-                }
-            }
-        }
-    };
-
-    // ---- prologue: table empty, window 0 indexed and staged ---------------------------------------------------
-    for (int i = threadIdx.x; i < DD_H; i += 256) table[i] = DD_EMPTY;
-    if (threadIdx.x == 0) dd_over = 0;
-    __syncthreads();
-    float pn[DD_W][3];
-    DdState sa, sb;
-    nrt_f4 Ta[DD_W], Tb[DD_W], R[DD_H / 32];
-    load_loc(0, pn);
-    index_window(0, pn, table, sa);
-    load_loc(min(1, nwin - 1), pn);
-    __syncthreads();
-    bool direct_a = dd_over != 0, direct_b = false;                        // block-uniform
-    if (!direct_a) issue_loads(table, R);
-    load_fixed(0, Ta);
-    __syncthreads();                                                       // table and flag read by everyone
-    for (int i = threadIdx.x; i < DD_H; i += 256) table[i] = DD_EMPTY;
-    if (threadIdx.x == 0) dd_over = 0;
-    if (!direct_a) store_rows(rowbuf, R);
-    __syncthreads();
-    for (int i = 0; i < nwin; ++i) {
-        const bool more = i + 1 < nwin;
-        if (more) {
-            index_window(i + 1, pn, table, sb);
-            load_loc(min(i + 2, nwin - 1), pn);
-        }
-        __syncthreads();                                                   // A: inserts of window i + 1 are complete
-        direct_b = more && dd_over != 0;
-        if (more) {
-            if (!direct_b) issue_loads(table, R);
-            load_fixed(i + 1, Tb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (direct_a) blend_window(rowbuf, sa, Ta, std::false_type{});
-        else blend_window(rowbuf, sa, Ta, std::true_type{});
-        __syncthreads();                                                   // B: buffer, table and flag no longer needed
-        for (int k = threadIdx.x; k < DD_H; k += 256) table[k] = DD_EMPTY;
-        if (threadIdx.x == 0) dd_over = 0;
-        if (more && !direct_b) store_rows(rowbuf, R);
-        __syncthreads();                                                   // C: window i + 1 staged, table empty
-        sa = sb;
-        direct_a = direct_b;
-#pragma unroll
-        for (int w = 0; w < DD_W; ++w) Ta[w] = Tb[w];
-    }
-
-    nrt_f4 stp = {stp_l[0], stp_l[1], stp_h[0], stp_h[1]}, stt = {stt_l[0], stt_l[1], stt_h[0], stt_h[1]},
-           spp = {spp_l[0], spp_l[1], spp_h[0], spp_h[1]};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        stp[c] = wave_xor_add(stp[c], G);
-        stt[c] = wave_xor_add(stt[c], G);
-        spp[c] = wave_xor_add(spp[c], G);
-    }
-    for (int off = 1; off < NRT_WAVE; off <<= 1) {
-        mnt = fminf(mnt, __shfl_xor(mnt, off, NRT_WAVE)); mxt = fmaxf(mxt, __shfl_xor(mxt, off, NRT_WAVE));
-        mnp = fminf(mnp, __shfl_xor(mnp, off, NRT_WAVE)); mxp = fmaxf(mxp, __shfl_xor(mxp, off, NRT_WAVE));
-    }
-    const int lane = threadIdx.x & (NRT_WAVE - 1), wv = threadIdx.x / NRT_WAVE;
-    if (lane < G) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            red[wv][0 * L + 4 * lane + c] = stp[c];
-            red[wv][1 * L + 4 * lane + c] = stt[c];
-            red[wv][2 * L + 4 * lane + c] = spp[c];
-        }
-    }
-    if (lane == 0) { red[wv][3 * L + 0] = mnt; red[wv][3 * L + 1] = mxt; red[wv][3 * L + 2] = mnp; red[wv][3 * L + 3] = mxp; }
-    __syncthreads();
-    const long long pbase = (long long)b * (tg.ncol * tg.nseg) + prow;
-    for (int i = threadIdx.x; i < 3 * L; i += 256) {
-        float s = red[0][i];
-#pragma unroll
-        for (int w2 = 1; w2 < 4; ++w2) s += red[w2][i];
-        fpart[pbase * 3 * L + i] = s;
-    }
-    if (threadIdx.x < 4) {
-        float m = red[0][3 * L + threadIdx.x];
-        for (int w2 = 1; w2 < 4; ++w2)
-            m = (threadIdx.x & 1) ? fmaxf(m, red[w2][3 * L + threadIdx.x]) : fminf(m, red[w2][3 * L + threadIdx.x]);
-        mpart[pbase * 4 + threadIdx.x] = m;
-    }
-}
-
 // the fused kernel writes one partial per block: size the workspace for its grid
 size_t fused_ws_bytes(unsigned nblocks, int L, int batch) {
     const size_t rows = (size_t)batch * nblocks;
@@ -602,37 +318,15 @@ void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int
 #undef NRT_FUSED
 }
 
-// experimental de-duplicating schedule (tune bit 30); false = not applicable, use the regular kernels
-bool launch_dedup(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, const float *fixed, float *fpart,
-                  float *mpart, hipStream_t st) {
-    if (!tg.x_march || tg.lty != 2 || tg.ltz != 3) return false;
-    if ((unsigned long long)a.S[0] * a.S[1] * a.S[2] * 128ull >= 0xffffff00ull) return false;
-    const dim3 grid(nrt_xcd_grid(nblocks * (unsigned)batch), 1), blk(256);
-#define NRT_DEDUP(MODE)                                                                                                  \
-    do {                                                                                                                 \
-        static bool attr = false;                                                                                        \
-        if (!attr) {                                                                                                     \
-            (void)hipFuncSetAttribute((const void *)warp_dice_dedup<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                      (int)DD_LDS_BYTES);                                                                \
-            attr = true;                                                                                                 \
-        }                                                                                                                \
-        hipLaunchKernelGGL((warp_dice_dedup<MODE>), grid, blk, DD_LDS_BYTES, st, a, tg, fixed, fpart, mpart);            \
-    } while (0)
-    switch (mode) {
-        case NRT_LOC_ABSOLUTE: NRT_DEDUP(NRT_LOC_ABSOLUTE); break;
-        case NRT_LOC_SHIFT: NRT_DEDUP(NRT_LOC_SHIFT); break;
-        default: NRT_DEDUP(NRT_LOC_LINSPACE); break;
-    }
-#undef NRT_DEDUP
-    return true;
-}
-
-constexpr int FUSED_TUNE_DEDUP = 1 << 30;
+constexpr int FUSED_TUNE_DEDUP = 1 << 30;   // retired: the ds_cmpswap hash schedule measured 1.82 ms vs 1.19 ms (profiles/r02_lab); ignored
+constexpr int FUSED_TUNE_WDD = 1 << 29;      // wave-window de-duplicating gather (gather_wdd.hip); low bits = its own tune word
 
 }  // namespace
 
 extern "C" size_t nrt_warp_dice_workspace_bytes(const int *out_shape, int nlabels, int batch, int tune) {
     if (!out_shape || nlabels < 4 || nlabels % 4 || batch < 1) return 0;
+    if (tune > 0 && (tune & FUSED_TUNE_WDD) && nlabels == 32)
+        return fused_ws_bytes(nrt_wdd_rows(out_shape, batch, tune & (FUSED_TUNE_WDD - 1)), nlabels, batch);
     if (tune > 0) tune &= ~FUSED_TUNE_DEDUP;
     TileGeom tg;
     unsigned nblocks;
@@ -665,7 +359,30 @@ extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, con
         (long long)out_shape[0] * out_shape[1] >= (1 << 24) || out_shape[2] >= (1 << 24)) return NRT_ERR_UNSUPPORTED;
     if ((((uintptr_t)moving | (uintptr_t)fixed | (uintptr_t)warped) & 15) != 0) return NRT_ERR_INVALID_ARG;
     if (a.nout == 0) return NRT_ERR_INVALID_ARG;
-    const bool dedup = tune > 0 && (tune & FUSED_TUNE_DEDUP);            // experimental schedule, see warp_dice_dedup
+    if (tune > 0 && (tune & FUSED_TUNE_WDD)) {
+        if (G != 8 || !nrt_wdd_supported(vol_shape, out_shape, nlabels)) return NRT_ERR_UNSUPPORTED;
+        const int wt = tune & (FUSED_TUNE_WDD - 1);
+        const unsigned nrows = nrt_wdd_rows(out_shape, batch, wt);
+        if (!workspace || workspace_bytes < fused_ws_bytes(nrows, nlabels, batch)) return NRT_ERR_WORKSPACE;
+        DiceWs w;
+        const size_t rows = (size_t)batch * nrows;
+        char *p = (char *)workspace;
+        w.fpart = (float *)p; p += rows * 3 * nlabels * sizeof(float);
+        w.mpart = (float *)p; p += rows * 4 * sizeof(float);
+        p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+        w.gsum = (double *)p; p += (size_t)batch * ((nrows + RED_ROWS - 1) / RED_ROWS) * 3 * nlabels * sizeof(double);
+        w.gmm = (float *)p;
+        w.ipart = nullptr;
+        WddCall c;
+        c.vol = moving; c.loc = loc; c.out = warped; c.fixed = fixed; c.fpart = w.fpart; c.mpart = w.mpart; c.minmax = minmax != nullptr;
+        for (int d = 0; d < 3; ++d) { c.S[d] = a.S[d]; c.O[d] = a.O[d]; c.delta[d] = a.delta[d]; }
+        c.batch = batch; c.vol_bs = a.vol_bs; c.loc_bs = a.loc_bs; c.out_bs = a.out_bs;
+        c.mode = loc_mode; c.has_fill = a.has_fill; c.fill = fill_value; c.tune = wt;
+        hipStream_t st = nrt_stream(stream);
+        rc = nrt_wdd_launch(c, st);
+        if (rc != NRT_OK) return rc;
+        return dice_finalize_soft(w, nrows, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
+    }
     if (tune > 0) tune &= ~FUSED_TUNE_DEDUP;
     TileGeom tg;
     unsigned nblocks;
@@ -683,9 +400,6 @@ extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, con
     w.ipart = nullptr;
     hipStream_t st = nrt_stream(stream);
     const bool store = warped != nullptr;
-    bool launched = false;
-    if (dedup && G == 8 && !store) launched = launch_dedup(a, tg, nblocks, batch, loc_mode, fixed, w.fpart, w.mpart, st);
-    if (!launched)
     switch (G) {
         case 1: launch_fused<1>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
         case 2: launch_fused<2>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;

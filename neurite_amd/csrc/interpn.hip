@@ -26,6 +26,7 @@
 // path is bit-identical to the CPU restatement, not merely within 1e-5.
 
 #include "interpn_core.h"
+#include "wdd.h"
 
 namespace {
 
@@ -849,6 +850,8 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
     const bool can_zrun = can_rows && channels == 32 && ndim == 3 && method == NRT_INTERP_LINEAR &&
                           vol_bytes < (1ull << 32);
     const bool can_lds = method == NRT_INTERP_LINEAR && lds_supported(a, ndim);
+    const bool can_wdd = can_rows && method == NRT_INTERP_LINEAR && ndim == 3 && nrt_wdd_supported(a.S, a.O, channels) &&
+                         ((uintptr_t)loc & 3) == 0;
     if (variant == 0) {
         if (can_zrun) { variant = g_auto_c32_variant; if (tune == 0) tune = (variant >= 3) ? g_auto_c32_tune : 0; }
         else if (can_lds) variant = 6;
@@ -870,6 +873,15 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 4: launch_zrun(a, batch, loc_mode, variant, tune, st); break;
         case 5: launch_tile_any(a, batch, loc_mode, tune, st); break;
         case 6: launch_lds(a, batch, loc_mode, st); break;
+        case 7: {
+            if (!can_wdd) return NRT_ERR_UNSUPPORTED;
+            WddCall w;
+            w.vol = vol; w.loc = loc; w.out = out; w.fixed = nullptr; w.fpart = nullptr; w.mpart = nullptr; w.minmax = 0;
+            for (int d = 0; d < 3; ++d) { w.S[d] = a.S[d]; w.O[d] = a.O[d]; w.delta[d] = a.delta[d]; }
+            w.batch = batch; w.vol_bs = a.vol_bs; w.loc_bs = a.loc_bs; w.out_bs = a.out_bs;
+            w.mode = loc_mode; w.has_fill = a.has_fill; w.fill = fill_value; w.tune = tune;
+            return nrt_wdd_launch(w, st);
+        }
         default: return NRT_ERR_INVALID_ARG;
     }
     NRT_CHECK_LAUNCH();

@@ -79,7 +79,8 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
             rc = lib.nrt_warp_dice_soft_f32(_lib.ptr(mov), _lib.ptr(shift), _lib.ptr(fix), _lib.ptr(warped),
                                             _lib.ints(S), o_shape, L, B, loc_bs, _lib.LOC_SHIFT,
                                             int(has_fill), float(fill_value) if has_fill else 0.0,
-                                            float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice), _lib.ptr(minmax),
+                                            float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice),
+                                            _lib.ptr(minmax) if check_input_limits else None,
                                             int(_tune), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_warp_dice_soft_f32')
         if check_input_limits:

@@ -274,7 +274,9 @@ def test_fused_x_march_schedule_ragged(dev):
              xm,                                 # x-march, no regions, one segment
              xm | (3 << 16),                     # three x segments (36 = 3 x 12)
              xm | (5 << 16) | (2 << 24) | (1 << 27),     # five segments (ragged last), 4 x 2 regions
-             3 | (3 << 4) | (3 << 8) | (1 << 14) | (1 << 24) | (3 << 27))        # 8 x 8 patches (two passes per plane), 2 x 8 regions
+             3 | (3 << 4) | (3 << 8) | (1 << 14) | (1 << 24) | (3 << 27),        # 8 x 8 patches (two passes per plane), 2 x 8 regions
+             (1 << 29), (1 << 29) | 1, (1 << 29) | 2 | 4, (1 << 29) | (3 << 8), (1 << 29) | 5 | (2 << 8) | (1 << 16) | (1 << 19),   # wave-window gather
+             (1 << 29) | 64, (1 << 29) | 65 | (3 << 8), (1 << 29) | 67, (1 << 29) | 192, (1 << 29) | 193 | (2 << 8))                        # lane-per-voxel gather
     for tune in tunes:
         d, w = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=0.0, return_warped=True, _tune=tune)
         assert bits_equal(N(w), w_ref), tune
@@ -318,24 +320,3 @@ def test_mean_squared_error_prob(dev):
         ne.metrics.MeanSquaredErrorProb()(tg, pg, sample_weight=[1.0, 2.0])
     with pytest.raises(ValueError, match='Invalid Reduction'):
         ne.metrics.MeanSquaredErrorProb(reduction='mean')
-
-
-@pytest.mark.skipif(os.environ.get('NRT_TEST_EXPERIMENTAL') != '1',
-                    reason='warp_dice_dedup (tune bit 30) is experimental and not yet validated on hardware; '
-                           'set NRT_TEST_EXPERIMENTAL=1 to run')
-def test_fused_dedup_schedule_experimental(dev):
-    """The de-duplicating x-march schedule (tune bit 30) must give the Dice of the default schedule to the last bit of
-    every blended value (same arithmetic; only the summation order of the block partials is shared too), on ragged shapes,
-    several x segments, a smooth and an incoherent field (hash overflow -> direct reads), with and without fill."""
-    rng = np.random.default_rng(91)
-    L = 32
-    for B, S, sigma in ((6, (36, 50, 61), 2.0), (2, (40, 64, 128), 30.0), (1, (19, 128, 131), 0.3)):
-        mov = rng.random((B,) + S + (L,)).astype(F)
-        fix = rng.random((B,) + S + (L,)).astype(F)
-        trf = rng.normal(0, sigma, (B,) + S + (3,)).astype(F)
-        for fill in (None, 0.0):
-            for seg in (0, 3 << 16):
-                base = 0 if seg == 0 else (3 | (2 << 4) | (3 << 8) | (1 << 14) | seg)
-                d0 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, _tune=base)
-                d1 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, _tune=base | (1 << 30))
-                np.testing.assert_allclose(N(d1), N(d0), rtol=2e-6, err_msg=str((B, S, sigma, fill, seg)))

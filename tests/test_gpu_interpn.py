@@ -71,7 +71,14 @@ def _tile(lx, ly, lz, zo):
                                           (4, 13), (5, 0), (5, _tile(0, 0, 5, 0)), (5, _tile(1, 1, 3, 1)),
                                           (5, _tile(2, 3, 4, 1)), (5, _tile(3, 3, 3, 0)), (5, _tile(4, 4, 3, 1)),
                                           (5, _tile(0, 0, 0, 0)), (5, (1 << 13) | (7 << 16)), (5, (1 << 13) | (1 << 12)),
-                                          (5, (1 << 13) | (20 << 16))])
+                                          (5, (1 << 13) | (20 << 16)),
+                                          # 7 = wave-window de-duplicating gather: window shapes 4x4x4 / 4x2x8 / 2x4x8,
+                                          # 192- / 256-row buffers, x segments, patch regions
+                                          (7, 0), (7, 1), (7, 2), (7, 4), (7, 5), (7, 6), (7, 1 | (3 << 8)),
+                                          (7, (2 << 8) | (1 << 16) | (2 << 19)),
+                                          # bit 6: lane-per-voxel gather without the row buffer (gather_lpv), four window shapes
+                                          (7, 64), (7, 65), (7, 66), (7, 67), (7, 64 | (3 << 8)),
+                                          (7, 192), (7, 193 | (2 << 8))])            # bit 7: four waves share a window
 def test_c32_every_kernel_variant(dev, variant, tune):
     """All kernels that can serve C = 32 must agree bit-for-bit with the oracle, for sizes that are not
     multiples of the 4x8 patch / z-chunk / 8-voxel shift batch, smooth and rough fields, all loc modes."""

@@ -36,7 +36,7 @@ for d in sorted(glob.glob(os.path.join(out, '*_*'))):
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row.get('Kernel_Name', '?').replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:60]
-            if not any(s in k for s in ('interpn', 'dice', 'warp')):
+            if not any(s in k for s in ('interpn', 'dice', 'warp', 'gather')):
                 continue
             a = acc[k][row['Counter_Name']]
             a[0] += float(row['Counter_Value']); a[1] += 1
