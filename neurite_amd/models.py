@@ -146,8 +146,26 @@ class _Conv(nn.Module):
         self._packed = None
         self._packed_version = None
 
+    def invalidate_packed(self):
+        """forget the MFMA-packed copy of the kernel.  The cache key below sees in-place writes through the Parameter
+        (`_version`), a new storage and a device move; writes through `.data` (EMA / weight averaging: `p.data.mul_()`)
+        bump no version, so the copy is also dropped on every `train()` / `eval()` switch, `set_weights`, `load_weights` and
+        `load_state_dict`, and it is never used while the model is in training mode."""
+        self._packed = None
+        self._packed_version = None
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _packed_weights(self):
         ver = (self.kernel._version, self.kernel.data_ptr(), self.kernel.device)
+        if self.training:
+            self._packed = None                       # training loops may write through .data between steps
         if self._packed is None or self._packed_version != ver:
             lib = _lib.lib()
             dev = self.kernel.device
@@ -682,6 +700,9 @@ class ConvNet(nn.Module):
                     raise ValueError('Layer weight shape %s not compatible with provided weight shape %s (%s)'
                                      % (tuple(t.shape), tuple(w.shape), name))
                 t.copy_(torch.from_numpy(w))
+        for m in self.layers_by_name.values():
+            if isinstance(m, _Conv):
+                m.invalidate_packed()
 
     def _weights_by_layer(self):
         """[(layer name, [(variable name, tensor, conv ndims or None), ...])] in Keras layer order"""
@@ -801,6 +822,90 @@ class ConvNet(nn.Module):
         if name in self.layer_names:
             return self.ops[self.layer_names.index(name)]
         raise ValueError('No such layer: %s' % name)
+
+    def keras_graph(self):
+        """
+        The network as the list of Keras layers the reference builders create (neurite/tf/models.py:1309-1617, :378-436):
+        per layer `name`, Keras `class`, constructor `config`, producer names of its `inputs`, and `output_shape`
+        (batch = None).  Fused ops are expanded (`up_N` + `merge_N` for the in-loader up-sampling/concatenation,
+        `likelihood` + `prediction` for the fused head); layers no output depends on are left out, as in a Keras Model.
+        tests/test_unet_graph.py compares this with the graphs recorded from the reference's own builders.
+        """
+        nd = self.ndims
+        layers = []
+
+        def shape_of(op):
+            sp, c = op['shape']
+            return [None] + [int(v) for v in sp[3 - nd:]] + [int(c)]
+
+        def emit(name, cls, config, inputs, out_shape):
+            layers.append({'name': name, 'class': cls, 'config': config, 'inputs': list(inputs), 'output_shape': out_shape})
+
+        ndrop = 0
+        for op in self.ops:
+            kind, name = op['kind'], op['name']
+            if kind == 'input':
+                emit(name, 'InputLayer', {}, [], shape_of(op))
+            elif kind == 'input_concat':
+                emit(name, 'Concatenate', {'axis': -1}, op['src'], shape_of(op))
+            elif kind in ('conv', 'likelihood'):
+                m = self.layers_by_name[name]
+                cfg = {'filters': m.cout, 'kernel_size': [int(k) for k in m.ksize3[3 - nd:]], 'strides': [1] * nd,
+                       'padding': getattr(m, 'keras_padding', m.padding), 'dilation_rate': [m.dilation] * nd,
+                       'activation': m.activation if m.activation is not None else 'linear', 'use_bias': True}
+                emit(name, 'Conv%dD' % nd, cfg, [op['merge'] if op.get('lo') else op['src']], shape_of(op))
+            elif kind == 'dropout':
+                sp, c = op['shape']
+                auto = 'dropout' if ndrop == 0 else 'dropout_%d' % ndrop
+                ndrop += 1
+                op_name = auto                                        # the reference passes no name: Keras numbers them
+                emit(op_name, 'Dropout', {'rate': float(op['rate']), 'noise_shape': [None] + [1] * nd + [int(c)]},
+                     [op['src']], shape_of(op))
+                layers[-1]['alias'] = name
+            elif kind == 'maxpool':
+                pool = [int(p) for p in op['pool'][3 - nd:]]
+                emit(name, 'MaxPooling%dD' % nd, {'pool_size': pool, 'strides': pool, 'padding': op['padding']}, [op['src']],
+                     shape_of(op))
+            elif kind == 'upsample':
+                emit(name, 'UpSampling%dD' % nd, {'size': [int(p) for p in op['up'][3 - nd:]]}, [op['src']], shape_of(op))
+            elif kind == 'merge':
+                if not op.get('up_materialised', True):
+                    sp, c = self._builder_state['shapes'][op['up_name']]
+                    emit(op['up_name'], 'UpSampling%dD' % nd, {'size': [int(p) for p in op['up'][3 - nd:]]}, [op['lo']],
+                         [None] + [int(v) for v in sp[3 - nd:]] + [int(c)])
+                emit(name, 'Concatenate', {'axis': nd + 1}, [op['skip'], op.get('up_name', op['lo'])], shape_of(op))
+            elif kind == 'add':
+                emit(name, 'Add', {}, [op['a'], op['b']], shape_of(op))
+            elif kind == 'multiply':
+                emit(name, 'Multiply', {}, [op['a'], op['b']], shape_of(op))
+            elif kind == 'activation':
+                emit(name, 'Activation', {'activation': op['activation']}, [op['src']], shape_of(op))
+            elif kind == 'bn':
+                m = self.layers_by_name[name]
+                emit(name, 'BatchNormalization', {'axis': int(op['axis']), 'momentum': float(m.momentum),
+                                                  'epsilon': float(m.epsilon)}, [op['src']], shape_of(op))
+            elif kind == 'prediction':
+                if op['activation'] == 'softmax':
+                    emit(name, 'Lambda', {'function': [['softmax', op.get('axis', nd + 1)]]}, [op['src']], shape_of(op))
+                else:
+                    emit(name, 'Activation', {'activation': op['activation']}, [op['src']], shape_of(op))
+            else:
+                raise RuntimeError('unknown op ' + kind)
+        # dropouts are referred to by their builder names inside the op list
+        alias = {l['alias']: l['name'] for l in layers if 'alias' in l}
+        for l in layers:
+            l['inputs'] = [alias.get(i, i) for i in l['inputs']]
+            l.pop('alias', None)
+        by_name = {l['name']: l for l in layers}
+        out = alias.get(self.output_name, self.output_name)
+        seen, stack = set(), [out]
+        while stack:
+            n = stack.pop()
+            if n not in seen:
+                seen.add(n)
+                stack.extend(by_name[n]['inputs'])
+        inputs = [op['name'] for op in sorted((o for o in self.ops if o['kind'] == 'input'), key=lambda o: o['index'])]
+        return {'name': self.name, 'inputs': inputs, 'outputs': [out], 'layers': [l for l in layers if l['name'] in seen]}
 
     def _affine(self, bn):
         scale = bn.gamma.detach() / torch.sqrt(bn.moving_variance + bn.epsilon)
@@ -991,10 +1096,12 @@ def _encoder(bld, nb_features, input_shape, nb_levels, conv_size, prefix, feat_m
                 nb_lvl_feats = layer_nb_feats[lfidx]
                 lfidx += 1
             name = '%s_conv_downarm_%d_%d' % (prefix, level, conv)
-            act = activation if (conv < (nb_conv_per_level - 1) or (not use_residuals)) else None   # :1384-1388
+            # with residuals the last conv of a level is built WITHOUT conv_kwargs: no activation and dilation_rate 1  :1384-1388
+            tail = use_residuals and conv == nb_conv_per_level - 1
+            act, cdil = (None, 1) if tail else (activation, dil)
             sp, cin = bld.shapes[last]
-            bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, dil, padding, act)
-            last = bld.add({'kind': 'conv', 'name': name, 'src': last}, (_conv_out(sp, k3, dil, padding), int(nb_lvl_feats)))
+            bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, cdil, padding, act)
+            last = bld.add({'kind': 'conv', 'name': name, 'src': last}, (_conv_out(sp, k3, cdil, padding), int(nb_lvl_feats)))
             if conv_dropout > 0:                                                 # :1390-1399
                 name = '%s_dropout_downarm_%d_%d' % (prefix, level, conv)
                 last = bld.add({'kind': 'dropout', 'name': name, 'src': last, 'rate': conv_dropout}, bld.shapes[last])
@@ -1008,9 +1115,8 @@ def _encoder(bld, nb_features, input_shape, nb_levels, conv_size, prefix, feat_m
                 bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, dil, padding, activation)
                 add_layer = bld.add({'kind': 'conv', 'name': name, 'src': lvl_first},
                                     (_conv_out(sp, k3, dil, padding), int(nb_lvl_feats)))
-                if conv_dropout > 0:
-                    name = '%s_dropout_down_merge_%d_%d' % (prefix, level, nb_conv_per_level - 1)
-                    bld.add({'kind': 'dropout', 'name': name, 'src': add_layer, 'rate': conv_dropout}, bld.shapes[add_layer])
+                # :1412-1423 builds a Dropout on this tensor too, but its output is overwritten by the KL.add below before
+                # anything reads it (add_layer was bound before the dropout): the layer is not part of the Keras model
             name = '%s_res_down_merge_%d' % (prefix, level)
             last = bld.add({'kind': 'add', 'name': name, 'a': add_layer, 'b': convarm}, bld.shapes[convarm])
             name = '%s_res_down_merge_act_%d' % (prefix, level)
@@ -1074,21 +1180,22 @@ def _decoder(bld, nb_features, nb_levels, conv_size, nb_labels, prefix, feat_mul
             name = '%s_merge_%d' % (prefix, nb_levels + level)
             if not need_up_tensor:
                 bld.shapes[up_name] = (sp_up, c_lo)      # UpSampling3D happens inside the next conv's loader
-            fused = {'skip': conv_name, 'lo': lo, 'up': pool3}
-            last = bld.add({'kind': 'merge', 'name': name, 'skip': conv_name, 'lo': lo, 'up': pool3, 'fused': True},
-                           (sp_up, c_s + c_lo))
+            fused = {'skip': conv_name, 'lo': lo, 'up': pool3, 'name': name}
+            last = bld.add({'kind': 'merge', 'name': name, 'skip': conv_name, 'lo': lo, 'up': pool3, 'fused': True,
+                            'up_name': up_name, 'up_materialised': need_up_tensor}, (sp_up, c_s + c_lo))
         for conv in range(nb_conv_per_level):                                    # :1545-1555
             if layer_nb_feats is not None:
                 nb_lvl_feats = layer_nb_feats[lfidx]
                 lfidx += 1
             name = '%s_conv_uparm_%d_%d' % (prefix, nb_levels + level, conv)
-            act = activation if (conv < (nb_conv_per_level - 1) or (not use_residuals)) else None
+            tail = use_residuals and conv == nb_conv_per_level - 1                # :1552-1555, as in the encoder
+            act, cdil = (None, 1) if tail else (activation, dil)
             sp, cin = bld.shapes[last]
-            bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, dil, padding, act)
+            bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, cdil, padding, act)
             op = {'kind': 'conv', 'name': name, 'src': last}
             if conv == 0 and fused is not None:
-                op.update({'src': fused['skip'], 'lo': fused['lo'], 'up': fused['up']})
-            last = bld.add(op, (_conv_out(sp, k3, dil, padding), int(nb_lvl_feats)))
+                op.update({'src': fused['skip'], 'lo': fused['lo'], 'up': fused['up'], 'merge': fused['name']})
+            last = bld.add(op, (_conv_out(sp, k3, cdil, padding), int(nb_lvl_feats)))
             if conv_dropout > 0:
                 name = '%s_dropout_uparm_%d_%d' % (prefix, level, conv)
                 last = bld.add({'kind': 'dropout', 'name': name, 'src': last, 'rate': conv_dropout}, bld.shapes[last])
@@ -1101,6 +1208,9 @@ def _decoder(bld, nb_features, nb_levels, conv_size, nb_labels, prefix, feat_mul
                 bld.modules[name] = _Conv(name, cin, int(nb_lvl_feats), k3, dil, padding, activation)
                 add_layer = bld.add({'kind': 'conv', 'name': name, 'src': add_layer},
                                     (_conv_out(sp, k3, dil, padding), int(nb_lvl_feats)))
+                if conv_dropout > 0:                                             # :1579-1582: a second Dropout on the conv arm
+                    name = '%s_dropout_up_merge_%d_%d' % (prefix, level, nb_conv_per_level - 1)
+                    last = bld.add({'kind': 'dropout', 'name': name, 'src': last, 'rate': conv_dropout}, bld.shapes[last])
             name = '%s_res_up_merge_%d' % (prefix, level)
             last = bld.add({'kind': 'add', 'name': name, 'a': last, 'b': add_layer}, bld.shapes[add_layer])
             name = '%s_res_up_merge_act_%d' % (prefix, level)
@@ -1114,6 +1224,7 @@ def _decoder(bld, nb_features, nb_levels, conv_size, nb_labels, prefix, feat_mul
     name = '%s_likelihood' % prefix
     sp, cin = bld.shapes[last]
     bld.modules[name] = _Conv(name, cin, int(nb_labels), (1, 1, 1), 1, 'same', None)
+    bld.modules[name].keras_padding = 'valid'     # convL(nb_labels, 1, activation=None): Keras' default; identical at 1x1x1
     pred = '%s_prediction' % prefix
     fuse = final_pred_activation == 'softmax' and nb_labels <= 64
     last = bld.add({'kind': 'likelihood', 'name': name, 'src': last, 'fuse_softmax': fuse, 'pred_name': pred},
@@ -1149,7 +1260,8 @@ def _append_prior(bld, last, model_name, prefix, spatial, nb_labels, ndims, inpu
     if final_pred_activation == 'softmax':
         assert use_logp, 'cannot do softmax when adding prior via P()'
         print("using final_pred_activation %s for %s" % (final_pred_activation, model_name))
-        return bld.add({'kind': 'prediction', 'name': '%s_prediction' % prefix, 'src': post, 'activation': 'softmax'}, (sp, nb_labels))
+        return bld.add({'kind': 'prediction', 'name': '%s_prediction' % prefix, 'src': post, 'activation': 'softmax', 'axis': -1},
+                       (sp, nb_labels))
     return bld.add({'kind': 'prediction', 'name': '%s_prediction' % prefix, 'src': post, 'activation': 'linear'}, (sp, nb_labels))
 
 

@@ -52,8 +52,8 @@ def unet_forward(x, weights, nb_levels, nb_conv_per_level=1, pool=(2, 2, 2), pre
         dil = dilation_rate_mult ** level
         for c in range(nb_conv_per_level):
             name = '%s_conv_downarm_%d_%d' % (prefix, level, c)
-            act = activation if (c < nb_conv_per_level - 1 or not use_residuals) else None
-            last = conv(last, *weights[name], activation=act, dilation=dil)
+            tail = use_residuals and c == nb_conv_per_level - 1          # :1384-1388: built without conv_kwargs
+            last = conv(last, *weights[name], activation=None if tail else activation, dilation=1 if tail else dil)
             t[name] = last
         if use_residuals:
             add = first
@@ -73,8 +73,8 @@ def unet_forward(x, weights, nb_levels, nb_conv_per_level=1, pool=(2, 2, 2), pre
         last = np.concatenate([skip, last], -1)
         for c in range(nb_conv_per_level):
             name = '%s_conv_uparm_%d_%d' % (prefix, nb_levels + level, c)
-            act = activation if (c < nb_conv_per_level - 1 or not use_residuals) else None
-            last = conv(last, *weights[name], activation=act, dilation=dil)
+            tail = use_residuals and c == nb_conv_per_level - 1          # :1552-1555
+            last = conv(last, *weights[name], activation=None if tail else activation, dilation=1 if tail else dil)
             t[name] = last
         if use_residuals:
             add = up

@@ -409,7 +409,64 @@ def gen_augment():
     cases['ngk'] = np.asarray(n)
     save('augment_small', **cases)
 
+
+# builder name, positional arguments, keyword arguments: the cases of tests/golden/unet_graph.json
+UNET_GRAPH_CASES = [
+    ('cfg3', 'unet', [16, [160, 160, 160, 1], 3, 3, 32], dict(feat_mult=2)),
+    ('cfg3_2conv', 'unet', [16, [160, 160, 160, 1], 3, 3, 32], dict(feat_mult=2, nb_conv_per_level=2)),
+    ('res_dil', 'unet', [8, [32, 32, 32, 2], 3, 3, 4], dict(feat_mult=2, use_residuals=True, dilation_rate_mult=2,
+                                                          nb_conv_per_level=2)),
+    ('res_dil_1conv', 'unet', [8, [32, 32, 32, 2], 3, 3, 4], dict(feat_mult=2, use_residuals=True, dilation_rate_mult=2)),
+    ('res_same_feats', 'unet', [8, [16, 16, 16, 8], 2, 3, 3], dict(use_residuals=True, nb_conv_per_level=2)),
+    ('layer_nb_feats', 'unet', [4, [16, 16, 16, 1], 2, 3, 3],
+     dict(nb_conv_per_level=2, layer_nb_feats=[3, 5, 7, 9, 11, 13])),
+    ('list_of_lists', 'unet', [[[4, 6], [8], [10, 12, 14]], [24, 24, 24, 1], None, 3, 5], dict(feat_mult=None)),
+    ('bn_dropout_res', 'unet', [6, [16, 16, 16, 3], 3, 3, 4], dict(feat_mult=2, use_residuals=True, nb_conv_per_level=2,
+                                                                conv_dropout=0.25, batch_norm=-1)),
+    ('dropout_plain', 'unet', [6, [16, 16, 16, 3], 2, 3, 4], dict(conv_dropout=0.5)),
+    ('prior_logp', 'unet', [4, [16, 16, 16, 1], 2, 3, 5], dict(add_prior_layer=True)),
+    ('prior_p', 'unet', [4, [16, 16, 16, 1], 2, 3, 5], dict(add_prior_layer=True, use_logp=False,
+                                                           final_pred_activation='linear')),
+    ('multi_input', 'unet', [4, [[16, 16, 16, 1], [16, 16, 16, 2]], 2, 3, 3], dict()),
+    ('two_d_pool', 'unet', [4, [32, 54, 2], 3, [3, 5], 3], dict(pool_size=[2, 3], activation='relu',
+                                                               final_pred_activation='linear')),
+    ('one_d', 'unet', [4, [64, 1], 3, 3, 2], dict(final_pred_activation=None)),
+    ('valid_enc', 'conv_enc', [4, [30, 30, 30, 1], 2, 3], dict(padding='valid', name='enc')),
+    ('enc_default', 'conv_enc', [8, [16, 16, 16, 2], 3, 3], dict(name='enc', feat_mult=2)),
+    ('enc_res_dil', 'conv_enc', [8, [32, 32, 32, 2], 3, 3], dict(name='enc', feat_mult=2, use_residuals=True,
+                                                                dilation_rate_mult=2)),
+    ('dec_alone', 'conv_dec', [8, [4, 4, 4, 16], 3, 3, 5], dict(name='dec', feat_mult=2)),
+    ('dec_alone_res', 'conv_dec', [8, [4, 4, 4, 16], 3, 3, 5], dict(name='dec', feat_mult=2, use_residuals=True,
+                                                                   dilation_rate_mult=3)),
+    ('dilation_net', 'dilation_net', [8, [32, 32, 32, 1], 3, 3, 4], dict(dilation_rate_mult=2, feat_mult=2,
+                                                                         use_residuals=True, nb_conv_per_level=2)),
+]
+
+
+def gen_unet_graph():
+    """The layer graphs the reference's own builders construct (neurite/tf/models.py:45-246, 378-436, 1309-1617), recorded by
+    tests/golden/keras_record.py: per layer its name, Keras class, constructor arguments, input producers, output shape."""
+    import contextlib
+    import io
+    import json
+    import warnings
+    import keras_record
+    graphs = {}
+    for tag, builder, args, kwargs in UNET_GRAPH_CASES:
+        keras_record.reset()
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            warnings.simplefilter('ignore')
+            model = getattr(ne.models, builder)(*args, **kwargs)
+        graphs[tag] = {'builder': builder, 'args': args, 'kwargs': kwargs, 'graph': model.graph()}
+    path = os.path.join(HERE, 'unet_graph.json')
+    with open(path, 'w') as f:
+        json.dump(graphs, f, indent=1, sort_keys=True)
+        f.write('\n')
+    print('%-28s %7.1f KB  (%d graphs)' % ('unet_graph.json', os.path.getsize(path) / 1024, len(graphs)))
+
+
 if __name__ == '__main__':
+    gen_unet_graph()
     gen_mi()
     gen_filter()
     gen_interpn()

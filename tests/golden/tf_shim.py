@@ -644,6 +644,18 @@ def _populate(m):
             setattr(m, k, v)
     if n == 'tensorflow.keras.layers':
         m.Layer = Layer
+        # symbolic, shape-propagating recorders for the Keras layer constructors the network builders call
+        import keras_record
+        keras_record.populate_layers_module(m)
+    if n == 'tensorflow.keras.models':
+        import keras_record
+        m.Model = keras_record.Model
+    if n == 'tensorflow.keras':
+        import keras_record
+        m.Model = keras_record.Model
+    if n == 'tensorflow.keras.activations':
+        import keras_record
+        m.softmax = keras_record.activations_softmax
     if n == 'tensorflow.keras.losses':
         m.CategoricalCrossentropy = KerasCCE
 
@@ -658,7 +670,7 @@ def install():
     for name in ('tensorflow', 'tensorflow.math', 'tensorflow.debugging', 'tensorflow.errors',
                  'tensorflow.compat', 'tensorflow.compat.v1', 'tensorflow.dtypes', 'tensorflow.keras',
                  'tensorflow.keras.backend', 'tensorflow.keras.layers', 'tensorflow.keras.losses',
-                 'tensorflow.keras.models', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
+                 'tensorflow.keras.models', 'tensorflow.keras.activations', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
                  'tensorflow.python', 'tensorflow.python.keras', 'tensorflow.python.keras.utils',
                  'tensorflow.python.ops', 'tensorflow.nn', 'tensorflow.random', 'tensorflow.experimental', 'tensorflow.experimental.numpy', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
         mod = importlib.import_module(name)

@@ -10,7 +10,14 @@ import torch
 
 import neurite_amd as ne
 from neurite_amd import models as nm
+import contextlib
+import io
+import json
+import os
+import warnings
+
 from oracle import c_oracle as co
+from oracle import keras_graph_oracle as kgo
 from oracle import unet_oracle as uo
 
 pytestmark = pytest.mark.gpu
@@ -172,7 +179,7 @@ def test_unet_small_configs_vs_oracle(dev):
             ref = uo.unet_forward(xb, w3, kw['nb_levels'], kw.get('nb_conv_per_level', 1), pool=(1,) * (3 - nd) + (2,) * nd,
                                   bn_params=bns or None, final_pred_activation=kw.get('final_pred_activation', 'softmax'),
                                   **okw)
-            close(y[b].reshape(ref.shape), ref, tol=2e-5)
+            close(y[b].reshape(ref.shape), ref, tol=1e-5)
         if 'final_pred_activation' not in kw:
             np.testing.assert_allclose(y.sum(-1), 1.0, rtol=1e-5)
         # MFMA and direct kernels agree
@@ -215,4 +222,35 @@ def test_unet_cfg3_full_size(dev):
     out = model(G(x, dev), return_tensors=names)
     ref = uo.unet_forward(x[0], weights, 3, 1, return_all=True)
     for n in names:
-        close(N(out[n])[0], ref[n], tol=2e-5)
+        close(N(out[n])[0], ref[n], tol=1e-5)
+
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'unet_graph.json')) as _f:
+    REF_GRAPHS = json.load(_f)
+
+
+@pytest.mark.parametrize('tag', ['res_dil', 'res_dil_1conv', 'res_same_feats', 'layer_nb_feats', 'list_of_lists',
+                                 'bn_dropout_res', 'dropout_plain', 'prior_logp', 'prior_p', 'multi_input', 'two_d_pool',
+                                 'one_d', 'valid_enc', 'enc_default', 'enc_res_dil', 'dec_alone', 'dec_alone_res',
+                                 'dilation_net'])
+def test_model_vs_reference_recorded_graph(dev, tag):
+    """The HIP network against oracle/keras_graph_oracle.py evaluating the graph the REFERENCE'S builder constructs
+    (tests/golden/unet_graph.json, recorded from neurite/tf/models.py by tests/golden/make_golden.py): residual levels with
+    dilation (the tail conv of a level has dilation 1 and no activation, models.py:1384-1388), per-conv feature lists,
+    batch-norm, prior heads, several inputs, 1-D / 2-D nets with anisotropic pooling, 'valid' padding."""
+    case = REF_GRAPHS[tag]
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        warnings.simplefilter('ignore')
+        model = getattr(ne.models, case['builder'])(*case['args'], **case['kwargs']).to(dev)
+    rng = np.random.default_rng(sum(map(ord, tag)))
+    weights, bns = _randomise(model, rng)
+    nd = model.ndims
+    wk = {n: (k.reshape(k.shape[3 - nd:]), b) for n, (k, b) in weights.items()}          # Keras kernel shapes
+    xs = [rng.standard_normal((2,) + tuple(s)).astype(F) for s in model.input_shapes]
+    if tag.startswith('prior'):
+        xs[1] = np.log(np.abs(xs[1]) + 0.1).astype(F) if tag == 'prior_logp' else np.abs(xs[1])
+    y = N(model([G(x, dev) for x in xs] if len(xs) > 1 else G(xs[0], dev)))
+    for b in range(2):
+        ref = kgo.run(case['graph'], [x[b] for x in xs], wk, bns or None)
+        assert y[b].shape == ref.shape
+        close(y[b], ref, tol=1e-5)

@@ -561,3 +561,23 @@ def test_augment_golden_cpu():
         ks = ks if isinstance(ks, list) else [ks]
         for i, k in enumerate(ks):
             np.testing.assert_allclose(k.numpy(), g['gk%d__k%d' % (n, i)], rtol=2e-6, atol=1e-9)
+
+
+def test_packed_weight_cache_is_dropped_when_weights_may_have_changed():
+    """writes through `.data` bump no version counter; the MFMA-packed kernel copy must not survive a mode switch,
+    set_weights or load_state_dict (neurite_amd/models.py::_Conv.invalidate_packed)."""
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ne.models.unet(4, (8, 8, 8, 1), 2, 3, 2)
+    convs = [m for m in net.layers_by_name.values() if hasattr(m, '_packed')]
+    assert convs
+
+    def poison():
+        for m in convs:
+            m._packed, m._packed_version = 'stale', (m.kernel._version, m.kernel.data_ptr(), m.kernel.device)
+
+    for action in (lambda: net.train(), lambda: net.eval(), lambda: net.set_weights(net.get_weights()),
+                   lambda: net.load_state_dict(net.state_dict())):
+        poison()
+        action()
+        assert all(m._packed is None for m in convs)

@@ -1,0 +1,90 @@
+"""
+The layer graphs `neurite_amd.models` builds against the graphs the REFERENCE's own builders construct.
+
+tests/golden/unet_graph.json is produced by tests/golden/make_golden.py::gen_unet_graph: it runs neurite/tf/models.py
+(`unet` :88-246, `conv_enc` :1309-1442, `conv_dec` :1445-1617, `add_prior` :378-436, `dilation_net` :45-85) on recording
+stand-ins for the Keras layer constructors (tests/golden/keras_record.py) and stores, per layer: name, Keras class,
+constructor arguments (filters, kernel, dilation, activation, padding, pool / up-sampling size, dropout rate and noise
+shape, batch-norm axis), the producers of its inputs and the output shape.  CPU only; no kernels run.
+"""
+
+import contextlib
+import io
+import json
+import os
+import warnings
+
+import pytest
+
+from neurite_amd import models
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+with open(os.path.join(HERE, 'golden', 'unet_graph.json')) as f:
+    GRAPHS = json.load(f)
+
+
+def _canon(graph):
+    """Keras numbers unnamed Dropout layers by creation order (including ones that end up outside the model), so a
+    dropout is identified by the layer it follows instead."""
+    ren = {}
+    for l in graph['layers']:
+        if l['class'] == 'Dropout':
+            ren[l['name']] = 'dropout@' + l['inputs'][0]
+    # chains of dropouts: resolve iteratively
+    def r(n):
+        while n in ren and ren[n] != n:
+            m = ren[n]
+            if m.startswith('dropout@') and m[8:] in ren:
+                m = 'dropout@' + r(m[8:])
+                ren[n] = m
+            return m
+        return n
+    out = {}
+    for l in graph['layers']:
+        d = dict(l)
+        d['name'] = r(l['name'])
+        d['inputs'] = [r(i) for i in l['inputs']]
+        assert d['name'] not in out, 'duplicate layer ' + d['name']
+        out[d['name']] = d
+    return out, [r(n) for n in graph['inputs']], [r(n) for n in graph['outputs']], [r(l['name']) for l in graph['layers']]
+
+
+def _build(case):
+    kwargs = dict(case['kwargs'])
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        warnings.simplefilter('ignore')
+        return getattr(models, case['builder'])(*case['args'], **kwargs)
+
+
+@pytest.mark.parametrize('tag', sorted(GRAPHS))
+def test_graph_matches_reference_builder(tag):
+    case = GRAPHS[tag]
+    ref, ref_in, ref_out, ref_order = _canon(case['graph'])
+    net = _build(case)
+    got, got_in, got_out, got_order = _canon(net.keras_graph())
+    assert got_in == ref_in
+    assert got_out == ref_out
+    assert sorted(got) == sorted(ref), 'layer sets differ: only ours %s, only reference %s' % (
+        sorted(set(got) - set(ref)), sorted(set(ref) - set(got)))
+    for name in ref_order:
+        g, r = got[name], ref[name]
+        assert g['class'] == r['class'], name
+        assert g['inputs'] == r['inputs'], name
+        assert g['output_shape'] == r['output_shape'], name
+        assert g['config'] == r['config'], (name, g['config'], r['config'])
+    # weights are exchanged as ordered lists (Keras get_weights order = layer order): the weighted layers must come in the
+    # same order
+    weighted = ('Conv1D', 'Conv2D', 'Conv3D', 'BatchNormalization')
+    assert [n for n in got_order if got[n]['class'] in weighted] == [n for n in ref_order if ref[n]['class'] in weighted]
+
+
+def test_residual_tail_conv_has_no_dilation_and_no_activation():
+    """the case round 1 got wrong (neurite/tf/models.py:1384-1388, 1552-1555)"""
+    net = _build(GRAPHS['res_dil'])
+    g = {l['name']: l for l in net.keras_graph()['layers']}
+    assert g['unet_conv_downarm_1_0']['config']['dilation_rate'] == [2, 2, 2]
+    assert g['unet_conv_downarm_1_1']['config']['dilation_rate'] == [1, 1, 1]
+    assert g['unet_conv_downarm_1_1']['config']['activation'] == 'linear'
+    assert g['unet_conv_uparm_3_1']['config']['dilation_rate'] == [1, 1, 1]
+    assert g['unet_expand_down_merge_2']['config']['dilation_rate'] == [4, 4, 4]
