@@ -66,19 +66,24 @@ def parse():
     ap.add_argument('--unet', action='store_true', help='only run the unet forward benchmark (BASELINE config 3)')
     ap.add_argument('--no-unet', action='store_true', help='skip the unet forward measurement in the default run')
     ap.add_argument('--unfused', action='store_true', help='run the drop-in two-kernel pipeline instead of the fused kernel')
+    ap.add_argument('--graph', action='store_true',
+                    help="capture a step's compute launches (gather + Dice second stage + mean pair) in one hipGraph")
     return ap.parse_args()
 
 
 def cpu_baseline(mov, fix, trf, budget_s=10.0):
-    """C oracle (port of the reference algorithm) on all host cores, bounded sample of the workload."""
+    """C oracle (port of the reference algorithm, oracle/oracle.c) on all host cores over a bounded sample of the workload.
+    The output volume is allocated and touched ONCE before the clock starts: a fresh 524 MB buffer per repetition made
+    the round-1 figure a measure of first-touch page faults, not of the algorithm."""
     from oracle import c_oracle as co
     m, f, t = mov[0].cpu().numpy(), fix[0].cpu().numpy(), trf[0].cpu().numpy()
     cores = os.cpu_count() or 1
     co.set_num_threads(cores)
     V = int(np.prod(m.shape[:-1]))
+    warped = np.zeros(t.shape[:-1] + (m.shape[-1],), np.float32)        # pre-touched
 
     def once():
-        w = co.interpn(m, t, 'linear', None, loc_mode=1)
+        w = co.interpn(m, t, 'linear', None, loc_mode=1, out=warped)
         sums, _ = co.dice_sums(f[None], w[None])
         return co.dice_from_sums(sums)
 
@@ -92,7 +97,53 @@ def cpu_baseline(mov, fix, trf, budget_s=10.0):
     dt = (time.perf_counter() - t0) / reps
     return {'value': round(V / dt / 1e6, 3), 'unit': 'Mvoxels/s', 'cores': co.num_threads(), 'kind': 'port',
             'sample': '%d x (SpatialTransformer linear + Dice on one %s x %d-label volume of the bench batch), '
-                      'C oracle with OpenMP' % (reps, 'x'.join(str(s) for s in m.shape[:-1]), m.shape[-1])}, d
+                      'C oracle with OpenMP, output buffer pre-touched' % (reps, 'x'.join(str(s) for s in m.shape[:-1]),
+                                                                          m.shape[-1])}, d
+
+
+def cpu_cfg1(budget_s=4.0):
+    """BASELINE config 1 -- "interpn linear warp of one 32^3 fp32 volume on CPU (reference path)" -- with the inputs of
+    SURVEY.md 8(d): the op-for-op NumPy restatement of neurite/tf/utils/utils.py:73-220 on ONE thread, a torch-CPU
+    vectorised form on all host cores, and the C/OpenMP port.  TensorFlow is not installed, so "reference path" means
+    these restatements (all three are pinned to the fixture the reference's own source produced, tests/test_oracle.py)."""
+    from oracle import c_oracle as co
+    from oracle import np_oracle as npo
+    from oracle import torch_cpu as tco
+    rng = np.random.default_rng(0)
+    vol = rng.standard_normal((32, 32, 32)).astype(np.float32)
+    ijk = np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing='ij'), -1).astype(np.float32)
+    loc = (ijk + rng.normal(0, 3, (32, 32, 32, 3)).astype(np.float32)).astype(np.float32)
+    V = 32 ** 3
+    cores = os.cpu_count() or 1
+
+    def rate(fn):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s / 3 or n >= 2000:
+                return round(V * n / dt / 1e6, 3), n
+
+    ref = npo.interpn(vol, loc)
+    vt, lt = torch.from_numpy(vol), torch.from_numpy(loc)
+    old = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        same_t = bool(np.array_equal(tco.interpn_linear(vt, lt).numpy(), ref))
+        r_t, n_t = rate(lambda: tco.interpn_linear(vt, lt))
+    finally:
+        torch.set_num_threads(old)
+    r_np, n_np = rate(lambda: npo.interpn(vol, loc))
+    co.set_num_threads(cores)
+    out = np.zeros((32, 32, 32, 1), np.float32)
+    same_c = bool(np.array_equal(co.interpn(vol[..., None], loc, out=out)[..., 0], ref))
+    r_c, n_c = rate(lambda: co.interpn(vol[..., None], loc, out=out))
+    return {'workload': 'BASELINE config 1: interpn linear, one 32^3 fp32 volume, loc = grid + N(0, 3), seed 0', 'unit': 'Mvoxels/s',
+            'numpy_1thread': {'value': r_np, 'cores': 1, 'reps': n_np},
+            'torch_cpu_allcores': {'value': r_t, 'cores': cores, 'reps': n_t, 'bit_identical_to_numpy': same_t},
+            'c_openmp': {'value': r_c, 'cores': co.num_threads(), 'reps': n_c, 'bit_identical_to_numpy': same_c}}
 
 
 def sweep(args, dev, mov, fix, trf):
@@ -420,6 +471,71 @@ def unet_train_bench(dev, size=160, labels=32, reps=3):
     return {'what': 'BASELINE config 3 unet, forward + backward + SGD, batch 1', 'ms': round(seg_ms, 3)}
 
 
+def timed(step, steps, warmup, dist=None, dev=None):
+    """
+    The timed region of the bench contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier and a
+    device synchronize on both sides; the wall time is the MAX over ranks.  `step(events)` enqueues one pass and returns a
+    PendingMean (neurite_amd.distributed): the all-reduce of step k runs on RCCL's stream while step k + 1's kernels run
+    on the compute stream; a step's global mean is collected (a stream-level wait, no host sync) after the next step has
+    been enqueued, and every mean is complete before the closing synchronize, so all K steps' work lies inside the region.
+    dev = None runs the same loop without a device (the gloo tests of this logic, tests/test_distributed_cpu.py).
+    Returns dict(elapsed = max over ranks [s], per_rank_s, ranks = size of the process group as the collective sees it,
+    k0_ms / k1_ms = mean event intervals of a step's two kernel slots (NaN without a device), mean = last global mean).
+    """
+    on_gpu = dev is not None
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    pending, m = None, None
+    for _ in range(warmup):
+        nxt = step(None)
+        if pending is not None:
+            pending.result()
+        pending = nxt
+    if pending is not None:
+        m = pending.result()
+    pending = None
+    sync()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)] if on_gpu else [None] * steps
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        nxt = step(evs[k])
+        if pending is not None:
+            m = pending.result()
+        pending = nxt
+    if pending is not None:
+        m = pending.result()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    per_rank, ranks = [elapsed], 1
+    if dist is not None:
+        world = dist.get_world_size()
+        kw = {'device': dev} if on_gpu else {}
+        mine = torch.tensor([elapsed], dtype=torch.float64, **kw)
+        allt = [torch.zeros(1, dtype=torch.float64, **kw) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank = [float(t[0]) for t in allt]
+        ones = torch.ones(1, dtype=torch.float32, **kw)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)         # how many ranks the collective really spans
+        ranks = int(round(float(ones[0])))
+        elapsed = max(per_rank)
+    if on_gpu:
+        k0 = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+        k1 = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    else:
+        k0 = k1 = float('nan')
+    return {'elapsed': elapsed, 'per_rank_s': per_rank, 'ranks': ranks, 'k0_ms': k0, 'k1_ms': k1,
+            'mean': None if m is None else float(m)}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -469,68 +585,69 @@ def main():
     # abort the pipeline (see tests/test_gpu_dice_cce.py); min/max are still computed by the kernel
     dice = ne.metrics.Dice(check_input_limits=False)
 
-    def step_unfused(events=None):
-        if events is not None:
-            events[0].record()
-        warped = st([mov, trf])
-        if events is not None:
-            events[1].record()
-        d = dice.dice(fix, warped)                      # [B, L]
-        if events is not None:
-            events[2].record()
-        return nd.all_reduce_mean_dice(d, async_op=True)    # one all-reduce of 2 floats when world > 1
+    def make_steps(mov, fix, trf):
+        def step_unfused(events=None):
+            if events is not None:
+                events[0].record()
+            warped = st([mov, trf])
+            if events is not None:
+                events[1].record()
+            d = dice.dice(fix, warped)                      # [B, L]
+            if events is not None:
+                events[2].record()
+            return nd.all_reduce_mean_dice(d, async_op=True)    # one all-reduce of 2 floats when world > 1
 
-    def step_fused(events=None):
-        if events is not None:
-            events[0].record()
-        d = ne.fused.warp_dice(mov, trf, fix, _tune=args.tune)      # [B, L]; `warped` never leaves registers
-        if events is not None:
-            events[1].record()
-            events[2].record()
-        return nd.all_reduce_mean_dice(d, async_op=True)
+        def step_fused(events=None):
+            if events is not None:
+                events[0].record()
+            d = ne.fused.warp_dice(mov, trf, fix, _tune=args.tune)      # [B, L]; `warped` never leaves registers
+            if events is not None:
+                events[1].record()
+                events[2].record()
+            return nd.all_reduce_mean_dice(d, async_op=True)
+        if not args.graph:
+            return step_fused, step_unfused
 
-    def timed(step, steps, warmup):
-        # the all-reduce of step k runs on RCCL's stream while step k + 1's kernels run on the compute stream: a step's
-        # global mean is collected (a stream-level wait, no host sync) after the next step has been enqueued; every mean
-        # is complete before the closing synchronize, so all K steps' work lies inside the timed region
-        pending = None
-        for _ in range(warmup):
-            nxt = step()
-            if pending is not None:
-                pending.result()
-            pending = nxt
-        m = pending.result() if pending is not None else None
-        pending = None
-        torch.cuda.synchronize()
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            nxt = step(evs[k])
-            if pending is not None:
-                m = pending.result()
-            pending = nxt
-        m = pending.result()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax[0])
-        k0 = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-        k1 = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
-        return elapsed, k0, k1, float(m)
+        # --graph: the launches of a step (gather / Dice kernels, the two-level second stage, the [sum, count] pair) are
+        # captured once and replayed as ONE hipGraph launch; the all-reduce stays outside the graph and works on a copy of
+        # the pair, because step k + 1's replay rewrites the captured buffer while step k's collective may still read it
+        def capture(compute):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    compute()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                pair = compute()
 
+            def step(events=None):
+                if events is not None:
+                    events[0].record()
+                g.replay()
+                if events is not None:
+                    events[1].record()
+                    events[2].record()
+                return nd.all_reduce_mean_pair(pair.clone(), async_op=True)
+            step._graph = g
+            return step
+        return (capture(lambda: nd.mean_dice_pair(ne.fused.warp_dice(mov, trf, fix, _tune=args.tune))),
+                capture(lambda: nd.mean_dice_pair(dice.dice(fix, st([mov, trf])))))
+
+    step_fused, step_unfused = make_steps(mov, fix, trf)
     fused = not args.unfused
-    elapsed, k0_ms, k1_ms, m = timed(step_fused if fused else step_unfused, args.steps, args.warmup)
+    r_main = timed(step_fused if fused else step_unfused, args.steps, args.warmup, dist, dev)
+    elapsed, k0_ms, k1_ms, m = r_main['elapsed'], r_main['k0_ms'], r_main['k1_ms'], r_main['mean']
     # the other form of the same pipeline, shorter run, for the record
-    o_elapsed, o_k0, o_k1, o_m = timed(step_unfused if fused else step_fused, max(5, args.steps // 5), 2)
     o_steps = max(5, args.steps // 5)
+    r_other = timed(step_unfused if fused else step_fused, o_steps, 2, dist, dev)
+    o_elapsed, o_k0, o_k1, o_m = r_other['elapsed'], r_other['k0_ms'], r_other['k1_ms'], r_other['mean']
+    # BASELINE config 2 proper is batch = 1: the same two pipelines on the first volume only (N = 1 runs)
+    r_b1 = None
+    if dist is None and B > 1:
+        f1, u1 = make_steps(mov[:1], fix[:1], trf[:1])
+        r_b1 = (timed(f1, o_steps, 2, None, dev), timed(u1, o_steps, 2, None, dev))
     unet_multi = None
     if dist is not None and not args.no_unet:
         # "3D UNet fwd ms at 1/2/4/8 GPU": every rank runs the config-3 forward on its own volume (data parallel inference);
@@ -551,46 +668,60 @@ def main():
     total_vox = world * B * V * args.steps
     value = total_vox / elapsed / 1e6
     interp_bytes = INTERPN_BYTES_PER_VOXEL(L, 3) * V * B
+    fused_bytes = (4 * L + 12 + 4 * L) * V * B
     if fused:
         # one kernel; it must move: moving row (4C) + loc (4D) + fixed row (4L) per voxel = 268 B at C=L=32
         kname = 'warp_dice_tile (fused SpatialTransformer gather + Dice reduction), one launch per step'
-        alg_bytes = (4 * L + 12 + 4 * L) * V * B
+        alg_bytes = fused_bytes
         kms = k0_ms
     else:
         kname = 'interpn (SpatialTransformer gather), one launch per step'
         alg_bytes = interp_bytes
         kms = k0_ms
     achieved = alg_bytes / (kms * 1e-3) / 1e9
-    traffic = None
+    # HBM-side bytes per launch are NOT measured in this process (PMC counters need a rocprofv3 pass of their own): the figure
+    # is the FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc pass recorded in profiles/hbm_traffic.json for this kernel and batch
+    traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(('fused' if fused else 'interpn') + '_bytes_per_launch_B%d' % B)
+            tj = json.load(open(tfile))
+            traffic = tj.get(('fused' if fused else 'interpn') + '_bytes_per_launch_B%d' % B)
+            if traffic is not None:
+                traffic_src = 'static: profiles/hbm_traffic.json (%s)' % tj.get('source', 'rocprofv3 --pmc pass')
         except Exception:   # noqa
             traffic = None
 
-    def other_block():
-        ov = world * B * V * o_steps / o_elapsed / 1e6
-        if fused:
-            return {'what': 'drop-in two-kernel pipeline (layers.SpatialTransformer -> metrics.Dice), %d steps' % o_steps,
-                    'value': round(ov, 2), 'unit': 'Mvoxels/s', 'ms_per_step': round(o_elapsed / o_steps * 1e3, 4),
-                    'interpn_ms': round(o_k0, 4), 'interpn_GBs': round(interp_bytes / (o_k0 * 1e-3) / 1e9, 1),
-                    'interpn_frac_of_peak': round(interp_bytes / (o_k0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    'dice_ms': round(o_k1, 4),
-                    'dice_GBs': round(DICE_BYTES_PER_VOXEL(L) * V * B / (o_k1 * 1e-3) / 1e9, 1),
-                    'mean_dice': round(o_m, 6)}
-        return {'what': 'fused warp+Dice kernel (neurite_amd.fused.warp_dice), %d steps' % o_steps,
-                'value': round(ov, 2), 'unit': 'Mvoxels/s', 'ms_per_step': round(o_elapsed / o_steps * 1e3, 4),
-                'kernel_ms': round(o_k0, 4), 'mean_dice': round(o_m, 6)}
+    # drop-in (reference-signature) pipeline figures, whichever form was the timed one
+    d_elapsed, d_steps, d_k0, d_k1, d_m = (o_elapsed, o_steps, o_k0, o_k1, o_m) if fused else (elapsed, args.steps, k0_ms, k1_ms, m)
+    f_elapsed, f_steps, f_k0, f_m = (elapsed, args.steps, k0_ms, m) if fused else (o_elapsed, o_steps, o_k0, o_m)
+    dropin = {'what': 'reference-signature pipeline: layers.SpatialTransformer(linear) -> metrics.Dice().dice, two kernels, '
+                      '`warped` written and re-read; %d steps' % d_steps,
+              'value': round(world * B * V * d_steps / d_elapsed / 1e6, 2), 'unit': 'Mvoxels/s',
+              'ms_per_step': round(d_elapsed / d_steps * 1e3, 4),
+              'interpn_ms': round(d_k0, 4), 'interpn_GBs': round(interp_bytes / (d_k0 * 1e-3) / 1e9, 1),
+              'interpn_frac_of_peak': round(interp_bytes / (d_k0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              'dice_ms': round(d_k1, 4), 'dice_GBs': round(DICE_BYTES_PER_VOXEL(L) * V * B / (d_k1 * 1e-3) / 1e9, 1),
+              'dice_frac_of_peak': round(DICE_BYTES_PER_VOXEL(L) * V * B / (d_k1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              'pipeline_524B_per_voxel_frac_of_peak': round(
+                  (interp_bytes + DICE_BYTES_PER_VOXEL(L) * V * B) / (d_elapsed / d_steps) / 1e9 / HBM_PEAK_GBS, 4),
+              'mean_dice': round(d_m, 6)}
+    fusedb = {'what': 'fused warp+Dice kernel (neurite_amd.fused.warp_dice; `warped` never written), %d steps' % f_steps,
+              'value': round(world * B * V * f_steps / f_elapsed / 1e6, 2), 'unit': 'Mvoxels/s',
+              'ms_per_step': round(f_elapsed / f_steps * 1e3, 4), 'kernel_ms': round(f_k0, 4),
+              'frac_of_peak_268B_per_voxel': round(fused_bytes / (f_k0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              'mean_dice': round(f_m, 6)}
 
     out = {
         'metric': 'Mvoxels/sec interpn+Dice on 160^3 x 32-label',
         'value': round(value, 2),
         'unit': 'Mvoxels/s',
         'n_gpus': world,
+        'rccl_ranks': r_main['ranks'],
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+        'ms_per_step_per_rank': [round(t / args.steps * 1e3, 4) for t in r_main['per_rank_s']],
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -603,6 +734,7 @@ def main():
                            'fused kernel (warped volume never written)' if fused else 'drop-in two-kernel pipeline'),
             'volumes_per_gpu': B, 'global_batch': B * world, 'size': S, 'labels': L,
             'pipeline': 'fused' if fused else 'unfused',
+            'step_launch': 'one hipGraph replay per step (--graph)' if args.graph else 'direct kernel launches',
             'parallelism': 'dp%d (batch-sharded, one RCCL all-reduce of 2 floats per step)' % world,
             'mean_dice': round(float(m), 6),
         },
@@ -614,11 +746,29 @@ def main():
             'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic,
+            'traffic_source': traffic_src,
             'algorithmic_bytes_per_launch': alg_bytes,
             'avg_launch_ms': round(kms, 4),
         },
-        'other_pipeline': other_block(),
+        # the reference-signature path (what `SpatialTransformer` + `Dice` callers reach) next to the fused headline
+        'roofline_dropin': {'kernel': 'interpn (SpatialTransformer gather, drop-in API), one launch per step', 'bound': 'hbm',
+                            'achieved': dropin['interpn_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': dropin['interpn_frac_of_peak'], 'avg_launch_ms': dropin['interpn_ms'],
+                            'algorithmic_bytes_per_launch': interp_bytes},
+        'dropin_pipeline': dropin,
+        'fused_pipeline': fusedb,
+        'other_pipeline': dropin if fused else fusedb,
     }
+    if r_b1 is not None:
+        rf, ru = r_b1
+        out['config2_batch1'] = {
+            'what': 'BASELINE config 2 as written: batch = 1, one %d^3 x %d-label volume per step, %d steps' % (S, L, o_steps),
+            'fused': {'ms': round(rf['elapsed'] / o_steps * 1e3, 4), 'Mvoxels_per_s': round(V * o_steps / rf['elapsed'] / 1e6, 1),
+                      'kernel_ms': round(rf['k0_ms'], 4),
+                      'frac': round((4 * L + 12 + 4 * L) * V / (rf['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            'dropin': {'ms': round(ru['elapsed'] / o_steps * 1e3, 4), 'Mvoxels_per_s': round(V * o_steps / ru['elapsed'] / 1e6, 1),
+                       'interpn_ms': round(ru['k0_ms'], 4), 'dice_ms': round(ru['k1_ms'], 4),
+                       'interpn_frac': round(INTERPN_BYTES_PER_VOXEL(L, 3) * V / (ru['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
     if fused:
         out['roofline']['unfused_api_accounting_524B_per_voxel_GBs'] = round(
             (INTERPN_BYTES_PER_VOXEL(L, 3) + DICE_BYTES_PER_VOXEL(L)) * V * B / (kms * 1e-3) / 1e9, 1)
@@ -630,6 +780,10 @@ def main():
         try:
             base, d_cpu = cpu_baseline(mov, fix, trf)
             out['cpu_baseline'] = base
+            try:
+                out['cpu_baseline']['cfg1_32cubed'] = cpu_cfg1()
+            except Exception as e:   # noqa
+                out['cpu_baseline']['cfg1_32cubed'] = {'error': str(e)}
             d_gpu = (ne.fused.warp_dice(mov[:1], trf[:1], fix[:1]) if fused
                      else dice.dice(fix[:1], st([mov[:1], trf[:1]]))).cpu().numpy()
             out['config']['max_abs_dice_diff_vs_oracle'] = float(np.abs(d_gpu - d_cpu).max())

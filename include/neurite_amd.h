@@ -139,6 +139,13 @@ int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_pred, long l
 int nrt_dice_from_sums_f32(const float *sums, int nlabels, int batch, float laplace_smoothing,
                            float *dice, void *stream);
 
+/* out2[0] = sum over the [batch, nlabels] entries of dice * weights, out2[1] = batch * nlabels: the pair a rank
+ * contributes to the single all-reduce behind Dice.mean_dice over a batch sharded across GPUs
+ * (neurite/tf/metrics.py:499-510, K.mean(dice * weights)).  weights: NULL, [nlabels], or with
+ * weights_per_batch != 0 [batch, nlabels].  One launch, fixed summation order. */
+int nrt_dice_mean_pair_f32(const float *dice, const float *weights, int nlabels, int batch,
+                           int weights_per_batch, float *out2, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused SpatialTransformer + soft Dice  (the BASELINE "interpn+Dice" pipeline in one pass)
  * replaces: SpatialTransformer (see nrt_interpn_f32, NRT_LOC_SHIFT) immediately followed by

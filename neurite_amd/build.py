@@ -49,9 +49,14 @@ def build(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     procs = []
+    # an object is reused when it is newer than its source, every header and this file (the flags)
+    common = max(os.path.getmtime(f) for f in glob.glob(os.path.join(CSRC, '*.h')) +
+                 [os.path.join(HERE, '..', 'include', 'neurite_amd.h'), os.path.abspath(__file__)])
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(common, os.path.getmtime(src)):
+            continue
         cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))

@@ -457,3 +457,37 @@ extern "C" int nrt_dice_from_sums_f32(const float *sums, int nlabels, int batch,
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
+
+// [sum over all (b, l) of dice * weights, number of entries] in one launch: what a rank contributes to the ONE all-reduce of
+// mean_dice (neurite/tf/metrics.py:499-510: K.mean(dice * weights) over the [B, L] entries; weights [1, L] or [B, L]).
+// One block, fixed order (thread i owns entries i, i + 256, ...; LDS tree) => bit-reproducible.
+namespace {
+__global__ __launch_bounds__(256) void dice_mean_pair(const float *__restrict__ dice, const float *__restrict__ weights,
+                                                      int n, int wmod, float *__restrict__ out2) {
+    __shared__ double sl[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float v = dice[i];
+        if (weights) v = nrt_mul(v, weights[i % wmod]);
+        acc += (double)v;
+    }
+    sl[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sl[threadIdx.x] += sl[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = (float)sl[0]; out2[1] = (float)n; }
+}
+}  // namespace
+
+extern "C" int nrt_dice_mean_pair_f32(const float *dice, const float *weights, int nlabels, int batch, int weights_per_batch,
+                                      float *out2, void *stream) {
+    if (!dice || !out2 || nlabels < 1 || batch < 1) return NRT_ERR_INVALID_ARG;
+    const long long n = (long long)nlabels * batch;
+    if (n >= (1ll << 31)) return NRT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dice_mean_pair, dim3(1), dim3(256), 0, nrt_stream(stream), dice, weights, (int)n,
+                       weights_per_batch ? (int)n : nlabels, out2);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

@@ -20,7 +20,7 @@ single-process tower replication; nothing of it is reproduced here.
 import torch
 import torch.distributed as dist
 
-__all__ = ['shard_range', 'PendingMean', 'all_reduce_mean_dice', 'all_reduce_mean', 'reduce_dice_sums', 'dice_from_sums',
+__all__ = ['shard_range', 'PendingMean', 'all_reduce_mean_dice', 'mean_dice_pair', 'all_reduce_mean_pair', 'all_reduce_mean', 'reduce_dice_sums', 'dice_from_sums',
            'all_reduce_gradients']
 
 
@@ -78,19 +78,62 @@ def all_reduce_mean_dice(local_dice, weights=None, group=None, async_op=False):
     of 2 floats.  With async_op a PendingMean is returned instead (also when there is nothing to reduce).
     """
     d = local_dice
-    if weights is not None:
-        d = d * torch.as_tensor(weights, dtype=d.dtype, device=d.device)
+    _, w = _world(group)
+    if d.device.type == 'cuda':
+        # one launch writes [sum of dice * weights, number of entries] (csrc/dice.hip: dice_mean_pair) -- the buffer the
+        # collective reduces; no sum / cat / scale launches around a ~1 ms step
+        buf = _mean_pair(d, weights)
+    else:
+        # host tensors (the gloo tests of the collective logic): plain torch arithmetic
+        if weights is not None:
+            d = d * torch.as_tensor(weights, dtype=d.dtype, device=d.device)
+        buf = torch.cat([d.sum(dtype=torch.float32).reshape(1), _count_tensor(d.numel(), d.device)])
+    return all_reduce_mean_pair(buf, group=group, async_op=async_op)
+
+
+def mean_dice_pair(local_dice, weights=None):
+    """[sum of dice * weights, number of entries] of this rank's [B_local, L] Dice values as a 2-float device buffer
+    (one kernel launch, csrc/dice.hip: dice_mean_pair) -- the operand of `all_reduce_mean_pair`.  Split from the
+    collective so that the compute part of a step can be captured in a hipGraph (bench.py --graph)."""
+    return _mean_pair(local_dice, weights)
+
+
+def all_reduce_mean_pair(buf, group=None, async_op=False):
+    """Global mean from a per-rank [sum, count] buffer: ONE all-reduce of 2 floats (in place), then sum / count."""
     _, w = _world(group)
     if w == 1 and not (dist.is_available() and dist.is_initialized()):
         if async_op:
-            return PendingMean(None, None, d.mean(dtype=torch.float32))
-        return d.mean(dtype=torch.float32)
-    # [sum, count] in one device buffer; the count constant is cached per (device, value): no H2D copy per step
-    buf = torch.cat([d.sum(dtype=torch.float32).reshape(1), _count_tensor(d.numel(), d.device)])
+            return PendingMean(buf, None)
+        return buf[0] / buf[1]
     if async_op:
         return PendingMean(buf, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf[0] / buf[1]
+
+
+def _mean_pair(dice, weights):
+    from . import _lib
+    lib = _lib.lib()
+    dev = _lib.require_device(dice)
+    if dice.dim() != 2:
+        raise ValueError('local_dice must be [B_local, L]')
+    B, L = dice.shape
+    d = dice.contiguous().to(torch.float32)
+    wt, per_batch = None, 0
+    if weights is not None:                       # metrics.py:499-506: weights [1, L] (or [L]) or [B, L]
+        wt = torch.as_tensor(weights, dtype=torch.float32, device=dev).contiguous()
+        if wt.numel() == L:
+            per_batch = 0
+        elif wt.numel() == B * L:
+            per_batch = 1
+        else:
+            raise ValueError('weights must be [L], [1, L] or [B, L]; got %s for dice %s' % (tuple(wt.shape), (B, L)))
+    buf = torch.empty(2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_dice_mean_pair_f32(_lib.ptr(d), _lib.ptr(wt), int(L), int(B), per_batch, _lib.ptr(buf),
+                                        _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_dice_mean_pair_f32')
+    return buf
 
 
 def all_reduce_mean(local_sum, local_count, group=None):

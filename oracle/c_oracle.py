@@ -40,10 +40,12 @@ def _ints(v):
     return (C.c_int * len(v))(*[int(x) for x in v])
 
 
-def interpn(vol, loc, interp_method='linear', fill_value=None, loc_mode=0, out_shape=None):
+def interpn(vol, loc, interp_method='linear', fill_value=None, loc_mode=0, out_shape=None, out=None):
     """
     loc_mode 0: loc [*S', D] absolute; 1: loc is a shift added to the identity grid;
     2: loc is a list of D coordinate tables (resize()).  vol [*S, C] float32 (C axis required).
+    out: optional pre-allocated (pre-touched) float32 result buffer -- timing loops pass one so that they measure the
+    algorithm and not the page faults of a fresh allocation.
     """
     vol = np.ascontiguousarray(vol, np.float32)
     if loc_mode == 2:
@@ -57,7 +59,10 @@ def interpn(vol, loc, interp_method='linear', fill_value=None, loc_mode=0, out_s
         out_shape = list(locbuf.shape[:-1])
     assert vol.ndim == D + 1
     Cc = vol.shape[-1]
-    out = np.empty(list(out_shape) + [Cc], np.float32)
+    if out is None:
+        out = np.empty(list(out_shape) + [Cc], np.float32)
+    else:
+        assert out.dtype == np.float32 and out.flags.c_contiguous and list(out.shape) == list(out_shape) + [Cc]
     method = {'linear': 0, 'nearest': 1}[interp_method]
     rc = lib().orc_interpn_f32(_p(vol), C.c_int(D), _ints(vol.shape[:-1]), C.c_int(Cc), _p(locbuf),
                                C.c_int(loc_mode), _ints(out_shape), C.c_int(method),

@@ -96,3 +96,57 @@ def test_world1_is_identity():
     prm = torch.nn.Parameter(torch.zeros(3))
     prm.grad = torch.ones(3)
     assert nd.all_reduce_gradients([prm]) == 0 and torch.equal(prm.grad, torch.ones(3))
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import time
+        import bench
+        from neurite_amd import distributed as nd
+        calls = []
+
+        def step(events):
+            # stub of one bench step: this rank's "dice" is a constant [B_local, L] block; rank 3 is the straggler
+            calls.append(events)
+            if rank == 3:
+                time.sleep(0.02)
+            d = torch.full((4, 8), float(rank + 1))
+            return nd.all_reduce_mean_dice(d, async_op=True)
+
+        r = bench.timed(step, steps=5, warmup=2, dist=dist, dev=None)
+        q.put((rank, len(calls), r))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_bench_timed_loop_world4():
+    """bench.py's timed region (barrier + sync on both sides, EXACTLY K timed steps after W warm-up steps, the collective of
+    step k collected after step k + 1 is enqueued, MAX over ranks, rank count taken from a collective) on 4 gloo ranks"""
+    world = 4
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=200) for _ in procs])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, ncalls, r in res:
+        assert ncalls == 7                                   # 2 warm-up + 5 timed, no extra step anywhere
+        assert r['ranks'] == world                           # counted by an all-reduce of ones, not read from the environment
+        assert len(r['per_rank_s']) == world
+        assert r['elapsed'] == max(r['per_rank_s'])
+        assert r['elapsed'] >= 5 * 0.02                      # everyone waits for the straggler: the closing barrier is inside
+        assert abs(r['mean'] - 2.5) < 1e-6                   # global mean over ranks of (rank + 1)
+    assert len({r['elapsed'] for _, _, r in res}) == 1       # every rank reports the same (max) time
+    # the same loop without a process group (N = 1)
+    import bench
+    r = bench.timed(lambda ev: None, 3, 1)
+    assert r['ranks'] == 1 and r['mean'] is None and len(r['per_rank_s']) == 1

@@ -320,3 +320,26 @@ def test_mean_squared_error_prob(dev):
         ne.metrics.MeanSquaredErrorProb()(tg, pg, sample_weight=[1.0, 2.0])
     with pytest.raises(ValueError, match='Invalid Reduction'):
         ne.metrics.MeanSquaredErrorProb(reduction='mean')
+
+
+def test_mean_dice_pair_kernel(dev):
+    """[sum of dice * weights, count] in one launch (csrc/dice.hip: dice_mean_pair; neurite/tf/metrics.py:499-510): the
+    operand of the single all-reduce behind a batch-sharded mean_dice"""
+    from neurite_amd import distributed as nd
+    rng = np.random.default_rng(5)
+    for B, L in ((4, 32), (1, 7), (33, 40), (300, 5)):
+        d = rng.random((B, L)).astype(F)
+        for w in (None, rng.random(L).astype(F), rng.random((1, L)).astype(F), rng.random((B, L)).astype(F)):
+            pair = N(nd.mean_dice_pair(G(d, dev), None if w is None else G(w, dev)))
+            dw = d if w is None else d * w.reshape(-1, L)                 # float32 product, as the kernel forms it
+            want = dw.astype(np.float64).sum()
+            assert pair[1] == B * L
+            np.testing.assert_allclose(pair[0], want, rtol=1e-6)
+            got = float(nd.all_reduce_mean_dice(G(d, dev), None if w is None else w))
+            np.testing.assert_allclose(got, want / (B * L), rtol=1e-6)
+    # run-to-run bit-identical (fixed summation order)
+    d = G(rng.random((64, 32)).astype(F), dev)
+    a, b = N(nd.mean_dice_pair(d)), N(nd.mean_dice_pair(d))
+    assert bits_equal(a, b)
+    with pytest.raises(ValueError):
+        nd.mean_dice_pair(d, np.ones(5, F))
