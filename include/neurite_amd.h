@@ -92,6 +92,16 @@ int nrt_interpn_nearest_i32(const int32_t *vol, const float *loc, int32_t *out,
                             int batch, long long vol_batch_stride, long long loc_batch_stride,
                             int loc_mode, int has_fill, int32_t fill_value, void *stream);
 
+/* interpn for every other dtype / rank the reference accepts (neurite/tf/utils/utils.py:106-127, 137-213 are dtype- and
+ * rank-generic): float16, bfloat16 and float64 volumes in 1..6 dimensions, float32 and (nearest only) int32 volumes in
+ * 4..6 dimensions.  `dtype` is an nrt_dtype value (below).  loc is cast to the volume dtype and the arithmetic runs in that
+ * dtype, one rounding per operation, as TensorFlow evaluates it.  loc: float32 [batch, out_shape, ndim] (float64 when
+ * loc_is_f64, float64 volumes with NRT_LOC_ABSOLUTE only), NULL for NRT_LOC_LINSPACE.  vol / out are `dtype`. */
+int nrt_interpn_any(const void *vol, const void *loc, void *out, int dtype, int ndim, const int *vol_shape,
+                    const int *out_shape, int channels, int batch, long long vol_batch_stride,
+                    long long loc_batch_stride, int loc_mode, int loc_is_f64, int method, int has_fill,
+                    double fill_value, void *stream);
+
 /* out = addend + interpn_linear(vol, loc): the update of voxelmorph's compose() (curr + transform(nxt, curr)) and of
  * integrate_vec() (vec += transform(vec, vec); scaling and squaring) in one pass -- call sites
  * neurite/tf/models.py:802-804, 1131, 1149-1154 (VecInt / ComposeTransform next to SpatialTransformer).
@@ -169,7 +179,7 @@ int nrt_warp_dice_soft_f32(const float *moving, const float *loc, const float *f
  * Label-weighted categorical cross-entropy
  * replaces: neurite/tf/metrics.py:640-650 + tf.keras.losses.CategoricalCrossentropy
  * ------------------------------------------------------------------------------------------ */
-typedef enum { NRT_DT_F32 = 0, NRT_DT_BF16 = 1 } nrt_dtype;
+typedef enum { NRT_DT_F32 = 0, NRT_DT_BF16 = 1, NRT_DT_F16 = 2, NRT_DT_F64 = 3, NRT_DT_I32 = 4 } nrt_dtype;
 
 size_t nrt_wcce_workspace_bytes(long long nvox_total, int channels);
 

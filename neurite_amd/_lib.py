@@ -19,7 +19,7 @@ HEADER_PATH = os.path.join(_HERE, '..', 'include', 'neurite_amd.h')
 NRT_OK = 0
 LOC_ABSOLUTE, LOC_SHIFT, LOC_LINSPACE = 0, 1, 2
 INTERP_LINEAR, INTERP_NEAREST = 0, 1
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16, DT_F64, DT_I32 = 0, 1, 2, 3, 4
 
 _lib = None
 
@@ -34,6 +34,7 @@ _SIGNATURES = {
     'nrt_interpn_f32_ex': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _i, _i, _vp]),
     'nrt_interpn_add_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _ll, _i, _i, _f, _vp]),
     'nrt_interpn_nearest_i32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, C.c_int32, _vp]),
+    'nrt_interpn_any': (_i, [_vp, _vp, _vp, _i, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _i, C.c_double, _vp]),
     'nrt_dice_workspace_bytes': (_sz, [_ll, _i, _i]),
     'nrt_dice_soft_f32': (_i, [_vp, _vp, _ll, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_hard_prob_f32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -106,13 +106,13 @@ def _launch_interpn_bwd(vol, loc, grad_out, cfg, need_vol, need_loc):
 
 def _interp_op(vol, loc, out_spatial, loc_mode, method, fill_value, batched, single_transform=False,
                variant=0, tune=0):
-    """Forward launch, recorded for autograd when an input requires grad (linear float32 only)."""
+    """Forward launch, recorded for autograd when an input requires grad (linear float32, 1-3-D only)."""
     cfg = dict(out_spatial=[int(s) for s in out_spatial], loc_mode=loc_mode, method=method, fill_value=fill_value,
                batched=batched, single_transform=single_transform, variant=variant, tune=tune)
     needs = torch.is_grad_enabled() and (vol.requires_grad or (loc is not None and loc.requires_grad))
     if not needs:
         return _launch_interpn(vol, loc, **cfg)
-    if method == _lib.INTERP_LINEAR and vol.dtype == torch.float32:
+    if method == _lib.INTERP_LINEAR and vol.dtype == torch.float32 and len(cfg['out_spatial']) <= 3:
         return _InterpnFn.apply(vol, loc, cfg)
     return _NoBackward.apply(lambda: _launch_interpn(vol, loc, **cfg), vol, *([] if loc is None else [loc]))
 
@@ -134,8 +134,9 @@ def _launch_interpn(vol, loc, out_spatial, loc_mode, method, fill_value, batched
         S = list(vol.shape[:-1])
     Cc = vol.shape[-1]
     D = len(S)
-    if D < 1 or D > 3:
-        raise NotImplementedError('neurite_amd.interpn supports 1-, 2- and 3-D volumes, got %d-D' % D)
+    if D < 1 or D > _ANY_MAXD:
+        raise NotImplementedError('neurite_amd.interpn supports 1- to %d-D volumes, got %d-D (2^D corner rows per output; '
+                                  'the reference, neurite/tf/utils/utils.py:159, has no rank limit)' % (_ANY_MAXD, D))
     out_spatial = [int(s) for s in out_spatial]
     out_shape = ([B] if batched else []) + out_spatial + [Cc]
     out = torch.empty(out_shape, dtype=vol.dtype, device=dev)
@@ -150,7 +151,17 @@ def _launch_interpn(vol, loc, out_spatial, loc_mode, method, fill_value, batched
     has_fill = fill_value is not None
     st = _lib.stream_ptr(dev)
     with torch.cuda.device(dev):
-        if vol.dtype == torch.float32:
+        if vol.dtype in _ANY_DTYPES and (D > 3 or vol.dtype not in (torch.float32, torch.int32)):
+            # float16 / bfloat16 / float64 volumes, and ranks 4-6: the dtype- and rank-generic kernel (csrc/interpn_any.hip);
+            # arithmetic in the volume dtype, one rounding per op, as TensorFlow evaluates utils.py:137-213
+            if vol.dtype == torch.int32:
+                assert method == _lib.INTERP_NEAREST
+            loc64 = loc is not None and loc.dtype == torch.float64
+            assert not loc64 or (vol.dtype == torch.float64 and loc_mode == _lib.LOC_ABSOLUTE)
+            rc = lib.nrt_interpn_any(_lib.ptr(vol), _lib.ptr(loc), _lib.ptr(out), _ANY_DTYPES[vol.dtype], D, _lib.ints(S),
+                                     _lib.ints(out_spatial), Cc, B, vol_bs, loc_bs, loc_mode, int(loc64), method,
+                                     int(has_fill), float(fill_value) if has_fill else 0.0, st)
+        elif vol.dtype == torch.float32:
             rc = lib.nrt_interpn_f32_ex(_lib.ptr(vol), _lib.ptr(loc), _lib.ptr(out), D, _lib.ints(S),
                                         _lib.ints(out_spatial), Cc, B, vol_bs, loc_bs, loc_mode, method,
                                         int(has_fill), float(fill_value) if has_fill else 0.0,
@@ -166,14 +177,29 @@ def _launch_interpn(vol, loc, out_spatial, loc_mode, method, fill_value, batched
     return out
 
 
+_ANY_MAXD = 6
+_ANY_DTYPES = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16,
+               torch.float64: _lib.DT_F64, torch.int32: _lib.DT_I32}
+
+
+def _loc_for(vol, loc):
+    """`loc` as the kernels take it.  The reference casts loc to the volume's dtype when both are floating (utils.py:123-127)
+    and integer locations to float32 (:124-125).  The kernels read float32 locations and round them to the volume dtype
+    themselves (float16 / bfloat16: RNE, the same rounding as tf.cast; values that already are of the narrow type survive the
+    float32 detour unchanged); only a float64 volume reads float64 locations."""
+    if not loc.dtype.is_floating_point:
+        return loc.to(torch.float32)
+    if vol.dtype == torch.float64:
+        return loc.to(torch.float64)
+    if vol.dtype in (torch.float16, torch.bfloat16):
+        return loc.to(vol.dtype).to(torch.float32) if loc.dtype == torch.float64 else loc.to(torch.float32)
+    return loc.to(torch.float32)
+
+
 def _prepare_vol(vol, interp_method):
-    """dtype policy of the HIP path.  Returns (vol32, restore_dtype)."""
-    if vol.dtype == torch.float32:
+    """dtype policy of the HIP path.  Returns (vol as the kernels take it, restore_dtype)."""
+    if vol.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
         return vol, None
-    if vol.dtype in (torch.float16, torch.bfloat16, torch.float64):
-        raise NotImplementedError(
-            'neurite_amd.interpn computes in float32 like the reference does for float32 inputs; '
-            '%s volumes are not implemented (cast explicitly if that is what you want)' % vol.dtype)
     # integer volumes
     if interp_method == 'linear':
         # the reference multiplies float weights with the gathered values (utils.py:191): TF raises
@@ -210,9 +236,7 @@ def interpn(vol, loc, interp_method='linear', fill_value=None, *, _variant=0, _t
     _lib.require_device(vol, loc)
     if vol.dim() == nb_dims:                                                 # :119-120
         vol = vol.unsqueeze(-1)
-    # loc is cast to the volume's float dtype (:123-127); the HIP path is float32
-    if loc.dtype != torch.float32:
-        loc = loc.to(torch.float32)
+    loc = _loc_for(vol, loc)                                                 # :123-127
     vol32, restore = _prepare_vol(vol, interp_method)
     if vol32.dtype == torch.int32 and fill_value is not None and float(fill_value) != int(fill_value):
         raise ValueError('fill_value %r is not representable in the integer volume dtype' % (fill_value,))

@@ -153,6 +153,80 @@ def interpn(vol, loc, interp_method='linear', fill_value=None):
     return interp_vol
 
 
+
+# --------------------------------------------------------------------------------------
+# interpn in a narrow float type that NumPy does not have (bfloat16)
+# --------------------------------------------------------------------------------------
+
+def round_bf16(x):
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 (the value set TF's bfloat16 tensors hold)"""
+    x = np.ascontiguousarray(x, np.float32)
+    u = x.view(np.uint32)
+    nan = (u & np.uint32(0x7fffffff)) > np.uint32(0x7f800000)
+    r = (u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)
+    r = np.where(nan, (u & np.uint32(0xffff0000)) | np.uint32(0x00400000), r).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def round_f16(x):
+    return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def interpn_emulated(vol, loc, interp_method='linear', fill_value=None, rnd=round_bf16):
+    """
+    neurite/tf/utils/utils.py:73-220 for a volume of a narrow float type T, emulated on float32 arrays that only ever hold
+    values of T: `rnd` (float32 -> nearest T, as float32) is applied to the inputs (tf.cast of loc to the volume dtype,
+    :123-127) and after EVERY arithmetic op -- which is how TensorFlow evaluates half / bfloat16 element-wise ops (compute in
+    float, round the result; exact for +, -, * because 24 >= 2p + 2).  Same op sequence as `interpn` above; with
+    rnd = round_f16 it reproduces `interpn` on float16 arrays bit for bit and with rnd = identity the float32 path
+    (tests/test_oracle.py), which is what vouches for the bfloat16 use.
+    vol [*S, C] (values of T), loc [*S', D].
+    """
+    vol = rnd(np.asarray(vol, np.float32))
+    if isinstance(loc, (list, tuple)):
+        loc = np.stack(loc, -1)
+    loc = rnd(np.asarray(loc, np.float32))                                 # :126-127 cast to the volume dtype
+    nb_dims = loc.shape[-1]
+    assert vol.ndim == nb_dims + 1
+    f = np.float32
+    max_loc = [rnd(f(d - 1)) for d in vol.shape[:-1]]                     # python ints become tensors of dtype T inside clip
+    vol_reshape = vol.reshape(-1, vol.shape[-1])
+    if interp_method == 'linear':
+        loc0 = np.floor(loc)
+        clipped = [np.clip(loc[..., d], f(0), max_loc[d]) for d in range(nb_dims)]
+        loc0lst = [np.clip(loc0[..., d], f(0), max_loc[d]) for d in range(nb_dims)]
+        loc1 = [np.clip(rnd(loc0lst[d] + f(1)), f(0), max_loc[d]) for d in range(nb_dims)]
+        locs = [[np.clip(x.astype(np.int32), 0, vol.shape[d] - 1) for d, x in enumerate(loc0lst)],
+                [np.clip(x.astype(np.int32), 0, vol.shape[d] - 1) for d, x in enumerate(loc1)]]
+        diff_loc1 = [rnd(loc1[d] - clipped[d]) for d in range(nb_dims)]
+        diff_loc0 = [rnd(f(1) - d) for d in diff_loc1]
+        weights_loc = [diff_loc1, diff_loc0]
+        interp_vol = f(0)
+        for c in itertools.product([0, 1], repeat=nb_dims):
+            subs = [locs[c[d]][d] for d in range(nb_dims)]
+            idx = sub2ind2d(vol.shape[:-1], subs)
+            vol_val = vol_reshape[idx]
+            wt = weights_loc[c[0]][0]
+            for d in range(1, nb_dims):
+                wt = rnd(wt * weights_loc[c[d]][d])
+            interp_vol = rnd(interp_vol + rnd(wt[..., None] * vol_val))
+    else:
+        assert interp_method == 'nearest'
+        with np.errstate(invalid='ignore'):
+            roundloc = np.rint(loc).astype(np.int32)
+        roundloc = [np.clip(roundloc[..., d], 0, vol.shape[d] - 1) for d in range(nb_dims)]
+        interp_vol = vol_reshape[sub2ind2d(vol.shape[:-1], roundloc)]
+    if fill_value is not None:
+        fill = rnd(f(fill_value))
+        below = [loc[..., d] < 0 for d in range(nb_dims)]
+        above = [loc[..., d] > max_loc[d] for d in range(nb_dims)]
+        oob = np.any(np.stack(below + above, axis=-1), axis=-1, keepdims=True)
+        with np.errstate(invalid='ignore'):
+            interp_vol = rnd(interp_vol * np.logical_not(oob).astype(np.float32))
+            interp_vol = rnd(interp_vol + rnd(oob.astype(np.float32) * fill))
+    return interp_vol
+
+
 def interpn_f64(vol, loc, fill_value=None):
     """Independent float64 'truth' for the linear path (same clamping rules, exact weights)."""
     vol = np.asarray(vol, np.float64)

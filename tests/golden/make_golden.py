@@ -102,6 +102,54 @@ def gen_interpn():
     save('interpn_cfg1_32', vol=vol, loc=loc, out=out)
 
 
+
+def gen_interpn_dtypes():
+    """interpn on the volume dtypes / ranks beyond float32 1-3-D: float16 and float64 volumes (loc is cast to the volume
+    dtype and the arithmetic runs in it, utils.py:123-127), 4-D and 5-D volumes (2^D corners, :159)."""
+    rng = np.random.default_rng(4321)
+    cases = {}
+
+    def add(tag, vol, loc, method='linear', fill=None):
+        out = A(ne.utils.interpn(T(vol), T(loc), interp_method=method, fill_value=fill))
+        assert out.dtype == vol.dtype, (tag, out.dtype, vol.dtype)
+        cases[tag + '__vol'] = vol
+        cases[tag + '__loc'] = loc
+        cases[tag + '__method'] = np.array(method)
+        cases[tag + '__fill'] = np.array(np.nan if fill is None else fill, F)
+        cases[tag + '__hasfill'] = np.array(fill is not None)
+        cases[tag + '__out'] = out
+
+    S = (9, 7, 11)
+    base = rng.standard_normal(S + (3,))
+    loc = (ijk(S) + rng.normal(0, 3, S + (3,))).astype(F)
+    special = np.array([-3.5, -0.5, 0.0, 0.5, 1.5, 2.5, 6.0, 6.5, 10.0, 10.5, 1e4, -1e4], F)
+    gs = np.stack(np.meshgrid(special, special[:6], special, indexing='ij'), -1).astype(F)
+    for name, dt in (('f16', np.float16), ('f64', np.float64)):
+        vol = base.astype(dt)
+        for method in ('linear', 'nearest'):
+            for fill in (None, -2.5):
+                add('%s_d3c3_%s_%s' % (name, method, 'nofill' if fill is None else 'fill'), vol, loc, method, fill)
+            add('%s_d3c3_special_%s' % (name, method), vol, gs, method, 7.0)
+        add('%s_d3c3_locsame' % name, vol, loc.astype(dt), 'linear', None)          # loc already of the volume dtype
+        v2 = rng.standard_normal((13, 5, 4)).astype(dt)
+        add('%s_d2c4_linear' % name, v2, rng.uniform(-2, 15, (6, 8, 2)).astype(F), 'linear', 0.0)
+        v1 = rng.standard_normal((13, 4)).astype(dt)
+        add('%s_d1c4_linear' % name, v1, rng.uniform(-2, 15, (20, 1)).astype(F), 'linear', None)
+    add('f64_d3c3_loc64', base.astype(np.float64), loc.astype(np.float64) + 1e-9, 'linear', None)
+    # ranks 4 and 5 (float32 and one float16 / int32-nearest case)
+    v4 = rng.standard_normal((4, 5, 3, 6, 2)).astype(F)
+    l4 = rng.uniform(-1.5, 6.5, (3, 4, 2, 5, 4)).astype(F)
+    add('f32_d4c2_linear', v4, l4, 'linear', None)
+    add('f32_d4c2_linear_fill', v4, l4, 'linear', 1.25)
+    add('f32_d4c2_nearest', v4, l4, 'nearest', None)
+    add('f16_d4c2_linear', v4.astype(np.float16), l4, 'linear', None)
+    add('i32_d4c1_nearest', rng.integers(0, 9, (4, 5, 3, 6, 1)).astype(np.int32), l4, 'nearest', None)
+    v5 = rng.standard_normal((3, 2, 4, 3, 2, 2)).astype(F)
+    l5 = rng.uniform(-1, 4, (2, 3, 2, 2, 3, 5)).astype(F)
+    add('f32_d5c2_linear', v5, l5, 'linear', 0.0)
+    save('interpn_dtypes', **cases)
+
+
 def gen_resize():
     rng = np.random.default_rng(77)
     cases = {}
@@ -264,6 +312,51 @@ def gen_lc3d():
         cases[tag + '__strides'] = np.array(st)
         cases[tag + '__out'] = out
     save('lc3d_small', **cases)
+
+
+
+def gen_lc3d_impl():
+    """The reference's LocallyConnected3D LAYER (build + call, neurite/tf/layers.py:912-1102) in its three weight layouts:
+    implementation 1 [O, F, Cout] (also channels_first, whose patch flattening is channel-major, :1176-1186), 2 dense-masked
+    [in..., Cin, out..., Cout] (:986-1006, 1260-1308) and 3 sparse COO values in sorted (out_idx, in_idx) order (:1008-1028,
+    1311-1343), 'valid' and 'same' padding, strides, bias, activation."""
+    rng = np.random.default_rng(20260926)
+    cases = {}
+    specs = [
+        ('i1_cl', dict(implementation=1), (2, 5, 4, 6, 3), 4, (3, 2, 3), (1, 1, 2)),
+        ('i1_cf', dict(implementation=1, data_format='channels_first'), (2, 3, 5, 4, 6), 4, (3, 2, 3), (1, 1, 2)),
+        ('i2_valid', dict(implementation=2), (2, 5, 4, 6, 3), 4, (3, 2, 3), (1, 1, 2)),
+        ('i2_same', dict(implementation=2, padding='same'), (2, 5, 4, 6, 2), 3, (3, 3, 3), (1, 1, 1)),
+        ('i2_same_stride', dict(implementation=2, padding='same', activation='relu'), (1, 6, 5, 7, 2), 3, (3, 2, 3), (2, 1, 3)),
+        ('i2_cf_same', dict(implementation=2, padding='same', data_format='channels_first'), (2, 2, 4, 5, 3), 3, (3, 3, 2), (1, 2, 1)),
+        ('i3_valid', dict(implementation=3), (2, 5, 4, 6, 3), 4, (3, 2, 3), (1, 1, 2)),
+        ('i3_same', dict(implementation=3, padding='same', activation='elu'), (2, 5, 4, 6, 2), 3, (3, 3, 3), (1, 1, 1)),
+        ('i3_same_stride', dict(implementation=3, padding='same'), (1, 6, 5, 7, 2), 3, (2, 3, 3), (2, 1, 3)),
+        ('i3_cf_same', dict(implementation=3, padding='same', data_format='channels_first'), (2, 2, 4, 5, 3), 3, (3, 3, 2), (1, 2, 1)),
+    ]
+    for tag, kw, in_shape, filters, ks, st in specs:
+        layer = ne.layers.LocallyConnected3D(filters, ks, strides=st, **kw)
+        x = rng.standard_normal(in_shape).astype(F)
+        layer(T(x))                                              # builds the weights (zeros in the shim)
+        kshape = tuple(A(layer.kernel).shape)
+        fan = int(np.prod(ks)) * (in_shape[1] if kw.get('data_format') == 'channels_first' else in_shape[-1])
+        layer.kernel.a[...] = (rng.standard_normal(kshape) / np.sqrt(fan)).astype(F)
+        layer.bias.a[...] = rng.standard_normal(tuple(A(layer.bias).shape)).astype(F)
+        out = A(layer(T(x)))
+        cases[tag + '__x'] = x
+        cases[tag + '__kernel'] = A(layer.kernel).copy()
+        cases[tag + '__bias'] = A(layer.bias).copy()
+        cases[tag + '__ks'] = np.array(ks)
+        cases[tag + '__strides'] = np.array(st)
+        cases[tag + '__filters'] = np.array(filters)
+        cases[tag + '__implementation'] = np.array(kw['implementation'])
+        cases[tag + '__padding'] = np.array(kw.get('padding', 'valid'))
+        cases[tag + '__data_format'] = np.array(kw.get('data_format', 'channels_last'))
+        cases[tag + '__activation'] = np.array(kw.get('activation') or 'linear')
+        cases[tag + '__out'] = out
+        if kw['implementation'] == 3:
+            cases[tag + '__kernel_idxs'] = np.asarray(layer.kernel_idxs, np.int64)
+    save('lc3d_impl', **cases)
 
 
 def gen_filter():
@@ -470,9 +563,11 @@ if __name__ == '__main__':
     gen_mi()
     gen_filter()
     gen_interpn()
+    gen_interpn_dtypes()
     gen_resize()
     gen_index_helpers()
     gen_dice()
     gen_cce()
     gen_lc3d()
+    gen_lc3d_impl()
     gen_augment()

@@ -556,6 +556,113 @@ def nn_convolution(x, filters, padding='VALID', strides=None, dilations=None, **
     return Tensor(out[..., None])
 
 
+
+# ---- keras conv_utils (tensorflow.python.keras.utils.conv_utils), restated: shape bookkeeping of LocallyConnected3D ----
+def cu_normalize_tuple(value, n, name):
+    if isinstance(value, int):
+        return (value,) * n
+    value_tuple = tuple(value)
+    if len(value_tuple) != n:
+        raise ValueError('The `' + name + '` argument must be a tuple of ' + str(n) + ' integers. Received: ' + str(value))
+    for v in value_tuple:
+        int(v)
+    return value_tuple
+
+
+def cu_normalize_padding(value):
+    if isinstance(value, (list, tuple)):
+        return value
+    padding = value.lower()
+    if padding not in {'valid', 'same', 'causal'}:
+        raise ValueError('The `padding` argument must be a list/tuple or one of "valid", "same" (or "causal", only for '
+                         '`Conv1D). Received: ' + str(padding))
+    return padding
+
+
+def cu_normalize_data_format(value):
+    if value is None:
+        value = 'channels_last'
+    data_format = value.lower()
+    if data_format not in {'channels_first', 'channels_last'}:
+        raise ValueError('The `data_format` argument must be one of "channels_first", "channels_last". Received: ' + str(value))
+    return data_format
+
+
+def cu_conv_output_length(input_length, filter_size, padding, stride, dilation=1):
+    if input_length is None:
+        return None
+    assert padding in {'same', 'valid', 'full', 'causal'}
+    dilated = filter_size + (filter_size - 1) * (dilation - 1)
+    if padding in ('same', 'causal'):
+        output_length = input_length
+    elif padding == 'valid':
+        output_length = input_length - dilated + 1
+    else:
+        output_length = input_length + dilated - 1
+    return (output_length + stride - 1) // stride
+
+
+def cu_conv_connected_inputs(input_shape, kernel_shape, output_position, strides, padding):
+    ranges = []
+    for d in range(len(input_shape)):
+        left_shift = int(kernel_shape[d] / 2)
+        right_shift = kernel_shape[d] - left_shift
+        center = output_position[d] * strides[d]
+        if padding == 'valid':
+            center += left_shift
+        ranges.append(range(max(0, center - left_shift), min(input_shape[d], center + right_shift)))
+    return ranges
+
+
+def cu_conv_kernel_mask(input_shape, kernel_shape, strides, padding):
+    """keras conv_utils.conv_kernel_mask: boolean [*input_shape, *output_shape], True where the output position reads the
+    input position"""
+    import itertools
+    if isinstance(kernel_shape, int):
+        kernel_shape = (kernel_shape,) * len(input_shape)
+    if isinstance(strides, int):
+        strides = (strides,) * len(input_shape)
+    output_shape = tuple(0 if input_shape[d] == 0 else cu_conv_output_length(input_shape[d], kernel_shape[d], padding, strides[d])
+                         for d in range(len(input_shape)))
+    mask = np.zeros(tuple(input_shape) + output_shape, bool)
+    for output_position in itertools.product(*[range(d) for d in output_shape]):
+        ticks = cu_conv_connected_inputs(input_shape, kernel_shape, output_position, strides, padding)
+        for input_position in itertools.product(*ticks):
+            mask[input_position + output_position] = True
+    return mask
+
+
+def activations_get(identifier):
+    if identifier is None or identifier == 'linear':
+        return lambda x: x
+    if identifier == 'relu':
+        return lambda x: Tensor(np.maximum(A(x), 0).astype(A(x).dtype))
+    if identifier == 'elu':
+        return lambda x: Tensor(np.where(A(x) > 0, A(x), np.exp(np.minimum(A(x), 0)) - 1).astype(A(x).dtype))
+    if callable(identifier):
+        return identifier
+    raise ValueError('shim: activation %r' % (identifier,))
+
+
+def linalg_matmul(a, b, **kw):
+    """tf.linalg.matmul of 2-D float tensors; float64 accumulation, result in the input dtype"""
+    a, b = A(a), A(b)
+    return Tensor((a.astype(np.float64) @ b.astype(np.float64)).astype(a.dtype))
+
+
+def sparse_tensor_dense_mat_mul(a_indices, a_values, a_shape, b, adjoint_a=False, adjoint_b=False, **kw):
+    """gen_sparse_ops.sparse_tensor_dense_mat_mul: SparseTensor(a_indices, a_values, a_shape) @ b (adjoints applied first)"""
+    assert not adjoint_a
+    idx = np.asarray([tuple(i) for i in a_indices], np.int64).reshape(-1, 2)
+    vals = A(a_values).astype(np.float64)
+    dense = np.zeros(tuple(int(v) for v in a_shape), np.float64)
+    np.add.at(dense, (idx[:, 0], idx[:, 1]), vals)
+    bb = A(b).astype(np.float64)
+    if adjoint_b:
+        bb = bb.T
+    return Tensor((dense @ bb).astype(A(b).dtype))
+
+
 # ---- scripted randomness: tf.random.uniform returns minval + u * (maxval - minval) for the next u of RANDOM_SCRIPT -------
 # (float32 arithmetic as TensorFlow's random_uniform; integer dtypes: minval + floor(u * (maxval - minval)))
 RANDOM_SCRIPT = []
@@ -613,6 +720,7 @@ def _populate(m):
         m.divide_no_nan = divide_no_nan
         m.log = log
         m.exp = exp
+        m.reduce_prod = reduce_prod
     if n == 'tensorflow.debugging':
         m.assert_greater_equal = assert_greater_equal
         m.assert_less_equal = assert_less_equal
@@ -656,6 +764,21 @@ def _populate(m):
     if n == 'tensorflow.keras.activations':
         import keras_record
         m.softmax = keras_record.activations_softmax
+        m.get = activations_get
+        m.serialize = lambda a: getattr(a, '__name__', None)
+    if n in ('tensorflow.keras.initializers', 'tensorflow.keras.regularizers', 'tensorflow.keras.constraints'):
+        m.get = lambda identifier: identifier
+        m.serialize = lambda v: v
+    if n == 'tensorflow.python.keras.utils.conv_utils':
+        m.normalize_tuple = cu_normalize_tuple
+        m.normalize_padding = cu_normalize_padding
+        m.normalize_data_format = cu_normalize_data_format
+        m.conv_output_length = cu_conv_output_length
+        m.conv_kernel_mask = cu_conv_kernel_mask
+    if n == 'tensorflow.linalg':
+        m.matmul = linalg_matmul
+    if n == 'tensorflow.python.ops.gen_sparse_ops':
+        m.sparse_tensor_dense_mat_mul = sparse_tensor_dense_mat_mul
     if n == 'tensorflow.keras.losses':
         m.CategoricalCrossentropy = KerasCCE
 
@@ -670,7 +793,9 @@ def install():
     for name in ('tensorflow', 'tensorflow.math', 'tensorflow.debugging', 'tensorflow.errors',
                  'tensorflow.compat', 'tensorflow.compat.v1', 'tensorflow.dtypes', 'tensorflow.keras',
                  'tensorflow.keras.backend', 'tensorflow.keras.layers', 'tensorflow.keras.losses',
-                 'tensorflow.keras.models', 'tensorflow.keras.activations', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
+                 'tensorflow.keras.models', 'tensorflow.keras.activations', 'tensorflow.keras.initializers',
+                 'tensorflow.keras.regularizers', 'tensorflow.keras.constraints', 'tensorflow.linalg',
+                 'tensorflow.python.keras.utils.conv_utils', 'tensorflow.python.ops.gen_sparse_ops', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
                  'tensorflow.python', 'tensorflow.python.keras', 'tensorflow.python.keras.utils',
                  'tensorflow.python.ops', 'tensorflow.nn', 'tensorflow.random', 'tensorflow.experimental', 'tensorflow.experimental.numpy', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
         mod = importlib.import_module(name)

@@ -334,3 +334,90 @@ def test_resize_deformation_upsample_full_size(dev):
     for z, method in ((2, 'linear'), (0.5, 'linear'), ([1.5, 2, 0.75], 'nearest')):
         got = N(ne.layers.Resize(z, method)(G(y, dev)))[0]
         assert bits_equal(got, npo.resize(y[0], z, method)), (z, method)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# volume dtypes and ranks beyond float32 1-3-D (csrc/interpn_any.hip; neurite/tf/utils/utils.py:106-127, 137-213 are generic)
+# ----------------------------------------------------------------------------------------------------------------------
+
+_TORCH_DT = {np.dtype(np.float16): torch.float16, np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32,
+             np.dtype(np.int32): torch.int32}
+
+
+def test_interpn_dtypes_and_ranks_golden_bit_exact(dev):
+    """float16 / float64 volumes (arithmetic in the volume dtype, loc cast to it) and 4-D / 5-D volumes against the fixtures
+    the reference's own interpn produced"""
+    cases = golden_cases(load_golden('interpn_dtypes'))
+    assert len(cases) >= 25
+    for tag, c in cases.items():
+        fill = float(c['fill']) if bool(c['hasfill']) else None
+        out = ne.utils.interpn(G(c['vol'], dev), G(c['loc'], dev), str(c['method']), fill)
+        assert out.dtype == _TORCH_DT[c['vol'].dtype], tag
+        assert tuple(out.shape) == c['out'].shape, tag
+        assert np.array_equal(N(out), c['out'], equal_nan=True), tag
+
+
+def _bf(a):
+    return npo.round_bf16(np.asarray(a, F))
+
+
+def test_interpn_bfloat16_vs_emulated_oracle(dev):
+    """bfloat16 volumes: NumPy has no bfloat16, the oracle emulates it on float32 arrays with a rounding after every op
+    (oracle/np_oracle.py: interpn_emulated -- the same emulation with binary16 rounding reproduces the reference-generated
+    float16 fixtures, tests/test_oracle.py).  Bit-exact."""
+    rng = np.random.default_rng(91)
+    for S, Cc in (((9, 7, 11), 3), ((6, 5, 7), 32), ((13, 5), 4), ((17,), 2), ((3, 4, 3, 5), 2)):
+        D = len(S)
+        vol = _bf(rng.standard_normal(S + (Cc,)))
+        osh = (6, 5, 4, 3)[:D]
+        loc = rng.uniform(-2, max(S) + 1, osh + (D,)).astype(F)
+        for method in ('linear', 'nearest'):
+            for fill in (None, 0.3):
+                got = ne.utils.interpn(G(vol, dev).to(torch.bfloat16), G(loc, dev), method, fill)
+                assert got.dtype == torch.bfloat16
+                ref = npo.interpn_emulated(vol, loc, method, fill, rnd=npo.round_bf16)
+                assert np.array_equal(N(got.to(torch.float32)), ref, equal_nan=True), (S, Cc, method, fill)
+    # a one-hot label map warps exactly like its float32 original wherever the weights are bfloat16 numbers
+    lab = rng.integers(0, 8, (10, 9, 8))
+    oh = np.eye(8, dtype=F)[lab]
+    loc = (ijk((10, 9, 8)) + rng.integers(-2, 3, (10, 9, 8, 3)) * 0.5).astype(F)
+    a = N(ne.utils.interpn(G(oh, dev).to(torch.bfloat16), G(loc, dev)).to(torch.float32))
+    b = N(ne.utils.interpn(G(oh, dev), G(loc, dev)))
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.bfloat16, torch.float64])
+def test_spatial_transformer_and_resize_in_other_dtypes(dev, dt):
+    """SpatialTransformer (shift + identity grid formed in float32, then cast to the volume dtype by interpn) and Resize
+    (tf.linspace grid in float32) on float16 / bfloat16 / float64 volumes against the oracle's transform / resize"""
+    rng = np.random.default_rng(17)
+    S, Cc = (8, 9, 7), 5
+    vol32 = rng.standard_normal((2,) + S + (Cc,)).astype(F)
+    trf = rng.normal(0, 1.5, (2,) + S + (3,)).astype(F)
+    if dt == torch.bfloat16:
+        vol_np = _bf(vol32)
+        ref_st = np.stack([npo.interpn_emulated(vol_np[b], ijk(S) + trf[b], 'linear', None) for b in range(2)])
+        from oracle.np_oracle import tf_linspace
+        grid = np.stack(np.meshgrid(*[tf_linspace(0., s - 1., 2 * s) for s in S], indexing='ij'), -1).astype(F)
+        ref_rs = np.stack([npo.interpn_emulated(vol_np[b], grid, 'linear', None) for b in range(2)])
+        vt = G(vol_np, dev).to(dt)
+        cmp = lambda t: N(t.to(torch.float32))
+    else:
+        npdt = np.float16 if dt == torch.float16 else np.float64
+        vol_np = vol32.astype(npdt)
+        ref_st = npo.spatial_transformer(vol_np, trf)
+        ref_rs = npo.resize_layer(vol_np, 2)
+        vt = G(vol_np, dev)
+        cmp = N
+    out = ne.layers.SpatialTransformer()([vt, G(trf, dev)])
+    assert out.dtype == dt
+    assert np.array_equal(cmp(out), ref_st, equal_nan=True)
+    out = ne.layers.Resize(2)(vt)
+    assert out.dtype == dt and tuple(out.shape) == (2, 16, 18, 14, Cc)
+    assert np.array_equal(cmp(out), ref_rs, equal_nan=True)
+
+
+def test_interpn_rank_limit_is_stated(dev):
+    v = torch.zeros((2,) * 7 + (1,), device=dev)
+    with pytest.raises(NotImplementedError, match='1- to 6-D'):
+        ne.utils.interpn(v, torch.zeros(3, 7, device=dev))

@@ -59,6 +59,25 @@ prof)
       python "$ROOT/bench.py" --unfused --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/prof_bench_unfused.json" 2>> "$OUT/prof.log" )
   find "$OUT/prof" -name "*kernel_stats.csv" | head -3 | while read f; do echo "$f"; head -12 "$f"; done | tee -a "$OUT/session.log"
   ;;
+dist1)
+  # the multi-process code path on one GPU: process group of size 1 over RCCL, with and without hipGraph capture of the step
+  stage dist1
+  for extra in "" "--graph"; do
+    NRT_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 \
+        --master-port 29511 bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --no-unet $extra \
+        > "$OUT/bench_dist1${extra}.json" 2> "$OUT/bench_dist1${extra}.log"
+    echo "dist1 $extra rc=$?" | tee -a "$OUT/session.log"
+    python - "$OUT/bench_dist1${extra}.json" <<'PY' | tee -a "$OUT/session.log"
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print({k: j[k] for k in ('value', 'ms_per_step', 'rccl_ranks', 'ms_per_step_per_rank')}, j['config'].get('step_launch'), j['roofline']['avg_launch_ms'])
+except Exception as e:
+    print('no json', e)
+PY
+  done
+  timeout 600 python bench.py --graph --no-cpu-baseline --no-unet > "$OUT/bench_graph.json" 2> "$OUT/bench_graph.log"; echo "graph rc=$?" | tee -a "$OUT/session.log"
+  ;;
 pmcsweep)
   stage pmcsweep
   for c in FETCH_SIZE; do
