@@ -295,6 +295,14 @@ int nrt_lc3d_bwd_f(const void *x, const void *kernel, const void *y, const void 
                    void *grad_bias, float *grad_x, int dtype, int batch, const int *in_shape, int cin,
                    const int *ksize, const int *strides, int cout, int activation, void *stream);
 
+/* Zero-pad (crop == 0) a channels-last volume [batch, in_shape, row] into [batch, out_shape, row] with pad_before voxels
+ * in front of every axis, or (crop != 0) copy the interior of a padded volume back out -- `in` is then the padded
+ * [batch, out_shape, row] tensor and `out` the [batch, in_shape, row] one.  row_bytes = channels * itemsize (even).
+ * padding='same' of LocallyConnected3D implementations 2 / 3 (neurite/tf/layers.py:934-936, 1474-1482: the window is
+ * clipped at the border) is the 'valid' layer on the input padded by kernel_size // 2; the crop is its gradient. */
+int nrt_pad3d(const void *in, void *out, int batch, const int *in_shape, const int *pad_before, const int *out_shape,
+              int row_bytes, int crop, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Backward passes (what tf.GradientTape derives from the reference graphs; float32)
  *

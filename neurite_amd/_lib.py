@@ -62,6 +62,7 @@ _SIGNATURES = {
     'nrt_channel_axpby_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
     'nrt_lc3d_f': (_i, [_vp, _vp, _vp, _vp, _i, _i, _ip, _i, _ip, _ip, _i, _i, _i, _vp]),
     'nrt_lc3d_bwd_f': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ip, _i, _ip, _ip, _i, _i, _vp]),
+    'nrt_pad3d': (_i, [_vp, _vp, _i, _ip, _ip, _ip, _i, _i, _vp]),
     'nrt_conv1d_axis_f32': (_i, [_vp, _vp, _vp, _ll, _i, _ll, _i, _i, _i, _i, _i, _vp]),
     'nrt_minmax_workspace_bytes': (_sz, [_ll, _i]),
     'nrt_minmax_norm_f32': (_i, [_vp, _vp, _ll, _ll, _i, _vp, _sz, _vp]),

@@ -455,3 +455,61 @@ extern "C" int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, v
     if (dtype == NRT_DT_F32) return launch_any<float>(a, variant, st);
     return launch_any<unsigned short>(a, variant, st);
 }
+
+// ---- zero padding / cropping of a channels-last volume ('same' padding of implementations 2 / 3) --------------------
+// LocallyConnected3D with padding='same' (neurite/tf/layers.py:1474-1482: conv_connected_inputs clips the window at the
+// volume border) = the 'valid' layer on the input zero-padded by k//2 voxels in front: the taps that fall into the padding
+// multiply zeros.  One thread per 16-bit or 32-bit unit of a voxel row; rows outside the source box are written as zero.
+// crop != 0 runs the copy the other way round (gradient of the padding: the interior of the padded gradient).
+namespace {
+template <typename U>
+__global__ __launch_bounds__(256) void pad3d_rows(const U *__restrict__ in, U *__restrict__ out, int S0, int S1, int S2,
+                                                   int P0, int P1, int P2, int O0, int O1, int O2, int units, int crop,
+                                                   unsigned long long total) {
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x; e < total;
+         e += (unsigned long long)gridDim.x * 256u) {
+        unsigned long long r = e;
+        const int u = (int)(r % (unsigned)units); r /= (unsigned)units;
+        // the index space is the destination: the padded volume, or (crop) the un-padded one
+        const int D0 = crop ? S0 : O0, D1 = crop ? S1 : O1, D2 = crop ? S2 : O2;
+        const int z = (int)(r % (unsigned)D2); r /= (unsigned)D2;
+        const int y = (int)(r % (unsigned)D1); r /= (unsigned)D1;
+        const int x = (int)(r % (unsigned)D0); r /= (unsigned)D0;
+        const long long b = (long long)r;
+        if (crop) {
+            const long long src = (((b * O0 + (x + P0)) * O1 + (y + P1)) * O2 + (z + P2)) * units + u;
+            out[e] = in[src];
+        } else {
+            const int sx = x - P0, sy = y - P1, sz = z - P2;
+            const bool inside = sx >= 0 && sx < S0 && sy >= 0 && sy < S1 && sz >= 0 && sz < S2;
+            out[e] = inside ? in[(((b * S0 + sx) * S1 + sy) * S2 + sz) * units + u] : (U)0;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int nrt_pad3d(const void *in, void *out, int batch, const int *in_shape, const int *pad_before, const int *out_shape,
+                         int row_bytes, int crop, void *stream) {
+    if (!in || !out || !in_shape || !pad_before || !out_shape || batch < 1 || row_bytes < 2 || (row_bytes & 1))
+        return NRT_ERR_INVALID_ARG;
+    for (int d = 0; d < 3; ++d)
+        if (in_shape[d] < 1 || pad_before[d] < 0 || out_shape[d] < in_shape[d] + pad_before[d]) return NRT_ERR_INVALID_ARG;
+    const int *D = crop ? in_shape : out_shape;
+    const bool wide = (row_bytes % 4) == 0 && (((uintptr_t)in | (uintptr_t)out) & 3) == 0;
+    const int units = wide ? row_bytes / 4 : row_bytes / 2;
+    const unsigned long long total = (unsigned long long)batch * D[0] * D[1] * D[2] * units;
+    unsigned long long nb = (total + 255) / 256;
+    if (nb > (1ull << 20)) nb = 1ull << 20;
+    if (nb == 0) return NRT_OK;
+    hipStream_t st = nrt_stream(stream);
+    if (wide)
+        hipLaunchKernelGGL((pad3d_rows<unsigned>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned *)in, (unsigned *)out,
+                           in_shape[0], in_shape[1], in_shape[2], pad_before[0], pad_before[1], pad_before[2], out_shape[0],
+                           out_shape[1], out_shape[2], units, crop, total);
+    else
+        hipLaunchKernelGGL((pad3d_rows<unsigned short>), dim3((unsigned)nb), dim3(256), 0, st, (const unsigned short *)in,
+                           (unsigned short *)out, in_shape[0], in_shape[1], in_shape[2], pad_before[0], pad_before[1],
+                           pad_before[2], out_shape[0], out_shape[1], out_shape[2], units, crop, total);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

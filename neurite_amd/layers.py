@@ -621,6 +621,113 @@ def _normalize_tuple(value, n, name):
     return value_tuple
 
 
+def _conv_output_length(input_length, filter_size, padding, stride):
+    """keras conv_utils.conv_output_length for 'valid' / 'same' (used at neurite/tf/layers.py:963-968)"""
+    if input_length is None:
+        return None
+    n = input_length if padding == 'same' else input_length - filter_size + 1
+    return (n + stride - 1) // stride
+
+
+def _lc3d_plan(ins, cin, ksize, strides, padding, outs, cout, implementation, data_format):
+    """
+    Host-side bookkeeping of LocallyConnected3D, built once per layer: how the layer's own kernel layout maps onto the
+    streaming layout W1[o, (a, b, e, ci), co] of the HIP kernel, and the zero padding that turns 'same' into 'valid'.
+
+    The window of output position p along axis d covers the inputs [p * s - left, p * s - left + k) clipped to the volume,
+    left = k // 2 for 'same' and 0 for 'valid' (conv_connected_inputs, layers.py:1474-1482).
+    gather[o, f, co]: flat index into the layer's kernel array of the weight of W1[o, f, co] (None = the kernel already is
+    W1); mask: 0 where the tap lies outside the volume.  Implementation 3 ranks the connected (out_idx, in_idx) pairs in
+    sorted order (the order of `kernel_idxs`, :1012-1022).
+    """
+    T3 = [int(k) for k in ksize]
+    T = T3[0] * T3[1] * T3[2]
+    O = int(np.prod(outs))
+    F = T * cin
+    cf = data_format == 'channels_first'
+    left = [k // 2 if padding == 'same' else 0 for k in T3]
+    need = [(outs[d] - 1) * strides[d] + T3[d] for d in range(3)]
+    padded = [max(need[d], ins[d] + left[d]) for d in range(3)]
+    plan = {'O': O, 'F': F, 'pad_before': tuple(left), 'padded': tuple(padded) if padding == 'same' else None,
+            'gather': None, 'mask': None, 'nnz': None}
+    if implementation == 1 and not cf:
+        return plan
+    if O * F * cout >= (1 << 31):
+        raise NotImplementedError('LocallyConnected3D: the re-layout table of implementation %d (%s) would have %d entries; '
+                                  'use implementation 1 / channels_last for layers of this size' % (implementation, data_format,
+                                                                                                     O * F * cout))
+    o_r, o_c, o_z = np.meshgrid(*[np.arange(n) for n in outs], indexing='ij')
+    o_pos = np.stack([o_r.reshape(-1), o_c.reshape(-1), o_z.reshape(-1)], 1)               # [O, 3] row-major
+    t_a, t_b, t_e = np.meshgrid(*[np.arange(k) for k in T3], indexing='ij')
+    taps = np.stack([t_a.reshape(-1), t_b.reshape(-1), t_e.reshape(-1)], 1)                # [T, 3]
+    ip = o_pos[:, None, :] * np.asarray(strides)[None, None, :] + taps[None, :, :] - np.asarray(left)[None, None, :]   # [O, T, 3]
+    valid = np.all((ip >= 0) & (ip < np.asarray(ins)[None, None, :]), -1)                  # [O, T]
+    ipc = np.clip(ip, 0, np.asarray(ins)[None, None, :] - 1)
+    ipflat = (ipc[..., 0] * ins[1] + ipc[..., 1]) * ins[2] + ipc[..., 2]                   # [O, T]
+    IN = int(np.prod(ins))
+    o = np.arange(O, dtype=np.int64)[:, None, None, None]
+    t = np.arange(T, dtype=np.int64)[None, :, None, None]
+    ci = np.arange(cin, dtype=np.int64)[None, None, :, None]
+    co = np.arange(cout, dtype=np.int64)[None, None, None, :]
+    ipf = ipflat.astype(np.int64)[:, :, None, None]
+    vmask = np.broadcast_to(valid[:, :, None, None], (O, T, cin, cout))
+    if implementation == 1:                                    # channels_first: feature order (cin, kr, kc, kz)
+        g = (o * F + ci * T + t) * cout + co
+        g = np.broadcast_to(g, (O, T, cin, cout))
+    elif implementation == 2:
+        if cf:                                                 # (cin, in..., cout, out...)
+            g = ((ci * IN + ipf) * cout + co) * O + o
+        else:                                                  # (in..., cin, out..., cout)
+            g = ((ipf * cin + ci) * O + o) * cout + co
+    else:
+        if cf:                                                 # concat_idxs = (filter,) + spatial   :1404-1405
+            out_idx = co * O + o
+            in_idx = ci * IN + ipf
+        else:
+            out_idx = o * cout + co
+            in_idx = ipf * cin + ci
+        out_idx = np.broadcast_to(out_idx, (O, T, cin, cout))
+        in_idx = np.broadcast_to(in_idx, (O, T, cin, cout))
+        keys = (out_idx * (IN * cin) + in_idx)[vmask]
+        order = np.argsort(keys, kind='stable')
+        rank = np.empty(order.size, np.int64)
+        rank[order] = np.arange(order.size)
+        g = np.zeros((O, T, cin, cout), np.int64)
+        g[vmask] = rank
+        plan['nnz'] = int(order.size)
+        plan['pairs'] = (out_idx[vmask][order], in_idx[vmask][order])       # == sorted(conv_kernel_idxs(...)), for the tests
+    plan['gather'] = np.ascontiguousarray(np.where(vmask, g, 0).reshape(O, F, cout))
+    plan['mask'] = None if valid.all() else np.ascontiguousarray(vmask.reshape(O, F, cout).astype(np.float32))
+    return plan
+
+
+class _Pad3dFn(torch.autograd.Function):
+    """zero padding of a channels-last volume (csrc/lc3d.hip: pad3d_rows); backward = the interior of the gradient"""
+
+    @staticmethod
+    def forward(ctx, x, before, padded):
+        ctx.cfg = (tuple(x.shape[1:4]), tuple(before), tuple(padded))
+        return _pad3d(x, ctx.cfg[0], before, padded, crop=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        ins, before, padded = ctx.cfg
+        return _pad3d(g.contiguous(), ins, before, padded, crop=True), None, None
+
+
+def _pad3d(t, ins, before, padded, crop):
+    lib = _lib.lib()
+    dev = _lib.require_device(t)
+    B, C = t.shape[0], t.shape[-1]
+    shape = [B] + list(ins if crop else padded) + [C]
+    out = torch.empty(shape, dtype=t.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_pad3d(_lib.ptr(t), _lib.ptr(out), B, _lib.ints(ins), _lib.ints(before), _lib.ints(padded),
+                           C * t.element_size(), int(crop), _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_pad3d')
+    return out
+
+
 class _Lc3dFn(torch.autograd.Function):
     """LocallyConnected3D forward / backward on csrc/lc3d.hip (x channels-last, contiguous)."""
 
@@ -677,14 +784,11 @@ class LocallyConnected3D(_Layer):
         self.bias_constraint = bias_constraint
         if implementation not in (1, 2, 3):
             raise ValueError('Unrecognized implementation mode: %d.' % implementation)
-        if implementation != 1:
-            raise NotImplementedError('implementation %d stores the same un-shared weights in a dense-masked / sparse '
-                                      'layout (layers.py:986-1028); only the implementation-1 layout [O, F, filters] is '
-                                      'implemented on the HIP path' % implementation)
         self.implementation = implementation
         self.kernel = None
         self.bias = None
         self._variant = 0
+        self._stream_cache = None
 
     def build(self, input_shape):
         if self.data_format == 'channels_last':                                           # layers.py:952-958
@@ -696,13 +800,33 @@ class LocallyConnected3D(_Layer):
         if input_row is None or input_col is None or input_z is None:
             raise ValueError('The spatial dimensions of the inputs to  a LocallyConnected3D layer should be '
                              'fully-defined, but layer received the inputs shape ' + str(input_shape))
-        out = [(n - k) // s + 1 for n, k, s in zip((input_row, input_col, input_z), self.kernel_size, self.strides)]
-        self.output_row, self.output_col, self.output_z = out                              # conv_output_length, valid
-        F = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2] * input_filter
+        ins = (int(input_row), int(input_col), int(input_z))
+        out = [_conv_output_length(n, k, self.padding, st) for n, k, st in zip(ins, self.kernel_size, self.strides)]
+        self.output_row, self.output_col, self.output_z = out                              # :963-971
+        T = self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        F = T * input_filter
         O = out[0] * out[1] * out[2]
-        self.kernel_shape = (O, F, self.filters)                                           # :974-977
-        # glorot_uniform with Keras' fan computation for a rank-3 shape (receptive field = O)
-        limit = (6.0 / (F * O + self.filters * O)) ** 0.5
+        IN = ins[0] * ins[1] * ins[2]
+        cf = self.data_format == 'channels_first'
+        if self.implementation == 1:                                                       # :973-984
+            self.kernel_shape = (O, F, self.filters)
+            fan_in, fan_out = F * O, self.filters * O          # Keras' fans of a rank-3 shape (receptive field = O)
+        elif self.implementation == 2:                                                     # :986-1006
+            self.kernel_shape = ((input_filter,) + ins + (self.filters,) + tuple(out)) if cf \
+                else (ins + (input_filter,) + tuple(out) + (self.filters,))
+            rf = int(np.prod(self.kernel_shape[:-2]))
+            fan_in, fan_out = self.kernel_shape[-2] * rf, self.kernel_shape[-1] * rf
+        else:                                                                              # :1008-1028
+            self.dense_kernel_shape = (O * self.filters, IN * input_filter)
+            fan_in = fan_out = None
+        self.input_filter = int(input_filter)
+        self.input_spatial = ins
+        self._plan = _lc3d_plan(ins, int(input_filter), self.kernel_size, self.strides, self.padding, tuple(out),
+                                self.filters, self.implementation, self.data_format)
+        if self.implementation == 3:
+            self.kernel_shape = (self._plan['nnz'],)
+            fan_in = fan_out = int(np.sqrt(self._plan['nnz']))  # Keras' fans of a rank-1 shape: sqrt(n) each
+        limit = (6.0 / max(1, fan_in + fan_out)) ** 0.5
         dev = getattr(self, '_build_device', None)
         dt = getattr(self, '_build_dtype', torch.float32)
         dt = dt if dt in (torch.float32, torch.bfloat16) else torch.float32
@@ -715,7 +839,6 @@ class LocallyConnected3D(_Layer):
         self.kernel = nn.Parameter(k)
         if self.use_bias:                                                                  # :1030-1039
             self.bias = nn.Parameter(torch.zeros(out[0], out[1], out[2], self.filters, dtype=dt, device=dev))
-        self.input_filter = input_filter
         self.built = True
 
     def compute_output_shape(self, input_shape):
@@ -723,10 +846,53 @@ class LocallyConnected3D(_Layer):
             dims = input_shape[2:5]
         else:
             dims = input_shape[1:4]
-        o = [(n - k) // s + 1 for n, k, s in zip(dims, self.kernel_size, self.strides)]
+        o = [_conv_output_length(n, k, self.padding, st) for n, k, st in zip(dims, self.kernel_size, self.strides)]
         if self.data_format == 'channels_first':
             return (input_shape[0], self.filters, o[0], o[1], o[2])
         return (input_shape[0], o[0], o[1], o[2], self.filters)
+
+    def train(self, mode=True):
+        self._stream_cache = None
+        return super().train(mode)
+
+    def _streaming_weights(self):
+        """
+        The un-shared weights in the layout the HIP kernel streams: [O, (kr, kc, kz, cin), filters] (= implementation 1,
+        channels_last).  The other layouts hold the SAME numbers elsewhere -- implementation 1 channels_first flattens the
+        patch channel-major (layers.py:1176-1186), 2 is a dense [in..., cin, out..., filters] array of which only the
+        connected entries are used (:986-1006, 1300-1308), 3 the values of the sparse matrix in sorted (out_idx, in_idx)
+        order (:1012-1028) -- and are re-laid out by ONE gather through an index table built at `build` time (a tap that
+        'same' padding clips away gets weight 0).  Differentiable (torch indexing), so the kernel's weight gradient flows
+        back into the layer's own parameter; cached while no gradient is being recorded.
+        """
+        plan = self._plan
+        if plan['gather'] is None:
+            return self.kernel
+        track = torch.is_grad_enabled() and self.kernel.requires_grad
+        key = (self.kernel._version, self.kernel.data_ptr(), self.kernel.device)
+        if not track and self._stream_cache is not None and self._stream_cache[0] == key:
+            return self._stream_cache[1]
+        dev = self.kernel.device
+        if plan.get('gather_dev') is None or plan['gather_dev'].device != dev:
+            plan['gather_dev'] = torch.from_numpy(plan['gather']).to(dev)
+            plan['mask_dev'] = None if plan['mask'] is None else torch.from_numpy(plan['mask']).to(dev)
+        w = self.kernel.reshape(-1)[plan['gather_dev']]
+        if plan['mask_dev'] is not None:
+            w = w * plan['mask_dev'].to(w.dtype)
+        w = w.reshape(plan['O'], plan['F'], self.filters)
+        if not track:
+            self._stream_cache = (key, w.detach())
+        return w
+
+    def _bias_channels_last(self):
+        if self.bias is None:
+            return None
+        if self.data_format == 'channels_first':
+            # K.bias_add on channels_first data RESHAPES the [or, oc, oz, filters] array to (1, filters, or, oc, oz)
+            # (keras backend.bias_add); expressed for the channels-last kernel: element [co, r, c, z] of that view
+            o = (self.output_row, self.output_col, self.output_z)
+            return self.bias.reshape((self.filters,) + o).permute(1, 2, 3, 0).contiguous()
+        return self.bias
 
     def get_config(self):
         config = {
@@ -754,21 +920,29 @@ class LocallyConnected3D(_Layer):
         if self.kernel.dtype != x.dtype:
             raise TypeError('input dtype %s does not match the layer weights %s (use layer.to(dtype))'
                             % (x.dtype, self.kernel.dtype))
-        B, S, cin = x.shape[0], list(x.shape[1:4]), x.shape[-1]
+        B, cin = x.shape[0], x.shape[-1]
         if cin != self.input_filter:
             raise ValueError('expected %d input channels, got %d' % (self.input_filter, cin))
+        if tuple(x.shape[1:4]) != tuple(self.input_spatial):
+            raise ValueError('input spatial shape %s does not match the shape the layer was built for'
+                             % (list(x.shape[1:4]),))
+        plan = self._plan
+        if plan['padded'] is not None:                      # padding='same': the 'valid' layer on the zero-padded input
+            x = _Pad3dFn.apply(x, plan['pad_before'], plan['padded'])
+        S = list(x.shape[1:4])
         O = [self.output_row, self.output_col, self.output_z]
-        if [(n - k) // s + 1 for n, k, s in zip(S, self.kernel_size, self.strides)] != O:
-            raise ValueError('input spatial shape %s does not match the shape the layer was built for' % S)
+        w1 = self._streaming_weights()
+        bias_cl = self._bias_channels_last()
         y = torch.empty([B] + O + [self.filters], dtype=x.dtype, device=dev)
         act = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}[self.activation]
         dt = _lib.DT_F32 if x.dtype == torch.float32 else _lib.DT_BF16
-        k = self.kernel.detach().contiguous()
-        bias = None if self.bias is None else self.bias.detach().contiguous()
+        k = w1.detach().contiguous()
+        bias = None if bias_cl is None else bias_cl.detach().contiguous()
+        xd = x.detach()
 
         def run():
             with torch.cuda.device(dev):
-                rc = lib.nrt_lc3d_f(_lib.ptr(x), _lib.ptr(k), _lib.ptr(bias), _lib.ptr(y), dt, B, _lib.ints(S), cin,
+                rc = lib.nrt_lc3d_f(_lib.ptr(xd), _lib.ptr(k), _lib.ptr(bias), _lib.ptr(y), dt, B, _lib.ints(S), cin,
                                     _lib.ints(self.kernel_size), _lib.ints(self.strides), self.filters, act,
                                     int(self._variant), _lib.stream_ptr(dev))
             _lib.check(rc, 'nrt_lc3d_f')
@@ -777,19 +951,19 @@ class LocallyConnected3D(_Layer):
         def run_backward(g, need_x, need_k, need_b):
             g = g.contiguous()
             dk = torch.empty_like(k) if need_k else None
-            db = torch.empty((int(np.prod(O)), self.filters), dtype=x.dtype, device=dev) if need_b else None
-            dx = torch.zeros(x.shape, dtype=torch.float32, device=dev) if need_x else None
+            db = torch.empty((int(np.prod(O)), self.filters), dtype=xd.dtype, device=dev) if need_b else None
+            dx = torch.zeros(xd.shape, dtype=torch.float32, device=dev) if need_x else None
             with torch.cuda.device(dev):
-                rc = lib.nrt_lc3d_bwd_f(_lib.ptr(x), _lib.ptr(k), _lib.ptr(y), _lib.ptr(g), _lib.ptr(dk), _lib.ptr(db),
+                rc = lib.nrt_lc3d_bwd_f(_lib.ptr(xd), _lib.ptr(k), _lib.ptr(y), _lib.ptr(g), _lib.ptr(dk), _lib.ptr(db),
                                         _lib.ptr(dx), dt, B, _lib.ints(S), cin, _lib.ints(self.kernel_size),
                                         _lib.ints(self.strides), self.filters, act, _lib.stream_ptr(dev))
             _lib.check(rc, 'nrt_lc3d_bwd_f')
-            return (None if dx is None else dx.to(x.dtype)), dk, (None if db is None else db.reshape(self.bias.shape))
+            return (None if dx is None else dx.to(xd.dtype)), dk, (None if db is None else db.reshape(bias.shape))
 
-        needs = torch.is_grad_enabled() and (x.requires_grad or self.kernel.requires_grad
-                                             or (self.bias is not None and self.bias.requires_grad))
+        needs = torch.is_grad_enabled() and (x.requires_grad or w1.requires_grad
+                                             or (bias_cl is not None and bias_cl.requires_grad))
         if needs:
-            out = _Lc3dFn.apply(x, self.kernel, self.bias, run, run_backward)
+            out = _Lc3dFn.apply(x, w1, bias_cl, run, run_backward)
         else:
             out = run()
         return out.permute(0, 4, 1, 2, 3) if self.data_format == 'channels_first' else out

@@ -109,6 +109,62 @@ def lc3d(x, kernel, bias=None, kernel_size=(3, 3, 3), strides=(1, 1, 1), activat
     return y
 
 
+def _act(y, activation):
+    if activation == 'elu':
+        return torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0.0)) - 1)
+    if activation == 'relu':
+        return torch.relu(y)
+    return y
+
+
+def lc3d_connection_mask(ins, ksize, strides, padding, outs):
+    """keras conv_utils.conv_kernel_mask (what LocallyConnected3D.get_locallyconnected_mask wraps, neurite/tf/layers.py:
+    1199-1257): bool [*ins, *outs], True where the output position reads the input position; the window of position p along
+    axis d is [c - k//2, c + k - k//2) clipped to the volume, c = p*s (+ k//2 for 'valid') (conv_connected_inputs :1436-1484)."""
+    import itertools
+    import numpy as np
+    mask = np.zeros(tuple(ins) + tuple(outs), bool)
+    for pos in itertools.product(*[range(n) for n in outs]):
+        rng = []
+        for d in range(3):
+            left = int(ksize[d] / 2)
+            right = ksize[d] - left
+            c = pos[d] * strides[d] + (left if padding == 'valid' else 0)
+            rng.append(range(max(0, c - left), min(ins[d], c + right)))
+        for ip in itertools.product(*rng):
+            mask[ip + pos] = True
+    return mask
+
+
+def lc3d_dense_masked(x, kernel, mask, bias, activation=None, data_format='channels_last'):
+    """LocallyConnected3D implementation 2 as the reference computes it (neurite/tf/layers.py:1260-1308): the flattened input
+    times the dense kernel multiplied by the 0/1 connection mask.  x [B, *ins, Cin] (or [B, Cin, *ins]); kernel
+    [*ins, Cin, *outs, Cout] (or [Cin, *ins, Cout, *outs]); mask bool [*ins, *outs]; bias [*outs, Cout]."""
+    cf = data_format == 'channels_first'
+    m = torch.from_numpy(mask).to(kernel.dtype)
+    m = m[None, :, :, :, None, :, :, :] if cf else m[:, :, :, None, :, :, :, None]            # :1245-1251
+    k = (m * kernel)
+    k2 = k.reshape(int(torch.tensor(k.shape[:4]).prod()), -1)                                  # make_2d, split at ndim // 2
+    y = (x.reshape(x.shape[0], -1) @ k2).reshape((x.shape[0],) + tuple(kernel.shape[4:]))
+    if bias is not None:
+        b = bias.reshape((bias.shape[-1],) + tuple(bias.shape[:-1])) if cf else bias           # K.bias_add: a reshape
+        y = y + b
+    return _act(y, activation)
+
+
+def lc3d_sparse(x, values, kernel_idxs, dense_shape, out_shape, bias, activation=None, data_format='channels_last'):
+    """LocallyConnected3D implementation 3 (neurite/tf/layers.py:1311-1343): SparseTensor(kernel_idxs, values, dense_shape) @
+    x_flat^T, transposed and reshaped to out_shape (without batch)."""
+    cf = data_format == 'channels_first'
+    idx = torch.as_tensor(kernel_idxs, dtype=torch.long)
+    dense = torch.zeros(tuple(int(v) for v in dense_shape), dtype=values.dtype).index_put((idx[:, 0], idx[:, 1]), values)
+    y = (dense @ x.reshape(x.shape[0], -1).T).T.reshape((x.shape[0],) + tuple(out_shape))
+    if bias is not None:
+        b = bias.reshape((bias.shape[-1],) + tuple(bias.shape[:-1])) if cf else bias
+        y = y + b
+    return _act(y, activation)
+
+
 def mi_channelwise(x, y, cx, cy, alpha, min_clip=float('-inf'), max_clip=float('inf'), eps=1e-7):
     """MutualInformation.channelwise (neurite/tf/metrics.py:188-282) with GIVEN bin centres cx, cy [nb] (held constant, as the
     HIP backward does): x, y [bs, ..., C] -> [bs, C]."""

@@ -326,13 +326,13 @@ def gen_lc3d_impl():
         ('i1_cl', dict(implementation=1), (2, 5, 4, 6, 3), 4, (3, 2, 3), (1, 1, 2)),
         ('i1_cf', dict(implementation=1, data_format='channels_first'), (2, 3, 5, 4, 6), 4, (3, 2, 3), (1, 1, 2)),
         ('i2_valid', dict(implementation=2), (2, 5, 4, 6, 3), 4, (3, 2, 3), (1, 1, 2)),
-        ('i2_same', dict(implementation=2, padding='same'), (2, 5, 4, 6, 2), 3, (3, 3, 3), (1, 1, 1)),
+        ('i2_same', dict(implementation=2, padding='same'), (2, 5, 4, 6, 2), 4, (3, 3, 3), (1, 1, 1)),
         ('i2_same_stride', dict(implementation=2, padding='same', activation='relu'), (1, 6, 5, 7, 2), 3, (3, 2, 3), (2, 1, 3)),
-        ('i2_cf_same', dict(implementation=2, padding='same', data_format='channels_first'), (2, 2, 4, 5, 3), 3, (3, 3, 2), (1, 2, 1)),
+        ('i2_cf_same', dict(implementation=2, padding='same', data_format='channels_first'), (2, 2, 4, 5, 3), 4, (3, 3, 2), (1, 2, 1)),
         ('i3_valid', dict(implementation=3), (2, 5, 4, 6, 3), 4, (3, 2, 3), (1, 1, 2)),
-        ('i3_same', dict(implementation=3, padding='same', activation='elu'), (2, 5, 4, 6, 2), 3, (3, 3, 3), (1, 1, 1)),
+        ('i3_same', dict(implementation=3, padding='same', activation='elu'), (2, 5, 4, 6, 2), 4, (3, 3, 3), (1, 1, 1)),
         ('i3_same_stride', dict(implementation=3, padding='same'), (1, 6, 5, 7, 2), 3, (2, 3, 3), (2, 1, 3)),
-        ('i3_cf_same', dict(implementation=3, padding='same', data_format='channels_first'), (2, 2, 4, 5, 3), 3, (3, 3, 2), (1, 2, 1)),
+        ('i3_cf_same', dict(implementation=3, padding='same', data_format='channels_first'), (2, 2, 4, 5, 3), 4, (3, 3, 2), (1, 2, 1)),
     ]
     for tag, kw, in_shape, filters, ks, st in specs:
         layer = ne.layers.LocallyConnected3D(filters, ks, strides=st, **kw)

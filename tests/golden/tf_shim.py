@@ -391,8 +391,13 @@ def k_batch_dot(x, y, axes=None):
 
 
 def k_bias_add(x, bias, data_format=None):
-    assert data_format in (None, 'channels_last')
-    return T(x) + T(A(bias)[None])
+    b = A(bias)
+    assert data_format in (None, 'channels_last', 'channels_first')
+    if data_format == 'channels_first' and b.ndim > 1:
+        # keras.backend.bias_add, N-D bias, channels_first data: x + reshape(bias, (1, bias_shape[-1]) + bias_shape[:-1])
+        # -- a RESHAPE of the (spatial..., C) array, not a transpose (TF semantics, restated)
+        b = b.reshape((b.shape[-1],) + b.shape[:-1])
+    return T(x) + T(b[None])
 
 
 # ----------------------------------------------------------------------------- keras classes
@@ -632,6 +637,21 @@ def cu_conv_kernel_mask(input_shape, kernel_shape, strides, padding):
     return mask
 
 
+def shape_type_conversion(fn):
+    """tf_utils.shape_type_conversion: shapes go in as tuples and come out as TensorShape"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(instance, input_shape):
+        if input_shape is not None:
+            input_shape = tuple(input_shape) if not isinstance(input_shape, list) else [tuple(s) for s in input_shape]
+        out = fn(instance, input_shape)
+        if out is not None and not isinstance(out, list):
+            out = TensorShape(tuple(out))
+        return out
+    return wrapper
+
+
 def activations_get(identifier):
     if identifier is None or identifier == 'linear':
         return lambda x: x
@@ -747,7 +767,7 @@ def _populate(m):
                  cast=cast, stack=stack, clip=clip_by_value,
                  min=lambda x, axis=None, keepdims=False: Tensor(np.min(A(x), axis=axis, keepdims=keepdims)),
                  max=lambda x, axis=None, keepdims=False: Tensor(np.max(A(x), axis=axis, keepdims=keepdims)),
-                 flatten=lambda x: Tensor(A(x).reshape(-1)))
+                 flatten=lambda x: Tensor(A(x).reshape(-1)), transpose=lambda x: Tensor(np.transpose(A(x))))
         for k, v in d.items():
             setattr(m, k, v)
     if n == 'tensorflow.keras.layers':
@@ -775,6 +795,8 @@ def _populate(m):
         m.normalize_data_format = cu_normalize_data_format
         m.conv_output_length = cu_conv_output_length
         m.conv_kernel_mask = cu_conv_kernel_mask
+    if n == 'tensorflow.python.keras.utils.tf_utils':
+        m.shape_type_conversion = shape_type_conversion
     if n == 'tensorflow.linalg':
         m.matmul = linalg_matmul
     if n == 'tensorflow.python.ops.gen_sparse_ops':
@@ -795,7 +817,8 @@ def install():
                  'tensorflow.keras.backend', 'tensorflow.keras.layers', 'tensorflow.keras.losses',
                  'tensorflow.keras.models', 'tensorflow.keras.activations', 'tensorflow.keras.initializers',
                  'tensorflow.keras.regularizers', 'tensorflow.keras.constraints', 'tensorflow.linalg',
-                 'tensorflow.python.keras.utils.conv_utils', 'tensorflow.python.ops.gen_sparse_ops', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
+                 'tensorflow.python.keras.utils.conv_utils', 'tensorflow.python.keras.utils.tf_utils',
+                 'tensorflow.python.ops.gen_sparse_ops', 'tensorflow.keras.utils', 'tensorflow.keras.datasets',
                  'tensorflow.python', 'tensorflow.python.keras', 'tensorflow.python.keras.utils',
                  'tensorflow.python.ops', 'tensorflow.nn', 'tensorflow.random', 'tensorflow.experimental', 'tensorflow.experimental.numpy', 'pystrum', 'pystrum.pynd', 'pystrum.pytools'):
         mod = importlib.import_module(name)

@@ -76,8 +76,13 @@ def test_lc3d_vs_oracle(dev, cin, cout, S, ks, st):
     y = layer(xb)
     assert y.dtype == torch.bfloat16
     close(N(y), refb, 2.0 ** -8)
-    # channels_first in / out
-    layer_cf = make_layer(dev, G(x, dev).permute(0, 4, 1, 2, 3).contiguous(), cout, ks, st, G(k, dev), G(b, dev),
+    # channels_first in / out: the reference flattens the patch channel-major there (layers.py:1176-1186: inputs[:, :, slices]
+    # reshaped to feature_dim => f = (cin, kr, kc, kz)) and K.bias_add RESHAPES the [or, oc, oz, filters] bias to
+    # (1, filters, or, oc, oz) -- pinned by tests/golden/lc3d_impl.npz::i1_cf; here the same weights in that layout
+    T = int(np.prod(ks))
+    k_cf = np.ascontiguousarray(k.reshape(O, T, cin, cout).transpose(0, 2, 1, 3).reshape(O, Fd, cout))
+    b_cf = np.ascontiguousarray(b.transpose(3, 0, 1, 2)).reshape(osh + (cout,))
+    layer_cf = make_layer(dev, G(x, dev).permute(0, 4, 1, 2, 3).contiguous(), cout, ks, st, G(k_cf, dev), G(b_cf, dev),
                           data_format='channels_first')
     ycf = layer_cf(G(x, dev).permute(0, 4, 1, 2, 3).contiguous())
     close(N(ycf.permute(0, 2, 3, 4, 1)), ref, 1e-5)
@@ -90,6 +95,11 @@ def test_lc3d_contract():
         ne.layers.LocallyConnected3D(4, (3, 3))
     with pytest.raises(ValueError, match='Unrecognized implementation mode'):
         ne.layers.LocallyConnected3D(4, 3, implementation=7)
+    for impl in (2, 3):
+        l = ne.layers.LocallyConnected3D(4, 3, padding='same', implementation=impl)
+        assert l.compute_output_shape((2, 9, 8, 7, 3)) == (2, 9, 8, 7, 4)
+        assert ne.layers.LocallyConnected3D(4, 3, strides=2, padding='same', implementation=impl) \
+            .compute_output_shape((2, 9, 8, 7, 3)) == (2, 5, 4, 4, 4)
     l = ne.layers.LocallyConnected3D(4, 3, strides=2, activation='elu', name='lc')
     cfg = l.get_config()
     assert cfg['filters'] == 4 and cfg['kernel_size'] == (3, 3, 3) and cfg['strides'] == (2, 2, 2)
@@ -172,3 +182,95 @@ def test_lc3d_backward(dev, dtype, cout, ks, strides, act, S, cin):
     close(layer.bias.grad, bo.grad, 'grad_bias')
     close(xg.grad, xo.grad, 'grad_x')
     assert layer.kernel.grad.dtype == tdt and xg.grad.dtype == tdt
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# implementations 2 (dense-masked kernel) and 3 (sparse COO values), 'same' padding, channels_first
+# (neurite/tf/layers.py:986-1028, 1260-1343): the same un-shared weights in other layouts, re-laid out once into the
+# streaming layout of the HIP kernel.  Fixtures: the reference LAYER (build + call) run by tests/golden/make_golden.py.
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _impl_cases():
+    return golden_cases(load_golden('lc3d_impl'))
+
+
+def _impl_layer(dev, c):
+    ks, st = tuple(int(v) for v in c['ks']), tuple(int(v) for v in c['strides'])
+    act = str(c['activation'])
+    layer = ne.layers.LocallyConnected3D(int(c['filters']), ks, strides=st, padding=str(c['padding']),
+                                         data_format=str(c['data_format']), activation=None if act == 'linear' else act,
+                                         implementation=int(c['implementation']))
+    x = G(c['x'], dev)
+    y0 = layer(x)
+    assert tuple(layer.kernel.shape) == c['kernel'].shape, (tuple(layer.kernel.shape), c['kernel'].shape)
+    assert tuple(layer.bias.shape) == c['bias'].shape
+    assert tuple(y0.shape) == c['out'].shape == tuple(layer.compute_output_shape(tuple(x.shape)))
+    with torch.no_grad():
+        layer.kernel.copy_(G(c['kernel'], dev))
+        layer.bias.copy_(G(c['bias'], dev))
+    return layer, x
+
+
+def test_lc3d_implementations_golden(dev):
+    cases = _impl_cases()
+    assert len(cases) == 10
+    for tag, c in cases.items():
+        layer, x = _impl_layer(dev, c)
+        close(N(layer(x)), c['out'], 1e-5)
+        if int(c['implementation']) == 3:                 # the sparse values are ordered like the reference's kernel_idxs
+            assert np.array_equal(np.stack(layer._plan['pairs'], 1), c['kernel_idxs']), tag
+        # cached re-layout: a second call, and a call after an in-place weight update, stay correct
+        close(N(layer(x)), c['out'], 1e-5)
+        with torch.no_grad():
+            layer.kernel.mul_(2.0)
+            layer.bias.mul_(2.0)
+        if str(c['activation']) == 'linear':
+            close(N(layer(x)), 2.0 * c['out'].astype(np.float64), 1e-5)
+
+
+@pytest.mark.parametrize('tag', ['i1_cf', 'i2_valid', 'i2_same', 'i2_cf_same', 'i3_valid', 'i3_same', 'i3_cf_same'])
+def test_lc3d_implementations_backward(dev, tag):
+    """gradients wrt the layer's OWN kernel layout, the bias and the input against float64 autograd of the reference's
+    formulation (dense kernel x connection mask matmul for implementation 2, sparse matrix for 3; oracle/grad_oracle.py)"""
+    from oracle import grad_oracle as go
+    c = _impl_cases()[tag]
+    layer, x = _impl_layer(dev, c)
+    impl, pad, fmt = int(c['implementation']), str(c['padding']), str(c['data_format'])
+    act = None if str(c['activation']) == 'linear' else str(c['activation'])
+    ks, st = tuple(int(v) for v in c['ks']), tuple(int(v) for v in c['strides'])
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal(c['out'].shape)
+    xg = x.clone().requires_grad_()
+    y = layer(xg)
+    (y.double() * G(w, dev)).sum().backward()
+    xo = torch.from_numpy(c['x']).double().requires_grad_()
+    ko = torch.from_numpy(c['kernel']).double().requires_grad_()
+    bo = torch.from_numpy(c['bias']).double().requires_grad_()
+    cf = fmt == 'channels_first'
+    ins = tuple(c['x'].shape[2:]) if cf else tuple(c['x'].shape[1:4])
+    outs = tuple(c['out'].shape[2:]) if cf else tuple(c['out'].shape[1:4])
+    if impl == 1:
+        xcl = xo.permute(0, 2, 3, 4, 1) if cf else xo
+        T = ks[0] * ks[1] * ks[2]
+        cin = xcl.shape[-1]
+        k1 = ko.reshape(ko.shape[0], cin, T, -1).permute(0, 2, 1, 3).reshape(ko.shape) if cf else ko     # (cin, taps) -> (taps, cin)
+        b1 = bo.reshape((bo.shape[-1],) + outs).permute(1, 2, 3, 0) if cf else bo
+        yo = go.lc3d(xcl, k1, b1, ks, st, act)
+        yo = yo.permute(0, 4, 1, 2, 3) if cf else yo
+    elif impl == 2:
+        yo = go.lc3d_dense_masked(xo, ko, go.lc3d_connection_mask(ins, ks, st, pad, outs), bo, act, fmt)
+    else:
+        dense_shape = (int(np.prod(c['out'].shape[1:])), int(np.prod(c['x'].shape[1:])))
+        yo = go.lc3d_sparse(xo, ko, c['kernel_idxs'], dense_shape, c['out'].shape[1:], bo, act, fmt)
+    np.testing.assert_allclose(yo.detach().numpy(), c['out'], rtol=1e-5, atol=1e-5 * np.abs(c['out']).max())   # the oracle itself
+    (yo * torch.from_numpy(w)).sum().backward()
+
+    def chk(got, want, what):
+        got = got.detach().cpu().double().numpy(); want = want.numpy()
+        err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+        assert got.shape == want.shape and err < 2e-5, (tag, what, err)
+
+    chk(y, yo.detach(), 'forward')
+    chk(layer.kernel.grad, ko.grad, 'grad_kernel')
+    chk(layer.bias.grad, bo.grad, 'grad_bias')
+    chk(xg.grad, xo.grad, 'grad_x')

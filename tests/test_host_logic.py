@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import neurite_amd as ne
-from conftest import load_golden
+from conftest import golden_cases, load_golden
 
 
 def test_library_loads_and_exports_header_symbols():
@@ -581,3 +581,46 @@ def test_packed_weight_cache_is_dropped_when_weights_may_have_changed():
         poison()
         action()
         assert all(m._packed is None for m in convs)
+
+
+def test_lc3d_relayout_plan_reproduces_the_reference_layer():
+    """LocallyConnected3D implementations 1 (channels_first), 2 (dense-masked) and 3 (sparse) with 'valid' / 'same' padding:
+    the host-side re-layout table (neurite_amd/layers.py::_lc3d_plan) applied to the reference-generated kernels, followed by a
+    plain 'valid' un-shared convolution on the zero-padded input, gives the outputs of the reference LAYER
+    (tests/golden/lc3d_impl.npz); implementation 3 orders its values like the reference's sorted kernel_idxs.  NumPy only."""
+    from neurite_amd import layers as L
+    cases = golden_cases(load_golden('lc3d_impl'))
+    assert len(cases) == 10
+    for tag, g in cases.items():
+        x = g['x']
+        ks, st = tuple(int(v) for v in g['ks']), tuple(int(v) for v in g['strides'])
+        fmt, impl, pad, cout = str(g['data_format']), int(g['implementation']), str(g['padding']), int(g['filters'])
+        cf = fmt == 'channels_first'
+        xs = np.moveaxis(x, 1, -1) if cf else x
+        ins, cin = xs.shape[1:4], xs.shape[-1]
+        outs = tuple(L._conv_output_length(n, k, pad, s) for n, k, s in zip(ins, ks, st))
+        plan = L._lc3d_plan(ins, cin, ks, st, pad, outs, cout, impl, fmt)
+        if impl == 3:
+            assert np.array_equal(np.stack(plan['pairs'], 1), g['kernel_idxs']), tag
+            assert plan['nnz'] == g['kernel'].size
+        W1 = g['kernel'] if plan['gather'] is None else \
+            g['kernel'].reshape(-1)[plan['gather']] * (1 if plan['mask'] is None else plan['mask'])
+        xp = xs.astype(np.float64)
+        if plan['padded'] is not None:
+            pb, P = plan['pad_before'], plan['padded']
+            xp = np.zeros((xs.shape[0],) + tuple(P) + (cin,))
+            xp[:, pb[0]:pb[0] + ins[0], pb[1]:pb[1] + ins[1], pb[2]:pb[2] + ins[2]] = xs
+        y = np.zeros((xs.shape[0],) + outs + (cout,))
+        oi = 0
+        for r in range(outs[0]):
+            for c in range(outs[1]):
+                for z in range(outs[2]):
+                    patch = xp[:, r * st[0]:r * st[0] + ks[0], c * st[1]:c * st[1] + ks[1], z * st[2]:z * st[2] + ks[2], :]
+                    y[:, r, c, z] = patch.reshape(xs.shape[0], -1) @ W1[oi].astype(np.float64)
+                    oi += 1
+        b = g['bias']
+        y = y + (np.transpose(b.reshape((cout,) + outs), (1, 2, 3, 0)) if cf else b)[None]
+        act = str(g['activation'])
+        y = np.maximum(y, 0) if act == 'relu' else (np.where(y > 0, y, np.exp(np.minimum(y, 0)) - 1) if act == 'elu' else y)
+        y = np.moveaxis(y, -1, 1) if cf else y
+        np.testing.assert_allclose(y, g['out'], rtol=1e-5, atol=1e-6 * np.abs(g['out']).max(), err_msg=tag)
