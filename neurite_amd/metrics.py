@@ -366,13 +366,25 @@ WeightedCategoricalCrossentropy = CategoricalCrossentropy
 # --------------------------------------------------------------------------------------
 
 class _MseProbFn(torch.autograd.Function):
-    """sum over everything of w_l (t - p)^2 from the Dice kernel's per-(batch, label) sums (sum t p, sum t^2, sum p^2 -- the
-    second reduction stage is in float64); backward dp = 2 w_l (p - t) g on the per-channel a x + b y kernel."""
+    """sum over everything of w_l (t - p)^2.  The difference d = t - p is formed first (per-channel a x + b y kernel) and
+    its squares are reduced by the Dice sums kernel (sum d^2 per (batch, label)); expanding to sum t^2 - 2 sum t p + sum p^2
+    cancels catastrophically for maps that nearly agree (0.6 % error at |t - p| ~ 3e-3 from the float32 sums
+    alone).  Backward dp = 2 w_l (p - t) g on the same a x + b y kernel."""
 
     @staticmethod
     def forward(ctx, t, p, w):
-        sums, _, _ = dice_partial_sums(t, p)
-        per_label = (sums[:, 1].double() - 2.0 * sums[:, 0].double() + sums[:, 2].double()).sum(0)        # [L]
+        lib = _lib.lib()
+        dev = p.device
+        L = p.shape[-1]
+        tc, pc = t.contiguous(), p.contiguous()
+        one = torch.ones(L, dtype=torch.float32, device=dev)
+        d = torch.empty_like(pc)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_channel_axpby_f32(_lib.ptr(tc), _lib.ptr(pc), _lib.ptr(one), _lib.ptr(-one), _lib.ptr(torch.zeros_like(one)),
+                                           _lib.ptr(d), pc.numel(), L, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_channel_axpby_f32')
+        sums, _, _ = dice_partial_sums(d, d)
+        per_label = sums[:, 1].double().sum(0)                                                             # [L] sum d^2
         ctx.save_for_backward(t, p, w)
         return (per_label * w.double()).sum().to(torch.float32)
 

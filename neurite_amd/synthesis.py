@@ -28,15 +28,21 @@ class SynthModel(nn.Module):
         self.cfg = cfg
         self.last_draws = {}
         self.name = 'synth_%d' % cfg['id']
+        self._seq = {}
 
     # ---- random draws -------------------------------------------------------------------------------------------
-    def _gen(self, dev, key, salt=0):
+    def _seed(self, key):
+        """Per-call seed of a component.  A seeded tf.random op yields a reproducible SEQUENCE that advances with every
+        call (the reference's seeds, models.py:690-694); so each key owns a NumPy generator seeded once from the user's seed
+        and every forward draws a fresh sub-seed from it: two models built alike agree call by call, two consecutive
+        calls of one model differ.  Unseeded keys draw from fresh entropy."""
+        if key not in self._seq:
+            self._seq[key] = np.random.default_rng(self.cfg['seeds'].get(key))
+        return int(self._seq[key].integers(2 ** 31 - 1))
+
+    def _gen(self, dev, key):
         g = torch.Generator(device=dev)
-        seed = self.cfg['seeds'].get(key)
-        if seed is None:
-            g.seed()
-        else:
-            g.manual_seed(int(seed) + 7919 * salt)
+        g.manual_seed(self._seed(key))
         return g
 
     def forward(self, labels):
@@ -63,10 +69,10 @@ class SynthModel(nn.Module):
         if c['warp_std'] > 0:
             vel_shape = tuple(int(s) for s in c['out_shape'] // 2) + (num_dim,)
             vel_scale = np.asarray(c['warp_res']) / 2
-            seed = c['seeds'].get('warp')
+            seed = self._seed('warp')
             vel_field = torch.stack([
                 augment.draw_perlin(vel_shape, scales=vel_scale, min_std=0 if c['warp_modulate'] else c['warp_std'],
-                                    max_std=c['warp_std'], seed=None if seed is None else seed + b, device=dev)
+                                    max_std=c['warp_std'], seed=seed + b, device=dev)
                 for b in range(B)], 0)
             def_field = layers.VecInt(int_steps=5, name='vec_int_%d' % c['id'])(vel_field)
             def_field = def_field * 2                                                    # layers.RescaleValues(2), half-resolution field
@@ -96,18 +102,18 @@ class SynthModel(nn.Module):
         # ---- blur (:851-857) ----------------------------------------------------------------------------------------
         if c['blur_std'] > 0:
             kernels = utils.gaussian_kernel([c['blur_std']] * num_dim, separate=True, random=c['blur_modulate'],
-                                            dtype=image.dtype, seed=c['seeds'].get('blur'))
+                                            dtype=image.dtype, seed=self._seed('blur'))
             kernels = kernels if isinstance(kernels, list) else [kernels]
             draws['blur_kernels'] = kernels
             image = utils.separable_conv(image, kernels, batched=True)
         # ---- bias field, clipping (:859-874) -----------------------------------------------------------------------
         bias = None
         if c['bias_std'] > 0:
-            seed = c['seeds'].get('bias')
+            seed = self._seed('bias')
             bias = torch.stack([
                 augment.draw_perlin(tuple(int(s) for s in c['out_shape']) + (1,), scales=c['bias_res'],
                                     min_std=0 if c['bias_modulate'] else c['bias_std'], max_std=c['bias_std'],
-                                    seed=None if seed is None else seed + b, device=dev)
+                                    seed=seed + b, device=dev)
                 for b in range(B)], 0).contiguous()
             if tuple(bias.shape[1:-1]) != S:
                 raise ValueError('Incompatible shapes: image %s and bias field %s' % (S, tuple(bias.shape[1:-1])))

@@ -343,3 +343,16 @@ def test_mean_dice_pair_kernel(dev):
     assert bits_equal(a, b)
     with pytest.raises(ValueError):
         nd.mean_dice_pair(d, np.ones(5, F))
+
+
+def test_mse_prob_nearly_equal_maps_do_not_cancel(dev):
+    """log-probability maps close to convergence (|t - p| ~ 3e-3 on values of order 1..10): the loss is a reduction of
+    (t - p)^2 itself, not of sum t^2 - 2 sum t p + sum p^2 (which loses ~1 % here in float32)"""
+    rng = np.random.default_rng(8)
+    t = (rng.standard_normal((1, 48, 48, 48, 4)) * 3 - 4).astype(F)
+    p = (t + 3e-3 * rng.standard_normal(t.shape)).astype(F)
+    w = np.array([0.5, 1.0, 2.0, 4.0], F)
+    want = float((w * (t.astype(np.float64) - p.astype(np.float64)) ** 2).mean())
+    got = float(ne.metrics.MeanSquaredErrorProb(label_weights=w)(G(t, dev), G(p, dev)))
+    assert got > 0
+    np.testing.assert_allclose(got, want, rtol=1e-5)
