@@ -321,9 +321,22 @@ int nrt_interpn_bwd_f32(const float *vol, const float *loc, const float *grad_ou
                         float *grad_loc, int ndim, const int *vol_shape, const int *out_shape, int channels,
                         int batch, long long vol_batch_stride, long long loc_batch_stride, int loc_mode,
                         int has_fill, void *stream);
+
+/* Backward of nearest-neighbour interpn (neurite/tf/utils/utils.py:193-204) wrt the volume: tf.gather's scatter-add of
+ * grad_out [batch, out_shape, channels] into grad_vol [batch, vol_shape, channels] (ZERO-FILLED by the caller; float atomics),
+ * masked where a fill value applies.  The location has no gradient (tf.round). */
+int nrt_interpn_nearest_bwd_f32(const float *loc, const float *grad_out, float *grad_vol, int ndim, const int *vol_shape,
+                                const int *out_shape, int channels, int batch, long long vol_batch_stride,
+                                long long loc_batch_stride, int loc_mode, int has_fill, void *stream);
 int nrt_dice_soft_bwd_f32(const float *y_true, const float *y_pred, const float *sums, const float *grad_dice,
                           long long nvox, int nlabels, int batch, float laplace_smoothing, float *grad_pred,
                           float *grad_true, void *stream);
+
+/* The same for Dice(normalize=True) (neurite/tf/metrics.py:434-436): `sums` are those of the per-voxel normalised maps, the
+ * gradient is pulled back through t <- divide_no_nan(t, sum_l t) (and p likewise) to the RAW maps y_true / y_pred. */
+int nrt_dice_soft_bwd_norm_f32(const float *y_true, const float *y_pred, const float *sums, const float *grad_dice,
+                               long long nvox, int nlabels, int batch, float laplace_smoothing, float *grad_pred,
+                               float *grad_true, void *stream);
 /* Fused backward of nrt_warp_dice_soft_f32 wrt the displacement / location field: rebuilds the warped row in
  * registers, forms d dice / d warped from `sums` (as returned by the forward) and grad_dice [batch, L], and writes
  * grad_loc [batch, out_shape, 3] only.  `warped` and its gradient never touch HBM. */
@@ -364,6 +377,10 @@ int nrt_minmax_f32(const float *x, long long n, float *out2, void *workspace, si
  * ------------------------------------------------------------------------------------------ */
 int nrt_soft_quantize_f32(const float *x, const float *centers, float alpha, float min_clip, float max_clip, int return_log,
                           float *out, long long n, int nb_bins, void *stream);
+
+/* Backward of soft_quantize wrt x (bin centres held constant): grad_x [n] from grad_out [n, nb_bins]. */
+int nrt_soft_quantize_bwd_f32(const float *x, const float *centers, float alpha, float min_clip, float max_clip,
+                              int return_log, const float *grad_out, float *grad_x, long long n, int nb_bins, void *stream);
 int nrt_mi_joint_f32(const float *x, const float *y, const float *centers_x, const float *centers_y, float alpha, float min_clip,
                      float max_clip, int batch, long long nvox, int channels, int nb_bins, float *joint, float *sum_x,
                      float *sum_y, void *stream);

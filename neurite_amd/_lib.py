@@ -84,6 +84,9 @@ _SIGNATURES = {
     'nrt_membench_copy_f32': (_i, [_vp, _vp, _ll, _i, _i, _vp]),
     'nrt_wcce': (_i, [_vp, _vp, _i, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'nrt_interpn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _vp]),
+    'nrt_interpn_nearest_bwd_f32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _vp]),
+    'nrt_soft_quantize_bwd_f32': (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _vp, _ll, _i, _vp]),
+    'nrt_dice_soft_bwd_norm_f32': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp]),
     'nrt_dice_soft_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp]),
     'nrt_warp_dice_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ip, _ip, _i, _i, _ll, _i, _i, _f, _vp]),
     'nrt_wcce_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _vp, _vp]),

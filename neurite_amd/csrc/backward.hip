@@ -305,6 +305,44 @@ __global__ __launch_bounds__(256) void wcce_bwd(const float *__restrict__ t, con
     }
 }
 
+// soft Dice with normalize=True (metrics.py:434-436: t <- divide_no_nan(t, sum_l t), p likewise, per voxel): the elementwise
+// gradient wrt the NORMALISED maps (coefficients from the sums, which the forward took over the normalised values) is pulled
+// back through the normalisation:  d / d p_k = (g_k - sum_l g_l pn_l) / Sp   (0 where Sp == 0: divide_no_nan's gradient).
+// One thread per voxel, three passes over its labels (the row stays in L1); coefficient table in LDS.
+__global__ __launch_bounds__(256) void dice_soft_bwd_norm(const float *__restrict__ t, const float *__restrict__ p,
+                                                          const float *__restrict__ sums, const float *__restrict__ gdice,
+                                                          long long nvox, int L, float eps, float *__restrict__ gp,
+                                                          float *__restrict__ gt) {
+    extern __shared__ float coef[];          // ca[L], cb[L]
+    const int b = blockIdx.y;
+    const float *s = sums + (long long)b * 3 * L;
+    for (int l = threadIdx.x; l < L; l += 256) {
+        const float num = 2.0f * s[l] + eps, den = s[L + l] + s[2 * L + l] + eps;
+        const float g = gdice[(long long)b * L + l];
+        coef[l] = den != 0.0f ? 2.0f * g / den : 0.0f;
+        coef[L + l] = den != 0.0f ? -2.0f * g * num / (den * den) : 0.0f;
+    }
+    __syncthreads();
+    const float *tb = t + (long long)b * nvox * L, *pb = p + (long long)b * nvox * L;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (long long)gridDim.x * 256) {
+        const float *tv = tb + v * L, *pv = pb + v * L;
+        float St = 0.0f, Sp = 0.0f;
+        for (int l = 0; l < L; ++l) { St += tv[l]; Sp += pv[l]; }
+        const float it = St != 0.0f ? 1.0f / St : 0.0f, ip = Sp != 0.0f ? 1.0f / Sp : 0.0f;
+        float dt = 0.0f, dp = 0.0f;              // sum_l g_l * normalised value
+        for (int l = 0; l < L; ++l) {
+            const float tn = tv[l] * it, pn = pv[l] * ip;
+            dp += (coef[l] * tn + coef[L + l] * pn) * pn;
+            dt += (coef[l] * pn + coef[L + l] * tn) * tn;
+        }
+        for (int l = 0; l < L; ++l) {
+            const float tn = tv[l] * it, pn = pv[l] * ip;
+            if (gp) gp[((long long)b * nvox + v) * L + l] = ((coef[l] * tn + coef[L + l] * pn) - dp) * ip;
+            if (gt) gt[((long long)b * nvox + v) * L + l] = ((coef[l] * pn + coef[L + l] * tn) - dt) * it;
+        }
+    }
+}
+
 // float4 version: L % 4 == 0 and 256 % (L/4) == 0, so that a thread keeps its 4 labels over the whole grid-stride loop
 __global__ __launch_bounds__(256) void dice_soft_bwd_vec(const nrt_f4 *__restrict__ t, const nrt_f4 *__restrict__ p,
                                                          const float *__restrict__ sums, const float *__restrict__ gdice,
@@ -529,6 +567,33 @@ __global__ __launch_bounds__(256) void warp_dice_bwd_rows(InterpBwdArgs ba, cons
     }
 }
 
+// nearest interpolation (utils.py:193-204): out[q, c] = vol[idx(round(loc_q)), c]  [* (1 - oob) + oob * fill].
+// tf.round has no gradient (d / d loc = 0); d / d vol is tf.gather's scatter-add of g[q, c] into the gathered element,
+// masked by (1 - oob) when a fill value is set.  One thread per output element, float atomics.
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void interpn_nearest_bwd(InterpBwdArgs ba) {
+    const InterpArgs &a = ba.f;
+    const int b = blockIdx.y;
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    const float *go = ba.gout + (long long)b * a.out_bs;
+    float *gv = ba.gvol + (long long)b * a.vol_bs;
+    const unsigned long long total = (unsigned long long)a.nout * (unsigned)a.C;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x; e < total;
+         e += (unsigned long long)gridDim.x * 256u) {
+        const unsigned q = (unsigned)(e / (unsigned)a.C);
+        const int c = (int)(e - (unsigned long long)q * (unsigned)a.C);
+        int qd[NRT_MAXD];
+        float p[NRT_MAXD];
+        decode<D>(a, q, qd);
+        load_loc<D, MODE>(a, locb, q, qd, p);
+        if (a.has_fill && out_of_bounds<D>(a, p)) continue;
+        long long idx = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) idx = idx * a.S[d] + nearest_1d(p[d], a.S[d]);
+        atomic_add_f32(&gv[idx * a.C + c], go[e]);
+    }
+}
+
 }  // namespace
 
 extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const float *grad_out, float *grad_vol,
@@ -592,6 +657,39 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
     return NRT_OK;
 }
 
+extern "C" int nrt_interpn_nearest_bwd_f32(const float *loc, const float *grad_out, float *grad_vol, int ndim, const int *vol_shape,
+                                           const int *out_shape, int channels, int batch, long long vol_batch_stride,
+                                           long long loc_batch_stride, int loc_mode, int has_fill, void *stream) {
+    if (!grad_out || !grad_vol) return NRT_ERR_INVALID_ARG;
+    InterpBwdArgs ba;
+    float dummy;
+    int rc = fill_args(ba.f, grad_vol, loc, &dummy, ndim, vol_shape, out_shape, channels, batch, vol_batch_stride,
+                       loc_batch_stride, loc_mode, has_fill);
+    if (rc != NRT_OK) return rc;
+    ba.f.out = nullptr;
+    ba.gout = grad_out; ba.gvol = grad_vol; ba.gloc = nullptr;
+    ba.tg.x_march = 0;
+    if (ba.f.nout == 0) return NRT_OK;
+    hipStream_t st = nrt_stream(stream);
+    unsigned long long nb = ((unsigned long long)ba.f.nout * (unsigned)channels + 255) / 256;
+    if (nb > 256ull * 64) nb = 256ull * 64;
+    dim3 grid((unsigned)nb, batch);
+#define NRT_NB(DD)                                                                                                              \
+    switch (loc_mode) {                                                                                                         \
+        case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((interpn_nearest_bwd<DD, NRT_LOC_ABSOLUTE>), grid, dim3(256), 0, st, ba); break; \
+        case NRT_LOC_SHIFT: hipLaunchKernelGGL((interpn_nearest_bwd<DD, NRT_LOC_SHIFT>), grid, dim3(256), 0, st, ba); break;       \
+        default: hipLaunchKernelGGL((interpn_nearest_bwd<DD, NRT_LOC_LINSPACE>), grid, dim3(256), 0, st, ba); break;               \
+    }
+    switch (ndim) {
+        case 1: NRT_NB(1) break;
+        case 2: NRT_NB(2) break;
+        default: NRT_NB(3) break;
+    }
+#undef NRT_NB
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
 extern "C" int nrt_dice_soft_bwd_f32(const float *y_true, const float *y_pred, const float *sums, const float *grad_dice,
                                      long long nvox, int nlabels, int batch, float laplace_smoothing, float *grad_pred,
                                      float *grad_true, void *stream) {
@@ -614,6 +712,20 @@ extern "C" int nrt_dice_soft_bwd_f32(const float *y_true, const float *y_pred, c
     if (blocks > 256u * 16u) blocks = 256u * 16u;
     hipLaunchKernelGGL(dice_soft_bwd, dim3(blocks, batch), dim3(256), 0, nrt_stream(stream), y_true, y_pred, sums, grad_dice,
                        nvox, nlabels, laplace_smoothing, grad_pred, grad_true);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_dice_soft_bwd_norm_f32(const float *y_true, const float *y_pred, const float *sums, const float *grad_dice,
+                                          long long nvox, int nlabels, int batch, float laplace_smoothing, float *grad_pred,
+                                          float *grad_true, void *stream) {
+    if (!y_true || !y_pred || !sums || !grad_dice || (!grad_pred && !grad_true)) return NRT_ERR_INVALID_ARG;
+    if (nvox < 0 || nlabels < 1 || nlabels > 4096 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (nvox == 0) return NRT_OK;
+    unsigned blocks = (unsigned)((nvox + 255) / 256);
+    if (blocks > 256u * 16u) blocks = 256u * 16u;
+    hipLaunchKernelGGL(dice_soft_bwd_norm, dim3(blocks, batch), dim3(256), (size_t)2 * nlabels * sizeof(float), nrt_stream(stream),
+                       y_true, y_pred, sums, grad_dice, nvox, nlabels, laplace_smoothing, grad_pred, grad_true);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

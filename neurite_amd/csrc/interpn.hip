@@ -26,6 +26,7 @@
 // path is bit-identical to the CPU restatement, not merely within 1e-5.
 
 #include "interpn_core.h"
+#include "lean.h"
 #include "wdd.h"
 
 namespace {
@@ -852,8 +853,11 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
     const bool can_lds = method == NRT_INTERP_LINEAR && lds_supported(a, ndim);
     const bool can_wdd = can_rows && method == NRT_INTERP_LINEAR && ndim == 3 && nrt_wdd_supported(a.S, a.O, channels) &&
                          ((uintptr_t)loc & 3) == 0;
+    const bool can_lean = method == NRT_INTERP_LINEAR && (loc_mode == NRT_LOC_LINSPACE || loc) &&
+                          nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride);
     if (variant == 0) {
         if (can_zrun) { variant = g_auto_c32_variant; if (tune == 0) tune = (variant >= 3) ? g_auto_c32_tune : 0; }
+        else if (can_lean) variant = 8;
         else if (can_lds) variant = 6;
         else if (can_rows) variant = 2;
         else variant = 1;
@@ -873,6 +877,9 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 4: launch_zrun(a, batch, loc_mode, variant, tune, st); break;
         case 5: launch_tile_any(a, batch, loc_mode, tune, st); break;
         case 6: launch_lds(a, batch, loc_mode, st); break;
+        case 8:
+            if (!can_lean) return NRT_ERR_UNSUPPORTED;
+            return nrt_lean_launch(&a, batch, loc_mode, st);
         case 7: {
             if (!can_wdd) return NRT_ERR_UNSUPPORTED;
             WddCall w;
@@ -901,6 +908,9 @@ extern "C" int nrt_interpn_add_f32(const float *vol, const float *loc, const flo
     a.fill_f = fill_value;
     a.addend = addend; a.addend_bs = addend_batch_stride;
     if (a.nout == 0) return NRT_OK;
+    if ((loc_mode == NRT_LOC_LINSPACE || loc) && (((uintptr_t)addend) & 15) == 0 && (addend_batch_stride * 4) % 16 == 0 &&
+        nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride))
+        return nrt_lean_launch(&a, batch, loc_mode, stream);
     if (lds_supported(a, ndim)) launch_lds(a, batch, loc_mode, nrt_stream(stream));
     else launch_generic<NRT_INTERP_LINEAR, float>(a, ndim, batch, loc_mode, nrt_stream(stream));
     NRT_CHECK_LAUNCH();

@@ -1,0 +1,382 @@
+// interpn, linear, 3-D, 1..4 channels (images, displacement fields): the instruction-lean kernel (variant 8).
+//
+// With 4..16 bytes per voxel the warp of an image or of a flow field (SpatialTransformer on C = 1 images, Resize(2) of the
+// C = 3 deformation at neurite/tf/models.py:804, VecInt / compose) is not bound by HBM but by instruction issue: the
+// LDS-staged kernel (variant 6) spends ~450 issue slots per voxel on bounding boxes, the box copy with its divisions and
+// 64-bit addresses (0.23-0.25 of the HBM roof at 160^3, profiles/r01_session50).  Here nothing is staged: the source of a
+// few-channel volume is small (16 MB at 160^3 x 1) and neighbouring lanes read neighbouring addresses, so the 8 corner
+// reads are L1 / L2 hits; what is left is the reference's arithmetic, strength-reduced:
+//   * a lane owns VPL consecutive-z output voxels (4 at C = 1, 2 at C = 2): x, y and their corner arithmetic are
+//     computed once per lane, the location is read with 16-byte loads, the result written with one 16-byte store;
+//   * blocks are laid out over (x-plane, chunk of the plane): the only division left is one multiply-high per lane;
+//   * tf.clip_by_value is one v_med3_f32, every corner address a 32-bit byte offset from a uniform base (one add per
+//     corner), channels of a corner one 4/8/12/16-byte load.
+// Same float32 op sequence as interpn_generic (one rounding per op, corners in itertools.product order) => bit-identical
+// results (tests/test_gpu_interpn.py); optional fill and addend epilogue (VecInt / compose).
+
+#include <stdlib.h>
+
+#include "interpn_core.h"
+#include "lean.h"
+
+namespace {
+
+template <int C> struct Vec;
+template <> struct Vec<1> { typedef float T; };
+template <> struct Vec<2> { typedef nrt_f2 T; };
+template <> struct Vec<3> { struct __attribute__((packed, aligned(4))) T { float v[3]; }; };
+template <> struct Vec<4> { typedef nrt_f4 T; };
+
+template <int C>
+__device__ __forceinline__ void load_c(const char *base, unsigned off, float (&v)[C]) {
+    if constexpr (C == 1) v[0] = *(const float *)(base + off);
+    else if constexpr (C == 2) { const nrt_f2 t = *(const nrt_f2 *)(base + off); v[0] = t[0]; v[1] = t[1]; }
+    else if constexpr (C == 3) {
+        const typename Vec<3>::T t = *(const typename Vec<3>::T *)(base + off);
+        v[0] = t.v[0]; v[1] = t.v[1]; v[2] = t.v[2];
+    } else { const nrt_f4 t = *(const nrt_f4 *)(base + off); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+}
+
+// utils.py:139-153 for one dimension; `up` = 1 when the upper corner is a different voxel (l1 != l0)
+__device__ __forceinline__ void lean_corner(float p, float mx, int imax, int &i0, int &up, float &w0, float &w1) {
+    const float f = floorf(p);                                           // :139
+    const float cl = __builtin_amdgcn_fmed3f(p, 0.0f, mx);               // :142  clip = median(p, 0, max)
+    const float l0 = __builtin_amdgcn_fmed3f(f, 0.0f, mx);               // :143
+    const float l1 = fminf(nrt_add(l0, 1.0f), mx);                       // :146  (l0 + 1 >= 1: the lower clip never binds)
+    i0 = min(max((int)l0, 0), imax);                                     // :147; the integer clamp only acts on NaN locations
+    up = (l1 > l0) ? 1 : 0;
+    w0 = nrt_sub(l1, cl);                                                // :152
+    w1 = nrt_sub(1.0f, w0);                                              // :153
+}
+
+template <int C, int VPL, int MODE>
+__global__ __launch_bounds__(256) void interpn_lean(InterpArgs a, unsigned lpr, unsigned m_lpr, unsigned cpp, unsigned nblk) {
+    const unsigned logical = nrt_xcd_block(blockIdx.x, gridDim.x);
+    if (logical >= nblk) return;
+    const unsigned x = logical / cpp, chunk = logical - x * cpp;          // uniform: scalar ALU
+    const unsigned g = chunk * 256u + threadIdx.x;                        // group of VPL voxels inside the x-plane
+    if (g >= (unsigned)a.O[1] * lpr) return;
+    const unsigned y = lpr == 1u ? g : __umulhi(g, m_lpr);                // g / lpr, exact for g * lpr < 2^32 (checked on the host)
+    const unsigned z0 = (g - y * lpr) * (unsigned)VPL;
+    const int b = blockIdx.y;
+    const char *vol = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    float *out = (float *)a.out + (long long)b * a.out_bs;
+    const unsigned q0 = nrt_mad24(nrt_mad24(x, (unsigned)a.O[1], y), (unsigned)a.O[2], z0);
+
+    // ---- locations of the VPL voxels -----------------------------------------------------------------------------
+    float raw[VPL * 3];
+    if (MODE != NRT_LOC_LINSPACE) {
+        const float *lp = locb + (size_t)q0 * 3u;
+        if constexpr (VPL == 4) {
+            const nrt_f4 t0 = ((const nrt_f4 *)lp)[0], t1 = ((const nrt_f4 *)lp)[1], t2 = ((const nrt_f4 *)lp)[2];
+            raw[0] = t0[0]; raw[1] = t0[1]; raw[2] = t0[2]; raw[3] = t0[3];
+            raw[4] = t1[0]; raw[5] = t1[1]; raw[6] = t1[2]; raw[7] = t1[3];
+            raw[8] = t2[0]; raw[9] = t2[1]; raw[10] = t2[2]; raw[11] = t2[3];
+        } else if constexpr (VPL == 2) {
+            const nrt_f2 t0 = ((const nrt_f2 *)lp)[0], t1 = ((const nrt_f2 *)lp)[1], t2 = ((const nrt_f2 *)lp)[2];
+            raw[0] = t0[0]; raw[1] = t0[1]; raw[2] = t1[0]; raw[3] = t1[1]; raw[4] = t2[0]; raw[5] = t2[1];
+        } else {
+            raw[0] = lp[0]; raw[1] = lp[1]; raw[2] = lp[2];
+        }
+    }
+    // ---- x and y: shared by the lane's voxels unless the location is per voxel ---------------------------------------
+    const float mxx = (float)(a.S[0] - 1), mxy = (float)(a.S[1] - 1), mxz = (float)(a.S[2] - 1);
+    const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
+    const unsigned str_x = SY * SZ * (unsigned)(C * 4), str_y = SZ * (unsigned)(C * 4), str_z = (unsigned)(C * 4);
+    float res[VPL][C];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const int qd[3] = {(int)x, (int)y, (int)z0 + k};
+        float p[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (MODE == NRT_LOC_ABSOLUTE) p[d] = raw[3 * k + d];
+            else if (MODE == NRT_LOC_SHIFT) p[d] = nrt_add((float)qd[d], raw[3 * k + d]);
+            else p[d] = (qd[d] == 0) ? 0.0f
+                      : ((qd[d] == a.O[d] - 1) ? (float)(a.S[d] - 1) : nrt_mul(a.delta[d], (float)qd[d]));
+        }
+        int ix, iy, iz, ux, uy, uz;
+        float w0x, w1x, w0y, w1y, w0z, w1z;
+        lean_corner(p[0], mxx, a.S[0] - 1, ix, ux, w0x, w1x);
+        lean_corner(p[1], mxy, a.S[1] - 1, iy, uy, w0y, w1y);
+        lean_corner(p[2], mxz, a.S[2] - 1, iz, uz, w0z, w1z);
+        const unsigned base = nrt_mad24(nrt_mad24((unsigned)ix, SY, (unsigned)iy), SZ, (unsigned)iz) * (unsigned)(C * 4);
+        const unsigned sx = ux ? str_x : 0u, sy = uy ? str_y : 0u, sz = uz ? str_z : 0u;
+        // (w_x * w_y) * w_z: the x*y products are shared by the two z corners (the rounding sequence of prod_n)
+        const float wxy[4] = {nrt_mul(w0x, w0y), nrt_mul(w0x, w1y), nrt_mul(w1x, w0y), nrt_mul(w1x, w1y)};
+        float v[8][C];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner)
+            load_c<C>(vol, base + ((corner & 4) ? sx : 0u) + ((corner & 2) ? sy : 0u) + ((corner & 1) ? sz : 0u), v[corner]);
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.0f;                       // :160
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const float wt = nrt_mul(wxy[corner >> 1], (corner & 1) ? w1z : w0z);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, v[corner][c]));     // :191
+        }
+        if (a.has_fill) {
+            const bool oob = (p[0] < 0.0f) || (p[0] > mxx) || (p[1] < 0.0f) || (p[1] > mxy) || (p[2] < 0.0f) || (p[2] > mxz);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = apply_fill(acc[c], oob, a.fill_f);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) res[k][c] = acc[c];
+    }
+    // ---- epilogue: optional addend, one vector store per lane ---------------------------------------------------------
+    float *po = out + (size_t)q0 * (unsigned)C;
+    if (a.addend) {
+        const float *pa = a.addend + (long long)b * a.addend_bs + (size_t)q0 * (unsigned)C;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) res[k][c] = nrt_add(pa[k * C + c], res[k][c]);
+    }
+    if constexpr (VPL * C == 4) {
+        const float *r = &res[0][0];
+        *(nrt_f4 *)po = (nrt_f4){r[0], r[1], r[2], r[3]};
+    } else if constexpr (VPL * C == 2) {
+        *(nrt_f2 *)po = (nrt_f2){res[0][0], res[VPL - 1][C - 1]};
+    } else {
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+#pragma unroll
+            for (int c = 0; c < C; ++c) po[k * C + c] = res[k][c];
+    }
+}
+
+// ---- tile form (per-voxel locations: ABSOLUTE / SHIFT) ---------------------------------------------------------------------
+// With a displacement field every voxel has its own location, so several voxels per lane share nothing, and lanes that are
+// 4 voxels apart in z make every corner read touch 2.5x the cache lines (measured: 0.29 ms against 0.18 ms of the LDS kernel
+// for 4 x 160^3 x 1).  Here a lane owns ONE voxel and a block a compact 2 x 4 x 32 (x, y, z) tile: a wave reads two 32-voxel
+// z-runs per corner (3-4 lines), and the tile's source box is ~110 lines that stay in L1 / L2 for the tile's 8 corner reads.
+template <int C, int MODE>
+__global__ __launch_bounds__(256) void interpn_lean_tile(InterpArgs a, int ltz, int lty, unsigned nTy, unsigned nTz, unsigned ntiles,
+                                                         unsigned tpb, unsigned nblk) {
+    // a block walks `tpb` consecutive tiles (z fastest): the scalar set-up is paid once, the tile index advances without
+    // divisions, and the location of the next tile's voxel is requested before the current tile's corners are blended
+    const unsigned blk = nrt_xcd_block(blockIdx.x, gridDim.x);
+    if (blk >= nblk) return;
+    const int ltx = 8 - ltz - lty;
+    unsigned tile = blk * tpb;
+    const unsigned tend = min(tile + tpb, ntiles);
+    unsigned tzi = tile % nTz, t2 = tile / nTz;                              // uniform: scalar ALU, once per block
+    unsigned tyi = t2 % nTy, txi = t2 / nTy;
+    const unsigned l = threadIdx.x;
+    const int lx = (int)(l >> (ltz + lty)), ly = (int)((l >> ltz) & ((1u << lty) - 1u)), lz = (int)(l & ((1u << ltz) - 1u));
+    const int b = blockIdx.y;
+    const char *vol = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const char *locb = (const char *)(a.loc + (long long)b * a.loc_bs);
+    float *out = (float *)a.out + (long long)b * a.out_bs;
+    const float *addb = a.addend ? a.addend + (long long)b * a.addend_bs : nullptr;
+    const float mxx = (float)(a.S[0] - 1), mxy = (float)(a.S[1] - 1), mxz = (float)(a.S[2] - 1);
+    const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
+    const unsigned str_x = SY * SZ * (unsigned)(C * 4), str_y = SZ * (unsigned)(C * 4), str_z = (unsigned)(C * 4);
+    const int O0 = a.O[0], O1 = a.O[1], O2 = a.O[2];
+
+    auto coords = [&](unsigned cx, unsigned cy, unsigned cz, int (&qd)[3], bool &valid) {
+        qd[0] = (int)(cx << ltx) + lx; qd[1] = (int)(cy << lty) + ly; qd[2] = (int)(cz << ltz) + lz;
+        valid = qd[0] < O0 && qd[1] < O1 && qd[2] < O2;
+        qd[0] = min(qd[0], O0 - 1); qd[1] = min(qd[1], O1 - 1); qd[2] = min(qd[2], O2 - 1);            // loads stay unconditional
+    };
+    auto flat = [&](const int (&qd)[3]) {
+        return nrt_mad24(nrt_mad24((unsigned)qd[0], (unsigned)O1, (unsigned)qd[1]), (unsigned)O2, (unsigned)qd[2]);
+    };
+    int qd[3];
+    bool valid;
+    coords(txi, tyi, tzi, qd, valid);
+    unsigned q = flat(qd);
+    float pn[3];
+    {
+        const float *lp = (const float *)(locb + (size_t)(nrt_times3(q) << 2));
+        pn[0] = lp[0]; pn[1] = lp[1]; pn[2] = lp[2];
+    }
+    for (; tile < tend; ++tile) {
+        float p[3] = {pn[0], pn[1], pn[2]};
+        const int cq[3] = {qd[0], qd[1], qd[2]};
+        const unsigned cqf = q;
+        const bool cvalid = valid;
+        // next tile (clamped to the last one of this block: its location load is then a repeat, never out of range)
+        if (tile + 1 < tend) {
+            if (++tzi == nTz) { tzi = 0; if (++tyi == nTy) { tyi = 0; ++txi; } }
+            coords(txi, tyi, tzi, qd, valid);
+            q = flat(qd);
+        }
+        {
+            const float *lp = (const float *)(locb + (size_t)(nrt_times3(q) << 2));
+            pn[0] = lp[0]; pn[1] = lp[1]; pn[2] = lp[2];
+        }
+        if (MODE == NRT_LOC_SHIFT) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) p[d] = nrt_add((float)cq[d], p[d]);
+        }
+        int ix, iy, iz, ux, uy, uz;
+        float w0x, w1x, w0y, w1y, w0z, w1z;
+        lean_corner(p[0], mxx, a.S[0] - 1, ix, ux, w0x, w1x);
+        lean_corner(p[1], mxy, a.S[1] - 1, iy, uy, w0y, w1y);
+        lean_corner(p[2], mxz, a.S[2] - 1, iz, uz, w0z, w1z);
+        const float wxy[4] = {nrt_mul(w0x, w0y), nrt_mul(w0x, w1y), nrt_mul(w1x, w0y), nrt_mul(w1x, w1y)};
+        const unsigned sx = ux ? str_x : 0u, sy = uy ? str_y : 0u, sz = uz ? str_z : 0u;
+        float v[8][C];
+        bool paired = false;
+        if constexpr (C <= 2) paired = a.S[2] >= 2;                      // uniform; a 1-voxel z extent has no pair to load
+        if (paired) {
+            // The texture-address unit spends ~1 cycle per LANE of a gather whose lanes are not consecutive (measured: 8.07 cache
+            // accesses per voxel, TA busy 88 %, profiles/r02_smallc): the two z corners of an (x, y) row are neighbours in
+            // memory, so ONE load of 2 C floats fetches both -- 4 lane accesses per voxel instead of 8.  At the upper border
+            // (z1 == z0 == SZ - 1) the pair starts one voxel earlier and both corners take its second half.
+            const unsigned izp = (unsigned)min(iz, a.S[2] - 2);
+            const bool second = (unsigned)iz != izp;                     // the lower corner is the pair's upper half
+            const unsigned base = nrt_mad24(nrt_mad24((unsigned)ix, SY, (unsigned)iy), SZ, izp) * (unsigned)(C * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t[2 * C];
+                load_c<(C <= 2 ? 2 * C : C)>(vol, base + ((r & 2) ? sx : 0u) + ((r & 1) ? sy : 0u), (float (&)[(C <= 2 ? 2 * C : C)])t);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float lo_v = second ? t[C + c] : t[c];
+                    v[2 * r][c] = lo_v;
+                    v[2 * r + 1][c] = uz ? t[C + c] : lo_v;
+                }
+            }
+        } else {
+            const unsigned base = nrt_mad24(nrt_mad24((unsigned)ix, SY, (unsigned)iy), SZ, (unsigned)iz) * (unsigned)(C * 4);
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner)
+                load_c<C>(vol, base + ((corner & 4) ? sx : 0u) + ((corner & 2) ? sy : 0u) + ((corner & 1) ? sz : 0u), v[corner]);
+        }
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.0f;                       // :160
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const float wt = nrt_mul(wxy[corner >> 1], (corner & 1) ? w1z : w0z);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, v[corner][c]));     // :191
+        }
+        if (a.has_fill) {
+            const bool oob = (p[0] < 0.0f) || (p[0] > mxx) || (p[1] < 0.0f) || (p[1] > mxy) || (p[2] < 0.0f) || (p[2] > mxz);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = apply_fill(acc[c], oob, a.fill_f);
+        }
+        if (addb) {
+            const float *pa = addb + (size_t)cqf * (unsigned)C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = nrt_add(pa[c], acc[c]);
+        }
+        if (cvalid) {
+            float *po = out + (size_t)cqf * (unsigned)C;
+            if constexpr (C == 4) __builtin_nontemporal_store((nrt_f4){acc[0], acc[1], acc[2], acc[3]}, (nrt_f4 *)po);
+            else if constexpr (C == 2) __builtin_nontemporal_store((nrt_f2){acc[0], acc[1]}, (nrt_f2 *)po);
+            else {
+                // C = 3: three 4-byte stores measured faster than one 12-byte store (0.331 vs 0.347 ms, 4 x 160^3 x 3)
+#pragma unroll
+                for (int c = 0; c < C; ++c) __builtin_nontemporal_store(acc[c], po + c);
+            }
+        }
+    }
+}
+
+template <int C>
+void launch_lean_tile(const InterpArgs &a, int batch, int mode, hipStream_t st) {
+    // 2 x 4 x 32 tiles; short z extents trade z for y / x
+    int ltz = 5, lty = 2;
+    while (ltz > 0 && (1 << (ltz - 1)) >= a.O[2]) { --ltz; ++lty; }
+    while (lty > 0 && (1 << (lty - 1)) >= a.O[1]) --lty;
+    const int ltx = 8 - ltz - lty;
+    const unsigned nTx = (a.O[0] + (1 << ltx) - 1) >> ltx, nTy = (a.O[1] + (1 << lty) - 1) >> lty, nTz = (a.O[2] + (1 << ltz) - 1) >> ltz;
+    const unsigned ntiles = nTx * nTy * nTz;
+    static int tpb_env = -1;
+    if (tpb_env < 0) { const char *e = getenv("NRT_LEAN_TPB"); tpb_env = e ? atoi(e) : 0; }
+    // tiles per block, measured at 4 x 160^3 (tools/lean_sweep.sh): C = 1 0.176 / 0.169 / 0.173 ms at 1 / 4 / 8; C = 3 0.298 / 0.323 / 0.331
+    unsigned tpb = tpb_env > 0 ? (unsigned)tpb_env : (C == 1 ? 4u : 1u);
+    while (tpb > 1 && (ntiles / tpb) * (unsigned)batch < 2048u) tpb >>= 1;     // keep the chip full on small volumes
+    const unsigned nblk = (ntiles + tpb - 1) / tpb;
+    dim3 grid(nrt_xcd_grid(nblk), batch), blk(256);
+    if (mode == NRT_LOC_ABSOLUTE)
+        hipLaunchKernelGGL((interpn_lean_tile<C, NRT_LOC_ABSOLUTE>), grid, blk, 0, st, a, ltz, lty, nTy, nTz, ntiles, tpb, nblk);
+    else
+        hipLaunchKernelGGL((interpn_lean_tile<C, NRT_LOC_SHIFT>), grid, blk, 0, st, a, ltz, lty, nTy, nTz, ntiles, tpb, nblk);
+}
+
+template <int C, int VPL>
+void launch_lean_cv(const InterpArgs &a, int batch, int mode, hipStream_t st) {
+    const unsigned lpr = (unsigned)a.O[2] / VPL;
+    const unsigned m_lpr = lpr == 1 ? 0u : (unsigned)(0x100000000ull / lpr) + 1u;
+    const unsigned groups = (unsigned)a.O[1] * lpr;
+    const unsigned cpp = (groups + 255u) / 256u;
+    const unsigned nblk = cpp * (unsigned)a.O[0];
+    dim3 grid(nrt_xcd_grid(nblk), batch), blk(256);
+    if (lpr == 1) {
+        // g / 1: the multiply-high constant would overflow; lpr == 1 means one group per row (y = g)
+        switch (mode) {
+            case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((interpn_lean<C, VPL, NRT_LOC_ABSOLUTE>), grid, blk, 0, st, a, 1u, 0u, cpp, nblk); break;
+            case NRT_LOC_SHIFT: hipLaunchKernelGGL((interpn_lean<C, VPL, NRT_LOC_SHIFT>), grid, blk, 0, st, a, 1u, 0u, cpp, nblk); break;
+            default: hipLaunchKernelGGL((interpn_lean<C, VPL, NRT_LOC_LINSPACE>), grid, blk, 0, st, a, 1u, 0u, cpp, nblk); break;
+        }
+        return;
+    }
+    switch (mode) {
+        case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((interpn_lean<C, VPL, NRT_LOC_ABSOLUTE>), grid, blk, 0, st, a, lpr, m_lpr, cpp, nblk); break;
+        case NRT_LOC_SHIFT: hipLaunchKernelGGL((interpn_lean<C, VPL, NRT_LOC_SHIFT>), grid, blk, 0, st, a, lpr, m_lpr, cpp, nblk); break;
+        default: hipLaunchKernelGGL((interpn_lean<C, VPL, NRT_LOC_LINSPACE>), grid, blk, 0, st, a, lpr, m_lpr, cpp, nblk); break;
+    }
+}
+
+}  // namespace
+
+// the kernel addresses the source with 32-bit byte offsets and 24-bit multiplies, and divides the in-plane group index by a
+// multiply-high that is exact while groups * lanes-per-row < 2^32
+bool nrt_lean_supported(const int *vol_shape, const int *out_shape, int channels, int ndim, const void *vol, const void *loc,
+                        const void *out, long long vol_bs, long long loc_bs) {
+    if (ndim != 3 || channels < 1 || channels > 4) return false;
+    unsigned long long vbytes = 4ull * channels;
+    for (int d = 0; d < 3; ++d) {
+        if (vol_shape[d] < 1 || out_shape[d] < 1 || vol_shape[d] >= (1 << 12) || out_shape[d] >= (1 << 12)) return false;
+        vbytes *= (unsigned long long)vol_shape[d];
+    }
+    if (vbytes >= (1ull << 32)) return false;
+    if ((unsigned long long)out_shape[1] * out_shape[2] * out_shape[2] >= (1ull << 32)) return false;
+    // vector accesses: C floats per source voxel, VPL * C per output group, VPL * 3 per location group.  Bases must be
+    // 16-byte aligned; the batch strides keep the alignment the channel count needs (the per-lane vector widths over z are
+    // chosen at launch from the z extent and the location stride)
+    if ((((uintptr_t)vol | (uintptr_t)out | (uintptr_t)loc) & 15) != 0) return false;
+    const int valign = channels == 4 ? 16 : (channels == 2 ? 8 : 4);
+    if ((vol_bs * 4) % valign != 0) return false;
+    (void)loc_bs;
+    return true;
+}
+
+int nrt_lean_launch(const void *args, int batch, int mode, void *stream) {
+    const InterpArgs &a = *(const InterpArgs *)args;
+    hipStream_t st = nrt_stream(stream);
+    if (mode != NRT_LOC_LINSPACE) {           // per-voxel locations: one voxel per lane, compact tiles
+        switch (a.C) {
+            case 1: launch_lean_tile<1>(a, batch, mode, st); break;
+            case 2: launch_lean_tile<2>(a, batch, mode, st); break;
+            case 3: launch_lean_tile<3>(a, batch, mode, st); break;
+            default: launch_lean_tile<4>(a, batch, mode, st); break;
+        }
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
+    switch (a.C) {
+        case 1:
+            // 4 voxels per lane: 16-byte location loads and stores need z % 4 == 0 (then nout % 4 == 0 and the contiguous batch
+            // strides of loc / out / addend are multiples of 16 bytes too; a foreign loc stride is checked)
+            if (a.O[2] % 4 == 0 && (a.loc_bs * 4) % 16 == 0 && (a.addend_bs * 4) % 16 == 0) launch_lean_cv<1, 4>(a, batch, mode, st);
+            else launch_lean_cv<1, 1>(a, batch, mode, st);
+            break;
+        case 2:
+            if (a.O[2] % 2 == 0 && (a.loc_bs * 4) % 8 == 0 && (a.addend_bs * 4) % 16 == 0) launch_lean_cv<2, 2>(a, batch, mode, st);
+            else launch_lean_cv<2, 1>(a, batch, mode, st);
+            break;
+        case 3: launch_lean_cv<3, 1>(a, batch, mode, st); break;
+        default: launch_lean_cv<4, 1>(a, batch, mode, st); break;
+    }
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

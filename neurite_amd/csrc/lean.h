@@ -1,0 +1,9 @@
+// interpn_lean.hip <-> interpn.hip: the instruction-lean few-channel linear kernel (variant 8)
+#pragma once
+
+// true when interpn_lean can run this call (3-D, 1..4 channels, 16-byte aligned tensors, sizes below the 32-bit / 24-bit
+// limits of its address arithmetic)
+bool nrt_lean_supported(const int *vol_shape, const int *out_shape, int channels, int ndim, const void *vol, const void *loc,
+                        const void *out, long long vol_bs, long long loc_bs);
+// args: the InterpArgs of the call (interpn_core.h)
+int nrt_lean_launch(const void *args, int batch, int mode, void *stream);

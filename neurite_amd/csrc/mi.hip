@@ -146,6 +146,27 @@ __global__ __launch_bounds__(256) void soft_quantize(const float *__restrict__ x
     }
 }
 
+// backward of soft_quantize (neurite/tf/utils/utils.py:1099-1172) wrt x with the bin centres held constant:
+//   out_b = exp(-alpha (xc - c_b)^2)  (or -alpha (xc - c_b)^2 with return_log),  xc = clip(x, lo, hi)
+//   d out_b / d x = [lo <= x <= hi] * (-2 alpha (xc - c_b)) * (out_b | 1)
+// One thread per voxel sums over the bins (g is [n, nb], read row-wise).
+__global__ __launch_bounds__(256) void soft_quantize_bwd(const float *__restrict__ x, const float *__restrict__ centers, float alpha,
+                                                         float lo, float hi, int ret_log, const float *__restrict__ g,
+                                                         float *__restrict__ gx, long long n, int nb) {
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
+        const float xv = x[v];
+        const float xc = clipf(xv, lo, hi);
+        const float pass = (xv >= lo && xv <= hi) ? 1.0f : 0.0f;          // tf.clip_by_value passes the gradient on the closed range
+        float acc = 0.0f;
+        for (int b = 0; b < nb; ++b) {
+            const float d = xc - centers[b];
+            const float dd = -2.0f * alpha * d;
+            acc += g[v * nb + b] * (ret_log ? dd : dd * expf(-alpha * (d * d)));
+        }
+        gx[v] = pass * acc;
+    }
+}
+
 // column sums of a [n, C] matrix per batch item: out[item][c] += sum_v x[item][v][c]  (atomics, zero-filled by the caller)
 __global__ __launch_bounds__(256) void colsum(const float *__restrict__ x, long long n, int C, float *__restrict__ out) {
     extern __shared__ float sm[];
@@ -217,6 +238,16 @@ extern "C" int nrt_soft_quantize_f32(const float *x, const float *centers, float
     if (n == 0) return NRT_OK;
     hipLaunchKernelGGL(soft_quantize, dim3(mblocks(n * nb_bins, 256)), dim3(256), 0, nrt_stream(stream), x, centers, alpha, min_clip,
                        max_clip, return_log, out, n, nb_bins);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_soft_quantize_bwd_f32(const float *x, const float *centers, float alpha, float min_clip, float max_clip,
+                                         int return_log, const float *grad_out, float *grad_x, long long n, int nb_bins, void *stream) {
+    if (!x || !centers || !grad_out || !grad_x || n < 0 || nb_bins < 1) return NRT_ERR_INVALID_ARG;
+    if (n == 0) return NRT_OK;
+    hipLaunchKernelGGL(soft_quantize_bwd, dim3(mblocks(n, 256)), dim3(256), 0, nrt_stream(stream), x, centers, alpha, min_clip, max_clip,
+                       return_log, grad_out, grad_x, n, nb_bins);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

@@ -88,8 +88,6 @@ class _SoftDiceFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_dice):
-        if ctx.normalize:
-            raise NotImplementedError('neurite_amd: backward of Dice(normalize=True) is not implemented')
         t, p, sums = ctx.saved_tensors
         lib = _lib.lib()
         dev = t.device
@@ -99,10 +97,11 @@ class _SoftDiceFn(torch.autograd.Function):
         gt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
         gp = torch.empty_like(p) if ctx.needs_input_grad[1] else None
         if t.numel() and (gt is not None or gp is not None):
+            fn = lib.nrt_dice_soft_bwd_norm_f32 if ctx.normalize else lib.nrt_dice_soft_bwd_f32
             with torch.cuda.device(dev):
-                rc = lib.nrt_dice_soft_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(sums), _lib.ptr(g), V, L, B,
-                                               float(ctx.eps), _lib.ptr(gp), _lib.ptr(gt), _lib.stream_ptr(dev))
-            _lib.check(rc, 'nrt_dice_soft_bwd_f32')
+                rc = fn(_lib.ptr(t), _lib.ptr(p), _lib.ptr(sums), _lib.ptr(g), V, L, B, float(ctx.eps), _lib.ptr(gp),
+                        _lib.ptr(gt), _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_dice_soft_bwd(_norm)_f32')
         return gt, gp, None, None, None
 
 
@@ -378,9 +377,10 @@ class _MseProbFn(torch.autograd.Function):
         L = p.shape[-1]
         tc, pc = t.contiguous(), p.contiguous()
         one = torch.ones(L, dtype=torch.float32, device=dev)
+        minus, zero = -one, torch.zeros_like(one)              # named: the pointers handed to the launch must stay alive
         d = torch.empty_like(pc)
         with torch.cuda.device(dev):
-            rc = lib.nrt_channel_axpby_f32(_lib.ptr(tc), _lib.ptr(pc), _lib.ptr(one), _lib.ptr(-one), _lib.ptr(torch.zeros_like(one)),
+            rc = lib.nrt_channel_axpby_f32(_lib.ptr(tc), _lib.ptr(pc), _lib.ptr(one), _lib.ptr(minus), _lib.ptr(zero),
                                            _lib.ptr(d), pc.numel(), L, _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_channel_axpby_f32')
         sums, _, _ = dice_partial_sums(d, d)

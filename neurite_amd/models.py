@@ -376,11 +376,23 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, g):
         x, lo, kernel, out = ctx.saved_tensors
         mod, up = ctx.mod, ctx.up
-        if mod.padding != 'same':
-            raise NotImplementedError("neurite_amd: conv backward is implemented for padding='same'")
         lib = _lib.lib()
         dev = g.device
         dpre = _act_bwd(g, out, mod.act)
+        if mod.padding != 'same':
+            # A 'valid' convolution is the 'same' convolution restricted to the outputs whose window lies inside the volume
+            # (output v = same-output v + pb, pb = ((k - 1) * dilation) // 2 as TF pads).  Its backward is therefore the
+            # 'same' backward of the output gradient embedded in zeros at those positions (nrt_pad3d): the positions that
+            # were never computed contribute nothing, and no window reads outside the input.
+            S = list(x.shape[1:4])
+            pb = [((mod.ksize3[d] - 1) * mod.dilation) // 2 for d in range(3)]
+            padded = torch.empty([dpre.shape[0]] + S + [dpre.shape[-1]], dtype=dpre.dtype, device=dev)
+            dpre = dpre.contiguous()
+            with torch.cuda.device(dev):
+                rc = lib.nrt_pad3d(_lib.ptr(dpre), _lib.ptr(padded), dpre.shape[0], _lib.ints(list(dpre.shape[1:4])), _lib.ints(pb),
+                                   _lib.ints(S), dpre.shape[-1] * 4, 0, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_pad3d')
+            dpre = padded
         need_x, need_lo, need_w, need_b = ctx.needs_input_grad[:4]
         dx = dlo = dw = db = None
         c0 = x.shape[-1]

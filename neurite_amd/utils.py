@@ -51,8 +51,9 @@ def _maybe_tracked(fn, *tensors):
 
 class _InterpnFn(torch.autograd.Function):
     """
-    Linear interpn with the hand-written backward of csrc/backward.hip: gradients wrt the volume (scatter-add)
-    and wrt the sampling locations / displacement field (what TF's autodiff derives from utils.py:137-213).
+    interpn (float32, 1-3-D) with the hand-written backward of csrc/backward.hip: gradients wrt the volume (scatter-add)
+    and, for linear interpolation, wrt the sampling locations / displacement field (what TF's autodiff derives from
+    utils.py:137-213); nearest interpolation passes no gradient to the locations (tf.round).
     """
 
     @staticmethod
@@ -83,6 +84,21 @@ def _launch_interpn_bwd(vol, loc, grad_out, cfg, need_vol, need_loc):
     Cc, D = vol.shape[-1], len(S)
     out_spatial = [int(s) for s in cfg['out_spatial']]
     g = grad_out.to(torch.float32).contiguous()
+    if cfg['method'] == _lib.INTERP_NEAREST:
+        # utils.py:193-204: tf.round has no gradient (TF returns None for loc; zeros here so that optimisers see a tensor),
+        # the volume receives tf.gather's scatter-add
+        gvol = torch.zeros_like(vol) if need_vol else None
+        gloc = torch.zeros_like(loc) if (need_loc and loc is not None) else None
+        if gvol is not None and g.numel():
+            nvol = int(np.prod(S)) * Cc
+            nloc = int(np.prod(out_spatial)) * D
+            loc_bs = 0 if (single or loc is None) else nloc
+            with torch.cuda.device(dev):
+                rc = lib.nrt_interpn_nearest_bwd_f32(_lib.ptr(loc), _lib.ptr(g), _lib.ptr(gvol), D, _lib.ints(S),
+                                                     _lib.ints(out_spatial), Cc, B, nvol, loc_bs, cfg['loc_mode'],
+                                                     int(cfg['fill_value'] is not None), _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_interpn_nearest_bwd_f32')
+        return gvol, gloc
     gvol = torch.zeros_like(vol) if need_vol else None
     gloc = None
     if need_loc:
@@ -112,7 +128,7 @@ def _interp_op(vol, loc, out_spatial, loc_mode, method, fill_value, batched, sin
     needs = torch.is_grad_enabled() and (vol.requires_grad or (loc is not None and loc.requires_grad))
     if not needs:
         return _launch_interpn(vol, loc, **cfg)
-    if method == _lib.INTERP_LINEAR and vol.dtype == torch.float32 and len(cfg['out_spatial']) <= 3:
+    if vol.dtype == torch.float32 and len(cfg['out_spatial']) <= 3:
         return _InterpnFn.apply(vol, loc, cfg)
     return _NoBackward.apply(lambda: _launch_interpn(vol, loc, **cfg), vol, *([] if loc is None else [loc]))
 
@@ -683,19 +699,53 @@ def soft_quantize(x, bin_centers=None, nb_bins=16, alpha=1, min_clip=-np.inf, ma
     dev = _lib.require_device(x)
     if x.dtype != torch.float32:
         raise NotImplementedError('soft_quantize: float32 tensors, got %s' % x.dtype)
-    if torch.is_grad_enabled() and x.requires_grad:
-        raise NotImplementedError('neurite_amd: soft_quantize has no backward (MutualInformation.volumes / channelwise '
-                                  'differentiate through the fused histogram kernel instead)')
     x = x.contiguous()
-    centers = _bin_centers(x, bin_centers, nb_bins)
+    centers = _bin_centers(x.detach(), bin_centers, nb_bins)
+    cfg = (float(alpha), float(min_clip), float(max_clip), int(bool(return_log)))
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _SoftQuantizeFn.apply(x, centers, cfg)
+    return _soft_quantize_fwd(x, centers, cfg)
+
+
+def _soft_quantize_fwd(x, centers, cfg):
+    lib = _lib.lib()
+    dev = x.device
     nb = centers.numel()
     out = torch.empty(tuple(x.shape) + (nb,), dtype=torch.float32, device=dev)
     if x.numel():
         with torch.cuda.device(dev):
-            rc = lib.nrt_soft_quantize_f32(_lib.ptr(x), _lib.ptr(centers), float(alpha), float(min_clip), float(max_clip),
-                                           int(bool(return_log)), _lib.ptr(out), x.numel(), nb, _lib.stream_ptr(dev))
+            rc = lib.nrt_soft_quantize_f32(_lib.ptr(x), _lib.ptr(centers), cfg[0], cfg[1], cfg[2], cfg[3], _lib.ptr(out),
+                                           x.numel(), nb, _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_soft_quantize_f32')
     return out
+
+
+class _SoftQuantizeFn(torch.autograd.Function):
+    """soft_quantize with its backward wrt x (csrc/mi.hip: soft_quantize_bwd).  The bin centres are treated as constants:
+    when they come from tf.linspace(min(x), max(x)) the reference also sends a term to the two extremal voxels -- the same
+    convention as the fused MutualInformation backward."""
+
+    @staticmethod
+    def forward(ctx, x, centers, cfg):
+        ctx.save_for_backward(x, centers)
+        ctx.cfg = cfg
+        with torch.no_grad():
+            return _soft_quantize_fwd(x, centers, cfg)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, centers = ctx.saved_tensors
+        cfg = ctx.cfg
+        lib = _lib.lib()
+        dev = x.device
+        g = g.to(torch.float32).contiguous()
+        gx = torch.empty_like(x)
+        if x.numel():
+            with torch.cuda.device(dev):
+                rc = lib.nrt_soft_quantize_bwd_f32(_lib.ptr(x), _lib.ptr(centers), cfg[0], cfg[1], cfg[2], cfg[3], _lib.ptr(g),
+                                                   _lib.ptr(gx), x.numel(), centers.numel(), _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_soft_quantize_bwd_f32')
+        return gx, None, None
 
 
 def soft_digitize(*args, **kwargs):

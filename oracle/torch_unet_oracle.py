@@ -23,10 +23,10 @@ def _cl(x):
     return x.permute(0, 2, 3, 4, 1)
 
 
-def conv3d_same(x, kernel, bias, dilation=1, activation=None):
-    """x [B,X,Y,Z,Cin] channels-last, kernel [kx,ky,kz,Cin,Cout]."""
+def conv3d_same(x, kernel, bias, dilation=1, activation=None, padding='same'):
+    """x [B,X,Y,Z,Cin] channels-last, kernel [kx,ky,kz,Cin,Cout]; Keras Conv3D with 'same' (odd kernels) or 'valid' padding."""
     w = kernel.permute(4, 3, 0, 1, 2)
-    pad = [dilation * (k - 1) // 2 for k in kernel.shape[:3]]
+    pad = [dilation * (k - 1) // 2 for k in kernel.shape[:3]] if padding == 'same' else 0
     y = Fn.conv3d(_cf(x), w, bias, padding=pad, dilation=dilation)
     y = _cl(y)
     if activation == 'elu':
@@ -70,7 +70,7 @@ def forward(net, x, params=None, return_tensors=None, dropout_scales=None, bn_tr
                 src = torch.cat([src, upsample(t[op['lo']], op['up'])], -1)
             m = net.layers_by_name[name]
             k, b = params[name]
-            t[name] = conv3d_same(src, k, b, m.dilation, m.activation)
+            t[name] = conv3d_same(src, k, b, m.dilation, m.activation, m.padding)
         elif kind == 'dropout':
             t[name] = t[op['src']]
             if dropout_scales and name in dropout_scales:             # training mode: the recorded [B, C] keep / (1 - rate) factors

@@ -99,12 +99,43 @@ def test_interpn_backward_partial_requires(dev):
         close(N(ll[d].grad), lo1.grad.numpy()[..., d], 'list loc %d' % d)
 
 
-def test_nearest_backward_is_an_error(dev):
-    v = torch.randn(5, 5, 5, 2, device=dev, requires_grad=True)
-    l = torch.rand(4, 4, 4, 3, device=dev) * 4
-    out = ne.utils.interpn(v, l, interp_method='nearest')
-    with pytest.raises(NotImplementedError):
-        out.sum().backward()
+def test_nearest_backward(dev):
+    """nearest interpolation (utils.py:193-204): the volume receives tf.gather's scatter-add (masked where a fill value applies),
+    the locations no gradient (tf.round); 3-D / 2-D, interpn / SpatialTransformer / Resize"""
+    rng = np.random.default_rng(12)
+    for S, Cc, O in (((5, 6, 4), 2, (4, 7, 5)), ((9, 7), 3, (6, 8))):
+        D = len(S)
+        vol = rng.standard_normal(S + (Cc,)).astype(F)
+        loc = rng.uniform(-1.5, max(S) + 0.5, O + (D,)).astype(F)
+        w = rng.standard_normal(O + (Cc,)).astype(F)
+        for fill in (None, 0.5):
+            v = G(vol, dev, True)
+            l = G(loc, dev, True)
+            out = ne.utils.interpn(v, l, interp_method='nearest', fill_value=fill)
+            (out * G(w, dev)).sum().backward()
+            idx = [np.clip(np.rint(loc[..., d]).astype(np.int64), 0, S[d] - 1) for d in range(D)]
+            keep = np.ones(O, bool) if fill is None else ~np.any([(loc[..., d] < 0) | (loc[..., d] > S[d] - 1) for d in range(D)], 0)
+            want = np.zeros(S + (Cc,), np.float64)
+            np.add.at(want, tuple(i[keep] for i in idx), w[keep].astype(np.float64))
+            close(N(v.grad), want, 'nearest grad_vol %s' % (fill,))
+            assert float(l.grad.abs().max()) == 0.0
+    # layers: SpatialTransformer(nearest) and Resize(nearest) are differentiable wrt the volume
+    vol = rng.standard_normal((2, 6, 5, 7, 3)).astype(F)
+    trf = rng.normal(0, 1.5, (2, 6, 5, 7, 3)).astype(F)
+    v = G(vol, dev, True)
+    ne.layers.SpatialTransformer(interp_method='nearest')([v, G(trf, dev)]).square().sum().backward()
+    vo = D64(vol, True)
+    grid = np.stack(np.meshgrid(*[np.arange(s, dtype=F) for s in (6, 5, 7)], indexing='ij'), -1)
+    tot = 0
+    for b in range(2):
+        loc = (grid + trf[b]).astype(F)
+        ii = [torch.from_numpy(np.clip(np.rint(loc[..., d]).astype(np.int64), 0, s - 1)) for d, s in enumerate((6, 5, 7))]
+        tot = tot + vo[b][ii[0], ii[1], ii[2]].square().sum()
+    tot.backward()
+    close(N(v.grad), vo.grad.numpy(), 'SpatialTransformer nearest grad_vol')
+    v = G(vol, dev, True)
+    ne.layers.Resize(2, interp_method='nearest')(v).sum().backward()
+    assert abs(float(v.grad.sum()) - 2 * 12 * 10 * 14 * 3) < 1e-3
 
 
 def _shift_oracle(vol, shift, fill=None):
@@ -232,6 +263,35 @@ def test_soft_dice_backward(dev, eps):
     po3 = D64(p3, True)
     (-go.soft_dice(D64(t3), po3).mean()).backward()
     close(N(p3t.grad), po3.grad.numpy(), 'grad_pred L=3')
+
+
+@pytest.mark.parametrize('L', [8, 5])
+def test_soft_dice_normalize_backward(dev, L):
+    """Dice(normalize=True) (metrics.py:434-436): gradients wrt the RAW maps through the per-voxel divide_no_nan normalisation,
+    against float64 autograd; a voxel whose labels sum to zero gets no gradient"""
+    rng = np.random.default_rng(19 + L)
+    B, S = 2, (6, 5, 7)
+    t = rng.uniform(0, 2, (B,) + S + (L,)).astype(F)
+    p = rng.uniform(0, 3, (B,) + S + (L,)).astype(F)
+    p[0, 0, 0, 0] = 0                                           # divide_no_nan: normalised to all-zero
+    t[1, 2, 3, 4] = 0
+    wl = rng.uniform(0.5, 1.5, (1, L)).astype(F)
+    tt, pt = G(t, dev, True), G(p, dev, True)
+    m = ne.metrics.Dice(weights=wl, normalize=True, check_input_limits=False, laplace_smoothing=0.1)
+    loss = -m.mean_dice(tt, pt)
+    loss.backward()
+    to, po = D64(t, True), D64(p, True)
+
+    def norm(x):
+        s = x.sum(-1, keepdim=True)
+        z = s == 0
+        return torch.where(z, torch.zeros_like(x), x / torch.where(z, torch.ones_like(s), s))
+    ref = -(go.soft_dice(norm(to), norm(po), 0.1) * D64(wl)).mean()
+    ref.backward()
+    close(float(loss.detach()), float(ref.detach()), 'loss')
+    close(N(pt.grad), po.grad.numpy(), 'grad_pred')
+    close(N(tt.grad), to.grad.numpy(), 'grad_true')
+    assert float(pt.grad[0, 0, 0, 0].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('logits,ls,reduction', [(False, 0., 'auto'), (False, 0.1, 'sum'), (True, 0., 'auto'),

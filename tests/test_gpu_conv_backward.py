@@ -74,6 +74,40 @@ def test_conv_backward(dev, cin, cout, k, dil, act, shape):
     close(N(xg.grad), xo.grad.numpy(), 'grad_x')
 
 
+@pytest.mark.parametrize('cin,cout,k,dil,act,shape', [
+    (16, 16, 3, 1, 'elu', (9, 10, 17)), (8, 12, 3, 2, 'relu', (11, 9, 13)), (4, 8, (1, 3, 3), 1, None, (1, 9, 12)),
+    (1, 16, 3, 1, 'elu', (8, 9, 10)),
+])
+def test_conv_backward_valid_padding(dev, cin, cout, k, dil, act, shape):
+    """padding='valid' (conv_enc / conv_dec pass `padding` to every Conv, neurite/tf/models.py:1345): forward and gradients against
+    float64 autograd.  The backward embeds the output gradient in zeros at the positions a 'same' convolution would also compute
+    and runs the 'same' backward kernels."""
+    rng = np.random.default_rng(cin * 10 + cout + dil)
+    ks = (k,) * 3 if isinstance(k, int) else tuple(k)
+    B = 2
+    conv = M._Conv('c', cin, cout, ks, dilation=dil, padding='valid', activation=act).to(dev)
+    kern = (rng.standard_normal(ks + (cin, cout)) * 0.2).astype(F)
+    bias = (rng.standard_normal(cout) * 0.1).astype(F)
+    with torch.no_grad():
+        conv.kernel.copy_(G(kern, dev)); conv.bias.copy_(G(bias, dev))
+    x = rng.standard_normal((B,) + shape + (cin,)).astype(F)
+    oshape = tuple(shape[d] - (ks[d] - 1) * dil for d in range(3))
+    w = rng.standard_normal((B,) + oshape + (cout,)).astype(F)
+    xg = G(x, dev, True)
+    y = conv(xg)
+    assert tuple(y.shape) == (B,) + oshape + (cout,)
+    (y * G(w, dev)).sum().backward()
+    xo = torch.from_numpy(x).double().requires_grad_()
+    ko = torch.from_numpy(kern).double().requires_grad_()
+    bo = torch.from_numpy(bias).double().requires_grad_()
+    yo = tuo.conv3d_same(xo, ko, bo, dil, act, padding='valid')
+    (yo * torch.from_numpy(w).double()).sum().backward()
+    close(N(y), yo.detach().numpy(), 'forward', 1e-4)
+    close(N(conv.kernel.grad), ko.grad.numpy(), 'grad_kernel')
+    close(N(conv.bias.grad), bo.grad.numpy(), 'grad_bias')
+    close(N(xg.grad), xo.grad.numpy(), 'grad_x')
+
+
 def test_conv_backward_fused_upsample_concat_loader(dev):
     """decoder conv: input = concat(skip, upsample(lo)) never materialised in the forward; grads to both sources"""
     rng = np.random.default_rng(5)

@@ -137,6 +137,65 @@ def test_lds_staged_kernel(dev, C):
             assert bits_equal(got[b], npo.resize(vb[b], z)), ('resize', z)
 
 
+@pytest.mark.parametrize('C', [1, 2, 3, 4])
+@pytest.mark.parametrize('S', [(12, 10, 40), (19, 13, 37), (9, 16, 4), (5, 7, 1)])
+def test_lean_kernel(dev, C, S):
+    """variant 8 (csrc/interpn_lean.hip: several consecutive-z voxels per lane, no staging) == generic kernel == oracle, bit
+    for bit: smooth / rough / edge-valued fields, fill, absolute / shift / linspace locations, z extents that are and are not
+    multiples of the voxels-per-lane count, addend epilogue, non-finite locations stay memory-safe."""
+    rng = np.random.default_rng(80 + C + S[2])
+    vol = rng.standard_normal(S + (C,)).astype(F)
+    fields = {
+        'smooth': N(synth.smooth_displacement(5, 40, 2.0, coarse=6))[:S[0], :S[1], :S[2]].copy(),
+        'rough': rng.uniform(-30, 30, S + (3,)).astype(F),
+        'edge': rng.choice(np.array([-3, -1, -0.5, 0, 0.5, 1, 2, 7.5], F), S + (3,)).astype(F),
+    }
+    lib = ne._lib.lib()
+    for kind, shift in fields.items():
+        for fill in (None, 0.25):
+            want = co.interpn(vol, shift, 'linear', fill, loc_mode=1)
+            st = ne.layers.SpatialTransformer(fill_value=fill)
+            st._variant = 8
+            got = N(st([G(vol[None], dev), G(shift[None], dev)]))[0]
+            assert bits_equal(got, want), (kind, fill)
+            got = N(ne.utils.interpn(G(vol, dev), G(ijk(S) + shift, dev), fill_value=fill, _variant=8))
+            assert bits_equal(got, co.interpn(vol, ijk(S) + shift, 'linear', fill)), (kind, fill, 'abs')
+    # batched, other output grid; auto selection takes the same kernel for these shapes
+    B, So = 3, (7, 9, 8)
+    vb = rng.standard_normal((B,) + S + (C,)).astype(F)
+    tb = rng.normal(0, 2, (B,) + So + (3,)).astype(F)
+    st = ne.layers.SpatialTransformer()
+    st._variant = 8
+    assert bits_equal(N(st([G(vb, dev), G(tb, dev)])), npo.spatial_transformer(vb, tb))
+    assert bits_equal(N(ne.layers.SpatialTransformer()([G(vb, dev), G(tb, dev)])), npo.spatial_transformer(vb, tb))
+    if S[2] > 1:
+        for z in (2, 0.5):
+            got = N(ne.layers.Resize(z)(G(vb, dev)))
+            for b in range(B):
+                assert bits_equal(got[b], npo.resize(vb[b], z)), ('resize', z)
+    # NaN / Inf locations: any value, no fault
+    bad = fields['smooth'].copy()
+    bad[::3, ::2, ::2, 0] = np.nan
+    bad[1::3, ::2, ::2, 1] = np.inf
+    bad[2::3, 1::2, ::2, 2] = -np.inf
+    st = ne.layers.SpatialTransformer(fill_value=0.0)
+    st._variant = 8
+    out = st([G(vol[None], dev), G(bad[None], dev)])
+    torch.cuda.synchronize()
+    assert out.shape == (1,) + S + (C,)
+
+
+def test_lean_kernel_warp_add(dev):
+    """compose / VecInt update b + transform(a, b) at a size that takes the lean kernel (C = 3, 16-byte aligned tensors)"""
+    rng = np.random.default_rng(72)
+    S = (20, 16, 32)
+    a = (rng.standard_normal(S + (3,)) * 2).astype(F)
+    b = N(synth.smooth_displacement(9, 32, 2.0, coarse=4))[:20, :16, :32].copy()
+    assert bits_equal(N(ne.utils.compose([G(a, dev), G(b, dev)])), npo.compose([a, b]))
+    out = N(ne.layers.VecInt(int_steps=4)(G(b[None], dev)))
+    assert bits_equal(out[0], npo.integrate_vec(b, 'ss', 4))
+
+
 def test_lds_staged_warp_add(dev):
     """compose / integrate update b + transform(a, b) at a size that takes the LDS kernel"""
     rng = np.random.default_rng(71)
@@ -270,15 +329,21 @@ def test_properties(dev):
 
 
 def test_backward_is_loud(dev):
-    """ops without a backward kernel raise in backward instead of returning a silent zero gradient
-    (linear interpolation has one: tests/test_gpu_backward.py)"""
+    """ops without a backward kernel raise in backward instead of returning a silent zero gradient (the reference's hard Dice is
+    not differentiable either, metrics.py:454-458); linear and nearest interpolation have one (tests/test_gpu_backward.py)"""
     vol = torch.randn(1, 6, 6, 6, 4, device=dev, requires_grad=True)
     trf = torch.zeros(1, 6, 6, 6, 3, device=dev)
-    out = ne.layers.SpatialTransformer(interp_method='nearest')([vol, trf])
-    with pytest.raises(NotImplementedError, match='backward'):
-        out.sum().backward()
-    ne.layers.SpatialTransformer()([vol, trf]).sum().backward()
-    assert vol.grad is not None and torch.allclose(vol.grad, torch.ones_like(vol.grad))
+    for method in ('nearest', 'linear'):
+        vol.grad = None
+        ne.layers.SpatialTransformer(interp_method=method)([vol, trf]).sum().backward()
+        assert vol.grad is not None and torch.allclose(vol.grad, torch.ones_like(vol.grad))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        d = ne.metrics.HardDice(nb_labels=4, input_type='prob').dice(torch.softmax(vol, -1), torch.softmax(vol, -1))
+    if d.requires_grad:
+        with pytest.raises(NotImplementedError, match='backward'):
+            d.sum().backward()
 
 
 def test_full_size_cfg2_spatial_transformer(dev):

@@ -116,8 +116,44 @@ def test_mi_backward(dev):
             want = want.numpy()
             err = np.abs(N(got) - want).max() / np.abs(want).max()
             assert err < 2e-3, (nm, err)
-    with pytest.raises(NotImplementedError, match='soft_quantize has no backward'):
-        MI().volume_seg(G(x[..., :1], dev, True), G(np.abs(y), dev))
+    # volume_seg: the image side differentiates through soft_quantize (csrc/mi.hip: soft_quantize_bwd), the maps through the
+    # 1x1 contractions; oracle = float64 autograd of exp(-alpha (x - c)^2) -> MutualInformation.maps, centres held constant
+    mi = MI()
+    xv = G(x[..., :1], dev, True)
+    seg = rng.dirichlet(np.ones(mi.nb_bins), x.shape[:-1])           # maps() wants as many labels as bins (metrics.py:249)
+    val = mi.volume_seg(xv, G(seg.astype(F), dev))
+    (-val.sum()).backward()
+    cen = ne.utils._bin_centers(xv.detach()[..., 0].contiguous(), None, mi.nb_bins).cpu().double()
+    xo = torch.from_numpy(x[..., 0]).double().requires_grad_()
+    xq = torch.exp(-float(mi.soft_bin_alpha) * (xo[..., None] - cen) ** 2)
+    ref = go.mi_maps(xq, torch.from_numpy(seg).double())
+    (-ref.sum()).backward()
+    np.testing.assert_allclose(N(val), ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    want = xo.grad.numpy()[..., None]
+    err = np.abs(N(xv.grad) - want).max() / np.abs(want).max()
+    assert err < 2e-3, err
+
+
+def test_soft_quantize_backward(dev):
+    """d soft_quantize / d x (bin centres constant; clip passes the gradient on the closed range) vs float64 autograd, plain and
+    return_log forms"""
+    import torch
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-0.2, 1.2, (2, 9, 7, 5)).astype(F)
+    cen = np.array([0.0, 0.3, 0.55, 1.0], F)
+    for ret_log in (False, True):
+        for lo, hi in ((-np.inf, np.inf), (0.1, 0.9)):
+            xg = G(x, dev, True)
+            out = ne.utils.soft_quantize(xg, bin_centers=cen, nb_bins=None, alpha=2.5, min_clip=lo, max_clip=hi, return_log=ret_log)
+            w = rng.standard_normal(out.shape)
+            (out.double() * G(w, dev)).sum().backward()
+            xo = torch.from_numpy(x).double().requires_grad_()
+            xc = torch.clamp(xo, lo, hi)
+            lg = -2.5 * (xc[..., None] - torch.from_numpy(cen).double()) ** 2
+            ref = lg if ret_log else torch.exp(lg)
+            (ref * torch.from_numpy(w)).sum().backward()
+            np.testing.assert_allclose(N(out), ref.detach().numpy(), rtol=2e-5, atol=1e-6)
+            np.testing.assert_allclose(N(xg.grad), xo.grad.numpy(), rtol=2e-4, atol=1e-5 * np.abs(xo.grad.numpy()).max())
 
 
 def test_mi_maps_backward(dev):
