@@ -66,6 +66,8 @@ def parse():
     ap.add_argument('--unet', action='store_true', help='only run the unet forward benchmark (BASELINE config 3)')
     ap.add_argument('--no-unet', action='store_true', help='skip the unet forward measurement in the default run')
     ap.add_argument('--unfused', action='store_true', help='run the drop-in two-kernel pipeline instead of the fused kernel')
+    ap.add_argument('--no-batch1', action='store_true',
+                    help='skip the extra batch = 1 runs (profiling: every launch of the gather kernels then has the headline shape)')
     ap.add_argument('--graph', action='store_true',
                     help="capture a step's compute launches (gather + Dice second stage + mean pair) in one hipGraph")
     return ap.parse_args()
@@ -691,7 +693,7 @@ def main():
     o_elapsed, o_k0, o_k1, o_m = r_other['elapsed'], r_other['k0_ms'], r_other['k1_ms'], r_other['mean']
     # BASELINE config 2 proper is batch = 1: the same two pipelines on the first volume only (N = 1 runs)
     r_b1 = None
-    if dist is None and B > 1:
+    if dist is None and B > 1 and not args.no_batch1:
         f1, u1 = make_steps(mov[:1], fix[:1], trf[:1])
         r_b1 = (timed(f1, o_steps, 2, None, dev), timed(u1, o_steps, 2, None, dev))
     unet_multi = None
