@@ -635,15 +635,33 @@ def main():
 
     def make_steps(mov, fix, trf):
         def step_unfused(events=None):
+            # the two reference-signature calls run EAGERLY: `warped` is written by one kernel and read back by the other
+            keep = ne.deferred.enabled
+            ne.deferred.enabled = False
+            try:
+                if events is not None:
+                    events[0].record()
+                warped = st([mov, trf])
+                if events is not None:
+                    events[1].record()
+                d = dice.dice(fix, warped)                      # [B, L]
+                if events is not None:
+                    events[2].record()
+            finally:
+                ne.deferred.enabled = keep
+            return nd.all_reduce_mean_dice(d, async_op=True)    # one all-reduce of 2 floats when world > 1
+
+        def step_refsig(events=None):
+            # the same two calls as a user of the reference writes them; SpatialTransformer defers the warp and Dice runs the
+            # fused kernel (neurite_amd/deferred.py)
             if events is not None:
                 events[0].record()
             warped = st([mov, trf])
+            d = dice.dice(fix, warped)
             if events is not None:
                 events[1].record()
-            d = dice.dice(fix, warped)                      # [B, L]
-            if events is not None:
                 events[2].record()
-            return nd.all_reduce_mean_dice(d, async_op=True)    # one all-reduce of 2 floats when world > 1
+            return nd.all_reduce_mean_dice(d, async_op=True)
 
         def step_fused(events=None):
             if events is not None:
@@ -654,7 +672,7 @@ def main():
                 events[2].record()
             return nd.all_reduce_mean_dice(d, async_op=True)
         if not args.graph:
-            return step_fused, step_unfused
+            return step_fused, step_unfused, step_refsig
 
         # --graph: the launches of a step (gather / Dice kernels, the two-level second stage, the [sum, count] pair) are
         # captured once and replayed as ONE hipGraph launch; the all-reduce stays outside the graph and works on a copy of
@@ -680,10 +698,17 @@ def main():
                 return nd.all_reduce_mean_pair(pair.clone(), async_op=True)
             step._graph = g
             return step
-        return (capture(lambda: nd.mean_dice_pair(ne.fused.warp_dice(mov, trf, fix, _tune=args.tune))),
+        def eager_pair():
+            keep = ne.deferred.enabled
+            ne.deferred.enabled = False
+            try:
+                return nd.mean_dice_pair(dice.dice(fix, st([mov, trf])))
+            finally:
+                ne.deferred.enabled = keep
+        return (capture(lambda: nd.mean_dice_pair(ne.fused.warp_dice(mov, trf, fix, _tune=args.tune))), capture(eager_pair),
                 capture(lambda: nd.mean_dice_pair(dice.dice(fix, st([mov, trf])))))
 
-    step_fused, step_unfused = make_steps(mov, fix, trf)
+    step_fused, step_unfused, step_refsig = make_steps(mov, fix, trf)
     fused = not args.unfused
     r_main = timed(step_fused if fused else step_unfused, args.steps, args.warmup, dist, dev)
     elapsed, k0_ms, k1_ms, m = r_main['elapsed'], r_main['k0_ms'], r_main['k1_ms'], r_main['mean']
@@ -691,10 +716,12 @@ def main():
     o_steps = max(5, args.steps // 5)
     r_other = timed(step_unfused if fused else step_fused, o_steps, 2, dist, dev)
     o_elapsed, o_k0, o_k1, o_m = r_other['elapsed'], r_other['k0_ms'], r_other['k1_ms'], r_other['mean']
+    # the reference-signature call sequence with the warp deferred (what `SpatialTransformer` -> `Dice` callers get by default)
+    r_ref = timed(step_refsig, o_steps, 2, dist, dev)
     # BASELINE config 2 proper is batch = 1: the same two pipelines on the first volume only (N = 1 runs)
     r_b1 = None
     if dist is None and B > 1 and not args.no_batch1:
-        f1, u1 = make_steps(mov[:1], fix[:1], trf[:1])
+        f1, u1, _ = make_steps(mov[:1], fix[:1], trf[:1])
         r_b1 = (timed(f1, o_steps, 2, None, dev), timed(u1, o_steps, 2, None, dev))
     unet_multi = None
     if dist is not None and not args.no_unet:
@@ -743,8 +770,8 @@ def main():
     # drop-in (reference-signature) pipeline figures, whichever form was the timed one
     d_elapsed, d_steps, d_k0, d_k1, d_m = (o_elapsed, o_steps, o_k0, o_k1, o_m) if fused else (elapsed, args.steps, k0_ms, k1_ms, m)
     f_elapsed, f_steps, f_k0, f_m = (elapsed, args.steps, k0_ms, m) if fused else (o_elapsed, o_steps, o_k0, o_m)
-    dropin = {'what': 'reference-signature pipeline: layers.SpatialTransformer(linear) -> metrics.Dice().dice, two kernels, '
-                      '`warped` written and re-read; %d steps' % d_steps,
+    dropin = {'what': 'reference-signature calls run eagerly (neurite_amd.deferred.enabled = False): layers.SpatialTransformer(linear) '
+                      '-> metrics.Dice().dice, two kernels, `warped` written and re-read; %d steps' % d_steps,
               'value': round(world * B * V * d_steps / d_elapsed / 1e6, 2), 'unit': 'Mvoxels/s',
               'ms_per_step': round(d_elapsed / d_steps * 1e3, 4),
               'interpn_ms': round(d_k0, 4), 'interpn_GBs': round(interp_bytes / (d_k0 * 1e-3) / 1e9, 1),
@@ -803,6 +830,15 @@ def main():
                             'achieved': dropin['interpn_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                             'frac': dropin['interpn_frac_of_peak'], 'avg_launch_ms': dropin['interpn_ms'],
                             'algorithmic_bytes_per_launch': interp_bytes},
+        # what a caller of the reference's own two calls gets by default: SpatialTransformer defers the warp, Dice runs the
+        # fused kernel on (moving, trf, fixed) -- same kernel and numbers as `fused_pipeline`, reached through the reference API
+        'reference_api_pipeline': {
+            'what': 'layers.SpatialTransformer(linear)([moving, trf]) -> metrics.Dice().dice(fixed, warped) as written against the '
+                    'reference; the warp is deferred and Dice launches the fused kernel (neurite_amd/deferred.py); %d steps' % o_steps,
+            'value': round(world * B * V * o_steps / r_ref['elapsed'] / 1e6, 2), 'unit': 'Mvoxels/s',
+            'ms_per_step': round(r_ref['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(r_ref['k0_ms'], 4),
+            'frac_of_peak_268B_per_voxel': round(fused_bytes / (r_ref['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            'mean_dice': round(r_ref['mean'], 6)},
         'dropin_pipeline': dropin,
         'fused_pipeline': fusedb,
         'other_pipeline': dropin if fused else fusedb,
@@ -833,7 +869,7 @@ def main():
             except Exception as e:   # noqa
                 out['cpu_baseline']['cfg1_32cubed'] = {'error': str(e)}
             d_gpu = (ne.fused.warp_dice(mov[:1], trf[:1], fix[:1]) if fused
-                     else dice.dice(fix[:1], st([mov[:1], trf[:1]]))).cpu().numpy()
+                     else dice.dice(fix[:1], ne.deferred.materialize(st([mov[:1], trf[:1]])))).cpu().numpy()
             out['config']['max_abs_dice_diff_vs_oracle'] = float(np.abs(d_gpu - d_cpu).max())
         except Exception as e:   # noqa
             out['cpu_baseline'] = {'value': None, 'unit': 'Mvoxels/s', 'cores': 0, 'kind': 'port',

@@ -152,6 +152,7 @@ def stream_ptr(device):
 
 
 def ptr(t):
+    # a DeferredWarp (neurite_amd/deferred.py) evaluates itself when its address is asked for
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 

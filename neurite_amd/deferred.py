@@ -1,0 +1,86 @@
+"""
+Deferred warps: how the reference-signature pipeline reaches the fused kernel.
+
+    warped = SpatialTransformer()([moving, trf]);   d = Dice().dice(fixed, warped)
+
+is the metric pipeline of neurite/tf/models.py:806-807 + neurite/tf/metrics.py:415-482.  Run eagerly it writes `warped`
+(128 B per voxel at 32 labels) only for the Dice kernel to read it back; the fused kernel (csrc/fused.hip) never writes it.
+TensorFlow's graph mode lets a compiler see both ops; an eager host has to defer: under the conditions below
+`SpatialTransformer` returns a `DeferredWarp` -- a tensor whose metadata (shape, dtype, device) is real and whose values are
+computed on first use by ANY torch operation or by any neurite_amd kernel.  `metrics.Dice.dice` recognises an unmaterialised
+DeferredWarp as one of its arguments and launches the fused warp + Dice kernel on (moving, trf, other map) instead.  Every other
+consumer simply triggers the stand-alone interpn kernel, exactly as an eager call would have.
+
+Deferral happens only for: linear interpolation, float32 3-D volumes with 4 * 2^k labels, dense displacement fields, no
+gradient being recorded (training graphs stay eager: autograd needs the real tensor), and `deferred.enabled` (env
+NRT_DEFER_WARP, default on).  The values are bit-identical to the eager path whenever they are materialised.
+"""
+
+import os
+
+import torch
+from torch.utils._pytree import tree_map
+
+enabled = os.environ.get('NRT_DEFER_WARP', '1') != '0'
+
+
+class DeferredWarp(torch.Tensor):
+    @staticmethod
+    def __new__(cls, shape, dtype, device, thunk, sources):
+        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=dtype, device=device, requires_grad=False)
+        t._thunk = thunk
+        t._value = None
+        t._sources = sources            # dict(vol, shift, single_transform, fill_value): what the fused kernel needs
+        return t
+
+    # ---- evaluation ------------------------------------------------------------------------------------------------
+    @property
+    def pending(self):
+        return self._value is None
+
+    def materialize(self):
+        if self._value is None:
+            self._value = self._thunk()
+            self._thunk = None
+            self._sources = None
+        return self._value
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        def un(a):
+            return a.materialize() if isinstance(a, DeferredWarp) else a
+        return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
+
+    # ---- the tensor methods that do not go through the dispatcher -----------------------------------------------------
+    def data_ptr(self):
+        return self.materialize().data_ptr()
+
+    def numpy(self, *a, **k):
+        return self.materialize().numpy(*a, **k)
+
+    def tolist(self):
+        return self.materialize().tolist()
+
+    def item(self):
+        return self.materialize().item()
+
+    def __array__(self, *a, **k):
+        return self.materialize().__array__(*a, **k)
+
+    def __dlpack__(self, *a, **k):
+        return self.materialize().__dlpack__(*a, **k)
+
+    def __reduce_ex__(self, proto):
+        return self.materialize().__reduce_ex__(proto)
+
+    def untyped_storage(self):
+        return self.materialize().untyped_storage()
+
+    def __repr__(self):
+        return repr(self.materialize()) if self._value is not None else \
+            'DeferredWarp(shape=%s, dtype=%s, device=%s, pending)' % (tuple(self.shape), self.dtype, self.device)
+
+
+def materialize(t):
+    """the real tensor behind `t` (identity for ordinary tensors)"""
+    return t.materialize() if isinstance(t, DeferredWarp) else t

@@ -17,6 +17,7 @@ from torch import nn
 
 from . import _lib
 from . import augment
+from . import deferred
 from . import utils
 
 __all__ = ['Resize', 'Zoom', 'SpatialTransformer', 'LocallyConnected3D', 'VecInt', 'RescaleTransform',
@@ -202,10 +203,25 @@ class SpatialTransformer(_Layer):
         shift = trf[:1] if self.single_transform else trf
         vol32, restore = utils._prepare_vol(vol, self.interp_method)
 
-        out = utils._interp_op(vol32, shift, shift.shape[1:-1], _lib.LOC_SHIFT,
-                               utils._METHODS[self.interp_method], self.fill_value, batched=True,
-                               single_transform=self.single_transform, variant=self._variant, tune=self._tune)
-        return out if restore is None else out.to(restore)
+        def run():
+            out = utils._interp_op(vol32, shift, shift.shape[1:-1], _lib.LOC_SHIFT,
+                                   utils._METHODS[self.interp_method], self.fill_value, batched=True,
+                                   single_transform=self.single_transform, variant=self._variant, tune=self._tune)
+            return out if restore is None else out.to(restore)
+
+        # SpatialTransformer -> Dice is the metric pipeline (models.py:806-807 + metrics.py:415-482): when nothing needs a
+        # gradient the warp is deferred so that Dice can run the fused kernel and `warped` is never written
+        # (neurite_amd/deferred.py); any other use of the result evaluates it with the stand-alone kernel, bit-identically
+        L = vol.shape[-1]
+        if (deferred.enabled and self.interp_method == 'linear' and D == 3 and vol.dtype == torch.float32
+                and self._variant == 0 and self._tune == 0 and L % 4 == 0 and (L // 4) in (1, 2, 4, 8, 16, 32, 64)
+                and shift.numel() > 0 and vol.numel() > 0
+                and not (torch.is_grad_enabled() and (vol.requires_grad or shift.requires_grad))):
+            vol_c, shift_c = vol32.contiguous(), shift.contiguous()
+            return deferred.DeferredWarp([B] + list(shift.shape[1:-1]) + [L], vol.dtype, vol.device, run,
+                                         dict(vol=vol_c, shift=shift_c, single_transform=self.single_transform,
+                                              fill_value=self.fill_value))
+        return run()
 
 
 # ------------------------------------------------------------------------------------------

@@ -183,6 +183,25 @@ class Dice:
             assert self.input_type in ['prob', 'one_hot'], \
                 'if doing soft Dice, must use probabilistic (one_hot)encoding'
 
+    def _dice_of_deferred_warp(self, y_true, y_pred, eps):
+        """Dice(fixed, SpatialTransformer([moving, trf])) with the warp still pending (neurite_amd/deferred.py): one fused kernel
+        gathers and reduces, the warped volume is never written.  Soft Dice is symmetric in its two arguments, so either one may
+        be the pending warp.  None = not applicable (the caller takes the ordinary path, which evaluates the warp)."""
+        from . import deferred, fused
+        a_def = isinstance(y_true, deferred.DeferredWarp) and y_true.pending
+        b_def = isinstance(y_pred, deferred.DeferredWarp) and y_pred.pending
+        if a_def == b_def or self.normalize:
+            return None
+        warp, other = (y_pred, y_true) if b_def else (y_true, y_pred)
+        if isinstance(other, deferred.DeferredWarp):
+            other = other.materialize()
+        if other.dtype != torch.float32 or tuple(other.shape) != tuple(warp.shape) or other.device != warp.device:
+            return None
+        src = warp._sources
+        return fused.warp_dice(src['vol'], src['shift'], other, indexing='ij', single_transform=src['single_transform'],
+                               fill_value=src['fill_value'], laplace_smoothing=eps,
+                               check_input_limits=bool(self.check_input_limits))
+
     # ------------------------------------------------------------------------------------------
     def dice(self, y_true, y_pred):
         """
@@ -195,7 +214,12 @@ class Dice:
 
         if self.dice_type != 'hard':
             if torch.is_grad_enabled() and (y_true.requires_grad or y_pred.requires_grad):
-                return _SoftDiceFn.apply(y_true, y_pred, eps, bool(self.normalize), bool(self.check_input_limits))
+                from .deferred import materialize
+                return _SoftDiceFn.apply(materialize(y_true), materialize(y_pred), eps, bool(self.normalize),
+                                         bool(self.check_input_limits))
+            fused_d = self._dice_of_deferred_warp(y_true, y_pred, eps)
+            if fused_d is not None:
+                return fused_d
             _, d, mm = dice_partial_sums(y_true, y_pred, self.normalize, eps)
             if self.check_input_limits:                                                   # :439-444
                 _check_limits(mm)
