@@ -824,6 +824,8 @@ def main():
             'traffic_source': traffic_src,
             'algorithmic_bytes_per_launch': alg_bytes,
             'avg_launch_ms': round(kms, 4),
+            'avg_launch_ms_covers': ('HIP events around the gather launch and, for the fused form, the two launches of its Dice second '
+                                     'stage (reduce_rows + dice_soft_finalize, ~0.03 ms together): rocprofv3 lists the gather alone'),
         },
         # the reference-signature path (what `SpatialTransformer` + `Dice` callers reach) next to the fused headline
         'roofline_dropin': {'kernel': 'interpn (SpatialTransformer gather, drop-in API), one launch per step', 'bound': 'hbm',
