@@ -723,6 +723,26 @@ def main():
     if dist is None and B > 1 and not args.no_batch1:
         f1, u1, _ = make_steps(mov[:1], fix[:1], trf[:1])
         r_b1 = (timed(f1, o_steps, 2, None, dev), timed(u1, o_steps, 2, None, dev))
+    # label maps stored as bfloat16 (exact for one-hot maps), float32 arithmetic: same Dice bit for bit, half the bytes per row
+    r_bf16 = None
+    if dist is None and not args.no_batch1:
+        try:
+            mov16, fix16 = mov.bfloat16(), fix.bfloat16()
+
+            def step_bf16(events=None):
+                if events is not None:
+                    events[0].record()
+                d = ne.fused.warp_dice(mov16, trf, fix16, _tune=args.tune)
+                if events is not None:
+                    events[1].record()
+                    events[2].record()
+                return nd.all_reduce_mean_dice(d, async_op=True)
+            r_bf16 = timed(step_bf16, o_steps, 2, None, dev)
+            r_bf16['same_dice'] = bool(torch.equal(ne.fused.warp_dice(mov16, trf, fix16), ne.fused.warp_dice(mov, trf, fix)))
+            del mov16, fix16
+        except Exception as e:   # noqa
+            log('bf16-storage run failed: %s' % e)
+            r_bf16 = None
     unet_multi = None
     if dist is not None and not args.no_unet:
         # "3D UNet fwd ms at 1/2/4/8 GPU": every rank runs the config-3 forward on its own volume (data parallel inference);
@@ -855,6 +875,15 @@ def main():
             'dropin': {'ms': round(ru['elapsed'] / o_steps * 1e3, 4), 'Mvoxels_per_s': round(V * o_steps / ru['elapsed'] / 1e6, 1),
                        'interpn_ms': round(ru['k0_ms'], 4), 'dice_ms': round(ru['k1_ms'], 4),
                        'interpn_frac': round(INTERPN_BYTES_PER_VOXEL(L, 3) * V / (ru['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    if r_bf16 is not None:
+        b16 = (2 * L + 12 + 2 * L) * V * B
+        out['bf16_storage'] = {
+            'what': 'the fused kernel on the same one-hot maps STORED as bfloat16 (float32 arithmetic on the widened rows; Dice '
+                    'bit-identical to the float32 run: same_dice); not the headline -- BASELINE names fp32 volumes; %d steps' % o_steps,
+            'value': round(B * V * o_steps / r_bf16['elapsed'] / 1e6, 2), 'unit': 'Mvoxels/s',
+            'ms_per_step': round(r_bf16['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(r_bf16['k0_ms'], 4),
+            'algorithmic_bytes_per_voxel': 2 * L + 12 + 2 * L,
+            'frac_of_peak': round(b16 / (r_bf16['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'same_dice': r_bf16['same_dice']}
     if fused:
         out['roofline']['unfused_api_accounting_524B_per_voxel_GBs'] = round(
             (INTERPN_BYTES_PER_VOXEL(L, 3) + DICE_BYTES_PER_VOXEL(L)) * V * B / (kms * 1e-3) / 1e9, 1)

@@ -175,6 +175,17 @@ int nrt_warp_dice_soft_f32(const float *moving, const float *loc, const float *f
                            float laplace_smoothing, float *sums, float *dice, float *minmax,
                            int tune, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with the two label maps STORED as bfloat16 (moving [batch, vol_shape, nlabels], fixed [batch, out_shape, nlabels]):
+ * half the bytes per row (a 32-label row is 64 B, two z-neighbours share a cache line).  The rows are widened to float32 in
+ * registers and the arithmetic is the float32 kernel's, so for maps whose values are bfloat16 numbers (one-hot label maps)
+ * sums / dice are bit-identical to nrt_warp_dice_soft_f32 on the widened maps.  An extension of this package (the reference
+ * has no fused form; TensorFlow would blend bfloat16 tensors in bfloat16 -- nrt_interpn_any does that for interpn).
+ * No `warped` output. */
+int nrt_warp_dice_soft_bf16(const void *moving, const float *loc, const void *fixed, const int *vol_shape,
+                            const int *out_shape, int nlabels, int batch, long long loc_batch_stride, int loc_mode,
+                            int has_fill, float fill_value, float laplace_smoothing, float *sums, float *dice,
+                            float *minmax, int tune, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Label-weighted categorical cross-entropy
  * replaces: neurite/tf/metrics.py:640-650 + tf.keras.losses.CategoricalCrossentropy

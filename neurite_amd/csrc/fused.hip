@@ -25,9 +25,32 @@
 
 namespace {
 
-template <int G, int MODE, bool STORE, int MINW>
-__global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
+// Storage type of the two label maps.  float: 16 bytes per lane and row.  bfloat16 (unsigned short): 8 bytes per lane -- a
+// 32-label row is 64 bytes, two z-neighbours share a cache line -- widened to float32 in registers (exact), after which the
+// arithmetic is the float32 kernel's: for maps whose values are bfloat16 numbers (one-hot label maps are) the result is
+// bit-identical to the float32 kernel on the widened maps.  "bf16 storage, fp32 math": an extension of this package, not a
+// reference behaviour (TensorFlow would run the blend in bfloat16; interpn_any.hip does that for `interpn` on bf16 volumes).
+typedef unsigned nrt_u2 __attribute__((ext_vector_type(2)));
+template <typename ST> struct RowT;
+template <> struct RowT<float> {
+    typedef nrt_f4 T;
+    static constexpr unsigned BYTES = 16;
+    static __device__ __forceinline__ nrt_f4 widen(const nrt_f4 &t) { return t; }
+};
+template <> struct RowT<unsigned short> {
+    typedef nrt_u2 T;
+    static constexpr unsigned BYTES = 8;
+    static __device__ __forceinline__ nrt_f4 widen(const nrt_u2 &t) {
+        return (nrt_f4){__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u), __uint_as_float(t[1] << 16),
+                        __uint_as_float(t[1] & 0xffff0000u)};
+    }
+};
+
+template <int G, int MODE, bool STORE, int MINW, typename ST = float>
+__global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGeom tg, const void *__restrict__ fixed,
                                                       float *__restrict__ fpart, float *__restrict__ mpart) {
+    typedef typename RowT<ST>::T Row;
+    constexpr unsigned RB = RowT<ST>::BYTES;
     constexpr int NG = 256 / G;
     constexpr int L = 4 * G;
     // persistent blocks: block (k = XCD, jb) walks the tiles jb, jb + nb, jb + 2 nb ... of XCD k's slab and
@@ -49,10 +72,10 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
         per = jb + 1; nb = 1;                                  // the tile loop below runs exactly once
     }
 
-    const char *volb = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const char *volb = (const char *)a.vol + (long long)b * a.vol_bs * (long long)sizeof(ST);
     const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
     nrt_f4 *out = (nrt_f4 *)((float *)a.out + (long long)b * a.out_bs);
-    const nrt_f4 *fix = (const nrt_f4 *)(fixed + (long long)b * a.out_bs);
+    const char *fix = (const char *)fixed + (long long)b * a.out_bs * (long long)sizeof(ST);
     const int lg = threadIdx.x % G;
     const int g = threadIdx.x / G;
     int npass = tg.plane_major ? tg.tz : (1 << (tg.ltx + tg.lty + tg.ltz)) / NG;
@@ -128,16 +151,20 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
                 const unsigned ix = (corner & 4) ? i1x : i0x;
                 const unsigned iy = (corner & 2) ? i1y : i0y;
                 const unsigned iz = (corner & 1) ? i1z : i0z;
-                off[corner] = (nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz) * (unsigned)G + (unsigned)lg) * 16u;
+                off[corner] = (nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz) * (unsigned)G + (unsigned)lg) * RB;
             }
             W0x = m.w0x; W0y = m.w0y; W0z = m.w0z; Q = m.q; VALID = m.valid; OOB = m.oob;
         };
-        auto load_rows = [&](const unsigned (&off)[8], unsigned q, nrt_f4 (&R)[8], nrt_f4 &T) {
+        auto load_rows = [&](const unsigned (&off)[8], unsigned q, Row (&R)[8], Row &T) {
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) R[corner] = *(const nrt_f4 *)(volb + (size_t)off[corner]);
-            T = __builtin_nontemporal_load((const nrt_f4 *)((const char *)fix + (size_t)((q * (unsigned)G + (unsigned)lg) * 16u)));
+            for (int corner = 0; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
+            T = __builtin_nontemporal_load((const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB)));
         };
-        auto finish = [&](float W0x, float W0y, float W0z, unsigned Q, bool VALID, bool OOB, const nrt_f4 (&R)[8], const nrt_f4 &T) {
+        auto finish = [&](float W0x, float W0y, float W0z, unsigned Q, bool VALID, bool OOB, const Row (&Rraw)[8], const Row &Traw) {
+            nrt_f4 R[8];
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) R[corner] = RowT<ST>::widen(Rraw[corner]);
+            const nrt_f4 T = RowT<ST>::widen(Traw);
             FM m;
             m.w0x = W0x; m.w0y = W0y; m.w0z = W0z; m.q = Q; m.valid = VALID; m.oob = OOB;
             m.w1x = nrt_sub(1.0f, W0x); m.w1y = nrt_sub(1.0f, W0y); m.w1z = nrt_sub(1.0f, W0z);      // corner_1d's w1
@@ -176,7 +203,7 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             }
         };
 
-        nrt_f4 Ra[8], Rb[8], Ta, Tb;
+        Row Ra[8], Rb[8], Ta, Tb;
         float Ax, Ay, Az, Bx, By, Bz;
         unsigned Aq, Bq;
         bool Av, Ao, Bv, Bo;
@@ -272,9 +299,9 @@ void fused_geom(const int *out_shape, int G, int batch, int tune, TileGeom &tg, 
     if (((t >> 14) & 1) && !tg.plane_major && out_shape[0] > 0) nblocks = xmarch_setup(out_shape, batch, t, tg);
 }
 
-template <int G>
+template <int G, typename ST>
 void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store,
-                  const float *fixed, float *fpart, float *mpart, hipStream_t st) {
+                  const void *fixed, float *fpart, float *mpart, hipStream_t st) {
     dim3 grid(nblocks, batch), blk(256);
     // experiment knob: NRT_FUSED_LDS_KB pads every block with unused dynamic LDS to cap the blocks per CU
     // NRT_FUSED_LDS_KB (experiments): unused dynamic LDS per block, caps the blocks per CU.  The x-march default is
@@ -285,15 +312,15 @@ void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int
     if (tg.x_march) {
         grid = dim3(nrt_xcd_grid(nblocks * (unsigned)batch), 1);
 #define NRT_FUSED_X(MODE)                                                                                           \
-    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, 4>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
+    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, 4, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
     else {                                                                                                          \
         static unsigned attr_dyn = 0;                                                                               \
         if (dyn > 48 * 1024 && attr_dyn != dyn) {                                                                   \
-            (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, 4>,                              \
+            (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, 4, ST>,                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                        \
             attr_dyn = dyn;                                                                                         \
         }                                                                                                           \
-        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 4>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart);    \
+        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 4, ST>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
     }
         switch (mode) {
             case NRT_LOC_ABSOLUTE: NRT_FUSED_X(NRT_LOC_ABSOLUTE); break;
@@ -304,11 +331,11 @@ void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int
         return;
     }
 #define NRT_FUSED(MODE)                                                                                          \
-    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, 1>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
+    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, 1, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
     else {                                                                                                       \
-        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, 1>,                \
+        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, 1, ST>,            \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);    \
-        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 1>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
+        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 1, ST>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
     }
     switch (mode) {
         case NRT_LOC_ABSOLUTE: NRT_FUSED(NRT_LOC_ABSOLUTE); break;
@@ -334,11 +361,12 @@ extern "C" size_t nrt_warp_dice_workspace_bytes(const int *out_shape, int nlabel
     return fused_ws_bytes(nblocks, nlabels, batch);
 }
 
-extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, const float *fixed, float *warped,
-                                      const int *vol_shape, const int *out_shape, int nlabels, int batch,
-                                      long long loc_batch_stride, int loc_mode, int has_fill, float fill_value,
-                                      float laplace_smoothing, float *sums, float *dice, float *minmax,
-                                      int tune, void *workspace, size_t workspace_bytes, void *stream) {
+namespace {
+template <typename ST>
+int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed, float *warped, const int *vol_shape,
+                        const int *out_shape, int nlabels, int batch, long long loc_batch_stride, int loc_mode, int has_fill,
+                        float fill_value, float laplace_smoothing, float *sums, float *dice, float *minmax, int tune,
+                        void *workspace, size_t workspace_bytes, void *stream) {
     if (!fixed || !sums || !dice) return NRT_ERR_INVALID_ARG;
     if (nlabels % 4) return NRT_ERR_UNSUPPORTED;
     const int G = nlabels / 4;
@@ -352,14 +380,16 @@ extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, con
     if (rc != NRT_OK) return rc;
     if (!warped) a.out = nullptr;
     a.fill_f = fill_value;
-    if ((unsigned long long)vol_bs * 4ull >= (1ull << 32)) return NRT_ERR_UNSUPPORTED;
+    if ((unsigned long long)vol_bs * sizeof(ST) >= (1ull << 32)) return NRT_ERR_UNSUPPORTED;
     // the kernel addresses `fixed` / `warped` / `loc` rows with 32-bit byte offsets and forms row indices with 24-bit multiplies
     if ((unsigned long long)a.nout * (unsigned long long)nlabels * 4ull >= (1ull << 32)) return NRT_ERR_UNSUPPORTED;
+    if (!std::is_same<ST, float>::value && warped) return NRT_ERR_UNSUPPORTED;      // the warped volume is a float32 output
     if ((long long)vol_shape[0] * vol_shape[1] >= (1 << 24) || vol_shape[2] >= (1 << 24) ||
         (long long)out_shape[0] * out_shape[1] >= (1 << 24) || out_shape[2] >= (1 << 24)) return NRT_ERR_UNSUPPORTED;
     if ((((uintptr_t)moving | (uintptr_t)fixed | (uintptr_t)warped) & 15) != 0) return NRT_ERR_INVALID_ARG;
     if (a.nout == 0) return NRT_ERR_INVALID_ARG;
     if (tune > 0 && (tune & FUSED_TUNE_WDD)) {
+        if (!std::is_same<ST, float>::value) return NRT_ERR_UNSUPPORTED;
         if (G != 8 || !nrt_wdd_supported(vol_shape, out_shape, nlabels)) return NRT_ERR_UNSUPPORTED;
         const int wt = tune & (FUSED_TUNE_WDD - 1);
         const unsigned nrows = nrt_wdd_rows(out_shape, batch, wt);
@@ -374,7 +404,7 @@ extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, con
         w.gmm = (float *)p;
         w.ipart = nullptr;
         WddCall c;
-        c.vol = moving; c.loc = loc; c.out = warped; c.fixed = fixed; c.fpart = w.fpart; c.mpart = w.mpart; c.minmax = minmax != nullptr;
+        c.vol = (const float *)moving; c.loc = loc; c.out = warped; c.fixed = (const float *)fixed; c.fpart = w.fpart; c.mpart = w.mpart; c.minmax = minmax != nullptr;
         for (int d = 0; d < 3; ++d) { c.S[d] = a.S[d]; c.O[d] = a.O[d]; c.delta[d] = a.delta[d]; }
         c.batch = batch; c.vol_bs = a.vol_bs; c.loc_bs = a.loc_bs; c.out_bs = a.out_bs;
         c.mode = loc_mode; c.has_fill = a.has_fill; c.fill = fill_value; c.tune = wt;
@@ -401,14 +431,34 @@ extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, con
     hipStream_t st = nrt_stream(stream);
     const bool store = warped != nullptr;
     switch (G) {
-        case 1: launch_fused<1>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 2: launch_fused<2>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 4: launch_fused<4>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 8: launch_fused<8>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 16: launch_fused<16>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 32: launch_fused<32>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        default: launch_fused<64>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 1: launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 2: launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 4: launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 8: launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 16: launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 32: launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        default: launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
     }
     NRT_CHECK_LAUNCH();
     return dice_finalize_soft(w, nblocks, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
+}
+}  // namespace
+
+extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, const float *fixed, float *warped,
+                                      const int *vol_shape, const int *out_shape, int nlabels, int batch,
+                                      long long loc_batch_stride, int loc_mode, int has_fill, float fill_value,
+                                      float laplace_smoothing, float *sums, float *dice, float *minmax,
+                                      int tune, void *workspace, size_t workspace_bytes, void *stream) {
+    return warp_dice_soft_impl<float>(moving, loc, fixed, warped, vol_shape, out_shape, nlabels, batch, loc_batch_stride, loc_mode,
+                                      has_fill, fill_value, laplace_smoothing, sums, dice, minmax, tune, workspace, workspace_bytes,
+                                      stream);
+}
+
+extern "C" int nrt_warp_dice_soft_bf16(const void *moving, const float *loc, const void *fixed, const int *vol_shape,
+                                       const int *out_shape, int nlabels, int batch, long long loc_batch_stride, int loc_mode,
+                                       int has_fill, float fill_value, float laplace_smoothing, float *sums, float *dice,
+                                       float *minmax, int tune, void *workspace, size_t workspace_bytes, void *stream) {
+    return warp_dice_soft_impl<unsigned short>(moving, loc, fixed, nullptr, vol_shape, out_shape, nlabels, batch, loc_batch_stride,
+                                               loc_mode, has_fill, fill_value, laplace_smoothing, sums, dice, minmax, tune, workspace,
+                                               workspace_bytes, stream);
 }

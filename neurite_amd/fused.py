@@ -34,7 +34,8 @@ class _WarpDiceFn(torch.autograd.Function):
 def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_value=None, laplace_smoothing=0.,
               check_input_limits=False, return_warped=False, return_sums=False, _tune=0):
     """
-    moving [B, X, Y, Z, L], trf [B, X', Y', Z', 3] (voxel displacements), fixed [B, X', Y', Z', L]; float32, 3-D,
+    moving [B, X, Y, Z, L], trf [B, X', Y', Z', 3] (voxel displacements), fixed [B, X', Y', Z', L]; float32 maps (or both maps
+    stored as bfloat16: float32 arithmetic on the widened values, exact for one-hot label maps, half the bytes), 3-D,
     L in {4, 8, 16, 32, 64, 128, 256}.  Linear interpolation.  Returns dice [B, L] (optionally also the warped
     volume and the partial sums [B, 3, L]).  check_input_limits defaults to False because a tri-linearly
     warped one-hot map exceeds 1.0 by an ulp (see tests); pass True for the reference's asserts.
@@ -45,9 +46,13 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
         raise Exception('warp_dice expects 3-D volumes [B, X, Y, Z, L] and a displacement field [B, X, Y, Z, 3]')
     if indexing not in ('ij', 'xy'):
         raise ValueError("indexing has to be 'ij' (matrix) or 'xy' (cartesian)")
-    for name, t in (('moving', moving), ('fixed', fixed)):
-        if t.dtype != torch.float32:
-            raise NotImplementedError('%s: warp_dice takes float32 maps, got %s' % (name, t.dtype))
+    if moving.dtype != fixed.dtype or moving.dtype not in (torch.float32, torch.bfloat16):
+        raise NotImplementedError('warp_dice takes two float32 maps, or two bfloat16 maps (bf16 STORAGE, float32 arithmetic: '
+                                  'exact for one-hot label maps, half the bytes per row); got %s and %s'
+                                  % (moving.dtype, fixed.dtype))
+    bf16 = moving.dtype == torch.bfloat16
+    if bf16 and return_warped:
+        raise NotImplementedError('warp_dice on bfloat16 maps does not return the warped volume (use layers.SpatialTransformer)')
     B, L = moving.shape[0], moving.shape[-1]
     if L % 4 or (L // 4) not in (1, 2, 4, 8, 16, 32, 64):
         raise NotImplementedError('warp_dice: nb_labels must be 4 * 2^k, got %d (use the unfused layers)' % L)
@@ -67,6 +72,8 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
     dice = torch.empty((B, L), dtype=torch.float32, device=dev)
     minmax = torch.empty((4,), dtype=torch.float32, device=dev)
     warped = torch.empty_like(fix) if return_warped else None
+    if bf16 and torch.is_grad_enabled() and trf.requires_grad:
+        raise NotImplementedError('warp_dice on bfloat16 maps has no backward; pass float32 maps for registration training')
     o_shape = _lib.ints(O)
     nws = lib.nrt_warp_dice_workspace_bytes(o_shape, L, B, int(_tune))
     ws = _lib.workspace(dev, nws)
@@ -76,13 +83,20 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
 
     def run():
         with torch.cuda.device(dev):
-            rc = lib.nrt_warp_dice_soft_f32(_lib.ptr(mov), _lib.ptr(shift), _lib.ptr(fix), _lib.ptr(warped),
-                                            _lib.ints(S), o_shape, L, B, loc_bs, _lib.LOC_SHIFT,
-                                            int(has_fill), float(fill_value) if has_fill else 0.0,
-                                            float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice),
-                                            _lib.ptr(minmax) if check_input_limits else None,
-                                            int(_tune), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
-        _lib.check(rc, 'nrt_warp_dice_soft_f32')
+            if bf16:
+                rc = lib.nrt_warp_dice_soft_bf16(_lib.ptr(mov), _lib.ptr(shift), _lib.ptr(fix), _lib.ints(S), o_shape, L, B,
+                                                 loc_bs, _lib.LOC_SHIFT, int(has_fill), float(fill_value) if has_fill else 0.0,
+                                                 float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice),
+                                                 _lib.ptr(minmax) if check_input_limits else None,
+                                                 int(_tune), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+            else:
+                rc = lib.nrt_warp_dice_soft_f32(_lib.ptr(mov), _lib.ptr(shift), _lib.ptr(fix), _lib.ptr(warped),
+                                                _lib.ints(S), o_shape, L, B, loc_bs, _lib.LOC_SHIFT,
+                                                int(has_fill), float(fill_value) if has_fill else 0.0,
+                                                float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice),
+                                                _lib.ptr(minmax) if check_input_limits else None,
+                                                int(_tune), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_warp_dice_soft')
         if check_input_limits:
             mn_t, mx_t, mn_p, mx_p = [float(v) for v in minmax.tolist()]
             if not (mn_t >= 0. and mn_p >= 0. and mx_t <= 1. and mx_p <= 1.):

@@ -356,3 +356,27 @@ def test_mse_prob_nearly_equal_maps_do_not_cancel(dev):
     got = float(ne.metrics.MeanSquaredErrorProb(label_weights=w)(G(t, dev), G(p, dev)))
     assert got > 0
     np.testing.assert_allclose(got, want, rtol=1e-5)
+
+
+def test_fused_bf16_storage(dev):
+    """fused.warp_dice on label maps STORED as bfloat16 (csrc/fused.hip, RowT<unsigned short>): the rows are widened to float32 in
+    registers and the float32 arithmetic runs, so sums / dice / min-max equal the float32 kernel on the widened maps bit for bit --
+    one-hot maps (values 0 / 1) and general bfloat16-valued maps alike; schedules: x-march (default at this size) and tiles"""
+    mov, fix, trf = synth.cfg2_batch(2, 48, 32, device=dev, seed0=5)
+    rng = np.random.default_rng(3)
+    soft = torch.from_numpy(rng.random((2, 48, 48, 48, 32)).astype(F)).to(dev).bfloat16()
+    for m, f in ((mov.bfloat16(), fix.bfloat16()), (soft, fix.bfloat16()), (mov.bfloat16(), soft)):
+        for tune in (0, 3 | (3 << 4) | (4 << 8)):
+            for fill in (None, 0.0):
+                d16, s16 = ne.fused.warp_dice(m, trf, f, fill_value=fill, return_sums=True, _tune=tune)
+                d32, s32 = ne.fused.warp_dice(m.float(), trf, f.float(), fill_value=fill, return_sums=True, _tune=tune)
+                assert bits_equal(N(s16), N(s32)) and bits_equal(N(d16), N(d32)), (tune, fill)
+    # one-hot maps are exact in bfloat16: the same Dice as the float32 pipeline on the original maps
+    assert bits_equal(N(ne.fused.warp_dice(mov.bfloat16(), trf, fix.bfloat16())), N(ne.fused.warp_dice(mov, trf, fix)))
+    with pytest.raises(NotImplementedError):
+        ne.fused.warp_dice(mov.bfloat16(), trf, fix)
+    with pytest.raises(NotImplementedError):
+        ne.fused.warp_dice(mov.bfloat16(), trf, fix.bfloat16(), return_warped=True)
+    # smaller label counts take the same template
+    m8, f8, t8 = synth.cfg2_batch(1, 24, 8, device=dev, seed0=9)
+    assert bits_equal(N(ne.fused.warp_dice(m8.bfloat16(), t8, f8.bfloat16())), N(ne.fused.warp_dice(m8, t8, f8)))
