@@ -7,10 +7,12 @@ A step = one pass of the hot path over one batch of synthetic volumes already re
     dice = SpatialTransformer('linear')([moving, trf])  ->  Dice(fixed, warped)   [B, L]
     N > 1: one RCCL all-reduce of [sum of dice, count] (mean Dice over the global batch); the collective of step k runs
            on RCCL's stream while step k + 1's kernels run, every mean is collected before the closing synchronize
-computed by default with the fused kernel (neurite_amd.fused.warp_dice: the warped volume is consumed in
-registers, never written -- SURVEY.md 8d anticipates exactly this), or with --unfused by the drop-in
-two-kernel pipeline (layers.SpatialTransformer -> metrics.Dice).  The JSON line always carries the other
-form too (`other_pipeline`), measured in the same process.
+written as a user of the reference writes it -- two calls with the reference's signatures.  When nothing needs a gradient
+SpatialTransformer defers the warp and Dice launches the fused kernel on (moving, trf, fixed) (neurite_amd/deferred.py; the
+warped volume is consumed in registers, never written -- SURVEY.md 8d anticipates this form).  --direct times the same kernel
+through neurite_amd.fused.warp_dice, --unfused the eager two-kernel pipeline (deferral off: `warped` written and read back).
+The JSON line always carries all three (`fused_pipeline` = the timed one, `fused_direct_pipeline`, `dropin_pipeline`) plus
+`roofline_dropin` (the stand-alone interpn kernel), `config2_batch1` and `bf16_storage`, measured in the same process.
 Workload: BASELINE config 2 (SpatialTransformer + Dice, 160^3 x 32 one-hot, fp32); every GPU holds
 `--batch-per-gpu` volumes (default 4 = config 4's sharding of B=32 over 8 GPUs), so scaling is weak
 and N=8 is exactly config 4.  1 voxel = 1 spatial output location.
@@ -23,7 +25,8 @@ Rank 0 prints ONE JSON line on stdout.  `roofline` is the dominant kernel: achie
 launch / its average duration measured with HIP events inside the timed region.  Algorithmic bytes per
 voxel (DESIGN.md 4): fused kernel 4C (moving row) + 12 (shift) + 4L (fixed row) = 268 B at C=L=32;
 unfused interpn 4C + 12 + 4C = 268 B, Dice 2*4L = 256 B.  `cpu_baseline` is the C oracle (a port of the
-reference algorithm, oracle/oracle.c) on the host cores over a bounded sample -- reported, not a target.
+reference algorithm, oracle/oracle.c) on the host cores this process may use, over a bounded sample, plus BASELINE config 1
+(one 32^3 volume) on the NumPy restatement, a torch-CPU form and the C port -- reported, not a target.
 At N = 1 the line also carries `unet_fwd` (BASELINE config 3 forward, per-layer fraction of the fp32 MFMA peak), `lc3d_wcce`
 (config 5) and `training` (registration step = fused warp+Dice forward + backward on the bench volumes; unet training step);
 at N > 1 `unet_fwd` is the slowest rank's forward with one volume per GPU.
@@ -65,7 +68,9 @@ def parse():
     ap.add_argument('--sweep', action='store_true', help='time every interpn kernel variant and exit')
     ap.add_argument('--unet', action='store_true', help='only run the unet forward benchmark (BASELINE config 3)')
     ap.add_argument('--no-unet', action='store_true', help='skip the unet forward measurement in the default run')
-    ap.add_argument('--unfused', action='store_true', help='run the drop-in two-kernel pipeline instead of the fused kernel')
+    ap.add_argument('--unfused', action='store_true', help='time the eager two-kernel pipeline (deferred warps off) instead')
+    ap.add_argument('--direct', action='store_true',
+                    help='time neurite_amd.fused.warp_dice called directly instead of the reference-signature calls (same kernel)')
     ap.add_argument('--no-batch1', action='store_true',
                     help='skip the extra batch = 1 runs (profiling: every launch of the gather kernels then has the headline shape)')
     ap.add_argument('--graph', action='store_true',
@@ -710,14 +715,17 @@ def main():
 
     step_fused, step_unfused, step_refsig = make_steps(mov, fix, trf)
     fused = not args.unfused
-    r_main = timed(step_fused if fused else step_unfused, args.steps, args.warmup, dist, dev)
+    # the timed pipeline: the reference's own two calls, SpatialTransformer -> Dice (the warp is deferred, Dice launches the fused
+    # kernel); --direct times fused.warp_dice itself, --unfused the eager two-kernel form
+    main_step = (step_fused if args.direct else step_refsig) if fused else step_unfused
+    r_main = timed(main_step, args.steps, args.warmup, dist, dev)
     elapsed, k0_ms, k1_ms, m = r_main['elapsed'], r_main['k0_ms'], r_main['k1_ms'], r_main['mean']
     # the other form of the same pipeline, shorter run, for the record
     o_steps = max(5, args.steps // 5)
     r_other = timed(step_unfused if fused else step_fused, o_steps, 2, dist, dev)
     o_elapsed, o_k0, o_k1, o_m = r_other['elapsed'], r_other['k0_ms'], r_other['k1_ms'], r_other['mean']
-    # the reference-signature call sequence with the warp deferred (what `SpatialTransformer` -> `Dice` callers get by default)
-    r_ref = timed(step_refsig, o_steps, 2, dist, dev)
+    # the same kernel through the other entry (direct fused API when the reference-signature calls are the timed pipeline)
+    r_ref = timed(step_fused if (fused and not args.direct) else step_refsig, o_steps, 2, dist, dev)
     # BASELINE config 2 proper is batch = 1: the same two pipelines on the first volume only (N = 1 runs)
     r_b1 = None
     if dist is None and B > 1 and not args.no_batch1:
@@ -766,7 +774,8 @@ def main():
     fused_bytes = (4 * L + 12 + 4 * L) * V * B
     if fused:
         # one kernel; it must move: moving row (4C) + loc (4D) + fixed row (4L) per voxel = 268 B at C=L=32
-        kname = 'warp_dice_tile (fused SpatialTransformer gather + Dice reduction), one launch per step'
+        kname = ('warp_dice_tile (fused SpatialTransformer gather + Dice reduction), one launch per step; reached through '
+                 + ('fused.warp_dice' if args.direct else 'layers.SpatialTransformer -> metrics.Dice (deferred warp)'))
         alg_bytes = fused_bytes
         kms = k0_ms
     else:
@@ -801,7 +810,9 @@ def main():
               'pipeline_524B_per_voxel_frac_of_peak': round(
                   (interp_bytes + DICE_BYTES_PER_VOXEL(L) * V * B) / (d_elapsed / d_steps) / 1e9 / HBM_PEAK_GBS, 4),
               'mean_dice': round(d_m, 6)}
-    fusedb = {'what': 'fused warp+Dice kernel (neurite_amd.fused.warp_dice; `warped` never written), %d steps' % f_steps,
+    fusedb = {'what': ('the timed pipeline: reference-signature calls, warp deferred, fused kernel; %d steps' % f_steps)
+                      if (fused and not args.direct) else
+                      'fused warp+Dice kernel (neurite_amd.fused.warp_dice; `warped` never written), %d steps' % f_steps,
               'value': round(world * B * V * f_steps / f_elapsed / 1e6, 2), 'unit': 'Mvoxels/s',
               'ms_per_step': round(f_elapsed / f_steps * 1e3, 4), 'kernel_ms': round(f_k0, 4),
               'frac_of_peak_268B_per_voxel': round(fused_bytes / (f_k0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -826,9 +837,11 @@ def main():
             'workload': 'BASELINE config 2/4: SpatialTransformer(linear)+Dice on %d^3 x %d-label one-hot fp32, '
                         '%d volumes per GPU per step (global batch %d), %s displacement field; %s'
                         % (S, L, B, B * world, 'worst-case U(-80,80)' if args.rough else 'smooth sigma=3 voxel',
-                           'fused kernel (warped volume never written)' if fused else 'drop-in two-kernel pipeline'),
+                           ('reference-signature calls layers.SpatialTransformer -> metrics.Dice (warp deferred, fused kernel, warped '
+                            'volume never written)' if not args.direct else 'fused kernel called directly (fused.warp_dice)') if fused
+                           else 'reference-signature calls run eagerly: two kernels'),
             'volumes_per_gpu': B, 'global_batch': B * world, 'size': S, 'labels': L,
-            'pipeline': 'fused' if fused else 'unfused',
+            'pipeline': ('reference_api' if not args.direct else 'fused_direct') if fused else 'unfused',
             'step_launch': 'one hipGraph replay per step (--graph)' if args.graph else 'direct kernel launches',
             'parallelism': 'dp%d (batch-sharded, one RCCL all-reduce of 2 floats per step)' % world,
             'mean_dice': round(float(m), 6),
@@ -854,9 +867,11 @@ def main():
                             'algorithmic_bytes_per_launch': interp_bytes},
         # what a caller of the reference's own two calls gets by default: SpatialTransformer defers the warp, Dice runs the
         # fused kernel on (moving, trf, fixed) -- same kernel and numbers as `fused_pipeline`, reached through the reference API
-        'reference_api_pipeline': {
-            'what': 'layers.SpatialTransformer(linear)([moving, trf]) -> metrics.Dice().dice(fixed, warped) as written against the '
-                    'reference; the warp is deferred and Dice launches the fused kernel (neurite_amd/deferred.py); %d steps' % o_steps,
+        ('fused_direct_pipeline' if (fused and not args.direct) else 'reference_api_pipeline'): {
+            'what': ('neurite_amd.fused.warp_dice(moving, trf, fixed) called directly: the same kernel without the deferred-warp '
+                     'indirection; %d steps' % o_steps) if (fused and not args.direct) else
+                    ('layers.SpatialTransformer(linear)([moving, trf]) -> metrics.Dice().dice(fixed, warped) as written against the '
+                     'reference; the warp is deferred and Dice launches the fused kernel (neurite_amd/deferred.py); %d steps' % o_steps),
             'value': round(world * B * V * o_steps / r_ref['elapsed'] / 1e6, 2), 'unit': 'Mvoxels/s',
             'ms_per_step': round(r_ref['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(r_ref['k0_ms'], 4),
             'frac_of_peak_268B_per_voxel': round(fused_bytes / (r_ref['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
