@@ -15,6 +15,8 @@
 // Float atomics (global_atomic_add_f32) make grad_vol's summation order non-deterministic, like TF's own
 // scatter-add on GPU; everything else is deterministic.
 
+#include <stdlib.h>
+
 #include "interpn_core.h"
 
 namespace {
@@ -567,6 +569,158 @@ __global__ __launch_bounds__(256) void warp_dice_bwd_rows(InterpBwdArgs ba, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// d out / d vol at C = 32 with the duplicate rows merged on chip before they reach L2.
+//
+// The scatter of interpn_bwd_rows sends 8 row-atomics (32 float atomics each) per voxel to L2, whose atomic units are the
+// bottleneck: 3.6 ms per 160^3 x 32 volume (~67 clk of CU time per row).  Neighbouring voxels hit the same rows again and
+// again -- 64 voxels of two x-planes of a 4 x 8 patch touch ~196 distinct rows with their 512 corner references, and the
+// next planes re-touch most of them.  Here a block keeps an LDS table of 1024 row accumulators (128 KB; the x-march
+// schedule runs one block per CU anyway): a (row, weight) pair claims or finds its row's slot with one `ds_cmpswap` probe
+// sequence, its 32 weighted gradient values are added with LDS float atomics, and only when the table fills up (or the
+// block ends) are the live rows flushed to global memory, one row-atomic each.  Pairs that find no slot in 8 probes go to
+// global memory directly.  Summation order differs from the plain scatter (float atomics already made it unordered).
+// G = 8 (C = 32), x-march schedule; computes d vol only (d loc has its own pass in interpn_bwd_rows).
+//
+// MEASURED (round 2, one 160^3 x 32 volume, tools/bwd_vol_bench.py with phases switched off one at a time): the merge works --
+// the flushes' global atomics cost 0.06 ms in total -- but the LDS float atomics that feed the table take 5.8 ms, the slot
+// search 1.0 ms, everything else 0.75 ms: 7.6 ms against 3.6 ms for the plain scatter.  ds_add_f32 retires about one lane
+// every 3.4 clk per CU (0.3 lane-atomics per clk), SLOWER than the L2 atomic units serve the same CU (0.47 per clk at 3.6 ms).
+// An on-chip merge therefore has to accumulate without LDS atomics (owner-computes over per-row chains, or a sort); this kernel
+// is kept as the correct, selectable experiment (env NRT_BWD_VOL_DEDUP=1), not as the default.
+constexpr int BV_SLOTS = 1024;           // power of two
+constexpr int BV_NG = 32;                // lane-groups (voxels) per x-plane of the block's 4 x 8 patch
+constexpr int BV_U = 2;                  // x-planes per iteration
+constexpr unsigned BV_EMPTY = 0xffffffffu;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void interpn_bwd_vol_dedup(InterpBwdArgs ba) {
+    constexpr int G = 8, C = 32, NPAIR = BV_NG * BV_U * 8;
+    const InterpArgs &a = ba.f;
+    int b = 0, x0 = 0, y0 = 0, z0 = 0, xlen = 0;
+    unsigned prow;
+    if (!xmarch_block(ba.tg, a.O[0], b, prow, x0, y0, z0, xlen)) return;
+    extern __shared__ __attribute__((aligned(16))) float bv_lds[];
+    float *acc = bv_lds;                                   // [BV_SLOTS][C]
+    unsigned *tag = (unsigned *)(acc + BV_SLOTS * C);      // [BV_SLOTS]
+    float *s_g = (float *)(tag + BV_SLOTS);                // [BV_NG * BV_U][C]
+    unsigned *s_idx = (unsigned *)(s_g + BV_NG * BV_U * C);   // [NPAIR]
+    float *s_wt = (float *)(s_idx + NPAIR);                // [NPAIR]
+    unsigned *s_slot = (unsigned *)(s_wt + NPAIR);         // [NPAIR]
+    __shared__ unsigned live_rows;
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    const nrt_f4 *go = (const nrt_f4 *)(ba.gout + (long long)b * a.out_bs);
+    float *gv = ba.gvol + (long long)b * a.vol_bs;
+    const int lg = threadIdx.x % G;
+    const unsigned g = threadIdx.x / G;
+    const unsigned Y = (unsigned)a.S[1], Z = (unsigned)a.S[2];
+    for (int i = threadIdx.x; i < BV_SLOTS * C; i += 256) acc[i] = 0.0f;
+    for (int i = threadIdx.x; i < BV_SLOTS; i += 256) tag[i] = BV_EMPTY;
+    if (threadIdx.x == 0) live_rows = 0;
+    __syncthreads();
+
+    auto flush = [&]() {
+        // every live row goes out as one 128-byte row of float atomics (a wave covers two rows per instruction)
+        for (unsigned i = threadIdx.x; i < (unsigned)(BV_SLOTS * C); i += 256) {
+            const unsigned slot = i / C, ch = i % C;
+            const unsigned row = tag[slot];
+            if (row != BV_EMPTY) {
+                const float v = acc[i];
+                if (v != 0.0f) atomic_add_f32(gv + (size_t)row * C + ch, v);
+                acc[i] = 0.0f;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < BV_SLOTS; i += 256) tag[i] = BV_EMPTY;
+        if (threadIdx.x == 0) live_rows = 0;
+        __syncthreads();
+    };
+
+    const unsigned niter = ((unsigned)xlen + BV_U - 1) / BV_U;
+    // the location and the gradient row of the next iteration's voxels are requested before this iteration's table work
+    float pre_p[BV_U][3];
+    nrt_f4 pre_g[BV_U];
+    bool pre_in[BV_U];
+    auto prefetch = [&](unsigned it) {
+#pragma unroll
+        for (int u = 0; u < BV_U; ++u) {
+            const int x = x0 + (int)(it * BV_U + u), y = y0 + (int)(g >> ba.tg.ltz), z = z0 + (int)(g & ((1u << ba.tg.ltz) - 1u));
+            pre_in[u] = x < x0 + xlen && y < a.O[1] && z < a.O[2];
+            const unsigned q = pre_in[u] ? ((unsigned)x * (unsigned)a.O[1] + (unsigned)y) * (unsigned)a.O[2] + (unsigned)z : a.nout - 1;
+            int qd[NRT_MAXD];
+            float p[NRT_MAXD];
+            decode<3>(a, q, qd);
+            load_loc<3, MODE>(a, locb, q, qd, p);
+            pre_p[u][0] = p[0]; pre_p[u][1] = p[1]; pre_p[u][2] = p[2];
+            pre_g[u] = go[(long long)q * G + lg];
+        }
+    };
+    prefetch(0);
+    for (unsigned it = 0; it < niter; ++it) {
+        // ---- file the iteration's (row, weight) pairs and gradient rows ------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < BV_U; ++u) {
+            float p[NRT_MAXD] = {pre_p[u][0], pre_p[u][1], pre_p[u][2]};
+            const bool oob = a.has_fill ? out_of_bounds<3>(a, p) : false;
+            int i0[3], i1[3];
+            float w0[3], w1[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+            nrt_f4 gq = pre_g[u];
+            const bool dead = !pre_in[u] || oob;
+            if (dead) gq = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+            const unsigned slot = (unsigned)u * BV_NG + g;
+            ((nrt_f4 *)s_g)[slot * G + lg] = gq;
+            const int bx = (lg >> 2) & 1, by = (lg >> 1) & 1, bz = lg & 1;       // lane lg files corner lg
+            const unsigned ix = bx ? i1[0] : i0[0], iy = by ? i1[1] : i0[1], iz = bz ? i1[2] : i0[2];
+            s_idx[slot * 8 + lg] = (ix * Y + iy) * Z + iz;
+            s_wt[slot * 8 + lg] = dead ? 0.0f : (bx ? w1[0] : w0[0]) * (by ? w1[1] : w0[1]) * (bz ? w1[2] : w0[2]);
+        }
+        __syncthreads();
+        if (it + 1 < niter) prefetch(it + 1);
+        // ---- every pair finds (or claims) the accumulator of its row --------------------------------------------------
+        for (unsigned pi = threadIdx.x; pi < (unsigned)NPAIR; pi += 256) {
+            unsigned found = BV_EMPTY;                          // BV_EMPTY = no slot: straight to global memory
+            if (s_wt[pi] != 0.0f) {
+                const unsigned row = s_idx[pi];
+                unsigned h = (row * 2654435761u) >> 22;         // multiplicative hash, top 10 bits
+#pragma unroll 1
+                for (int probe = 0; probe < 8; ++probe) {
+                    const unsigned old = atomicCAS(&tag[h], BV_EMPTY, row);
+                    if (old == BV_EMPTY) { atomicAdd(&live_rows, 1u); found = h; break; }
+                    if (old == row) { found = h; break; }
+                    h = (h + 1u) & (BV_SLOTS - 1u);
+                }
+            }
+            s_slot[pi] = found;
+        }
+        __syncthreads();
+        // ---- accumulate: a lane-group takes one pair, a lane 4 channels of its gradient row (one 16-byte LDS read, four LDS
+        // float atomics); the 16 passes are independent and issue back to back ------------------------------------------
+#pragma unroll
+        for (int pass = 0; pass < NPAIR / 32; ++pass) {
+            const unsigned r = (unsigned)pass * 32u + g;
+            const float wt = s_wt[r];
+            const unsigned slot = s_slot[r];
+            const nrt_f4 gr = ((const nrt_f4 *)s_g)[(r >> 3) * G + lg];
+            if (wt != 0.0f) {
+                if (slot != BV_EMPTY) {
+                    float *dst = acc + slot * C + 4 * lg;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) atomicAdd(dst + c, wt * gr[c]);
+                } else {
+                    float *dst = gv + (size_t)s_idx[r] * C + 4 * lg;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) atomic_add_f32(dst + c, wt * gr[c]);
+                }
+            }
+        }
+        __syncthreads();
+        if (live_rows > (unsigned)(BV_SLOTS * 5 / 8)) flush();   // uniform: live_rows is read after the barrier by everyone
+    }
+    flush();
+}
+
 // nearest interpolation (utils.py:193-204): out[q, c] = vol[idx(round(loc_q)), c]  [* (1 - oob) + oob * fill].
 // tf.round has no gradient (d / d loc = 0); d / d vol is tf.gather's scatter-add of g[q, c] into the gathered element,
 // masked by (1 - oob) when a fill value is set.  One thread per output element, float atomics.
@@ -632,6 +786,30 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
             tile_geometry(out_shape, G, t, t, ba.tg, nt);
             const unsigned per_batch = xmarch_setup(out_shape, batch, t, ba.tg);
             grid = dim3(nrt_xcd_grid(per_batch * (unsigned)batch), 1);
+            const char *dedup_env = getenv("NRT_BWD_VOL_DEDUP");          // read per call: tests switch it
+            const int use_dedup = dedup_env ? atoi(dedup_env) : 0;
+            unsigned long long rows = 1;
+            for (int d = 0; d < 3; ++d) rows *= (unsigned long long)vol_shape[d];
+            if (grad_vol && use_dedup && rows < 0xffffffffull) {
+                // d vol through the LDS row-accumulator table (duplicate rows merged before L2), d loc by the rows kernel
+                const size_t dyn = (size_t)BV_SLOTS * 32 * 4 + BV_SLOTS * 4 + (size_t)BV_NG * BV_U * 32 * 4 + 3 * (size_t)BV_NG * BV_U * 8 * 4;
+                InterpBwdArgs bv = ba;
+                bv.gloc = nullptr;
+#define NRT_BV(MODE)                                                                                                         \
+    do {                                                                                                                     \
+        (void)hipFuncSetAttribute((const void *)interpn_bwd_vol_dedup<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+        hipLaunchKernelGGL((interpn_bwd_vol_dedup<MODE>), grid, dim3(256), dyn, st, bv);                                     \
+    } while (0)
+                switch (loc_mode) {
+                    case NRT_LOC_ABSOLUTE: NRT_BV(NRT_LOC_ABSOLUTE); break;
+                    case NRT_LOC_SHIFT: NRT_BV(NRT_LOC_SHIFT); break;
+                    default: NRT_BV(NRT_LOC_LINSPACE); break;
+                }
+#undef NRT_BV
+                NRT_CHECK_LAUNCH();
+                if (!grad_loc) return NRT_OK;
+                ba.gvol = nullptr;
+            }
         }
         switch (G) {
             case 1: NRT_BWD_MODE(interpn_bwd_rows, 1) break;

@@ -408,3 +408,28 @@ def test_backward_x_march_schedule_ragged(dev):
         dd = go.soft_dice(D64(fix[b:b + 1]), ref[None])
         (-(dd * D64(wl[b:b + 1])).sum() / (B * L)).backward()
         close(N(f.grad[b]), lo.grad.numpy(), 'grad_flow b%d' % b)
+
+
+@pytest.mark.parametrize('fill', [None, 0.0])
+@pytest.mark.parametrize('dedup', ['0', '1'])
+def test_grad_vol_row_accumulator_kernel(dev, fill, dedup, monkeypatch):
+    """d out / d vol at 32 channels under the x-march schedule: the plain scatter (default) and the experimental LDS row-accumulator
+    table (interpn_bwd_vol_dedup, env NRT_BWD_VOL_DEDUP=1): duplicate rows merged on chip, rows that find no slot go to memory
+    directly, the table is flushed when it fills -- against the float64 oracle; smooth field (heavy re-use), rough field (every
+    pair its own row: the direct path and many flushes)"""
+    monkeypatch.setenv('NRT_BWD_VOL_DEDUP', dedup)
+    rng = np.random.default_rng(37)
+    B, S, L = 3, (18, 47, 60), 32
+    mov = rng.standard_normal((B,) + S + (L,)).astype(F)
+    w = rng.standard_normal((B,) + S + (L,)).astype(F)
+    for kind in ('smooth', 'rough'):
+        flow = (rng.standard_normal((B,) + S + (3,)) * (1.5 if kind == 'smooth' else 25.0)).astype(F)
+        v = G(mov, dev, True)
+        f = G(flow, dev, True)
+        out = ne.layers.SpatialTransformer(fill_value=fill)([v, f])
+        (out * G(w, dev)).sum().backward()
+        for b in (0, B - 1):
+            ref, vo, lo = _shift_oracle(mov[b], flow[b], fill)
+            (ref * D64(w[b])).sum().backward()
+            close(N(v.grad[b]), vo.grad.numpy(), 'grad_vol %s b%d' % (kind, b))
+            close(N(f.grad[b]), lo.grad.numpy(), 'grad_flow %s b%d' % (kind, b))
