@@ -624,3 +624,36 @@ def test_lc3d_relayout_plan_reproduces_the_reference_layer():
         y = np.maximum(y, 0) if act == 'relu' else (np.where(y > 0, y, np.exp(np.minimum(y, 0)) - 1) if act == 'elu' else y)
         y = np.moveaxis(y, -1, 1) if cf else y
         np.testing.assert_allclose(y, g['out'], rtol=1e-5, atol=1e-6 * np.abs(g['out']).max(), err_msg=tag)
+
+
+def test_deferred_warp_tensor_mechanics_cpu():
+    """neurite_amd/deferred.py without a GPU: a DeferredWarp carries real metadata, evaluates its thunk exactly once on the first use by
+    a torch op or by a host accessor that bypasses the dispatcher, and then behaves like the tensor it stands for"""
+    from neurite_amd import deferred
+    calls = []
+
+    def thunk():
+        calls.append(1)
+        return torch.arange(48, dtype=torch.float32).reshape(1, 2, 2, 3, 4)
+
+    d = deferred.DeferredWarp((1, 2, 2, 3, 4), torch.float32, torch.device('cpu'), thunk, dict(vol=None))
+    assert isinstance(d, torch.Tensor) and d.pending and not calls
+    assert tuple(d.shape) == (1, 2, 2, 3, 4) and d.dtype == torch.float32 and d.dim() == 5 and d.numel() == 48
+    assert 'pending' in repr(d) and not calls                          # printing does not evaluate
+    assert float((d * 2).sum()) == 2 * sum(range(48)) and calls == [1] and not d.pending
+    assert type(d + 1) is torch.Tensor and type(d[0, 1]) is torch.Tensor and calls == [1]
+    assert d.data_ptr() != 0 and d.tolist()[0][0][0][0] == [0.0, 1.0, 2.0, 3.0] and d.numpy().shape == (1, 2, 2, 3, 4)
+    assert deferred.materialize(d) is d.materialize() and deferred.materialize(torch.ones(2)).shape == (2,)
+    import pickle
+    assert torch.equal(pickle.loads(pickle.dumps(d)), d.materialize())
+    # accessors that bypass the dispatcher evaluate a still-pending tensor too
+    for access in (lambda t: t.data_ptr(), lambda t: t.tolist(), lambda t: t.numpy(), lambda t: t.sum().item()):
+        calls.clear()
+        e = deferred.DeferredWarp((1, 2, 2, 3, 4), torch.float32, torch.device('cpu'), thunk, dict(vol=None))
+        access(e)
+        assert calls == [1] and not e.pending
+    # gradients flow through a materialised operand like through any constant tensor
+    x = torch.nn.Parameter(torch.ones(1, 2, 2, 3, 4))
+    e = deferred.DeferredWarp((1, 2, 2, 3, 4), torch.float32, torch.device('cpu'), thunk, dict(vol=None))
+    (x * e).sum().backward()
+    assert torch.equal(x.grad, e.materialize())
