@@ -107,3 +107,27 @@ def test_deferred_respects_semantics(dev, batch):
     assert w.data_ptr() != 0 and not w.pending
     assert isinstance(st([mov, trf]).tolist()[0][0][0][0][0], float)
     assert st([mov, trf]).cpu().numpy().shape == tuple(fix.shape)
+
+
+def test_full_size_reference_api_pipeline_and_few_channel_warps(dev):
+    """BASELINE config 2 size (160^3 x 32 one-hot, sigma = 3 field): the reference-signature pipeline with the deferred warp against
+    the C oracle's warp + Dice; the same maps stored as bfloat16 give the same Dice bit for bit; and the few-channel kernels
+    (variant 8) at 160^3: a C = 1 image and a C = 3 flow warped by the field, bit-exact against the C oracle"""
+    mov, fix, trf = synth.cfg2_batch(1, 160, 32, device=dev, seed0=1)
+    d = ne.metrics.Dice(check_input_limits=False).dice(fix, ne.layers.SpatialTransformer()([mov, trf]))
+    w = co.interpn(N(mov)[0], N(trf)[0], 'linear', None, loc_mode=1)
+    sums, _ = co.dice_sums(N(fix), w[None])
+    np.testing.assert_allclose(N(d), co.dice_from_sums(sums), rtol=1e-5)
+    assert bits_equal(N(ne.fused.warp_dice(mov.bfloat16(), trf, fix.bfloat16())), N(ne.fused.warp_dice(mov, trf, fix)))
+    del mov, fix, w
+    rng = np.random.default_rng(2)
+    for C in (1, 3):
+        vol = rng.standard_normal((160, 160, 160, C)).astype(F)
+        got = N(ne.layers.SpatialTransformer()([torch.from_numpy(vol[None]).to(dev), trf]))[0]
+        assert bits_equal(got, co.interpn(vol, N(trf)[0], 'linear', None, loc_mode=1)), C
+    # Resize(2) of a half-resolution flow (models.py:804) at full size, lean row kernel vs the oracle's resize
+    from oracle import np_oracle as npo
+    half = rng.standard_normal((80, 80, 80, 3)).astype(F)
+    got = N(ne.layers.Resize(2)(torch.from_numpy(half[None]).to(dev)))[0]
+    lin = [npo.tf_linspace(0., 79., 160) for _ in range(3)]
+    assert bits_equal(got, co.interpn(half, lin, 'linear', None, loc_mode=2))
