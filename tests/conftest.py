@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """The C-ABI library and the C oracle are build products (git-ignored): a fresh checkout builds them once before the
+    first test (hipcc cross-compiles gfx950 without a GPU; `__graft_entry__.build()` does the same)."""
+    import shutil
+    from neurite_amd import build as nbuild
+    if nbuild.is_stale() and shutil.which(os.environ.get('HIPCC', 'hipcc')):
+        nbuild.build()
+    from oracle import build as obuild
+    if shutil.which('gcc'):
+        obuild.build()
+
+
 def load_golden(name):
     """Fixtures produced by tests/golden/make_golden.py from the reference's own source."""
     with np.load(os.path.join(GOLDEN_DIR, name + '.npz'), allow_pickle=False) as z:
