@@ -19,7 +19,7 @@ for C in (1, 2, 3, 4, 8, 16):
     vol = torch.randn(B, S, S, S, C, device=dev)
     for method in ('linear', 'nearest'):
         st = ne.layers.SpatialTransformer(interp_method=method)
-        ms = timeit(lambda: st([vol, flow]))
+        ms = timeit(lambda: ne.deferred.materialize(st([vol, flow])))      # a deferred warp (C = 4 * 2^k) is evaluated here
         nbytes = B * S ** 3 * (8 * C + 12)
         print(json.dumps({'op': 'warp', 'C': C, 'method': method, 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1),
                           'frac': round(nbytes / ms / 1e6 / 8000, 3)}))

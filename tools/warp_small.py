@@ -12,5 +12,5 @@ vol = torch.randn(B, S, S, S, C, device=dev)
 st = ne.layers.SpatialTransformer()
 st._variant = variant
 for _ in range(6):
-    st([vol, flow])
+    ne.deferred.materialize(st([vol, flow]))
 torch.cuda.synchronize()
