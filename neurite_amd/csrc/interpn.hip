@@ -859,6 +859,12 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         if (can_zrun) { variant = g_auto_c32_variant; if (tune == 0) tune = (variant >= 3) ? g_auto_c32_tune : 0; }
         else if (can_lean) variant = 8;
         else if (can_lds) variant = 6;
+        else if (can_rows && method == NRT_INTERP_LINEAR && vol_bytes < (1ull << 32) && a.nout >= 4096) {
+            // 8 / 16 / 64 ... channels (feature maps): the pipelined 3-D tiles beat the row kernel at 4 x 160^3 -- C = 8 0.490 vs
+            // 0.636 ms, C = 16 0.787 vs 0.907, C = 64 2.70 vs 3.09 (tools/midc_sweep.py, profiles/r02_smallc/midc_sweep.jsonl)
+            variant = 5;
+            if (tune == 0) tune = channels <= 16 ? (2 | (3 << 4) | (4 << 8) | (1 << 12)) : 0;
+        }
         else if (can_rows) variant = 2;
         else variant = 1;
     }
