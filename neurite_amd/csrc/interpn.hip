@@ -853,7 +853,7 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
     const bool can_lds = method == NRT_INTERP_LINEAR && lds_supported(a, ndim);
     const bool can_wdd = can_rows && method == NRT_INTERP_LINEAR && ndim == 3 && nrt_wdd_supported(a.S, a.O, channels) &&
                          ((uintptr_t)loc & 3) == 0;
-    const bool can_lean = method == NRT_INTERP_LINEAR && (loc_mode == NRT_LOC_LINSPACE || loc) &&
+    const bool can_lean = (method == NRT_INTERP_LINEAR ? (loc_mode == NRT_LOC_LINSPACE || loc) : (loc_mode != NRT_LOC_LINSPACE && loc)) &&
                           nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride);
     if (variant == 0) {
         if (can_zrun) { variant = g_auto_c32_variant; if (tune == 0) tune = (variant >= 3) ? g_auto_c32_tune : 0; }
@@ -885,7 +885,7 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 6: launch_lds(a, batch, loc_mode, st); break;
         case 8:
             if (!can_lean) return NRT_ERR_UNSUPPORTED;
-            return nrt_lean_launch(&a, batch, loc_mode, st);
+            return nrt_lean_launch(&a, batch, loc_mode, method == NRT_INTERP_NEAREST ? 1 : 0, st);
         case 7: {
             if (!can_wdd) return NRT_ERR_UNSUPPORTED;
             WddCall w;
@@ -916,7 +916,7 @@ extern "C" int nrt_interpn_add_f32(const float *vol, const float *loc, const flo
     if (a.nout == 0) return NRT_OK;
     if ((loc_mode == NRT_LOC_LINSPACE || loc) && (((uintptr_t)addend) & 15) == 0 && (addend_batch_stride * 4) % 16 == 0 &&
         nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride))
-        return nrt_lean_launch(&a, batch, loc_mode, stream);
+        return nrt_lean_launch(&a, batch, loc_mode, 0, stream);
     if (lds_supported(a, ndim)) launch_lds(a, batch, loc_mode, nrt_stream(stream));
     else launch_generic<NRT_INTERP_LINEAR, float>(a, ndim, batch, loc_mode, nrt_stream(stream));
     NRT_CHECK_LAUNCH();
@@ -941,6 +941,9 @@ extern "C" int nrt_interpn_nearest_i32(const int32_t *vol, const float *loc, int
     if (rc != NRT_OK) return rc;
     a.fill_i = fill_value;
     if (a.nout == 0) return NRT_OK;
+    if (loc_mode != NRT_LOC_LINSPACE && loc &&
+        nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride))
+        return nrt_lean_launch(&a, batch, loc_mode, 2, stream);        // label maps (C <= 4): the lean tile kernel
     launch_generic<NRT_INTERP_NEAREST, int32_t>(a, ndim, batch, loc_mode, nrt_stream(stream));
     NRT_CHECK_LAUNCH();
     return NRT_OK;

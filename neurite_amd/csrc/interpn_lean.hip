@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256) void interpn_lean(InterpArgs a, unsigned lpr, 
 // 4 voxels apart in z make every corner read touch 2.5x the cache lines (measured: 0.29 ms against 0.18 ms of the LDS kernel
 // for 4 x 160^3 x 1).  Here a lane owns ONE voxel and a block a compact 2 x 4 x 32 (x, y, z) tile: a wave reads two 32-voxel
 // z-runs per corner (3-4 lines), and the tile's source box is ~110 lines that stay in L1 / L2 for the tile's 8 corner reads.
-template <int C, int MODE>
+// METHOD: 0 linear; 1 nearest on float32 data; 2 nearest on int32 data (utils.py:193-204: one gathered element per channel; the
+// fill arithmetic runs in the volume's dtype)
+template <int C, int MODE, int METHOD = 0>
 __global__ __launch_bounds__(256) void interpn_lean_tile(InterpArgs a, int ltz, int lty, unsigned nTy, unsigned nTz, unsigned ntiles,
                                                          unsigned tpb, unsigned nblk) {
     // a block walks `tpb` consecutive tiles (z fastest): the scalar set-up is paid once, the tile index advances without
@@ -212,6 +214,30 @@ __global__ __launch_bounds__(256) void interpn_lean_tile(InterpArgs a, int ltz, 
         if (MODE == NRT_LOC_SHIFT) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) p[d] = nrt_add((float)cq[d], p[d]);
+        }
+        if constexpr (METHOD != 0) {
+            const unsigned ri = nrt_mad24(nrt_mad24((unsigned)nearest_1d(p[0], a.S[0]), SY, (unsigned)nearest_1d(p[1], a.S[1])), SZ,
+                                          (unsigned)nearest_1d(p[2], a.S[2])) * (unsigned)(C * 4);
+            float v[C];
+            load_c<C>(vol, ri, v);
+            if (a.has_fill) {
+                const bool oob = (p[0] < 0.0f) || (p[0] > mxx) || (p[1] < 0.0f) || (p[1] > mxy) || (p[2] < 0.0f) || (p[2] > mxz);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (METHOD == 1) v[c] = apply_fill(v[c], oob, a.fill_f);
+                    else v[c] = __int_as_float(__float_as_int(v[c]) * (oob ? 0 : 1) + (oob ? 1 : 0) * a.fill_i);
+                }
+            }
+            if (cvalid) {
+                float *po = out + (size_t)cqf * (unsigned)C;
+                if constexpr (C == 4) __builtin_nontemporal_store((nrt_f4){v[0], v[1], v[2], v[3]}, (nrt_f4 *)po);
+                else if constexpr (C == 2) __builtin_nontemporal_store((nrt_f2){v[0], v[1]}, (nrt_f2 *)po);
+                else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) __builtin_nontemporal_store(v[c], po + c);
+                }
+            }
+            continue;
         }
         int ix, iy, iz, ux, uy, uz;
         float w0x, w1x, w0y, w1y, w0z, w1z;
@@ -281,7 +307,7 @@ __global__ __launch_bounds__(256) void interpn_lean_tile(InterpArgs a, int ltz, 
 }
 
 template <int C>
-void launch_lean_tile(const InterpArgs &a, int batch, int mode, hipStream_t st) {
+void launch_lean_tile(const InterpArgs &a, int batch, int mode, int method_kind, hipStream_t st) {
     // 2 x 4 x 32 tiles; short z extents trade z for y / x
     int ltz = 5, lty = 2;
     while (ltz > 0 && (1 << (ltz - 1)) >= a.O[2]) { --ltz; ++lty; }
@@ -296,10 +322,15 @@ void launch_lean_tile(const InterpArgs &a, int batch, int mode, hipStream_t st) 
     while (tpb > 1 && (ntiles / tpb) * (unsigned)batch < 2048u) tpb >>= 1;     // keep the chip full on small volumes
     const unsigned nblk = (ntiles + tpb - 1) / tpb;
     dim3 grid(nrt_xcd_grid(nblk), batch), blk(256);
-    if (mode == NRT_LOC_ABSOLUTE)
-        hipLaunchKernelGGL((interpn_lean_tile<C, NRT_LOC_ABSOLUTE>), grid, blk, 0, st, a, ltz, lty, nTy, nTz, ntiles, tpb, nblk);
-    else
-        hipLaunchKernelGGL((interpn_lean_tile<C, NRT_LOC_SHIFT>), grid, blk, 0, st, a, ltz, lty, nTy, nTz, ntiles, tpb, nblk);
+#define NRT_LEAN_T(MODE)                                                                                                         \
+    switch (method_kind) {                                                                                                       \
+        case 1: hipLaunchKernelGGL((interpn_lean_tile<C, MODE, 1>), grid, blk, 0, st, a, ltz, lty, nTy, nTz, ntiles, tpb, nblk); break; \
+        case 2: hipLaunchKernelGGL((interpn_lean_tile<C, MODE, 2>), grid, blk, 0, st, a, ltz, lty, nTy, nTz, ntiles, tpb, nblk); break; \
+        default: hipLaunchKernelGGL((interpn_lean_tile<C, MODE, 0>), grid, blk, 0, st, a, ltz, lty, nTy, nTz, ntiles, tpb, nblk); break; \
+    }
+    if (mode == NRT_LOC_ABSOLUTE) { NRT_LEAN_T(NRT_LOC_ABSOLUTE) }
+    else { NRT_LEAN_T(NRT_LOC_SHIFT) }
+#undef NRT_LEAN_T
 }
 
 template <int C, int VPL>
@@ -350,19 +381,20 @@ bool nrt_lean_supported(const int *vol_shape, const int *out_shape, int channels
     return true;
 }
 
-int nrt_lean_launch(const void *args, int batch, int mode, void *stream) {
+int nrt_lean_launch(const void *args, int batch, int mode, int method_kind, void *stream) {
     const InterpArgs &a = *(const InterpArgs *)args;
     hipStream_t st = nrt_stream(stream);
     if (mode != NRT_LOC_LINSPACE) {           // per-voxel locations: one voxel per lane, compact tiles
         switch (a.C) {
-            case 1: launch_lean_tile<1>(a, batch, mode, st); break;
-            case 2: launch_lean_tile<2>(a, batch, mode, st); break;
-            case 3: launch_lean_tile<3>(a, batch, mode, st); break;
-            default: launch_lean_tile<4>(a, batch, mode, st); break;
+            case 1: launch_lean_tile<1>(a, batch, mode, method_kind, st); break;
+            case 2: launch_lean_tile<2>(a, batch, mode, method_kind, st); break;
+            case 3: launch_lean_tile<3>(a, batch, mode, method_kind, st); break;
+            default: launch_lean_tile<4>(a, batch, mode, method_kind, st); break;
         }
         NRT_CHECK_LAUNCH();
         return NRT_OK;
     }
+    if (method_kind != 0) return NRT_ERR_UNSUPPORTED;      // the row form (regular grids) is linear only
     switch (a.C) {
         case 1:
             // 4 voxels per lane: 16-byte location loads and stores need z % 4 == 0 (then nout % 4 == 0 and the contiguous batch

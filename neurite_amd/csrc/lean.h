@@ -5,5 +5,6 @@
 // limits of its address arithmetic)
 bool nrt_lean_supported(const int *vol_shape, const int *out_shape, int channels, int ndim, const void *vol, const void *loc,
                         const void *out, long long vol_bs, long long loc_bs);
-// args: the InterpArgs of the call (interpn_core.h)
-int nrt_lean_launch(const void *args, int batch, int mode, void *stream);
+// args: the InterpArgs of the call (interpn_core.h); method_kind 0 linear, 1 nearest (float32 data), 2 nearest (int32 data; per-voxel
+// locations only)
+int nrt_lean_launch(const void *args, int batch, int mode, int method_kind, void *stream);

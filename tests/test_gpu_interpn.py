@@ -160,6 +160,17 @@ def test_lean_kernel(dev, C, S):
             assert bits_equal(got, want), (kind, fill)
             got = N(ne.utils.interpn(G(vol, dev), G(ijk(S) + shift, dev), fill_value=fill, _variant=8))
             assert bits_equal(got, co.interpn(vol, ijk(S) + shift, 'linear', fill)), (kind, fill, 'abs')
+    # nearest interpolation through the same tile kernel: float32 data, and int32 label maps (fill arithmetic in int32)
+    for kind in ('smooth', 'edge'):
+        for fill in (None, 2.0):
+            st = ne.layers.SpatialTransformer(interp_method='nearest', fill_value=fill)
+            st._variant = 8
+            got = N(st([G(vol[None], dev), G(fields[kind][None], dev)]))[0]
+            assert bits_equal(got, co.interpn(vol, fields[kind], 'nearest', fill, loc_mode=1)), ('nearest', kind, fill)
+            lab = rng.integers(0, 50, S + (C,)).astype(np.int32)
+            goti = N(ne.utils.interpn(G(lab, dev), G(ijk(S) + fields[kind], dev), 'nearest', None if fill is None else int(fill)))
+            assert goti.dtype == np.int32
+            assert np.array_equal(goti, npo.interpn(lab, ijk(S) + fields[kind], 'nearest', None if fill is None else int(fill)))
     # batched, other output grid; auto selection takes the same kernel for these shapes
     B, So = 3, (7, 9, 8)
     vb = rng.standard_normal((B,) + S + (C,)).astype(F)
