@@ -886,6 +886,11 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 8:
             if (!can_lean) return NRT_ERR_UNSUPPORTED;
             return nrt_lean_launch(&a, batch, loc_mode, method == NRT_INTERP_NEAREST ? 1 : 0, st);
+        case 9:
+            if (method != NRT_INTERP_LINEAR ||
+                !nrt_lds2_supported(a.S, a.O, channels, ndim, vol, loc, out, nullptr, vol_batch_stride, loc_batch_stride, 0, loc_mode))
+                return NRT_ERR_UNSUPPORTED;
+            return nrt_lds2_launch(&a, batch, loc_mode, st);
         case 7: {
             if (!can_wdd) return NRT_ERR_UNSUPPORTED;
             WddCall w;

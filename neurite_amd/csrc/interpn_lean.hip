@@ -18,36 +18,9 @@
 
 #include "interpn_core.h"
 #include "lean.h"
+#include "lean_core.h"
 
 namespace {
-
-template <int C> struct Vec;
-template <> struct Vec<1> { typedef float T; };
-template <> struct Vec<2> { typedef nrt_f2 T; };
-template <> struct Vec<3> { struct __attribute__((packed, aligned(4))) T { float v[3]; }; };
-template <> struct Vec<4> { typedef nrt_f4 T; };
-
-template <int C>
-__device__ __forceinline__ void load_c(const char *base, unsigned off, float (&v)[C]) {
-    if constexpr (C == 1) v[0] = *(const float *)(base + off);
-    else if constexpr (C == 2) { const nrt_f2 t = *(const nrt_f2 *)(base + off); v[0] = t[0]; v[1] = t[1]; }
-    else if constexpr (C == 3) {
-        const typename Vec<3>::T t = *(const typename Vec<3>::T *)(base + off);
-        v[0] = t.v[0]; v[1] = t.v[1]; v[2] = t.v[2];
-    } else { const nrt_f4 t = *(const nrt_f4 *)(base + off); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
-}
-
-// utils.py:139-153 for one dimension; `up` = 1 when the upper corner is a different voxel (l1 != l0)
-__device__ __forceinline__ void lean_corner(float p, float mx, int imax, int &i0, int &up, float &w0, float &w1) {
-    const float f = floorf(p);                                           // :139
-    const float cl = __builtin_amdgcn_fmed3f(p, 0.0f, mx);               // :142  clip = median(p, 0, max)
-    const float l0 = __builtin_amdgcn_fmed3f(f, 0.0f, mx);               // :143
-    const float l1 = fminf(nrt_add(l0, 1.0f), mx);                       // :146  (l0 + 1 >= 1: the lower clip never binds)
-    i0 = min(max((int)l0, 0), imax);                                     // :147; the integer clamp only acts on NaN locations
-    up = (l1 > l0) ? 1 : 0;
-    w0 = nrt_sub(l1, cl);                                                // :152
-    w1 = nrt_sub(1.0f, w0);                                              // :153
-}
 
 template <int C, int VPL, int MODE>
 __global__ __launch_bounds__(256) void interpn_lean(InterpArgs a, unsigned lpr, unsigned m_lpr, unsigned cpp, unsigned nblk) {
@@ -308,10 +281,16 @@ __global__ __launch_bounds__(256) void interpn_lean_tile(InterpArgs a, int ltz, 
 
 template <int C>
 void launch_lean_tile(const InterpArgs &a, int batch, int mode, int method_kind, hipStream_t st) {
-    // 2 x 4 x 32 tiles; short z extents trade z for y / x
+    // 2 x 4 x 32 tiles (a wave: two 32-voxel z-runs); linear interpolation of 2..4 channels: 8 x 2 x 16 (a wave: 2 x 2 x 16), whose
+    // corner loads touch fewer distinct lines per instruction (tools/lean_geo_sweep.sh, 4 x 160^3: C = 2 0.206 -> 0.186 ms,
+    // C = 3 0.299 -> 0.263, C = 4 0.344 -> 0.297; C = 1 0.117 -> 0.136).  Short z extents trade z for y / x
     int ltz = 5, lty = 2;
+    if (C >= 2 && method_kind == 0) { ltz = 4; lty = 1; }
     while (ltz > 0 && (1 << (ltz - 1)) >= a.O[2]) { --ltz; ++lty; }
     while (lty > 0 && (1 << (lty - 1)) >= a.O[1]) --lty;
+    static int geo_env = -1;                  // experiments: NRT_LEAN_GEO = ltz * 16 + lty (tools/lean_geo_sweep.sh)
+    if (geo_env < 0) { const char *e = getenv("NRT_LEAN_GEO"); geo_env = e ? atoi(e) : 0; }
+    if (geo_env > 0 && (geo_env >> 4) + (geo_env & 15) <= 8) { ltz = geo_env >> 4; lty = geo_env & 15; }
     const int ltx = 8 - ltz - lty;
     const unsigned nTx = (a.O[0] + (1 << ltx) - 1) >> ltx, nTy = (a.O[1] + (1 << lty) - 1) >> lty, nTz = (a.O[2] + (1 << ltz) - 1) >> ltz;
     const unsigned ntiles = nTx * nTy * nTz;

@@ -196,6 +196,49 @@ def test_lean_kernel(dev, C, S):
     assert out.shape == (1,) + S + (C,)
 
 
+@pytest.mark.parametrize('C', [1, 2, 3, 4])
+@pytest.mark.parametrize('S', [(12, 10, 32), (19, 13, 48), (4, 4, 16), (5, 7, 16)])
+def test_lds2_kernel(dev, C, S):
+    """variant 9 (csrc/interpn_lds2.hip: coalesced 16-byte location loads, source box staged in LDS by 16-byte buffer loads,
+    results stored through LDS) == generic kernel == oracle, bit for bit: smooth fields (staged), rough fields (box too large ->
+    global corners), edge values, fill, absolute / shift locations, ragged x / y tile edges, source volumes of another shape"""
+    rng = np.random.default_rng(90 + C + S[0])
+    vol = rng.standard_normal(S + (C,)).astype(F)
+    fields = {
+        'smooth': N(synth.smooth_displacement(5, 48, 2.0, coarse=6))[:S[0], :S[1], :S[2]].copy(),
+        'rough': rng.uniform(-30, 30, S + (3,)).astype(F),
+        'edge': rng.choice(np.array([-3, -1, -0.5, 0, 0.5, 1, 2, 7.5], F), S + (3,)).astype(F),
+    }
+    for kind, shift in fields.items():
+        for fill in (None, 0.25):
+            st = ne.layers.SpatialTransformer(fill_value=fill)
+            st._variant = 9
+            got = N(st([G(vol[None], dev), G(shift[None], dev)]))[0]
+            assert bits_equal(got, co.interpn(vol, shift, 'linear', fill, loc_mode=1)), (kind, fill)
+            got = N(ne.utils.interpn(G(vol, dev), G(ijk(S) + shift, dev), fill_value=fill, _variant=9))
+            assert bits_equal(got, co.interpn(vol, ijk(S) + shift, 'linear', fill)), (kind, fill, 'abs')
+    # batched; the source volume has another shape than the output grid (and is smaller than a tile's box in z)
+    B, Sv = 3, (7, 9, 8)
+    vb = rng.standard_normal((B,) + Sv + (C,)).astype(F)
+    tb = rng.normal(0, 2, (B,) + S + (3,)).astype(F)
+    st = ne.layers.SpatialTransformer()
+    st._variant = 9
+    assert bits_equal(N(st([G(vb, dev), G(tb, dev)])), npo.spatial_transformer(vb, tb))
+    # NaN / Inf locations: any value, no fault
+    bad = fields['smooth'].copy()
+    bad[::3, ::2, ::2, 0] = np.nan
+    bad[1::3, ::2, ::2, 1] = np.inf
+    bad[2::3, 1::2, ::2, 2] = -np.inf
+    st = ne.layers.SpatialTransformer(fill_value=0.0)
+    st._variant = 9
+    out = st([G(vol[None], dev), G(bad[None], dev)])
+    torch.cuda.synchronize()
+    assert out.shape == (1,) + S + (C,)
+    # z extents that are not multiples of 16 are refused by this variant (the auto-selection takes another kernel)
+    with pytest.raises(ne.errors.NeuriteAmdError):
+        ne.utils.interpn(G(vol[:, :, :9].copy(), dev), G(ijk(S)[:, :, :9].copy(), dev), _variant=9)
+
+
 def test_lean_kernel_warp_add(dev):
     """compose / VecInt update b + transform(a, b) at a size that takes the lean kernel (C = 3, 16-byte aligned tensors)"""
     rng = np.random.default_rng(72)

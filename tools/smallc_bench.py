@@ -19,6 +19,8 @@ for C in (1, 2, 3, 4, 8, 16):
     vol = torch.randn(B, S, S, S, C, device=dev)
     for method in ('linear', 'nearest'):
         st = ne.layers.SpatialTransformer(interp_method=method)
+        import os
+        st._variant = int(os.environ.get('NRT_SMALLC_VARIANT', '0')) if (method == 'linear' and C <= 4) else 0
         ms = timeit(lambda: ne.deferred.materialize(st([vol, flow])))      # a deferred warp (C = 4 * 2^k) is evaluated here
         nbytes = B * S ** 3 * (8 * C + 12)
         print(json.dumps({'op': 'warp', 'C': C, 'method': method, 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1),
