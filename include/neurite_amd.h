@@ -373,7 +373,7 @@ int nrt_conv1d_axis_f32(const float *x, const float *kernel, float *y, long long
 size_t nrt_minmax_workspace_bytes(long long outer, int inner);
 int nrt_minmax_norm_f32(const float *x, float *y, long long outer, long long reduce_len, int inner, void *workspace,
                         size_t workspace_bytes, void *stream);
-/* out2 = {min, max} of x[0..n) on the device (no host synchronisation); workspace >= 8 bytes */
+/* out2 = {min, max} of x[0..n) on the device (no host synchronisation); workspace >= nrt_minmax_workspace_bytes(1, 1) */
 int nrt_minmax_f32(const float *x, long long n, float *out2, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------

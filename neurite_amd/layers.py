@@ -424,8 +424,18 @@ class GaussianBlur(_Layer):
     def call(self, x):
         if not any(s > 0 for s in self.sigma):
             return x
-        kernel = utils.gaussian_kernel(sigma=self.sigma, random=self.random, min_sigma=self.min_sigma, separate=True,
-                                       dtype=x.dtype, seed=self.seed)
+        if self.random:
+            kernel = utils.gaussian_kernel(sigma=self.sigma, random=True, min_sigma=self.min_sigma, separate=True,
+                                           dtype=x.dtype, seed=self.seed)
+        else:
+            # fixed sigmas: the taps are built once per device (a host-built kernel costs three blocking copies per call)
+            key = (str(x.device), x.dtype, tuple(self.sigma))
+            if getattr(self, '_taps_key', None) != key:
+                kernel = utils.gaussian_kernel(sigma=self.sigma, separate=True, dtype=x.dtype)
+                kernel = kernel if isinstance(kernel, (list, tuple)) else [kernel]
+                self._taps = [k.to(x.device).contiguous() for k in kernel]
+                self._taps_key = key
+            kernel = self._taps
         return utils.separable_conv(x, kernel, batched=True)
 
 

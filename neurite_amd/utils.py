@@ -664,9 +664,10 @@ def _device_minmax(x):
     lib = _lib.lib()
     dev = x.device
     out = torch.empty((2,), dtype=torch.float32, device=dev)
-    ws = torch.empty((16,), dtype=torch.uint8, device=dev)
+    nws = int(lib.nrt_minmax_workspace_bytes(1, 1))
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.nrt_minmax_f32(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.ptr(ws), 16, _lib.stream_ptr(dev))
+        rc = lib.nrt_minmax_f32(_lib.ptr(x), x.numel(), _lib.ptr(out), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
     _lib.check(rc, 'nrt_minmax_f32')
     return out
 

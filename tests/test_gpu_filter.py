@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import neurite_amd as ne
-from conftest import load_golden
+from conftest import bits_equal, load_golden
 from oracle import np_oracle as npo
 
 pytestmark = pytest.mark.gpu
@@ -91,6 +91,39 @@ def test_blur_larger_shapes_vs_oracle(dev):
         mm = N(ne.utils.minmax_norm(G(x, dev), axis=tuple(range(1, x.ndim))))
         np.testing.assert_allclose(mm, npo.minmax_norm(x, axis=tuple(range(1, x.ndim))), rtol=1e-6, atol=1e-7)
         assert mm.min() == 0.0 and mm.max() == 1.0
+
+
+def test_fast_separable_passes_equal_plain_kernels(dev, monkeypatch):
+    """conv1d_axis_rows / conv1d_inner_lds (csrc/filter.hip: R outputs per lane, taps from the scalar cache, LDS-staged rows for the
+    innermost axis) add the taps of an output in the order of the plain kernel: bit-identical results, borders included; and the
+    vectorised min-max passes equal the oracle"""
+    rng = np.random.default_rng(11)
+    cases = [((2, 40, 36, 64, 1), [3.0, 1.0, 2.0]), ((1, 21, 40, 136, 1), [1.0, 2.5, 3.0]), ((3, 9, 70, 33, 1), 1.2),
+             ((2, 24, 20, 16, 8), 1.5), ((1, 130, 260, 1), [2.0, 4.0]), ((4, 8, 8, 300, 1), [0.0, 0.0, 6.0])]
+    for shape, sigma in cases:
+        x = G(rng.standard_normal(shape).astype(F), dev)
+        monkeypatch.delenv('NRT_CONV1D_GENERIC', raising=False)
+        fast = N(ne.layers.GaussianBlur(sigma=sigma)(x))
+        monkeypatch.setenv('NRT_CONV1D_GENERIC', '1')
+        plain = N(ne.layers.GaussianBlur(sigma=sigma)(x))
+        monkeypatch.delenv('NRT_CONV1D_GENERIC', raising=False)
+        assert bits_equal(fast, plain), (shape, sigma)
+        np.testing.assert_allclose(fast, npo.gaussian_blur(N(x), sigma), rtol=1e-5, atol=2e-6)
+    # even widths, VALID padding, widths above the run length, non-finite taps (skipped at the borders by both forms)
+    x = G(rng.standard_normal((2, 33, 48, 72, 1)).astype(F), dev)
+    ks = [rng.standard_normal(w).astype(F) for w in (4, 11, 30)]
+    ks[1][3] = np.inf
+    for padding in ('SAME', 'VALID'):
+        monkeypatch.delenv('NRT_CONV1D_GENERIC', raising=False)
+        fast = N(ne.utils.separable_conv(x, ks, batched=True, padding=padding))
+        monkeypatch.setenv('NRT_CONV1D_GENERIC', '1')
+        plain = N(ne.utils.separable_conv(x, ks, batched=True, padding=padding))
+        monkeypatch.delenv('NRT_CONV1D_GENERIC', raising=False)
+        assert bits_equal(fast, plain), padding
+    for shape in ((3, 50, 40, 36, 1), (2, 1001), (5, 7, 9, 11, 1)):
+        x = rng.standard_normal(shape).astype(F)
+        ax = tuple(range(1, x.ndim))
+        np.testing.assert_allclose(N(ne.utils.minmax_norm(G(x, dev), axis=ax)), npo.minmax_norm(x, axis=ax), rtol=1e-6, atol=1e-7)
 
 
 def test_draw_perlin(dev):
