@@ -139,8 +139,14 @@ int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long long nvox, 
 int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
                            float laplace_smoothing, long long *counts, float *dice,
                            void *workspace, size_t workspace_bytes, void *stream);
+/* the same with minmax [4] = min t, max t, min p, max p of the inputs from the same pass (the range asserts of
+ * neurite/tf/metrics.py:439-444); nlabels in {4, 8, ..., 256} and 16-byte aligned maps, else NRT_ERR_UNSUPPORTED */
+int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                                  float laplace_smoothing, long long *counts, float *dice, float *minmax,
+                                  void *workspace, size_t workspace_bytes, void *stream);
 
-/* Hard Dice from label maps [batch, nvox] int32; labels outside [0, nlabels) match nothing. */
+/* Hard Dice from label maps [batch, nvox] int32; labels outside [0, nlabels) match nothing.  workspace: NULL, or
+ * nrt_dice_workspace_bytes(nvox, nlabels, batch) bytes (then the block histograms are reduced without global atomics). */
 int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_pred, long long nvox, int nlabels,
                             int batch, float laplace_smoothing, long long *counts, float *dice,
                             void *workspace, size_t workspace_bytes, void *stream);

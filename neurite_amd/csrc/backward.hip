@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void warp_dice_bwd_rows(InterpBwdArgs ba, cons
 // search 1.0 ms, everything else 0.75 ms: 7.6 ms against 3.6 ms for the plain scatter.  ds_add_f32 retires about one lane
 // every 3.4 clk per CU (0.3 lane-atomics per clk), SLOWER than the L2 atomic units serve the same CU (0.47 per clk at 3.6 ms).
 // An on-chip merge therefore has to accumulate without LDS atomics (owner-computes over per-row chains, or a sort); this kernel
-// is kept as the correct, selectable experiment (env NRT_BWD_VOL_DEDUP=1), not as the default.
+// is kept as the correct, selectable experiment (env NRT_BWD_VOL_DEDUP=1); interpn_bwd_vol_sort below is the merge that pays.
 constexpr int BV_SLOTS = 1024;           // power of two
 constexpr int BV_NG = 32;                // lane-groups (voxels) per x-plane of the block's 4 x 8 patch
 constexpr int BV_U = 2;                  // x-planes per iteration
@@ -721,6 +721,154 @@ __global__ __launch_bounds__(256) void interpn_bwd_vol_dedup(InterpBwdArgs ba) {
     flush();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// d out / d vol at C = 32, duplicate rows merged by a counting sort (no LDS float atomics).
+//
+// Per iteration a block files the (row, weight) pairs of BS_U x-planes of its 4 x 8 patch (128 voxels, 1024 pairs: on the bench
+// field they name ~310 distinct rows, tools/ measurements in DESIGN 4.7).  Then, with integer LDS atomics only:
+//   1. every pair finds or claims the slot of its row in an open-addressing table (ds_cmpswap) and takes a rank inside the slot
+//      (returning ds_add_u32);
+//   2. a block scan over the slot counts gives every used slot a segment of the sorted pair list and an index in the list of
+//      distinct rows;
+//   3. every pair writes itself to segment offset + rank;
+//   4. a half-wave (32 lanes = the 32 channels) per distinct row walks the row's segment, sums weight * gradient in a register
+//      and sends ONE row of float atomics to memory, then clears the slot.
+// The L2 atomic units, the bottleneck of the plain scatter (interpn_bwd_rows), see 1024 / 310 = 3.3x fewer rows.
+// MEASURED (round 2, one 160^3 x 32 volume, tools/bwd_vol_bench.py, time including the 524 MB zero fill): plain scatter 3.61 ms,
+// this kernel 1.68 ms with 256 threads and 1.33 ms with 512 (two x-planes filed at a time, 16 half-waves merging); worst-case
+// field U(-80, 80): 2.87 -> 2.58 ms.  Default for d vol at C = 32 (NRT_BWD_VOL_DEDUP=0 selects the plain scatter).
+constexpr int BS_SLOTS = 2048;           // power of two, >= 2 x pairs per iteration
+constexpr int BS_U = 4;                  // x-planes per iteration
+constexpr int BS_NV = BV_NG * BS_U;      // voxels per iteration
+constexpr int BS_NPAIR = BS_NV * 8;
+constexpr int BS_NT = 512;               // threads: two x-planes are filed at a time, 16 half-waves merge rows
+
+template <int MODE>
+__global__ __launch_bounds__(BS_NT) void interpn_bwd_vol_sort(InterpBwdArgs ba) {
+    constexpr int G = 8, C = 32, NT = BS_NT, NW = NT / 64, SPT = BS_SLOTS / NT, PL = NT / (BV_NG * G);   // PL: planes filed per pass
+    static_assert(BS_U % PL == 0 && BS_SLOTS % NT == 0, "geometry");
+    const InterpArgs &a = ba.f;
+    int b = 0, x0 = 0, y0 = 0, z0 = 0, xlen = 0;
+    unsigned prow;
+    if (!xmarch_block(ba.tg, a.O[0], b, prow, x0, y0, z0, xlen)) return;
+    __shared__ __attribute__((aligned(16))) float s_g[BS_NV * C];     // gradient rows of the iteration's voxels
+    __shared__ unsigned s_idx[BS_NPAIR];                              // row of a pair; then its slot | rank << 16
+    __shared__ float s_wt[BS_NPAIR];                                  // its weight
+    __shared__ unsigned short s_sorted[BS_NPAIR];                     // pairs ordered by slot
+    __shared__ unsigned tag[BS_SLOTS];                                // row held by a slot
+    __shared__ unsigned cnt[BS_SLOTS];                                // pairs of the slot, then offset | count << 16
+    __shared__ unsigned short ulist[BS_NPAIR];                        // used slots
+    __shared__ unsigned wsum[NW];
+    __shared__ unsigned nuniq_s;
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    const nrt_f4 *go = (const nrt_f4 *)(ba.gout + (long long)b * a.out_bs);
+    float *gv = ba.gvol + (long long)b * a.vol_bs;
+    const int lg = threadIdx.x % G;
+    const unsigned g = (threadIdx.x / G) % BV_NG, pl = threadIdx.x / (G * BV_NG);     // patch voxel, plane of the pass
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned Y = (unsigned)a.S[1], Z = (unsigned)a.S[2];
+    for (int i = threadIdx.x; i < BS_SLOTS; i += NT) { tag[i] = BV_EMPTY; cnt[i] = 0u; }
+    __syncthreads();
+
+    const unsigned niter = ((unsigned)xlen + BS_U - 1) / BS_U;
+    for (unsigned it = 0; it < niter; ++it) {
+        // ---- file the iteration's (row, weight) pairs and gradient rows ------------------------------------------------
+#pragma unroll
+        for (int up = 0; up < BS_U / PL; ++up) {
+            const unsigned u = (unsigned)up * PL + pl;
+            const int x = x0 + (int)(it * BS_U + u), y = y0 + (int)(g >> ba.tg.ltz), z = z0 + (int)(g & ((1u << ba.tg.ltz) - 1u));
+            const bool in = x < x0 + xlen && y < a.O[1] && z < a.O[2];
+            const unsigned q = in ? ((unsigned)x * (unsigned)a.O[1] + (unsigned)y) * (unsigned)a.O[2] + (unsigned)z : a.nout - 1;
+            int qd[NRT_MAXD];
+            float p[NRT_MAXD];
+            decode<3>(a, q, qd);
+            load_loc<3, MODE>(a, locb, q, qd, p);
+            nrt_f4 gq = go[(long long)q * G + lg];
+            const bool oob = a.has_fill ? out_of_bounds<3>(a, p) : false;
+            int i0[3], i1[3];
+            float w0[3], w1[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+            const bool dead = !in || oob;
+            if (dead) gq = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+            const unsigned vslot = u * BV_NG + g;
+            ((nrt_f4 *)s_g)[vslot * G + lg] = gq;
+            const int bx = (lg >> 2) & 1, by = (lg >> 1) & 1, bz = lg & 1;       // lane lg files corner lg
+            const unsigned ix = bx ? i1[0] : i0[0], iy = by ? i1[1] : i0[1], iz = bz ? i1[2] : i0[2];
+            s_idx[vslot * 8 + lg] = dead ? BV_EMPTY : (ix * Y + iy) * Z + iz;       // a dead pair names no row
+            s_wt[vslot * 8 + lg] = dead ? 0.0f : (bx ? w1[0] : w0[0]) * (by ? w1[1] : w0[1]) * (bz ? w1[2] : w0[2]);
+        }
+        __syncthreads();
+        // ---- 1. slot and rank of every pair ----------------------------------------------------------------------------
+        for (unsigned pi = threadIdx.x; pi < (unsigned)BS_NPAIR; pi += NT) {
+            unsigned found = BV_EMPTY;
+            const unsigned row = s_idx[pi];
+            if (row != BV_EMPTY) {
+                unsigned h = (row * 2654435761u) >> 21;         // multiplicative hash, top 11 bits
+#pragma unroll 1
+                for (;;) {                                      // <= 1024 distinct rows in 2048 slots: always ends
+                    const unsigned old = atomicCAS(&tag[h], BV_EMPTY, row);
+                    if (old == BV_EMPTY || old == row) break;
+                    h = (h + 1u) & (BS_SLOTS - 1u);
+                }
+                found = h | (atomicAdd(&cnt[h], 1u) << 16);
+            }
+            s_idx[pi] = found;                                  // the row lives in tag[slot] from here on
+        }
+        __syncthreads();
+        // ---- 2. segments: exclusive scan of the slot counts (pairs | used slots << 16), SPT slots per thread --------------
+        {
+            unsigned c[SPT], tot = 0u;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) { c[j] = cnt[threadIdx.x * SPT + j]; tot += c[j] | (c[j] ? 0x10000u : 0u); }
+            unsigned incl = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = (unsigned)__shfl_up((int)incl, off, 64);
+                if (lane >= (unsigned)off) incl += o;
+            }
+            if (lane == 63u) wsum[wv] = incl;
+            __syncthreads();
+            unsigned base = incl - tot;
+            for (unsigned w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+            if (threadIdx.x == NT - 1) nuniq_s = (base + tot) >> 16;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                if (c[j]) {
+                    cnt[threadIdx.x * SPT + j] = (base & 0xffffu) | (c[j] << 16);
+                    ulist[base >> 16] = (unsigned short)(threadIdx.x * SPT + j);
+                    base += c[j] | 0x10000u;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. pairs into their segments ---------------------------------------------------------------------------------
+        for (unsigned pi = threadIdx.x; pi < (unsigned)BS_NPAIR; pi += NT) {
+            const unsigned sl = s_idx[pi];
+            if (sl != BV_EMPTY) s_sorted[(cnt[sl & 0xffffu] & 0xffffu) + (sl >> 16)] = (unsigned short)pi;
+        }
+        __syncthreads();
+        // ---- 4. one half-wave per distinct row: sum its pairs, one row of atomics, clear the slot ---------------------------
+        {
+            const unsigned grp = threadIdx.x >> 5, ch = threadIdx.x & 31u;
+            const unsigned nuniq = nuniq_s;
+            for (unsigned u = grp; u < nuniq; u += NT / 32) {
+                const unsigned slot = ulist[u];
+                const unsigned sg = cnt[slot], off = sg & 0xffffu, n = sg >> 16;
+                const unsigned row = tag[slot];
+                float acc = 0.0f;
+                for (unsigned j = 0; j < n; ++j) {
+                    const unsigned e = s_sorted[off + j];
+                    acc += s_wt[e] * s_g[(e >> 3) * C + ch];
+                }
+                if (acc != 0.0f) atomic_add_f32(gv + (size_t)row * C + ch, acc);
+                if (ch == 0u) { tag[slot] = BV_EMPTY; cnt[slot] = 0u; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // nearest interpolation (utils.py:193-204): out[q, c] = vol[idx(round(loc_q)), c]  [* (1 - oob) + oob * fill].
 // tf.round has no gradient (d / d loc = 0); d / d vol is tf.gather's scatter-add of g[q, c] into the gathered element,
 // masked by (1 - oob) when a fill value is set.  One thread per output element, float atomics.
@@ -787,10 +935,22 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
             const unsigned per_batch = xmarch_setup(out_shape, batch, t, ba.tg);
             grid = dim3(nrt_xcd_grid(per_batch * (unsigned)batch), 1);
             const char *dedup_env = getenv("NRT_BWD_VOL_DEDUP");          // read per call: tests switch it
-            const int use_dedup = dedup_env ? atoi(dedup_env) : 0;
+            const int use_dedup = dedup_env ? atoi(dedup_env) : 2;       // 0 plain scatter, 1 LDS accumulator table, 2 counting-sort merge
             unsigned long long rows = 1;
             for (int d = 0; d < 3; ++d) rows *= (unsigned long long)vol_shape[d];
-            if (grad_vol && use_dedup && rows < 0xffffffffull) {
+            if (grad_vol && use_dedup == 2 && rows < 0xffffffffull) {
+                // d vol by the sort-merge kernel (duplicate rows merged before L2), d loc by the rows kernel
+                InterpBwdArgs bv = ba;
+                bv.gloc = nullptr;
+                switch (loc_mode) {
+                    case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((interpn_bwd_vol_sort<NRT_LOC_ABSOLUTE>), grid, dim3(BS_NT), 0, st, bv); break;
+                    case NRT_LOC_SHIFT: hipLaunchKernelGGL((interpn_bwd_vol_sort<NRT_LOC_SHIFT>), grid, dim3(BS_NT), 0, st, bv); break;
+                    default: hipLaunchKernelGGL((interpn_bwd_vol_sort<NRT_LOC_LINSPACE>), grid, dim3(BS_NT), 0, st, bv); break;
+                }
+                NRT_CHECK_LAUNCH();
+                if (!grad_loc) return NRT_OK;
+                ba.gvol = nullptr;
+            } else if (grad_vol && use_dedup && rows < 0xffffffffull) {
                 // d vol through the LDS row-accumulator table (duplicate rows merged before L2), d loc by the rows kernel
                 const size_t dyn = (size_t)BV_SLOTS * 32 * 4 + BV_SLOTS * 4 + (size_t)BV_NG * BV_U * 32 * 4 + 3 * (size_t)BV_NG * BV_U * 8 * 4;
                 InterpBwdArgs bv = ba;

@@ -168,9 +168,11 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const float *__r
 // ============================================================================================
 // hard Dice from probabilities: arg-max (ties -> lowest label) + one-hot counting, G lanes/voxel
 // ============================================================================================
-template <int G>
+// MINMAX: also the extrema of both inputs (the range asserts of metrics.py:439-444 without a second pass over the maps)
+template <int G, bool MINMAX>
 __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const float *__restrict__ yt, const float *__restrict__ yp,
-                                                            long long nvox, unsigned *__restrict__ ipart) {
+                                                            long long nvox, unsigned *__restrict__ ipart,
+                                                            float *__restrict__ mpart) {
     constexpr int NG = DICE_BLOCK / G;
     constexpr int L = 4 * G;
     const int b = blockIdx.y;
@@ -180,11 +182,16 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const float *__restr
     const long long g = threadIdx.x / G;
     const long long stride = (long long)gridDim.x * NG;
     unsigned ntp[4] = {0, 0, 0, 0}, nt[4] = {0, 0, 0, 0}, np_[4] = {0, 0, 0, 0};
+    float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
 
 #pragma unroll 2
     for (long long v = (long long)blockIdx.x * NG + g; v < nvox; v += stride) {
         const nrt_f4 t = __builtin_nontemporal_load(&t4[v * G + lg]);
         const nrt_f4 p = __builtin_nontemporal_load(&p4[v * G + lg]);
+        if (MINMAX) {
+            mnt = fminf(mnt, fminf(fminf(t[0], t[1]), fminf(t[2], t[3]))); mxt = fmaxf(mxt, fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])));
+            mnp = fminf(mnp, fminf(fminf(p[0], p[1]), fminf(p[2], p[3]))); mxp = fmaxf(mxp, fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));
+        }
         float bt = t[0], bp = p[0];
         int at = 4 * lg, ap = 4 * lg;
 #pragma unroll
@@ -215,6 +222,7 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const float *__restr
         np_[k] = wave_xor_add(np_[k], G);
     }
     __shared__ unsigned red[DICE_BLOCK / NRT_WAVE][3 * L];
+    __shared__ float redm[DICE_BLOCK / NRT_WAVE][4];
     const int lane = threadIdx.x & (NRT_WAVE - 1), wv = threadIdx.x / NRT_WAVE;
     if (lane < G) {
 #pragma unroll
@@ -224,12 +232,44 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const float *__restr
             red[wv][2 * L + 4 * lane + k] = np_[k];
         }
     }
+    if (MINMAX) {
+        for (int off = 1; off < NRT_WAVE; off <<= 1) {
+            mnt = fminf(mnt, __shfl_xor(mnt, off, NRT_WAVE)); mxt = fmaxf(mxt, __shfl_xor(mxt, off, NRT_WAVE));
+            mnp = fminf(mnp, __shfl_xor(mnp, off, NRT_WAVE)); mxp = fmaxf(mxp, __shfl_xor(mxp, off, NRT_WAVE));
+        }
+        if (lane == 0) { redm[wv][0] = mnt; redm[wv][1] = mxt; redm[wv][2] = mnp; redm[wv][3] = mxp; }
+    }
     __syncthreads();
     const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
     for (int i = threadIdx.x; i < 3 * L; i += DICE_BLOCK) {
         unsigned s = red[0][i];
         for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2) s += red[w2][i];
         ipart[pbase * 3 * L + i] = s;
+    }
+    if (MINMAX && threadIdx.x < 4) {
+        float m = redm[0][threadIdx.x];
+        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2)
+            m = (threadIdx.x & 1) ? fmaxf(m, redm[w2][threadIdx.x]) : fminf(m, redm[w2][threadIdx.x]);
+        mpart[pbase * 4 + threadIdx.x] = m;
+    }
+}
+
+// extrema of `rows` block quadruples (min t, max t, min p, max p) -> minmax[4]
+__global__ __launch_bounds__(256) void minmax_rows(const float *__restrict__ mpart, int rows, float *__restrict__ minmax) {
+    __shared__ float sm[256][4];
+    float m[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+    for (int k = threadIdx.x; k < rows; k += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = (i & 1) ? fmaxf(m[i], mpart[(long long)k * 4 + i]) : fminf(m[i], mpart[(long long)k * 4 + i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[threadIdx.x][i] = m[i];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int i = threadIdx.x;
+        float r = sm[0][i];
+        for (int k = 1; k < 256; ++k) r = (i & 1) ? fmaxf(r, sm[k][i]) : fminf(r, sm[k][i]);
+        minmax[i] = r;
     }
 }
 
@@ -255,8 +295,28 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_generic(const float
 }
 
 // hard Dice from int32 label maps: per-block LDS histogram (integer atomics: order-independent)
+// One LDS atomic per DISTINCT label of a wave: label maps are piecewise constant, so the 64 lanes of a wave hold one to three
+// labels and per-lane atomics would all queue on the same LDS address.  The first four distinct labels are counted by ballot +
+// popcount and added by one lane each; whatever is left takes the per-lane atomic.
+__device__ __forceinline__ void wave_hist_add(unsigned *hist, int label, bool ok) {
+    const int lane = threadIdx.x & (NRT_WAVE - 1);
+    unsigned long long todo = __ballot(ok);
+    for (int it = 0; it < 4 && todo; ++it) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lab = __shfl(label, leader, NRT_WAVE);
+        const unsigned long long same = __ballot(ok && label == lab);
+        if (lane == leader) atomicAdd(&hist[lab], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&hist[label], 1u);
+}
+
+// PARTIAL: the block's histogram is written as one row of ipart [B][nblk][3 L] (reduced by reduce_rows, no global atomics: 2000
+// blocks adding to the same 96 addresses serialise in L2); otherwise it is added to counts (zero-filled by the caller)
+template <bool PARTIAL>
 __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_label(const int *__restrict__ yt, const int *__restrict__ yp,
-                                                              long long nvox, int L, int use_lds, long long *counts) {
+                                                              long long nvox, int L, int use_lds, long long *counts,
+                                                              unsigned *__restrict__ ipart) {
     extern __shared__ unsigned hist[];      // [3*L] when use_lds
     const int b = blockIdx.y;
     const int *t = yt + (long long)b * nvox;
@@ -266,23 +326,43 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_label(const int *__restr
         for (int i = threadIdx.x; i < 3 * L; i += blockDim.x) hist[i] = 0u;
         __syncthreads();
     }
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
-        const int a = t[v], q = p[v];
-        const bool oka = a >= 0 && a < L, okq = q >= 0 && q < L;   // tf.one_hot: out of range -> zero row
+    auto count = [&](int a, int q, bool live) {
+        const bool oka = live && a >= 0 && a < L, okq = live && q >= 0 && q < L;   // tf.one_hot: out of range -> zero row
         if (use_lds) {
-            if (oka) atomicAdd(&hist[L + a], 1u);
-            if (okq) atomicAdd(&hist[2 * L + q], 1u);
-            if (oka && okq && a == q) atomicAdd(&hist[a], 1u);
+            wave_hist_add(hist + L, a, oka);
+            wave_hist_add(hist + 2 * L, q, okq);
+            wave_hist_add(hist, a, oka && okq && a == q);
         } else {
             if (oka) atomicAdd(&c[L + a], 1ull);
             if (okq) atomicAdd(&c[2 * L + q], 1ull);
             if (oka && okq && a == q) atomicAdd(&c[a], 1ull);
         }
+    };
+    // 16-byte loads over the aligned body (every lane of a wave runs every round: the ballots need the whole wave)
+    const long long n4 = ((((uintptr_t)t | (uintptr_t)p) & 15) == 0) ? nvox / 4 : 0;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long v0 = (long long)blockIdx.x * blockDim.x; v0 < n4; v0 += step) {
+        const long long v = v0 + threadIdx.x;
+        const bool live = v < n4;
+        nrt_i4 a = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+        if (live) { a = ((const nrt_i4 *)t)[v]; q = ((const nrt_i4 *)p)[v]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) count(a[j], q[j], live);
+    }
+    for (long long v0 = n4 * 4 + (long long)blockIdx.x * blockDim.x; v0 < nvox; v0 += step) {
+        const long long v = v0 + threadIdx.x;
+        const bool live = v < nvox;
+        count(live ? t[v] : 0, live ? p[v] : 0, live);
     }
     if (use_lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < 3 * L; i += blockDim.x)
-            if (hist[i]) atomicAdd(&c[i], (unsigned long long)hist[i]);
+        if (PARTIAL) {
+            const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
+            for (int i = threadIdx.x; i < 3 * L; i += blockDim.x) ipart[pbase * 3 * L + i] = hist[i];
+        } else {
+            for (int i = threadIdx.x; i < 3 * L; i += blockDim.x)
+                if (hist[i]) atomicAdd(&c[i], (unsigned long long)hist[i]);
+        }
     }
 }
 
@@ -338,8 +418,9 @@ void launch_soft_vec(const float *t, const float *p, long long nvox, int batch, 
 
 template <int G>
 void launch_hard_vec(const float *t, const float *p, long long nvox, int batch, unsigned nblk, const DiceWs &w,
-                     hipStream_t st) {
-    hipLaunchKernelGGL((dice_hard_vec<G>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart);
+                     bool minmax, hipStream_t st) {
+    if (minmax) hipLaunchKernelGGL((dice_hard_vec<G, true>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart);
+    else hipLaunchKernelGGL((dice_hard_vec<G, false>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart);
 }
 
 }  // namespace
@@ -389,6 +470,13 @@ extern "C" int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long 
 extern "C" int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
                                       float laplace_smoothing, long long *counts, float *dice, void *workspace,
                                       size_t workspace_bytes, void *stream) {
+    return nrt_dice_hard_prob_minmax_f32(y_true, y_pred, nvox, nlabels, batch, laplace_smoothing, counts, dice, nullptr, workspace,
+                                         workspace_bytes, stream);
+}
+
+extern "C" int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                                             float laplace_smoothing, long long *counts, float *dice, float *minmax,
+                                             void *workspace, size_t workspace_bytes, void *stream) {
     if (!y_true || !y_pred || !counts || !dice) return NRT_ERR_INVALID_ARG;
     if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < dice_ws_bytes(nlabels, batch)) return NRT_ERR_WORKSPACE;
@@ -399,13 +487,13 @@ extern "C" int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, 
         const int G = nlabels / 4;
         const unsigned nblk = dice_num_blocks(nvox, (DICE_BLOCK / G) * 4);
         switch (G) {
-            case 1: launch_hard_vec<1>(y_true, y_pred, nvox, batch, nblk, w, st); break;
-            case 2: launch_hard_vec<2>(y_true, y_pred, nvox, batch, nblk, w, st); break;
-            case 4: launch_hard_vec<4>(y_true, y_pred, nvox, batch, nblk, w, st); break;
-            case 8: launch_hard_vec<8>(y_true, y_pred, nvox, batch, nblk, w, st); break;
-            case 16: launch_hard_vec<16>(y_true, y_pred, nvox, batch, nblk, w, st); break;
-            case 32: launch_hard_vec<32>(y_true, y_pred, nvox, batch, nblk, w, st); break;
-            default: launch_hard_vec<64>(y_true, y_pred, nvox, batch, nblk, w, st); break;
+            case 1: launch_hard_vec<1>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 2: launch_hard_vec<2>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 4: launch_hard_vec<4>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 8: launch_hard_vec<8>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 16: launch_hard_vec<16>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 32: launch_hard_vec<32>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            default: launch_hard_vec<64>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
         }
         NRT_CHECK_LAUNCH();
         const int ngrp = ((int)nblk + RED_ROWS - 1) / RED_ROWS;
@@ -415,7 +503,12 @@ extern "C" int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, 
         NRT_CHECK_LAUNCH();
         hipLaunchKernelGGL(dice_counts_reduce, dim3(batch), dim3(256), 0, st, (const long long *)w.gsum, ngrp,
                            nlabels, counts);
+        if (minmax) {
+            NRT_CHECK_LAUNCH();
+            hipLaunchKernelGGL(minmax_rows, dim3(1), dim3(256), 0, st, (const float *)w.mpart, (int)(nblk * (unsigned)batch), minmax);
+        }
     } else {
+        if (minmax) return NRT_ERR_UNSUPPORTED;       // the generic kernel has no extrema: the caller runs the soft pass for them
         if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
             return NRT_ERR_LAUNCH;
         const unsigned nblk = dice_num_blocks(nvox, DICE_BLOCK);
@@ -432,17 +525,34 @@ extern "C" int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, 
 extern "C" int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_pred, long long nvox, int nlabels,
                                        int batch, float laplace_smoothing, long long *counts, float *dice,
                                        void *workspace, size_t workspace_bytes, void *stream) {
-    (void)workspace; (void)workspace_bytes;
     if (!y_true || !y_pred || !counts || !dice) return NRT_ERR_INVALID_ARG;
     if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
     hipStream_t st = nrt_stream(stream);
-    if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
-        return NRT_ERR_LAUNCH;
     const int use_lds = (size_t)3 * nlabels * sizeof(unsigned) <= 64 * 1024;
     const size_t shm = use_lds ? (size_t)3 * nlabels * sizeof(unsigned) : 0;
-    const unsigned nblk = dice_num_blocks(nvox, DICE_BLOCK * 8);
-    hipLaunchKernelGGL(dice_hard_label, dim3(nblk, batch), dim3(DICE_BLOCK), shm, st, (const int *)y_true,
-                       (const int *)y_pred, nvox, nlabels, use_lds, counts);
+    unsigned nblk = dice_num_blocks(nvox, DICE_BLOCK * 8);
+    // with a workspace (nrt_dice_workspace_bytes) the block histograms are reduced as rows; without one they are added with
+    // global atomics (the round-1 form)
+    const bool partial = use_lds && workspace && workspace_bytes >= dice_ws_bytes(nlabels, batch);
+    if (partial) {
+        if (nblk > 512u) nblk = 512u;
+        DiceWs w = dice_ws_carve(workspace, nlabels, batch);
+        hipLaunchKernelGGL((dice_hard_label<true>), dim3(nblk, batch), dim3(DICE_BLOCK), shm, st, (const int *)y_true,
+                           (const int *)y_pred, nvox, nlabels, use_lds, counts, w.ipart);
+        NRT_CHECK_LAUNCH();
+        const int ngrp = ((int)nblk + RED_ROWS - 1) / RED_ROWS;
+        hipLaunchKernelGGL((reduce_rows<unsigned, long long>), dim3(batch, ngrp), dim3(256), 0, st,
+                           (const unsigned *)w.ipart, (int)nblk, 3 * nlabels, (long long *)w.gsum,
+                           (const float *)nullptr, (float *)nullptr, 0);
+        NRT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(dice_counts_reduce, dim3(batch), dim3(256), 0, st, (const long long *)w.gsum, ngrp,
+                           nlabels, counts);
+    } else {
+        if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
+            return NRT_ERR_LAUNCH;
+        hipLaunchKernelGGL((dice_hard_label<false>), dim3(nblk, batch), dim3(DICE_BLOCK), shm, st, (const int *)y_true,
+                           (const int *)y_pred, nvox, nlabels, use_lds, counts, (unsigned *)nullptr);
+    }
     NRT_CHECK_LAUNCH();
     hipLaunchKernelGGL(dice_from_counts, dim3(batch), dim3(256), 0, st, (const long long *)counts, nlabels,
                        laplace_smoothing, dice);

@@ -239,24 +239,31 @@ class Dice:
                 self.nb_labels = p.shape[-1]
             if self.nb_labels != p.shape[-1]:
                 raise NotImplementedError('hard Dice on prob maps with nb_labels != last dimension')
-            if self.normalize or self.check_input_limits:
-                # the arg-max is invariant to the (positive) per-voxel normalisation; the range
-                # asserts of :439-444 still apply to the probabilistic inputs
+            B, L = t.shape[0], t.shape[-1]
+            V = t.numel() // max(B * L, 1)
+            # the range asserts of :439-444 apply to the probabilistic inputs: their extrema come out of the counting pass
+            # itself when its vector kernel runs (4 * 2^k labels), else (and for normalize=True, whose asserts look at the
+            # normalised maps; the arg-max is invariant to the positive per-voxel normalisation) out of a soft pass
+            fused_limits = (self.check_input_limits and not self.normalize and L % 4 == 0 and (L // 4) & (L // 4 - 1) == 0
+                            and 4 <= L <= 256 and t.data_ptr() % 16 == 0 and p.data_ptr() % 16 == 0)
+            if (self.normalize or self.check_input_limits) and not fused_limits:
                 _, _, mm = dice_partial_sums(t, p, self.normalize, 0.)
                 if self.check_input_limits:
                     _check_limits(mm)
                 elif float(mm[0]) < 0 or float(mm[2]) < 0:
                     raise NotImplementedError('normalize=True with negative inputs on the hard path')
-            B, L = t.shape[0], t.shape[-1]
-            V = t.numel() // max(B * L, 1)
             counts = torch.empty((B, 3, L), dtype=torch.int64, device=dev)
             d = torch.empty((B, L), dtype=torch.float32, device=dev)
             nws = lib.nrt_dice_workspace_bytes(V, L, B)
             ws = _lib.workspace(dev, nws)
+            mm = torch.empty((4,), dtype=torch.float32, device=dev) if fused_limits else None
             with torch.cuda.device(dev):
-                rc = lib.nrt_dice_hard_prob_f32(_lib.ptr(t), _lib.ptr(p), V, L, B, eps, _lib.ptr(counts),
-                                                _lib.ptr(d), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
-            _lib.check(rc, 'nrt_dice_hard_prob_f32')
+                rc = lib.nrt_dice_hard_prob_minmax_f32(_lib.ptr(t), _lib.ptr(p), V, L, B, eps, _lib.ptr(counts), _lib.ptr(d),
+                                                       _lib.ptr(mm) if fused_limits else None, _lib.ptr(ws), nws,
+                                                       _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_dice_hard_prob_minmax_f32')
+            if fused_limits:
+                _check_limits(mm)
             return d
 
         # max_label inputs: label id at every location (tf.one_hot needs integer indices)
@@ -273,9 +280,11 @@ class Dice:
         L = int(self.nb_labels)
         counts = torch.empty((B, 3, L), dtype=torch.int64, device=dev)
         d = torch.empty((B, L), dtype=torch.float32, device=dev)
+        nws = lib.nrt_dice_workspace_bytes(V, L, B)
+        ws = _lib.workspace(dev, nws)
         with torch.cuda.device(dev):
             rc = lib.nrt_dice_hard_label_i32(_lib.ptr(t), _lib.ptr(p), V, L, B, eps, _lib.ptr(counts),
-                                             _lib.ptr(d), None, 0, _lib.stream_ptr(dev))
+                                             _lib.ptr(d), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_dice_hard_label_i32')
         return d
 

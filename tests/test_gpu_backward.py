@@ -411,11 +411,12 @@ def test_backward_x_march_schedule_ragged(dev):
 
 
 @pytest.mark.parametrize('fill', [None, 0.0])
-@pytest.mark.parametrize('dedup', ['0', '1'])
+@pytest.mark.parametrize('dedup', ['0', '1', '2'])
 def test_grad_vol_row_accumulator_kernel(dev, fill, dedup, monkeypatch):
-    """d out / d vol at 32 channels under the x-march schedule: the plain scatter (default) and the experimental LDS row-accumulator
+    """d out / d vol at 32 channels under the x-march schedule: the plain scatter (NRT_BWD_VOL_DEDUP=0), the experimental LDS row-accumulator
     table (interpn_bwd_vol_dedup, env NRT_BWD_VOL_DEDUP=1): duplicate rows merged on chip, rows that find no slot go to memory
-    directly, the table is flushed when it fills -- against the float64 oracle; smooth field (heavy re-use), rough field (every
+    directly, the table is flushed when it fills; and the counting-sort merge (interpn_bwd_vol_sort, NRT_BWD_VOL_DEDUP=2, the default) -- against
+    the float64 oracle; smooth field (heavy re-use), rough field (every
     pair its own row: the direct path and many flushes)"""
     monkeypatch.setenv('NRT_BWD_VOL_DEDUP', dedup)
     rng = np.random.default_rng(37)

@@ -108,6 +108,61 @@ def test_hard_label_dice_many_labels_and_out_of_range(dev):
         assert bits_equal(got, want), L
 
 
+def test_hard_dice_single_pass_paths(dev):
+    """round 2: the hard-from-probabilities kernel returns the extrema of its inputs from the counting pass (the range asserts
+    no longer cost a soft pass), and the label-map kernel counts per distinct label of a wave and reduces block histograms
+    as rows; both equal the oracle bit for bit, piecewise-constant and random maps, ragged sizes, with and without workspace"""
+    import ctypes
+    from neurite_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(21)
+    # ---- probabilities: extrema + counts ----
+    for shape in ((2, 17, 13, 11, 32), (1, 40, 40, 40, 8), (3, 5, 5, 5, 4)):
+        t = rng.random(shape).astype(F)
+        p = rng.random(shape).astype(F)
+        got = N(ne.metrics.HardDice(shape[-1], input_type='prob').dice(G(t, dev), G(p, dev)))
+        assert bits_equal(got, npo.dice(t, p, dice_type='hard', input_type='prob', nb_labels=shape[-1]))
+        tt, pp = G(t, dev), G(p, dev)
+        B, L = shape[0], shape[-1]
+        V = t.size // (B * L)
+        counts = torch.empty((B, 3, L), dtype=torch.int64, device=dev)
+        d = torch.empty((B, L), dtype=torch.float32, device=dev)
+        mm = torch.empty((4,), dtype=torch.float32, device=dev)
+        nws = lib.nrt_dice_workspace_bytes(V, L, B)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+        rc = lib.nrt_dice_hard_prob_minmax_f32(_lib.ptr(tt), _lib.ptr(pp), V, L, B, 0.0, _lib.ptr(counts), _lib.ptr(d), _lib.ptr(mm),
+                                               _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+        assert rc == 0
+        assert N(mm).tolist() == [t.min(), t.max(), p.min(), p.max()]
+        assert bits_equal(N(d), got)
+    bad = rng.random((1, 6, 6, 6, 8)).astype(F)
+    bad[0, 3, 3, 3, 5] = 1.5
+    with pytest.raises(ne.metrics.InvalidArgumentError):
+        ne.metrics.HardDice(8, input_type='prob').dice(G(bad, dev), G(np.abs(bad) / 2, dev))
+    # 20 labels: not a vector-kernel count, the extrema come from the soft pass as before
+    t = rng.random((2, 9, 9, 9, 20)).astype(F)
+    p = rng.random((2, 9, 9, 9, 20)).astype(F)
+    assert bits_equal(N(ne.metrics.HardDice(20, input_type='prob').dice(G(t, dev), G(p, dev))),
+                      npo.dice(t, p, dice_type='hard', input_type='prob', nb_labels=20))
+    # ---- label maps ----
+    blobs = synth.one_hot_volume(5, 48, 8, dev).argmax(-1).to(torch.int32)
+    other = synth.one_hot_volume(6, 48, 8, dev).argmax(-1).to(torch.int32)
+    cases = [(N(blobs)[None], N(other)[None], 8),
+             (rng.integers(0, 40, (2, 33, 17, 5)).astype(np.int32), rng.integers(-1, 41, (2, 33, 17, 5)).astype(np.int32), 40),
+             (rng.integers(0, 3, (1, 1027)).astype(np.int32), rng.integers(0, 3, (1, 1027)).astype(np.int32), 3)]
+    for t, p, L in cases:
+        want = npo.dice(t, p, dice_type='hard', input_type='max_label', nb_labels=L)
+        assert bits_equal(N(ne.metrics.HardDice(L).dice(G(t, dev), G(p, dev))), want), L
+        tt, pp = G(t, dev), G(p, dev)
+        B = t.shape[0]
+        V = t.size // B
+        counts = torch.empty((B, 3, L), dtype=torch.int64, device=dev)
+        d = torch.empty((B, L), dtype=torch.float32, device=dev)
+        rc = lib.nrt_dice_hard_label_i32(_lib.ptr(tt), _lib.ptr(pp), V, L, B, 0.0, _lib.ptr(counts), _lib.ptr(d), None, 0,
+                                         _lib.stream_ptr(dev))                    # no workspace: the global-atomic form
+        assert rc == 0 and bits_equal(N(d), want), L
+
+
 def test_dice_deterministic_and_empty(dev):
     t = torch.rand(2, 40, 40, 40, 32, device=dev)
     p = torch.rand(2, 40, 40, 40, 32, device=dev)

@@ -1,0 +1,41 @@
+"""Secondary entries of the metric rows at the headline shape, 4 x 160^3: ms and fraction of the HBM roof
+of their algorithmic bytes -- a sweep for outliers (the min-max reduction of round 1 hid 2000 same-address atomics)."""
+import json, torch
+import neurite_amd as ne
+from neurite_amd import synth
+dev = torch.device('cuda:0')
+
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+def row(op, ms, nbytes):
+    print(json.dumps({'op': op, 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / 8000, 3)}), flush=True)
+
+S, B, L = 160, 4, 32
+mov, fix, trf = synth.cfg2_batch(B, S, L, dev)
+nvox = B * S ** 3
+lt, lp = mov.argmax(-1).to(torch.int32), fix.argmax(-1).to(torch.int32)
+row('soft Dice [4,160^3,32]', timeit(lambda: ne.metrics.Dice().dice(fix, mov)), nvox * 256)
+row('soft Dice, check_input_limits=False', timeit(lambda: ne.metrics.Dice(check_input_limits=False).dice(fix, mov)), nvox * 256)
+row('soft Dice normalize=True', timeit(lambda: ne.metrics.Dice(normalize=True).dice(fix, mov)), nvox * 256)
+row('hard Dice from probabilities (argmax)', timeit(lambda: ne.metrics.HardDice(L, input_type='prob').dice(fix, mov)), nvox * 256)
+row('hard Dice from int32 label maps', timeit(lambda: ne.metrics.HardDice(L, input_type='max_label').dice(lt, lp)), nvox * 8)
+blobs = synth.one_hot_volume(5, S, 8, dev).argmax(-1).to(torch.int32)[None].repeat(B, 1, 1, 1)
+row('hard Dice from int32 label maps, 8 labels', timeit(lambda: ne.metrics.HardDice(8, input_type='max_label').dice(blobs, blobs)), nvox * 8)
+m20, f20 = mov[..., :20].contiguous(), fix[..., :20].contiguous()
+row('soft Dice, 20 labels (generic kernel)', timeit(lambda: ne.metrics.Dice().dice(f20, m20)), nvox * 160)
+w = torch.rand(L, device=dev) + 0.5
+p = torch.softmax(torch.randn(B, S, S, S, L, device=dev), -1)
+row('weighted CCE [4,160^3,32]', timeit(lambda: ne.metrics.CategoricalCrossentropy(label_weights=w)(fix, p)), nvox * 256)
+row('MeanSquaredErrorProb', timeit(lambda: ne.metrics.MeanSquaredErrorProb()(fix, p)), nvox * 256)
+row('mean_dice (weights [1, L])', timeit(lambda: ne.metrics.Dice(weights=w[None]).mean_dice(fix, mov)), nvox * 256)
+st = ne.layers.SpatialTransformer(interp_method='nearest')
+row('nearest warp [4,160^3,32]', timeit(lambda: st([mov, trf])), nvox * 268)
+lab1 = lt[..., None].to(torch.float32)
+row('nearest warp of a label map + one-hot', timeit(lambda: torch.nn.functional.one_hot(st([lab1, trf])[..., 0].long(), L)), nvox * (4 + 12 + 4))
