@@ -381,6 +381,10 @@ int nrt_minmax_norm_f32(const float *x, float *y, long long outer, long long red
                         size_t workspace_bytes, void *stream);
 /* out2 = {min, max} of x[0..n) on the device (no host synchronisation); workspace >= nrt_minmax_workspace_bytes(1, 1) */
 int nrt_minmax_f32(const float *x, long long n, float *out2, void *workspace, size_t workspace_bytes, void *stream);
+/* centers[0..nb_bins) = tf.linspace(min(x), max(x), nb_bins), the bin centres of utils.soft_quantize / MutualInformation
+ * (neurite/tf/utils/utils.py:1152-1154), on the device; workspace as nrt_minmax_f32 */
+int nrt_bin_centers_f32(const float *x, long long n, int nb_bins, float *centers, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Soft quantisation and mutual information (neurite/tf/utils/utils.py:1099-1172, neurite/tf/metrics.py:41-336)
@@ -406,6 +410,9 @@ int nrt_mi_joint_bwd_f32(const float *x, const float *y, const float *centers_x,
                          const float *grad_joint, const float *grad_sum_x, const float *grad_sum_y, float *grad_x, float *grad_y,
                          void *stream);
 int nrt_colsum_f32(const float *x, int items, long long rows, int cols, float *out, void *stream);
+/* mi[item] from joint [items, nb, nb] and the marginal sums [items, nb] (neurite/tf/metrics.py:262-281); nb_bins <= 64 */
+int nrt_mi_from_joint_f32(const float *joint, const float *sum_x, const float *sum_y, int items, int nb_bins, float eps, float *mi,
+                          void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise stages of the label-to-image synthesis model (neurite/tf/models.py:649-918); random numbers are inputs

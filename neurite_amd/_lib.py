@@ -69,10 +69,12 @@ _SIGNATURES = {
     'nrt_minmax_workspace_bytes': (_sz, [_ll, _i]),
     'nrt_minmax_norm_f32': (_i, [_vp, _vp, _ll, _ll, _i, _vp, _sz, _vp]),
     'nrt_minmax_f32': (_i, [_vp, _ll, _vp, _vp, _sz, _vp]),
+    'nrt_bin_centers_f32': (_i, [_vp, _ll, _i, _vp, _vp, _sz, _vp]),
     'nrt_soft_quantize_f32': (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _ll, _i, _vp]),
     'nrt_mi_joint_f32': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _ll, _i, _i, _vp, _vp, _vp, _vp]),
     'nrt_mi_joint_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _i, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nrt_colsum_f32': (_i, [_vp, _i, _ll, _i, _vp, _vp]),
+    'nrt_mi_from_joint_f32': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     'nrt_synth_relabel_i32': (_i, [_vp, _vp, _i, _vp, _ll, _vp]),
     'nrt_synth_intensity_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp]),
     'nrt_synth_bias_clip_f32': (_i, [_vp, _vp, _vp, _ll, _i, _f, _f, _vp]),

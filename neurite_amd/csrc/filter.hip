@@ -417,6 +417,23 @@ __global__ __launch_bounds__(256) void minmax_decode(const int *part, int nb, fl
     if (threadIdx.x == 0) { out[0] = key2f(mn); out[1] = key2f(mx); }
 }
 
+// tf.linspace(min(x), max(x), nb) from the block pairs of minmax_reduce1 (utils.py:1152-1154): start + delta * i with
+// delta = (stop - start) / (nb - 1), one rounding per op, the ends exact
+__global__ __launch_bounds__(256) void minmax_centers(const int *part, int nbp, int nb, float *out) {
+    __shared__ int sm[8];
+    int kmn = 0x7fffffff, kmx = (int)0x80000000;
+    if ((int)threadIdx.x < nbp) { kmn = part[threadIdx.x * 2]; kmx = part[threadIdx.x * 2 + 1]; }
+    block_minmax(kmn, kmx, sm);
+    const float mn = key2f(kmn), mx = key2f(kmx);
+    const float delta = nb > 1 ? (mx - mn) / (float)(nb - 1) : 0.0f;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        float c = nrt_add(mn, nrt_mul(delta, (float)i));
+        if (i == 0) c = mn;
+        if (i == nb - 1 && nb > 1) c = mx;
+        out[i] = c;
+    }
+}
+
 unsigned fblocks(long long n) {
     long long b = (n + 255) / 256;
     if (b > 256ll * 16) b = 256ll * 16;
@@ -517,6 +534,20 @@ extern "C" int nrt_minmax_f32(const float *x, long long n, float *out2, void *wo
     if (nb > MM_NB) nb = MM_NB;
     hipLaunchKernelGGL(minmax_reduce1, dim3((unsigned)nb, 1), dim3(256), 0, st, x, ws, n);
     hipLaunchKernelGGL(minmax_decode, dim3(1), dim3(256), 0, st, ws, (int)nb, out2);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_bin_centers_f32(const float *x, long long n, int nb_bins, float *centers, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
+    if (!x || !centers || n < 1 || nb_bins < 1) return NRT_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < nrt_minmax_workspace_bytes(1, 1)) return NRT_ERR_WORKSPACE;
+    hipStream_t st = nrt_stream(stream);
+    int *ws = (int *)workspace;
+    long long nb = (n + 256 * 16 - 1) / (256 * 16);
+    if (nb > MM_NB) nb = MM_NB;
+    hipLaunchKernelGGL(minmax_reduce1, dim3((unsigned)nb, 1), dim3(256), 0, st, x, ws, n);
+    hipLaunchKernelGGL(minmax_centers, dim3(1), dim3(256), 0, st, ws, (int)nb, nb_bins, centers);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

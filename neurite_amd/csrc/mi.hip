@@ -78,25 +78,36 @@ __global__ __launch_bounds__(256) void mi_joint(MiArgs a) {
         }
     }
     // marginals: sum the four voxel slots of a bin (lanes l, l^16, l^32, l^48)
+    // The four waves of the block are summed in LDS first and a block sends ONE atomic per histogram entry: every wave of
+    // every block adding to the same nb^2 + 2 nb addresses of an item (round 1: 4 x 1000 same-address atomics per entry and item)
+    // serialised in L2 and cost more than the arithmetic.
+    constexpr int NJ = NBT * NBT * 256, NM = NBT * 16;
+    __shared__ float red[4][NJ + 2 * NM];
 #pragma unroll
     for (int t = 0; t < NBT; ++t) {
         sx[t] += __shfl_xor(sx[t], 16, 64); sx[t] += __shfl_xor(sx[t], 32, 64);
         sy[t] += __shfl_xor(sy[t], 16, 64); sy[t] += __shfl_xor(sy[t], 32, 64);
-        if (l4 == 0 && live[t]) {
-            unsafeAtomicAdd(&a.sx[(long long)item * a.nb + 16 * t + l15], sx[t]);
-            unsafeAtomicAdd(&a.sy[(long long)item * a.nb + 16 * t + l15], sy[t]);
-        }
+        if (l4 == 0) { red[wv][NJ + 16 * t + l15] = sx[t]; red[wv][NJ + NM + 16 * t + l15] = sy[t]; }
     }
-    // joint: D row = 4 (l >> 4) + r (x bin), col = l & 15 (y bin)
+    // joint: D row = 4 (l >> 4) + r (x bin), col = l & 15 (y bin); tile (i, j) holds entry [row][col] at (i NBT + j) 256 + row 16 + col
 #pragma unroll
     for (int i = 0; i < NBT; ++i)
 #pragma unroll
         for (int j = 0; j < NBT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int bi = 16 * i + 4 * l4 + r, bj = 16 * j + l15;
-                if (bi < a.nb && bj < a.nb) unsafeAtomicAdd(&a.joint[((long long)item * a.nb + bi) * a.nb + bj], acc[i][j][r]);
-            }
+            for (int r = 0; r < 4; ++r) red[wv][(i * NBT + j) * 256 + (4 * l4 + r) * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < NJ + 2 * NM; e += 256) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e < NJ) {
+            const int tile = e >> 8, row = (e >> 4) & 15, col = e & 15;
+            const int bi = 16 * (tile / NBT) + row, bj = 16 * (tile % NBT) + col;
+            if (bi < a.nb && bj < a.nb) unsafeAtomicAdd(&a.joint[((long long)item * a.nb + bi) * a.nb + bj], v);
+        } else {
+            const int m = e - NJ, which = m / NM, bin = m % NM;
+            if (bin < a.nb) unsafeAtomicAdd(&(which ? a.sy : a.sx)[(long long)item * a.nb + bin], v);
+        }
+    }
 }
 
 // backward: one thread per voxel of an item; G [items, nb, nb], gsx / gsy [items, nb]
@@ -188,6 +199,42 @@ __global__ __launch_bounds__(256) void colsum(const float *__restrict__ x, long 
     for (int i = threadIdx.x; i < C; i += 256) unsafeAtomicAdd(&out[(long long)item * C + i], sm[i]);
 }
 
+// metrics.py:262-281 on one item's joint histogram and marginal sums: pxy = J / (sum J + eps), px = sx / (sum sx + eps),
+// py likewise, mi = sum_ij pxy log(pxy / (px_i py_j + eps) + eps).  One block per item (the inference path; under autograd the
+// same arithmetic runs as torch ops so that d mi / d J comes from autodiff).
+__device__ __forceinline__ float block_sum(float v, float *sm) {          // every lane gets the block's sum
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();                                                       // sm may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void mi_from_joint(const float *__restrict__ J, const float *__restrict__ sx,
+                                                     const float *__restrict__ sy, int nb, float eps, float *__restrict__ out) {
+    __shared__ float sm[4], px[64], py[64];
+    const int item = blockIdx.x;
+    const float *Ji = J + (long long)item * nb * nb;
+    float a = 0.0f;
+    for (int e = threadIdx.x; e < nb * nb; e += 256) a += Ji[e];
+    const float sj = block_sum(a, sm);
+    const float tsx = block_sum((int)threadIdx.x < nb ? sx[(long long)item * nb + threadIdx.x] : 0.0f, sm);
+    const float tsy = block_sum((int)threadIdx.x < nb ? sy[(long long)item * nb + threadIdx.x] : 0.0f, sm);
+    if ((int)threadIdx.x < nb) {
+        px[threadIdx.x] = sx[(long long)item * nb + threadIdx.x] / (tsx + eps);
+        py[threadIdx.x] = sy[(long long)item * nb + threadIdx.x] / (tsy + eps);
+    }
+    __syncthreads();
+    float t = 0.0f;
+    for (int e = threadIdx.x; e < nb * nb; e += 256) {
+        const float pxy = Ji[e] / (sj + eps);
+        const float pp = px[e / nb] * py[e % nb] + eps;
+        t += pxy * logf(pxy / pp + eps);
+    }
+    const float mi = block_sum(t, sm);
+    if (threadIdx.x == 0) out[item] = mi;
+}
+
 unsigned mblocks(long long n, int per) {
     long long b = (n + per - 1) / per;
     if (b > 256ll * 8) b = 256ll * 8;
@@ -207,7 +254,9 @@ extern "C" int nrt_mi_joint_f32(const float *x, const float *y, const float *cen
     MiArgs a;
     a.x = x; a.y = y; a.cx = centers_x; a.cy = centers_y; a.alpha = alpha; a.lo = min_clip; a.hi = max_clip;
     a.V = nvox; a.C = channels; a.nb = nb_bins; a.items = batch * channels; a.joint = joint; a.sx = sum_x; a.sy = sum_y;
-    dim3 grid(mblocks(nvox, 256 * 16), (unsigned)a.items);
+    unsigned chunks = mblocks(nvox, 256 * 16);
+    if (chunks > 256u) chunks = 256u;                       // <= 256 atomics per histogram entry and item
+    dim3 grid(chunks, (unsigned)a.items);
     if (nb_bins <= 16) hipLaunchKernelGGL((mi_joint<1>), grid, dim3(256), 0, nrt_stream(stream), a);
     else hipLaunchKernelGGL((mi_joint<2>), grid, dim3(256), 0, nrt_stream(stream), a);
     NRT_CHECK_LAUNCH();
@@ -257,6 +306,15 @@ extern "C" int nrt_colsum_f32(const float *x, int items, long long rows, int col
     if (rows == 0) return NRT_OK;
     hipLaunchKernelGGL(colsum, dim3(mblocks(rows * cols, 256 * 32), (unsigned)items), dim3(256), (size_t)cols * sizeof(float),
                        nrt_stream(stream), x, rows, cols, out);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_mi_from_joint_f32(const float *joint, const float *sum_x, const float *sum_y, int items, int nb_bins, float eps,
+                                     float *mi, void *stream) {
+    if (!joint || !sum_x || !sum_y || !mi || items < 1 || nb_bins < 1) return NRT_ERR_INVALID_ARG;
+    if (nb_bins > 64) return NRT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(mi_from_joint, dim3((unsigned)items), dim3(256), 0, nrt_stream(stream), joint, sum_x, sum_y, nb_bins, eps, mi);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

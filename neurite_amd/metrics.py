@@ -499,8 +499,18 @@ class MeanSquaredErrorProb:
 # --------------------------------------------------------------------------------------
 
 def _mi_from_joint(joint, sx, sy, eps=1e-7):
-    """metrics.py:262-281 on the [items, B, B] joint histogram and the [items, B] marginal sums (tiny tensors: glue;
-    differentiable, so autograd supplies d mi / d joint for the backward kernel)."""
+    """metrics.py:262-281 on the [items, B, B] joint histogram and the [items, B] marginal sums.  Under autograd: torch ops on
+    the tiny tensors, so that autodiff supplies d mi / d joint for the backward kernel; otherwise one kernel (csrc/mi.hip)."""
+    needs_graph = torch.is_grad_enabled() and (joint.requires_grad or sx.requires_grad or sy.requires_grad)
+    if not needs_graph and joint.is_cuda and joint.shape[-1] <= 64:
+        lib = _lib.lib()
+        joint, sx, sy = joint.contiguous(), sx.contiguous(), sy.contiguous()
+        mi = torch.empty((joint.shape[0],), dtype=torch.float32, device=joint.device)
+        with torch.cuda.device(joint.device):
+            rc = lib.nrt_mi_from_joint_f32(_lib.ptr(joint), _lib.ptr(sx), _lib.ptr(sy), int(joint.shape[0]), int(joint.shape[-1]),
+                                           float(eps), _lib.ptr(mi), _lib.stream_ptr(joint.device))
+        _lib.check(rc, 'nrt_mi_from_joint_f32')
+        return mi
     pxy = joint / (joint.sum((1, 2), keepdim=True) + eps)
     px = sx / (sx.sum(1, keepdim=True) + eps)
     py = sy / (sy.sum(1, keepdim=True) + eps)
@@ -517,9 +527,10 @@ class _MiJointFn(torch.autograd.Function):
         dev = x.device
         B, V, C = x.shape
         nb = cx.numel()
-        joint = torch.zeros((B * C, nb, nb), dtype=torch.float32, device=dev)
-        sx = torch.zeros((B * C, nb), dtype=torch.float32, device=dev)
-        sy = torch.zeros((B * C, nb), dtype=torch.float32, device=dev)
+        acc = torch.zeros((B * C * (nb * nb + 2 * nb),), dtype=torch.float32, device=dev)        # one zero fill for the three
+        joint = acc[:B * C * nb * nb].view(B * C, nb, nb)
+        sx = acc[B * C * nb * nb:B * C * (nb * nb + nb)].view(B * C, nb)
+        sy = acc[B * C * (nb * nb + nb):].view(B * C, nb)
         with torch.cuda.device(dev):
             rc = lib.nrt_mi_joint_f32(_lib.ptr(x), _lib.ptr(y), _lib.ptr(cx), _lib.ptr(cy), float(alpha), float(lo), float(hi),
                                       B, V, C, nb, _lib.ptr(joint), _lib.ptr(sx), _lib.ptr(sy), _lib.stream_ptr(dev))

@@ -680,14 +680,16 @@ def _bin_centers(x, bin_centers, nb_bins):
         return torch.as_tensor(bin_centers, dtype=torch.float32).reshape(-1).to(dev).contiguous()
     if nb_bins is None:
         nb_bins = 16
-    mm = _device_minmax(x)
-    if nb_bins == 1:
-        return mm[:1].clone()
-    delta = (mm[1] - mm[0]) / float(nb_bins - 1)
-    c = mm[0] + delta * torch.arange(nb_bins, dtype=torch.float32, device=dev)      # nb_bins numbers: glue
-    c[0] = mm[0]
-    c[-1] = mm[1]                                                                  # tf.linspace ends exactly on `stop`
-    return c.contiguous()
+    # one reduction + one tiny kernel (csrc/filter.hip): start + delta * i, the ends exact as tf.linspace's are
+    lib = _lib.lib()
+    x = x.contiguous()
+    c = torch.empty((int(nb_bins),), dtype=torch.float32, device=dev)
+    nws = int(lib.nrt_minmax_workspace_bytes(1, 1))
+    ws = torch.empty((nws,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_bin_centers_f32(_lib.ptr(x), x.numel(), int(nb_bins), _lib.ptr(c), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_bin_centers_f32')
+    return c
 
 
 def soft_quantize(x, bin_centers=None, nb_bins=16, alpha=1, min_clip=-np.inf, max_clip=np.inf, return_log=False):
