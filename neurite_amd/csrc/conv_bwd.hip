@@ -677,7 +677,7 @@ extern "C" int nrt_channel_sums_f32(const float *a, const float *b, long long ro
     if (!a || !out || rows < 0 || channels < 1 || channels > 4096) return NRT_ERR_INVALID_ARG;
     if (rows == 0) return NRT_OK;
     long long bx = (rows * channels + 256 * 32 - 1) / (256 * 32);
-    if (bx > 2048) bx = 2048;
+    if (bx > 512) bx = 512;                 // every block ends with one atomic per channel: same-address atomics serialise in L2
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(channel_sums, dim3((unsigned)bx), dim3(256), (size_t)channels * sizeof(float), nrt_stream(stream), a, b, rows,
                        channels, out);

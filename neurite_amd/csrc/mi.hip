@@ -304,7 +304,9 @@ extern "C" int nrt_soft_quantize_bwd_f32(const float *x, const float *centers, f
 extern "C" int nrt_colsum_f32(const float *x, int items, long long rows, int cols, float *out, void *stream) {
     if (!x || !out || items < 1 || items > 65535 || rows < 0 || cols < 1 || cols > 4096) return NRT_ERR_INVALID_ARG;
     if (rows == 0) return NRT_OK;
-    hipLaunchKernelGGL(colsum, dim3(mblocks(rows * cols, 256 * 32), (unsigned)items), dim3(256), (size_t)cols * sizeof(float),
+    unsigned chunks = mblocks(rows * cols, 256 * 32);
+    if (chunks > 256u) chunks = 256u;                       // one atomic per column and block: keep the same-address chain short
+    hipLaunchKernelGGL(colsum, dim3(chunks, (unsigned)items), dim3(256), (size_t)cols * sizeof(float),
                        nrt_stream(stream), x, rows, cols, out);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
