@@ -111,6 +111,12 @@ int nrt_interpn_add_f32(const float *vol, const float *loc, const float *addend,
                         long long vol_batch_stride, long long loc_batch_stride, long long addend_batch_stride,
                         int loc_mode, int has_fill, float fill_value, void *stream);
 
+/* voxelmorph.utils.affine_to_dense_shift ('ij' indexing; called on affine inputs of SpatialTransformer / AffineToDenseShift and by
+ * the synthesis models, neurite/tf/models.py:1131-1154): out[b, q, :] = A_b [q - c; 1] - (q - c), c = (shape - 1) / 2 when
+ * shift_center else 0.  matrix [batch, ndim, ndim + 1], out [batch, *shape, ndim]; ndim 2 or 3. */
+int nrt_affine_to_dense_shift_f32(const float *matrix, int batch, int ndim, const int *shape, int shift_center, float *out,
+                                  void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dice
  * replaces: neurite/tf/metrics.py:415-482 (Dice.dice) incl. the optional renormalisation

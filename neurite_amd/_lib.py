@@ -33,6 +33,7 @@ _SIGNATURES = {
     'nrt_interpn_f32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _vp]),
     'nrt_interpn_f32_ex': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _i, _i, _vp]),
     'nrt_interpn_add_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _ll, _i, _i, _f, _vp]),
+    'nrt_affine_to_dense_shift_f32': (_i, [_vp, _i, _i, _ip, _i, _vp, _vp]),
     'nrt_interpn_nearest_i32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, C.c_int32, _vp]),
     'nrt_interpn_any': (_i, [_vp, _vp, _vp, _i, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _i, C.c_double, _vp]),
     'nrt_dice_workspace_bytes': (_sz, [_ll, _i, _i]),

@@ -76,13 +76,18 @@ __global__ __launch_bounds__(256) void labels_out(const float *__restrict__ idx,
     if (onehot && (depth & 3) == 0 && n * depth < (1ll << 32) && (((uintptr_t)onehot) & 15) == 0) {
         // one 16-byte store per thread and iteration, 32-bit index arithmetic (the scalar form below spends its time in a
         // 64-bit division per element)
+        // (round 2: non-temporal stores and a shift instead of the division when depth / 4 is a power of two -- a pure write
+        // stream; 4 x 160^3 x 32: 0.545 ms = 3.9 TB/s before)
         const unsigned q = (unsigned)depth >> 2, total = (unsigned)((n * depth) >> 2);
+        const bool pow2 = (q & (q - 1u)) == 0u;
+        const unsigned sh = (unsigned)__builtin_ctz(q);
         nrt_f4 *o4 = (nrt_f4 *)onehot;
         for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
-            const unsigned v = e / q;
+            const unsigned v = pow2 ? e >> sh : e / q;
             const int d0 = (int)(e - v * q) * 4;
             const int l = lut[min(max((int)idx[v], 0), lut_len - 1)];
-            o4[e] = (nrt_f4){l == d0 ? 1.0f : 0.0f, l == d0 + 1 ? 1.0f : 0.0f, l == d0 + 2 ? 1.0f : 0.0f, l == d0 + 3 ? 1.0f : 0.0f};
+            __builtin_nontemporal_store((nrt_f4){l == d0 ? 1.0f : 0.0f, l == d0 + 1 ? 1.0f : 0.0f, l == d0 + 2 ? 1.0f : 0.0f,
+                                                 l == d0 + 3 ? 1.0f : 0.0f}, o4 + e);
         }
     } else if (onehot) {
         for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n * depth; e += (long long)gridDim.x * 256) {

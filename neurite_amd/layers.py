@@ -186,9 +186,8 @@ class SpatialTransformer(_Layer):
         if trf.dim() == 3 and trf.shape[-1] == D + 1 and trf.shape[-2] in (D, D + 1):
             out_spatial = list(self.shape) if self.shape is not None else list(vol.shape[1:-1])
             nb = 1 if self.single_transform else trf.shape[0]
-            trf = torch.stack([utils.affine_to_dense_shift(trf[b], out_spatial, shift_center=self.shift_center,
-                                                           indexing=self.indexing).to(vol.device)
-                               for b in range(nb)], 0)
+            trf = utils.affine_to_dense_shift(trf[:nb].to(vol.device), out_spatial, shift_center=self.shift_center,
+                                              indexing=self.indexing)                      # batched: one launch on the device
         else:
             if trf.dim() != D + 2 or trf.shape[-1] != D:
                 raise Exception("Number of loc Tensors %d does not match volume dimension %d"
@@ -361,8 +360,7 @@ class AffineToDenseShift(_Layer):
 
     def call(self, mat):
         _lib.require_device(mat)
-        return torch.stack([utils.affine_to_dense_shift(mat[b], self.shape, shift_center=self.shift_center)
-                            for b in range(mat.shape[0])], 0)
+        return utils.affine_to_dense_shift(mat, self.shape, shift_center=self.shift_center)      # batched: one launch
 
 
 class GaussianBlur(_Layer):

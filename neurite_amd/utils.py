@@ -339,7 +339,8 @@ def transform(vol, loc_shift, interp_method='linear', indexing='ij', fill_value=
 def affine_to_dense_shift(matrix, shape, shift_center=True, indexing='ij'):
     """
     voxelmorph.utils.affine_to_dense_shift: dense displacement field [*shape, D] of an affine
-    [D, D+1] (or [D+1, D+1]).  Host-side glue (tiny matmul over the grid), float32.
+    [D, D+1] (or [D+1, D+1]); a batch of affines [B, D, D+1] gives [B, *shape, D].  float32.  Device matrices: one kernel
+    (csrc/vxm.hip); host matrices, 'xy' indexing and matrices that need a gradient: torch ops (tiny matmul over the grid).
     """
     D = len(shape)
     matrix = torch.as_tensor(matrix, dtype=torch.float32)
@@ -347,6 +348,23 @@ def affine_to_dense_shift(matrix, shape, shift_center=True, indexing='ij'):
         matrix = matrix[..., :D, :]
     if tuple(matrix.shape[-2:]) != (D, D + 1):
         raise ValueError('affine matrix must be [%d, %d] or [%d, %d]' % (D, D + 1, D + 1, D + 1))
+    if (indexing == 'ij' and matrix.device.type == 'cuda' and D in (2, 3) and matrix.dim() in (2, 3)
+            and not (torch.is_grad_enabled() and matrix.requires_grad)):
+        # one kernel writes the D floats of a voxel (csrc/vxm.hip); a leading batch axis gives [B, *shape, D].  Under autograd
+        # (an affine that a network predicted) the differentiable torch form below runs instead.
+        lib = _lib.lib()
+        m = matrix.detach().contiguous()
+        batch = m.shape[0] if m.dim() == 3 else 1
+        out = torch.empty(((batch,) if m.dim() == 3 else ()) + tuple(int(n) for n in shape) + (D,), dtype=torch.float32, device=m.device)
+        if out.numel():
+            with torch.cuda.device(m.device):
+                rc = lib.nrt_affine_to_dense_shift_f32(_lib.ptr(m), int(batch), D, _lib.ints([int(n) for n in shape]),
+                                                       int(bool(shift_center)), _lib.ptr(out), _lib.stream_ptr(m.device))
+            _lib.check(rc, 'nrt_affine_to_dense_shift_f32')
+        return out
+    if matrix.dim() == 3:
+        return torch.stack([affine_to_dense_shift(matrix[b], shape, shift_center=shift_center, indexing=indexing)
+                            for b in range(matrix.shape[0])], 0)
     if indexing == 'ij' and matrix.device.type == 'cuda':
         # the grid is built where the matrix lives (the host grid + copy cost ~15 ms per 160^3 field)
         lin = [torch.arange(int(n), dtype=torch.float32, device=matrix.device) for n in shape]

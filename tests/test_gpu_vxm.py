@@ -150,3 +150,33 @@ def test_affine_to_dense_shift_layer(dev):
         np.testing.assert_allclose(out[b], npo.affine_to_dense_shift(aff[b], shape), rtol=1e-5, atol=1e-5)
     with pytest.raises(ValueError):
         ne.layers.AffineToDenseShift(shape)(G(np.zeros((B, 3, 3), F), dev))
+
+
+def test_affine_to_dense_shift_kernel(dev):
+    """csrc/vxm.hip (one kernel, batched) == the torch form (used under autograd and on the host) == the oracle: 2-D and 3-D,
+    with and without the centre shift, square [D + 1, D + 1] matrices, the affine input of SpatialTransformer"""
+    rng = np.random.default_rng(23)
+    for shape in ((33, 20, 17), (40, 27), (160, 160, 160)):
+        D = len(shape)
+        aff = (np.eye(D, D + 1, dtype=F)[None] + rng.standard_normal((3, D, D + 1)).astype(F) * F(0.05))
+        aff[..., -1] += rng.standard_normal((3, D)).astype(F) * 4
+        for center in (True, False):
+            got = N(ne.utils.affine_to_dense_shift(G(aff, dev), shape, shift_center=center))
+            assert got.shape == (3,) + shape + (D,)
+            g = G(aff, dev).requires_grad_()
+            via_torch = ne.utils.affine_to_dense_shift(g, shape, shift_center=center)
+            assert via_torch.requires_grad                       # the differentiable form
+            scale = max(shape)
+            np.testing.assert_allclose(got, N(via_torch), rtol=1e-5, atol=2e-6 * scale)
+            if np.prod(shape) < 1e5:
+                for b in range(3):
+                    np.testing.assert_allclose(got[b], npo.affine_to_dense_shift(aff[b], shape, shift_center=center), rtol=1e-5, atol=1e-5)
+                    one = N(ne.utils.affine_to_dense_shift(G(aff[b], dev), shape, shift_center=center))
+                    assert np.array_equal(one, got[b])
+        sq = np.concatenate([aff, np.tile(np.eye(D + 1, dtype=F)[-1:], (3, 1, 1))], 1)
+        assert np.array_equal(N(ne.utils.affine_to_dense_shift(G(sq, dev), shape)), N(ne.utils.affine_to_dense_shift(G(aff, dev), shape)))
+    # SpatialTransformer on affines: the dense field is formed on the device, the warp equals the oracle's
+    vol = rng.standard_normal((2, 12, 10, 9, 3)).astype(F)
+    aff = (np.eye(3, 4, dtype=F)[None] + rng.standard_normal((2, 3, 4)).astype(F) * F(0.05))
+    out = N(ne.layers.SpatialTransformer()([G(vol, dev), G(aff, dev)]))
+    np.testing.assert_allclose(out, npo.spatial_transformer(vol, aff), rtol=1e-4, atol=1e-4)
