@@ -520,10 +520,7 @@ def compose(transforms, interp_method='linear', shift_center=True, indexing='ij'
     def densify(t, shape):
         if not affine(t):
             return t
-        if _batched:
-            return torch.stack([affine_to_dense_shift(t[b], shape, shift_center=shift_center, indexing=indexing)
-                                for b in range(t.shape[0])], 0)
-        return affine_to_dense_shift(t, shape, shift_center=shift_center, indexing=indexing)
+        return affine_to_dense_shift(t, shape, shift_center=shift_center, indexing=indexing)     # [B, D, D+1] -> [B, *shape, D]
 
     curr = transforms[-1]
     for nxt in reversed(transforms[:-1]):

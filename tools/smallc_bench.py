@@ -26,11 +26,12 @@ for C in (1, 2, 3, 4, 8, 16):
         print(json.dumps({'op': 'warp', 'C': C, 'method': method, 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1),
                           'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
 # Resize x2 of a half-resolution flow field (RescaleTransform / labels_to_image, models.py:802-804)
-half = torch.randn(B, 80, 80, 80, 3, device=dev)
-rs = ne.layers.Resize(2)
-ms = timeit(lambda: rs(half))
-nbytes = B * (80 ** 3 * 12 + 160 ** 3 * 12)
-print(json.dumps({'op': 'resize x2 C=3', 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
+for C in (3, 1, 2, 4):
+    rs = ne.layers.Resize(2)
+    half = torch.randn(B, 80, 80, 80, C, device=dev)
+    ms = timeit(lambda: rs(half))
+    nbytes = B * (80 ** 3 + 160 ** 3) * 4 * C
+    print(json.dumps({'op': 'resize x2 C=%d' % C, 'ms': round(ms, 4), 'GBs': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / 8000, 3)}))
 vi = ne.layers.VecInt(int_steps=7)
 ms = timeit(lambda: vi(flow), n=5)
 nbytes = 7 * B * S ** 3 * 36
