@@ -134,6 +134,29 @@ def test_mi_backward(dev):
     assert err < 2e-3, err
 
 
+def test_mi_backward_mfma_equals_scalar_kernel(dev, monkeypatch):
+    """the matrix-core backward (mi_joint_bwd_mfma: G wy and G^T wx as 16x16x4 MFMAs, 32 exponentials per voxel) against the
+    one-thread-per-voxel kernel (NRT_MI_BWD_SCALAR=1): ragged voxel counts, 5 / 16 / 32 bins, clipping, one or both gradients"""
+    rng = np.random.default_rng(29)
+    for shape, kw, both in (((2, 13, 11, 7, 1), dict(nb_bins=16), True), ((1, 37, 5, 3, 3), dict(nb_bins=5), True),
+                            ((3, 20, 20, 20, 1), dict(nb_bins=32, min_clip=0.1, max_clip=0.9), False),
+                            ((1, 1, 1, 1, 1), dict(nb_bins=16), True)):
+        x = rng.random(shape).astype(F)
+        y = (0.6 * x + 0.4 * rng.random(shape)).astype(F)
+        grads = {}
+        for mode in ('0', '1'):
+            monkeypatch.setenv('NRT_MI_BWD_SCALAR', mode)
+            with contextlib.redirect_stdout(io.StringIO()):
+                mi = MI(**kw)
+            xg, yg = G(x, dev, True), G(y, dev, both)
+            (-mi.channelwise(xg, yg).sum()).backward()
+            grads[mode] = (N(xg.grad), N(yg.grad) if both else None)
+        monkeypatch.delenv('NRT_MI_BWD_SCALAR')
+        for a, b in zip(grads['0'], grads['1']):
+            if a is not None:
+                assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), (shape, kw)
+
+
 def test_soft_quantize_backward(dev):
     """d soft_quantize / d x (bin centres constant; clip passes the gradient on the closed range) vs float64 autograd, plain and
     return_log forms"""
