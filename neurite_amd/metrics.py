@@ -280,11 +280,13 @@ class Dice:
         L = int(self.nb_labels)
         counts = torch.empty((B, 3, L), dtype=torch.int64, device=dev)
         d = torch.empty((B, L), dtype=torch.float32, device=dev)
-        nws = lib.nrt_dice_workspace_bytes(V, L, B)
-        ws = _lib.workspace(dev, nws)
+        # block histograms reduced as rows (no global atomics) while the row buffer stays small; label sets in the thousands keep
+        # the atomic form, whose workspace is nothing (the row buffer grows with 2048 * 3 * L per batch entry)
+        nws = lib.nrt_dice_workspace_bytes(V, L, B) if L <= 256 else 0
+        ws = _lib.workspace(dev, nws) if nws else None
         with torch.cuda.device(dev):
             rc = lib.nrt_dice_hard_label_i32(_lib.ptr(t), _lib.ptr(p), V, L, B, eps, _lib.ptr(counts),
-                                             _lib.ptr(d), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+                                             _lib.ptr(d), _lib.ptr(ws) if nws else None, nws, _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_dice_hard_label_i32')
         return d
 
