@@ -273,9 +273,67 @@ __global__ __launch_bounds__(256) void minmax_rows(const float *__restrict__ mpa
     }
 }
 
-// hard Dice, any L, from probabilities: one thread per voxel
+// hard Dice from int32 label maps: per-block LDS histogram (integer atomics: order-independent)
+// One LDS atomic per DISTINCT label of a wave: label maps are piecewise constant, so the 64 lanes of a wave hold one to three
+// labels and per-lane atomics would all queue on the same LDS address.  The first four distinct labels are counted by ballot +
+// popcount and added by one lane each; whatever is left takes the per-lane atomic.
+__device__ __forceinline__ void wave_hist_add(unsigned *hist, int label, bool ok) {
+    const int lane = threadIdx.x & (NRT_WAVE - 1);
+    unsigned long long todo = __ballot(ok);
+    for (int it = 0; it < 4 && todo; ++it) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int lab = __shfl(label, leader, NRT_WAVE);
+        const unsigned long long same = __ballot(ok && label == lab);
+        if (lane == leader) atomicAdd(&hist[lab], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+    if ((todo >> lane) & 1ull) atomicAdd(&hist[label], 1u);
+}
+
+// hard Dice, any L, from probabilities.  A block stages the rows of VP voxels (VP * L floats, both maps in turn) in LDS with
+// coalesced 4-byte loads, then a thread scans its voxel's row for the arg-max (ties -> lowest label); the counts go to a per-block
+// LDS histogram (one atomic per distinct label of a wave) and to `counts` once per block.  (The first version read the rows
+// straight from memory, a lane per voxel -- 80-byte strides at 20 labels -- and sent three global atomics per VOXEL.)
 __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_generic(const float *__restrict__ yt, const float *__restrict__ yp,
-                                                                     long long nvox, int L, long long *counts) {
+                                                                     long long nvox, int L, int VP, long long *counts) {
+    extern __shared__ unsigned dh_lds[];    // hist [3 * L], rows [VP * L]
+    unsigned *hist = dh_lds;
+    float *rows = (float *)(dh_lds + 3 * L);
+    const int b = blockIdx.y;
+    const float *t = yt + (long long)b * nvox * L;
+    const float *p = yp + (long long)b * nvox * L;
+    unsigned long long *c = (unsigned long long *)counts + (long long)b * 3 * L;
+    for (int i = threadIdx.x; i < 3 * L; i += blockDim.x) hist[i] = 0u;
+    auto argmax_of = [&](const float *src, long long v0, int nv) -> int {
+        const long long n = (long long)nv * L;
+        __syncthreads();                                     // the previous scan is over
+        for (long long i = threadIdx.x; i < n; i += blockDim.x) rows[i] = src[v0 * L + i];
+        __syncthreads();
+        int am = 0;
+        if ((int)threadIdx.x < nv) {
+            const float *r = rows + (long long)threadIdx.x * L;
+            float best = r[0];
+            for (int l = 1; l < L; ++l) { const float x = r[l]; if (x > best) { best = x; am = l; } }
+        }
+        return am;
+    };
+    for (long long v0 = (long long)blockIdx.x * VP; v0 < nvox; v0 += (long long)gridDim.x * VP) {
+        const int nv = (int)((nvox - v0) < VP ? (nvox - v0) : VP);
+        const int at = argmax_of(t, v0, nv);
+        const int ap = argmax_of(p, v0, nv);
+        const bool live = (int)threadIdx.x < nv;
+        wave_hist_add(hist + L, at, live);
+        wave_hist_add(hist + 2 * L, ap, live);
+        wave_hist_add(hist, at, live && at == ap);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * L; i += blockDim.x)
+        if (hist[i]) atomicAdd(&c[i], (unsigned long long)hist[i]);
+}
+
+// the same for label counts whose rows do not fit in LDS: rows read from memory, global atomics
+__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_direct(const float *__restrict__ yt, const float *__restrict__ yp,
+                                                                    long long nvox, int L, long long *counts) {
     const int b = blockIdx.y;
     const float *t = yt + (long long)b * nvox * L;
     const float *p = yp + (long long)b * nvox * L;
@@ -292,23 +350,6 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_generic(const float
         atomicAdd(&c[2 * L + ap], 1ull);
         if (at == ap) atomicAdd(&c[at], 1ull);
     }
-}
-
-// hard Dice from int32 label maps: per-block LDS histogram (integer atomics: order-independent)
-// One LDS atomic per DISTINCT label of a wave: label maps are piecewise constant, so the 64 lanes of a wave hold one to three
-// labels and per-lane atomics would all queue on the same LDS address.  The first four distinct labels are counted by ballot +
-// popcount and added by one lane each; whatever is left takes the per-lane atomic.
-__device__ __forceinline__ void wave_hist_add(unsigned *hist, int label, bool ok) {
-    const int lane = threadIdx.x & (NRT_WAVE - 1);
-    unsigned long long todo = __ballot(ok);
-    for (int it = 0; it < 4 && todo; ++it) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int lab = __shfl(label, leader, NRT_WAVE);
-        const unsigned long long same = __ballot(ok && label == lab);
-        if (lane == leader) atomicAdd(&hist[lab], (unsigned)__popcll(same));
-        todo &= ~same;
-    }
-    if ((todo >> lane) & 1ull) atomicAdd(&hist[label], 1u);
 }
 
 // PARTIAL: the block's histogram is written as one row of ipart [B][nblk][3 L] (reduced by reduce_rows, no global atomics: 2000
@@ -511,9 +552,19 @@ extern "C" int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y
         if (minmax) return NRT_ERR_UNSUPPORTED;       // the generic kernel has no extrema: the caller runs the soft pass for them
         if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
             return NRT_ERR_LAUNCH;
-        const unsigned nblk = dice_num_blocks(nvox, DICE_BLOCK);
-        hipLaunchKernelGGL(dice_hard_prob_generic, dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox,
-                           nlabels, counts);
+        // rows of VP voxels in LDS: VP = 256 while 256 * L floats + the histogram fit in 48 KB, fewer voxels for wide rows
+        int VP = DICE_BLOCK;
+        while (VP > 8 && ((size_t)VP * nlabels + 3 * (size_t)nlabels) * 4 > 48 * 1024) VP >>= 1;
+        if (((size_t)VP * nlabels + 3 * (size_t)nlabels) * 4 <= 48 * 1024) {
+            long long nb = (nvox + VP - 1) / VP;
+            if (nb > 1024) nb = 1024;                             // one atomic per label and block at the end
+            if (nb < 1) nb = 1;
+            hipLaunchKernelGGL(dice_hard_prob_generic, dim3((unsigned)nb, batch), dim3(DICE_BLOCK),
+                               ((size_t)VP * nlabels + 3 * (size_t)nlabels) * 4, st, y_true, y_pred, nvox, nlabels, VP, counts);
+        } else {
+            hipLaunchKernelGGL(dice_hard_prob_direct, dim3(dice_num_blocks(nvox, DICE_BLOCK), batch), dim3(DICE_BLOCK), 0, st, y_true, y_pred,
+                               nvox, nlabels, counts);
+        }
     }
     NRT_CHECK_LAUNCH();
     hipLaunchKernelGGL(dice_from_counts, dim3(batch), dim3(256), 0, st, (const long long *)counts, nlabels,

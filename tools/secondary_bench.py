@@ -29,6 +29,9 @@ row('hard Dice from int32 label maps', timeit(lambda: ne.metrics.HardDice(L, inp
 blobs = synth.one_hot_volume(5, S, 8, dev).argmax(-1).to(torch.int32)[None].repeat(B, 1, 1, 1)
 row('hard Dice from int32 label maps, 8 labels', timeit(lambda: ne.metrics.HardDice(8, input_type='max_label').dice(blobs, blobs)), nvox * 8)
 m20, f20 = mov[..., :20].contiguous(), fix[..., :20].contiguous()
+with __import__('warnings').catch_warnings():
+    __import__('warnings').simplefilter('ignore')
+    row('hard Dice from probabilities, 20 labels (generic kernel)', timeit(lambda: ne.metrics.HardDice(20, input_type='prob').dice(f20, m20), n=3), nvox * 160)
 row('soft Dice, 20 labels (generic kernel)', timeit(lambda: ne.metrics.Dice().dice(f20, m20)), nvox * 160)
 w = torch.rand(L, device=dev) + 0.5
 p = torch.softmax(torch.randn(B, S, S, S, L, device=dev), -1)
