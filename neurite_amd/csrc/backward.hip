@@ -56,29 +56,64 @@ __global__ __launch_bounds__(256) void interpn_bwd_generic(InterpBwdArgs ba) {
         }
         float gacc[NRT_MAXD] = {0.0f, 0.0f, 0.0f};
         if (!oob) {
-            for (int c = 0; c < a.C; ++c) {
-                const float g = go[(long long)q * a.C + c];
+            // per corner: row index, weight, and the weight products with one dimension's factor replaced by its derivative
+            // (formed once per voxel, not once per channel)
+            long long cidx[1 << D];
+            float cwt[1 << D], cwexc[1 << D][D];
 #pragma unroll
-                for (int corner = 0; corner < (1 << D); ++corner) {
-                    long long idx = 0;
-                    float wt = 1.0f;
-                    float wexc[NRT_MAXD];                 // product of the other dims' weights, signed
+            for (int corner = 0; corner < (1 << D); ++corner) {
+                long long idx = 0;
+                float wt = 1.0f;
+                float wexc[D];
 #pragma unroll
-                    for (int d = 0; d < D; ++d) wexc[d] = 1.0f;
+                for (int d = 0; d < D; ++d) wexc[d] = 1.0f;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        const int bit = (corner >> (D - 1 - d)) & 1;
-                        idx = idx * a.S[d] + (bit ? i1[d] : i0[d]);
-                        const float w = bit ? w1[d] : w0[d];
-                        wt *= w;
+                for (int d = 0; d < D; ++d) {
+                    const int bit = (corner >> (D - 1 - d)) & 1;
+                    idx = idx * a.S[d] + (bit ? i1[d] : i0[d]);
+                    const float w = bit ? w1[d] : w0[d];
+                    wt *= w;
 #pragma unroll
-                        for (int e = 0; e < D; ++e) wexc[e] *= (e == d) ? (bit ? m[d] : -m[d]) : w;
+                    for (int e = 0; e < D; ++e) wexc[e] *= (e == d) ? (bit ? m[d] : -m[d]) : w;
+                }
+                cidx[corner] = idx * a.C;
+                cwt[corner] = wt;
+#pragma unroll
+                for (int d = 0; d < D; ++d) cwexc[corner][d] = wexc[d];
+            }
+            // channel counts that are multiples of 4 (12, 20, 24 ... -- the powers of two have their own kernel): 16-byte loads of
+            // the gradient row and of the corner rows, the same sums channel by channel
+            const bool quads = (a.C & 3) == 0 && (a.vol_bs & 3) == 0 && (a.out_bs & 3) == 0 &&
+                               ((((uintptr_t)a.vol | (uintptr_t)ba.gout) & 15) == 0);
+            if (quads) {
+                for (int c = 0; c < a.C; c += 4) {
+                    const nrt_f4 g4 = *(const nrt_f4 *)(go + (long long)q * a.C + c);
+#pragma unroll
+                    for (int corner = 0; corner < (1 << D); ++corner) {
+                        if (gv) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) atomic_add_f32(&gv[cidx[corner] + c + k], cwt[corner] * g4[k]);
+                        }
+                        if (gl) {
+                            const nrt_f4 v4 = *(const nrt_f4 *)(vol + cidx[corner] + c);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                for (int d = 0; d < D; ++d) gacc[d] += g4[k] * cwexc[corner][d] * v4[k];
+                        }
                     }
-                    if (gv) atomic_add_f32(&gv[idx * a.C + c], wt * g);
-                    if (gl) {
-                        const float v = vol[idx * a.C + c];
+                }
+            } else {
+                for (int c = 0; c < a.C; ++c) {
+                    const float g = go[(long long)q * a.C + c];
 #pragma unroll
-                        for (int d = 0; d < D; ++d) gacc[d] += g * wexc[d] * v;
+                    for (int corner = 0; corner < (1 << D); ++corner) {
+                        if (gv) atomic_add_f32(&gv[cidx[corner] + c], cwt[corner] * g);
+                        if (gl) {
+                            const float v = vol[cidx[corner] + c];
+#pragma unroll
+                            for (int d = 0; d < D; ++d) gacc[d] += g * cwexc[corner][d] * v;
+                        }
                     }
                 }
             }
@@ -86,6 +121,46 @@ __global__ __launch_bounds__(256) void interpn_bwd_generic(InterpBwdArgs ba) {
         if (gl) {
 #pragma unroll
             for (int d = 0; d < D; ++d) gl[(long long)q * D + d] = gacc[d];
+        }
+    }
+}
+
+// d out / d vol for any channel count: one thread per output ELEMENT (voxel, channel), channel fastest.  The lanes of a wave then
+// cover whole rows of consecutive voxels, so an atomic instruction reaches 64 / C rows instead of 64 (the L2 atomic units are
+// bound by requests, not by dwords: the per-voxel kernel above took 28 / 132 ms for 4 x 160^3 x 5 / 20).  The corner arithmetic is
+// repeated per channel -- cheap next to the atomics.
+template <int D, int MODE>
+__global__ __launch_bounds__(256) void interpn_bwd_vol_elems(InterpBwdArgs ba) {
+    const InterpArgs &a = ba.f;
+    const int b = blockIdx.y;
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    const float *go = ba.gout + (long long)b * a.out_bs;
+    float *gv = ba.gvol + (long long)b * a.vol_bs;
+    const unsigned long long total = (unsigned long long)a.nout * (unsigned)a.C;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x; e < total; e += (unsigned long long)gridDim.x * 256u) {
+        const unsigned q = (unsigned)(e / (unsigned)a.C);
+        const int c = (int)(e - (unsigned long long)q * (unsigned)a.C);
+        int qd[NRT_MAXD];
+        float p[NRT_MAXD];
+        decode<D>(a, q, qd);
+        load_loc<D, MODE>(a, locb, q, qd, p);
+        if (a.has_fill && out_of_bounds<D>(a, p)) continue;
+        int i0[NRT_MAXD], i1[NRT_MAXD];
+        float w0[NRT_MAXD], w1[NRT_MAXD];
+#pragma unroll
+        for (int d = 0; d < D; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+        const float g = go[e];
+#pragma unroll
+        for (int corner = 0; corner < (1 << D); ++corner) {
+            long long idx = 0;
+            float wt = 1.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int bit = (corner >> (D - 1 - d)) & 1;
+                idx = idx * a.S[d] + (bit ? i1[d] : i0[d]);
+                wt *= bit ? w1[d] : w0[d];
+            }
+            atomic_add_f32(&gv[idx * a.C + c], wt * g);
         }
     }
 }
@@ -260,15 +335,15 @@ __global__ __launch_bounds__(256) void dice_soft_bwd(const float *__restrict__ t
 // ---------------------------------------------------------------------------------------------
 // weighted CCE backward wrt y_pred: one thread per voxel (C in a loop), float32
 // ---------------------------------------------------------------------------------------------
+// VP > 0: the rows of VP voxels of t and p are staged in LDS with coalesced loads, the gradient rows leave the same way (a lane
+// walking its own row in memory touches one line per element: 17 ms for 4 x 160^3 x 20); VP == 0: rows too wide, straight access
 __global__ __launch_bounds__(256) void wcce_bwd(const float *__restrict__ t, const float *__restrict__ p,
                                                 const float *__restrict__ w, const float *__restrict__ gscalar,
                                                 const float *__restrict__ gper_voxel, long long n, int C, int logits,
-                                                float smooth, float scale, float *__restrict__ gp) {
+                                                float smooth, float scale, int VP, float *__restrict__ gp) {
+    extern __shared__ float wb_lds[];       // [2][VP * C]: t rows (then the gradient rows), p rows
     const float keep = 1.0f - smooth, add = smooth / (float)C;
-    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
-        const float g = (gper_voxel ? gper_voxel[v] : gscalar[0]) * scale;
-        const float *tv = t + v * C, *pv = p + v * C;
-        float *gv = gp + v * C;
+    auto voxel = [&](const float *tv, const float *pv, float *gv, float g) {     // gv may alias tv (element c is read before written)
         if (logits) {
             float mx = -INFINITY;
             for (int c = 0; c < C; ++c) mx = fmaxf(mx, pv[c]);
@@ -304,6 +379,28 @@ __global__ __launch_bounds__(256) void wcce_bwd(const float *__restrict__ t, con
                 gv[c] = -g * (r - rq) / s;
             }
         }
+    };
+    if (VP > 0) {
+        float *st = wb_lds, *sp = wb_lds + (long long)VP * C;
+        for (long long v0 = (long long)blockIdx.x * VP; v0 < n; v0 += (long long)gridDim.x * VP) {
+            const int nv = (int)((n - v0) < VP ? (n - v0) : VP);
+            const long long ne = (long long)nv * C;
+            __syncthreads();
+            for (long long i = threadIdx.x; i < ne; i += blockDim.x) { st[i] = t[v0 * C + i]; sp[i] = p[v0 * C + i]; }
+            __syncthreads();
+            if ((int)threadIdx.x < nv) {
+                const long long v = v0 + threadIdx.x;
+                const float g = (gper_voxel ? gper_voxel[v] : gscalar[0]) * scale;
+                voxel(st + (long long)threadIdx.x * C, sp + (long long)threadIdx.x * C, st + (long long)threadIdx.x * C, g);
+            }
+            __syncthreads();
+            for (long long i = threadIdx.x; i < ne; i += blockDim.x) gp[v0 * C + i] = st[i];
+        }
+        return;
+    }
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+        const float g = (gper_voxel ? gper_voxel[v] : gscalar[0]) * scale;
+        voxel(t + v * C, p + v * C, gp + v * C, g);
     }
 }
 
@@ -981,6 +1078,20 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
             default: NRT_BWD_MODE(interpn_bwd_rows, 64) break;
         }
     } else {
+        if (grad_vol && channels > 1) {
+            // d vol per element (coalesced atomic requests), d loc per voxel
+            unsigned long long nb = ((unsigned long long)ba.f.nout * (unsigned)channels + 255) / 256;
+            if (nb > 65536ull * 4) nb = 65536ull * 4;
+            dim3 grid((unsigned)nb, batch);
+            switch (ndim) {
+                case 1: NRT_BWD_MODE(interpn_bwd_vol_elems, 1) break;
+                case 2: NRT_BWD_MODE(interpn_bwd_vol_elems, 2) break;
+                default: NRT_BWD_MODE(interpn_bwd_vol_elems, 3) break;
+            }
+            NRT_CHECK_LAUNCH();
+            if (!grad_loc) return NRT_OK;
+            ba.gvol = nullptr;
+        }
         unsigned blocks = (ba.f.nout + 255) / 256;
         if (blocks > 256u * 16u) blocks = 256u * 16u;
         dim3 grid(blocks, batch);
@@ -1101,10 +1212,15 @@ extern "C" int nrt_wcce_bwd_f32(const float *y_true, const float *y_pred, const 
         NRT_CHECK_LAUNCH();
         return NRT_OK;
     }
-    unsigned blocks = (unsigned)((nvox_total + 255) / 256);
-    if (blocks > 256u * 16u) blocks = 256u * 16u;
-    hipLaunchKernelGGL(wcce_bwd, dim3(blocks), dim3(256), 0, nrt_stream(stream), y_true, y_pred, label_weights, grad_scalar,
-                       grad_per_voxel, nvox_total, channels, from_logits, label_smoothing, scale, grad_pred);
+    int VP = 256;                                                 // rows of VP voxels of both tensors in 48 KB of LDS
+    while (VP > 8 && (size_t)2 * VP * channels * 4 > 48 * 1024) VP >>= 1;
+    if ((size_t)2 * VP * channels * 4 > 48 * 1024) VP = 0;
+    const int per = VP > 0 ? VP : 256;
+    long long nb = (nvox_total + per - 1) / per;
+    if (nb > 256ll * 16) nb = 256ll * 16;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(wcce_bwd, dim3((unsigned)nb), dim3(256), (size_t)2 * VP * channels * 4, nrt_stream(stream), y_true, y_pred,
+                       label_weights, grad_scalar, grad_per_voxel, nvox_total, channels, from_logits, label_smoothing, scale, VP, grad_pred);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
