@@ -866,6 +866,12 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
             if (tune == 0) tune = channels <= 16 ? (2 | (3 << 4) | (4 << 8) | (1 << 12)) : 0;
         }
         else if (can_rows) variant = 2;
+        else if (channels % 4 == 0 && aligned) {
+            // 12, 20, 24 ... channels: the rank-templated kernel of interpn_any.hip with 4 channels per thread (16-byte accesses,
+            // corner arithmetic once per group); the same operations in the same order as interpn_generic
+            return nrt_interpn_any(vol, loc, out, NRT_DT_F32, ndim, vol_shape, out_shape, channels, batch, vol_batch_stride,
+                                   loc_batch_stride, loc_mode, 0, method, has_fill, (double)fill_value, stream);
+        }
         else variant = 1;
     }
     if (variant == 6 && !can_lds) return NRT_ERR_UNSUPPORTED;

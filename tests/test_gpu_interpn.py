@@ -239,6 +239,28 @@ def test_lds2_kernel(dev, C, S):
         ne.utils.interpn(G(vol[:, :, :9].copy(), dev), G(ijk(S)[:, :, :9].copy(), dev), _variant=9)
 
 
+@pytest.mark.parametrize('C', [12, 20])
+def test_channel_counts_multiple_of_four_off_the_row_kernels(dev, C):
+    """float32 volumes with 12 / 20 channels (4 k, but no power of two): the auto-selection takes the rank-templated kernel of
+    interpn_any.hip with 4 channels per thread -- bit-identical to the oracle and to the per-element kernel (variant 1)"""
+    rng = np.random.default_rng(70 + C)
+    S = (11, 9, 14)
+    vol = rng.standard_normal(S + (C,)).astype(F)
+    shift = rng.normal(0, 3, S + (3,)).astype(F)
+    for method in ('linear', 'nearest'):
+        for fill in (None, 0.5):
+            st = ne.layers.SpatialTransformer(interp_method=method, fill_value=fill)
+            got = N(st([G(vol[None], dev), G(shift[None], dev)]))[0]
+            assert bits_equal(got, co.interpn(vol, shift, method, fill, loc_mode=1)), (method, fill)
+            one = N(ne.utils.interpn(G(vol, dev), G(ijk(S) + shift, dev), interp_method=method, fill_value=fill, _variant=1))
+            assert bits_equal(got, one), (method, fill, 'variant 1')
+    up = N(ne.utils.resize(G(vol, dev), 1.5))
+    assert bits_equal(up, npo.resize(vol, 1.5))
+    vb = rng.standard_normal((2, 6, 7, 8, C)).astype(F)
+    tb = rng.normal(0, 2, (2, 6, 7, 8, 3)).astype(F)
+    assert bits_equal(N(ne.layers.SpatialTransformer()([G(vb, dev), G(tb, dev)])), npo.spatial_transformer(vb, tb))
+
+
 def test_lean_kernel_warp_add(dev):
     """compose / VecInt update b + transform(a, b) at a size that takes the lean kernel (C = 3, 16-byte aligned tensors)"""
     rng = np.random.default_rng(72)
