@@ -272,18 +272,30 @@ __global__ __launch_bounds__(256) void soft_quantize(const float *__restrict__ x
 // One thread per voxel sums over the bins (g is [n, nb], read row-wise).
 __global__ __launch_bounds__(256) void soft_quantize_bwd(const float *__restrict__ x, const float *__restrict__ centers, float alpha,
                                                          float lo, float hi, int ret_log, const float *__restrict__ g,
-                                                         float *__restrict__ gx, long long n, int nb) {
-    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
-        const float xv = x[v];
-        const float xc = clipf(xv, lo, hi);
-        const float pass = (xv >= lo && xv <= hi) ? 1.0f : 0.0f;          // tf.clip_by_value passes the gradient on the closed range
-        float acc = 0.0f;
-        for (int b = 0; b < nb; ++b) {
-            const float d = xc - centers[b];
-            const float dd = -2.0f * alpha * d;
-            acc += g[v * nb + b] * (ret_log ? dd : dd * expf(-alpha * (d * d)));
+                                                         float *__restrict__ gx, long long n, int nb, int staged) {
+    extern __shared__ float sq_lds[];       // staged: the gradient rows of the block's 256 voxels, read with coalesced loads
+    for (long long v0 = (long long)blockIdx.x * 256; v0 < n; v0 += (long long)gridDim.x * 256) {
+        const long long v = v0 + threadIdx.x;
+        const int nv = (int)((n - v0) < 256 ? (n - v0) : 256);
+        const float *grow = g + v * nb;
+        if (staged) {
+            __syncthreads();
+            for (long long i = threadIdx.x; i < (long long)nv * nb; i += 256) sq_lds[i] = g[v0 * nb + i];
+            __syncthreads();
+            grow = sq_lds + (long long)threadIdx.x * nb;
         }
-        gx[v] = pass * acc;
+        if (v < n) {
+            const float xv = x[v];
+            const float xc = clipf(xv, lo, hi);
+            const float pass = (xv >= lo && xv <= hi) ? 1.0f : 0.0f;          // tf.clip_by_value passes the gradient on the closed range
+            float acc = 0.0f;
+            for (int b = 0; b < nb; ++b) {
+                const float d = xc - centers[b];
+                const float dd = -2.0f * alpha * d;
+                acc += grow[b] * (ret_log ? dd : dd * expf(-alpha * (d * d)));
+            }
+            gx[v] = pass * acc;
+        }
     }
 }
 
@@ -413,8 +425,9 @@ extern "C" int nrt_soft_quantize_bwd_f32(const float *x, const float *centers, f
                                          int return_log, const float *grad_out, float *grad_x, long long n, int nb_bins, void *stream) {
     if (!x || !centers || !grad_out || !grad_x || n < 0 || nb_bins < 1) return NRT_ERR_INVALID_ARG;
     if (n == 0) return NRT_OK;
-    hipLaunchKernelGGL(soft_quantize_bwd, dim3(mblocks(n, 256)), dim3(256), 0, nrt_stream(stream), x, centers, alpha, min_clip, max_clip,
-                       return_log, grad_out, grad_x, n, nb_bins);
+    const int staged = (size_t)256 * nb_bins * sizeof(float) <= 48 * 1024;      // a lane reading its own row touches a line per bin
+    hipLaunchKernelGGL(soft_quantize_bwd, dim3(mblocks(n, 256)), dim3(256), staged ? (size_t)256 * nb_bins * sizeof(float) : 0,
+                       nrt_stream(stream), x, centers, alpha, min_clip, max_clip, return_log, grad_out, grad_x, n, nb_bins, staged);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
