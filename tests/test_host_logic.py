@@ -177,6 +177,20 @@ def test_affine_to_dense_shift_matches_oracle():
     # identity affine -> zero shift
     z = ne.utils.affine_to_dense_shift(torch.eye(4)[:3], (3, 3, 3))
     assert float(z.abs().max()) < 1e-6
+    # a batch of affines (the form SpatialTransformer / AffineToDenseShift / compose hand over) = the stack of the single fields;
+    # square [D + 1, D + 1] matrices drop their last row; a matrix that needs a gradient stays differentiable
+    Ab = (np.eye(3, 4)[None] + 0.1 * rng.standard_normal((3, 3, 4))).astype(np.float32)
+    both = ne.utils.affine_to_dense_shift(torch.from_numpy(Ab), (5, 6, 4))
+    assert tuple(both.shape) == (3, 5, 6, 4, 3)
+    for b in range(3):
+        assert torch.equal(both[b], ne.utils.affine_to_dense_shift(torch.from_numpy(Ab[b]), (5, 6, 4)))
+    sq = np.concatenate([Ab, np.tile(np.eye(4, dtype=np.float32)[-1:], (3, 1, 1))], 1)
+    assert torch.equal(ne.utils.affine_to_dense_shift(torch.from_numpy(sq), (5, 6, 4)), both)
+    g = torch.from_numpy(Ab[0]).requires_grad_()
+    ne.utils.affine_to_dense_shift(g, (5, 6, 4)).sum().backward()
+    assert g.grad is not None and tuple(g.grad.shape) == (3, 4)
+    with pytest.raises(ValueError):
+        ne.utils.affine_to_dense_shift(torch.zeros(3, 3), (5, 6, 4))
 
 
 def test_shard_range():
