@@ -966,6 +966,134 @@ __global__ __launch_bounds__(BS_NT) void interpn_bwd_vol_sort(InterpBwdArgs ba) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The counting-sort merge of interpn_bwd_vol_sort for few channels (C <= 8: flow fields -- the backward of VecInt / compose --
+// and warped few-channel network outputs), 3-D.  A block takes 4 x 4 x 8 tiles of output voxels (128 voxels, 1024 pairs; the
+// distinct rows are about a third of the pairs on the bench field); the rows are C floats, so the merge phase runs over
+// (distinct row, channel) elements.  Same steps, integer LDS atomics only.
+constexpr int BG_NV = 128, BG_NPAIR = BG_NV * 8, BG_SLOTS = 2048, BG_CMAX = 8;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void interpn_bwd_vol_sort_any(InterpBwdArgs ba, unsigned nTy, unsigned nTz, unsigned ntiles) {
+    constexpr int NT = 256, SPT = BG_SLOTS / NT;
+    const InterpArgs &a = ba.f;
+    const int C = a.C, b = blockIdx.y;
+    __shared__ float s_g[BG_NV * BG_CMAX];
+    __shared__ unsigned s_idx[BG_NPAIR];
+    __shared__ float s_wt[BG_NPAIR];
+    __shared__ unsigned short s_sorted[BG_NPAIR];
+    __shared__ unsigned tag[BG_SLOTS];
+    __shared__ unsigned cnt[BG_SLOTS];
+    __shared__ unsigned short ulist[BG_NPAIR];
+    __shared__ unsigned wsum[NT / 64];
+    __shared__ unsigned nuniq_s;
+    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
+    const float *go = ba.gout + (long long)b * a.out_bs;
+    float *gv = ba.gvol + (long long)b * a.vol_bs;
+    const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned Y = (unsigned)a.S[1], Z = (unsigned)a.S[2];
+    for (int i = threadIdx.x; i < BG_SLOTS; i += NT) { tag[i] = BV_EMPTY; cnt[i] = 0u; }
+    __syncthreads();
+    const unsigned vi = threadIdx.x & 127u, half = threadIdx.x >> 7;            // voxel of the tile, which four corners it files
+    const int lx = (int)(vi >> 5), ly = (int)((vi >> 3) & 3u), lz = (int)(vi & 7u);
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const unsigned tz = tile % nTz, t2 = tile / nTz, ty = t2 % nTy, tx = t2 / nTy;
+        // ---- file the tile's (row, weight) pairs and gradient rows -------------------------------------------------------
+        {
+            const int x = (int)(tx << 2) + lx, y = (int)(ty << 2) + ly, z = (int)(tz << 3) + lz;
+            const bool in = x < a.O[0] && y < a.O[1] && z < a.O[2];
+            const unsigned q = in ? ((unsigned)x * (unsigned)a.O[1] + (unsigned)y) * (unsigned)a.O[2] + (unsigned)z : a.nout - 1;
+            int qd[NRT_MAXD];
+            float p[NRT_MAXD];
+            decode<3>(a, q, qd);
+            load_loc<3, MODE>(a, locb, q, qd, p);
+            const bool oob = a.has_fill ? out_of_bounds<3>(a, p) : false;
+            int i0[3], i1[3];
+            float w0[3], w1[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) corner_1d(p[d], a.S[d], i0[d], i1[d], w0[d], w1[d]);
+            const bool dead = !in || oob;
+            if (half == 0u) {
+                for (int c = 0; c < C; ++c) s_g[vi * (unsigned)C + c] = dead ? 0.0f : go[(long long)q * C + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int corner = (int)half * 4 + k;
+                const int bx = (corner >> 2) & 1, by = (corner >> 1) & 1, bz = corner & 1;
+                const unsigned ix = bx ? i1[0] : i0[0], iy = by ? i1[1] : i0[1], iz = bz ? i1[2] : i0[2];
+                s_idx[vi * 8u + corner] = dead ? BV_EMPTY : (ix * Y + iy) * Z + iz;
+                s_wt[vi * 8u + corner] = dead ? 0.0f : (bx ? w1[0] : w0[0]) * (by ? w1[1] : w0[1]) * (bz ? w1[2] : w0[2]);
+            }
+        }
+        __syncthreads();
+        // ---- 1. slot and rank of every pair ----------------------------------------------------------------------------
+        for (unsigned pi = threadIdx.x; pi < (unsigned)BG_NPAIR; pi += NT) {
+            unsigned found = BV_EMPTY;
+            const unsigned row = s_idx[pi];
+            if (row != BV_EMPTY) {
+                unsigned h = (row * 2654435761u) >> 21;
+#pragma unroll 1
+                for (;;) {
+                    const unsigned old = atomicCAS(&tag[h], BV_EMPTY, row);
+                    if (old == BV_EMPTY || old == row) break;
+                    h = (h + 1u) & (BG_SLOTS - 1u);
+                }
+                found = h | (atomicAdd(&cnt[h], 1u) << 16);
+            }
+            s_idx[pi] = found;
+        }
+        __syncthreads();
+        // ---- 2. segments ---------------------------------------------------------------------------------------------------
+        {
+            unsigned c[SPT], tot = 0u;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) { c[j] = cnt[threadIdx.x * SPT + j]; tot += c[j] | (c[j] ? 0x10000u : 0u); }
+            unsigned incl = tot;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = (unsigned)__shfl_up((int)incl, off, 64);
+                if (lane >= (unsigned)off) incl += o;
+            }
+            if (lane == 63u) wsum[wv] = incl;
+            __syncthreads();
+            unsigned base = incl - tot;
+            for (unsigned w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+            if (threadIdx.x == NT - 1) nuniq_s = (base + tot) >> 16;
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                if (c[j]) {
+                    cnt[threadIdx.x * SPT + j] = (base & 0xffffu) | (c[j] << 16);
+                    ulist[base >> 16] = (unsigned short)(threadIdx.x * SPT + j);
+                    base += c[j] | 0x10000u;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. pairs into their segments ---------------------------------------------------------------------------------
+        for (unsigned pi = threadIdx.x; pi < (unsigned)BG_NPAIR; pi += NT) {
+            const unsigned sl = s_idx[pi];
+            if (sl != BV_EMPTY) s_sorted[(cnt[sl & 0xffffu] & 0xffffu) + (sl >> 16)] = (unsigned short)pi;
+        }
+        __syncthreads();
+        // ---- 4. one thread per (distinct row, channel): sum the row's pairs, one atomic --------------------------------------
+        const unsigned nuniq = nuniq_s;
+        for (unsigned e = threadIdx.x; e < nuniq * (unsigned)C; e += NT) {
+            const unsigned u = e / (unsigned)C, ch = e - u * (unsigned)C;
+            const unsigned slot = ulist[u];
+            const unsigned sg = cnt[slot], off = sg & 0xffffu, n = sg >> 16;
+            float acc = 0.0f;
+            for (unsigned j = 0; j < n; ++j) {
+                const unsigned pe = s_sorted[off + j];
+                acc += s_wt[pe] * s_g[(pe >> 3) * (unsigned)C + ch];
+            }
+            if (acc != 0.0f) atomic_add_f32(gv + (size_t)tag[slot] * C + ch, acc);
+        }
+        __syncthreads();
+        for (unsigned u = threadIdx.x; u < nuniq; u += NT) { const unsigned slot = ulist[u]; tag[slot] = BV_EMPTY; cnt[slot] = 0u; }
+        __syncthreads();
+    }
+}
+
 // nearest interpolation (utils.py:193-204): out[q, c] = vol[idx(round(loc_q)), c]  [* (1 - oob) + oob * fill].
 // tf.round has no gradient (d / d loc = 0); d / d vol is tf.gather's scatter-add of g[q, c] into the gathered element,
 // masked by (1 - oob) when a fill value is set.  One thread per output element, float atomics.
@@ -1078,7 +1206,27 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
             default: NRT_BWD_MODE(interpn_bwd_rows, 64) break;
         }
     } else {
-        if (grad_vol && channels > 1) {
+        unsigned long long grows = 1;
+        for (int d = 0; d < ndim; ++d) grows *= (unsigned long long)vol_shape[d];
+        const char *sa = getenv("NRT_BWD_VOL_SORT_ANY");               // 0: the per-element scatter below for every channel count
+        if (grad_vol && ndim == 3 && channels <= BG_CMAX && grows < 0xffffffffull && !(sa && sa[0] == '0')) {
+            // few channels, 3-D: duplicate rows merged on chip (counting sort), d loc by the per-voxel kernel
+            const unsigned nTx = (unsigned)(out_shape[0] + 3) / 4, nTy = (unsigned)(out_shape[1] + 3) / 4, nTz = (unsigned)(out_shape[2] + 7) / 8;
+            const unsigned ntiles = nTx * nTy * nTz;
+            unsigned gx = ntiles < 256u * 8u ? ntiles : 256u * 8u;
+            if (gx < 1u) gx = 1u;
+            dim3 sgrid(gx, batch);
+            InterpBwdArgs bv = ba;
+            bv.gloc = nullptr;
+            switch (loc_mode) {
+                case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((interpn_bwd_vol_sort_any<NRT_LOC_ABSOLUTE>), sgrid, dim3(256), 0, st, bv, nTy, nTz, ntiles); break;
+                case NRT_LOC_SHIFT: hipLaunchKernelGGL((interpn_bwd_vol_sort_any<NRT_LOC_SHIFT>), sgrid, dim3(256), 0, st, bv, nTy, nTz, ntiles); break;
+                default: hipLaunchKernelGGL((interpn_bwd_vol_sort_any<NRT_LOC_LINSPACE>), sgrid, dim3(256), 0, st, bv, nTy, nTz, ntiles); break;
+            }
+            NRT_CHECK_LAUNCH();
+            if (!grad_loc) return NRT_OK;
+            ba.gvol = nullptr;
+        } else if (grad_vol && channels > 1) {
             // d vol per element (coalesced atomic requests), d loc per voxel
             unsigned long long nb = ((unsigned long long)ba.f.nout * (unsigned)channels + 255) / 256;
             if (nb > 65536ull * 4) nb = 65536ull * 4;

@@ -410,6 +410,32 @@ def test_backward_x_march_schedule_ragged(dev):
         close(N(f.grad[b]), lo.grad.numpy(), 'grad_flow b%d' % b)
 
 
+@pytest.mark.parametrize('C', [1, 3, 5, 8])
+@pytest.mark.parametrize('mode', ['1', '0'])
+def test_grad_vol_few_channels(dev, C, mode, monkeypatch):
+    """d out / d vol at few channels, 3-D (the backward of VecInt / compose and of warped few-channel network outputs): the
+    counting-sort merge over 4 x 4 x 8 tiles (interpn_bwd_vol_sort_any, default) and the per-element scatter
+    (NRT_BWD_VOL_SORT_ANY=0) against the float64 oracle: smooth field (many duplicate rows), rough field (every pair its own row),
+    fill value (masked voxels), output extents that are no multiples of the tile, a source volume of another shape"""
+    monkeypatch.setenv('NRT_BWD_VOL_SORT_ANY', mode)
+    rng = np.random.default_rng(41 + C)
+    B, S = 2, (9, 14, 21)
+    mov = rng.standard_normal((B, 11, 13, 17, C)).astype(F)
+    w = rng.standard_normal((B,) + S + (C,)).astype(F)
+    grid_scale = np.array([10.0 / 8, 12.0 / 13, 16.0 / 20], F)
+    for kind, fill in (('smooth', None), ('smooth', 0.0), ('rough', None)):
+        flow = (rng.standard_normal((B,) + S + (3,)) * (1.5 if kind == 'smooth' else 12.0)).astype(F)
+        grid = np.stack(np.meshgrid(*[np.arange(n, dtype=F) for n in S], indexing='ij'), -1) * grid_scale
+        loc = (grid[None] + flow).astype(F)
+        v = G(mov, dev, True)
+        out = torch.stack([ne.utils.interpn(v[b], G(loc[b], dev), fill_value=fill) for b in range(B)])
+        (out * G(w, dev)).sum().backward()
+        for b in range(B):
+            vo, lo = D64(mov[b], True), D64(loc[b])
+            (go.interpn(vo, lo, fill) * D64(w[b])).sum().backward()
+            close(N(v.grad[b]), vo.grad.numpy(), 'grad_vol %s fill=%r b%d' % (kind, fill, b))
+
+
 @pytest.mark.parametrize('fill', [None, 0.0])
 @pytest.mark.parametrize('dedup', ['0', '1', '2'])
 def test_grad_vol_row_accumulator_kernel(dev, fill, dedup, monkeypatch):
