@@ -27,6 +27,7 @@
 
 #include "interpn_core.h"
 #include "lean.h"
+#include "lc.h"
 #include "wdd.h"
 
 namespace {
@@ -897,6 +898,17 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
                 !nrt_lds2_supported(a.S, a.O, channels, ndim, vol, loc, out, nullptr, vol_batch_stride, loc_batch_stride, 0, loc_mode))
                 return NRT_ERR_UNSUPPORTED;
             return nrt_lds2_launch(&a, batch, loc_mode, st);
+        case 10: {       // LDS row cache (gather_lc.hip)
+            if (!(can_rows && method == NRT_INTERP_LINEAR && ndim == 3 && nrt_lc_supported(a.S, a.O, channels) && ((uintptr_t)loc & 3) == 0 &&
+                  vol_bytes < (1ull << 32)))
+                return NRT_ERR_UNSUPPORTED;
+            LcCall w;
+            w.vol = vol; w.loc = loc; w.out = out; w.fixed = nullptr; w.fpart = nullptr; w.mpart = nullptr; w.minmax = 0;
+            for (int d = 0; d < 3; ++d) { w.S[d] = a.S[d]; w.O[d] = a.O[d]; w.delta[d] = a.delta[d]; }
+            w.batch = batch; w.vol_bs = a.vol_bs; w.loc_bs = a.loc_bs; w.out_bs = a.out_bs;
+            w.mode = loc_mode; w.has_fill = a.has_fill; w.fill = fill_value; w.tune = tune;
+            return nrt_lc_launch(w, st);
+        }
         case 7: {
             if (!can_wdd) return NRT_ERR_UNSUPPORTED;
             WddCall w;

@@ -1,0 +1,142 @@
+"""Correctness and timing of the LDS-row-cache gather (csrc/gather_lc.hip) against the register kernels (GPU session tool).
+
+    python tools/lc_check.py [check] [time] [--sizes small|full]
+check: bit-exact warped volume + Dice vs the default kernels over shapes / fields / fill / location modes.
+time : event timing of the default fused kernel, the LC fused kernel (and its data-path-only diagnostic), the drop-in interpn
+       kernels and a few roofs (nearest warp, soft Dice) on the bench tensors (4 x 160^3 x 32).
+"""
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+import neurite_amd as ne
+from neurite_amd import synth
+
+LC = 1 << 28
+dev = torch.device('cuda:0')
+
+
+def bits_equal(a, b):
+    return a.shape == b.shape and torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def check():
+    bad = 0
+    rng = np.random.default_rng(0)
+    for S in [(8, 8, 8), (12, 10, 32), (19, 13, 21), (33, 6, 5), (40, 40, 40), (64, 48, 36)]:
+        for kind in ('smooth', 'steep', 'rough', 'edge'):
+            for fill in (None, 0.0, 0.25):
+                B = 2
+                mov = torch.from_numpy(rng.standard_normal((B,) + S + (32,)).astype(np.float32)).to(dev)
+                fix = torch.from_numpy(rng.random((B,) + S + (32,)).astype(np.float32)).to(dev)
+                if kind == 'smooth':
+                    trf = torch.stack([synth.smooth_displacement(5 + b, max(S), sigma=1.0, coarse=6, device=dev)[:S[0], :S[1], :S[2]] for b in range(B)])
+                elif kind == 'steep':
+                    trf = torch.stack([synth.smooth_displacement(9 + b, max(S), sigma=3.0, coarse=max(2, max(S) // 8), device=dev)[:S[0], :S[1], :S[2]] for b in range(B)])
+                elif kind == 'rough':
+                    trf = torch.from_numpy(rng.uniform(-max(S), max(S), (B,) + S + (3,)).astype(np.float32)).to(dev)
+                else:
+                    trf = torch.from_numpy(rng.uniform(-1.5, 1.5, (B,) + S + (3,)).astype(np.float32)).to(dev)
+                    trf[:, 0] -= 2.0
+                    trf[:, :, -1] += 3.0
+                trf = trf.contiguous()
+                d0, w0, s0 = ne.fused.warp_dice(mov, trf, fix, fill_value=fill, return_warped=True, return_sums=True)
+                for tune in (LC, LC | 1, LC | 3):
+                    d1, w1, s1 = ne.fused.warp_dice(mov, trf, fix, fill_value=fill, return_warped=True, return_sums=True, _tune=tune)
+                    d2, s2 = ne.fused.warp_dice(mov, trf, fix, fill_value=fill, return_sums=True, _tune=tune)
+                    torch.cuda.synchronize()
+                    okw = bits_equal(w0, w1)
+                    oks = torch.allclose(s0, s1, rtol=2e-5, atol=1e-4) and torch.allclose(s0, s2, rtol=2e-5, atol=1e-4)
+                    if not (okw and oks):
+                        bad += 1
+                        nb = int((w0.view(torch.int32) != w1.view(torch.int32)).sum())
+                        print('FAIL fused', S, kind, fill, hex(tune), 'warped bits differ at', nb, 'of', w0.numel(),
+                              'sums maxrel', float(((s0 - s1).abs() / (s0.abs() + 1e-3)).max()), flush=True)
+                # drop-in interpn, absolute locations (un-batched API) and the SpatialTransformer form
+                for b in range(B):
+                    grid = torch.stack(torch.meshgrid(*[torch.arange(n, device=dev, dtype=torch.float32) for n in S], indexing='ij'), -1)
+                    loc = grid + trf[b]
+                    r0 = ne.utils.interpn(mov[b], loc, fill_value=fill)
+                    r1 = ne.utils.interpn(mov[b], loc, fill_value=fill, _variant=10)
+                    if not bits_equal(r0, r1):
+                        bad += 1
+                        print('FAIL interpn', S, kind, fill, int((r0.view(torch.int32) != r1.view(torch.int32)).sum()), flush=True)
+        # resize (linspace locations)
+        vol = torch.from_numpy(rng.standard_normal((2,) + S + (32,)).astype(np.float32)).to(dev)
+        for z in (2, 0.5, 1.5):
+            if min(int(n * z) for n in S) < 1:
+                continue
+            from neurite_amd import utils as U, _lib as L
+            new_shape = U._new_shape(list(S), [z] * 3)
+            r0 = U._interp_op(vol, None, new_shape, L.LOC_LINSPACE, U._METHODS['linear'], None, batched=True)
+            r1 = U._interp_op(vol, None, new_shape, L.LOC_LINSPACE, U._METHODS['linear'], None, batched=True, variant=10)
+            if not bits_equal(r0, r1):
+                bad += 1
+                print('FAIL resize', S, z, flush=True)
+    print('lc_check: %d failures' % bad, flush=True)
+    return bad
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def timing(batch=4, size=160):
+    mov, fix, trf = synth.cfg2_batch(batch, size, 32, device=dev)
+    nvox = batch * size ** 3
+    rows = []
+
+    def rec(name, ms, bytes_per_vox):
+        r = {'kernel': name, 'batch': batch, 'ms': round(ms, 4), 'TBs': round(nvox * bytes_per_vox / ms / 1e9, 3),
+             'frac': round(nvox * bytes_per_vox / ms / 1e9 / 8.0, 4)}
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+
+    rec('fused_default', timeit(lambda: ne.fused.warp_dice(mov, trf, fix)), 268)
+    for nseg in (0, 3, 5, 8, 10):
+        rec('fused_lc_nseg%d' % nseg, timeit(lambda: ne.fused.warp_dice(mov, trf, fix, _tune=LC | nseg)), 268)
+    rec('fused_lc_diag1', timeit(lambda: ne.fused.warp_dice(mov, trf, fix, _tune=LC | (1 << 8))), 268)
+    st = ne.layers.SpatialTransformer()
+    from neurite_amd import deferred
+    old = deferred.enabled
+    deferred.enabled = False
+    rec('interpn_default', timeit(lambda: st([mov, trf])), 268)
+    st10 = ne.layers.SpatialTransformer()
+    st10._variant = 10
+    rec('interpn_lc', timeit(lambda: st10([mov, trf])), 268)
+    stn = ne.layers.SpatialTransformer(interp_method='nearest')
+    rec('nearest_warp', timeit(lambda: stn([mov, trf])), 268)
+    deferred.enabled = old
+    dice = ne.metrics.Dice(check_input_limits=False)
+    rec('dice_soft', timeit(lambda: dice.dice(fix, mov)), 256)
+    # gentler fields
+    for sig in (1.0, 0.3):
+        trf2 = torch.stack([synth.smooth_displacement(50 + b, size, sigma=sig, device=dev) for b in range(batch)])
+        rec('fused_default_sigma%g' % sig, timeit(lambda: ne.fused.warp_dice(mov, trf2, fix)), 268)
+        rec('fused_lc_sigma%g' % sig, timeit(lambda: ne.fused.warp_dice(mov, trf2, fix, _tune=LC)), 268)
+    return rows
+
+
+if __name__ == '__main__':
+    args = sys.argv[1:] or ['check', 'time']
+    rc = 0
+    if 'check' in args:
+        rc = check()
+    if 'time' in args:
+        timing()
+        if '--b1' in args:
+            timing(batch=1)
+    sys.exit(1 if rc else 0)
