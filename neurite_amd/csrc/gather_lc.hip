@@ -218,7 +218,8 @@ __global__ __launch_bounds__(128) void gather_lc(LcK a) {
                                                   max((unsigned)__builtin_amdgcn_readlane((int)age, 32), (unsigned)__builtin_amdgcn_readlane((int)age, 48)));
                         const unsigned keep = max(amax, Aprev + (H - Hprev));
                         const unsigned room = keep >= (unsigned)LC_NR ? 0u : (unsigned)LC_NR - keep;
-                        const unsigned limit = min(room, LC_LIST_SCR - 8u);          // the list holds 128 ring entries incl. padding
+                        const unsigned limit = min(room, LC_LIST_SCR - 8u) & ~7u;   // whole 8-row instructions (their padding rows are written
+                                                                                       // too); the list holds 128 ring entries incl. padding
                         Aprev = amax; Hprev = H;
                         // 3. claim: one owner per distinct missing row
 #pragma unroll
