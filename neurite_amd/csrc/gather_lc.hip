@@ -4,22 +4,27 @@
 // Why: the register kernels (interpn.hip, fused.hip) pull 8 corner rows + 1 fixed row = 1152 B per voxel through the
 // texture path (TA -> L1 -> VGPR, 64 B/clk/CU); of those only ~2.3 rows are HBM misses, the rest are L1 / L2 hits that still
 // occupy the path (profiles/r02_lab: hits and misses issued by one CU cost additively).  On the SURVEY 8d field a voxel shares
-// its corner rows with its (y,z) neighbours and with the next x plane: an x-marching 4 x 4 patch needs only ~2.1 NEW rows per
-// voxel.  So every wave keeps a private software cache of source rows in LDS and the texture path carries each row once:
+// its corner rows with its (y,z) neighbours and with the next x plane: an x-marching 4 x 8 patch needs only ~2.0 NEW rows per
+// voxel.  So a workgroup keeps a software cache of source rows in LDS and the texture path carries each row once:
 //
-//   * one wave = one workgroup = one 4 x 4 (y,z) patch marching along x; a step is one x plane (16 voxels);
-//   * LDS per wave (38.1 KB, four waves per CU): 224-row FIFO ring + 2 x 16 scratch rows (128 B each), a 1024-entry
-//     direct-mapped tag table (hash = low bits of the row's x, y, z), a fetch list and three hand-off buffers;
-//   * MGMT(t+2): lane = (voxel, x-corner, y-corner) looks its two z-corner rows up in the tag table; misses are claimed through
-//     the table (write token, read back: one owner per distinct row), owners take consecutive ring slots (ballot + mbcnt) and
-//     append the row to the fetch list; the slots of all 8 corners and the weights go to the hand-off buffer;
-//   * ISSUE(t+1): the list is fetched by global_load_lds_dwordx4 (8 rows per instruction, straight into the ring);
-//   * BLEND(t): 8 lanes per voxel read the 8 corner rows from LDS (ds_read_b128) and run the reference's op sequence
-//     (bit-identical to interpn.hip), the fixed row comes from registers loaded one step ahead.
+//   * one workgroup (6 waves, 80 KB of LDS, two per CU) = one 4 x 8 (y,z) patch marching along x; a step is one x plane
+//     (32 voxels);
+//   * waves 0 and 1 each manage the source rows of one x parity (a voxel's two x corners have different parities): a 256-row
+//     FIFO ring (128 B rows), a 512-entry direct-mapped tag table (hash = low bits of the row's x / 2, y, z) and a fetch list.
+//     MGMT(t+3): lane = (voxel, y corner) looks its two z-corner rows up in the tag table; misses are claimed through the table
+//     (write token, read back: one owner per distinct row), owners take consecutive ring slots (ballot + mbcnt) and append the
+//     row to the fetch list; the slots and the weights go to one of four hand-off buffers.  These waves touch LDS only, and the
+//     location arithmetic of step t+4 is interleaved with the LDS round trips of the protocol of step t+3;
+//   * waves 2-5, ISSUE(t+2): each fetches a quarter of both lists by global_load_lds_dwordx4 (8 rows per instruction, straight
+//     into the rings), and waits for its own loads of step t before the barrier of step t;
+//     BLEND(t): 8 lanes per voxel read the 8 corner rows from LDS (ds_read_b128) and run the reference's op sequence
+//     (bit-identical to interpn.hip); the fixed row comes from registers loaded two steps ahead;
+//   * one s_barrier per step: A(t) = "rows and hand-off of step t are in LDS, the blend of step t - 1 is done".
 //   A ring row may be overwritten only when no step that still has to blend needs it: a step may allocate at most
-//   224 - (age of the oldest row the previous and the current step hit) rows; the overflow goes to the scratch rows of the
-//   step and, beyond those (1-2 % of the steps on the 8d field), to direct loads in the blend ("slow" corners).
+//   256 - (age of the oldest row that it or the two steps before it hit) rows; what does not fit (a few % of the steps on the
+//   8d field) is loaded directly by the blend ("slow" corners).
 //   All vector-memory loads are inline asm: the compiler's s_waitcnt model would otherwise serialise against the LDS-DMA.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "dice_reduce.h"
@@ -28,22 +33,17 @@
 
 namespace {
 
-#ifdef LC_PHASE_MARKS
-#define LC_PH(x) asm volatile("; ##PH " x ::: "memory")
-#else
-#define LC_PH(x)
-#endif
-
-constexpr int LC_NR = 224;            // ring rows (multiple of 8)
-constexpr int LC_SCR = 16;            // scratch rows per step, two buffers
-constexpr int LC_WIN = 112;           // a cached row counts as a hit while it is younger than this many allocations
-constexpr unsigned LC_TAB = 32768;    // byte offsets inside the wave's LDS
-constexpr unsigned LC_HAND = LC_TAB + 4096;
-constexpr unsigned LC_LIST = LC_HAND + 3 * 512;
-constexpr unsigned LC_LIST_SCR = 128; // list index of the first scratch entry
-constexpr unsigned LC_DUMMY = LC_LIST + (LC_LIST_SCR + LC_SCR + 8) * 4;   // 64 dwords
-constexpr unsigned LC_LDS = LC_DUMMY + 256;
-static_assert(LC_LDS <= 40960, "four waves per CU");
+constexpr int LC_NR = 256;            // ring rows per management wave (a power of two: ring slot = allocation counter & 255)
+constexpr int LC_WIN = 96;            // a cached row counts as a hit while it is younger than this many allocations
+constexpr int LC_CAP = 120;           // ring rows a wave may allocate per step (its list holds 128 entries incl. padding)
+constexpr unsigned LC_TAB = 2 * LC_NR * 128;               // byte offsets inside the workgroup's LDS: two tag tables of 512 entries
+constexpr unsigned LC_HAND = LC_TAB + 2 * 2048;            // 4 buffers x 32 voxels x 32 B
+constexpr unsigned LC_LIST = LC_HAND + 4096;               // fetch lists [2 buffers][2 parities][128 entries]
+constexpr unsigned LC_CTL = LC_LIST + 2048;                // [2 buffers][2 parities] {rows, first ring slot}
+constexpr unsigned LC_SHIFT = LC_CTL + 64;                 // 4 buffers x 96 floats
+constexpr unsigned LC_DUMMY = LC_SHIFT + 4 * 384;          // 128 dwords
+constexpr unsigned LC_LDS = LC_DUMMY + 512;
+static_assert(LC_LDS <= 81920, "two workgroups per CU");
 
 struct LcK {
     const char *vol, *loc, *fixed;
@@ -58,58 +58,67 @@ struct LcK {
     int lry, lrz;
     unsigned nyh, nzh, ntask;
     int minmax;
+    int strict;      // diagnostic: every wait of the fetching waves drains all of their loads
 };
 
 typedef unsigned nrt_u4 __attribute__((ext_vector_type(4)));
-typedef float nrt_f3 __attribute__((ext_vector_type(3)));
 
 __device__ __forceinline__ void lc_dma16(const void *base, unsigned voff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
-// the same with an explicit lane mask (rows of the list that do not exist): no branch around the instruction
-__device__ __forceinline__ void lc_dma16m(const void *base, unsigned voff, unsigned lds_dst, unsigned long long mask) {
-    unsigned long long save;
-    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
-                 : "=&s"(save) : "v"(voff), "s"(base), "s"(lds_dst), "s"(mask) : "memory");
+__device__ __forceinline__ void lc_dma4(const void *base, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
-__device__ __forceinline__ nrt_f4 lc_ld16(const void *base, unsigned voff) {
+__device__ __forceinline__ nrt_f4 lc_ld16(const void *base, unsigned voff) {          // streamed once (fixed rows)
     nrt_f4 r;
     asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(r) : "v"(voff), "s"(base) : "memory");
     return r;
 }
-__device__ __forceinline__ nrt_f4 lc_ld16c(const void *base, unsigned voff) {     // cached (source rows)
+__device__ __forceinline__ nrt_f4 lc_ld16c(const void *base, unsigned voff) {         // cached (source rows)
     nrt_f4 r;
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(base) : "memory");
-    return r;
-}
-__device__ __forceinline__ nrt_f3 lc_ld12(const void *base, unsigned voff) {
-    nrt_f3 r;
-    asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(base) : "memory");
     return r;
 }
 __device__ __forceinline__ unsigned lc_mbcnt(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 __device__ __forceinline__ unsigned lc_uni(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
-
 __device__ __forceinline__ unsigned lc_sel(bool c, unsigned x, unsigned y) { return c ? x : y; }
 // workgroup barrier that also publishes this wave's LDS writes / retires its LDS reads (no vmcnt: the waves time their own loads)
 __device__ __forceinline__ void lc_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
+// wait until at most k of this wave's vector-memory instructions are outstanding (they retire in order)
+__device__ __forceinline__ void lc_wait_vm(unsigned k) {
+#define LC_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" : : : "memory"); break;
+    switch (k) {
+        LC_W(0) LC_W(1) LC_W(2) LC_W(3) LC_W(4) LC_W(5) LC_W(6) LC_W(7) LC_W(8) LC_W(9) LC_W(10) LC_W(11) LC_W(12) LC_W(13) LC_W(14) LC_W(15)
+        LC_W(16) LC_W(17) LC_W(18) LC_W(19) LC_W(20) LC_W(21) LC_W(22) LC_W(23) LC_W(24) LC_W(25) LC_W(26) LC_W(27) LC_W(28) LC_W(29) LC_W(30)
+        LC_W(31) LC_W(32) LC_W(33) LC_W(34) LC_W(35) LC_W(36) LC_W(37) LC_W(38) LC_W(39) LC_W(40)
+        default: asm volatile("s_waitcnt vmcnt(40)" : : : "memory"); break;      // fewer outstanding than allowed is only stricter
+    }
+#undef LC_W
+}
+
+// DIAG == 2: per-phase shader clocks summed over all workgroups (read back and printed by the launcher; tools/lc_check.py phases)
+__device__ unsigned long long lc_dbg[16];
+#define LC_T(var) do { if (DIAG == 2) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dbg_[var] += now_ - last_; last_ = now_; } } while (0)
+
+// what MGMT's location arithmetic hands to its protocol (one step ahead, in registers)
+struct LcPrep {
+    unsigned id[2], tpo[2], idhi[2], tok[2];     // row, byte offset of its tag, tag bits 17..31, the claim this lane would write
+    unsigned id0flags, hoff0, hoff1;             // row of corner 0 | flags; byte offsets of the hand-off dwords (or the dummy)
+    float w0x, w0y, w0z;
+    bool mine;
+};
 
 // MODE = location mode; DICE = accumulate the soft-Dice sums against `fixed`; STORE = write the warped rows; FILL = fill_value
-// given.  DIAG: 0 = product; 1 = no tag protocol (every corner "hits" slot id % 224, 32 arbitrary rows fetched per step): the cost
-// of the data path alone (profiles/r03_lc).
-// A workgroup is two waves that share one row cache: wave 0 manages it (tags, allocation, fetch list, LDS-DMA), wave 1 blends.
-// One s_barrier per step: A(t) = "rows and hand-off of step t are in LDS, blend of step t - 1 is done".
+// given.  DIAG: 0 = product; 1 = no tag protocol (every corner "hits" slot id % 256, 32 arbitrary rows fetched per wave and step):
+// the cost of the data path alone; 2 = product + phase clocks (profiles/r03_lc).
 template <int MODE, bool DICE, bool STORE, bool FILL, int DIAG>
-__global__ __launch_bounds__(128) void gather_lc(LcK a) {
-    __shared__ __attribute__((aligned(16))) unsigned char sm[LC_LDS];
+__global__ __launch_bounds__(384, 3) void gather_lc(LcK a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const unsigned l = threadIdx.x & 63u;
-    const bool is_mgmt = lc_uni(threadIdx.x >> 6) == 0u;
+    const unsigned wv = lc_uni(threadIdx.x >> 6);
     const unsigned lds0 = lc_uni((unsigned)(size_t)sm);
-    unsigned *const tab = (unsigned *)(sm + LC_TAB);
-    unsigned *const list = (unsigned *)(sm + LC_LIST);
-    unsigned *const dummy = (unsigned *)(sm + LC_DUMMY) + l;       // where the writes of lanes that have nothing to write go (no branch)
 
     const unsigned kx = blockIdx.x % NRT_NXCD, jw = blockIdx.x / NRT_NXCD, J = gridDim.x / NRT_NXCD;
     const unsigned perU = (a.ntask + NRT_NXCD - 1) / NRT_NXCD;
@@ -123,333 +132,394 @@ __global__ __launch_bounds__(128) void gather_lc(LcK a) {
         const unsigned nRz = (a.nTz + RZ - 1) / RZ;
         const unsigned reg = ucol / (RY * RZ), w = ucol % (RY * RZ);
         const unsigned cy = (reg / nRz) * RY + w / RZ, cz = (reg % nRz) * RZ + w % RZ;
-        const int x0 = (int)(useg * a.seglen), y0 = (int)cy * 4, z0 = (int)cz * 4;
+        const int x0 = (int)(useg * a.seglen), y0 = (int)cy * 4, z0 = (int)cz * 8;
         int len = min((int)a.seglen, a.O0 - x0);
         if (cy >= a.nTy || cz >= a.nTz) len = 0;
         const char *volb = a.vol + (unsigned long long)b * a.vol_bs;
 
-        if (is_mgmt) {
-            // ================================ wave 0: cache management ================================
-            if (len > 0) {
-                const char *locb = a.loc ? a.loc + (unsigned long long)b * a.loc_bs : a.vol;
-                // lane = (voxel mv of the plane, x corner mxc, y corner myc), both z corners
-                const unsigned mv = l & 15, myy = mv >> 2, mzz = mv & 3, mcp = l >> 4, mxc = mcp >> 1, myc = mcp & 1;
-                const unsigned lrow = l >> 3, lg = l & 7;                  // DMA role: row lrow of an 8-row instruction, 16 bytes lg
-                unsigned H = 0, Hpos = 0, Aprev = 0, Hprev = 0;           // allocation counter, ring position, oldest row of the previous step
-                unsigned inr = 0, ins = 0, ihp = 0;                       // what the next ISSUE fetches: ring rows, scratch rows, ring position
-                if (DIAG == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) ((nrt_u4 *)tab)[i * 64 + l] = (nrt_u4){~0u, ~0u, ~0u, ~0u};
-                }
-                // lanes past the volume's edge hold a copy of the edge voxel (clamped coordinates)
-                const int myq = min(y0 + (int)myy, a.O1 - 1), mzq = min(z0 + (int)mzz, a.O2 - 1);
-                const bool mvalid = (y0 + (int)myy < a.O1) && (z0 + (int)mzz < a.O2);
-                auto load_shift = [&](int t) -> nrt_f3 {
-                    if (MODE == NRT_LOC_LINSPACE) return (nrt_f3){0, 0, 0};
-                    const unsigned q = nrt_mad24(nrt_mad24((unsigned)min(x0 + t, a.O0 - 1), (unsigned)a.O1, (unsigned)myq), (unsigned)a.O2, (unsigned)mzq);
-                    return lc_ld12(locb, nrt_times3(q) << 2);
-                };
+        // barriers of a task (every wave): P1 (locations of steps 0..3 staged), P2 (lists of steps 0, 1 written), P3 (... and read),
+        // A(0) .. A(len - 1), A(len)
+        if (wv < 2) {
+            // ================================ waves 0, 1: cache management of the rows with x parity P (LDS only) ================================
+            const unsigned P = wv;
+            unsigned *const tab = (unsigned *)(sm + LC_TAB + P * 2048u);
+            const unsigned dummy_o = LC_DUMMY + (P * 64u + l) * 4u;                   // where lanes with nothing to write write (no branch)
+            unsigned *const dummy = (unsigned *)(sm + dummy_o);
+            const unsigned rbase = P * (unsigned)LC_NR;               // first ring row of this wave
+            // lane = (voxel mv of the plane, y corner myc): the two z corners of the x corner whose source plane has parity P
+            const unsigned mv = l & 31, myy = mv >> 3, mzz = mv & 7, myc = l >> 5;
+            unsigned H = 0;                                            // allocation counter (16 bits used); ring slot = H & 255
+            unsigned A1 = 0, H1 = 0, A2 = 0, H2 = 0;                   // oldest hit of the previous two steps (age, counter then)
+            // lanes past the volume's edge hold a copy of the edge voxel (clamped coordinates)
+            const int myq = min(y0 + (int)myy, a.O1 - 1), mzq = min(z0 + (int)mzz, a.O2 - 1);
+            const bool mvalid = (y0 + (int)myy < a.O1) && (z0 + (int)mzz < a.O2);
 
-                // ---- MGMT(t): tag lookups, claims, slot allocation, fetch list, hand-off ----
-                auto mgmt = [&](int t, bool live, const nrt_f3 &sh) {
-                    const int qd[3] = {min(x0 + t, a.O0 - 1), myq, mzq};
-                    const int Sd[3] = {a.S0, a.S1, a.S2}, Od[3] = {a.O0, a.O1, a.O2};
-                    const float dd[3] = {a.d0, a.d1, a.d2};
-                    float p[3];
+            // ---- PREP(t): location -> corners, weights, row ids, tag addresses (no protocol state involved) ----
+            auto prep = [&](int t, LcPrep &q) {
+                const int qd[3] = {min(x0 + t, a.O0 - 1), myq, mzq};       // (a step past the end reads whatever its location buffer holds)
+                const int Sd[3] = {a.S0, a.S1, a.S2}, Od[3] = {a.O0, a.O1, a.O2};
+                const float dd[3] = {a.d0, a.d1, a.d2};
+                const float *shp = (const float *)(sm + LC_SHIFT + ((unsigned)t & 3u) * 384u) + 3u * mv;
+                float p[3];
 #pragma unroll
-                    for (int d = 0; d < 3; ++d) {
-                        if (MODE == NRT_LOC_ABSOLUTE) p[d] = sh[d];
-                        else if (MODE == NRT_LOC_SHIFT) p[d] = nrt_add((float)qd[d], sh[d]);
-                        else p[d] = (qd[d] == 0) ? 0.0f : ((qd[d] == Od[d] - 1) ? (float)(Sd[d] - 1) : nrt_mul(dd[d], (float)qd[d]));
-                    }
-                    int i0x, i1x, i0y, i1y, i0z, i1z;
-                    float w0x, w0y, w0z, w1x, w1y, w1z;
-                    corner_1d(p[0], a.S0, i0x, i1x, w0x, w1x);
-                    corner_1d(p[1], a.S1, i0y, i1y, w0y, w1y);
-                    corner_1d(p[2], a.S2, i0z, i1z, w0z, w1z);
-                    bool oob = false;
-                    if (FILL) oob = (p[0] < 0.0f) || (p[0] > (float)(a.S0 - 1)) || (p[1] < 0.0f) || (p[1] > (float)(a.S1 - 1)) ||
-                                    (p[2] < 0.0f) || (p[2] > (float)(a.S2 - 1));
-                    const unsigned sx = lc_sel(mxc != 0, (unsigned)i1x, (unsigned)i0x), sy = lc_sel(myc != 0, (unsigned)i1y, (unsigned)i0y);
-                    const unsigned rowxy = nrt_mad24(sx, (unsigned)a.S1, sy);
-                    const unsigned hxy = ((sx & 3) << 8) | ((sy & 15) << 4), hixy = nrt_mad24(sx >> 2, a.nyh, sy >> 4);
-                    unsigned id[2], idhi[2], slot[2], slow[2], tok[2];
-                    unsigned *tp[2];
+                for (int d = 0; d < 3; ++d) {
+                    if (MODE == NRT_LOC_ABSOLUTE) p[d] = shp[d];
+                    else if (MODE == NRT_LOC_SHIFT) p[d] = nrt_add((float)qd[d], shp[d]);
+                    else p[d] = (qd[d] == 0) ? 0.0f : ((qd[d] == Od[d] - 1) ? (float)(Sd[d] - 1) : nrt_mul(dd[d], (float)qd[d]));
+                }
+                int i0x, i1x, i0y, i1y, i0z, i1z;
+                float w1x, w1y, w1z;
+                corner_1d(p[0], a.S0, i0x, i1x, q.w0x, w1x);
+                corner_1d(p[1], a.S1, i0y, i1y, q.w0y, w1y);
+                corner_1d(p[2], a.S2, i0z, i1z, q.w0z, w1z);
+                bool oob = false;
+                if (FILL) oob = (p[0] < 0.0f) || (p[0] > (float)(a.S0 - 1)) || (p[1] < 0.0f) || (p[1] > (float)(a.S1 - 1)) ||
+                                (p[2] < 0.0f) || (p[2] > (float)(a.S2 - 1));
+                // the x corner of parity P: corner 0 if i0x has it, else corner 1; at the clamped border (i1x == i0x) one wave owns
+                // both x corners and the other none
+                const bool c0mine = (((unsigned)i0x ^ P) & 1u) == 0u, both = i1x == i0x;
+                q.mine = c0mine || !both;
+                const unsigned mxc = c0mine ? 0u : 1u;
+                const unsigned sx = c0mine ? (unsigned)i0x : (unsigned)i1x;
+                const unsigned sy = myc ? (unsigned)i1y : (unsigned)i0y;
+                const unsigned rowxy = nrt_mad24(sx, (unsigned)a.S1, sy);
+                const unsigned hxy = ((sx & 2) << 7) | ((sy & 15) << 4), hixy = ((sx >> 2) * a.nyh + (sy >> 4)) * a.nzh;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned sz = j ? (unsigned)i1z : (unsigned)i0z;
+                    q.id[j] = nrt_mad24(rowxy, (unsigned)a.S2, sz);
+                    q.tpo[j] = (hxy | (sz & 15)) << 2;
+                    q.idhi[j] = (hixy + (sz >> 4)) << 17;                       // kept in place: bits 17..31 of a tag
+                    q.tok[j] = q.idhi[j] | 0x10000u | (l << 1) | (unsigned)j;
+                }
+                const unsigned id0 = nrt_mad24(nrt_mad24((unsigned)i0x, (unsigned)a.S1, (unsigned)i0y), (unsigned)a.S2, (unsigned)i0z);
+                q.id0flags = id0 | ((unsigned)(i1x != i0x) << 26) | ((unsigned)(i1y != i0y) << 27) | ((unsigned)(i1z != i0z) << 28) |
+                             ((unsigned)mvalid << 29) | ((unsigned)oob << 30);
+                const unsigned hb = LC_HAND + ((unsigned)t & 3u) * 1024u + mv * 32u;
+                const unsigned o0 = hb + (2 * mxc + myc) * 4u, o1 = hb + (2 * (1 - mxc) + myc) * 4u;
+                q.hoff0 = q.mine ? o0 : dummy_o;
+                q.hoff1 = (q.mine && both) ? o1 : dummy_o;
+            };
+
+            // ---- PROTO(t): tag lookups, claims, slot allocation, fetch list, hand-off ----
+            auto proto = [&](int t, bool live, const LcPrep &q) {
+                unsigned *const list = (unsigned *)(sm + LC_LIST + (((unsigned)t & 1u) * 2u + P) * 512u);
+                unsigned *tp[2] = {(unsigned *)((unsigned char *)tab + q.tpo[0]), (unsigned *)((unsigned char *)tab + q.tpo[1])};
+                unsigned slot[2], slow[2];
+                H = (H + 7u) & ~7u;                                   // ring allocations of a step start on a multiple of 8 rows
+                unsigned nr;
+                if (DIAG == 1) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { slot[j] = q.id[j] & 255u; slow[j] = 0; }
+                    *(l < 32 ? &list[l] : dummy) = q.id[0];
+                    nr = live ? 32u : 0u;
+                } else {
+                    // 1. hits
+                    unsigned e[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) e[j] = *tp[j];
+                    bool miss[2];
+                    unsigned age = 0;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const unsigned sz = j ? (unsigned)i1z : (unsigned)i0z;
-                        id[j] = nrt_mad24(rowxy, (unsigned)a.S2, sz);
-                        tp[j] = tab + (hxy | (sz & 15));
-                        idhi[j] = nrt_mad24(hixy, a.nzh, sz >> 4) << 17;          // kept in place: bits 17..31 of a tag
-                        tok[j] = idhi[j] | 0x10000u | (l << 1) | (unsigned)j;     // the claim this lane would write
+                        const unsigned ag = (H - e[j]) & 0xffffu;
+                        const bool hit = ((e[j] ^ q.idhi[j]) >> 16) == 0u && ag < (unsigned)LC_WIN;     // same row, a ring tag, young
+                        miss[j] = q.mine && !hit;
+                        age = max(age, lc_sel(hit && q.mine, ag, 0u));
+                        slot[j] = e[j] & 255u;
                     }
-                    const unsigned id0 = nrt_mad24(nrt_mad24((unsigned)i0x, (unsigned)a.S1, (unsigned)i0y), (unsigned)a.S2, (unsigned)i0z);
-                    const unsigned flags = ((unsigned)(i1x != i0x) << 26) | ((unsigned)(i1y != i0y) << 27) | ((unsigned)(i1z != i0z) << 28) |
-                                           ((unsigned)mvalid << 29) | ((unsigned)oob << 30);
-                    H = (H + 7u) & ~7u;                                   // ring allocations of a step start on a multiple of 8 rows
-                    unsigned nr, ns;
-                    if (DIAG == 1) {
+                    // 2. the oldest row that this step, or the two before it (not blended yet), still reads bounds the allocation
+                    age = max(age, (unsigned)__builtin_amdgcn_update_dpp((int)age, (int)age, 0xB1, 0xF, 0xF, false));    // lane ^ 1
+                    age = max(age, (unsigned)__builtin_amdgcn_update_dpp((int)age, (int)age, 0x4E, 0xF, 0xF, false));    // lane ^ 2
+                    age = max(age, (unsigned)__builtin_amdgcn_update_dpp((int)age, (int)age, 0x141, 0xF, 0xF, false));   // row_half_mirror
+                    age = max(age, (unsigned)__builtin_amdgcn_update_dpp((int)age, (int)age, 0x140, 0xF, 0xF, false));   // row_mirror
+                    const unsigned amax = max(max((unsigned)__builtin_amdgcn_readlane((int)age, 0), (unsigned)__builtin_amdgcn_readlane((int)age, 16)),
+                                              max((unsigned)__builtin_amdgcn_readlane((int)age, 32), (unsigned)__builtin_amdgcn_readlane((int)age, 48)));
+                    const unsigned keep = max(amax, max(A1 + (H - H1), A2 + (H - H2)));
+                    const unsigned room = keep >= (unsigned)LC_NR ? 0u : (unsigned)LC_NR - keep;
+                    const unsigned limit = min(room, (unsigned)LC_CAP) & ~7u;    // whole 8-row instructions (their padding rows are written too)
+                    A2 = A1; H2 = H1; A1 = amax; H1 = H;
+                    // 3. claim: one owner per distinct missing row
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) { slot[j] = id[j] % (unsigned)LC_NR; slow[j] = 0; }
-                        *(l < 32 ? &list[l] : dummy) = id[0];
-                        nr = live ? 32u : 0u; ns = 0;
-                    } else {
-                        // 1. hits
-                        unsigned e[2];
+                    for (int j = 0; j < 2; ++j) *(miss[j] ? tp[j] : dummy) = q.tok[j];
+                    unsigned e2[2];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) e[j] = *tp[j];
-                        bool miss[2];
-                        unsigned age = 0;
+                    for (int j = 0; j < 2; ++j) e2[j] = *tp[j];
+                    bool owner[2], follower[2], fetcher[2];
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const unsigned ag = (H - e[j]) & 0xffffu;
-                            const bool hit = ((e[j] ^ idhi[j]) >> 16) == 0u && ag < (unsigned)LC_WIN;     // same row, not a claim / scratch tag, young
-                            miss[j] = !hit;
-                            age = max(age, lc_sel(hit, ag, 0u));
-                            const unsigned pos = Hpos - ag, posw = pos + (unsigned)LC_NR;
-                            slot[j] = lc_sel(hit, lc_sel((int)pos < 0, posw, pos), 0u);
-                        }
-                        // 2. the oldest row that this step, or the previous one (not blended yet), still reads bounds the allocation
-                        age = max(age, (unsigned)__builtin_amdgcn_update_dpp((int)age, (int)age, 0xB1, 0xF, 0xF, false));    // lane ^ 1
-                        age = max(age, (unsigned)__builtin_amdgcn_update_dpp((int)age, (int)age, 0x4E, 0xF, 0xF, false));    // lane ^ 2
-                        age = max(age, (unsigned)__builtin_amdgcn_update_dpp((int)age, (int)age, 0x141, 0xF, 0xF, false));   // row_half_mirror
-                        age = max(age, (unsigned)__builtin_amdgcn_update_dpp((int)age, (int)age, 0x140, 0xF, 0xF, false));   // row_mirror
-                        const unsigned amax = max(max((unsigned)__builtin_amdgcn_readlane((int)age, 0), (unsigned)__builtin_amdgcn_readlane((int)age, 16)),
-                                                  max((unsigned)__builtin_amdgcn_readlane((int)age, 32), (unsigned)__builtin_amdgcn_readlane((int)age, 48)));
-                        const unsigned keep = max(amax, Aprev + (H - Hprev));
-                        const unsigned room = keep >= (unsigned)LC_NR ? 0u : (unsigned)LC_NR - keep;
-                        const unsigned limit = min(room, LC_LIST_SCR - 8u) & ~7u;   // whole 8-row instructions (their padding rows are written
-                                                                                       // too); the list holds 128 ring entries incl. padding
-                        Aprev = amax; Hprev = H;
-                        // 3. claim: one owner per distinct missing row
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) *(miss[j] ? tp[j] : dummy) = tok[j];
-                        unsigned e2[2];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) e2[j] = *tp[j];
-                        bool owner[2], follower[2], fetcher[2];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const bool same = ((e2[j] ^ idhi[j]) >> 17) == 0u;
-                            owner[j] = miss[j] && e2[j] == tok[j];
-                            follower[j] = miss[j] && same && !owner[j];
-                            fetcher[j] = miss[j] && !follower[j];         // owners, and rows that lost their table entry to another row
-                        }
-                        // 4. consecutive slots for everything that is fetched
-                        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(fetcher[0]), b1 = __builtin_amdgcn_ballot_w64(fetcher[1]);
-                        const unsigned c0 = (unsigned)__builtin_popcountll(b0), ntot = c0 + (unsigned)__builtin_popcountll(b1);
-                        const unsigned pos[2] = {lc_mbcnt(b0), c0 + lc_mbcnt(b1)};
-                        nr = live ? min(ntot, limit) : 0u;
-                        ns = live ? min(ntot - nr, (unsigned)LC_SCR) : 0u;
-                        // pad both lists to whole instructions with a row of this step (overwritten below where a real entry exists)
-                        unsigned *const padp = l < 8 ? &list[(nr & ~7u) + l] : &list[LC_LIST_SCR + (ns & ~7u) + (l & 7)];
-                        *(l < 16 ? padp : dummy) = id[0];
-                        const unsigned sbase = (unsigned)LC_NR + ((unsigned)t & 1u) * (unsigned)LC_SCR;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const bool ring = fetcher[j] && pos[j] < nr, scr = fetcher[j] && !ring && pos[j] < nr + ns;
-                            const unsigned rp0 = Hpos + pos[j], rp = lc_sel(rp0 >= (unsigned)LC_NR, rp0 - (unsigned)LC_NR, rp0);
-                            const unsigned si = pos[j] - nr, sslot = sbase + si;
-                            slot[j] = lc_sel(ring, rp, lc_sel(scr, sslot, slot[j]));
-                            slow[j] = (fetcher[j] && !ring && !scr) ? 1u : 0u;
-                            unsigned *const lp_ring = &list[pos[j]], *const lp_scr = &list[LC_LIST_SCR + si];
-                            unsigned *const lp = ring ? lp_ring : (scr ? lp_scr : dummy);
-                            *lp = id[j];
-                            const unsigned tag_ring = idhi[j] | ((H + pos[j]) & 0xffffu), tag_scr = idhi[j] | 0x18000u | sslot;
-                            const unsigned tagv = lc_sel(ring, tag_ring, lc_sel(scr, tag_scr, ~0u));
-                            *(owner[j] ? tp[j] : dummy) = tagv;
-                        }
-                        // 5. rows another lane fetches
-                        unsigned e3[2];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) e3[j] = *tp[j];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const bool same = ((e3[j] ^ idhi[j]) >> 17) == 0u;
-                            const unsigned rp0 = Hpos + ((e3[j] - H) & 0xffffu), rp = lc_sel(rp0 >= (unsigned)LC_NR, rp0 - (unsigned)LC_NR, rp0);
-                            const unsigned fs = lc_sel((e3[j] & 0x10000u) != 0u, e3[j] & 0xffu, rp);      // scratch row of this step : ring row
-                            slot[j] = lc_sel(follower[j], lc_sel(same, fs, 0u), slot[j]);
-                            slow[j] = lc_sel(follower[j] && !same, 1u, slow[j]);
-                        }
+                    for (int j = 0; j < 2; ++j) {
+                        const bool same = ((e2[j] ^ q.idhi[j]) >> 17) == 0u;
+                        owner[j] = miss[j] && e2[j] == q.tok[j];
+                        follower[j] = miss[j] && same && !owner[j];
+                        fetcher[j] = miss[j] && !follower[j];         // owners, and rows that lost their table entry to another row
                     }
-                    // hand-off: dword cp = LDS byte offsets of the lane's two rows (bit 0 = slow); dwords 4..7 (same value from the four
-                    // lanes of the voxel) = weights, row of corner 0, flags
-                    unsigned char *hb = sm + LC_HAND + ((unsigned)t % 3u) * 512u + mv * 32u;
-                    ((unsigned *)hb)[mcp] = ((slot[0] << 7) | slow[0]) | (((slot[1] << 7) | slow[1]) << 16);
-                    *(nrt_u4 *)(hb + 16) = (nrt_u4){__float_as_uint(w0x), __float_as_uint(w0y), __float_as_uint(w0z), id0 | flags};
-                    inr = nr; ins = ns; ihp = Hpos;
-                    H += nr;
-                    const unsigned hp1 = Hpos + ((nr + 7u) & ~7u);
-                    Hpos = lc_sel(hp1 >= (unsigned)LC_NR, hp1 - (unsigned)LC_NR, hp1);
-                };
-
-                // ---- ISSUE(t): fetch the list of step t into the ring / scratch rows.  Whole instructions only: the list is padded to
-                // a multiple of 8 rows with the address of a row that is fetched anyway, and the rows of the padding land in the ring
-                // slots that the 8-row alignment of a step leaves unused ----
-                auto issue_rows = [&](int t) {
-                    const unsigned nr = inr, ns = ins, hp = ihp;
-                    unsigned v[8], vs[2];
+                    // 4. consecutive slots for everything that is fetched
+                    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(fetcher[0]), b1 = __builtin_amdgcn_ballot_w64(fetcher[1]);
+                    const unsigned c0 = (unsigned)__builtin_popcountll(b0), ntot = c0 + (unsigned)__builtin_popcountll(b1);
+                    const unsigned pos[2] = {lc_mbcnt(b0), c0 + lc_mbcnt(b1)};
+                    nr = live ? min(ntot, limit) : 0u;
+                    // pad the list to whole instructions with a row of this step (overwritten below where a real entry exists)
+                    *(l < 8 ? &list[(nr & ~7u) + l] : dummy) = q.id[0];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = list[8 * i + lrow];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) vs[i] = list[LC_LIST_SCR + 8 * i + lrow];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (8u * i < nr) {
-                            const unsigned rp0 = hp + 8u * i, rp = rp0 >= (unsigned)LC_NR ? rp0 - (unsigned)LC_NR : rp0;
-                            lc_dma16(volb, (v[i] << 7) + lg * 16u, lds0 + rp * 128u);
-                        }
+                    for (int j = 0; j < 2; ++j) {
+                        const bool ring = fetcher[j] && pos[j] < nr;
+                        const unsigned seq = H + pos[j];
+                        slot[j] = lc_sel(ring, seq & 255u, slot[j]);
+                        slow[j] = (fetcher[j] && !ring) ? 1u : 0u;
+                        *(ring ? &list[pos[j]] : dummy) = q.id[j];
+                        *(owner[j] ? tp[j] : dummy) = lc_sel(ring, q.idhi[j] | (seq & 0xffffu), ~0u);
                     }
-                    if (nr > 64) {
-                        for (unsigned i = 8; 8u * i < nr; ++i) {
-                            const unsigned rp0 = hp + 8u * i, rp = rp0 >= (unsigned)LC_NR ? rp0 - (unsigned)LC_NR : rp0;
-                            const unsigned idr = list[8 * i + lrow];
-                            lc_dma16(volb, (idr << 7) + lg * 16u, lds0 + rp * 128u);
-                        }
-                    }
+                    // 5. rows another lane fetches
+                    unsigned e3[2];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        if (8u * i < ns)
-                            lc_dma16(volb, (vs[i] << 7) + lg * 16u, lds0 + ((unsigned)LC_NR + ((unsigned)t & 1u) * (unsigned)LC_SCR + 8u * i) * 128u);
-                };
-
-                // iteration t: rows of step t have landed -> A(t) -> ISSUE(t + 1), MGMT(t + 2)
-                nrt_f3 S0r = load_shift(0), S1r = load_shift(min(1, len - 1));
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0r), "+v"(S1r) : : "memory");
-                mgmt(0, true, S0r);
-                issue_rows(0);
-                S0r = load_shift(min(2, len - 1));
-                mgmt(min(1, len - 1), 1 < len, S1r);
-                S1r = load_shift(min(3, len - 1));
-                for (int t = 0; t < len; t += 2) {
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0r), "+v"(S1r) : : "memory");
-                    lc_barrier();                                          // A(t)
-                    issue_rows(t + 1);
-                    mgmt(min(t + 2, len - 1), t + 2 < len, S0r);
-                    S0r = load_shift(min(t + 4, len - 1));
-                    if (t + 1 >= len) break;
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0r), "+v"(S1r) : : "memory");
-                    lc_barrier();                                          // A(t + 1)
-                    issue_rows(t + 2);
-                    mgmt(min(t + 3, len - 1), t + 3 < len, S1r);
-                    S1r = load_shift(min(t + 5, len - 1));
+                    for (int j = 0; j < 2; ++j) e3[j] = *tp[j];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const bool same = ((e3[j] ^ q.idhi[j]) >> 16) == 0u;        // the owner got a ring slot
+                        slot[j] = lc_sel(follower[j], e3[j] & 255u, slot[j]);
+                        slow[j] = lc_sel(follower[j] && !same, 1u, slow[j]);
+                    }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(S0r), "+v"(S1r) : : "memory");
+                // hand-off: dword 2 xc + yc = the lane's two rows as (row << 1 | slow) 16-bit fields; dwords 4..7 (wave 0) = weights,
+                // row of corner 0, flags
+                const unsigned hv = (((rbase + slot[0]) << 1) | slow[0]) | ((((rbase + slot[1]) << 1) | slow[1]) << 16);
+                *(unsigned *)(sm + q.hoff0) = hv;
+                *(unsigned *)(sm + q.hoff1) = hv;
+                if (P == 0)
+                    *(nrt_u4 *)(sm + LC_HAND + ((unsigned)t & 3u) * 1024u + mv * 32u + 16u) =
+                        (nrt_u4){__float_as_uint(q.w0x), __float_as_uint(q.w0y), __float_as_uint(q.w0z), q.id0flags};
+                if (l == 0) *(uint2 *)(sm + LC_CTL + (((unsigned)t & 1u) * 2u + P) * 8u) = make_uint2(nr, H & 255u);
+                H += nr;
+            };
+
+            unsigned long long dbg_[4] = {0, 0, 0, 0}, last_ = (DIAG == 2) ? __builtin_amdgcn_s_memtime() : 0ull;
+            if (DIAG != 1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ((nrt_u4 *)tab)[i * 64 + l] = (nrt_u4){~0u, ~0u, ~0u, ~0u};
             }
-            lc_barrier();                                                  // A(len): the blend of the last step is done
+            lc_barrier();                                            // P1
+            LcPrep qa, qb;
+            prep(0, qa); proto(0, len > 0, qa);
+            prep(1, qa); proto(1, 1 < len, qa);
+            lc_barrier();                                            // P2
+            prep(2, qa);
+            lc_barrier();                                            // P3
+            proto(2, 2 < len, qa);
+            prep(3, qa);                                             // (the locations of step 3 were staged before P1)
+            LC_T(3);
+            for (int t = 0; t < len; t += 2) {
+                lc_barrier();                                        // A(t)
+                LC_T(1);
+                proto(t + 3, t + 3 < len, qa);
+                prep(t + 4, qb);
+                LC_T(3);
+                if (t + 1 >= len) break;
+                lc_barrier();                                        // A(t + 1)
+                LC_T(1);
+                proto(t + 4, t + 4 < len, qb);
+                prep(t + 5, qa);
+                LC_T(3);
+            }
+            lc_barrier();                                            // A(len): the blend of the last step is done
+            if (DIAG == 2 && l == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd(&lc_dbg[P * 4 + i], dbg_[i]);
+            }
         } else {
-            // ================================ wave 1: blend ================================
+            // ================================ waves 2..5: fetches, and the blend of the plane's row y0 + (wv - 2) ================================
             const char *fixb = DICE ? a.fixed + (unsigned long long)b * a.out_bs : a.vol;
+            const char *locb = a.loc ? a.loc + (unsigned long long)b * a.loc_bs : a.vol;
             char *outb = STORE ? a.out + (unsigned long long)b * a.out_bs : nullptr;
-            const unsigned bvv = l >> 3, lg = l & 7;        // lane group bvv (voxel 8 s + bvv of the plane), channels 4 lg .. 4 lg + 3
+            const unsigned bw = wv - 2u;
+            const unsigned bvv = l >> 3, lg = l & 7;        // lane group bvv = voxel z0 + bvv; channels 4 lg .. 4 lg + 3
             const unsigned SYZ = (unsigned)a.S1 * (unsigned)a.S2;
             nrt_f2 stp_l = {0, 0}, stp_h = {0, 0}, stt_l = {0, 0}, stt_h = {0, 0}, spp_l = {0, 0}, spp_h = {0, 0};
             float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
-            if (len > 0) {
-                unsigned qyz[2];                                             // (y, z) part of the voxel index of the two sub-passes
+            const unsigned yy = bw, vox = yy * 8u + bvv;
+            const unsigned qyz = nrt_mad24((unsigned)min(y0 + (int)yy, a.O1 - 1), (unsigned)a.O2, (unsigned)min(z0 + (int)bvv, a.O2 - 1));
+            const unsigned OYZ = (unsigned)a.O1 * (unsigned)a.O2;
+            auto row_off = [&](int t) -> unsigned { return ((nrt_mad24((unsigned)min(x0 + t, a.O0 - 1), OYZ, qyz)) * 8u + lg) * 16u; };
+            auto load_fixed = [&](int t, nrt_f4 &F) -> unsigned { if (DICE) { F = lc_ld16(fixb, row_off(t)); return 1u; } return 0u; };
+            // locations of step t -> LDS (96 floats, voxel-major): two dword DMAs (wave 2)
+            auto issue_shift = [&](int t) -> unsigned {
+                if (MODE == NRT_LOC_LINSPACE || bw != 0) return 0u;
+                const unsigned xq = (unsigned)min(x0 + t, a.O0 - 1);
+                const unsigned dst = lds0 + LC_SHIFT + ((unsigned)t & 3u) * 384u;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const unsigned v = 8u * s + bvv;
-                    qyz[s] = nrt_mad24((unsigned)min(y0 + (int)(v >> 2), a.O1 - 1), (unsigned)a.O2, (unsigned)min(z0 + (int)(v & 3), a.O2 - 1));
+                for (int i = 0; i < 2; ++i) {
+                    const unsigned e = min(64u * i + l, 95u), ev = e / 3u, ec = e - 3u * ev;      // element -> voxel, component
+                    const int yq = min(y0 + (int)(ev >> 3), a.O1 - 1), zq = min(z0 + (int)(ev & 7), a.O2 - 1);
+                    const unsigned q = nrt_mad24(nrt_mad24(xq, (unsigned)a.O1, (unsigned)yq), (unsigned)a.O2, (unsigned)zq);
+                    if (i == 0 || l < 32) lc_dma4(locb, (nrt_times3(q) + ec) << 2, dst + 256u * i);
                 }
-                const unsigned OYZ = (unsigned)a.O1 * (unsigned)a.O2;
-                auto row_off = [&](int t, int s) -> unsigned { return ((nrt_mad24((unsigned)min(x0 + t, a.O0 - 1), OYZ, qyz[s])) * 8u + lg) * 16u; };
-                auto load_fixed = [&](int t, nrt_f4 (&F)[2]) {
-                    if (!DICE) return;
+                return 2u;
+            };
+            // ---- ISSUE(t): this wave's quarter of both fetch lists of step t into the rings.  Whole instructions only: the lists are
+            // padded to a multiple of 8 rows with the address of a row that is fetched anyway, and the rows of the padding land in the
+            // ring slots that the 8-row alignment of a step leaves unused.  Returns the number of instructions issued ----
+            auto issue_rows = [&](int t) -> unsigned {
+                unsigned n = 0;
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) F[s] = lc_ld16(fixb, row_off(t, s));
-                };
-                // BLEND(t): 8 lanes per voxel read the 8 corner rows from LDS and run the reference's op sequence
-                auto blend = [&](int t, const nrt_f4 (&F)[2]) {
+                for (unsigned P = 0; P < 2; ++P) {
+                    const unsigned lb = ((unsigned)t & 1u) * 2u + P;
+                    const uint2 ctl = *(const uint2 *)(sm + LC_CTL + lb * 8u);
+                    const unsigned nr = lc_uni(ctl.x), hp = lc_uni(ctl.y);
+                    const unsigned *list = (const unsigned *)(sm + LC_LIST + lb * 512u);
+                    unsigned v[4];
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const unsigned v = 8u * s + bvv;
-                        const unsigned char *hb = sm + LC_HAND + ((unsigned)t % 3u) * 512u + v * 32u;
-                        const nrt_u4 A = *(const nrt_u4 *)hb, Bw = *(const nrt_u4 *)(hb + 16);
-                        nrt_f4 R[8];
-                        unsigned slowm = 0;
+                    for (int i = 0; i < 4; ++i) v[i] = list[8 * (4 * i + bw) + bvv];
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const unsigned f = (c & 1) ? (A[c >> 1] >> 16) : (A[c >> 1] & 0xffffu);
-                            R[c] = *(const nrt_f4 *)(sm + (f & 0xfffeu) + lg * 16u);
-                            slowm |= (f & 1u) << c;
-                        }
-                        const unsigned pack = Bw[3];
-                        if (__builtin_amdgcn_ballot_w64(slowm != 0)) {        // rare: a corner row that found no place in LDS
-                            const unsigned id0 = pack & 0x3ffffffu;
-                            const unsigned dx = ((pack >> 26) & 1u) ? SYZ : 0u, dy = ((pack >> 27) & 1u) ? (unsigned)a.S2 : 0u, dz = (pack >> 28) & 1u;
-                            nrt_f4 G[8];
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) {
-                                const unsigned idc = id0 + ((c & 4) ? dx : 0u) + ((c & 2) ? dy : 0u) + ((c & 1) ? dz : 0u);
-                                G[c] = lc_ld16c(volb, (idc << 7) + lg * 16u);
-                            }
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3]), "+v"(G[4]), "+v"(G[5]), "+v"(G[6]), "+v"(G[7]) : : "memory");
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) R[c] = ((slowm >> c) & 1u) ? G[c] : R[c];
-                        }
-                        const bool valid = (pack >> 29) & 1u, oob = (pack >> 30) & 1u;
-                        const float w0x = __uint_as_float(Bw[0]), w0y = __uint_as_float(Bw[1]), w0z = __uint_as_float(Bw[2]);
-                        const float w1x = nrt_sub(1.0f, w0x), w1y = nrt_sub(1.0f, w0y), w1z = nrt_sub(1.0f, w0z);
-                        const nrt_f2 wy2 = {w0y, w1y}, wz2 = {w0z, w1z};
-                        const nrt_f2 wxy0 = (nrt_f2){w0x, w0x} * wy2, wxy1 = (nrt_f2){w1x, w1x} * wy2;
-                        nrt_f2 wt2[4];
-                        wt2[0] = (nrt_f2){wxy0[0], wxy0[0]} * wz2;
-                        wt2[1] = (nrt_f2){wxy0[1], wxy0[1]} * wz2;
-                        wt2[2] = (nrt_f2){wxy1[0], wxy1[0]} * wz2;
-                        wt2[3] = (nrt_f2){wxy1[1], wxy1[1]} * wz2;
-                        nrt_f2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const float wt = wt2[c >> 1][c & 1];
-                            const nrt_f2 w2 = {wt, wt};
-                            al = al + w2 * (nrt_f2){R[c][0], R[c][1]};
-                            ah = ah + w2 * (nrt_f2){R[c][2], R[c][3]};
-                        }
-                        nrt_f4 acc = {al[0], al[1], ah[0], ah[1]};
-                        if (FILL) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], oob, a.fill);
-                        }
-                        // a lane group past the volume's edge holds a copy of the edge voxel (same rows, same bits): its store rewrites
-                        // that voxel with the same value (the number of stores per step stays constant for the s_waitcnt below); only
-                        // the Dice sums must not count it twice
-                        if (STORE) __builtin_nontemporal_store(acc, (nrt_f4 *)(outb + (size_t)row_off(t, s)));
-                        if (DICE) {
-                            const nrt_f4 T = F[s];
-                            nrt_f2 pl = {acc[0], acc[1]}, ph = {acc[2], acc[3]}, tl = {T[0], T[1]}, th = {T[2], T[3]};
-                            if (a.minmax) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    mnt = fminf(mnt, T[c]); mxt = fmaxf(mxt, T[c]);
-                                    mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
-                                }
-                            }
-                            // a copy's t and p are zeroed: x + 0 * 0 = x exactly, no branch
-                            const nrt_f2 z2 = {0.0f, 0.0f};
-                            pl = valid ? pl : z2; ph = valid ? ph : z2; tl = valid ? tl : z2; th = valid ? th : z2;
-                            stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
-                            stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
-                            spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned first = 8u * (4u * i + bw);
+                        if (first < nr) {
+                            lc_dma16(volb, (v[i] << 7) + lg * 16u, lds0 + (P * (unsigned)LC_NR + ((hp + first) & 255u)) * 128u);
+                            ++n;
                         }
                     }
-                };
-                nrt_f4 F0[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, F1[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-                load_fixed(0, F0);
-                for (int t = 0; t < len; t += 2) {
-                    lc_barrier();                                          // A(t)
-                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(F0[0]), "+v"(F0[1]) : "n"(STORE ? 2 : 0) : "memory");
-                    load_fixed(min(t + 1, len - 1), F1);
-                    blend(t, F0);
-                    if (t + 1 >= len) break;
-                    lc_barrier();                                          // A(t + 1)
-                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(F1[0]), "+v"(F1[1]) : "n"(STORE ? 2 : 0) : "memory");
-                    load_fixed(min(t + 2, len - 1), F0);
-                    blend(t + 1, F1);
                 }
-                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                return n;
+            };
+            // BLEND(t): 8 lanes per voxel read the 8 corner rows from LDS and run the reference's op sequence
+            auto blend = [&](int t, const nrt_f4 &T) {
+                const unsigned char *hb = sm + LC_HAND + ((unsigned)t & 3u) * 1024u + vox * 32u;
+                const nrt_u4 A = *(const nrt_u4 *)hb, Bw = *(const nrt_u4 *)(hb + 16);
+                nrt_f4 R[8];
+                unsigned slowm = 0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    // corner c = 4 xc + 2 yc + zc: dword 2 xc + yc, half zc
+                    const unsigned f = (c & 1) ? (A[c >> 1] >> 16) : (A[c >> 1] & 0xffffu);
+                    R[c] = *(const nrt_f4 *)(sm + ((f & 0xfffeu) << 6) + lg * 16u);
+                    slowm |= (f & 1u) << c;
+                }
+                const unsigned pack = Bw[3];
+                if (__builtin_amdgcn_ballot_w64(slowm != 0)) {        // rare: a corner row that found no place in LDS
+                    if (DIAG == 2 && l == 0) atomicAdd(&lc_dbg[12], 1ull);
+                    const unsigned id0 = pack & 0x3ffffffu;
+                    const unsigned dx = ((pack >> 26) & 1u) ? SYZ : 0u, dy = ((pack >> 27) & 1u) ? (unsigned)a.S2 : 0u, dz = (pack >> 28) & 1u;
+                    nrt_f4 G[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const unsigned idc = id0 + ((c & 4) ? dx : 0u) + ((c & 2) ? dy : 0u) + ((c & 1) ? dz : 0u);
+                        G[c] = lc_ld16c(volb, (idc << 7) + lg * 16u);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(G[0]), "+v"(G[1]), "+v"(G[2]), "+v"(G[3]), "+v"(G[4]), "+v"(G[5]), "+v"(G[6]), "+v"(G[7]) : : "memory");
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) R[c] = ((slowm >> c) & 1u) ? G[c] : R[c];
+                }
+                const bool valid = (pack >> 29) & 1u, oob = (pack >> 30) & 1u;
+                const float w0x = __uint_as_float(Bw[0]), w0y = __uint_as_float(Bw[1]), w0z = __uint_as_float(Bw[2]);
+                const float w1x = nrt_sub(1.0f, w0x), w1y = nrt_sub(1.0f, w0y), w1z = nrt_sub(1.0f, w0z);
+                const nrt_f2 wy2 = {w0y, w1y}, wz2 = {w0z, w1z};
+                const nrt_f2 wxy0 = (nrt_f2){w0x, w0x} * wy2, wxy1 = (nrt_f2){w1x, w1x} * wy2;
+                nrt_f2 wt2[4];
+                wt2[0] = (nrt_f2){wxy0[0], wxy0[0]} * wz2;
+                wt2[1] = (nrt_f2){wxy0[1], wxy0[1]} * wz2;
+                wt2[2] = (nrt_f2){wxy1[0], wxy1[0]} * wz2;
+                wt2[3] = (nrt_f2){wxy1[1], wxy1[1]} * wz2;
+                nrt_f2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float wt = wt2[c >> 1][c & 1];
+                    const nrt_f2 w2 = {wt, wt};
+                    al = al + w2 * (nrt_f2){R[c][0], R[c][1]};
+                    ah = ah + w2 * (nrt_f2){R[c][2], R[c][3]};
+                }
+                nrt_f4 acc = {al[0], al[1], ah[0], ah[1]};
+                if (FILL) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], oob, a.fill);
+                }
+                // a lane group past the volume's edge holds a copy of the edge voxel (same rows, same bits): its store rewrites
+                // that voxel with the same value (the number of stores per step stays constant for the s_waitcnt below); only
+                // the Dice sums must not count it twice
+                if (STORE) __builtin_nontemporal_store(acc, (nrt_f4 *)(outb + (size_t)row_off(t)));
+                if (DICE) {
+                    nrt_f2 pl = {acc[0], acc[1]}, ph = {acc[2], acc[3]}, tl = {T[0], T[1]}, th = {T[2], T[3]};
+                    if (a.strict & 2) { tl = (nrt_f2){1.0f, 1.0f}; th = tl; }      // diagnostic: count voxels
+                    if (a.minmax) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            mnt = fminf(mnt, T[c]); mxt = fmaxf(mxt, T[c]);
+                            mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
+                        }
+                    }
+                    // a copy's t and p are zeroed: x + 0 * 0 = x exactly, no branch
+                    const nrt_f2 z2 = {0.0f, 0.0f};
+                    pl = valid ? pl : z2; ph = valid ? ph : z2; tl = valid ? tl : z2; th = valid ? th : z2;
+                    stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
+                    stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
+                    spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
+                }
+            };
+
+            unsigned long long dbg_[4] = {0, 0, 0, 0}, last_ = (DIAG == 2) ? __builtin_amdgcn_s_memtime() : 0ull;
+            // start-up: locations of steps 0..3 (-> P1), then the fetches of steps 0 and 1 (after P2), locations of steps 4, 5
+            for (int s = 0; s < 4; ++s) if (s < len) (void)issue_shift(s);
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            lc_barrier();                                            // P1
+            lc_barrier();                                            // P2: the lists of steps 0 and 1 are written
+            // the fixed row is loaded two steps ahead (three registers in rotation).  This wave's loads retire in order: before A(t) it
+            // waits for everything but what it issued in iteration t - 1 (plus, with STORE, the row it stored in iteration t - 1)
+            nrt_f4 F0 = {0, 0, 0, 0}, F1 = {0, 0, 0, 0}, F2 = {0, 0, 0, 0};
+            unsigned kprev = 0;
+            if (len > 0) {
+                (void)load_fixed(0, F0);
+                (void)issue_rows(0);
+                if (4 < len) (void)issue_shift(4);
+                kprev = load_fixed(min(1, len - 1), F1);
+                kprev += issue_rows(1);
+                if (5 < len) kprev += issue_shift(5);
             }
+            lc_barrier();                                            // P3: ... and read
+            for (int t = 0; t < len; t += 3) {
+                // ---- step t ----
+                lc_wait_vm((a.strict & 1) ? 0u : kprev + (STORE && t >= 1 ? 1u : 0u));
+                LC_T(1);
+                lc_barrier();                                          // A(t)
+                LC_T(0);
+                asm volatile("" : "+v"(F0) : : "memory");
+                kprev = (t + 6 < len) ? issue_shift(t + 6) : 0u;
+                kprev += load_fixed(min(t + 2, len - 1), F2);
+                kprev += issue_rows(t + 2);
+                LC_T(3);
+                blend(t, F0);
+                LC_T(2);
+                if (t + 1 >= len) break;
+                // ---- step t + 1 ----
+                lc_wait_vm((a.strict & 1) ? 0u : kprev + (STORE ? 1u : 0u));
+                LC_T(1);
+                lc_barrier();                                          // A(t + 1)
+                LC_T(0);
+                asm volatile("" : "+v"(F1) : : "memory");
+                kprev = (t + 7 < len) ? issue_shift(t + 7) : 0u;
+                kprev += load_fixed(min(t + 3, len - 1), F0);
+                kprev += issue_rows(t + 3);
+                LC_T(3);
+                blend(t + 1, F1);
+                LC_T(2);
+                if (t + 2 >= len) break;
+                // ---- step t + 2 ----
+                lc_wait_vm((a.strict & 1) ? 0u : kprev + (STORE ? 1u : 0u));
+                LC_T(1);
+                lc_barrier();                                          // A(t + 2)
+                LC_T(0);
+                asm volatile("" : "+v"(F2) : : "memory");
+                kprev = (t + 8 < len) ? issue_shift(t + 8) : 0u;
+                kprev += load_fixed(min(t + 4, len - 1), F1);
+                kprev += issue_rows(t + 4);
+                LC_T(3);
+                blend(t + 2, F2);
+                LC_T(2);
+            }
+            // drain: the registers of loads that nobody consumes any more (the look-ahead of the last steps) must stay reserved until
+            // the data has landed, or a late load would overwrite whatever the compiler put there
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(F0), "+v"(F1), "+v"(F2) : : "memory");
             lc_barrier();                                                  // A(len)
+            if (DIAG == 2 && l == 0 && wv == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) atomicAdd(&lc_dbg[8 + i], dbg_[i]);
+            }
             if (DICE) {
                 nrt_f4 stp = {stp_l[0], stp_l[1], stp_h[0], stp_h[1]}, stt = {stt_l[0], stt_l[1], stt_h[0], stt_h[1]},
                        spp = {spp_l[0], spp_l[1], spp_h[0], spp_h[1]};
@@ -459,7 +529,7 @@ __global__ __launch_bounds__(128) void gather_lc(LcK a) {
                     stt[c] = wave_xor_add(stt[c], 8);
                     spp[c] = wave_xor_add(spp[c], 8);
                 }
-                const unsigned long long prow_g = (unsigned long long)b * per_batch + prow;
+                const unsigned long long prow_g = ((unsigned long long)b * per_batch + prow) * 4ull + bw;    // four partial rows per task
                 if (l < 8) {
                     float *fp = a.fpart + prow_g * 96ull;
                     *(nrt_f4 *)(fp + 4 * l) = stp;
@@ -485,30 +555,45 @@ struct LcGeom {
 
 void lc_geom(const int *O, int batch, int tune, LcGeom &g) {
     g.nTy = ((unsigned)O[1] + 3) / 4;
-    g.nTz = ((unsigned)O[2] + 3) / 4;
-    // the 128 waves an XCD runs together cover one region of 8 x 16 patches = 32 x 64 voxels
-    g.lry = 3; g.lrz = 4;
-    const unsigned RY = 1u << g.lry, RZ = 1u << g.lrz;
-    g.ncol = ((g.nTy + RY - 1) / RY) * ((g.nTz + RZ - 1) / RZ) * RY * RZ;
+    g.nTz = ((unsigned)O[2] + 7) / 8;
+    // the 64 workgroups an XCD runs together cover one or two regions of patches: the region shape with the least padding
+    // (padding patches are empty tasks that unbalance the persistent workgroups), larger regions first
+    static const int cand[][2] = {{3, 3}, {4, 2}, {2, 4}, {3, 2}, {2, 3}, {2, 2}, {3, 1}, {1, 3}, {2, 1}, {1, 2}, {1, 1}, {0, 0}};
+    unsigned best = ~0u;
+    for (const auto &c : cand) {
+        const unsigned RY = 1u << c[0], RZ = 1u << c[1];
+        const unsigned n = ((g.nTy + RY - 1) / RY) * ((g.nTz + RZ - 1) / RZ) * RY * RZ;
+        if (n < best) { best = n; g.lry = c[0]; g.lrz = c[1]; g.ncol = n; }
+    }
     unsigned nseg = (unsigned)tune & 0xffu;
     if (nseg == 0) {
-        // auto: every wave slot of the chip (1024) gets at least ~12 tasks, and a task is at most 64 planes
-        nseg = (12288u + g.ncol * (unsigned)batch - 1) / (g.ncol * (unsigned)batch);
-        const unsigned cap = ((unsigned)O[0] + 63) / 64;
+        // auto: every workgroup slot of the chip (512) gets at least ~12 tasks, and a task is at most 96 planes
+        nseg = (6144u + g.ncol * (unsigned)batch - 1) / (g.ncol * (unsigned)batch);
+        const unsigned cap = ((unsigned)O[0] + 95) / 96;
         if (nseg < cap) nseg = cap;
     }
-    if (nseg < ((unsigned)O[0] + 255) / 256) nseg = ((unsigned)O[0] + 255) / 256;   // the 16-bit allocation counter of a task
+    if (nseg < ((unsigned)O[0] + 383) / 384) nseg = ((unsigned)O[0] + 383) / 384;   // the 16-bit allocation counter of a task (<= 128 per step)
     if (nseg > (unsigned)O[0]) nseg = (unsigned)O[0];
     if (nseg < 1) nseg = 1;
     g.seglen = ((unsigned)O[0] + nseg - 1) / nseg;
     g.nseg = ((unsigned)O[0] + g.seglen - 1) / g.seglen;
 }
 
+template <int MODE, bool DICE, bool STORE, bool FILL, int DIAG>
+void lc_launch_one(const LcK &k, unsigned grid, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)gather_lc<MODE, DICE, STORE, FILL, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LC_LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gather_lc<MODE, DICE, STORE, FILL, DIAG>), dim3(grid), dim3(384), LC_LDS, st, k);
+}
+
 template <int MODE, bool FILL, int DIAG>
 void lc_launch_mode(const LcK &k, unsigned grid, bool dice, bool store, hipStream_t st) {
-    if (dice && store) hipLaunchKernelGGL((gather_lc<MODE, true, true, FILL, DIAG>), dim3(grid), dim3(128), 0, st, k);
-    else if (dice) hipLaunchKernelGGL((gather_lc<MODE, true, false, FILL, DIAG>), dim3(grid), dim3(128), 0, st, k);
-    else hipLaunchKernelGGL((gather_lc<MODE, false, true, FILL, DIAG>), dim3(grid), dim3(128), 0, st, k);
+    if (dice && store) lc_launch_one<MODE, true, true, FILL, DIAG>(k, grid, st);
+    else if (dice) lc_launch_one<MODE, true, false, FILL, DIAG>(k, grid, st);
+    else lc_launch_one<MODE, false, true, FILL, DIAG>(k, grid, st);
 }
 
 template <bool FILL>
@@ -535,7 +620,7 @@ bool nrt_lc_supported(const int *S, const int *O, int channels) {
 unsigned nrt_lc_rows(const int *O, int batch, int tune) {
     LcGeom g;
     lc_geom(O, batch, tune, g);
-    return g.ncol * g.nseg;
+    return g.ncol * g.nseg * 4u;             // four blend waves per task, one partial row each
 }
 
 int nrt_lc_launch(const LcCall &c, hipStream_t st) {
@@ -556,13 +641,25 @@ int nrt_lc_launch(const LcCall &c, hipStream_t st) {
     k.nyh = ((unsigned)c.S[1] + 15) / 16; k.nzh = ((unsigned)c.S[2] + 15) / 16;
     k.ntask = g.ncol * g.nseg * (unsigned)c.batch;
     k.minmax = c.minmax;
-    // persistent waves: 4 per CU (LDS), 256 CUs; fewer when there are fewer tasks
-    unsigned grid = 1024;
+    k.strict = (c.tune >> 10) & 3;
+    // persistent workgroups: 2 per CU (LDS), 256 CUs; fewer when there are fewer tasks
+    unsigned grid = 512;
     if (k.ntask < grid) grid = NRT_NXCD * ((k.ntask + NRT_NXCD - 1) / NRT_NXCD);
     const int diag = (c.tune >> 8) & 3;
     if (diag == 1) {                    // diagnostic build of the data path (no tag protocol; results are NOT the warp)
         if (c.mode != NRT_LOC_SHIFT || c.has_fill) return NRT_ERR_UNSUPPORTED;
         lc_launch_mode<NRT_LOC_SHIFT, false, 1>(k, grid, dice, store, st);
+    } else if (diag == 2) {             // product kernel + phase clocks (synchronous; prints to stderr)
+        if (c.mode != NRT_LOC_SHIFT || c.has_fill) return NRT_ERR_UNSUPPORTED;
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(lc_dbg), z, sizeof(z));
+        lc_launch_mode<NRT_LOC_SHIFT, false, 2>(k, grid, dice, store, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(lc_dbg), sizeof(z));
+        const double steps = (double)g.seglen * g.nseg * g.nTy * g.nTz * c.batch;      // workgroup steps in the launch
+        fprintf(stderr, "lc phases (s_memtime ticks per step): mgmt0 barrier %.0f mgmt %.0f | mgmt1 barrier %.0f mgmt %.0f | "
+                        "wave 2: barrier %.0f wait %.0f issue %.0f blend %.0f | slow sub-passes per step %.3f\n",
+                z[1] / steps, z[3] / steps, z[5] / steps, z[7] / steps, z[8] / steps, z[9] / steps, z[11] / steps, z[10] / steps, z[12] / steps);
     } else if (c.has_fill) lc_launch_fill<true>(k, grid, c.mode, dice, store, st);
     else lc_launch_fill<false>(k, grid, c.mode, dice, store, st);
     NRT_CHECK_LAUNCH();

@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import neurite_amd as ne
 from neurite_amd import synth
 
@@ -135,6 +135,17 @@ if __name__ == '__main__':
     rc = 0
     if 'check' in args:
         rc = check()
+    if 'phases' in args:
+        mov, fix, trf = synth.cfg2_batch(4, 160, 32, device=dev)
+        for _ in range(2):
+            ne.fused.warp_dice(mov, trf, fix, _tune=LC | (2 << 8))
+        st10 = ne.layers.SpatialTransformer()
+        st10._variant, st10._tune = 10, (2 << 8)
+        from neurite_amd import deferred
+        deferred.enabled = False
+        for _ in range(2):
+            st10([mov, trf])
+        torch.cuda.synchronize()
     if 'time' in args:
         timing()
         if '--b1' in args:
