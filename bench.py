@@ -318,24 +318,7 @@ def sweep(args, dev, mov, fix, trf):
                 log(json.dumps(r))
                 res.append(r)
             del tr0
-    # calibration: our own float4 copy kernel (plain / non-temporal, several grid sizes)
-    lib = ne._lib.lib()
     dst = torch.empty_like(mov)
-    for nt in (0, 1):
-        for blocks in (1024, 2048, 4096, 8192):
-            for _ in range(2):
-                lib.nrt_membench_copy_f32(ne._lib.ptr(mov), ne._lib.ptr(dst), mov.numel(), nt, blocks, ne._lib.stream_ptr(dev))
-            e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
-            e0.record()
-            for _ in range(10):
-                lib.nrt_membench_copy_f32(ne._lib.ptr(mov), ne._lib.ptr(dst), mov.numel(), nt, blocks, ne._lib.stream_ptr(dev))
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 10
-            r = {'kernel': 'membench_copy', 'nontemporal': nt, 'blocks': blocks, 'ms': round(ms, 4),
-                 'GBs': round(2 * mov.numel() * 4 / ms / 1e6, 1)}
-            log(json.dumps(r))
-            res.append(r)
     # reference point: plain device-to-device copy of the same volume (achievable HBM rate on this box)
     for _ in range(2):
         dst.copy_(mov)

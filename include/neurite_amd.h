@@ -452,16 +452,6 @@ int nrt_synth_noise_add_f32(const float *x, const float *noise, const float *sd,
 int nrt_synth_bg_clear_f32(const float *image, const float *labels, const float *flag, float *y, int batch, long long nvox,
                            int channels, void *stream);
 
-/* ------------------------------------------------------------------------------------------
- * Diagnostic: float4 streaming copy of n floats (n % 4 == 0) with `blocks` x 256 threads, plain or
- * non-temporal; calibrates the achievable mixed read/write HBM rate next to the kernels above.
- * ------------------------------------------------------------------------------------------ */
-int nrt_membench_copy_f32(const float *src, float *dst, long long n, int nontemporal, int blocks, void *stream);
-/* Diagnostic: L1-resident row gather with the lane pattern of the interpn kernels (8 lanes x 16 B per 128-byte row);
- * src holds blocks * rows * 32 floats, every block re-reads its own window `iters` x 8 times.  pattern 0 contiguous,
- * 1 scattered rows, 2 corner-like overlapping rows.  Calibrates the TA/L1 hit bandwidth next to the kernels. */
-int nrt_membench_l1_f32(const float *src, float *sink, int rows, int iters, int pattern, int blocks, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -21,8 +21,6 @@
 
 #include "dice_reduce.h"
 #include "interpn_core.h"
-#include "lc.h"
-#include "wdd.h"
 
 namespace {
 
@@ -346,19 +344,10 @@ void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int
 #undef NRT_FUSED
 }
 
-constexpr int FUSED_TUNE_DEDUP = 1 << 30;   // retired: the ds_cmpswap hash schedule measured 1.82 ms vs 1.19 ms (profiles/r02_lab); ignored
-constexpr int FUSED_TUNE_LC = 1 << 28;       // LDS row cache (gather_lc.hip); low bits = its own tune word
-constexpr int FUSED_TUNE_WDD = 1 << 29;      // wave-window de-duplicating gather (gather_wdd.hip); low bits = its own tune word
-
 }  // namespace
 
 extern "C" size_t nrt_warp_dice_workspace_bytes(const int *out_shape, int nlabels, int batch, int tune) {
     if (!out_shape || nlabels < 4 || nlabels % 4 || batch < 1) return 0;
-    if (tune > 0 && (tune & FUSED_TUNE_WDD) && nlabels == 32)
-        return fused_ws_bytes(nrt_wdd_rows(out_shape, batch, tune & (FUSED_TUNE_WDD - 1)), nlabels, batch);
-    if (tune > 0 && (tune & FUSED_TUNE_LC) && nlabels == 32)
-        return fused_ws_bytes(nrt_lc_rows(out_shape, batch, tune & (FUSED_TUNE_LC - 1)), nlabels, batch);
-    if (tune > 0) tune &= ~FUSED_TUNE_DEDUP;
     TileGeom tg;
     unsigned nblocks;
     fused_geom(out_shape, nlabels / 4, batch, tune, tg, nblocks);
@@ -392,57 +381,6 @@ int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed,
         (long long)out_shape[0] * out_shape[1] >= (1 << 24) || out_shape[2] >= (1 << 24)) return NRT_ERR_UNSUPPORTED;
     if ((((uintptr_t)moving | (uintptr_t)fixed | (uintptr_t)warped) & 15) != 0) return NRT_ERR_INVALID_ARG;
     if (a.nout == 0) return NRT_ERR_INVALID_ARG;
-    if (tune > 0 && !(tune & FUSED_TUNE_WDD) && (tune & FUSED_TUNE_LC)) {
-        if (!std::is_same<ST, float>::value) return NRT_ERR_UNSUPPORTED;
-        if (G != 8 || !nrt_lc_supported(vol_shape, out_shape, nlabels)) return NRT_ERR_UNSUPPORTED;
-        const int lt = tune & (FUSED_TUNE_LC - 1);
-        const unsigned nrows = nrt_lc_rows(out_shape, batch, lt);
-        if (!workspace || workspace_bytes < fused_ws_bytes(nrows, nlabels, batch)) return NRT_ERR_WORKSPACE;
-        DiceWs w;
-        const size_t rows = (size_t)batch * nrows;
-        char *p = (char *)workspace;
-        w.fpart = (float *)p; p += rows * 3 * nlabels * sizeof(float);
-        w.mpart = (float *)p; p += rows * 4 * sizeof(float);
-        p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-        w.gsum = (double *)p; p += (size_t)batch * ((nrows + RED_ROWS - 1) / RED_ROWS) * 3 * nlabels * sizeof(double);
-        w.gmm = (float *)p;
-        w.ipart = nullptr;
-        LcCall c;
-        c.vol = (const float *)moving; c.loc = loc; c.out = warped; c.fixed = (const float *)fixed; c.fpart = w.fpart; c.mpart = w.mpart; c.minmax = minmax != nullptr;
-        for (int d = 0; d < 3; ++d) { c.S[d] = a.S[d]; c.O[d] = a.O[d]; c.delta[d] = a.delta[d]; }
-        c.batch = batch; c.vol_bs = a.vol_bs; c.loc_bs = a.loc_bs; c.out_bs = a.out_bs;
-        c.mode = loc_mode; c.has_fill = a.has_fill; c.fill = fill_value; c.tune = lt;
-        hipStream_t st = nrt_stream(stream);
-        rc = nrt_lc_launch(c, st);
-        if (rc != NRT_OK) return rc;
-        return dice_finalize_soft(w, nrows, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
-    }
-    if (tune > 0 && (tune & FUSED_TUNE_WDD)) {
-        if (!std::is_same<ST, float>::value) return NRT_ERR_UNSUPPORTED;
-        if (G != 8 || !nrt_wdd_supported(vol_shape, out_shape, nlabels)) return NRT_ERR_UNSUPPORTED;
-        const int wt = tune & (FUSED_TUNE_WDD - 1);
-        const unsigned nrows = nrt_wdd_rows(out_shape, batch, wt);
-        if (!workspace || workspace_bytes < fused_ws_bytes(nrows, nlabels, batch)) return NRT_ERR_WORKSPACE;
-        DiceWs w;
-        const size_t rows = (size_t)batch * nrows;
-        char *p = (char *)workspace;
-        w.fpart = (float *)p; p += rows * 3 * nlabels * sizeof(float);
-        w.mpart = (float *)p; p += rows * 4 * sizeof(float);
-        p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-        w.gsum = (double *)p; p += (size_t)batch * ((nrows + RED_ROWS - 1) / RED_ROWS) * 3 * nlabels * sizeof(double);
-        w.gmm = (float *)p;
-        w.ipart = nullptr;
-        WddCall c;
-        c.vol = (const float *)moving; c.loc = loc; c.out = warped; c.fixed = (const float *)fixed; c.fpart = w.fpart; c.mpart = w.mpart; c.minmax = minmax != nullptr;
-        for (int d = 0; d < 3; ++d) { c.S[d] = a.S[d]; c.O[d] = a.O[d]; c.delta[d] = a.delta[d]; }
-        c.batch = batch; c.vol_bs = a.vol_bs; c.loc_bs = a.loc_bs; c.out_bs = a.out_bs;
-        c.mode = loc_mode; c.has_fill = a.has_fill; c.fill = fill_value; c.tune = wt;
-        hipStream_t st = nrt_stream(stream);
-        rc = nrt_wdd_launch(c, st);
-        if (rc != NRT_OK) return rc;
-        return dice_finalize_soft(w, nrows, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
-    }
-    if (tune > 0) tune &= ~FUSED_TUNE_DEDUP;
     TileGeom tg;
     unsigned nblocks;
     fused_geom(out_shape, G, batch, tune, tg, nblocks);

@@ -27,8 +27,6 @@
 
 #include "interpn_core.h"
 #include "lean.h"
-#include "lc.h"
-#include "wdd.h"
 
 namespace {
 
@@ -569,176 +567,6 @@ template <int C> struct LdsCfg {
     static constexpr int CAP = C == 1 ? 5120 : 10240;          // floats (20 / 40 KB)
 };
 
-template <int C, int MODE>
-__global__ __launch_bounds__(256) void interpn_lds(InterpArgs a, unsigned nTy, unsigned nTz, unsigned ntiles) {
-    constexpr int LTX = LdsCfg<C>::LTX;
-    constexpr int VPT = 1 << (LTX - 1);                        // (2^LTX x 8 x 16) / 256 voxels per thread
-    extern __shared__ __attribute__((aligned(16))) float box[];
-    __shared__ int red[4][6];
-    const unsigned tile = nrt_xcd_block(blockIdx.x, gridDim.x);
-    if (tile >= ntiles) return;
-    const int b = blockIdx.y;
-    const float *vol = (const float *)a.vol + (long long)b * a.vol_bs;
-    const float *locb = a.loc ? a.loc + (long long)b * a.loc_bs : nullptr;
-    float *out = (float *)a.out + (long long)b * a.out_bs;
-    const int x0 = (int)(tile / (nTy * nTz)) << LTX, y0 = (int)((tile / nTz) % nTy) * 8, z0 = (int)(tile % nTz) * 16;
-    const int tid = threadIdx.x;
-
-    int i0[VPT][3];
-    unsigned up = 0;                                           // bit (3k+d): upper corner index = lower + 1
-    float w0[VPT][3], w1[VPT][3];
-    unsigned q[VPT];
-    bool valid[VPT], oob[VPT];
-    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-        const int v = tid + 256 * k;
-        int qd[NRT_MAXD] = {x0 + (v >> 7), y0 + ((v >> 4) & 7), z0 + (v & 15)};
-        valid[k] = qd[0] < a.O[0] && qd[1] < a.O[1] && qd[2] < a.O[2];
-        qd[0] = min(qd[0], a.O[0] - 1); qd[1] = min(qd[1], a.O[1] - 1); qd[2] = min(qd[2], a.O[2] - 1);
-        q[k] = __umul24(__umul24((unsigned)qd[0], (unsigned)a.O[1]) + (unsigned)qd[1], (unsigned)a.O[2]) + (unsigned)qd[2];   // dims < 2^12 checked on the host
-        float p[NRT_MAXD];
-        load_loc<3, MODE>(a, locb, q[k], qd, p);
-        oob[k] = a.has_fill ? out_of_bounds<3>(a, p) : false;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            int i1;
-            corner_1d(p[d], a.S[d], i0[k][d], i1, w0[k][d], w1[k][d]);
-            up |= (unsigned)(i1 - i0[k][d]) << (3 * k + d);
-            lo[d] = min(lo[d], i0[k][d]);
-            hi[d] = max(hi[d], i1);
-        }
-    }
-    // ---- block-wide bounding box of the corner indices ------------------------------------------
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-        for (int off = 1; off < NRT_WAVE; off <<= 1) {
-            lo[d] = min(lo[d], __shfl_xor(lo[d], off, NRT_WAVE));
-            hi[d] = max(hi[d], __shfl_xor(hi[d], off, NRT_WAVE));
-        }
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { red[tid >> 6][d] = lo[d]; red[tid >> 6][3 + d] = hi[d]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        lo[d] = min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d]));
-        hi[d] = max(max(red[0][3 + d], red[1][3 + d]), max(red[2][3 + d], red[3][3 + d]));
-    }
-    const int ex = hi[0] - lo[0] + 1, ey = hi[1] - lo[1] + 1, ez = hi[2] - lo[2] + 1;
-    constexpr int CL = LdsCfg<C>::CL;
-    const int rowf = ez * C;                                   // floats per box row (contiguous in the source)
-    const int rowl = ez * CL;                                  // floats per box row in LDS
-    const bool staged = (long long)ex * ey * rowl <= LdsCfg<C>::CAP;
-    if (staged) {
-        // flat copy, 8 independent loads in flight per thread; (row, col) of element e by multiply-high division
-        // (exact for e < 2^16: the box holds at most LdsCfg<C>::CAP elements)
-        const int n = ex * ey * rowf;
-        const unsigned m_row = (unsigned)(0x100000000ull / (unsigned)rowf) + 1u;
-        const unsigned m_ey = (unsigned)(0x100000000ull / (unsigned)ey) + 1u;
-        const float *src0 = vol + (((long long)lo[0] * a.S[1] + lo[1]) * a.S[2] + lo[2]) * C;
-        const int planef = a.S[1] * a.S[2] * C, linef = a.S[2] * C;
-        for (int base = 0; base < n; base += 256 * 8) {
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = min(base + j * 256 + tid, n - 1);                 // clamped: every load unconditional
-                const unsigned r = rowf == 1 ? (unsigned)e : __umulhi((unsigned)e, m_row);
-                const unsigned bx = ey == 1 ? r : __umulhi(r, m_ey);
-                t[j] = src0[(int)bx * planef + (int)(r - bx * (unsigned)ey) * linef + (e - (int)r * rowf)];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = base + j * 256 + tid;
-                if (e < n) {
-                    if (CL == C) box[e] = t[j];
-                    else {                                                     // C = 3 rows are padded to 4 floats per voxel
-                        const unsigned r = __umulhi((unsigned)e, m_row), col = (unsigned)e - r * (unsigned)rowf;
-                        const unsigned vx = (col * 43691u) >> 17;              // col / 3 for col < 2^16
-                        box[r * (unsigned)rowl + vx * 4u + (col - vx * 3u)] = t[j];
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- gather + blend (interpn_generic's op order).  Index arithmetic is strength-reduced: one base offset per
-    // voxel (24-bit multiplies) plus three strides that are zero when the upper corner is clamped onto the lower one ----
-#pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-        const int ux = (int)((up >> (3 * k + 0)) & 1u), uy = (int)((up >> (3 * k + 1)) & 1u), uz = (int)((up >> (3 * k + 2)) & 1u);
-        // (w_x * w_y) * w_z : the x*y products are shared by the two z corners (same rounding sequence as prod_n)
-        const float wxy[4] = {nrt_mul(w0[k][0], w0[k][1]), nrt_mul(w0[k][0], w1[k][1]), nrt_mul(w1[k][0], w0[k][1]),
-                              nrt_mul(w1[k][0], w1[k][1])};
-        float acc[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = 0.0f;
-        if (staged) {
-            const int base = __mul24(__mul24(i0[k][0] - lo[0], ey) + (i0[k][1] - lo[1]), rowl) + (i0[k][2] - lo[2]) * CL;
-            const int sx = ux ? __mul24(ey, rowl) : 0, sy = uy ? rowl : 0, sz = uz ? CL : 0;
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const float *pv = box + base + ((corner & 4) ? sx : 0) + ((corner & 2) ? sy : 0) + ((corner & 1) ? sz : 0);
-                const float wt = nrt_mul(wxy[corner >> 1], (corner & 1) ? w1[k][2] : w0[k][2]);
-                float vv[CL];
-                if (CL == 4) { const nrt_f4 t4 = *(const nrt_f4 *)pv; vv[0] = t4[0]; vv[1] = t4[1]; vv[2] = t4[2]; vv[CL - 1] = t4[3]; }
-                else if (CL == 2) { const nrt_f2 t2 = *(const nrt_f2 *)pv; vv[0] = t2[0]; vv[CL - 1] = t2[1]; }
-                else vv[0] = pv[0];
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, vv[c]));
-            }
-        } else {
-            const float *pb = vol + (((long long)i0[k][0] * a.S[1] + i0[k][1]) * a.S[2] + i0[k][2]) * C;
-            const long long sx = ux ? (long long)a.S[1] * a.S[2] * C : 0, sy = uy ? (long long)a.S[2] * C : 0, sz = uz ? C : 0;
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const float *pv = pb + ((corner & 4) ? sx : 0) + ((corner & 2) ? sy : 0) + ((corner & 1) ? sz : 0);
-                const float wt = nrt_mul(wxy[corner >> 1], (corner & 1) ? w1[k][2] : w0[k][2]);
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, pv[c]));
-            }
-        }
-        if (valid[k]) {
-            float *po = out + (long long)q[k] * C;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float r = acc[c];
-                if (a.has_fill) r = apply_fill(r, oob[k], a.fill_f);
-                if (a.addend) r = nrt_add(a.addend[(long long)b * a.addend_bs + (long long)q[k] * C + c], r);
-                po[c] = r;
-            }
-        }
-    }
-}
-
-template <int C>
-void launch_lds_c(const InterpArgs &a, int batch, int mode, hipStream_t st) {
-    constexpr int TX = 1 << LdsCfg<C>::LTX;
-    const unsigned nTx = (a.O[0] + TX - 1) / TX, nTy = (a.O[1] + 7) / 8, nTz = (a.O[2] + 15) / 16;
-    const unsigned ntiles = nTx * nTy * nTz;
-    dim3 grid(nrt_xcd_grid(ntiles), batch), blk(256);
-    const unsigned dyn = LdsCfg<C>::CAP * sizeof(float);
-    switch (mode) {
-        case NRT_LOC_ABSOLUTE: hipLaunchKernelGGL((interpn_lds<C, NRT_LOC_ABSOLUTE>), grid, blk, dyn, st, a, nTy, nTz, ntiles); break;
-        case NRT_LOC_SHIFT: hipLaunchKernelGGL((interpn_lds<C, NRT_LOC_SHIFT>), grid, blk, dyn, st, a, nTy, nTz, ntiles); break;
-        default: hipLaunchKernelGGL((interpn_lds<C, NRT_LOC_LINSPACE>), grid, blk, dyn, st, a, nTy, nTz, ntiles); break;
-    }
-}
-
-bool lds_supported(const InterpArgs &a, int ndim) {
-    return ndim == 3 && a.C >= 1 && a.C <= 4 && a.nout >= 1024 && a.O[0] < 4096 && a.O[1] < 4096 && a.O[2] < 4096;
-}
-
-void launch_lds(const InterpArgs &a, int batch, int mode, hipStream_t st) {
-    switch (a.C) {
-        case 1: launch_lds_c<1>(a, batch, mode, st); break;
-        case 2: launch_lds_c<2>(a, batch, mode, st); break;
-        case 3: launch_lds_c<3>(a, batch, mode, st); break;
-        default: launch_lds_c<4>(a, batch, mode, st); break;
-    }
-}
-
 bool rows_supported(int channels) {
     if (channels % 4) return false;
     const int g = channels / 4;
@@ -851,15 +679,11 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
     for (int d = 0; d < ndim; ++d) vol_bytes *= (unsigned long long)vol_shape[d];
     const bool can_zrun = can_rows && channels == 32 && ndim == 3 && method == NRT_INTERP_LINEAR &&
                           vol_bytes < (1ull << 32);
-    const bool can_lds = method == NRT_INTERP_LINEAR && lds_supported(a, ndim);
-    const bool can_wdd = can_rows && method == NRT_INTERP_LINEAR && ndim == 3 && nrt_wdd_supported(a.S, a.O, channels) &&
-                         ((uintptr_t)loc & 3) == 0;
     const bool can_lean = (method == NRT_INTERP_LINEAR ? (loc_mode == NRT_LOC_LINSPACE || loc) : (loc_mode != NRT_LOC_LINSPACE && loc)) &&
                           nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride);
     if (variant == 0) {
         if (can_zrun) { variant = g_auto_c32_variant; if (tune == 0) tune = (variant >= 3) ? g_auto_c32_tune : 0; }
         else if (can_lean) variant = 8;
-        else if (can_lds) variant = 6;
         else if (can_rows && method == NRT_INTERP_LINEAR && vol_bytes < (1ull << 32) && a.nout >= 4096) {
             // 8 / 16 / 64 ... channels (feature maps): the pipelined 3-D tiles beat the row kernel at 4 x 160^3 -- C = 8 0.490 vs
             // 0.636 ms, C = 16 0.787 vs 0.907, C = 64 2.70 vs 3.09 (tools/midc_sweep.py, profiles/r02_smallc/midc_sweep.jsonl)
@@ -875,7 +699,6 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         }
         else variant = 1;
     }
-    if (variant == 6 && !can_lds) return NRT_ERR_UNSUPPORTED;
     if ((variant == 3 || variant == 4) && !can_zrun) return NRT_ERR_UNSUPPORTED;
     const bool can_tile = can_rows && method == NRT_INTERP_LINEAR && vol_bytes < (1ull << 32);
     if (variant == 5 && !can_tile) return NRT_ERR_UNSUPPORTED;
@@ -889,35 +712,9 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 3:
         case 4: launch_zrun(a, batch, loc_mode, variant, tune, st); break;
         case 5: launch_tile_any(a, batch, loc_mode, tune, st); break;
-        case 6: launch_lds(a, batch, loc_mode, st); break;
         case 8:
             if (!can_lean) return NRT_ERR_UNSUPPORTED;
             return nrt_lean_launch(&a, batch, loc_mode, method == NRT_INTERP_NEAREST ? 1 : 0, st);
-        case 9:
-            if (method != NRT_INTERP_LINEAR ||
-                !nrt_lds2_supported(a.S, a.O, channels, ndim, vol, loc, out, nullptr, vol_batch_stride, loc_batch_stride, 0, loc_mode))
-                return NRT_ERR_UNSUPPORTED;
-            return nrt_lds2_launch(&a, batch, loc_mode, st);
-        case 10: {       // LDS row cache (gather_lc.hip)
-            if (!(can_rows && method == NRT_INTERP_LINEAR && ndim == 3 && nrt_lc_supported(a.S, a.O, channels) && ((uintptr_t)loc & 3) == 0 &&
-                  vol_bytes < (1ull << 32)))
-                return NRT_ERR_UNSUPPORTED;
-            LcCall w;
-            w.vol = vol; w.loc = loc; w.out = out; w.fixed = nullptr; w.fpart = nullptr; w.mpart = nullptr; w.minmax = 0;
-            for (int d = 0; d < 3; ++d) { w.S[d] = a.S[d]; w.O[d] = a.O[d]; w.delta[d] = a.delta[d]; }
-            w.batch = batch; w.vol_bs = a.vol_bs; w.loc_bs = a.loc_bs; w.out_bs = a.out_bs;
-            w.mode = loc_mode; w.has_fill = a.has_fill; w.fill = fill_value; w.tune = tune;
-            return nrt_lc_launch(w, st);
-        }
-        case 7: {
-            if (!can_wdd) return NRT_ERR_UNSUPPORTED;
-            WddCall w;
-            w.vol = vol; w.loc = loc; w.out = out; w.fixed = nullptr; w.fpart = nullptr; w.mpart = nullptr; w.minmax = 0;
-            for (int d = 0; d < 3; ++d) { w.S[d] = a.S[d]; w.O[d] = a.O[d]; w.delta[d] = a.delta[d]; }
-            w.batch = batch; w.vol_bs = a.vol_bs; w.loc_bs = a.loc_bs; w.out_bs = a.out_bs;
-            w.mode = loc_mode; w.has_fill = a.has_fill; w.fill = fill_value; w.tune = tune;
-            return nrt_wdd_launch(w, st);
-        }
         default: return NRT_ERR_INVALID_ARG;
     }
     NRT_CHECK_LAUNCH();
@@ -940,8 +737,7 @@ extern "C" int nrt_interpn_add_f32(const float *vol, const float *loc, const flo
     if ((loc_mode == NRT_LOC_LINSPACE || loc) && (((uintptr_t)addend) & 15) == 0 && (addend_batch_stride * 4) % 16 == 0 &&
         nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride))
         return nrt_lean_launch(&a, batch, loc_mode, 0, stream);
-    if (lds_supported(a, ndim)) launch_lds(a, batch, loc_mode, nrt_stream(stream));
-    else launch_generic<NRT_INTERP_LINEAR, float>(a, ndim, batch, loc_mode, nrt_stream(stream));
+    launch_generic<NRT_INTERP_LINEAR, float>(a, ndim, batch, loc_mode, nrt_stream(stream));
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

@@ -9,7 +9,3 @@ bool nrt_lean_supported(const int *vol_shape, const int *out_shape, int channels
 // locations only)
 int nrt_lean_launch(const void *args, int batch, int mode, int method_kind, void *stream);
 
-// interpn_lds2.hip: LDS-staged box with coalesced 16-byte I/O (variant 9; linear, per-voxel locations)
-bool nrt_lds2_supported(const int *vol_shape, const int *out_shape, int channels, int ndim, const void *vol, const void *loc,
-                        const void *out, const void *addend, long long vol_bs, long long loc_bs, long long addend_bs, int loc_mode);
-int nrt_lds2_launch(const void *args, int batch, int mode, void *stream);

@@ -330,8 +330,7 @@ def test_fused_x_march_schedule_ragged(dev):
              xm | (3 << 16),                     # three x segments (36 = 3 x 12)
              xm | (5 << 16) | (2 << 24) | (1 << 27),     # five segments (ragged last), 4 x 2 regions
              3 | (3 << 4) | (3 << 8) | (1 << 14) | (1 << 24) | (3 << 27),        # 8 x 8 patches (two passes per plane), 2 x 8 regions
-             (1 << 29), (1 << 29) | 1, (1 << 29) | 2 | 4, (1 << 29) | (3 << 8), (1 << 29) | 5 | (2 << 8) | (1 << 16) | (1 << 19),   # wave-window gather
-             (1 << 29) | 64, (1 << 29) | 65 | (3 << 8), (1 << 29) | 67, (1 << 29) | 192, (1 << 29) | 193 | (2 << 8))                        # lane-per-voxel gather
+             )
     for tune in tunes:
         d, w = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=0.0, return_warped=True, _tune=tune)
         assert bits_equal(N(w), w_ref), tune

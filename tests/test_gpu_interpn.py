@@ -71,14 +71,7 @@ def _tile(lx, ly, lz, zo):
                                           (4, 13), (5, 0), (5, _tile(0, 0, 5, 0)), (5, _tile(1, 1, 3, 1)),
                                           (5, _tile(2, 3, 4, 1)), (5, _tile(3, 3, 3, 0)), (5, _tile(4, 4, 3, 1)),
                                           (5, _tile(0, 0, 0, 0)), (5, (1 << 13) | (7 << 16)), (5, (1 << 13) | (1 << 12)),
-                                          (5, (1 << 13) | (20 << 16)),
-                                          # 7 = wave-window de-duplicating gather: window shapes 4x4x4 / 4x2x8 / 2x4x8,
-                                          # 192- / 256-row buffers, x segments, patch regions
-                                          (7, 0), (7, 1), (7, 2), (7, 4), (7, 5), (7, 6), (7, 1 | (3 << 8)),
-                                          (7, (2 << 8) | (1 << 16) | (2 << 19)),
-                                          # bit 6: lane-per-voxel gather without the row buffer (gather_lpv), four window shapes
-                                          (7, 64), (7, 65), (7, 66), (7, 67), (7, 64 | (3 << 8)),
-                                          (7, 192), (7, 193 | (2 << 8))])            # bit 7: four waves share a window
+                                          (5, (1 << 13) | (20 << 16))])
 def test_c32_every_kernel_variant(dev, variant, tune):
     """All kernels that can serve C = 32 must agree bit-for-bit with the oracle, for sizes that are not
     multiples of the 4x8 patch / z-chunk / 8-voxel shift batch, smooth and rough fields, all loc modes."""
@@ -135,108 +128,6 @@ def test_lds_staged_kernel(dev, C):
         got = N(ne.layers.Resize(z)(G(vb, dev)))
         for b in range(B):
             assert bits_equal(got[b], npo.resize(vb[b], z)), ('resize', z)
-
-
-@pytest.mark.parametrize('C', [1, 2, 3, 4])
-@pytest.mark.parametrize('S', [(12, 10, 40), (19, 13, 37), (9, 16, 4), (5, 7, 1)])
-def test_lean_kernel(dev, C, S):
-    """variant 8 (csrc/interpn_lean.hip: several consecutive-z voxels per lane, no staging) == generic kernel == oracle, bit
-    for bit: smooth / rough / edge-valued fields, fill, absolute / shift / linspace locations, z extents that are and are not
-    multiples of the voxels-per-lane count, addend epilogue, non-finite locations stay memory-safe."""
-    rng = np.random.default_rng(80 + C + S[2])
-    vol = rng.standard_normal(S + (C,)).astype(F)
-    fields = {
-        'smooth': N(synth.smooth_displacement(5, 40, 2.0, coarse=6))[:S[0], :S[1], :S[2]].copy(),
-        'rough': rng.uniform(-30, 30, S + (3,)).astype(F),
-        'edge': rng.choice(np.array([-3, -1, -0.5, 0, 0.5, 1, 2, 7.5], F), S + (3,)).astype(F),
-    }
-    lib = ne._lib.lib()
-    for kind, shift in fields.items():
-        for fill in (None, 0.25):
-            want = co.interpn(vol, shift, 'linear', fill, loc_mode=1)
-            st = ne.layers.SpatialTransformer(fill_value=fill)
-            st._variant = 8
-            got = N(st([G(vol[None], dev), G(shift[None], dev)]))[0]
-            assert bits_equal(got, want), (kind, fill)
-            got = N(ne.utils.interpn(G(vol, dev), G(ijk(S) + shift, dev), fill_value=fill, _variant=8))
-            assert bits_equal(got, co.interpn(vol, ijk(S) + shift, 'linear', fill)), (kind, fill, 'abs')
-    # nearest interpolation through the same tile kernel: float32 data, and int32 label maps (fill arithmetic in int32)
-    for kind in ('smooth', 'edge'):
-        for fill in (None, 2.0):
-            st = ne.layers.SpatialTransformer(interp_method='nearest', fill_value=fill)
-            st._variant = 8
-            got = N(st([G(vol[None], dev), G(fields[kind][None], dev)]))[0]
-            assert bits_equal(got, co.interpn(vol, fields[kind], 'nearest', fill, loc_mode=1)), ('nearest', kind, fill)
-            lab = rng.integers(0, 50, S + (C,)).astype(np.int32)
-            goti = N(ne.utils.interpn(G(lab, dev), G(ijk(S) + fields[kind], dev), 'nearest', None if fill is None else int(fill)))
-            assert goti.dtype == np.int32
-            assert np.array_equal(goti, npo.interpn(lab, ijk(S) + fields[kind], 'nearest', None if fill is None else int(fill)))
-    # batched, other output grid; auto selection takes the same kernel for these shapes
-    B, So = 3, (7, 9, 8)
-    vb = rng.standard_normal((B,) + S + (C,)).astype(F)
-    tb = rng.normal(0, 2, (B,) + So + (3,)).astype(F)
-    st = ne.layers.SpatialTransformer()
-    st._variant = 8
-    assert bits_equal(N(st([G(vb, dev), G(tb, dev)])), npo.spatial_transformer(vb, tb))
-    assert bits_equal(N(ne.layers.SpatialTransformer()([G(vb, dev), G(tb, dev)])), npo.spatial_transformer(vb, tb))
-    if S[2] > 1:
-        for z in (2, 0.5):
-            got = N(ne.layers.Resize(z)(G(vb, dev)))
-            for b in range(B):
-                assert bits_equal(got[b], npo.resize(vb[b], z)), ('resize', z)
-    # NaN / Inf locations: any value, no fault
-    bad = fields['smooth'].copy()
-    bad[::3, ::2, ::2, 0] = np.nan
-    bad[1::3, ::2, ::2, 1] = np.inf
-    bad[2::3, 1::2, ::2, 2] = -np.inf
-    st = ne.layers.SpatialTransformer(fill_value=0.0)
-    st._variant = 8
-    out = st([G(vol[None], dev), G(bad[None], dev)])
-    torch.cuda.synchronize()
-    assert out.shape == (1,) + S + (C,)
-
-
-@pytest.mark.parametrize('C', [1, 2, 3, 4])
-@pytest.mark.parametrize('S', [(12, 10, 32), (19, 13, 48), (4, 4, 16), (5, 7, 16)])
-def test_lds2_kernel(dev, C, S):
-    """variant 9 (csrc/interpn_lds2.hip: coalesced 16-byte location loads, source box staged in LDS by 16-byte buffer loads,
-    results stored through LDS) == generic kernel == oracle, bit for bit: smooth fields (staged), rough fields (box too large ->
-    global corners), edge values, fill, absolute / shift locations, ragged x / y tile edges, source volumes of another shape"""
-    rng = np.random.default_rng(90 + C + S[0])
-    vol = rng.standard_normal(S + (C,)).astype(F)
-    fields = {
-        'smooth': N(synth.smooth_displacement(5, 48, 2.0, coarse=6))[:S[0], :S[1], :S[2]].copy(),
-        'rough': rng.uniform(-30, 30, S + (3,)).astype(F),
-        'edge': rng.choice(np.array([-3, -1, -0.5, 0, 0.5, 1, 2, 7.5], F), S + (3,)).astype(F),
-    }
-    for kind, shift in fields.items():
-        for fill in (None, 0.25):
-            st = ne.layers.SpatialTransformer(fill_value=fill)
-            st._variant = 9
-            got = N(st([G(vol[None], dev), G(shift[None], dev)]))[0]
-            assert bits_equal(got, co.interpn(vol, shift, 'linear', fill, loc_mode=1)), (kind, fill)
-            got = N(ne.utils.interpn(G(vol, dev), G(ijk(S) + shift, dev), fill_value=fill, _variant=9))
-            assert bits_equal(got, co.interpn(vol, ijk(S) + shift, 'linear', fill)), (kind, fill, 'abs')
-    # batched; the source volume has another shape than the output grid (and is smaller than a tile's box in z)
-    B, Sv = 3, (7, 9, 8)
-    vb = rng.standard_normal((B,) + Sv + (C,)).astype(F)
-    tb = rng.normal(0, 2, (B,) + S + (3,)).astype(F)
-    st = ne.layers.SpatialTransformer()
-    st._variant = 9
-    assert bits_equal(N(st([G(vb, dev), G(tb, dev)])), npo.spatial_transformer(vb, tb))
-    # NaN / Inf locations: any value, no fault
-    bad = fields['smooth'].copy()
-    bad[::3, ::2, ::2, 0] = np.nan
-    bad[1::3, ::2, ::2, 1] = np.inf
-    bad[2::3, 1::2, ::2, 2] = -np.inf
-    st = ne.layers.SpatialTransformer(fill_value=0.0)
-    st._variant = 9
-    out = st([G(vol[None], dev), G(bad[None], dev)])
-    torch.cuda.synchronize()
-    assert out.shape == (1,) + S + (C,)
-    # z extents that are not multiples of 16 are refused by this variant (the auto-selection takes another kernel)
-    with pytest.raises(ne.errors.NeuriteAmdError):
-        ne.utils.interpn(G(vol[:, :, :9].copy(), dev), G(ijk(S)[:, :, :9].copy(), dev), _variant=9)
 
 
 @pytest.mark.parametrize('C', [12, 20])

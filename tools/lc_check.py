@@ -1,4 +1,4 @@
-"""Correctness and timing of the LDS-row-cache gather (csrc/gather_lc.hip) against the register kernels (GPU session tool).
+"""Correctness and timing of the LDS-row-cache gather (tools/lab/csrc/gather_lc.hip, a lab kernel: tools/lab/README.md) against the register kernels (GPU session tool).
 
     python tools/lc_check.py [check] [time] [--sizes small|full]
 check: bit-exact warped volume + Dice vs the default kernels over shapes / fields / fill / location modes.
@@ -15,6 +15,8 @@ import torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import neurite_amd as ne
 from neurite_amd import synth
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), 'lab'))
+import lab
 
 LC = 1 << 28
 dev = torch.device('cuda:0')
@@ -46,8 +48,8 @@ def check():
                 trf = trf.contiguous()
                 d0, w0, s0 = ne.fused.warp_dice(mov, trf, fix, fill_value=fill, return_warped=True, return_sums=True)
                 for tune in (LC, LC | 1, LC | 3):
-                    d1, w1, s1 = ne.fused.warp_dice(mov, trf, fix, fill_value=fill, return_warped=True, return_sums=True, _tune=tune)
-                    d2, s2 = ne.fused.warp_dice(mov, trf, fix, fill_value=fill, return_sums=True, _tune=tune)
+                    d1, w1, s1 = lab.lc_warp_dice(mov, trf, fix, fill_value=fill, return_warped=True, return_sums=True, tune=tune & 0xfffffff)
+                    d2, s2 = lab.lc_warp_dice(mov, trf, fix, fill_value=fill, return_sums=True, tune=tune & 0xfffffff)
                     torch.cuda.synchronize()
                     okw = bits_equal(w0, w1)
                     oks = torch.allclose(s0, s1, rtol=2e-5, atol=1e-4) and torch.allclose(s0, s2, rtol=2e-5, atol=1e-4)
@@ -61,7 +63,7 @@ def check():
                     grid = torch.stack(torch.meshgrid(*[torch.arange(n, device=dev, dtype=torch.float32) for n in S], indexing='ij'), -1)
                     loc = grid + trf[b]
                     r0 = ne.utils.interpn(mov[b], loc, fill_value=fill)
-                    r1 = ne.utils.interpn(mov[b], loc, fill_value=fill, _variant=10)
+                    r1 = lab.lc_interpn(mov[b:b + 1], loc[None], S, 0, fill_value=fill)[0]
                     if not bits_equal(r0, r1):
                         bad += 1
                         print('FAIL interpn', S, kind, fill, int((r0.view(torch.int32) != r1.view(torch.int32)).sum()), flush=True)
@@ -73,7 +75,7 @@ def check():
             from neurite_amd import utils as U, _lib as L
             new_shape = U._new_shape(list(S), [z] * 3)
             r0 = U._interp_op(vol, None, new_shape, L.LOC_LINSPACE, U._METHODS['linear'], None, batched=True)
-            r1 = U._interp_op(vol, None, new_shape, L.LOC_LINSPACE, U._METHODS['linear'], None, batched=True, variant=10)
+            r1 = lab.lc_interpn(vol, None, new_shape, 2)
             if not bits_equal(r0, r1):
                 bad += 1
                 print('FAIL resize', S, z, flush=True)
@@ -107,16 +109,14 @@ def timing(batch=4, size=160):
 
     rec('fused_default', timeit(lambda: ne.fused.warp_dice(mov, trf, fix)), 268)
     for nseg in (0, 3, 5, 8, 10):
-        rec('fused_lc_nseg%d' % nseg, timeit(lambda: ne.fused.warp_dice(mov, trf, fix, _tune=LC | nseg)), 268)
-    rec('fused_lc_diag1', timeit(lambda: ne.fused.warp_dice(mov, trf, fix, _tune=LC | (1 << 8))), 268)
+        rec('fused_lc_nseg%d' % nseg, timeit(lambda: lab.lc_warp_dice(mov, trf, fix, tune=nseg)), 268)
+    rec('fused_lc_diag1_data_path_only', timeit(lambda: lab.lc_warp_dice(mov, trf, fix, tune=1 << 8)), 268)
     st = ne.layers.SpatialTransformer()
     from neurite_amd import deferred
     old = deferred.enabled
     deferred.enabled = False
     rec('interpn_default', timeit(lambda: st([mov, trf])), 268)
-    st10 = ne.layers.SpatialTransformer()
-    st10._variant = 10
-    rec('interpn_lc', timeit(lambda: st10([mov, trf])), 268)
+    rec('interpn_lc', timeit(lambda: lab.lc_interpn(mov, trf, mov.shape[1:-1], 1)), 268)
     stn = ne.layers.SpatialTransformer(interp_method='nearest')
     rec('nearest_warp', timeit(lambda: stn([mov, trf])), 268)
     deferred.enabled = old
@@ -126,8 +126,45 @@ def timing(batch=4, size=160):
     for sig in (1.0, 0.3):
         trf2 = torch.stack([synth.smooth_displacement(50 + b, size, sigma=sig, device=dev) for b in range(batch)])
         rec('fused_default_sigma%g' % sig, timeit(lambda: ne.fused.warp_dice(mov, trf2, fix)), 268)
-        rec('fused_lc_sigma%g' % sig, timeit(lambda: ne.fused.warp_dice(mov, trf2, fix, _tune=LC)), 268)
+        rec('fused_lc_sigma%g' % sig, timeit(lambda: lab.lc_warp_dice(mov, trf2, fix)), 268)
     return rows
+
+
+def probes(batch=4, size=160):
+    """The roofs VERDICT r2 asked to reconcile: tuned float4 streams (read-only, copy), the nearest warp of the bench tensor,
+    the fused kernel and the data path of the LDS-row-cache kernel."""
+    from neurite_amd import _lib, deferred
+    mov, fix, trf = synth.cfg2_batch(batch, size, 32, device=dev)
+    nvox = batch * size ** 3
+    L = lab.lib()
+    dst = torch.empty_like(mov)
+    n = mov.numel()
+    gb = n * 4 / 1e9
+
+    def rec(name, ms, nbytes):
+        print(json.dumps({'probe': name, 'ms': round(ms, 4), 'TBs': round(nbytes / ms / 1e9, 3), 'frac_of_8TBs': round(nbytes / ms / 1e9 / 8, 4)}), flush=True)
+
+    for blocks in (2048, 4096, 8192, 16384):
+        for unroll in (1, 2, 4, 8):
+            for nt in (0, 1):
+                ms = timeit(lambda: L.nrt_lab_stream_f32(_lib.ptr(mov), _lib.ptr(dst), n, 0, unroll, nt, blocks, _lib.stream_ptr(dev)))
+                rec('copy blocks=%d unroll=%d nt=%d' % (blocks, unroll, nt), ms, 2 * gb * 1e9)
+    for blocks in (2048, 4096, 8192, 16384):
+        for unroll in (2, 4, 8):
+            ms = timeit(lambda: L.nrt_lab_stream_f32(_lib.ptr(mov), _lib.ptr(dst), n, 1, unroll, 1, blocks, _lib.stream_ptr(dev)))
+            rec('read blocks=%d unroll=%d' % (blocks, unroll), ms, gb * 1e9)
+    rec('torch copy_', timeit(lambda: dst.copy_(mov)), 2 * gb * 1e9)
+    old = deferred.enabled
+    deferred.enabled = False
+    stn = ne.layers.SpatialTransformer(interp_method='nearest')
+    rec('nearest warp of [4,160^3,32] (268 B/voxel)', timeit(lambda: stn([mov, trf])), nvox * 268)
+    deferred.enabled = old
+    rec('fused kernel (product)', timeit(lambda: ne.fused.warp_dice(mov, trf, fix)), nvox * 268)
+    trf0 = torch.zeros_like(trf)
+    rec('fused kernel (product), zero displacement', timeit(lambda: ne.fused.warp_dice(mov, trf0, fix)), nvox * 268)
+    rec('LDS-row-cache kernel, data path only (no tag protocol; tools/lab)', timeit(lambda: lab.lc_warp_dice(mov, trf, fix, tune=1 << 8)), nvox * 268)
+    dice = ne.metrics.Dice(check_input_limits=False)
+    rec('soft Dice of two [4,160^3,32] maps (256 B/voxel)', timeit(lambda: dice.dice(fix, mov)), nvox * 256)
 
 
 if __name__ == '__main__':
@@ -138,14 +175,12 @@ if __name__ == '__main__':
     if 'phases' in args:
         mov, fix, trf = synth.cfg2_batch(4, 160, 32, device=dev)
         for _ in range(2):
-            ne.fused.warp_dice(mov, trf, fix, _tune=LC | (2 << 8))
-        st10 = ne.layers.SpatialTransformer()
-        st10._variant, st10._tune = 10, (2 << 8)
-        from neurite_amd import deferred
-        deferred.enabled = False
+            lab.lc_warp_dice(mov, trf, fix, tune=2 << 8)
         for _ in range(2):
-            st10([mov, trf])
+            lab.lc_interpn(mov, trf, mov.shape[1:-1], 1, tune=2 << 8)
         torch.cuda.synchronize()
+    if 'probes' in args:
+        probes()
     if 'time' in args:
         timing()
         if '--b1' in args:
