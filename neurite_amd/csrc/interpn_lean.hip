@@ -470,7 +470,9 @@ bool nrt_lean_supported(const int *vol_shape, const int *out_shape, int channels
         vbytes *= (unsigned long long)vol_shape[d];
     }
     if (vbytes >= (1ull << 32)) return false;
-    if ((unsigned long long)out_shape[1] * out_shape[2] * out_shape[2] >= (1ull << 32)) return false;
+    // 32-bit byte offsets into the location field (12 B per output voxel) and into the output / addend rows (4 C B per voxel)
+    const unsigned long long nout = (unsigned long long)out_shape[0] * out_shape[1] * out_shape[2];
+    if (nout * 12ull >= (1ull << 32) || nout * 4ull * (unsigned long long)channels >= (1ull << 32)) return false;
     // vector accesses: C floats per source voxel, VPL * C per output group, VPL * 3 per location group.  Bases must be
     // 16-byte aligned; the batch strides keep the alignment the channel count needs (the per-lane vector widths over z are
     // chosen at launch from the z extent and the location stride)

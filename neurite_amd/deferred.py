@@ -14,6 +14,14 @@ consumer simply triggers the stand-alone interpn kernel, exactly as an eager cal
 Deferral happens only for: linear interpolation, float32 3-D volumes with 4 * 2^k labels, dense displacement fields, no
 gradient being recorded (training graphs stay eager: autograd needs the real tensor), and `deferred.enabled` (env
 NRT_DEFER_WARP, default on).  The values are bit-identical to the eager path whenever they are materialised.
+
+Immutability.  TensorFlow tensors are immutable, so in the reference the value of `warped` is fixed when SpatialTransformer
+returns.  A deferred warp reads its inputs when it is first used, and PyTorch lets a program overwrite them in between
+(`buf.copy_(next_batch)`, `moving.mul_(mask)`).  The DeferredWarp therefore records the version counters (and addresses) of the
+volume and the transform it aliases and checks them when it is evaluated -- by `materialize()` or by the fused Dice kernel: if
+either was modified in place, the result the eager path would have produced no longer exists and a `DeferredWarpError` is raised
+(loudly, at the use site, naming the remedy: keep the inputs unchanged until the result is used, pass clones, or set
+`neurite_amd.deferred.enabled = False`).  Inputs that had to be converted (dtype, layout) are private copies and cannot change.
 """
 
 import os
@@ -24,6 +32,14 @@ from torch.utils._pytree import tree_map
 enabled = os.environ.get('NRT_DEFER_WARP', '1') != '0'
 
 
+class DeferredWarpError(RuntimeError):
+    """an input of a deferred SpatialTransformer call was modified in place before the result was used"""
+
+
+def _stamp(t):
+    return (t._version, t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+
+
 class DeferredWarp(torch.Tensor):
     @staticmethod
     def __new__(cls, shape, dtype, device, thunk, sources):
@@ -31,6 +47,7 @@ class DeferredWarp(torch.Tensor):
         t._thunk = thunk
         t._value = None
         t._sources = sources            # dict(vol, shift, single_transform, fill_value): what the fused kernel needs
+        t._stamps = tuple((k, sources[k], _stamp(sources[k])) for k in ('vol', 'shift') if sources and sources.get(k) is not None)
         return t
 
     # ---- evaluation ------------------------------------------------------------------------------------------------
@@ -38,11 +55,23 @@ class DeferredWarp(torch.Tensor):
     def pending(self):
         return self._value is None
 
+    def check_sources(self):
+        """raise DeferredWarpError if the volume or the transform changed since SpatialTransformer was called"""
+        for name, t, stamp in self._stamps or ():
+            if _stamp(t) != stamp:
+                raise DeferredWarpError(
+                    'the %s passed to SpatialTransformer was modified in place before the (deferred) warped volume was used: the '
+                    'warp of the ORIGINAL data can no longer be computed.  Keep the inputs unchanged until the result has been used, '
+                    'pass clones, or set neurite_amd.deferred.enabled = False (env NRT_DEFER_WARP=0) for eager evaluation'
+                    % ('volume' if name == 'vol' else 'transform'))
+
     def materialize(self):
         if self._value is None:
+            self.check_sources()
             self._value = self._thunk()
             self._thunk = None
             self._sources = None
+            self._stamps = None
         return self._value
 
     @classmethod

@@ -79,12 +79,13 @@ def all_reduce_mean_dice(local_dice, weights=None, group=None, async_op=False):
     """
     d = local_dice
     _, w = _world(group)
-    if d.device.type == 'cuda':
+    if d.device.type == 'cuda' and d.dim() == 2 and not (torch.is_grad_enabled() and d.requires_grad):
         # one launch writes [sum of dice * weights, number of entries] (csrc/dice.hip: dice_mean_pair) -- the buffer the
         # collective reduces; no sum / cat / scale launches around a ~1 ms step
         buf = _mean_pair(d, weights)
     else:
-        # host tensors (the gloo tests of the collective logic): plain torch arithmetic
+        # host tensors (the gloo tests of the collective logic), inputs of another rank than [B, L], and values a gradient is being
+        # recorded for (the kernel's output carries no autograd graph): plain torch arithmetic
         if weights is not None:
             d = d * torch.as_tensor(weights, dtype=d.dtype, device=d.device)
         buf = torch.cat([d.sum(dtype=torch.float32).reshape(1), _count_tensor(d.numel(), d.device)])

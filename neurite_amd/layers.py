@@ -676,7 +676,9 @@ def _lc3d_plan(ins, cin, ksize, strides, padding, outs, cout, implementation, da
             'gather': None, 'mask': None, 'nnz': None}
     if implementation == 1 and not cf:
         return plan
-    if O * F * cout >= (1 << 31):
+    # the table is built on the host from several int64 arrays of O * F * cout entries (~40 B per entry at the peak) and kept on
+    # the device: 2^27 entries is ~5 GB of host memory; beyond that a promise of NotImplementedError is better than an opaque OOM
+    if O * F * cout >= (1 << 27):
         raise NotImplementedError('LocallyConnected3D: the re-layout table of implementation %d (%s) would have %d entries; '
                                   'use implementation 1 / channels_last for layers of this size' % (implementation, data_format,
                                                                                                      O * F * cout))

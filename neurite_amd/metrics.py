@@ -197,10 +197,17 @@ class Dice:
             other = other.materialize()
         if other.dtype != torch.float32 or tuple(other.shape) != tuple(warp.shape) or other.device != warp.device:
             return None
+        warp.check_sources()            # DeferredWarpError if an input was overwritten since SpatialTransformer returned
         src = warp._sources
-        return fused.warp_dice(src['vol'], src['shift'], other, indexing='ij', single_transform=src['single_transform'],
-                               fill_value=src['fill_value'], laplace_smoothing=eps,
-                               check_input_limits=bool(self.check_input_limits))
+        if other.data_ptr() % 16 or src['vol'].data_ptr() % 16 or not other.is_contiguous():
+            return None                 # what the fused kernel cannot take goes the ordinary way (which evaluates the warp)
+        try:
+            return fused.warp_dice(src['vol'], src['shift'], other, indexing='ij', single_transform=src['single_transform'],
+                                   fill_value=src['fill_value'], laplace_smoothing=eps,
+                                   check_input_limits=bool(self.check_input_limits))
+        except (NotImplementedError, _lib.NeuriteAmdError):
+            # sizes beyond the fused kernel's 32-bit offsets and the like: the eager pipeline handles them
+            return None
 
     # ------------------------------------------------------------------------------------------
     def dice(self, y_true, y_pred):

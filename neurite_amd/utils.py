@@ -83,6 +83,7 @@ def _launch_interpn_bwd(vol, loc, grad_out, cfg, need_vol, need_loc):
     S = list(vol.shape[1:-1]) if batched else list(vol.shape[:-1])
     Cc, D = vol.shape[-1], len(S)
     out_spatial = [int(s) for s in cfg['out_spatial']]
+    abi_spatial = out_spatial if len(out_spatial) == D else [int(np.prod(out_spatial))] + [1] * (D - 1)     # see _launch_interpn
     g = grad_out.to(torch.float32).contiguous()
     if cfg['method'] == _lib.INTERP_NEAREST:
         # utils.py:193-204: tf.round has no gradient (TF returns None for loc; zeros here so that optimisers see a tensor),
@@ -95,7 +96,7 @@ def _launch_interpn_bwd(vol, loc, grad_out, cfg, need_vol, need_loc):
             loc_bs = 0 if (single or loc is None) else nloc
             with torch.cuda.device(dev):
                 rc = lib.nrt_interpn_nearest_bwd_f32(_lib.ptr(loc), _lib.ptr(g), _lib.ptr(gvol), D, _lib.ints(S),
-                                                     _lib.ints(out_spatial), Cc, B, nvol, loc_bs, cfg['loc_mode'],
+                                                     _lib.ints(abi_spatial), Cc, B, nvol, loc_bs, cfg['loc_mode'],
                                                      int(cfg['fill_value'] is not None), _lib.stream_ptr(dev))
             _lib.check(rc, 'nrt_interpn_nearest_bwd_f32')
         return gvol, gloc
@@ -112,7 +113,7 @@ def _launch_interpn_bwd(vol, loc, grad_out, cfg, need_vol, need_loc):
         loc_bs = 0 if (single or loc is None) else nloc
         with torch.cuda.device(dev):
             rc = lib.nrt_interpn_bwd_f32(_lib.ptr(vol), _lib.ptr(loc), _lib.ptr(g), _lib.ptr(gvol), _lib.ptr(gloc), D,
-                                         _lib.ints(S), _lib.ints(out_spatial), Cc, B, nvol, loc_bs, cfg['loc_mode'],
+                                         _lib.ints(S), _lib.ints(abi_spatial), Cc, B, nvol, loc_bs, cfg['loc_mode'],
                                          int(cfg['fill_value'] is not None), _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_interpn_bwd_f32')
     if gloc is not None and single and batched:
@@ -128,7 +129,8 @@ def _interp_op(vol, loc, out_spatial, loc_mode, method, fill_value, batched, sin
     needs = torch.is_grad_enabled() and (vol.requires_grad or (loc is not None and loc.requires_grad))
     if not needs:
         return _launch_interpn(vol, loc, **cfg)
-    if vol.dtype == torch.float32 and len(cfg['out_spatial']) <= 3:
+    vol_rank = vol.dim() - (2 if batched else 1)                        # the backward kernels take 1- to 3-D volumes
+    if vol.dtype == torch.float32 and vol_rank <= 3:
         return _InterpnFn.apply(vol, loc, cfg)
     return _NoBackward.apply(lambda: _launch_interpn(vol, loc, **cfg), vol, *([] if loc is None else [loc]))
 
@@ -160,6 +162,12 @@ def _launch_interpn(vol, loc, out_spatial, loc_mode, method, fill_value, batched
         return out
     nvol = int(np.prod(S)) * Cc
     nloc = int(np.prod(out_spatial)) * D
+    # the C ABI takes exactly D output extents.  The reference accepts location tensors of any leading rank (e.g. [N, D] sample
+    # points for a 3-D volume): flatten them to [N, 1, ...]; the output is contiguous, so the shape above already is its final one
+    if len(out_spatial) != D:
+        if loc_mode == _lib.LOC_LINSPACE:
+            raise ValueError('resize needs one output extent per volume dimension')
+        out_spatial = [int(np.prod(out_spatial))] + [1] * (D - 1)
     if loc is not None:
         loc = loc.contiguous()
     vol_bs = nvol

@@ -109,6 +109,41 @@ def test_deferred_respects_semantics(dev, batch):
     assert st([mov, trf]).cpu().numpy().shape == tuple(fix.shape)
 
 
+def test_deferred_warp_is_safe_against_buffer_reuse(dev, batch):
+    """warped = st([buf, trf]); buf.copy_(next); dice(fixed, warped): the eager path (and TF's immutable tensors) give the Dice of the
+    ORIGINAL data.  The deferred path must give the same or refuse loudly -- never the Dice of the new data."""
+    mov, fix, trf = batch
+    other = torch.roll(mov, 3, dims=1).contiguous()
+    st = ne.layers.SpatialTransformer()
+    dice = ne.metrics.Dice(check_input_limits=False)
+    d_ref = eager(lambda: dice.dice(fix, st([mov, trf])))
+    # buffer reuse between the layer and its consumer
+    for mutate in (lambda buf, t: buf.copy_(other), lambda buf, t: buf.mul_(0.5), lambda buf, t: t.add_(1.0), lambda buf, t: buf[:, :4].zero_()):
+        buf, t = mov.clone(), trf.clone()
+        warped = st([buf, t])
+        assert isinstance(warped, ne.deferred.DeferredWarp)
+        mutate(buf, t)
+        with pytest.raises(ne.deferred.DeferredWarpError):
+            dice.dice(fix, warped)                                   # the fused path checks before it launches
+        with pytest.raises(ne.deferred.DeferredWarpError):
+            warped.sum()                                             # and so does every other consumer
+    # eager evaluation (deferred.enabled = False) is the documented remedy and gives the value of the original data
+    buf = mov.clone()
+    w = eager(lambda: st([buf, trf]))
+    buf.copy_(other)
+    np.testing.assert_allclose(N(dice.dice(fix, w)), N(d_ref), rtol=1e-6, atol=1e-7)
+    # inputs that had to be converted are private copies: overwriting the caller's tensor afterwards is harmless
+    buf16 = mov.to(torch.float16)
+    w16 = st([buf16, trf])
+    ref16 = eager(lambda: st([mov.to(torch.float16), trf]))
+    buf16.zero_()
+    assert bits_equal(N(w16.float()), N(ref16.float()))
+    # unaligned / non-contiguous second maps fall back to the ordinary kernels instead of surfacing kernel argument errors
+    fix_pad = torch.zeros((fix.shape[0],) + tuple(fix.shape[1:-1]) + (fix.shape[-1] + 1,), device=dev)[..., 1:]
+    fix_pad.copy_(fix)
+    np.testing.assert_allclose(N(dice.dice(fix_pad, st([mov, trf]))), N(d_ref), rtol=1e-6, atol=1e-7)
+
+
 def test_full_size_reference_api_pipeline_and_few_channel_warps(dev):
     """BASELINE config 2 size (160^3 x 32 one-hot, sigma = 3 field): the reference-signature pipeline with the deferred warp against
     the C oracle's warp + Dice; the same maps stored as bfloat16 give the same Dice bit for bit; and the few-channel kernels

@@ -671,3 +671,38 @@ def test_deferred_warp_tensor_mechanics_cpu():
     e = deferred.DeferredWarp((1, 2, 2, 3, 4), torch.float32, torch.device('cpu'), thunk, dict(vol=None))
     (x * e).sum().backward()
     assert torch.equal(x.grad, e.materialize())
+
+
+def test_deferred_warp_detects_modified_inputs_cpu():
+    """TensorFlow tensors are immutable: the value of SpatialTransformer's result is fixed when the layer returns.  A deferred warp that
+    aliases its inputs must not silently compute the warp of data written afterwards: any in-place change of
+    the volume or the transform -- through the tensor itself or through a view -- is detected when the warp is evaluated."""
+    from neurite_amd import deferred
+
+    def make():
+        vol = torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4)
+        shift = torch.zeros(1, 2, 3, 3)
+        d = deferred.DeferredWarp((1, 2, 3, 4), torch.float32, torch.device('cpu'), lambda: vol.clone(),
+                                  dict(vol=vol, shift=shift, single_transform=False, fill_value=None))
+        return vol, shift, d
+
+    vol, shift, d = make()
+    assert torch.equal(d.materialize(), vol)                            # untouched inputs: evaluates
+    for mutate in (lambda v, s: v.copy_(torch.ones_like(v)), lambda v, s: v.mul_(2.0), lambda v, s: v[0, 0].zero_(),
+                   lambda v, s: s.add_(1.0), lambda v, s: v.view(-1)[3:5].fill_(7.0)):
+        vol, shift, d = make()
+        mutate(vol, shift)
+        with pytest.raises(deferred.DeferredWarpError):
+            d.materialize()
+        with pytest.raises(deferred.DeferredWarpError):
+            d.check_sources()
+        assert d.pending
+        with pytest.raises(deferred.DeferredWarpError):                 # any torch op on the pending tensor evaluates it, and raises
+            d + 1
+    vol, shift, d = make()
+    _ = vol + 1                                                          # out-of-place uses of the inputs are fine
+    _ = shift * 2
+    d.check_sources()
+    assert torch.equal(d.materialize(), vol)
+    vol.mul_(3.0)                                                        # after the evaluation the result is its own tensor
+    assert torch.equal(d.materialize(), torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4))
