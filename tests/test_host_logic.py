@@ -706,3 +706,26 @@ def test_deferred_warp_detects_modified_inputs_cpu():
     assert torch.equal(d.materialize(), vol)
     vol.mul_(3.0)                                                        # after the evaluation the result is its own tensor
     assert torch.equal(d.materialize(), torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4))
+
+
+def test_lean_kernel_size_guard_cpu():
+    """the few-channel tile kernel forms the byte offset of a voxel's location (12 B) and of its output row (4 C B) in 32-bit
+    arithmetic; `nrt_lean_supported` has to refuse outputs beyond that, not only extents of 4096 and more (a 768^3 output passed the old
+    guard and read its locations from wrapped addresses)."""
+    import ctypes as C
+    h = ne._lib.lib()
+    fn = getattr(h, '_Z18nrt_lean_supportedPKiS0_iiPKvS2_S2_xx')
+    fn.restype = C.c_bool
+    fn.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong]
+    ints = ne._lib.ints
+    aligned = 0x10000
+
+    def ok(vol_shape, out_shape, ch):
+        return bool(fn(ints(vol_shape), ints(out_shape), ch, 3, aligned, aligned, aligned, 0, 0))
+
+    assert ok([160, 160, 160], [160, 160, 160], 1) and ok([160, 160, 160], [160, 160, 160], 4)
+    assert ok([64, 64, 64], [700, 700, 700], 1)                           # 343e6 voxels x 12 B < 2^32
+    assert not ok([64, 64, 64], [768, 768, 768], 1)                       # 453e6 voxels x 12 B wraps
+    assert not ok([64, 64, 64], [720, 720, 720], 1)                       # 373e6 x 12 B = 4.48e9 wraps
+    assert ok([64, 64, 64], [640, 640, 640], 4) and not ok([64, 64, 64], [660, 660, 660], 4)      # output rows: 16 B per voxel
+    assert not ok([64, 64, 64], [4096, 8, 8], 1) and not ok([64, 64, 64], [16, 16, 16], 5)
