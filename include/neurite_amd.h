@@ -136,6 +136,13 @@ int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long long nvox, 
                       int normalize, float laplace_smoothing,
                       float *sums, float *dice, float *minmax,
                       void *workspace, size_t workspace_bytes, void *stream);
+/* The same for maps STORED as float32, bfloat16 or float16 (dtype: NRT_DT_F32 / NRT_DT_BF16 / NRT_DT_F16, both maps alike): the
+ * values are widened to float32 in registers and every sum is a float32 sum, as TensorFlow's reductions of 16-bit tensors
+ * accumulate; sums / dice / minmax are float32.  (neurite/tf/metrics.py:415-482 is dtype-agnostic.) */
+int nrt_dice_soft(const void *y_true, const void *y_pred, int dtype, long long nvox, int nlabels, int batch, int normalize,
+                  float laplace_smoothing, float *sums, float *dice, float *minmax, void *workspace, size_t workspace_bytes,
+                  void *stream);
+
 
 /*
  * Hard Dice from probabilistic maps: argmax over labels (ties -> lowest index) then one-hot.
@@ -150,6 +157,12 @@ int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, long long n
 int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
                                   float laplace_smoothing, long long *counts, float *dice, float *minmax,
                                   void *workspace, size_t workspace_bytes, void *stream);
+/* Hard Dice of probability maps stored as float32 / bfloat16 / float16 (arg-max of the stored values: exact in any of them);
+ * minmax [4] may be NULL. */
+int nrt_dice_hard_prob(const void *y_true, const void *y_pred, int dtype, long long nvox, int nlabels, int batch,
+                       float laplace_smoothing, long long *counts, float *dice, float *minmax, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 
 /* Hard Dice from label maps [batch, nvox] int32; labels outside [0, nlabels) match nothing.  workspace: NULL, or
  * nrt_dice_workspace_bytes(nvox, nlabels, batch) bytes (then the block histograms are reduced without global atomics). */

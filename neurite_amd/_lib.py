@@ -38,6 +38,8 @@ _SIGNATURES = {
     'nrt_interpn_any': (_i, [_vp, _vp, _vp, _i, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _i, C.c_double, _vp]),
     'nrt_dice_workspace_bytes': (_sz, [_ll, _i, _i]),
     'nrt_dice_soft_f32': (_i, [_vp, _vp, _ll, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nrt_dice_soft': (_i, [_vp, _vp, _i, _ll, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nrt_dice_hard_prob': (_i, [_vp, _vp, _i, _ll, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_hard_prob_f32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_hard_prob_minmax_f32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_hard_label_i32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -19,18 +19,48 @@
 
 namespace {
 
+// Storage type of the two maps: float32, or bfloat16 / float16 (ST = unsigned short / _Float16).  16-bit maps are widened to
+// float32 in registers (exact) and everything below runs in float32, as for float32 maps: "16-bit storage, float32 math", the
+// same convention as the weighted CCE (csrc/cce.hip) -- TensorFlow's own reductions of bfloat16 / float16 tensors accumulate in
+// float32 as well (metrics.py:415-482 is dtype-agnostic).  Results are float32.
+typedef unsigned nrt_u2 __attribute__((ext_vector_type(2)));
+typedef _Float16 nrt_h4 __attribute__((ext_vector_type(4)));
+struct DiceBf16 { unsigned short bits; };
+template <typename ST> struct DiceIn;
+template <> struct DiceIn<float> {
+    static constexpr int BYTES = 4;
+    static __device__ __forceinline__ nrt_f4 load4(const void *base, long long i4) { return __builtin_nontemporal_load((const nrt_f4 *)base + i4); }
+    static __device__ __forceinline__ float load1(const void *base, long long i) { return ((const float *)base)[i]; }
+};
+template <> struct DiceIn<DiceBf16> {
+    static constexpr int BYTES = 2;
+    static __device__ __forceinline__ nrt_f4 load4(const void *base, long long i4) {
+        const nrt_u2 t = __builtin_nontemporal_load((const nrt_u2 *)base + i4);
+        return (nrt_f4){__uint_as_float(t[0] << 16), __uint_as_float(t[0] & 0xffff0000u), __uint_as_float(t[1] << 16), __uint_as_float(t[1] & 0xffff0000u)};
+    }
+    static __device__ __forceinline__ float load1(const void *base, long long i) { return __uint_as_float((unsigned)((const unsigned short *)base)[i] << 16); }
+};
+template <> struct DiceIn<_Float16> {
+    static constexpr int BYTES = 2;
+    static __device__ __forceinline__ nrt_f4 load4(const void *base, long long i4) {
+        const nrt_h4 t = __builtin_nontemporal_load((const nrt_h4 *)base + i4);
+        return (nrt_f4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    }
+    static __device__ __forceinline__ float load1(const void *base, long long i) { return (float)((const _Float16 *)base)[i]; }
+};
+
 // ============================================================================================
 // soft Dice, vectorised: G lanes per voxel
 // ============================================================================================
-template <int G, bool NORMALIZE>
-__global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const float *__restrict__ yt, const float *__restrict__ yp,
+template <int G, bool NORMALIZE, typename ST = float>
+__global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const void *__restrict__ yt, const void *__restrict__ yp,
                                                             long long nvox, float *__restrict__ fpart,
                                                             float *__restrict__ mpart) {
     constexpr int NG = DICE_BLOCK / G;           // voxels per block pass
     constexpr int L = 4 * G;
     const int b = blockIdx.y;
-    const nrt_f4 *t4 = (const nrt_f4 *)(yt + (long long)b * nvox * L);
-    const nrt_f4 *p4 = (const nrt_f4 *)(yp + (long long)b * nvox * L);
+    const char *t4 = (const char *)yt + (long long)b * nvox * L * DiceIn<ST>::BYTES;
+    const char *p4 = (const char *)yp + (long long)b * nvox * L * DiceIn<ST>::BYTES;
     const int lg = threadIdx.x % G;
     const long long g = threadIdx.x / G;
     const long long stride = (long long)gridDim.x * NG;
@@ -40,8 +70,8 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const float *__restr
 
 #pragma unroll 4
     for (long long v = (long long)blockIdx.x * NG + g; v < nvox; v += stride) {
-        nrt_f4 t = __builtin_nontemporal_load(&t4[v * G + lg]);
-        nrt_f4 p = __builtin_nontemporal_load(&p4[v * G + lg]);
+        nrt_f4 t = DiceIn<ST>::load4(t4, v * G + lg);
+        nrt_f4 p = DiceIn<ST>::load4(p4, v * G + lg);
         if (NORMALIZE) {
             // y / sum_l y with divide_no_nan (metrics.py:435-436); the label sum spans the lane-group
             float st = (t[0] + t[1]) + (t[2] + t[3]);
@@ -108,15 +138,15 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const float *__restr
 
 // soft Dice, any L (slow path for label counts that are not 4*2^k): thread = (voxel row r, label li)
 // inside a label chunk of up to 256 labels (blockIdx.z); consecutive threads read consecutive labels.
-template <bool NORMALIZE>
-__global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const float *__restrict__ yt, const float *__restrict__ yp,
+template <bool NORMALIZE, typename ST = float>
+__global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const void *__restrict__ yt, const void *__restrict__ yp,
                                                                 long long nvox, int L, float *__restrict__ fpart,
                                                                 float *__restrict__ mpart) {
     __shared__ float sh[3 * DICE_BLOCK];
     __shared__ float mm[DICE_BLOCK / NRT_WAVE][4];
     const int b = blockIdx.y;
-    const float *t = yt + (long long)b * nvox * L;
-    const float *p = yp + (long long)b * nvox * L;
+    const char *t = (const char *)yt + (long long)b * nvox * L * DiceIn<ST>::BYTES;
+    const char *p = (const char *)yp + (long long)b * nvox * L * DiceIn<ST>::BYTES;
     const int Lc = L < DICE_BLOCK ? L : DICE_BLOCK;       // labels in this chunk (last chunk may be short)
     const int R = DICE_BLOCK / Lc;                        // voxel rows per pass (1 when L >= 256)
     const int r = threadIdx.x / Lc, li = threadIdx.x % Lc;
@@ -126,10 +156,10 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const float *__r
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
     if (active) {
         for (long long v = (long long)blockIdx.x * R + r; v < nvox; v += (long long)gridDim.x * R) {
-            float tv = t[v * L + l], pv = p[v * L + l];
+            float tv = DiceIn<ST>::load1(t, v * L + l), pv = DiceIn<ST>::load1(p, v * L + l);
             if (NORMALIZE) {
                 float st = 0.0f, sp = 0.0f;
-                for (int k = 0; k < L; ++k) { st += t[v * L + k]; sp += p[v * L + k]; }
+                for (int k = 0; k < L; ++k) { st += DiceIn<ST>::load1(t, v * L + k); sp += DiceIn<ST>::load1(p, v * L + k); }
                 tv = (st == 0.0f) ? 0.0f : tv / st;
                 pv = (sp == 0.0f) ? 0.0f : pv / sp;
             }
@@ -169,15 +199,15 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const float *__r
 // hard Dice from probabilities: arg-max (ties -> lowest label) + one-hot counting, G lanes/voxel
 // ============================================================================================
 // MINMAX: also the extrema of both inputs (the range asserts of metrics.py:439-444 without a second pass over the maps)
-template <int G, bool MINMAX>
-__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const float *__restrict__ yt, const float *__restrict__ yp,
+template <int G, bool MINMAX, typename ST = float>
+__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const void *__restrict__ yt, const void *__restrict__ yp,
                                                             long long nvox, unsigned *__restrict__ ipart,
                                                             float *__restrict__ mpart) {
     constexpr int NG = DICE_BLOCK / G;
     constexpr int L = 4 * G;
     const int b = blockIdx.y;
-    const nrt_f4 *t4 = (const nrt_f4 *)(yt + (long long)b * nvox * L);
-    const nrt_f4 *p4 = (const nrt_f4 *)(yp + (long long)b * nvox * L);
+    const char *t4 = (const char *)yt + (long long)b * nvox * L * DiceIn<ST>::BYTES;
+    const char *p4 = (const char *)yp + (long long)b * nvox * L * DiceIn<ST>::BYTES;
     const int lg = threadIdx.x % G;
     const long long g = threadIdx.x / G;
     const long long stride = (long long)gridDim.x * NG;
@@ -186,8 +216,8 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const float *__restr
 
 #pragma unroll 2
     for (long long v = (long long)blockIdx.x * NG + g; v < nvox; v += stride) {
-        const nrt_f4 t = __builtin_nontemporal_load(&t4[v * G + lg]);
-        const nrt_f4 p = __builtin_nontemporal_load(&p4[v * G + lg]);
+        const nrt_f4 t = DiceIn<ST>::load4(t4, v * G + lg);
+        const nrt_f4 p = DiceIn<ST>::load4(p4, v * G + lg);
         if (MINMAX) {
             mnt = fminf(mnt, fminf(fminf(t[0], t[1]), fminf(t[2], t[3]))); mxt = fmaxf(mxt, fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])));
             mnp = fminf(mnp, fminf(fminf(p[0], p[1]), fminf(p[2], p[3]))); mxp = fmaxf(mxp, fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));
@@ -294,20 +324,21 @@ __device__ __forceinline__ void wave_hist_add(unsigned *hist, int label, bool ok
 // coalesced 4-byte loads, then a thread scans its voxel's row for the arg-max (ties -> lowest label); the counts go to a per-block
 // LDS histogram (one atomic per distinct label of a wave) and to `counts` once per block.  (The first version read the rows
 // straight from memory, a lane per voxel -- 80-byte strides at 20 labels -- and sent three global atomics per VOXEL.)
-__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_generic(const float *__restrict__ yt, const float *__restrict__ yp,
+template <typename ST>
+__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_generic(const void *__restrict__ yt, const void *__restrict__ yp,
                                                                      long long nvox, int L, int VP, long long *counts) {
     extern __shared__ unsigned dh_lds[];    // hist [3 * L], rows [VP * L]
     unsigned *hist = dh_lds;
     float *rows = (float *)(dh_lds + 3 * L);
     const int b = blockIdx.y;
-    const float *t = yt + (long long)b * nvox * L;
-    const float *p = yp + (long long)b * nvox * L;
+    const char *t = (const char *)yt + (long long)b * nvox * L * DiceIn<ST>::BYTES;
+    const char *p = (const char *)yp + (long long)b * nvox * L * DiceIn<ST>::BYTES;
     unsigned long long *c = (unsigned long long *)counts + (long long)b * 3 * L;
     for (int i = threadIdx.x; i < 3 * L; i += blockDim.x) hist[i] = 0u;
-    auto argmax_of = [&](const float *src, long long v0, int nv) -> int {
+    auto argmax_of = [&](const char *src, long long v0, int nv) -> int {
         const long long n = (long long)nv * L;
         __syncthreads();                                     // the previous scan is over
-        for (long long i = threadIdx.x; i < n; i += blockDim.x) rows[i] = src[v0 * L + i];
+        for (long long i = threadIdx.x; i < n; i += blockDim.x) rows[i] = DiceIn<ST>::load1(src, v0 * L + i);
         __syncthreads();
         int am = 0;
         if ((int)threadIdx.x < nv) {
@@ -332,17 +363,18 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_generic(const float
 }
 
 // the same for label counts whose rows do not fit in LDS: rows read from memory, global atomics
-__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_direct(const float *__restrict__ yt, const float *__restrict__ yp,
+template <typename ST>
+__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_prob_direct(const void *__restrict__ yt, const void *__restrict__ yp,
                                                                     long long nvox, int L, long long *counts) {
     const int b = blockIdx.y;
-    const float *t = yt + (long long)b * nvox * L;
-    const float *p = yp + (long long)b * nvox * L;
+    const char *t = (const char *)yt + (long long)b * nvox * L * DiceIn<ST>::BYTES;
+    const char *p = (const char *)yp + (long long)b * nvox * L * DiceIn<ST>::BYTES;
     unsigned long long *c = (unsigned long long *)counts + (long long)b * 3 * L;
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
         int at = 0, ap = 0;
-        float bt = t[v * L], bp = p[v * L];
+        float bt = DiceIn<ST>::load1(t, v * L), bp = DiceIn<ST>::load1(p, v * L);
         for (int l = 1; l < L; ++l) {
-            const float tv = t[v * L + l], pv = p[v * L + l];
+            const float tv = DiceIn<ST>::load1(t, v * L + l), pv = DiceIn<ST>::load1(p, v * L + l);
             if (tv > bt) { bt = tv; at = l; }
             if (pv > bp) { bp = pv; ap = l; }
         }
@@ -449,32 +481,24 @@ bool vec_labels(int L) {
     return g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64;
 }
 
-template <int G>
-void launch_soft_vec(const float *t, const float *p, long long nvox, int batch, int normalize, unsigned nblk,
+template <int G, typename ST>
+void launch_soft_vec(const void *t, const void *p, long long nvox, int batch, int normalize, unsigned nblk,
                      const DiceWs &w, hipStream_t st) {
     dim3 grid(nblk, batch);
-    if (normalize) hipLaunchKernelGGL((dice_soft_vec<G, true>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart);
-    else hipLaunchKernelGGL((dice_soft_vec<G, false>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart);
+    if (normalize) hipLaunchKernelGGL((dice_soft_vec<G, true, ST>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart);
+    else hipLaunchKernelGGL((dice_soft_vec<G, false, ST>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart);
 }
 
-template <int G>
-void launch_hard_vec(const float *t, const float *p, long long nvox, int batch, unsigned nblk, const DiceWs &w,
+template <int G, typename ST>
+void launch_hard_vec(const void *t, const void *p, long long nvox, int batch, unsigned nblk, const DiceWs &w,
                      bool minmax, hipStream_t st) {
-    if (minmax) hipLaunchKernelGGL((dice_hard_vec<G, true>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart);
-    else hipLaunchKernelGGL((dice_hard_vec<G, false>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart);
+    if (minmax) hipLaunchKernelGGL((dice_hard_vec<G, true, ST>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart);
+    else hipLaunchKernelGGL((dice_hard_vec<G, false, ST>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart);
 }
 
-}  // namespace
-
-extern "C" size_t nrt_dice_workspace_bytes(long long nvox, int nlabels, int batch) {
-    (void)nvox;
-    if (nlabels < 1 || batch < 1) return 0;
-    return dice_ws_bytes(nlabels, batch);
-}
-
-extern "C" int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
-                                 int normalize, float laplace_smoothing, float *sums, float *dice, float *minmax,
-                                 void *workspace, size_t workspace_bytes, void *stream) {
+template <typename ST>
+int dice_soft_impl(const void *y_true, const void *y_pred, long long nvox, int nlabels, int batch, int normalize, float laplace_smoothing,
+                   float *sums, float *dice, float *minmax, void *workspace, size_t workspace_bytes, void *stream) {
     if (!y_true || !y_pred || !sums || !dice) return NRT_ERR_INVALID_ARG;
     if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < dice_ws_bytes(nlabels, batch)) return NRT_ERR_WORKSPACE;
@@ -482,18 +506,18 @@ extern "C" int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long 
     hipStream_t st = nrt_stream(stream);
     DiceWs w = dice_ws_carve(workspace, nlabels, batch);
     unsigned nblk, gz = 1;
-    const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
+    const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & (4 * DiceIn<ST>::BYTES - 1)) == 0;      // 4 labels per lane access
     if (vec_labels(nlabels) && aligned) {
         const int G = nlabels / 4;
         nblk = dice_num_blocks(nvox, (DICE_BLOCK / G) * 4);
         switch (G) {
-            case 1: launch_soft_vec<1>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 2: launch_soft_vec<2>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 4: launch_soft_vec<4>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 8: launch_soft_vec<8>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 16: launch_soft_vec<16>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 32: launch_soft_vec<32>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            default: launch_soft_vec<64>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 1: launch_soft_vec<1, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 2: launch_soft_vec<2, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 4: launch_soft_vec<4, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 8: launch_soft_vec<8, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 16: launch_soft_vec<16, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 32: launch_soft_vec<32, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            default: launch_soft_vec<64, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
         }
     } else {
         const int Lc = nlabels < DICE_BLOCK ? nlabels : DICE_BLOCK;
@@ -501,40 +525,33 @@ extern "C" int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long 
         nblk = dice_num_blocks(nvox, DICE_BLOCK / Lc);
         if (nblk > DICE_MAX_BLOCKS / gz) nblk = DICE_MAX_BLOCKS / gz;
         dim3 grid(nblk, batch, gz);
-        if (normalize) hipLaunchKernelGGL((dice_soft_generic<true>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
-        else hipLaunchKernelGGL((dice_soft_generic<false>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
+        if (normalize) hipLaunchKernelGGL((dice_soft_generic<true, ST>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
+        else hipLaunchKernelGGL((dice_soft_generic<false, ST>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
     }
     NRT_CHECK_LAUNCH();
     return dice_finalize_soft(w, nblk, gz, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
 }
 
-extern "C" int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
-                                      float laplace_smoothing, long long *counts, float *dice, void *workspace,
-                                      size_t workspace_bytes, void *stream) {
-    return nrt_dice_hard_prob_minmax_f32(y_true, y_pred, nvox, nlabels, batch, laplace_smoothing, counts, dice, nullptr, workspace,
-                                         workspace_bytes, stream);
-}
-
-extern "C" int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
-                                             float laplace_smoothing, long long *counts, float *dice, float *minmax,
-                                             void *workspace, size_t workspace_bytes, void *stream) {
+template <typename ST>
+int dice_hard_prob_impl(const void *y_true, const void *y_pred, long long nvox, int nlabels, int batch, float laplace_smoothing,
+                        long long *counts, float *dice, float *minmax, void *workspace, size_t workspace_bytes, void *stream) {
     if (!y_true || !y_pred || !counts || !dice) return NRT_ERR_INVALID_ARG;
     if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < dice_ws_bytes(nlabels, batch)) return NRT_ERR_WORKSPACE;
     hipStream_t st = nrt_stream(stream);
     DiceWs w = dice_ws_carve(workspace, nlabels, batch);
-    const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
+    const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & (4 * DiceIn<ST>::BYTES - 1)) == 0;
     if (vec_labels(nlabels) && aligned) {
         const int G = nlabels / 4;
         const unsigned nblk = dice_num_blocks(nvox, (DICE_BLOCK / G) * 4);
         switch (G) {
-            case 1: launch_hard_vec<1>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 2: launch_hard_vec<2>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 4: launch_hard_vec<4>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 8: launch_hard_vec<8>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 16: launch_hard_vec<16>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 32: launch_hard_vec<32>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            default: launch_hard_vec<64>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 1: launch_hard_vec<1, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 2: launch_hard_vec<2, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 4: launch_hard_vec<4, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 8: launch_hard_vec<8, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 16: launch_hard_vec<16, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 32: launch_hard_vec<32, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            default: launch_hard_vec<64, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
         }
         NRT_CHECK_LAUNCH();
         const int ngrp = ((int)nblk + RED_ROWS - 1) / RED_ROWS;
@@ -559,10 +576,10 @@ extern "C" int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y
             long long nb = (nvox + VP - 1) / VP;
             if (nb > 1024) nb = 1024;                             // one atomic per label and block at the end
             if (nb < 1) nb = 1;
-            hipLaunchKernelGGL(dice_hard_prob_generic, dim3((unsigned)nb, batch), dim3(DICE_BLOCK),
+            hipLaunchKernelGGL(dice_hard_prob_generic<ST>, dim3((unsigned)nb, batch), dim3(DICE_BLOCK),
                                ((size_t)VP * nlabels + 3 * (size_t)nlabels) * 4, st, y_true, y_pred, nvox, nlabels, VP, counts);
         } else {
-            hipLaunchKernelGGL(dice_hard_prob_direct, dim3(dice_num_blocks(nvox, DICE_BLOCK), batch), dim3(DICE_BLOCK), 0, st, y_true, y_pred,
+            hipLaunchKernelGGL(dice_hard_prob_direct<ST>, dim3(dice_num_blocks(nvox, DICE_BLOCK), batch), dim3(DICE_BLOCK), 0, st, y_true, y_pred,
                                nvox, nlabels, counts);
         }
     }
@@ -571,6 +588,63 @@ extern "C" int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y
                        laplace_smoothing, dice);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t nrt_dice_workspace_bytes(long long nvox, int nlabels, int batch) {
+    (void)nvox;
+    if (nlabels < 1 || batch < 1) return 0;
+    return dice_ws_bytes(nlabels, batch);
+}
+
+extern "C" int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                                 int normalize, float laplace_smoothing, float *sums, float *dice, float *minmax,
+                                 void *workspace, size_t workspace_bytes, void *stream) {
+    return dice_soft_impl<float>(y_true, y_pred, nvox, nlabels, batch, normalize, laplace_smoothing, sums, dice, minmax, workspace,
+                                 workspace_bytes, stream);
+}
+
+extern "C" int nrt_dice_soft(const void *y_true, const void *y_pred, int dtype, long long nvox, int nlabels, int batch, int normalize,
+                             float laplace_smoothing, float *sums, float *dice, float *minmax, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+    switch (dtype) {
+        case NRT_DT_F32: return dice_soft_impl<float>(y_true, y_pred, nvox, nlabels, batch, normalize, laplace_smoothing, sums, dice, minmax,
+                                                      workspace, workspace_bytes, stream);
+        case NRT_DT_BF16: return dice_soft_impl<DiceBf16>(y_true, y_pred, nvox, nlabels, batch, normalize, laplace_smoothing, sums, dice,
+                                                          minmax, workspace, workspace_bytes, stream);
+        case NRT_DT_F16: return dice_soft_impl<_Float16>(y_true, y_pred, nvox, nlabels, batch, normalize, laplace_smoothing, sums, dice,
+                                                         minmax, workspace, workspace_bytes, stream);
+        default: return NRT_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                                      float laplace_smoothing, long long *counts, float *dice, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    return dice_hard_prob_impl<float>(y_true, y_pred, nvox, nlabels, batch, laplace_smoothing, counts, dice, nullptr, workspace,
+                                      workspace_bytes, stream);
+}
+
+extern "C" int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
+                                             float laplace_smoothing, long long *counts, float *dice, float *minmax,
+                                             void *workspace, size_t workspace_bytes, void *stream) {
+    return dice_hard_prob_impl<float>(y_true, y_pred, nvox, nlabels, batch, laplace_smoothing, counts, dice, minmax, workspace,
+                                      workspace_bytes, stream);
+}
+
+extern "C" int nrt_dice_hard_prob(const void *y_true, const void *y_pred, int dtype, long long nvox, int nlabels, int batch,
+                                  float laplace_smoothing, long long *counts, float *dice, float *minmax, void *workspace,
+                                  size_t workspace_bytes, void *stream) {
+    switch (dtype) {
+        case NRT_DT_F32: return dice_hard_prob_impl<float>(y_true, y_pred, nvox, nlabels, batch, laplace_smoothing, counts, dice, minmax,
+                                                           workspace, workspace_bytes, stream);
+        case NRT_DT_BF16: return dice_hard_prob_impl<DiceBf16>(y_true, y_pred, nvox, nlabels, batch, laplace_smoothing, counts, dice, minmax,
+                                                               workspace, workspace_bytes, stream);
+        case NRT_DT_F16: return dice_hard_prob_impl<_Float16>(y_true, y_pred, nvox, nlabels, batch, laplace_smoothing, counts, dice, minmax,
+                                                              workspace, workspace_bytes, stream);
+        default: return NRT_ERR_UNSUPPORTED;
+    }
 }
 
 extern "C" int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_pred, long long nvox, int nlabels,

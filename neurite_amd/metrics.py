@@ -25,25 +25,42 @@ __all__ = ['Dice', 'SoftDice', 'HardDice', 'CategoricalCrossentropy', 'WeightedC
 _INT_DTYPES = (torch.int8, torch.uint8, torch.int16, torch.int32, torch.int64, torch.bool)
 
 
+_MAP_DTYPES = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16}
+
+
 def _as_f32(x, what):
+    """a float32 tensor for the kernels that take only float32 (backward passes): 16-bit maps are widened, which is exact"""
     if x.dtype != torch.float32:
-        if x.dtype in (torch.float16, torch.bfloat16, torch.float64):
-            raise NotImplementedError('%s: the HIP Dice path takes float32 probability maps, got %s'
-                                      % (what, x.dtype))
-        raise TypeError('%s: expected a float32 probability / one-hot map, got %s' % (what, x.dtype))
+        if x.dtype in (torch.float16, torch.bfloat16):
+            return x.to(torch.float32).contiguous()
+        if x.dtype == torch.float64:
+            raise NotImplementedError('%s: the HIP Dice path takes float32 / bfloat16 / float16 probability maps, got float64' % what)
+        raise TypeError('%s: expected a floating-point probability / one-hot map, got %s' % (what, x.dtype))
     return x.contiguous()
+
+
+def _as_maps(y_true, y_pred):
+    """both maps as the Dice kernels take them: contiguous, one common storage dtype (float32, bfloat16 or float16; the arithmetic
+    is float32 whatever the storage, csrc/dice.hip).  Maps of different dtypes are widened to float32 first."""
+    for what, x in (('y_true', y_true), ('y_pred', y_pred)):
+        if x.dtype == torch.float64:
+            raise NotImplementedError('%s: the HIP Dice path takes float32 / bfloat16 / float16 probability maps, got float64' % what)
+        if x.dtype not in _MAP_DTYPES:
+            raise TypeError('%s: expected a floating-point probability / one-hot map, got %s' % (what, x.dtype))
+    if y_true.dtype != y_pred.dtype:
+        y_true, y_pred = y_true.to(torch.float32), y_pred.to(torch.float32)
+    return y_true.contiguous(), y_pred.contiguous(), _MAP_DTYPES[y_true.dtype]
 
 
 def dice_partial_sums(y_true, y_pred, normalize=False, laplace_smoothing=0.):
     """
-    One pass over two [B, ..., L] float32 maps on the GPU.
+    One pass over two [B, ..., L] maps on the GPU (float32, or bfloat16 / float16 storage with float32 arithmetic).
     Returns (sums [B, 3, L] = sum t*p, sum t^2, sum p^2;  dice [B, L];  minmax [4] = min t, max t, min p, max p).
     `sums` is the quantity to all-reduce when a batch entry is split across ranks.
     """
     lib = _lib.lib()
     dev = _lib.require_device(y_true, y_pred)
-    t = _as_f32(y_true, 'y_true')
-    p = _as_f32(y_pred, 'y_pred')
+    t, p, dt = _as_maps(y_true, y_pred)
     if t.shape != p.shape:
         raise ValueError('y_true and y_pred must have the same shape, got %s and %s'
                          % (tuple(t.shape), tuple(p.shape)))
@@ -65,10 +82,10 @@ def dice_partial_sums(y_true, y_pred, normalize=False, laplace_smoothing=0.):
     nws = lib.nrt_dice_workspace_bytes(V, L, B)
     ws = _lib.workspace(dev, nws)
     with torch.cuda.device(dev):
-        rc = lib.nrt_dice_soft_f32(_lib.ptr(t), _lib.ptr(p), V, L, B, int(bool(normalize)),
-                                   float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice), _lib.ptr(minmax),
-                                   _lib.ptr(ws), nws, _lib.stream_ptr(dev))
-    _lib.check(rc, 'nrt_dice_soft_f32')
+        rc = lib.nrt_dice_soft(_lib.ptr(t), _lib.ptr(p), dt, V, L, B, int(bool(normalize)),
+                               float(laplace_smoothing), _lib.ptr(sums), _lib.ptr(dice), _lib.ptr(minmax),
+                               _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_dice_soft')
     return sums, dice, minmax
 
 
@@ -84,6 +101,7 @@ class _SoftDiceFn(torch.autograd.Function):
             _check_limits(mm)
         ctx.save_for_backward(t, p, sums)
         ctx.eps, ctx.normalize = eps, normalize
+        ctx.in_dtypes = (y_true.dtype, y_pred.dtype)       # 16-bit maps: float32 arithmetic, gradients rounded to the maps' dtype
         return d
 
     @staticmethod
@@ -102,6 +120,10 @@ class _SoftDiceFn(torch.autograd.Function):
                 rc = fn(_lib.ptr(t), _lib.ptr(p), _lib.ptr(sums), _lib.ptr(g), V, L, B, float(ctx.eps), _lib.ptr(gp),
                         _lib.ptr(gt), _lib.stream_ptr(dev))
             _lib.check(rc, 'nrt_dice_soft_bwd(_norm)_f32')
+        if gt is not None:
+            gt = gt.to(ctx.in_dtypes[0])
+        if gp is not None:
+            gp = gp.to(ctx.in_dtypes[1])
         return gt, gp, None, None, None
 
 
@@ -238,8 +260,7 @@ class Dice:
                           'and computing *hard* dice. \n For this, we use argmax to'
                           'get the optimal label at each location, which is not'
                           'differentiable. Do not use expecting gradients.')
-            t = _as_f32(y_true, 'y_true')
-            p = _as_f32(y_pred, 'y_pred')
+            t, p, dt = _as_maps(y_true, y_pred)
             if t.shape != p.shape:
                 raise ValueError('y_true and y_pred must have the same shape')
             if self.nb_labels is None:                                                    # :460-461
@@ -265,10 +286,9 @@ class Dice:
             ws = _lib.workspace(dev, nws)
             mm = torch.empty((4,), dtype=torch.float32, device=dev) if fused_limits else None
             with torch.cuda.device(dev):
-                rc = lib.nrt_dice_hard_prob_minmax_f32(_lib.ptr(t), _lib.ptr(p), V, L, B, eps, _lib.ptr(counts), _lib.ptr(d),
-                                                       _lib.ptr(mm) if fused_limits else None, _lib.ptr(ws), nws,
-                                                       _lib.stream_ptr(dev))
-            _lib.check(rc, 'nrt_dice_hard_prob_minmax_f32')
+                rc = lib.nrt_dice_hard_prob(_lib.ptr(t), _lib.ptr(p), dt, V, L, B, eps, _lib.ptr(counts), _lib.ptr(d),
+                                            _lib.ptr(mm) if fused_limits else None, _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_dice_hard_prob')
             if fused_limits:
                 _check_limits(mm)
             return d

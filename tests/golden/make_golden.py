@@ -262,6 +262,15 @@ def gen_dice():
     assert raised
     cases['not_checked_bad'] = A(ne.metrics.Dice(check_input_limits=False).dice(T(pr_t), T(bad)))
     cases['bad'] = bad
+    # float16 probability maps (metrics.py:415-482 is dtype-agnostic: products and quotients in float16, the shim's reduce_sum
+    # accumulates wide and rounds once, as TensorFlow's reductions of 16-bit tensors do)
+    h_t, h_p = pr_t.astype(np.float16), pr_p.astype(np.float16)
+    cases['f16_t'], cases['f16_p'] = h_t, h_p
+    cases['f16_soft_prob'] = A(ne.metrics.SoftDice().dice(T(h_t), T(h_p)))
+    cases['f16_soft_prob_laplace'] = A(ne.metrics.SoftDice(laplace_smoothing=0.1).dice(T(h_t), T(h_p)))
+    cases['f16_mean_soft_prob'] = A(ne.metrics.Dice().mean_dice(T(h_t), T(h_p)))
+    cases['f16_hard_prob'] = A(ne.metrics.HardDice(L, input_type='prob').dice(T(h_t), T(h_p)))
+    assert cases['f16_soft_prob'].dtype == np.float16
     save('dice_small', **cases)
 
 

@@ -71,6 +71,59 @@ def test_dice_golden(dev):
         ne.metrics.Dice(weights=np.ones(L, F)).mean_dice(t, p)
 
 
+def test_dice_on_16bit_probability_maps(dev):
+    """neurite/tf/metrics.py:415-482 is dtype-agnostic (BASELINE config 5 is a bfloat16 pipeline).  Here 16-bit maps are STORAGE:
+    the kernels widen to float32 (exact) and run the float32 arithmetic, results are float32 -- so they are bit-identical to the
+    float32 kernels on the widened maps, and agree with the reference's own float16 evaluation (reference through the golden shim:
+    float16 products and quotients, wide accumulation) to float16 resolution."""
+    g = load_golden('dice_small')
+    L = g['oh_t'].shape[-1]
+    ht, hp = G(g['f16_t'], dev), G(g['f16_p'], dev)
+    assert ht.dtype == torch.float16
+    tol = dict(rtol=3e-3, atol=1e-3)                                       # float16: 2^-11 per rounded product / quotient
+    np.testing.assert_allclose(N(ne.metrics.SoftDice().dice(ht, hp)), g['f16_soft_prob'].astype(F), **tol)
+    np.testing.assert_allclose(N(ne.metrics.SoftDice(laplace_smoothing=0.1).dice(ht, hp)), g['f16_soft_prob_laplace'].astype(F), **tol)
+    np.testing.assert_allclose(N(ne.metrics.Dice().mean_dice(ht, hp)), g['f16_mean_soft_prob'].astype(F), **tol)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        np.testing.assert_allclose(N(ne.metrics.HardDice(L, input_type='prob').dice(ht, hp)), g['f16_hard_prob'].astype(F), **tol)
+    rng = np.random.default_rng(31)
+    for Lk, S in ((32, (9, 10, 11)), (8, (7, 5, 6)), (5, (6, 5, 7)), (20, (4, 9, 3))):          # vector kernels and the generic ones
+        t32 = torch.from_numpy(rng.random((2,) + S + (Lk,)).astype(F)).to(dev)
+        p32 = torch.from_numpy(rng.random((2,) + S + (Lk,)).astype(F)).to(dev)
+        for dt in (torch.bfloat16, torch.float16):
+            t, p = t32.to(dt), p32.to(dt)
+            tw, pw = t.float(), p.float()
+            for kw in (dict(), dict(laplace_smoothing=0.3), dict(normalize=True)):
+                m = ne.metrics.Dice(check_input_limits=False, **kw)
+                d = m.dice(t, p)
+                assert d.dtype == torch.float32 and bits_equal(N(d), N(m.dice(tw, pw))), (Lk, dt, kw)
+                assert bits_equal(N(m.mean_dice(t, p)), N(m.mean_dice(tw, pw)))
+            assert bits_equal(N(ne.metrics.Dice().dice(t, p)), N(ne.metrics.Dice().dice(tw, pw)))      # range asserts on the widened extrema
+            assert bits_equal(N(ne.losses.Dice(check_input_limits=False).loss(t, p)), N(ne.losses.Dice(check_input_limits=False).loss(tw, pw)))
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                for kw in (dict(), dict(check_input_limits=False), dict(laplace_smoothing=1.0)):
+                    h = ne.metrics.HardDice(Lk, input_type='prob', **kw)
+                    assert bits_equal(N(h.dice(t, p)), N(h.dice(tw, pw))), (Lk, dt, kw)
+            # mixed storage: widened to float32
+            assert bits_equal(N(ne.metrics.Dice(check_input_limits=False).dice(t, pw)), N(ne.metrics.Dice(check_input_limits=False).dice(tw, pw)))
+        # range assert fires on 16-bit maps too
+        bad = p32.clone()
+        bad[0, 0, 0, 0, 0] = 1.5
+        with pytest.raises(ne.errors.InvalidArgumentError, match='value outside range'):
+            ne.metrics.Dice().dice(t32.bfloat16(), bad.bfloat16())
+    # gradients: float32 arithmetic, returned in the maps' dtype
+    t = torch.rand(1, 5, 6, 7, 8, device=dev).bfloat16()
+    p = torch.rand(1, 5, 6, 7, 8, device=dev).bfloat16().requires_grad_()
+    ne.metrics.Dice(check_input_limits=False).mean_dice(t, p).backward()
+    p2 = p.detach().float().requires_grad_()
+    ne.metrics.Dice(check_input_limits=False).mean_dice(t.float(), p2).backward()
+    assert p.grad.dtype == torch.bfloat16 and bits_equal(N(p.grad.float()), N(p2.grad.bfloat16().float()))
+    with pytest.raises(NotImplementedError, match='float64'):
+        ne.metrics.Dice().dice(t.double(), t.double())
+
+
 @pytest.mark.parametrize('L', [1, 3, 4, 5, 8, 16, 32, 64, 128, 256, 300])
 def test_soft_dice_label_counts(dev, L):
     rng = np.random.default_rng(L)

@@ -95,41 +95,6 @@ def test_c32_every_kernel_variant(dev, variant, tune):
             assert bits_equal(got, co.interpn(vol, ijk(S) + shift, 'linear', fill)), (kind, fill, 'abs')
 
 
-@pytest.mark.parametrize('C', [1, 2, 3, 4])
-def test_lds_staged_kernel(dev, C):
-    """variant 6 (source box of a tile staged in LDS) == generic kernel == oracle, bit for bit: smooth fields (staged),
-    rough fields (box too large -> global gathers), edge values, fill, absolute / shift / linspace locations,
-    ragged tile edges, addend epilogue (compose / VecInt)."""
-    rng = np.random.default_rng(60 + C)
-    S = (19, 13, 37)
-    vol = rng.standard_normal(S + (C,)).astype(F)
-    fields = {
-        'smooth': N(synth.smooth_displacement(5, 37, 2.0, coarse=6))[:19, :13, :37].copy(),
-        'rough': rng.uniform(-30, 30, S + (3,)).astype(F),
-        'edge': rng.choice(np.array([-3, -1, -0.5, 0, 0.5, 1, 2, 7.5], F), S + (3,)).astype(F),
-    }
-    for kind, shift in fields.items():
-        for fill in (None, 0.25):
-            want = co.interpn(vol, shift, 'linear', fill, loc_mode=1)
-            for variant in (6, 1, 0):
-                st = ne.layers.SpatialTransformer(fill_value=fill)
-                st._variant = variant
-                got = N(st([G(vol[None], dev), G(shift[None], dev)]))[0]
-                assert bits_equal(got, want), (kind, fill, variant)
-            got = N(ne.utils.interpn(G(vol, dev), G(ijk(S) + shift, dev), fill_value=fill, _variant=6))
-            assert bits_equal(got, co.interpn(vol, ijk(S) + shift, 'linear', fill)), (kind, fill, 'abs')
-    # batched, output grid different from the volume grid
-    B, So = 3, (21, 9, 18)
-    vb = rng.standard_normal((B,) + S + (C,)).astype(F)
-    tb = rng.normal(0, 2, (B,) + So + (3,)).astype(F)
-    assert bits_equal(N(ne.layers.SpatialTransformer()([G(vb, dev), G(tb, dev)])), npo.spatial_transformer(vb, tb))
-    # linspace mode (Resize x2 and x0.5) through the same kernel
-    for z in (2, 0.5):
-        got = N(ne.layers.Resize(z)(G(vb, dev)))
-        for b in range(B):
-            assert bits_equal(got[b], npo.resize(vb[b], z)), ('resize', z)
-
-
 @pytest.mark.parametrize('C', [12, 20])
 def test_channel_counts_multiple_of_four_off_the_row_kernels(dev, C):
     """float32 volumes with 12 / 20 channels (4 k, but no power of two): the auto-selection takes the rank-templated kernel of
