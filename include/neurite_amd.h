@@ -239,7 +239,10 @@ int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *lab
  * (:1601-1605) and the residual add / activation / BatchNormalization (:1401-1433).
  * All tensors channels-last float32 [batch, X, Y, Z, C]; `shape`, `ksize`, `pool`, `up` are host int[3].
  * ------------------------------------------------------------------------------------------ */
-typedef enum { NRT_ACT_NONE = 0, NRT_ACT_ELU = 1, NRT_ACT_RELU = 2, NRT_ACT_SIGMOID = 3 } nrt_activation;
+/* element-wise activations as tf.keras.activations defines them (elu alpha 1, hard_sigmoid = clip(0.2 x + 0.5, 0, 1), leaky_relu slope
+ * 0.2); accepted by every `activation` argument below.  The channel softmax is a kernel of its own (nrt_softmax_lastdim_f32). */
+typedef enum { NRT_ACT_NONE = 0, NRT_ACT_ELU = 1, NRT_ACT_RELU = 2, NRT_ACT_SIGMOID = 3, NRT_ACT_TANH = 4, NRT_ACT_SOFTPLUS = 5,
+               NRT_ACT_SOFTSIGN = 6, NRT_ACT_SELU = 7, NRT_ACT_EXPONENTIAL = 8, NRT_ACT_HARD_SIGMOID = 9, NRT_ACT_LEAKY_RELU = 10 } nrt_activation;
 /* nrt_add_act_affine_f32 only: or-ed into `activation`, y = act(a) * b instead of act(a + b) (models.add_prior, use_logp=False) */
 #define NRT_ACT_MUL_B 0x100
 

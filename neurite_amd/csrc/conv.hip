@@ -24,24 +24,14 @@
 #include <type_traits>
 
 #include "nrt_common.h"
+#include "activations.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_MUL_B = 0x100 };
-
-__device__ __forceinline__ float activate(float v, int act) {
-    if (act == ACT_ELU) return v > 0.0f ? v : (expf(v) - 1.0f);      // Keras elu, alpha = 1
-    if (act == ACT_RELU) return fmaxf(v, 0.0f);
-    return v;
-}
-
-// stand-alone Activation layers also know the sigmoid (models.py:409-411); the conv epilogues do not need it
-__device__ __forceinline__ float activate_ew(float v, int act) {
-    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
-    return activate(v, act);
-}
+__device__ __forceinline__ float activate(float v, int act) { return nrt_activate(v, act); }
+__device__ __forceinline__ float activate_ew(float v, int act) { return nrt_activate(v, act); }
 
 struct ConvArgs {
     const float *src0;       // [B, X, Y, Z, c0]
@@ -726,7 +716,7 @@ extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int 
     int rc = conv_args(a, src0, c0, src1, c1, up, bias, out, shape, ksize, cout, dilation, padding_same, activation);
     if (rc != NRT_OK) return rc;
     if (batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
-    if (activation < ACT_NONE || activation > ACT_RELU) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_LAST) return NRT_ERR_INVALID_ARG;
     hipStream_t st = nrt_stream(stream);
     const bool can_mfma = mfma_ok(a, padding_same) && packed_weights != nullptr;
     if (variant == 0) variant = can_mfma ? 2 : 1;
@@ -874,7 +864,7 @@ extern "C" int nrt_add_act_affine_f32(const float *a, const float *b, const floa
                                       long long n, int channels, int activation, void *stream) {
     if (!a || !y || n < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
     if ((scale == nullptr) != (shift == nullptr)) return NRT_ERR_INVALID_ARG;
-    if ((activation & 0xff) > ACT_SIGMOID || (activation & ~(0xff | ACT_MUL_B)) || activation < 0) return NRT_ERR_INVALID_ARG;
+    if ((activation & 0xff) > ACT_LAST || (activation & ~(0xff | ACT_MUL_B)) || activation < 0) return NRT_ERR_INVALID_ARG;
     if ((activation & ACT_MUL_B) && !b) return NRT_ERR_INVALID_ARG;
     if (n == 0) return NRT_OK;
     unsigned blocks = (unsigned)((n + 255) / 256);

@@ -18,12 +18,12 @@
 #include <type_traits>
 
 #include "nrt_common.h"
+#include "activations.h"
 
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_bwd(const nrt_f4 *__restrict__ g, const nrt_f4 *__restrict__ y, int act,
@@ -33,11 +33,7 @@ __global__ __launch_bounds__(256) void act_bwd(const nrt_f4 *__restrict__ g, con
         nrt_f4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float s = 1.0f;
-            if (act == ACT_ELU) s = yv[k] > 0.0f ? 1.0f : yv[k] + 1.0f;
-            else if (act == ACT_RELU) s = yv[k] > 0.0f ? 1.0f : 0.0f;
-            else if (act == ACT_SIGMOID) s = yv[k] * (1.0f - yv[k]);
-            o[k] = gv[k] * s;
+            o[k] = gv[k] * nrt_activate_slope(yv[k], act);
         }
         d[i] = o;
     }
@@ -47,11 +43,7 @@ __global__ __launch_bounds__(256) void act_bwd_tail(const float *__restrict__ g,
                                                     float *__restrict__ d, long long from, long long n) {
     const long long i = from + threadIdx.x;
     if (i < n) {
-        float s = 1.0f;
-        if (act == ACT_ELU) s = y[i] > 0.0f ? 1.0f : y[i] + 1.0f;
-        else if (act == ACT_RELU) s = y[i] > 0.0f ? 1.0f : 0.0f;
-        else if (act == ACT_SIGMOID) s = y[i] * (1.0f - y[i]);
-        d[i] = g[i] * s;
+        d[i] = g[i] * nrt_activate_slope(y[i], act);
     }
 }
 
@@ -557,7 +549,7 @@ unsigned ew_blocks(long long n, int per) {
 extern "C" int nrt_act_bwd_f32(const float *grad_out, const float *y, int activation, float *grad_pre, long long n,
                                void *stream) {
     if (!grad_out || !y || !grad_pre || n < 0) return NRT_ERR_INVALID_ARG;
-    if (activation < ACT_NONE || activation > ACT_SIGMOID) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_LAST) return NRT_ERR_INVALID_ARG;
     if (n == 0) return NRT_OK;
     hipStream_t st = nrt_stream(stream);
     const bool al = ((((uintptr_t)grad_out | (uintptr_t)y | (uintptr_t)grad_pre) & 15) == 0);

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "nrt_common.h"
+#include "activations.h"
 
 namespace {
 
@@ -43,11 +44,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 __device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_out(unsigned short *p, float v) { *p = f32_to_bf16(v); }
 
-__device__ __forceinline__ float lc_act(float v, int act) {
-    if (act == 1) return v > 0.0f ? v : (expf(v) - 1.0f);
-    if (act == 2) return fmaxf(v, 0.0f);
-    return v;
-}
+__device__ __forceinline__ float lc_act(float v, int act) { return nrt_activate(v, act); }
 
 template <typename T> __device__ __forceinline__ T buf_load_elem(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
 template <> __device__ __forceinline__ unsigned short buf_load_elem<unsigned short>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -248,11 +245,7 @@ struct LcBwdArgs {
 };
 
 template <typename T>
-__device__ __forceinline__ float lc_dpre(float g, float y, int act) {
-    if (act == 1) return g * (y > 0.0f ? 1.0f : y + 1.0f);
-    if (act == 2) return y > 0.0f ? g : 0.0f;
-    return g;
-}
+__device__ __forceinline__ float lc_dpre(float g, float y, int act) { return g * nrt_activate_slope(y, act); }
 
 // NB batch entries per pass (the first pass writes dK, later passes add to it: a lane owns its 16-byte slices exclusively);
 // HAS_DX: also stream the weights and scatter the input gradient.  Buffer addressing as in the forward kernel.

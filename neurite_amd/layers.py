@@ -797,8 +797,9 @@ class LocallyConnected3D(_Layer):
         if self.data_format not in ('channels_last', 'channels_first'):
             raise ValueError('The `data_format` argument must be one of "channels_first", "channels_last". Received: '
                              + str(data_format))
-        if activation not in (None, 'linear', 'elu', 'relu'):
-            raise NotImplementedError('activation %r is not fused by the HIP path (linear, elu, relu are)' % (activation,))
+        if activation != 'softmax':
+            from .models import _act_code
+            _act_code(activation)                   # NotImplementedError for what the kernels do not know
         self.activation = activation
         self.use_bias = use_bias
         self.kernel_initializer = kernel_initializer
@@ -960,7 +961,8 @@ class LocallyConnected3D(_Layer):
         w1 = self._streaming_weights()
         bias_cl = self._bias_channels_last()
         y = torch.empty([B] + O + [self.filters], dtype=x.dtype, device=dev)
-        act = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}[self.activation]
+        from .models import _ACTS
+        act = 0 if self.activation == 'softmax' else _ACTS[self.activation]       # softmax: linear epilogue + the softmax kernel below
         dt = _lib.DT_F32 if x.dtype == torch.float32 else _lib.DT_BF16
         k = w1.detach().contiguous()
         bias = None if bias_cl is None else bias_cl.detach().contiguous()
@@ -992,4 +994,7 @@ class LocallyConnected3D(_Layer):
             out = _Lc3dFn.apply(x, w1, bias_cl, run, run_backward)
         else:
             out = run()
+        if self.activation == 'softmax':            # Keras softmax: over the channel axis of the layer's data format
+            from .models import _softmax
+            out = _softmax(out.float()).to(out.dtype) if out.dtype != torch.float32 else _softmax(out)
         return out.permute(0, 4, 1, 2, 3) if self.data_format == 'channels_first' else out

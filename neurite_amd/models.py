@@ -32,15 +32,18 @@ from . import utils
 
 __all__ = ['unet', 'conv_enc', 'conv_dec', 'conv_block', 'ConvNet', 'labels_to_image', 'labels_to_image_new', 'SynthStrip', 'add_prior', 'dilation_net', 'load', 'load_config']
 
-_ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2}
-_EW_ACTS = dict(_ACTS, sigmoid=3)            # stand-alone Activation layers only (nrt_add_act_affine_f32)
+# element-wise activations, codes of include/neurite_amd.h (nrt_activation); definitions follow tf.keras.activations -- the reference
+# hands the string straight to Keras (neurite/tf/models.py:1346, 1429, 1507, 1588)
+_ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2, 'sigmoid': 3, 'tanh': 4, 'softplus': 5, 'softsign': 6, 'selu': 7,
+         'exponential': 8, 'hard_sigmoid': 9, 'leaky_relu': 10}
+_EW_ACTS = _ACTS                              # stand-alone Activation layers (nrt_add_act_affine_f32) take the same set
 _ACT_MUL_B = 0x100
 
 
 def _act_code(activation):
     if activation not in _ACTS:
-        raise NotImplementedError('activation %r is not implemented by the HIP path (elu, relu, linear/None are)'
-                                  % (activation,))
+        raise NotImplementedError('activation %r is not implemented by the HIP path (%s are; softmax as a layer activation runs as '
+                                  'its own kernel)' % (activation, ', '.join(sorted(str(k) for k in _ACTS))))
     return _ACTS[activation]
 
 
@@ -137,7 +140,9 @@ class _Conv(nn.Module):
             raise ValueError('padding must be same or valid')
         self.padding = padding
         self.activation = activation
-        self.act = _act_code(activation)
+        # the channel softmax is not element-wise: a linear epilogue, then the softmax kernel
+        self.post_softmax = activation == 'softmax'
+        self.act = 0 if self.post_softmax else _act_code(activation)
         k = self.ksize3
         fan = k[0] * k[1] * k[2]
         limit = math.sqrt(6.0 / (fan * self.cin + fan * self.cout))
@@ -182,8 +187,10 @@ class _Conv(nn.Module):
         """x [B, X, Y, Z, c0]; optional lo [B, X/up, Y/up, Z/up, c1] is nearest-upsampled and concatenated after x."""
         if torch.is_grad_enabled() and (x.requires_grad or (lo is not None and lo.requires_grad)
                                         or self.kernel.requires_grad or self.bias.requires_grad):
-            return _ConvFn.apply(x, lo, self.kernel, self.bias, self, up, variant, False)
-        return self._run(x, lo, up, variant)
+            y = _ConvFn.apply(x, lo, self.kernel, self.bias, self, up, variant, False)
+        else:
+            y = self._run(x, lo, up, variant)
+        return _softmax(y) if self.post_softmax else y
 
     def _run(self, x, lo=None, up=None, variant=0):
         lib = _lib.lib()
@@ -1056,7 +1063,7 @@ class ConvNet(nn.Module):
                 elif op['activation'] in (None, 'linear'):
                     t[name] = t[op['src']]
                 else:
-                    raise NotImplementedError('neurite_amd: training with final activation %r' % (op['activation'],))
+                    t[name] = _AddActFn.apply(t[op['src']], None, _act_code(op['activation']))
             else:
                 raise NotImplementedError('neurite_amd: training through %r layers (%s) is not implemented' % (kind, name))
         if return_tensors:

@@ -23,17 +23,44 @@ def _cl(x):
     return x.permute(0, 2, 3, 4, 1)
 
 
+def keras_activation(y, activation):
+    """tf.keras.activations (TF 2.x) restated: elu = exp(x) - 1 below 0 (alpha 1), hard_sigmoid = clip(0.2 x + 0.5, 0, 1),
+    leaky_relu slope 0.2, selu with Keras' constants, softmax over the channel (last) axis.  The reference hands the activation
+    string straight to Keras (neurite/tf/models.py:1346, 1429, 1507, 1588; layers.py:1101)."""
+    if activation in (None, 'linear'):
+        return y
+    if activation == 'elu':
+        return torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0.0)) - 1)
+    if activation == 'relu':
+        return torch.relu(y)
+    if activation == 'sigmoid':
+        return torch.sigmoid(y)
+    if activation == 'tanh':
+        return torch.tanh(y)
+    if activation == 'softplus':
+        return Fn.softplus(y, threshold=1e9)
+    if activation == 'softsign':
+        return y / (1 + y.abs())
+    if activation == 'selu':
+        scale, alpha = 1.05070098735548049342, 1.67326324235437728481
+        return scale * torch.where(y > 0, y, alpha * (torch.exp(torch.clamp(y, max=0.0)) - 1))
+    if activation == 'exponential':
+        return torch.exp(y)
+    if activation == 'hard_sigmoid':
+        return torch.clamp(0.2 * y + 0.5, 0.0, 1.0)
+    if activation == 'leaky_relu':
+        return torch.where(y > 0, y, 0.2 * y)
+    if activation == 'softmax':
+        return torch.softmax(y, -1)
+    raise NotImplementedError(activation)
+
+
 def conv3d_same(x, kernel, bias, dilation=1, activation=None, padding='same'):
     """x [B,X,Y,Z,Cin] channels-last, kernel [kx,ky,kz,Cin,Cout]; Keras Conv3D with 'same' (odd kernels) or 'valid' padding."""
     w = kernel.permute(4, 3, 0, 1, 2)
     pad = [dilation * (k - 1) // 2 for k in kernel.shape[:3]] if padding == 'same' else 0
     y = Fn.conv3d(_cf(x), w, bias, padding=pad, dilation=dilation)
-    y = _cl(y)
-    if activation == 'elu':
-        y = torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0.0)) - 1)
-    elif activation == 'relu':
-        y = torch.relu(y)
-    return y
+    return keras_activation(_cl(y), activation)
 
 
 def maxpool_same(x, pool):
@@ -95,21 +122,14 @@ def forward(net, x, params=None, return_tensors=None, dropout_scales=None, bn_tr
         elif kind == 'add':
             t[name] = t[op['a']] + t[op['b']]
         elif kind == 'activation':
-            y = t[op['src']]
-            if op['activation'] == 'elu':
-                y = torch.where(y > 0, y, torch.exp(torch.clamp(y, max=0.0)) - 1)
-            elif op['activation'] == 'relu':
-                y = torch.relu(y)
-            elif op['activation'] == 'sigmoid':
-                y = torch.sigmoid(y)
-            t[name] = y
+            t[name] = keras_activation(t[op['src']], op['activation'])
         elif kind == 'multiply':                      # KL.multiply (models.py:412-417)
             t[name] = t[op['a']] * t[op['b']]
         elif kind == 'likelihood':
             k, b = params[name]
             t[name] = conv3d_same(t[op['src']], k, b, 1, None)
         elif kind == 'prediction':
-            t[name] = torch.softmax(t[op['src']], -1) if op['activation'] == 'softmax' else t[op['src']]
+            t[name] = keras_activation(t[op['src']], op['activation'])
         else:
             raise NotImplementedError(kind)
     if return_tensors:
