@@ -995,6 +995,7 @@ class LocallyConnected3D(_Layer):
         else:
             out = run()
         if self.activation == 'softmax':            # Keras softmax: over the channel axis of the layer's data format
-            from .models import _softmax
-            out = _softmax(out.float()).to(out.dtype) if out.dtype != torch.float32 else _softmax(out)
+            from .models import _softmax, _SoftmaxFn
+            sm = _SoftmaxFn.apply if (torch.is_grad_enabled() and out.requires_grad) else _softmax
+            out = sm(out.float()).to(out.dtype) if out.dtype != torch.float32 else sm(out)
         return out.permute(0, 4, 1, 2, 3) if self.data_format == 'channels_first' else out

@@ -190,7 +190,9 @@ class _Conv(nn.Module):
             y = _ConvFn.apply(x, lo, self.kernel, self.bias, self, up, variant, False)
         else:
             y = self._run(x, lo, up, variant)
-        return _softmax(y) if self.post_softmax else y
+        if self.post_softmax:
+            return _SoftmaxFn.apply(y) if (torch.is_grad_enabled() and y.requires_grad) else _softmax(y)
+        return y
 
     def _run(self, x, lo=None, up=None, variant=0):
         lib = _lib.lib()
