@@ -16,6 +16,15 @@ enum {
 #define NRT_SELU_SCALE 1.05070098735548049342f
 #define NRT_SELU_ALPHA 1.67326324235437728481f
 
+// the activations fused into the conv / LocallyConnected3D epilogues (every other one runs as an element-wise pass over the layer
+// output, nrt_add_act_affine_f32: inlining the whole table into 32 accumulators of a tile blew the kernels up and spilled)
+__device__ __forceinline__ float nrt_activate_fused(float v, int act) {
+    if (act == ACT_ELU) return v > 0.0f ? v : (expf(v) - 1.0f);
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+#define ACT_LAST_FUSED ACT_RELU
+
 __device__ __forceinline__ float nrt_activate(float v, int act) {
     switch (act) {
         case ACT_ELU: return v > 0.0f ? v : (expf(v) - 1.0f);                    // Keras elu: exp(x) - 1, not expm1

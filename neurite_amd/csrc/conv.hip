@@ -30,7 +30,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float activate(float v, int act) { return nrt_activate(v, act); }
+__device__ __forceinline__ float activate(float v, int act) { return nrt_activate_fused(v, act); }
 __device__ __forceinline__ float activate_ew(float v, int act) { return nrt_activate(v, act); }
 
 struct ConvArgs {
@@ -716,7 +716,7 @@ extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int 
     int rc = conv_args(a, src0, c0, src1, c1, up, bias, out, shape, ksize, cout, dilation, padding_same, activation);
     if (rc != NRT_OK) return rc;
     if (batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
-    if (activation < ACT_NONE || activation > ACT_LAST) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_LAST_FUSED) return NRT_ERR_INVALID_ARG;
     hipStream_t st = nrt_stream(stream);
     const bool can_mfma = mfma_ok(a, padding_same) && packed_weights != nullptr;
     if (variant == 0) variant = can_mfma ? 2 : 1;

@@ -439,6 +439,63 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_label(const int *__restr
     }
 }
 
+// Label maps, few labels (3 L counters x 256 lanes fit in LDS: L <= 40): every LANE owns a private histogram in LDS
+// (counter (kind, label) of lane j at word (kind * L + label) * 256 + j: the lanes of an instruction hit different banks whatever
+// their labels are), so counting is three conflict-free ds_add per voxel and no ballot / shuffle / same-address queue -- blob-like
+// label maps put whole waves on one label, which made the shared-histogram form above run at 0.15 of the HBM roof
+// (profiles/r02_smallc/secondary_bench.jsonl).  Each lane streams 16-byte quads of both maps, four quads in flight.
+__global__ __launch_bounds__(DICE_BLOCK) void dice_hard_label_private(const int *__restrict__ yt, const int *__restrict__ yp,
+                                                                      long long nvox, int L, unsigned *__restrict__ ipart) {
+    extern __shared__ unsigned hist[];      // [3 * L][256]
+    const int b = blockIdx.y;
+    const int *t = yt + (long long)b * nvox;
+    const int *p = yp + (long long)b * nvox;
+    for (int i = threadIdx.x; i < 3 * L * DICE_BLOCK / 4; i += DICE_BLOCK) ((nrt_i4 *)hist)[i] = (nrt_i4){0, 0, 0, 0};
+    __syncthreads();
+    unsigned *mine = hist + threadIdx.x;
+    const unsigned uL = (unsigned)L;
+    auto count = [&](int a, int q) {
+        // tf.one_hot: an out-of-range id is an all-zero row.  The address is clamped, the increment is 0 or 1: no branch
+        const unsigned ua = (unsigned)a, uq = (unsigned)q;
+        const unsigned oka = ua < uL ? 1u : 0u, okq = uq < uL ? 1u : 0u;
+        const unsigned ca = min(ua, uL - 1u), cq = min(uq, uL - 1u);
+        atomicAdd(mine + (uL + ca) * DICE_BLOCK, oka);
+        atomicAdd(mine + (2u * uL + cq) * DICE_BLOCK, okq);
+        atomicAdd(mine + ca * DICE_BLOCK, (oka & okq & (ua == uq ? 1u : 0u)));
+    };
+    const long long n4 = ((((uintptr_t)t | (uintptr_t)p) & 15) == 0) ? nvox / 4 : 0;
+    const long long step = (long long)gridDim.x * DICE_BLOCK;
+    long long v = (long long)blockIdx.x * DICE_BLOCK + threadIdx.x;
+    for (; v + 3 * step < n4; v += 4 * step) {
+        nrt_i4 a[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = __builtin_nontemporal_load((const nrt_i4 *)t + v + u * step); q[u] = __builtin_nontemporal_load((const nrt_i4 *)p + v + u * step); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) count(a[u][j], q[u][j]);
+        }
+    }
+    for (; v < n4; v += step) {
+        const nrt_i4 a = ((const nrt_i4 *)t)[v], q = ((const nrt_i4 *)p)[v];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) count(a[j], q[j]);
+    }
+    for (long long w = n4 * 4 + (long long)blockIdx.x * DICE_BLOCK + threadIdx.x; w < nvox; w += step) count(t[w], p[w]);
+    __syncthreads();
+    // fold the 256 private histograms: two threads per counter row (3 L rows of 256 words), 128 words each, the start staggered by
+    // the row so that the threads of a wave read different banks
+    const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
+    for (int r0 = 0; r0 < 3 * L; r0 += DICE_BLOCK / 2) {
+        const int r = r0 + (threadIdx.x >> 1), half = threadIdx.x & 1;
+        unsigned sum = 0;
+        if (r < 3 * L)
+            for (int k = 0; k < DICE_BLOCK / 2; ++k) sum += hist[r * DICE_BLOCK + half * (DICE_BLOCK / 2) + ((k + r) & (DICE_BLOCK / 2 - 1))];
+        sum += __shfl_xor(sum, 1, NRT_WAVE);
+        if (r < 3 * L && half == 0) ipart[pbase * 3 * L + r] = sum;
+    }
+}
+
 __global__ void dice_counts_reduce(const long long *__restrict__ gcnt, int ngrp, int L, long long *counts) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < 3 * L; i += blockDim.x) {
@@ -662,6 +719,19 @@ extern "C" int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_p
     if (partial) {
         if (nblk > 512u) nblk = 512u;
         DiceWs w = dice_ws_carve(workspace, nlabels, batch);
+        const size_t shm_private = (size_t)3 * nlabels * DICE_BLOCK * sizeof(unsigned);
+        if (shm_private <= 120 * 1024 && nvox >= 65536) {
+            // lane-private histograms: one block per CU is resident (LDS), so size the grid to the chip
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void *)dice_hard_label_private, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+                attr = true;
+            }
+            const unsigned per_batch = (unsigned)max(1, (int)(512 / batch));
+            nblk = min(nblk, per_batch);
+            hipLaunchKernelGGL(dice_hard_label_private, dim3(nblk, batch), dim3(DICE_BLOCK), shm_private, st, (const int *)y_true,
+                               (const int *)y_pred, nvox, nlabels, w.ipart);
+        } else
         hipLaunchKernelGGL((dice_hard_label<true>), dim3(nblk, batch), dim3(DICE_BLOCK), shm, st, (const int *)y_true,
                            (const int *)y_pred, nvox, nlabels, use_lds, counts, w.ipart);
         NRT_CHECK_LAUNCH();

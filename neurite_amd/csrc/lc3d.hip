@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
 __device__ __forceinline__ void store_out(float *p, float v) { *p = v; }
 __device__ __forceinline__ void store_out(unsigned short *p, float v) { *p = f32_to_bf16(v); }
 
-__device__ __forceinline__ float lc_act(float v, int act) { return nrt_activate(v, act); }
+__device__ __forceinline__ float lc_act(float v, int act) { return nrt_activate_fused(v, act); }
 
 template <typename T> __device__ __forceinline__ T buf_load_elem(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff);
 template <> __device__ __forceinline__ unsigned short buf_load_elem<unsigned short>(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -55,26 +55,32 @@ template <> __device__ __forceinline__ float buf_load_elem<float>(__amdgpu_buffe
 }
 
 // T = float or unsigned short (bf16 bits); VEC = elements per 16-byte load; NB = batch entries per pass
-template <typename T, int NB, int MAXIT, bool NT>
+// SPLIT = 2: layers with more than 16 row groups per lane (32 filters in bfloat16: 27) -- two waves share a position, each streams
+// half of the rows with the 16-group registers budget and the halves meet in LDS (one wave with all 32 groups in flight spilled
+// 200 registers to scratch)
+template <typename T, int NB, int MAXIT, bool NT, int SPLIT = 1>
 __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
     constexpr int VEC = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     const int LPR = a.Cout / VEC;                  // lanes per weight row (power of two, <= 64)
     const int RPW = 64 / LPR;                      // weight rows per wave iteration
     const int F = a.kr * a.kc * a.kz * a.Cin;
-    const int nit = (F + RPW - 1) / RPW;           // <= MAXIT
+    const int nit = (F + RPW - 1) / RPW;           // <= MAXIT * SPLIT
     const long long O = (long long)a.orr * a.occ * a.ozz;
     const int lane = threadIdx.x & 63;
     const int sl = lane % LPR, row0 = lane / LPR;
-    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform
+    const int part = wave % SPLIT, itb = part * MAXIT;                        // this wave's row groups: itb .. itb + MAXIT - 1
+    const long long nwaves = (long long)gridDim.x * ((blockDim.x >> 6) / SPLIT);
     const T *xb = (const T *)a.x;
+    __shared__ float red[SPLIT > 1 ? 2 * 4 * 64 : 1];                         // [positions of a block][NB][Cout <= 64]
     // a lane touches the same patch elements f = it * RPW + row0 at every position: their offsets
     // relative to the patch origin are computed once (the divisions are not in the streaming loop)
     int xoff[MAXIT];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        const int f = it * RPW + row0;
-        const int ff = ((it < nit) && (f < F)) ? f : F - 1;   // dead slots re-read a valid element (no branch around loads)
+        const int f = (itb + it) * RPW + row0;
+        const int ff = ((itb + it < nit) && (f < F)) ? f : F - 1;   // dead slots re-read a valid element (no branch around loads)
         const int ci = ff % a.Cin, tap = ff / a.Cin;
         const int dz = tap % a.kz, dc = (tap / a.kz) % a.kc, dr = tap / (a.kz * a.kc);
         xoff[it] = ((dr * a.C + dc) * a.Z + dz) * a.Cin + ci;
@@ -87,45 +93,56 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
     const unsigned w0 = (unsigned)lane * 16u;
     const unsigned wbytes = (unsigned)F * (unsigned)a.Cout * (unsigned)sizeof(T);
     const long long xbs = (long long)a.R * a.C * a.Z * a.Cin;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform
     unsigned xvoff[MAXIT];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) xvoff[it] = (unsigned)xoff[it] * (unsigned)sizeof(T);
-    for (long long o = (long long)blockIdx.x * (blockDim.x >> 6) + wave; o < O; o += nwaves) {
+    // (every wave of a block runs the same number of rounds: the SPLIT form meets at block barriers)
+    for (long long ob = (long long)blockIdx.x * ((blockDim.x >> 6) / SPLIT); ob < O; ob += nwaves) {
+        const long long oreal = ob + wave / SPLIT;
+        const bool oact = oreal < O;
+        const long long o = oact ? oreal : O - 1;
         const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
         const unsigned xbase = (unsigned)((((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin * (long long)sizeof(T));
         const char *kp = (const char *)((const T *)a.k + o * (long long)F * a.Cout);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)kp, 0, (int)wbytes, 0x00020000);
-        // ---- issue every load of this position before the first use ---------------------------------------
-        vec_t w[MAXIT];
-        T xr[NB][MAXIT];
-#pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, it * 1024, NT ? 2 : 0);
-            w[it] = __builtin_bit_cast(vec_t, raw);
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
-#pragma unroll
-            for (int it = 0; it < MAXIT; ++it) xr[b][it] = buf_load_elem<T>(xres, xvoff[it], xbase);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        // ---- issue the loads of (up to) 16 weight rows and their patch elements before the first use; layers with more rows per
+        // lane (32 filters in bfloat16: 27) take two such chunks -- all 32 at once needs more registers than a wave has and
+        // spilled to scratch ---------------------------------------------------------------------------------
+        constexpr int CH = MAXIT;                 // (one chunk: every instantiation has at most 16 row groups per wave)
         float acc[NB][VEC];
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) acc[b][e] = 0.0f;
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
-            const bool live = (it < nit) && (it * RPW + row0 < F);
+        for (int c0 = 0; c0 < MAXIT; c0 += CH) {
+            vec_t w[CH];
+            T xr[NB][CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, (itb + c0 + i) * 1024, NT ? 2 : 0);
+                w[i] = __builtin_bit_cast(vec_t, raw);
+            }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                const float xv = live ? to_f32(xr[b][it]) : 0.0f;
+                const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[b][e] = fmaf(xv, to_f32(w[it][e]), acc[b][e]);
+                for (int i = 0; i < CH; ++i) xr[b][i] = buf_load_elem<T>(xres, xvoff[c0 + i], xbase);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int it = itb + c0 + i;
+                const bool live = (it < nit) && (it * RPW + row0 < F);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const float xv = live ? to_f32(xr[b][i]) : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[b][e] = fmaf(xv, to_f32(w[i][e]), acc[b][e]);
+                }
+            }
+            if (c0 + CH < MAXIT) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- combine the 64 / LPR row slices ----------------------------------------------------
 #pragma unroll
@@ -133,7 +150,24 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 for (int off = LPR; off < 64; off <<= 1) acc[b][e] += __shfl_xor(acc[b][e], off, 64);
-        if (lane < LPR) {
+        if (SPLIT > 1) {                                 // the second wave's half of the sum goes through LDS
+            float *rp = red + (wave / SPLIT) * (4 * 64);
+            if (part == 1 && lane < LPR) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) rp[b * 64 + sl * VEC + e] = acc[b][e];
+            }
+            __syncthreads();
+            if (part == 0 && lane < LPR) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[b][e] += rp[b * 64 + sl * VEC + e];
+            }
+            __syncthreads();
+        }
+        if (lane < LPR && part == 0 && oact) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 if (b < nb) {
@@ -176,28 +210,28 @@ __global__ __launch_bounds__(256) void lc3d_generic(LcArgs a) {
     }
 }
 
-template <typename T, int MAXIT, bool NT>
+template <typename T, int MAXIT, bool NT, int SPLIT = 1>
 void launch_vec_nt(const LcArgs &a, unsigned blocks, hipStream_t st) {
     for (int b0 = 0; b0 < a.B; b0 += 4) {
         const int nb = a.B - b0 < 4 ? a.B - b0 : 4;
-        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT, NT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
-        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT, NT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
-        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT, NT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT, NT, SPLIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT, NT, SPLIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT, NT, SPLIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
     }
 }
 
-template <typename T, int MAXIT>
+template <typename T, int MAXIT, int SPLIT = 1>
 void launch_vec(const LcArgs &a, hipStream_t st) {
     // experiment knobs: NRT_LC_BLOCKS (grid size), NRT_LC_NT (0: plain weight loads)
     static int kblocks = -1, knt = -1;
     if (kblocks < 0) { const char *e = getenv("NRT_LC_BLOCKS"); kblocks = e ? atoi(e) : 0; }
     if (knt < 0) { const char *e = getenv("NRT_LC_NT"); knt = e ? atoi(e) : 1; }
     const long long O = (long long)a.orr * a.occ * a.ozz;
-    unsigned blocks = (unsigned)((O + 3) / 4);
+    unsigned blocks = (unsigned)((O + 4 / SPLIT - 1) / (4 / SPLIT));
     const unsigned cap = kblocks > 0 ? (unsigned)kblocks : 256u * 20u;     // 5 resident blocks per CU x 4 rounds (profiles/)
     if (blocks > cap) blocks = cap;
-    if (knt) launch_vec_nt<T, MAXIT, true>(a, blocks, st);
-    else launch_vec_nt<T, MAXIT, false>(a, blocks, st);
+    if (knt) launch_vec_nt<T, MAXIT, true, SPLIT>(a, blocks, st);
+    else launch_vec_nt<T, MAXIT, false, SPLIT>(a, blocks, st);
 }
 
 template <typename T>
@@ -217,7 +251,7 @@ int launch_any(const LcArgs &a, int variant, hipStream_t st) {
         if (nit <= 8) launch_vec<T, 8>(a, st);
         else if (nit <= 14) launch_vec<T, 14>(a, st);
         else if (nit <= 16) launch_vec<T, 16>(a, st);
-        else launch_vec<T, 32>(a, st);
+        else launch_vec<T, 16, 2>(a, st);                 // up to 32 row groups: two waves per position
     } else {
         const long long total = (long long)a.orr * a.occ * a.ozz * a.Cout;
         unsigned blocks = (unsigned)((total + 255) / 256);
@@ -249,7 +283,7 @@ __device__ __forceinline__ float lc_dpre(float g, float y, int act) { return g *
 
 // NB batch entries per pass (the first pass writes dK, later passes add to it: a lane owns its 16-byte slices exclusively);
 // HAS_DX: also stream the weights and scatter the input gradient.  Buffer addressing as in the forward kernel.
-template <typename T, int MAXIT, int NB, bool HAS_DX>
+template <typename T, int MAXIT, int NB, bool HAS_DX, int SPLIT = 1>
 __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb) {
     const LcArgs &a = ba.f;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -260,13 +294,15 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb)
     const long long O = (long long)a.orr * a.occ * a.ozz;
     const int lane = threadIdx.x & 63;
     const int sl = lane % LPR, row0 = lane / LPR;
-    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int part = wave % SPLIT, itb = part * MAXIT;           // SPLIT = 2: two waves share a position, each owns half of the row groups
+    const long long nwaves = (long long)gridDim.x * ((blockDim.x >> 6) / SPLIT);
     const T *xb = (const T *)a.x;
     unsigned xvoff[MAXIT];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        const int f = it * RPW + row0;
-        const int ff = ((it < nit) && (f < F)) ? f : F - 1;
+        const int f = (itb + it) * RPW + row0;
+        const int ff = ((itb + it < nit) && (f < F)) ? f : F - 1;
         const int ci = ff % a.Cin, tap = ff / a.Cin;
         const int dz = tap % a.kz, dc = (tap / a.kz) % a.kc, dr = tap / (a.kz * a.kc);
         xvoff[it] = (unsigned)((((dr * a.C + dc) * a.Z + dz) * a.Cin + ci) * (int)sizeof(T));
@@ -274,28 +310,10 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb)
     const unsigned w0 = (unsigned)lane * 16u;
     const unsigned wbytes = (unsigned)F * (unsigned)a.Cout * (unsigned)sizeof(T);
     const long long xbs = (long long)a.R * a.C * a.Z * a.Cin;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (long long o = (long long)blockIdx.x * (blockDim.x >> 6) + wave; o < O; o += nwaves) {
+    for (long long o = (long long)blockIdx.x * ((blockDim.x >> 6) / SPLIT) + wave / SPLIT; o < O; o += nwaves) {
         const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
         const long long xbase_e = (((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin;
         const unsigned xbase = (unsigned)(xbase_e * (long long)sizeof(T));
-        // ---- issue the loads: patch elements of the NB batch entries, the weight slices if dx is wanted ----------------
-        T xr[NB][MAXIT];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
-#pragma unroll
-            for (int it = 0; it < MAXIT; ++it) xr[b][it] = buf_load_elem<T>(xres, xvoff[it], xbase);
-        }
-        vec_t w[HAS_DX ? MAXIT : 1];
-        if (HAS_DX) {
-            const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-                (void *)((const char *)a.k + o * (long long)wbytes), 0, (int)wbytes, 0x00020000);
-#pragma unroll
-            for (int it = 0; it < MAXIT; ++it)
-                w[HAS_DX ? it : 0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(wr, w0, it * 1024, 2));
-        }
         // ---- this lane's cout slice of dpre[b][o] -------------------------------------------------------------------------
         float dp[NB][VEC], db[VEC];
 #pragma unroll
@@ -315,10 +333,32 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) db[e] += dp[b][e];
         }
-        __builtin_amdgcn_sched_barrier(0);
         char *dkp = ba.dk ? (char *)ba.dk + o * (long long)wbytes : nullptr;
+        // the patch elements (and, for dx, the weight slices) of a chunk of row groups are in flight at a time: 8 where 16 of them with
+        // four batch entries and the weights would not fit in the registers
+        constexpr int CH = (MAXIT >= 16 && HAS_DX && NB == 4) ? 8 : MAXIT;
 #pragma unroll
-        for (int it = 0; it < MAXIT; ++it) {
+        for (int c0 = 0; c0 < MAXIT; c0 += CH) {
+        T xr[NB][CH];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) xr[b][i] = buf_load_elem<T>(xres, xvoff[c0 + i], xbase);
+        }
+        vec_t w[HAS_DX ? CH : 1];
+        if (HAS_DX) {
+            const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)((const char *)a.k + o * (long long)wbytes), 0, (int)wbytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                w[HAS_DX ? i : 0] = __builtin_bit_cast(vec_t, __builtin_amdgcn_raw_buffer_load_b128(wr, w0, (itb + c0 + i) * 1024, 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int it = itb + c0 + i;
             const bool live = (it < nit) && (it * RPW + row0 < F);
             const unsigned off = w0 + (unsigned)it * 1024u;
             if (dkp && off < wbytes) {
@@ -327,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb)
                 for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const float xv = live ? to_f32(xr[b][it]) : 0.0f;
+                    const float xv = live ? to_f32(xr[b][i]) : 0.0f;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) acc[e] = fmaf(xv, dp[b][e], acc[e]);
                 }
@@ -347,14 +387,15 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb)
                 for (int b = 0; b < NB; ++b) {
                     float t = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) t = fmaf(to_f32(w[HAS_DX ? it : 0][e]), dp[b][e], t);
+                    for (int e = 0; e < VEC; ++e) t = fmaf(to_f32(w[HAS_DX ? i : 0][e]), dp[b][e], t);
                     for (int off2 = 1; off2 < LPR; off2 <<= 1) t += __shfl_xor(t, off2, 64);      // over the cout slices of row f
                     if (live && sl == 0 && b < nb)
-                        unsafeAtomicAdd(ba.dx + (long long)(b0 + b) * xbs + xbase_e + (long long)(xvoff[it] / (unsigned)sizeof(T)), t);
+                        unsafeAtomicAdd(ba.dx + (long long)(b0 + b) * xbs + xbase_e + (long long)(xvoff[c0 + i] / (unsigned)sizeof(T)), t);
                 }
             }
         }
-        if (ba.dbias && lane < LPR) {
+        }
+        if (ba.dbias && lane < LPR && part == 0) {
             T *dbp = (T *)ba.dbias + o * a.Cout + sl * VEC;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -366,14 +407,14 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb)
     }
 }
 
-template <typename T, int MAXIT>
+template <typename T, int MAXIT, int SPLIT = 1>
 void launch_bwd_it(const LcBwdArgs &ba, unsigned blocks, hipStream_t st) {
     const int B = ba.f.B;
     for (int b0 = 0; b0 < B; b0 += 4) {
         const int nb = B - b0 < 4 ? B - b0 : 4;
 #define NRT_LCB(NBV)                                                                                               \
-        if (ba.dx) hipLaunchKernelGGL((lc3d_bwd<T, MAXIT, NBV, true>), dim3(blocks), dim3(256), 0, st, ba, b0, nb); \
-        else hipLaunchKernelGGL((lc3d_bwd<T, MAXIT, NBV, false>), dim3(blocks), dim3(256), 0, st, ba, b0, nb)
+        if (ba.dx) hipLaunchKernelGGL((lc3d_bwd<T, MAXIT, NBV, true, SPLIT>), dim3(blocks), dim3(256), 0, st, ba, b0, nb); \
+        else hipLaunchKernelGGL((lc3d_bwd<T, MAXIT, NBV, false, SPLIT>), dim3(blocks), dim3(256), 0, st, ba, b0, nb)
         if (nb == 1) { NRT_LCB(1); } else if (nb == 2) { NRT_LCB(2); } else { NRT_LCB(4); }
 #undef NRT_LCB
     }
@@ -397,7 +438,7 @@ int launch_bwd(const LcBwdArgs &ba, hipStream_t st) {
     if (nit <= 8) launch_bwd_it<T, 8>(ba, blocks, st);
     else if (nit <= 14) launch_bwd_it<T, 14>(ba, blocks, st);
     else if (nit <= 16) launch_bwd_it<T, 16>(ba, blocks, st);
-    else launch_bwd_it<T, 32>(ba, blocks, st);
+    else launch_bwd_it<T, 16, 2>(ba, (unsigned)min((long long)256 * 16, (O + 1) / 2), st);      // two waves per position
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

@@ -963,6 +963,7 @@ class LocallyConnected3D(_Layer):
         y = torch.empty([B] + O + [self.filters], dtype=x.dtype, device=dev)
         from .models import _ACTS
         act = 0 if self.activation == 'softmax' else _ACTS[self.activation]       # softmax: linear epilogue + the softmax kernel below
+        kact = act if act <= 2 else 0               # elu / relu are fused; the other activations run as an element-wise pass
         dt = _lib.DT_F32 if x.dtype == torch.float32 else _lib.DT_BF16
         k = w1.detach().contiguous()
         bias = None if bias_cl is None else bias_cl.detach().contiguous()
@@ -971,9 +972,12 @@ class LocallyConnected3D(_Layer):
         def run():
             with torch.cuda.device(dev):
                 rc = lib.nrt_lc3d_f(_lib.ptr(xd), _lib.ptr(k), _lib.ptr(bias), _lib.ptr(y), dt, B, _lib.ints(S), cin,
-                                    _lib.ints(self.kernel_size), _lib.ints(self.strides), self.filters, act,
+                                    _lib.ints(self.kernel_size), _lib.ints(self.strides), self.filters, kact,
                                     int(self._variant), _lib.stream_ptr(dev))
             _lib.check(rc, 'nrt_lc3d_f')
+            if act > 2:
+                from .models import _elementwise
+                y.copy_(_elementwise(y.float(), act=act))        # in place: the backward reads the activated output
             return y
 
         def run_backward(g, need_x, need_k, need_b):

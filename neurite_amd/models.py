@@ -38,6 +38,7 @@ _ACTS = {None: 0, 'linear': 0, 'elu': 1, 'relu': 2, 'sigmoid': 3, 'tanh': 4, 'so
          'exponential': 8, 'hard_sigmoid': 9, 'leaky_relu': 10}
 _EW_ACTS = _ACTS                              # stand-alone Activation layers (nrt_add_act_affine_f32) take the same set
 _ACT_MUL_B = 0x100
+_ACT_LAST_FUSED = 2          # elu, relu are fused into the conv / LocallyConnected3D epilogues; the others run as an element-wise pass
 
 
 def _act_code(activation):
@@ -220,8 +221,11 @@ class _Conv(nn.Module):
             rc = lib.nrt_conv3d_f32(_lib.ptr(x), c0, _lib.ptr(lo), c1, _lib.ints(up) if lo is not None else None,
                                     _lib.ptr(w), _lib.ptr(self._packed_weights()), _lib.ptr(self.bias.detach()),
                                     _lib.ptr(out), B, _lib.ints(S), _lib.ints(self.ksize3), self.cout, self.dilation,
-                                    int(self.padding == 'same'), self.act, int(variant), _lib.stream_ptr(dev))
+                                    int(self.padding == 'same'), self.act if self.act <= _ACT_LAST_FUSED else 0, int(variant),
+                                    _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_conv3d_f32')
+        if self.act > _ACT_LAST_FUSED:            # activations beyond elu / relu: an element-wise pass over the layer output
+            out = _elementwise(out, act=self.act)
         return out
 
 

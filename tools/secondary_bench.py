@@ -41,4 +41,13 @@ row('mean_dice (weights [1, L])', timeit(lambda: ne.metrics.Dice(weights=w[None]
 st = ne.layers.SpatialTransformer(interp_method='nearest')
 row('nearest warp [4,160^3,32]', timeit(lambda: st([mov, trf])), nvox * 268)
 lab1 = lt[..., None].to(torch.float32)
-row('nearest warp of a label map + one-hot', timeit(lambda: torch.nn.functional.one_hot(st([lab1, trf])[..., 0].long(), L)), nvox * (4 + 12 + 4))
+# the output stage of labels_to_image as the product runs it (neurite/tf/models.py:806-807 + one_hot): nearest warp of the label map
+# (4 + 12 B read, 4 B written per voxel), then the LUT + one-hot kernel (4 B read, 4 L written)
+from neurite_amd import _lib
+lut = torch.arange(L, dtype=torch.int32, device=dev)
+oh = torch.empty((B, S, S, S, L), dtype=torch.float32, device=dev)
+def warp_onehot():
+    idx = st([lab1, trf])
+    rc = _lib.lib().nrt_synth_labels_out(_lib.ptr(idx), _lib.ptr(lut), L, L, _lib.ptr(oh), None, nvox, _lib.stream_ptr(dev))
+    assert rc == 0
+row('nearest warp of a label map + LUT / one-hot (labels_to_image output stage)', timeit(warp_onehot), nvox * (4 + 12 + 4 + 4 + 4 * L))
