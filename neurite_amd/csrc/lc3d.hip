@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
     const int part = wave % SPLIT, itb = part * MAXIT;                        // this wave's row groups: itb .. itb + MAXIT - 1
     const long long nwaves = (long long)gridDim.x * ((blockDim.x >> 6) / SPLIT);
     const T *xb = (const T *)a.x;
-    __shared__ float red[SPLIT > 1 ? 2 * 4 * 64 : 1];                         // [positions of a block][NB][Cout <= 64]
+    __shared__ float red[SPLIT > 1 ? 3 * 4 * 64 : 1];                         // [positions of a block x other parts <= 3][NB][Cout <= 64]
     // a lane touches the same patch elements f = it * RPW + row0 at every position: their offsets
     // relative to the patch origin are computed once (the divisions are not in the streaming loop)
     int xoff[MAXIT];
@@ -150,20 +150,22 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e)
                 for (int off = LPR; off < 64; off <<= 1) acc[b][e] += __shfl_xor(acc[b][e], off, 64);
-        if (SPLIT > 1) {                                 // the second wave's half of the sum goes through LDS
-            float *rp = red + (wave / SPLIT) * (4 * 64);
-            if (part == 1 && lane < LPR) {
+        if (SPLIT > 1) {                                 // the other waves' shares of the sum go through LDS
+            float *rp = red + (wave / SPLIT) * ((SPLIT - 1) * 4 * 64);
+            if (part > 0 && lane < LPR) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) rp[b * 64 + sl * VEC + e] = acc[b][e];
+                    for (int e = 0; e < VEC; ++e) rp[((part - 1) * 4 + b) * 64 + sl * VEC + e] = acc[b][e];
             }
             __syncthreads();
             if (part == 0 && lane < LPR) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b)
+                for (int q = 0; q < SPLIT - 1; ++q)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[b][e] += rp[b * 64 + sl * VEC + e];
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[b][e] += rp[(q * 4 + b) * 64 + sl * VEC + e];
             }
             __syncthreads();
         }
@@ -242,7 +244,7 @@ int launch_any(const LcArgs &a, int variant, hipStream_t st) {
     int LPR = vec_ok ? a.Cout / VEC : 0;
     vec_ok = vec_ok && LPR >= 1 && LPR <= 64 && (LPR & (LPR - 1)) == 0 && (((uintptr_t)a.k) & 15) == 0;
     int nit = vec_ok ? (F + (64 / LPR) - 1) / (64 / LPR) : 0;
-    vec_ok = vec_ok && nit <= 32;
+    vec_ok = vec_ok && nit <= 64;
     vec_ok = vec_ok && (long long)a.R * a.C * a.Z * a.Cin * (long long)sizeof(T) < (1ll << 31) &&
              (long long)F * a.Cout * (long long)sizeof(T) < (1ll << 31);          // 32-bit buffer offsets
     if (variant == 0) variant = vec_ok ? 2 : 1;
@@ -251,7 +253,8 @@ int launch_any(const LcArgs &a, int variant, hipStream_t st) {
         if (nit <= 8) launch_vec<T, 8>(a, st);
         else if (nit <= 14) launch_vec<T, 14>(a, st);
         else if (nit <= 16) launch_vec<T, 16>(a, st);
-        else launch_vec<T, 16, 2>(a, st);                 // up to 32 row groups: two waves per position
+        else if (nit <= 32) launch_vec<T, 16, 2>(a, st);  // up to 32 row groups: two waves per position
+        else launch_vec<T, 16, 4>(a, st);                 // up to 64 (32 filters in float32: 54): four
     } else {
         const long long total = (long long)a.orr * a.occ * a.ozz * a.Cout;
         unsigned blocks = (unsigned)((total + 255) / 256);
@@ -429,7 +432,7 @@ int launch_bwd(const LcBwdArgs &ba, hipStream_t st) {
     const int LPR = a.Cout / VEC;
     if (LPR < 1 || LPR > 64 || (LPR & (LPR - 1))) return NRT_ERR_UNSUPPORTED;
     const int nit = (F + (64 / LPR) - 1) / (64 / LPR);
-    if (nit > 32 || (long long)F * a.Cout * (long long)sizeof(T) >= (1ll << 31)) return NRT_ERR_UNSUPPORTED;
+    if (nit > 64 || (long long)F * a.Cout * (long long)sizeof(T) >= (1ll << 31)) return NRT_ERR_UNSUPPORTED;
     if ((((uintptr_t)a.k | (uintptr_t)ba.g | (uintptr_t)a.y | (uintptr_t)ba.dk) & 15) != 0) return NRT_ERR_UNSUPPORTED;
     const long long O = (long long)a.orr * a.occ * a.ozz;
     unsigned blocks = (unsigned)((O + 3) / 4);
@@ -438,7 +441,8 @@ int launch_bwd(const LcBwdArgs &ba, hipStream_t st) {
     if (nit <= 8) launch_bwd_it<T, 8>(ba, blocks, st);
     else if (nit <= 14) launch_bwd_it<T, 14>(ba, blocks, st);
     else if (nit <= 16) launch_bwd_it<T, 16>(ba, blocks, st);
-    else launch_bwd_it<T, 16, 2>(ba, (unsigned)min((long long)256 * 16, (O + 1) / 2), st);      // two waves per position
+    else if (nit <= 32) launch_bwd_it<T, 16, 2>(ba, (unsigned)min((long long)256 * 16, (O + 1) / 2), st);      // two waves per position
+    else launch_bwd_it<T, 16, 4>(ba, (unsigned)min((long long)256 * 16, O), st);                             // four
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

@@ -1,6 +1,7 @@
 """Secondary entries of the metric rows at the headline shape, 4 x 160^3: ms and fraction of the HBM roof
 of their algorithmic bytes -- a sweep for outliers (the min-max reduction of round 1 hid 2000 same-address atomics)."""
-import json, torch
+import json, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import neurite_amd as ne
 from neurite_amd import synth
 dev = torch.device('cuda:0')
