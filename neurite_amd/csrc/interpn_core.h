@@ -149,10 +149,11 @@ inline unsigned xmarch_setup(const int *out_shape, int batch, int t, TileGeom &t
     const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;             // regions are padded; out-of-range patches are empty blocks
     tg.ncol = ((tg.nTy + RY - 1) / RY) * ((tg.nTz + RZ - 1) / RZ) * RY * RZ;
     unsigned nseg = (unsigned)(t >> 16) & 0xffu;
-    if (nseg == 0) {                                                 // auto: at least six blocks per CU over the launch
+    if (nseg == 0) {                                                 // auto: at least twelve blocks per CU over the launch
         // (one block is resident per CU, so a launch runs in rounds of 256 blocks: 800 blocks = one 160^3 volume leave the
         // fourth round 12 % full; measured at batch 1: 0.358 ms with 1 segment, 0.328 with 2-4, tools/b1_nseg_sweep.sh)
-        nseg = (1536u + tg.ncol * batch - 1) / (tg.ncol * batch);
+        // (round 3, tools/b1_sweep.py: 0.326 ms with 4 segments at batch 1 whatever the blocks per CU and the region shape, 0.330 with 2)
+        nseg = (3072u + tg.ncol * batch - 1) / (tg.ncol * batch);
         if (nseg < 1) nseg = 1;
     }
     if (nseg > (unsigned)out_shape[0]) nseg = (unsigned)out_shape[0];
