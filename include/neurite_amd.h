@@ -265,6 +265,23 @@ int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int c1, const i
                    int batch, const int *shape, const int *ksize, int cout, int dilation,
                    int padding_same, int activation, int variant, void *stream);
 
+/*
+ * The decoder convolution of models.unet (neurite/tf/models.py:1531-1555: UpSampling3D(2) -> concatenate([skip, up]) ->
+ * Conv3D 3x3x3 SAME) with the up-sampled half FOLDED: on a nearest-up-sampled tensor the 27 taps collapse to 8 taps
+ * on the low-resolution grid, with one of 8 pre-summed weight sets chosen by the parity of the output voxel
+ * (K = 27 c0 + 8 c1 instead of 27 (c0 + c1)).  Same result as nrt_conv3d_f32(skip, c0, lo, c1, up = {2,2,2}, ...)
+ * up to float32 rounding of the weight sums.  c0 % 16 == 0, c1 % 16 == 0, cout <= 64, activation none / elu / relu.
+ *   nrt_conv3d_up2_supported            1 when the shapes qualify (otherwise use nrt_conv3d_f32)
+ *   nrt_conv3d_up2_packed_weight_floats size of the folded, fragment-ordered weights
+ *   nrt_conv3d_up2_pack_weights_f32     weights Keras layout [3,3,3,c0+c1,cout] -> packed
+ */
+int nrt_conv3d_up2_supported(int c0, int c1, int cout, const int *shape);
+size_t nrt_conv3d_up2_packed_weight_floats(int c0, int c1, int cout);
+int nrt_conv3d_up2_pack_weights_f32(const float *weights, int c0, int c1, int cout, float *packed, void *stream);
+int nrt_conv3d_up2_f32(const float *skip /* [batch, shape, c0] */, int c0, const float *lo /* [batch, shape/2, c1] */, int c1,
+                       const float *packed_weights, const float *bias, float *out, int batch, const int *shape, int cout,
+                       int activation, void *stream);
+
 /* 1x1 convolution with the channel softmax (or an activation) fused; cout <= 64. x [nvox, cin]. */
 int nrt_conv1x1_softmax_f32(const float *x, const float *weights /* [cin, cout] */, const float *bias,
                             float *y, long long nvox, int cin, int cout, int softmax, int activation,

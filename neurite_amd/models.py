@@ -151,6 +151,8 @@ class _Conv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(self.cout))
         self._packed = None
         self._packed_version = None
+        self._packed_up2 = None                      # folded weights of the decoder form (see _run), keyed like _packed + c0
+        self._packed_up2_version = None
 
     def invalidate_packed(self):
         """forget the MFMA-packed copy of the kernel.  The cache key below sees in-place writes through the Parameter
@@ -159,6 +161,8 @@ class _Conv(nn.Module):
         `load_state_dict`, and it is never used while the model is in training mode."""
         self._packed = None
         self._packed_version = None
+        self._packed_up2 = None
+        self._packed_up2_version = None
 
     def train(self, mode=True):
         self.invalidate_packed()
@@ -183,6 +187,24 @@ class _Conv(nn.Module):
             _lib.check(rc, 'nrt_conv3d_pack_weights_f32')
             self._packed, self._packed_version = packed, ver
         return self._packed
+
+    def _packed_weights_up2(self, c0):
+        """the kernel folded for nrt_conv3d_up2_f32: skip channels [0, c0) keep their 27 taps, the up-sampled channels
+        get 8 parity classes x 8 taps of pre-summed weights"""
+        ver = (self.kernel._version, self.kernel.data_ptr(), self.kernel.device, int(c0))
+        if self.training:
+            self._packed_up2 = None
+        if self._packed_up2 is None or self._packed_up2_version != ver:
+            lib = _lib.lib()
+            dev = self.kernel.device
+            n = lib.nrt_conv3d_up2_packed_weight_floats(int(c0), self.cin - int(c0), self.cout)
+            packed = torch.empty(int(n), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                rc = lib.nrt_conv3d_up2_pack_weights_f32(_lib.ptr(self.kernel.detach().contiguous()), int(c0), self.cin - int(c0),
+                                                         self.cout, _lib.ptr(packed), _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_conv3d_up2_pack_weights_f32')
+            self._packed_up2, self._packed_up2_version = packed, ver
+        return self._packed_up2
 
     def forward(self, x, lo=None, up=None, variant=0):
         """x [B, X, Y, Z, c0]; optional lo [B, X/up, Y/up, Z/up, c1] is nearest-upsampled and concatenated after x."""
@@ -217,6 +239,22 @@ class _Conv(nn.Module):
             O = [S[d] - (self.ksize3[d] - 1) * self.dilation for d in range(3)]
         out = torch.empty([B] + O + [self.cout], dtype=torch.float32, device=dev)
         w = self.kernel.detach().contiguous()
+        # decoder form (UpSampling3D(2) + concatenate + 3x3x3 SAME): the up-sampled half runs as 8 folded taps on the
+        # low-resolution grid (variant 0 = auto, 4 = required; 2 keeps the plain implicit GEMM over all 27 taps)
+        folded = (variant in (0, 4) and lo is not None and tuple(up) == (2, 2, 2) and self.ksize3 == (3, 3, 3)
+                  and self.dilation == 1 and self.padding == 'same'
+                  and lib.nrt_conv3d_up2_supported(c0, c1, self.cout, _lib.ints(S)) == 1)
+        if variant == 4 and not folded:
+            raise NotImplementedError('%s: shapes outside the folded decoder kernel' % self.layer_name)
+        if folded:
+            with torch.cuda.device(dev):
+                rc = lib.nrt_conv3d_up2_f32(_lib.ptr(x), c0, _lib.ptr(lo), c1, _lib.ptr(self._packed_weights_up2(c0)),
+                                            _lib.ptr(self.bias.detach()), _lib.ptr(out), B, _lib.ints(S), self.cout,
+                                            self.act if self.act <= _ACT_LAST_FUSED else 0, _lib.stream_ptr(dev))
+            _lib.check(rc, 'nrt_conv3d_up2_f32')
+            if self.act > _ACT_LAST_FUSED:
+                out = _elementwise(out, act=self.act)
+            return out
         with torch.cuda.device(dev):
             rc = lib.nrt_conv3d_f32(_lib.ptr(x), c0, _lib.ptr(lo), c1, _lib.ints(up) if lo is not None else None,
                                     _lib.ptr(w), _lib.ptr(self._packed_weights()), _lib.ptr(self.bias.detach()),

@@ -86,6 +86,45 @@ def test_conv3d_fused_upsample_concat(dev):
             np.testing.assert_allclose(y, y2, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('c0,c1,cout,S,act', [
+    (16, 32, 16, (8, 8, 32), 'elu'),          # the last decoder level of BASELINE config 3, whole tiles
+    (32, 64, 32, (8, 12, 16), 'elu'),         # the level above (two N-tiles)
+    (16, 16, 5, (10, 6, 18), None),           # ragged tiles along every axis, partial N-tile
+    (32, 16, 48, (6, 14, 34), 'relu'),        # three N-tiles, skip wider than the up-sampled tensor
+    (16, 48, 64, (4, 4, 16), 'elu'),          # one tile: every border at once
+    (16, 32, 16, (2, 2, 2), None),            # smaller than a tile
+])
+def test_conv3d_folded_decoder_kernel(dev, c0, c1, cout, S, act):
+    """UpSampling3D(2) + concatenate + Conv3D with the up-sampled half as 8 folded taps (nrt_conv3d_up2_f32) against the
+    float64 oracle on the materialised concatenation and against the 27-tap implicit GEMM."""
+    rng = np.random.default_rng(c0 + 7 * c1 + cout)
+    conv = nm._Conv('c', c0 + c1, cout, (3, 3, 3), 1, 'same', act).to(dev)
+    w, b = set_weights(conv, rng)
+    skip = rng.standard_normal((2,) + S + (c0,)).astype(F)
+    lo = rng.standard_normal((2,) + tuple(s // 2 for s in S) + (c1,)).astype(F)
+    cat = np.concatenate([skip, lo.repeat(2, 1).repeat(2, 2).repeat(2, 3)], -1)
+    y = N(conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2), variant=4))
+    y27 = N(conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2), variant=2))
+    for bi in range(2):
+        ref = uo.conv(cat[bi], w, b, 'elu' if act == 'elu' else None)
+        close(y[bi], np.maximum(ref, 0) if act == 'relu' else ref)
+    np.testing.assert_allclose(y, y27, rtol=1e-5, atol=1e-5 * np.abs(y27).max())
+    # auto picks the folded kernel for these shapes: identical bits
+    assert np.array_equal(N(conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2))), y)
+
+
+def test_conv3d_folded_decoder_kernel_falls_back(dev):
+    """channel counts that are not multiples of 16 or other up-sampling factors stay on the 27-tap kernel"""
+    rng = np.random.default_rng(5)
+    conv = nm._Conv('c', 4 + 12, 7, (3, 3, 3), 1, 'same', 'elu').to(dev)
+    set_weights(conv, rng)
+    skip = G(rng.standard_normal((1, 6, 6, 6, 4)).astype(F), dev)
+    lo = G(rng.standard_normal((1, 3, 3, 3, 12)).astype(F), dev)
+    with pytest.raises(NotImplementedError):
+        conv(skip, lo=lo, up=(2, 2, 2), variant=4)
+    assert np.array_equal(N(conv(skip, lo=lo, up=(2, 2, 2))), N(conv(skip, lo=lo, up=(2, 2, 2), variant=2)))
+
+
 def test_direct_conv_shapes(dev):
     """First layer (Cin = 1), odd channel counts, VALID padding, large dilation: the direct kernel."""
     rng = np.random.default_rng(8)
