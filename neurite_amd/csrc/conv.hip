@@ -22,6 +22,7 @@
 // maxpool3d_f32, upsample_concat_f32, softmax_lastdim_f32 -- the remaining Keras layers.
 
 #include <type_traits>
+#include <utility>
 
 #include "nrt_common.h"
 #include "activations.h"
@@ -690,261 +691,7 @@ int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t 
     return NRT_OK;
 }
 
-// ============================================================================================
-// decoder convolution with the up-sampled half folded: 3x3x3 SAME over concat(skip, UpSampling3D(2)(lo))
-// ============================================================================================
-// An output voxel o = 2q + p (p = its parity along one axis) sees the nearest-up-sampled tensor at o-1, o, o+1, i.e. the
-// low-resolution voxels (q-1, q, q) for p = 0 and (q, q, q+1) for p = 1: per axis the three taps collapse to TWO taps on
-// the low-resolution grid with weights (w0, w1+w2) resp. (w0+w1, w2); SAME zero padding of the up-sampled grid is zero
-// padding of the low-resolution grid.  In 3-D the 27 taps over the c1 up-sampled channels become 8 taps with one of 8
-// pre-summed weight sets (by output parity): K = 27 c0 + 8 c1 instead of 27 (c0 + c1) -- 0.53 of the matrix work at
-// neurite's decoder shapes (c1 = 2 c0).  The sums of up to 8 weights are formed once per layer in float32 (same
-// rounding class as the accumulation order of any GEMM).
-// An MFMA M-tile must hold voxels of ONE parity class: block = 4 x 4 x 16 outputs, wave w = the (x, y) parity
-// (w & 1, w >> 1), its 4 M-tiles = (x in {px, px+2}) x (z parity), rows = (y in {py, py+2}) x (8 z of that parity).
-// LDS: the skip halo [6][6][18] is stored with z de-interleaved by parity ([6][6][2][9] rows) and the y-stride padded
-// so that the 16 rows of every ds_read_b128 group fall on distinct banks exactly as 16 consecutive rows do.
-constexpr int U2_SY = 2 * 9 * LDS_ROW + 8, U2_SX = 6 * U2_SY;        // skip halo (floats)
-constexpr int U2_SYA = 10 * LDS_ROW + 24, U2_SXA = 4 * U2_SYA;       // low-resolution halo [4][4][10] rows
-constexpr int U2_LDS_FLOATS = 6 * U2_SX;
-static_assert((2 * U2_SY) % 64 == 32 && U2_SYA % 64 == 32, "row groups must keep the 20-float bank walk");
-static_assert(4 * U2_SXA <= U2_LDS_FLOATS, "the low-resolution halo shares the buffer");
-
-template <int NT>
-__global__ __launch_bounds__(256) void conv3d_up2_mfma(ConvArgs a, const float *__restrict__ wpacked, unsigned nblk,
-                                                       unsigned nby, unsigned nbz) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const unsigned lb = nrt_xcd_block(blockIdx.x, gridDim.x);
-    if (lb >= nblk) return;
-    const int b = blockIdx.y;
-    const int bz = lb % nbz, by = (lb / nbz) % nby, bx = lb / (nbz * nby);
-    const int x0 = bx * CT_X, y0 = by * CT_Y, z0 = bz * CT_Z;
-    const int nA = a.c1 >> 4, nB = a.c0 >> 4;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int px = w & 1, py = w >> 1, iy = li >> 3, iz = li & 7;
-    const int q4 = threadIdx.x & 3;
-
-    const float *s0 = a.src0 + (long long)b * a.X * a.Y * a.Z * a.c0;
-    const float *s1 = a.src1 + (long long)b * a.X1 * a.Y1 * a.Z1 * a.c1;
-
-    f32x4 acc[4][NT];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-
-    // rows of the two halo tiles this thread stages (fixed over the chunks): global offset, LDS offset, in-bounds bit
-    constexpr int PFB = 11, PFA = 3;                          // 64 * 11 >= 648 rows, 64 * 3 >= 160 rows
-    unsigned offB[PFB], offA[PFA];
-    unsigned short dstB[PFB], dstA[PFA];
-    unsigned okB = 0, okA = 0;
-    {
-        const unsigned sZ0 = (unsigned)a.c0, sY0 = (unsigned)a.Z * sZ0, sX0 = (unsigned)a.Y * sY0;
-        const unsigned tZ = (unsigned)a.c1, tY = (unsigned)a.Z1 * tZ, tX = (unsigned)a.Y1 * tY;
-#pragma unroll
-        for (int i = 0; i < PFB; ++i) {
-            const int r = (threadIdx.x >> 2) + 64 * i;
-            const int rz = r % 18, ry = (r / 18) % 6, rx = r / 108;
-            const int x = x0 - 1 + rx, y = y0 - 1 + ry, z = z0 - 1 + rz;
-            const bool ok = (r < 648) & (x >= 0) & (x < a.X) & (y >= 0) & (y < a.Y) & (z >= 0) & (z < a.Z);
-            const unsigned off = __umul24((unsigned)x, sX0) + __umul24((unsigned)y, sY0) + __umul24((unsigned)z, sZ0) + 4u * q4;
-            offB[i] = ok ? off : 0u;
-            okB |= (ok ? 1u : 0u) << i;
-            dstB[i] = (unsigned short)((r < 648 ? rx * U2_SX + ry * U2_SY + (rz & 1) * (9 * LDS_ROW) + (rz >> 1) * LDS_ROW : 0) + 4 * q4);
-        }
-#pragma unroll
-        for (int i = 0; i < PFA; ++i) {
-            const int r = (threadIdx.x >> 2) + 64 * i;
-            const int rz = r % 10, ry = (r / 10) % 4, rx = r / 40;
-            const int x = (x0 >> 1) - 1 + rx, y = (y0 >> 1) - 1 + ry, z = (z0 >> 1) - 1 + rz;
-            const bool ok = (r < 160) & (x >= 0) & (x < a.X1) & (y >= 0) & (y < a.Y1) & (z >= 0) & (z < a.Z1);
-            const unsigned off = __umul24((unsigned)x, tX) + __umul24((unsigned)y, tY) + __umul24((unsigned)z, tZ) + 4u * q4;
-            offA[i] = ok ? off : 0u;
-            okA |= (ok ? 1u : 0u) << i;
-            dstA[i] = (unsigned short)((r < 160 ? rx * U2_SXA + ry * U2_SYA + rz * LDS_ROW : 0) + 4 * q4);
-        }
-    }
-    f32x4 stage[PFB];
-    auto fetchA = [&](int ch) {
-#pragma unroll
-        for (int i = 0; i < PFA; ++i) stage[i] = *(const f32x4 *)(s1 + offA[i] + 16 * ch);
-    };
-    auto fetchB = [&](int ch) {
-#pragma unroll
-        for (int i = 0; i < PFB; ++i) stage[i] = *(const f32x4 *)(s0 + offB[i] + 16 * ch);
-    };
-    const f32x4 zero4 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-
-    // ---- up-sampled channels: 8 folded taps on the low-resolution grid ---------------------------------------------
-    if (nA > 0) fetchA(0); else fetchB(0);
-    for (int ch = 0; ch < nA; ++ch) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < PFA; ++i)
-            if ((threadIdx.x >> 2) + 64 * i < 160) *(f32x4 *)&lds[dstA[i]] = ((okA >> i) & 1u) ? stage[i] : zero4;
-        __syncthreads();
-        // [chunk][wave parity][step = (tx, ty, tz)][z parity][nt][lane] float4
-        const f32x4 *wp = (const f32x4 *)wpacked + ((long long)(ch * 4 + w) * 16) * NT * 64 + lane;
-        constexpr int WA = NT == 1 ? 4 : NT == 2 ? 2 : 1;    // steps whose weights are requested before the halo prefetch
-        f32x4 bpre[WA][2][NT];
-#pragma unroll
-        for (int s = 0; s < WA; ++s)
-#pragma unroll
-            for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bpre[s][pz][nt] = wp[((s * 2 + pz) * NT + nt) * 64];
-        if (ch + 1 < nA) fetchA(ch + 1);
-        else if (nB > 0) fetchB(0);
-        f32x4 bfrag[2][NT];
-#pragma unroll
-        for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfrag[pz][nt] = bpre[0][pz][nt];
-        const float *abase = &lds[px * U2_SXA + (py + iy) * U2_SYA + iz * LDS_ROW + 4 * kq];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            f32x4 bnext[2][NT];
-            const int sn = (s + 1 < 8) ? s + 1 : s;
-#pragma unroll
-            for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bnext[pz][nt] = (sn < WA) ? bpre[sn][pz][nt] : wp[((sn * 2 + pz) * NT + nt) * 64];
-            const int tz = s & 1, ty = (s >> 1) & 1, tx = s >> 2;
-            f32x4 av[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int ix = mt & 1, pz = mt >> 1;
-                av[mt] = *(const f32x4 *)(abase + (ix + tx) * U2_SXA + ty * U2_SYA + (pz + tz) * LDS_ROW);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][m], bfrag[mt >> 1][nt][m], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int pz = 0; pz < 2; ++pz)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bfrag[pz][nt] = bnext[pz][nt];
-        }
-    }
-    // ---- skip channels: the 27 taps at full resolution ---------------------------------------------------------------
-    const f32x4 *wB = (const f32x4 *)wpacked + (long long)nA * 4 * 16 * NT * 64 + lane;
-    for (int ch = 0; ch < nB; ++ch) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < PFB; ++i)
-            if ((threadIdx.x >> 2) + 64 * i < 648) *(f32x4 *)&lds[dstB[i]] = ((okB >> i) & 1u) ? stage[i] : zero4;
-        __syncthreads();
-        const f32x4 *wp = wB + (long long)ch * 27 * NT * 64;
-        constexpr int WPRE = NT == 1 ? 6 : NT == 2 ? 4 : NT == 3 ? 3 : 2;
-        f32x4 bpre[WPRE][NT];
-#pragma unroll
-        for (int t = 0; t < WPRE; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bpre[t][nt] = wp[(t * NT + nt) * 64];
-        if (ch + 1 < nB) fetchB(ch + 1);
-        f32x4 bfrag[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bfrag[nt] = bpre[0][nt];
-        const float *abase = &lds[px * U2_SX + (py + 2 * iy) * U2_SY + iz * LDS_ROW + 4 * kq];
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            f32x4 bnext[NT];
-            const int tn = (t + 1 < 27) ? t + 1 : t;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bnext[nt] = (tn < WPRE) ? bpre[tn][nt] : wp[(tn * NT + nt) * 64];
-            const int dz = t % 3, dy = (t / 3) % 3, dx = t / 9;
-            f32x4 av[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int ix = mt & 1, pz = mt >> 1;
-                av[mt] = *(const f32x4 *)(abase + (2 * ix + dx) * U2_SX + dy * U2_SY + ((pz + dz) & 1) * (9 * LDS_ROW) +
-                                          ((pz + dz) >> 1) * LDS_ROW);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][m], bfrag[nt][m], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfrag[nt] = bnext[nt];
-        }
-    }
-    // ---- epilogue: D[row = (lane>>4)*4 + r][col = lane&15], row = (y pair member, z of the parity) -----------------
-    float *ob = a.out + (long long)b * a.OX * a.OY * a.OZ * a.Cout;
-    const int y = y0 + py + 2 * (kq >> 1);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int x = x0 + px + 2 * (mt & 1), pz = mt >> 1;
-        if (x >= a.OX || y >= a.OY) continue;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 16 + li;
-            if (co >= a.Cout) continue;
-            const float bv = a.bias ? a.bias[co] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int z = z0 + 2 * ((kq & 1) * 4 + r) + pz;
-                if (z < a.OZ)
-                    ob[(((long long)x * a.OY + y) * a.OZ + z) * a.Cout + co] = activate(acc[mt][nt][r] + bv, a.act);
-            }
-        }
-    }
-}
-
-// folded + fragment-ordered weights of conv3d_up2_mfma:
-//   [c1/16 chunks][wave parity (px + 2 py)][step (tx, ty, tz)][z parity][nt][lane][m]  then  [c0/16 chunks][27 taps][nt][lane][m]
-__global__ void conv3d_pack_weights_up2(const float *__restrict__ w, int c0, int c1, int Cout, int NT, float *__restrict__ packed) {
-    const int Cin = c0 + c1, nA = c1 / 16, nB = c0 / 16;
-    const long long totA = (long long)nA * 4 * 16 * NT * 256, totB = (long long)nB * 27 * NT * 256;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < totA + totB; e += (long long)gridDim.x * blockDim.x) {
-        const int m = e & 3, lane = (e >> 2) & 63;
-        long long r = (e < totA ? e : e - totA) >> 8;
-        const int nt = r % NT; r /= NT;
-        const int co = nt * 16 + (lane & 15);
-        float v = 0.0f;
-        if (e < totA) {
-            const int pz = r & 1, s = (r >> 1) & 7, wv = (r >> 4) & 3, ch = r >> 6;
-            const int tz = s & 1, ty = (s >> 1) & 1, tx = s >> 2, px = wv & 1, py = wv >> 1;
-            const int ci = c0 + ch * 16 + 4 * (lane >> 4) + m;
-            // taps of one axis that land on low-resolution tap t for output parity p: p=0: {0}, {1,2};  p=1: {0,1}, {2}
-            auto lo = [](int p, int t) { return p == 0 ? (t == 0 ? 0 : 1) : (t == 0 ? 0 : 2); };
-            auto hi = [](int p, int t) { return p == 0 ? (t == 0 ? 0 : 2) : (t == 0 ? 1 : 2); };
-            if (co < Cout)
-                for (int dx = lo(px, tx); dx <= hi(px, tx); ++dx)
-                    for (int dy = lo(py, ty); dy <= hi(py, ty); ++dy)
-                        for (int dz = lo(pz, tz); dz <= hi(pz, tz); ++dz)
-                            v += w[((long long)((dx * 3 + dy) * 3 + dz) * Cin + ci) * Cout + co];
-        } else {
-            const int t = r % 27, ch = r / 27;
-            const int ci = ch * 16 + 4 * (lane >> 4) + m;
-            if (co < Cout) v = w[((long long)t * Cin + ci) * Cout + co];
-        }
-        packed[e] = v;
-    }
-}
-
-bool up2_ok(const ConvArgs &a, int padding_same) {
-    return padding_same && a.kx == 3 && a.ky == 3 && a.kz == 3 && a.dil == 1 && a.c1 > 0 && a.ux == 2 && a.uy == 2 && a.uz == 2 &&
-           a.c0 % 16 == 0 && a.c1 % 16 == 0 && a.Cout <= 64 &&
-           (long long)a.X * a.Y * a.Z * a.c0 < (1ll << 31) && (long long)a.Y * a.Z * (a.c0 > a.c1 ? a.c0 : a.c1) < (1ll << 24);
-}
-
-template <int NT>
-int launch_up2(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st) {
-    const unsigned nbx = (a.OX + CT_X - 1) / CT_X, nby = (a.OY + CT_Y - 1) / CT_Y, nbz = (a.OZ + CT_Z - 1) / CT_Z;
-    const unsigned nblk = nbx * nby * nbz;
-    dim3 grid(nrt_xcd_grid(nblk), batch);
-    hipLaunchKernelGGL((conv3d_up2_mfma<NT>), grid, dim3(256), U2_LDS_FLOATS * sizeof(float), st, a, wpacked, nblk, nby, nbz);
-    NRT_CHECK_LAUNCH();
-    return NRT_OK;
-}
+#include "conv_up2.h"
 
 }  // namespace
 
@@ -965,9 +712,8 @@ extern "C" int nrt_conv3d_pack_weights_f32(const float *weights, const int *ksiz
 }
 
 extern "C" size_t nrt_conv3d_up2_packed_weight_floats(int c0, int c1, int cout) {
-    if (c0 < 0 || c1 < 16 || c0 % 16 || c1 % 16 || cout < 1) return 0;
-    const size_t NT = (size_t)(cout + 15) / 16;
-    return ((size_t)(c1 / 16) * 4 * 16 + (size_t)(c0 / 16) * 27) * NT * 256;
+    if (c0 < 16 || c1 < 16 || c0 % 16 || c1 % 16 || cout < 1) return 0;
+    return up2_weight_floats(c0, c1, cout) + U2_ZERO_FLOATS;
 }
 
 extern "C" int nrt_conv3d_up2_pack_weights_f32(const float *weights, int c0, int c1, int cout, float *packed, void *stream) {

@@ -59,3 +59,16 @@ static inline unsigned nrt_xcd_grid(unsigned nblocks) {
 }
 
 static inline hipStream_t nrt_stream(void *s) { return (hipStream_t)s; }
+
+// compute units of the current device (persistent kernels size their grid with it)
+static inline int nrt_num_cus() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}

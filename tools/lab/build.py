@@ -16,7 +16,7 @@ OUT = os.path.join(HERE, 'liblab.so')
 LIB_SOURCES = ['gather_lc.hip', 'lab_api.hip', 'membench.hip']
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize', '-Wno-unused-function',
          '-Wno-pass-failed', '-I' + PROD]
-PROBES = ['occ_probe', 'dma_probe', 'valu_rate', 'valu_ops', 'vmem_issue', 'mix_probe']      # stand-alone programs
+PROBES = ['occ_probe', 'dma_probe', 'valu_rate', 'valu_ops', 'vmem_issue', 'mix_probe', 'mfma_rate']      # stand-alone programs
 
 
 def build(force=False, probes=False):
