@@ -282,6 +282,19 @@ int nrt_conv3d_up2_f32(const float *skip /* [batch, shape, c0] */, int c0, const
                        const float *packed_weights, const float *bias, float *out, int batch, const int *shape, int cout,
                        int activation, void *stream);
 
+/*
+ * Backward of the folded decoder convolution with respect to its low-resolution input (what tf.GradientTape derives through
+ * UpSampling3D + concatenate + Conv3D, neurite/tf/models.py:1531-1555): the gradient of the up-sampled tensor summed over
+ * the 2^3 blocks is a 4x4x4 stride-2 convolution of dpre = 8 parity sub-lattices x 2x2x2 taps on the low-resolution grid.
+ *   nrt_space_to_depth2_f32   y[b][q][P * channels + c] = x[b][2 q + p][c], P = (px * 2 + py) * 2 + pz (shape = x's, even)
+ *   nrt_conv3d_s2d_taps_f32   3x3x3 SAME convolution of x [batch, shape, 8 * group] in which the channels of parity group P only
+ *                             use the taps e = (p ? 1 : 2) - t, t in {0, 1}, per axis (all other weights are taken as zero);
+ *                             packed_weights = nrt_conv3d_pack_weights_f32 of [3,3,3, 8 * group, cout]; group % 16 == 0
+ */
+int nrt_space_to_depth2_f32(const float *x, float *y, int batch, const int *shape, int channels, void *stream);
+int nrt_conv3d_s2d_taps_f32(const float *x, int group, const float *packed_weights, float *out, int batch, const int *shape,
+                            int cout, void *stream);
+
 /* 1x1 convolution with the channel softmax (or an activation) fused; cout <= 64. x [nvox, cin]. */
 int nrt_conv1x1_softmax_f32(const float *x, const float *weights /* [cin, cout] */, const float *bias,
                             float *y, long long nvox, int cin, int cout, int softmax, int activation,
@@ -319,6 +332,13 @@ int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float *grad_weig
 int nrt_conv3d_wgrad2_f32(const float *x, int c0, const float *x_lo, int c1, const int *up, const float *grad_pre,
                           float *grad_weights, float *grad_bias, int batch, const int *shape, int cout, const int *ksize,
                           int dilation, void *stream);
+/* folded form for the up-sampled channels of a decoder convolution (see nrt_conv3d_up2_f32): x_lo [batch, shape, cin] is the
+ * low-resolution tensor, grad_pre_s2d [batch, shape, 8 * group] = nrt_space_to_depth2_f32 of the layer's grad_pre (group = cout);
+ * grad_folded [8 parity groups][8 taps (tx, ty, tz)][cin][group] += sum_q x_lo[q + p + t - 1] (x) grad_pre_s2d[q][P], ZERO-FILLED by
+ * the caller; the 27-tap gradient is dW[d] = sum over the (p, t) with d in S(p, t) per axis (S(0,0) = {0}, S(0,1) = {1,2},
+ * S(1,0) = {0,1}, S(1,1) = {2}) -- a 27 x 64 matrix product over cin * group values (host side) */
+int nrt_conv3d_wgrad_s2d_f32(const float *x_lo, const float *grad_pre_s2d, float *grad_folded, int batch, const int *shape, int cin,
+                             int group, void *stream);
 int nrt_maxpool3d_bwd_f32(const float *x, const float *grad_out, float *grad_x, int batch, const int *shape,
                           int channels, const int *pool, int padding_same, void *stream);
 int nrt_upsample_sum_f32(const float *grad_up, int grad_channels, int channel_offset, float *grad_lo, int channels,

@@ -56,6 +56,8 @@ _SIGNATURES = {
     'nrt_conv3d_up2_packed_weight_floats': (_sz, [_i, _i, _i]),
     'nrt_conv3d_up2_pack_weights_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'nrt_conv3d_up2_f32': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _ip, _i, _i, _vp]),
+    'nrt_space_to_depth2_f32': (_i, [_vp, _vp, _i, _ip, _i, _vp]),
+    'nrt_conv3d_s2d_taps_f32': (_i, [_vp, _i, _vp, _vp, _i, _ip, _i, _vp]),
     'nrt_conv1x1_softmax_f32': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp]),
     'nrt_softmax_lastdim_f32': (_i, [_vp, _vp, _ll, _i, _vp]),
     'nrt_maxpool3d_f32': (_i, [_vp, _vp, _i, _ip, _i, _ip, _i, _vp]),
@@ -64,6 +66,7 @@ _SIGNATURES = {
     'nrt_act_bwd_f32': (_i, [_vp, _vp, _i, _vp, _ll, _vp]),
     'nrt_conv3d_wgrad_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ip, _i, _i, _ip, _i, _vp]),
     'nrt_conv3d_wgrad2_f32': (_i, [_vp, _i, _vp, _i, _ip, _vp, _vp, _vp, _i, _ip, _i, _ip, _i, _vp]),
+    'nrt_conv3d_wgrad_s2d_f32': (_i, [_vp, _vp, _vp, _i, _ip, _i, _i, _vp]),
     'nrt_maxpool3d_bwd_f32': (_i, [_vp, _vp, _vp, _i, _ip, _i, _ip, _i, _vp]),
     'nrt_upsample_sum_f32': (_i, [_vp, _i, _i, _vp, _i, _i, _ip, _ip, _vp]),
     'nrt_softmax_bwd_f32': (_i, [_vp, _vp, _vp, _ll, _i, _vp]),

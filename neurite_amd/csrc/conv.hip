@@ -48,6 +48,8 @@ struct ConvArgs {
     int dil;
     int px, py, pz;          // padding before
     int act;
+    int fold;                // > 0: input channels come in 8 parity groups of `fold` (space-to-depth of a 2x finer tensor) and a group
+                             // only has the 2 x 2 x 2 taps (e = (p ? 1 : 2) - t per axis) of the folded decoder backward
 };
 
 // ============================================================================================
@@ -57,7 +59,7 @@ constexpr int CT_X = 4, CT_Y = 4, CT_Z = 16;   // output tile
 constexpr int LDS_ROW = 20;                     // floats per staged voxel row (16 channels + 4 pad)
 
 // FAST: 3x3x3 kernel, dilation 1 -- the tap loop is fully unrolled, every LDS address is base + immediate
-template <int NT, bool FAST>
+template <int NT, bool FAST, bool FOLD = false>
 __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__restrict__ wpacked, unsigned nblk,
                                                    unsigned nbx, unsigned nby, unsigned nbz) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -175,9 +177,15 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
         constexpr int WPRE = FAST ? (NT == 1 ? 6 : NT == 2 ? 4 : NT == 3 ? 3 : 2) : 1;
         f32x4 bpre[WPRE][NT];
 #pragma unroll
-        for (int t = 0; t < WPRE; ++t)
+        for (int t = 0; t < WPRE; ++t) {
+            int tt = t;
+            if (FOLD) {                                          // t-th tap of this chunk's parity group
+                const int P = cbase / a.fold;
+                tt = ((((P & 4) ? 1 : 2) - ((t >> 2) & 1)) * 3 + (((P & 2) ? 1 : 2) - ((t >> 1) & 1))) * 3 + (((P & 1) ? 1 : 2) - (t & 1));
+            }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bpre[t][nt] = wp[(t * NT + nt) * 64];
+            for (int nt = 0; nt < NT; ++nt) bpre[t][nt] = wp[(tt * NT + nt) * 64];
+        }
         if (FAST) {
             if (ch + 1 < nchunk) {
                 if (a.c1) fetch_fast(cbase + 16, std::true_type{});
@@ -191,7 +199,35 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
         f32x4 bfrag[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bfrag[nt] = bpre[0][nt];
-        if (FAST) {
+        if (FAST && FOLD) {
+            // this chunk belongs to one parity group: its 8 taps, 3x3x3 tap index e = (p ? 1 : 2) - t per axis (scalar
+            // arithmetic; one VALU add per tap puts the tap's row offset on the lane's LDS base)
+            constexpr int FHY = CT_Y + 2, FHZ = CT_Z + 2;
+            const int P = cbase / a.fold, ex0 = (P & 4) ? 1 : 2, ey0 = (P & 2) ? 1 : 2, ez0 = (P & 1) ? 1 : 2;
+            const float *abase = &lds[((w * FHY) * FHZ + li) * LDS_ROW + 4 * kq];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ex = ex0 - ((k >> 2) & 1), ey = ey0 - ((k >> 1) & 1), ez = ez0 - (k & 1);
+                f32x4 bnext[NT];
+                const int kn = k + 1 < 8 ? k + 1 : k;
+                const int tn = ((ex0 - ((kn >> 2) & 1)) * 3 + (ey0 - ((kn >> 1) & 1))) * 3 + (ez0 - (kn & 1));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bnext[nt] = (kn < WPRE) ? bpre[kn][nt] : wp[(tn * NT + nt) * 64];
+                const float *at = abase + ((ex * FHY + ey) * FHZ + ez) * LDS_ROW;
+                f32x4 av[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) av[mt] = *(const f32x4 *)(at + (mt * FHZ) * LDS_ROW);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][m], bfrag[nt][m], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bfrag[nt] = bnext[nt];
+            }
+        } else if (FAST) {
             constexpr int FHY = CT_Y + 2, FHZ = CT_Z + 2;
             const float *abase = &lds[((w * FHY) * FHZ + li) * LDS_ROW + 4 * kq];
 #pragma unroll
@@ -653,6 +689,7 @@ int conv_args(ConvArgs &a, const float *src0, int c0, const float *src1, int c1,
         if (a.OX < 1 || a.OY < 1 || a.OZ < 1) return NRT_ERR_INVALID_ARG;
     }
     a.act = act;
+    a.fold = 0;
     return NRT_OK;
 }
 
@@ -685,13 +722,32 @@ int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t 
             return NRT_ERR_LAUNCH;
     }
     dim3 grid(nrt_xcd_grid(nblk), batch);
-    if (fast) hipLaunchKernelGGL((conv3d_mfma<NT, true>), grid, dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
+    if (a.fold) {
+        if (!fast || a.c1 || a.fold % 16 || a.c0 != 8 * a.fold) return NRT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((conv3d_mfma<NT, true, true>), grid, dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
+    } else if (fast) hipLaunchKernelGGL((conv3d_mfma<NT, true>), grid, dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
     else hipLaunchKernelGGL((conv3d_mfma<NT, false>), grid, dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }
 
 #include "conv_up2.h"
+
+// y[b][q][P * C + c] = x[b][2 q + p][c], P = (px * 2 + py) * 2 + pz: the 8 parity sub-lattices of x as channel groups
+__global__ __launch_bounds__(256) void space_to_depth2(const f32x4 *__restrict__ x, f32x4 *__restrict__ y, int X1, int Y1, int Z1, int C4) {
+    const int b = blockIdx.y;
+    const long long total = (long long)X1 * Y1 * Z1 * 8 * C4;
+    const f32x4 *xb = x + (long long)b * total;
+    f32x4 *yb = y + (long long)b * total;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int c = (int)(e % C4);
+        long long r = e / C4;
+        const int P = (int)(r & 7); r >>= 3;
+        const int z = (int)(r % Z1), yy = (int)((r / Z1) % Y1), xx = (int)(r / ((long long)Z1 * Y1));
+        const long long src = (((long long)(2 * xx + (P >> 2)) * (2 * Y1) + (2 * yy + ((P >> 1) & 1))) * (2 * Z1) + (2 * z + (P & 1))) * C4 + c;
+        yb[e] = xb[src];
+    }
+}
 
 }  // namespace
 
@@ -748,6 +804,38 @@ extern "C" int nrt_conv3d_up2_f32(const float *skip, int c0, const float *lo, in
         case 2: return launch_up2<2>(a, packed_weights, batch, st);
         case 3: return launch_up2<3>(a, packed_weights, batch, st);
         default: return launch_up2<4>(a, packed_weights, batch, st);
+    }
+}
+
+extern "C" int nrt_space_to_depth2_f32(const float *x, float *y, int batch, const int *shape, int channels, void *stream) {
+    if (!x || !y || !shape || batch < 1 || batch > 65535 || channels < 4 || channels % 4) return NRT_ERR_INVALID_ARG;
+    if (shape[0] < 2 || shape[1] < 2 || shape[2] < 2 || shape[0] % 2 || shape[1] % 2 || shape[2] % 2) return NRT_ERR_INVALID_ARG;
+    if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return NRT_ERR_UNSUPPORTED;
+    const long long total = (long long)shape[0] * shape[1] * shape[2] * (channels / 4);
+    long long nb = (total + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(space_to_depth2, dim3((unsigned)nb, batch), dim3(256), 0, nrt_stream(stream), (const f32x4 *)x, (f32x4 *)y,
+                       shape[0] / 2, shape[1] / 2, shape[2] / 2, channels / 4);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_conv3d_s2d_taps_f32(const float *x, int group, const float *packed_weights, float *out, int batch,
+                                       const int *shape, int cout, void *stream) {
+    ConvArgs a;
+    const int k3[3] = {3, 3, 3};
+    if (group < 16 || group % 16 || !packed_weights) return NRT_ERR_INVALID_ARG;
+    int rc = conv_args(a, x, 8 * group, nullptr, 0, nullptr, nullptr, out, shape, k3, cout, 1, 1, ACT_NONE);
+    if (rc != NRT_OK) return rc;
+    if (batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (!mfma_ok(a, 1)) return NRT_ERR_UNSUPPORTED;
+    a.fold = group;
+    hipStream_t st = nrt_stream(stream);
+    switch ((cout + 15) / 16) {
+        case 1: return launch_mfma<1>(a, packed_weights, batch, st);
+        case 2: return launch_mfma<2>(a, packed_weights, batch, st);
+        case 3: return launch_mfma<3>(a, packed_weights, batch, st);
+        default: return launch_mfma<4>(a, packed_weights, batch, st);
     }
 }
 

@@ -149,17 +149,21 @@ struct WgArgs {
     int c0, c1, ux, uy, uz;  // channels of x (the layer saw concat(x, upsample(x1)), Cin = c0 + c1); c0 % 4 == 0 when x1 is given
     int im2col;              // single-channel input, 3x3x3 kernel: the 27 taps are staged as 27 "channels" of a 1x1x1 conv
                              // (Cin = 27, kx = ky = kz = 1 above; dW[tap][0][co] and dW[0][tap][co] are the same memory)
+    int dps;                 // channels per voxel row of dp (Cout, or 8 * Cout in the folded form)
+    int fold;                // folded decoder backward: dp is the space-to-depth tensor of the fine gradient (8 parity groups of Cout
+                             // channels), blockIdx.z = parity group P, its 8 taps are e = p + t per axis (t in {0,1}), and
+                             // dw is [8 groups][8 taps][Cin][Cout]
 };
 
 constexpr int WT_X = 4, WT_Y = 4, WT_Z = 8;     // voxel tile: 128 voxels = 32 k-steps of 4
-constexpr int WG_MAXT = 7;                       // taps per wave: ceil(27 / 4)
+// WG_MAXT (template): taps per wave = ceil(27 / 4) = 7, or 2 for the 8 taps of the folded form
 
 // NA, NB: 16-channel blocks of the cin / cout chunk handled by one block
 // K3: 3x3x3 kernel, dilation 1 -- the halo geometry is a compile-time constant, which turns the staging loop's row
 // decode (two runtime divisions per 16-byte load) into multiply-shifts
 // KM = 1: 1x1x1 kernel (also the im2col form of the first layer) -- same staging; the four waves split the 32 k-steps
 // instead of the taps and each adds its partial sums at the end
-template <int NA, int NB, int KM>
+template <int NA, int NB, int KM, int WG_MAXT = 7>
 __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
     constexpr bool K3 = KM == 3, K1 = KM == 1, KF = K3 || K1;
     constexpr int HALO = K3 ? 1 : 0;
@@ -172,7 +176,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
     const int nrowsA = HX * HY * HZ;
     float *la = lds;                                            // [nrowsA][RSA]
     float *lb = lds + nrowsA * RSA;                             // [128][RSB]
-    const int ntap = K3 ? 27 : K1 ? 1 : a.kx * a.ky * a.kz;
+    const bool FOLD = WG_MAXT == 2;
+    const int ntap = FOLD ? 8 : K3 ? 27 : K1 ? 1 : a.kx * a.ky * a.kz;
+    const int P = FOLD ? blockIdx.z : 0;                        // parity group: its channels of dp and its taps
     const int cic = blockIdx.y % a.ncic, coc = blockIdx.y / a.ncic;
     const int ci0 = cic * CC, co0 = coc * CO;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -193,7 +199,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
     for (int i = 0; i < WG_MAXT; ++i) {
         const int t = min(wv + 4 * i, ntap - 1);
         const int kz = K3 ? 3 : K1 ? 1 : a.kz, ky = K3 ? 3 : K1 ? 1 : a.ky, dil = KF ? 1 : a.dil;
-        const int dz = t % kz, dy = (t / kz) % ky, dx = t / (kz * ky);
+        int dz = t % kz, dy = (t / kz) % ky, dx = t / (kz * ky);
+        if (FOLD) { dx = ((P >> 2) & 1) + ((t >> 2) & 1); dy = ((P >> 1) & 1) + ((t >> 1) & 1); dz = (P & 1) + (t & 1); }
         toff[i] = ((dx * dil) * HY + dy * dil) * HZ + dz * dil;
     }
 
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
         const int x0 = (int)(tv / ((long long)a.nty * a.ntz)) * WT_X, y0 = (int)((tv / a.ntz) % a.nty) * WT_Y,
                   z0 = (int)(tv % a.ntz) * WT_Z;
         const float *xb = a.x + (long long)b * a.X * a.Y * a.Z * (a.x1 ? a.c0 : a.Cin);
-        const float *pb = a.dp + (long long)b * a.X * a.Y * a.Z * a.Cout;
+        const float *pb = a.dp + (long long)b * a.X * a.Y * a.Z * a.dps + P * a.Cout;
         __syncthreads();                                        // previous tile fully consumed
         // ---- stage the x halo tile (zero outside the volume = SAME padding, zero beyond Cin) ---------------
         if (KF) {
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
                 const int rz = r % WT_Z, ry = (r / WT_Z) % WT_Y, rx = r / (WT_Z * WT_Y);
                 const int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
                 okb[u] = e < TOTB && gx < a.X && gy < a.Y && gz < a.Z && co0 + c4 < a.Cout;
-                const float *src = okb[u] ? pb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.Cout + co0 + c4 : a.dp;
+                const float *src = okb[u] ? pb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.dps + co0 + c4 : a.dp;
                 vb[u] = *(const nrt_f4 *)src;
             }
 #pragma unroll
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
             const int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
             nrt_f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
             if (gx < a.X && gy < a.Y && gz < a.Z) {
-                const float *src = pb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.Cout + co0 + c4;
+                const float *src = pb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.dps + co0 + c4;
                 if (co0 + c4 + 3 < a.Cout && (a.Cout & 3) == 0) v = *(const nrt_f4 *)src;
                 else {
 #pragma unroll
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const int ci = ci0 + na * 16 + l4 * 4 + r;
                         if (ci < a.Cin && co < a.Cout)
-                            unsafeAtomicAdd(&a.dw[((long long)t * a.Cin + ci) * a.Cout + co], acc[i][na][nb][r]);
+                            unsafeAtomicAdd(&a.dw[((long long)(P * 8 + t) * a.Cin + ci) * a.Cout + co], acc[i][na][nb][r]);
                     }
                 }
         }
@@ -495,7 +502,15 @@ int launch_wgrad(WgArgs &a, hipStream_t st) {
                                       (int)lds);                                                                            \
         hipLaunchKernelGGL((conv3d_wgrad<NA, NB, KM>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);         \
     } while (0)
-    if (km == 3) NRT_WG_LAUNCH(3);
+    if (a.fold) {
+        if (km != 3) return NRT_ERR_UNSUPPORTED;
+        bx = 256ll * per_cu / (a.ncic * a.ncoc * 8);
+        if (bx < 16) bx = 16;
+        if (bx > ntiles) bx = ntiles;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)conv3d_wgrad<NA, NB, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3d_wgrad<NA, NB, 3, 2>), dim3((unsigned)bx, a.ncic * a.ncoc, 8), dim3(256), lds, st, a);
+    } else if (km == 3) NRT_WG_LAUNCH(3);
     else if (km == 1) NRT_WG_LAUNCH(1);
     else NRT_WG_LAUNCH(0);
 #undef NRT_WG_LAUNCH
@@ -641,6 +656,7 @@ extern "C" int nrt_conv3d_wgrad2_f32(const float *x, int c0, const float *x_lo, 
     a.kx = ksize[0]; a.ky = ksize[1]; a.kz = ksize[2]; a.dil = dilation;
     a.ntx = (a.X + WT_X - 1) / WT_X; a.nty = (a.Y + WT_Y - 1) / WT_Y; a.ntz = (a.Z + WT_Z - 1) / WT_Z;
     a.im2col = 0;
+    a.dps = cout; a.fold = 0;
     if (cin == 1 && ksize[0] == 3 && ksize[1] == 3 && ksize[2] == 3) {
         a.im2col = 1; a.Cin = 27; a.kx = a.ky = a.kz = 1;
         cin = 27;
@@ -663,6 +679,28 @@ extern "C" int nrt_conv3d_wgrad_f32(const float *x, const float *grad_pre, float
                                     const int *shape, int cin, int cout, const int *ksize, int dilation, void *stream) {
     return nrt_conv3d_wgrad2_f32(x, cin, nullptr, 0, nullptr, grad_pre, grad_weights, grad_bias, batch, shape, cout, ksize, dilation,
                                  stream);
+}
+
+extern "C" int nrt_conv3d_wgrad_s2d_f32(const float *x_lo, const float *grad_pre_s2d, float *grad_folded, int batch, const int *shape,
+                                        int cin, int group, void *stream) {
+    if (!x_lo || !grad_pre_s2d || !grad_folded || !shape || batch < 1 || cin < 4 || cin % 4 || group < 4 || group % 4)
+        return NRT_ERR_INVALID_ARG;
+    for (int d = 0; d < 3; ++d)
+        if (shape[d] < 1) return NRT_ERR_INVALID_ARG;
+    if (group > 32) return NRT_ERR_UNSUPPORTED;                                   // one cout chunk per parity group
+    WgArgs a;
+    a.x = x_lo; a.dp = grad_pre_s2d; a.dw = grad_folded; a.db = nullptr;
+    a.x1 = nullptr; a.c0 = cin; a.c1 = 0; a.ux = a.uy = a.uz = 1;
+    a.B = batch; a.X = shape[0]; a.Y = shape[1]; a.Z = shape[2]; a.Cin = cin; a.Cout = group;
+    a.kx = a.ky = a.kz = 3; a.dil = 1;
+    a.ntx = (a.X + WT_X - 1) / WT_X; a.nty = (a.Y + WT_Y - 1) / WT_Y; a.ntz = (a.Z + WT_Z - 1) / WT_Z;
+    a.im2col = 0;
+    a.dps = 8 * group; a.fold = 1;
+    hipStream_t st = nrt_stream(stream);
+    const int na = cin <= 16 ? 1 : (cin <= 32 ? 2 : 3), nb = group <= 16 ? 1 : 2;
+    if (na == 1) return nb == 1 ? launch_wgrad<1, 1>(a, st) : launch_wgrad<1, 2>(a, st);
+    if (na == 2) return nb == 1 ? launch_wgrad<2, 1>(a, st) : launch_wgrad<2, 2>(a, st);
+    return nb == 1 ? launch_wgrad<3, 1>(a, st) : launch_wgrad<3, 2>(a, st);
 }
 
 extern "C" int nrt_channel_sums_f32(const float *a, const float *b, long long rows, int channels, float *out, void *stream) {

@@ -153,6 +153,7 @@ class _Conv(nn.Module):
         self._packed_version = None
         self._packed_up2 = None                      # folded weights of the decoder form (see _run), keyed like _packed + c0
         self._packed_up2_version = None
+        self.fold_backward = True                    # decoder form: differentiate the up-sampled channels on the low-resolution grid
 
     def invalidate_packed(self):
         """forget the MFMA-packed copy of the kernel.  The cache key below sees in-place writes through the Parameter
@@ -409,6 +410,81 @@ def _conv_dgrad(dpre, wpart, ksize3, dilation):
     return out
 
 
+# ---- folded backward of a decoder convolution (UpSampling3D(2) + concatenate + Conv3D 3x3x3 'same') -------------------------
+# Per axis, output parity p and low-resolution tap t cover the 3x3x3 taps d in S(p, t): S(0,0) = {0}, S(0,1) = {1,2},
+# S(1,0) = {0,1}, S(1,1) = {2} (csrc/conv_up2.h).  _FOLD_A[p][t][d] is that membership; _FOLD_B[p][e][d] is the same
+# seen from the low-resolution grid in the backward direction (3x3x3 tap e = 2 - p - t of the space-to-depth gradient).
+_FOLD_A = ((( 1, 0, 0), (0, 1, 1)), ((1, 1, 0), (0, 0, 1)))
+_FOLD_B = (((0, 0, 0), (0, 1, 1), (1, 0, 0)), ((0, 0, 1), (1, 1, 0), (0, 0, 0)))
+
+
+def _fold_dgrad_weights(k_lo):
+    """kernel rows of the up-sampled channels [3,3,3,c1,cout] -> the 3x3x3 kernel [3,3,3, 8 * cout, c1] that maps the
+    space-to-depth gradient (parity group P = (px*2 + py)*2 + pz, channels P*cout + co) to the gradient of the
+    low-resolution tensor; only 2 x 2 x 2 taps per parity group are non-zero."""
+    Bm = torch.tensor(_FOLD_B, dtype=k_lo.dtype, device=k_lo.device)
+    c1, cout = k_lo.shape[3], k_lo.shape[4]
+    return torch.einsum('xea,yfb,zgc,abcio->efgxyzoi', Bm, Bm, Bm, k_lo).reshape(3, 3, 3, 8 * cout, c1).contiguous()
+
+
+def _unfold_wgrad(dwf):
+    """folded weight gradient [8 parity groups, 8 taps, c1, cout] -> [3,3,3,c1,cout]"""
+    Am = torch.tensor(_FOLD_A, dtype=dwf.dtype, device=dwf.device)
+    c1, cout = dwf.shape[2], dwf.shape[3]
+    return torch.einsum('xta,yub,zvc,xyztuvio->abcio', Am, Am, Am, dwf.reshape(2, 2, 2, 2, 2, 2, c1, cout))
+
+
+def _fold_backward_ok(mod, x, lo, up):
+    return (lo is not None and tuple(up) == (2, 2, 2) and mod.ksize3 == (3, 3, 3) and mod.dilation == 1 and mod.padding == 'same'
+            and x.shape[-1] % 16 == 0 and lo.shape[-1] % 16 == 0 and mod.cout % 16 == 0 and mod.cout <= 32 and lo.shape[-1] <= 64
+            and all(s % 2 == 0 for s in x.shape[1:4]))
+
+
+def _space_to_depth2(dpre):
+    lib = _lib.lib()
+    dev = dpre.device
+    dpre = dpre.contiguous()
+    B, S, C = dpre.shape[0], list(dpre.shape[1:4]), dpre.shape[-1]
+    y = torch.empty([B] + [s // 2 for s in S] + [8 * C], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_space_to_depth2_f32(_lib.ptr(dpre), _lib.ptr(y), B, _lib.ints(S), C, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_space_to_depth2_f32')
+    return y
+
+
+def _conv_dgrad_lo_folded(s2d, k_lo):
+    """gradient of the low-resolution input: 2 x 2 x 2 taps per parity group of the space-to-depth gradient (replaces the 27-tap
+    dgrad over the up-sampled channels at full resolution + the 2^3 block sum)"""
+    lib = _lib.lib()
+    dev = s2d.device
+    c1, cout = k_lo.shape[3], k_lo.shape[4]
+    wf = _fold_dgrad_weights(k_lo)
+    k3 = (3, 3, 3)
+    n = lib.nrt_conv3d_packed_weight_floats(_lib.ints(k3), 8 * cout, c1)
+    packed = torch.empty(int(n), dtype=torch.float32, device=dev)
+    B, S1 = s2d.shape[0], list(s2d.shape[1:4])
+    out = torch.empty([B] + S1 + [c1], dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_conv3d_pack_weights_f32(_lib.ptr(wf), _lib.ints(k3), 8 * cout, c1, _lib.ptr(packed), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv3d_pack_weights_f32')
+        rc = lib.nrt_conv3d_s2d_taps_f32(_lib.ptr(s2d), cout, _lib.ptr(packed), _lib.ptr(out), B, _lib.ints(S1), c1, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_conv3d_s2d_taps_f32')
+    return out
+
+
+def _conv_wgrad_lo_folded(lo, s2d, cout):
+    lib = _lib.lib()
+    dev = lo.device
+    lo = lo.contiguous()
+    c1 = lo.shape[-1]
+    dwf = torch.zeros(8, 8, c1, cout, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.nrt_conv3d_wgrad_s2d_f32(_lib.ptr(lo), _lib.ptr(s2d), _lib.ptr(dwf), lo.shape[0], _lib.ints(list(lo.shape[1:4])), c1,
+                                          cout, _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_conv3d_wgrad_s2d_f32')
+    return _unfold_wgrad(dwf)
+
+
 class _ConvFn(torch.autograd.Function):
     """Conv3D (+ fused up-sample/concat loader, bias, activation) with dgrad / wgrad."""
 
@@ -447,6 +523,28 @@ class _ConvFn(torch.autograd.Function):
         need_x, need_lo, need_w, need_b = ctx.needs_input_grad[:4]
         dx = dlo = dw = db = None
         c0 = x.shape[-1]
+        if mod.fold_backward and _fold_backward_ok(mod, x, lo, up):
+            # decoder form: the up-sampled channels are differentiated on the low-resolution grid (8 parity groups x 2x2x2 taps of
+            # the space-to-depth gradient: 0.30 of the matrix work of the 27-tap form), the skip channels as a plain convolution
+            k5 = kernel.detach()
+            s2d = _space_to_depth2(dpre) if (need_lo or need_w) else None
+            if need_x:
+                dx = _conv_dgrad(dpre, k5[..., :c0, :], mod.ksize3, 1)
+            if need_lo:
+                dlo = _conv_dgrad_lo_folded(s2d, k5[..., c0:, :])
+            if need_w or need_b:
+                dw = torch.empty_like(kernel, dtype=torch.float32)
+                dws = torch.zeros(3, 3, 3, c0, mod.cout, dtype=torch.float32, device=dev)
+                db = torch.zeros(mod.cout, dtype=torch.float32, device=dev)
+                xs = x.contiguous()
+                with torch.cuda.device(dev):
+                    rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xs), _lib.ptr(dpre), _lib.ptr(dws), _lib.ptr(db), xs.shape[0],
+                                                  _lib.ints(list(xs.shape[1:4])), c0, mod.cout, _lib.ints(mod.ksize3), 1,
+                                                  _lib.stream_ptr(dev))
+                _lib.check(rc, 'nrt_conv3d_wgrad_f32')
+                dw[..., :c0, :] = dws
+                dw[..., c0:, :] = _conv_wgrad_lo_folded(lo, s2d, mod.cout)
+            return dx, dlo, dw if need_w else None, db if need_b else None, None, None, None, None
         if need_w or need_b:
             dw = torch.zeros_like(kernel, dtype=torch.float32)
             db = torch.zeros(mod.cout, dtype=torch.float32, device=dev)

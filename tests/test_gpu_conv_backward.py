@@ -108,11 +108,19 @@ def test_conv_backward_valid_padding(dev, cin, cout, k, dil, act, shape):
     close(N(xg.grad), xo.grad.numpy(), 'grad_x')
 
 
-def test_conv_backward_fused_upsample_concat_loader(dev):
+@pytest.mark.parametrize('folded,S,c0,c1,cout', [
+    (True, (8, 12, 8), 16, 32, 16),         # dec1-like: the up-sampled channels are differentiated on the low-resolution grid
+    (False, (8, 12, 8), 16, 32, 16),        # the 27-tap form of the same layer
+    (True, (8, 4, 16), 32, 64, 32),         # dec0-like: two cout blocks per parity group, 64 low-resolution channels
+    (True, (12, 6, 20), 16, 16, 16),        # ragged tiles on the low-resolution grid
+    (True, (4, 4, 4), 8, 12, 5),            # channel counts outside the folded form: falls back to the 27-tap form
+])
+def test_conv_backward_fused_upsample_concat_loader(dev, folded, S, c0, c1, cout):
     """decoder conv: input = concat(skip, upsample(lo)) never materialised in the forward; grads to both sources"""
     rng = np.random.default_rng(5)
-    B, S, c0, c1, cout, up = 2, (8, 12, 8), 16, 32, 16, (2, 2, 2)
+    B, up = 2, (2, 2, 2)
     conv = M._Conv('c', c0 + c1, cout, (3, 3, 3), activation='elu').to(dev)
+    conv.fold_backward = folded
     kern = (rng.standard_normal((3, 3, 3, c0 + c1, cout)) * 0.1).astype(F)
     with torch.no_grad():
         conv.kernel.copy_(G(kern, dev))

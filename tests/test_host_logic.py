@@ -729,3 +729,42 @@ def test_lean_kernel_size_guard_cpu():
     assert not ok([64, 64, 64], [720, 720, 720], 1)                       # 373e6 x 12 B = 4.48e9 wraps
     assert ok([64, 64, 64], [640, 640, 640], 4) and not ok([64, 64, 64], [660, 660, 660], 4)      # output rows: 16 B per voxel
     assert not ok([64, 64, 64], [4096, 8, 8], 1) and not ok([64, 64, 64], [16, 16, 16], 5)
+
+
+def test_folded_decoder_backward_matrices_cpu():
+    """the host-side fold / unfold of the decoder convolution's backward (models._fold_dgrad_weights, _unfold_wgrad) against
+    torch float64 autograd through UpSampling3D(2) + Conv3D 3x3x3 'same' on the CPU"""
+    import torch
+    import torch.nn.functional as Fn
+    from neurite_amd import models as nm
+    torch.manual_seed(0)
+    c1, cout, S = 6, 5, (6, 4, 8)
+    X1, Y1, Z1 = [v // 2 for v in S]
+    lo = torch.randn(1, X1, Y1, Z1, c1, dtype=torch.float64, requires_grad=True)
+    W = torch.randn(3, 3, 3, c1, cout, dtype=torch.float64, requires_grad=True)
+    upt = lo.repeat_interleave(2, 1).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    y = Fn.conv3d(upt.permute(0, 4, 1, 2, 3), W.permute(4, 3, 0, 1, 2), padding=1).permute(0, 2, 3, 4, 1)
+    dpre = torch.randn_like(y)
+    (y * dpre).sum().backward()
+    s2d = dpre.reshape(1, X1, 2, Y1, 2, Z1, 2, cout).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(1, X1, Y1, Z1, 8, cout)
+    # gradient of the low-resolution input: a 3x3x3 convolution of the space-to-depth gradient with 2x2x2 live taps per group
+    wf = nm._fold_dgrad_weights(W.detach())
+    assert wf.shape == (3, 3, 3, 8 * cout, c1)
+    dlo = Fn.conv3d(s2d.reshape(1, X1, Y1, Z1, 8 * cout).permute(0, 4, 1, 2, 3), wf.permute(4, 3, 0, 1, 2), padding=1).permute(0, 2, 3, 4, 1)
+    assert float((dlo - lo.grad).abs().max()) < 1e-12
+    for P in range(8):                                   # the taps nrt_conv3d_s2d_taps_f32 visits: e = (p ? 1 : 2) - t per axis
+        live = (wf[:, :, :, P * cout:(P + 1) * cout, :].abs().sum((3, 4)) > 0).nonzero().tolist()
+        p = ((P >> 2) & 1, (P >> 1) & 1, P & 1)
+        want = sorted([[(1 if p[0] else 2) - tx, (1 if p[1] else 2) - ty, (1 if p[2] else 2) - tz]
+                       for tx in (0, 1) for ty in (0, 1) for tz in (0, 1)])
+        assert sorted(live) == want
+    # folded weight gradient as nrt_conv3d_wgrad_s2d_f32 defines it, unfolded to the 27 taps
+    lop = Fn.pad(lo.detach(), (0, 0, 1, 1, 1, 1, 1, 1))
+    dwf = torch.zeros(8, 8, c1, cout, dtype=torch.float64)
+    for P in range(8):
+        p = ((P >> 2) & 1, (P >> 1) & 1, P & 1)
+        for k in range(8):
+            e = [p[0] + ((k >> 2) & 1), p[1] + ((k >> 1) & 1), p[2] + (k & 1)]
+            xs = lop[0, e[0]:e[0] + X1, e[1]:e[1] + Y1, e[2]:e[2] + Z1]
+            dwf[P, k] = torch.einsum('xyzi,xyzo->io', xs, s2d[0, :, :, :, P])
+    assert float((nm._unfold_wgrad(dwf) - W.grad).abs().max()) < 1e-12

@@ -4,6 +4,8 @@ import sys
 
 import torch
 
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import neurite_amd as ne
 from neurite_amd import synth
 

@@ -1,6 +1,8 @@
 """Separable passes (GaussianBlur) and min-max normalisation at 4 x 160^3 x 1: ms per pass and fraction of the HBM roof
 (8 bytes per element and pass; min-max: 12 bytes per element)."""
 import json, os, torch
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import neurite_amd as ne
 dev = torch.device('cuda:0')
 

@@ -5,6 +5,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 OUT="$ROOT/gpurun_out/$1"; shift
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+if [ -f "$ROOT/$1" ]; then set -- "$ROOT/$1" "${@:2}"; fi      # the command runs from /tmp
 ( cd /tmp && timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o t -- python "$@" > "$OUT/run.log" 2>&1 < /dev/null )
 echo "rocprof rc=$?"
 f=$(find "$OUT/prof" -name "*kernel_stats.csv" 2>/dev/null | head -1)

@@ -1,5 +1,7 @@
 """Warp / resize of few-channel volumes (images, flow fields): ms and fraction of the HBM roof (algorithmic bytes)."""
 import json, torch
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import neurite_amd as ne
 from neurite_amd import synth
 dev = torch.device('cuda:0')

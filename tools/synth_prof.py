@@ -1,5 +1,7 @@
 """rocprofv3 target: kernel breakdown of labels_to_image_new at 160^3 (run under rocprofv3 --kernel-trace --stats)."""
 import json, torch, warnings
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 import neurite_amd as ne
 from neurite_amd import synth
 dev = torch.device('cuda:0')

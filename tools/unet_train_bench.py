@@ -1,5 +1,6 @@
 """unet (BASELINE config 3) training step on one GPU: forward + backward (CCE + Dice loss) + SGD update, ms per step."""
-import contextlib, io, json, sys, torch
+import contextlib, io, json, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import neurite_amd as ne
 
 dev = torch.device('cuda:0')
