@@ -37,6 +37,15 @@ row('soft Dice, 20 labels (generic kernel)', timeit(lambda: ne.metrics.Dice().di
 w = torch.rand(L, device=dev) + 0.5
 p = torch.softmax(torch.randn(B, S, S, S, L, device=dev), -1)
 row('weighted CCE [4,160^3,32]', timeit(lambda: ne.metrics.CategoricalCrossentropy(label_weights=w)(fix, p)), nvox * 256)
+logits = torch.randn(B, S, S, S, L, device=dev)
+row('weighted CCE from logits (softmax in registers, one pass) [4,160^3,32]',
+    timeit(lambda: ne.metrics.CategoricalCrossentropy(label_weights=w, from_logits=True)(fix, logits)), nvox * 256)
+lg5, t5 = torch.randn(1, 96, 96, 96, 16, device=dev), torch.softmax(torch.randn(1, 96, 96, 96, 16, device=dev), -1)
+w5 = torch.rand(16, device=dev) + 0.5
+row('config 5 shape: weighted CCE from logits [1,96^3,16] (launch-bound: 113 MB)',
+    timeit(lambda: ne.metrics.CategoricalCrossentropy(label_weights=w5, from_logits=True)(t5, lg5), n=30), 96 ** 3 * 128)
+row('config 5 shape: softmax then weighted CCE (two kernels) [1,96^3,16]',
+    timeit(lambda: ne.metrics.CategoricalCrossentropy(label_weights=w5)(t5, torch.softmax(lg5, -1)), n=30), 96 ** 3 * 256)
 row('MeanSquaredErrorProb', timeit(lambda: ne.metrics.MeanSquaredErrorProb()(fix, p)), nvox * 256)
 row('mean_dice (weights [1, L])', timeit(lambda: ne.metrics.Dice(weights=w[None]).mean_dice(fix, mov)), nvox * 256)
 st = ne.layers.SpatialTransformer(interp_method='nearest')
