@@ -31,6 +31,9 @@ struct LcArgs {
     int kr, kc, kz, sr, sc, sz;
     int orr, occ, ozz, Cout;
     int act;
+    int stage_chunks;     // > 0: the patch of a position is kr * kc runs of kz * Cin contiguous elements whose byte length is a multiple
+                          // of 16: it is staged in LDS with this many 16-byte loads per batch entry (<= 256) instead of one load per
+                          // element and lane (forward kernel)
 };
 
 __device__ __forceinline__ float to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -58,8 +61,9 @@ template <> __device__ __forceinline__ float buf_load_elem<float>(__amdgpu_buffe
 // SPLIT = 2: layers with more than 16 row groups per lane (32 filters in bfloat16: 27) -- two waves share a position, each streams
 // half of the rows with the 16-group registers budget and the halves meet in LDS (one wave with all 32 groups in flight spilled
 // 200 registers to scratch)
-template <typename T, int NB, int MAXIT, bool NT, int SPLIT = 1>
+template <typename T, int NB, int MAXIT, bool STAGED, int SPLIT = 1>
 __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
+    constexpr bool NT = true;                      // weights are streamed once: non-temporal loads
     constexpr int VEC = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(VEC)));
     const int LPR = a.Cout / VEC;                  // lanes per weight row (power of two, <= 64)
@@ -74,6 +78,35 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
     const long long nwaves = (long long)gridDim.x * ((blockDim.x >> 6) / SPLIT);
     const T *xb = (const T *)a.x;
     __shared__ float red[SPLIT > 1 ? 3 * 4 * 64 : 1];                         // [positions of a block x other parts <= 3][NB][Cout <= 64]
+    // staged patches: [wave][NB][stage_chunks * 16 bytes], private to the wave (its LDS operations execute in order: no barrier)
+    extern __shared__ __attribute__((aligned(16))) char lc_patch[];
+    typedef unsigned u32x4z __attribute__((ext_vector_type(4)));
+    constexpr int NCH = 2;                                                    // 16-byte loads per lane and batch entry (<= 128 chunks)
+    constexpr bool staged = STAGED;
+    const unsigned pbytes = (unsigned)a.stage_chunks * 16u + 16u;             // + a zero slot: what the dead row groups of a lane read
+    char *mypatch = lc_patch + (size_t)(threadIdx.x >> 6) * NB * pbytes;
+    unsigned loff[MAXIT];                                                     // byte offset of this lane's element of row group it in the staged patch
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int f = (itb + it) * RPW + row0;
+        loff[it] = ((itb + it < nit) && (f < F)) ? (unsigned)f * (unsigned)sizeof(T) : pbytes - 16u;
+    }
+    if (STAGED && lane == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) *(u32x4z *)(mypatch + b * pbytes + pbytes - 16u) = (u32x4z){0u, 0u, 0u, 0u};
+    }
+    unsigned choff[NCH];                                                      // byte offset of this lane's chunk from the patch origin
+    {
+        const unsigned cpr = (unsigned)(a.kz * a.Cin) * (unsigned)sizeof(T) / 16u;   // chunks per run
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const unsigned c = (unsigned)k * 64u + (unsigned)lane;
+            const unsigned cc = staged && c < (unsigned)a.stage_chunks ? c : 0u;
+            const unsigned run = staged ? cc / cpr : 0u, j = staged ? cc % cpr : 0u;
+            const unsigned dr = run / (unsigned)a.kc, dc = run % (unsigned)a.kc;
+            choff[k] = ((dr * (unsigned)a.C + dc) * (unsigned)a.Z) * (unsigned)a.Cin * (unsigned)sizeof(T) + j * 16u;
+        }
+    }
     // a lane touches the same patch elements f = it * RPW + row0 at every position: their offsets
     // relative to the patch origin are computed once (the divisions are not in the streaming loop)
     int xoff[MAXIT];
@@ -101,7 +134,8 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
         const long long oreal = ob + wave / SPLIT;
         const bool oact = oreal < O;
         const long long o = oact ? oreal : O - 1;
-        const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
+        const unsigned o32 = (unsigned)o, q32 = o32 / (unsigned)a.ozz;              // positions fit 32 bits (launchers): no 64-bit division here
+        const int oz = (int)(o32 - q32 * (unsigned)a.ozz), oc = (int)(q32 % (unsigned)a.occ), orr = (int)(q32 / (unsigned)a.occ);
         const unsigned xbase = (unsigned)((((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin * (long long)sizeof(T));
         const char *kp = (const char *)((const T *)a.k + o * (long long)F * a.Cout);
         const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void *)kp, 0, (int)wbytes, 0x00020000);
@@ -118,17 +152,43 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
         for (int c0 = 0; c0 < MAXIT; c0 += CH) {
             vec_t w[CH];
             T xr[NB][CH];
+            if constexpr (STAGED) {
+                // the patch as 16-byte pieces (requested BEFORE the weights: vmcnt retires in order and the pieces are wanted first),
+                // through LDS to the lanes: one or two loads per batch entry instead of one per element
+                const int nk = (a.stage_chunks + 63) >> 6;
+                u32x4 pc[NB][NCH];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, (itb + c0 + i) * 1024, NT ? 2 : 0);
-                w[i] = __builtin_bit_cast(vec_t, raw);
-            }
+                for (int b = 0; b < NB; ++b) {
+                    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-                    (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
+                    for (int k = 0; k < NCH; ++k)
+                        if (k < nk) pc[b][k] = __builtin_amdgcn_raw_buffer_load_b128(xres, choff[k], xbase, 0);
+                }
 #pragma unroll
-                for (int i = 0; i < CH; ++i) xr[b][i] = buf_load_elem<T>(xres, xvoff[c0 + i], xbase);
+                for (int i = 0; i < CH; ++i) {
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, (itb + c0 + i) * 1024, NT ? 2 : 0);
+                    w[i] = __builtin_bit_cast(vec_t, raw);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int k = 0; k < NCH; ++k)
+                        if (k < nk && k * 64 + lane < a.stage_chunks) *(u32x4 *)(mypatch + b * pbytes + (k * 64 + lane) * 16) = pc[b][k];
+                __builtin_amdgcn_wave_barrier();                  // the pieces of the other lanes: same wave, LDS operations in order
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, (itb + c0 + i) * 1024, NT ? 2 : 0);
+                    w[i] = __builtin_bit_cast(vec_t, raw);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)(xb + (long long)(b0 + (b < nb ? b : 0)) * xbs), 0, (int)(xbs * (long long)sizeof(T)), 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) xr[b][i] = buf_load_elem<T>(xres, xvoff[c0 + i], xbase);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -137,19 +197,31 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
                 const bool live = (it < nit) && (it * RPW + row0 < F);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    const float xv = live ? to_f32(xr[b][i]) : 0.0f;
+                    T xe;
+                    if constexpr (STAGED) xe = *(const T *)(mypatch + b * pbytes + loff[c0 + i]);
+                    else xe = xr[b][i];
+                    const float xv = (STAGED || live) ? to_f32(xe) : 0.0f;      // staged: dead row groups read the zero slot
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) acc[b][e] = fmaf(xv, to_f32(w[i][e]), acc[b][e]);
                 }
+                if (STAGED && NB > 1 && sizeof(T) == 2 && (i & 1)) __builtin_amdgcn_sched_barrier(0);   // keeps the widened weights of two row groups live, not sixteen
             }
             if (c0 + CH < MAXIT) __builtin_amdgcn_sched_barrier(0);
         }
         // ---- combine the 64 / LPR row slices ----------------------------------------------------
+        // (level by level with the NB x VEC exchanges of a level in flight together: the other nesting -- a run-time loop over the
+        // levels per value -- was a chain of NB x VEC x log2(64 / LPR) dependent LDS round trips per position)
+        for (int off = LPR; off < 64; off <<= 1) {
+            float other[NB][VEC];
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e)
-                for (int off = LPR; off < 64; off <<= 1) acc[b][e] += __shfl_xor(acc[b][e], off, 64);
+                for (int e = 0; e < VEC; ++e) other[b][e] = __shfl_xor(acc[b][e], off, 64);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[b][e] += other[b][e];
+        }
         if (SPLIT > 1) {                                 // the other waves' shares of the sum go through LDS
             float *rp = red + (wave / SPLIT) * ((SPLIT - 1) * 4 * 64);
             if (part > 0 && lane < LPR) {
@@ -170,16 +242,25 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
             __syncthreads();
         }
         if (lane < LPR && part == 0 && oact) {
+            // bias and output rows are 16-byte vectors per lane (one load, one store per batch entry; element-wise loads with a wait
+            // each were a chain of NB x VEC memory latencies per position)
+            vec_t bv;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) bv[e] = (T)0;
+            if (a.bias) bv = *(const vec_t *)((const T *)a.bias + o * a.Cout + sl * VEC);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 if (b < nb) {
-                    T *yp = (T *)a.y + ((long long)(b0 + b) * O + o) * a.Cout + sl * VEC;
+                    vec_t ov;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         float v = acc[b][e];
-                        if (a.bias) v += to_f32(((const T *)a.bias)[o * a.Cout + sl * VEC + e]);
-                        store_out(yp + e, lc_act(v, a.act));
+                        if (a.bias) v += to_f32(bv[e]);
+                        T q;
+                        store_out(&q, lc_act(v, a.act));
+                        ov[e] = q;
                     }
+                    *(vec_t *)((T *)a.y + ((long long)(b0 + b) * O + o) * a.Cout + sl * VEC) = ov;
                 }
             }
         }
@@ -212,32 +293,33 @@ __global__ __launch_bounds__(256) void lc3d_generic(LcArgs a) {
     }
 }
 
-template <typename T, int MAXIT, bool NT, int SPLIT = 1>
-void launch_vec_nt(const LcArgs &a, unsigned blocks, hipStream_t st) {
+template <typename T, int MAXIT, bool STAGED, int SPLIT = 1>
+void launch_vec_st(const LcArgs &a, unsigned blocks, hipStream_t st) {
     for (int b0 = 0; b0 < a.B; b0 += 4) {
         const int nb = a.B - b0 < 4 ? a.B - b0 : 4;
-        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT, NT, SPLIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
-        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT, NT, SPLIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
-        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT, NT, SPLIT>), dim3(blocks), dim3(256), 0, st, a, b0, nb);
+        const size_t ps = ((size_t)a.stage_chunks * 16 + 16) * 4;               // per batch entry: 4 waves, + the zero slot
+        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), ps, st, a, b0, nb);
+        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), 2 * ps, st, a, b0, nb);
+        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), 4 * ps, st, a, b0, nb);
     }
 }
 
 template <typename T, int MAXIT, int SPLIT = 1>
 void launch_vec(const LcArgs &a, hipStream_t st) {
-    // experiment knobs: NRT_LC_BLOCKS (grid size), NRT_LC_NT (0: plain weight loads)
-    static int kblocks = -1, knt = -1;
+    // experiment knob: NRT_LC_BLOCKS (grid size)
+    static int kblocks = -1;
     if (kblocks < 0) { const char *e = getenv("NRT_LC_BLOCKS"); kblocks = e ? atoi(e) : 0; }
-    if (knt < 0) { const char *e = getenv("NRT_LC_NT"); knt = e ? atoi(e) : 1; }
     const long long O = (long long)a.orr * a.occ * a.ozz;
     unsigned blocks = (unsigned)((O + 4 / SPLIT - 1) / (4 / SPLIT));
     const unsigned cap = kblocks > 0 ? (unsigned)kblocks : 256u * 20u;     // 5 resident blocks per CU x 4 rounds (profiles/)
     if (blocks > cap) blocks = cap;
-    if (knt) launch_vec_nt<T, MAXIT, true, SPLIT>(a, blocks, st);
-    else launch_vec_nt<T, MAXIT, false, SPLIT>(a, blocks, st);
+    if (a.stage_chunks > 0) launch_vec_st<T, MAXIT, true, SPLIT>(a, blocks, st);
+    else launch_vec_st<T, MAXIT, false, SPLIT>(a, blocks, st);
 }
 
 template <typename T>
-int launch_any(const LcArgs &a, int variant, hipStream_t st) {
+int launch_any(const LcArgs &a_in, int variant, hipStream_t st) {
+    const LcArgs &a = a_in;
     constexpr int VEC = 16 / (int)sizeof(T);
     const int F = a.kr * a.kc * a.kz * a.Cin;
     bool vec_ok = (a.Cout % VEC) == 0;
@@ -250,6 +332,13 @@ int launch_any(const LcArgs &a, int variant, hipStream_t st) {
     if (variant == 0) variant = vec_ok ? 2 : 1;
     if (variant == 2) {
         if (!vec_ok) return NRT_ERR_UNSUPPORTED;
+        LcArgs a = a_in;
+        // stage the patch through LDS when its kr * kc runs (kz * Cin contiguous elements) are whole 16-byte pieces
+        const long long runb = (long long)a.kz * a.Cin * (long long)sizeof(T), chunks = runb / 16 * a.kr * a.kc;
+        static int kstage = -1;
+        if (kstage < 0) { const char *e = getenv("NRT_LC_STAGE"); kstage = e ? atoi(e) : 1; }
+        a.stage_chunks = (kstage && runb % 16 == 0 && ((long long)a.Cin * (long long)sizeof(T)) % 16 == 0 && chunks <= 128 &&
+                          (((uintptr_t)a.x) & 15) == 0 && chunks * 16 * 4 * 4 <= 48 * 1024) ? (int)chunks : 0;
         if (nit <= 8) launch_vec<T, 8>(a, st);
         else if (nit <= 14) launch_vec<T, 14>(a, st);
         else if (nit <= 16) launch_vec<T, 16>(a, st);
@@ -314,7 +403,8 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb)
     const unsigned wbytes = (unsigned)F * (unsigned)a.Cout * (unsigned)sizeof(T);
     const long long xbs = (long long)a.R * a.C * a.Z * a.Cin;
     for (long long o = (long long)blockIdx.x * ((blockDim.x >> 6) / SPLIT) + wave / SPLIT; o < O; o += nwaves) {
-        const int oz = (int)(o % a.ozz), oc = (int)((o / a.ozz) % a.occ), orr = (int)(o / ((long long)a.ozz * a.occ));
+        const unsigned o32 = (unsigned)o, q32 = o32 / (unsigned)a.ozz;              // positions fit 32 bits (launchers): no 64-bit division here
+        const int oz = (int)(o32 - q32 * (unsigned)a.ozz), oc = (int)(q32 % (unsigned)a.occ), orr = (int)(q32 / (unsigned)a.occ);
         const long long xbase_e = (((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin;
         const unsigned xbase = (unsigned)(xbase_e * (long long)sizeof(T));
         // ---- this lane's cout slice of dpre[b][o] -------------------------------------------------------------------------
@@ -385,27 +475,57 @@ __global__ __launch_bounds__(256, 2) void lc3d_bwd(LcBwdArgs ba, int b0, int nb)
                 for (int e = 0; e < VEC; ++e) { T tmp; store_out(&tmp, acc[e]); ov[e] = tmp; }
                 __builtin_nontemporal_store(ov, dst);
             }
-            if (HAS_DX) {
+        }
+        if (HAS_DX) {
+            // dx[b][patch element f] += sum over cout of w[f][:] * dpre[b][:]: the partial sums of all row groups and batch entries of
+            // the chunk cross the cout slices of a row level by level (one level = CH x NB independent exchanges in flight; a run-time
+            // loop per value was a chain of CH x NB x log2(LPR) dependent LDS round trips)
+            float t[CH][NB];
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    float t = 0.0f;
+                    float v = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) t = fmaf(to_f32(w[HAS_DX ? i : 0][e]), dp[b][e], t);
-                    for (int off2 = 1; off2 < LPR; off2 <<= 1) t += __shfl_xor(t, off2, 64);      // over the cout slices of row f
-                    if (live && sl == 0 && b < nb)
-                        unsafeAtomicAdd(ba.dx + (long long)(b0 + b) * xbs + xbase_e + (long long)(xvoff[c0 + i] / (unsigned)sizeof(T)), t);
+                    for (int e = 0; e < VEC; ++e) v = fmaf(to_f32(w[HAS_DX ? i : 0][e]), dp[b][e], v);
+                    t[i][b] = v;
                 }
+            for (int off2 = 1; off2 < LPR; off2 <<= 1) {
+                float u[CH][NB];
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) u[i][b] = __shfl_xor(t[i][b], off2, 64);
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) t[i][b] += u[i][b];
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int it = itb + c0 + i;
+                const bool live = (it < nit) && (it * RPW + row0 < F);
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if (live && sl == 0 && b < nb)
+                        unsafeAtomicAdd(ba.dx + (long long)(b0 + b) * xbs + xbase_e + (long long)(xvoff[c0 + i] / (unsigned)sizeof(T)), t[i][b]);
             }
         }
         }
         if (ba.dbias && lane < LPR && part == 0) {
-            T *dbp = (T *)ba.dbias + o * a.Cout + sl * VEC;
+            vec_t *dbp = (vec_t *)((T *)ba.dbias + o * a.Cout + sl * VEC);            // one 16-byte row slice per lane
+            vec_t oldv;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) oldv[e] = (T)0;
+            if (b0 > 0) oldv = *dbp;
+            vec_t nv;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                float v = db[e];
-                if (b0 > 0) v += to_f32(dbp[e]);
-                store_out(dbp + e, v);
+                T q;
+                store_out(&q, b0 > 0 ? db[e] + to_f32(oldv[e]) : db[e]);
+                nv[e] = q;
             }
+            *dbp = nv;
         }
     }
 }
@@ -465,7 +585,7 @@ extern "C" int nrt_lc3d_bwd_f(const void *x, const void *kernel, const void *y, 
     if (a.kr < 1 || a.kc < 1 || a.kz < 1 || a.sr < 1 || a.sc < 1 || a.sz < 1) return NRT_ERR_INVALID_ARG;
     if (a.R < a.kr || a.C < a.kc || a.Z < a.kz) return NRT_ERR_INVALID_ARG;
     a.orr = (a.R - a.kr) / a.sr + 1; a.occ = (a.C - a.kc) / a.sc + 1; a.ozz = (a.Z - a.kz) / a.sz + 1;
-    a.Cout = cout; a.act = activation;
+    a.Cout = cout; a.act = activation; a.stage_chunks = 0;
     ba.g = grad_out; ba.dk = grad_kernel; ba.dbias = grad_bias; ba.dx = grad_x;
     hipStream_t st = nrt_stream(stream);
     if (dtype == NRT_DT_F32) return launch_bwd<float>(ba, st);
@@ -488,7 +608,7 @@ extern "C" int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, v
     if (a.kr < 1 || a.kc < 1 || a.kz < 1 || a.sr < 1 || a.sc < 1 || a.sz < 1) return NRT_ERR_INVALID_ARG;
     if (a.R < a.kr || a.C < a.kc || a.Z < a.kz) return NRT_ERR_INVALID_ARG;
     a.orr = (a.R - a.kr) / a.sr + 1; a.occ = (a.C - a.kc) / a.sc + 1; a.ozz = (a.Z - a.kz) / a.sz + 1;   // 'valid'
-    a.Cout = cout; a.act = activation;
+    a.Cout = cout; a.act = activation; a.stage_chunks = 0;
     hipStream_t st = nrt_stream(stream);
     if (dtype == NRT_DT_F32) return launch_any<float>(a, variant, st);
     return launch_any<unsigned short>(a, variant, st);
