@@ -32,6 +32,11 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float activate(float v, int act) { return nrt_activate_fused(v, act); }
+// exp(d) for the channel softmax (d = x - max <= 0): one v_exp_f32 on the argument scaled by log2(e) instead of the ~17-instruction
+// libm expansion -- the 1x1 + softmax head was bound by VALU issue (185 instructions per 8 voxels), not by its 786 MB.  Relative error
+// <= 2^-23 + |d| 2^-24 (|d| < 40 for anything that survives the sum): below 2e-6, inside the 1e-5 of the layer tests
+__device__ __forceinline__ float softmax_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.44269504088896341f); }
+__device__ __forceinline__ float softmax_rcp(float s) { return __builtin_amdgcn_rcpf(s); }          // s in [1, C]: 1 ulp
 __device__ __forceinline__ float activate_ew(float v, int act) { return nrt_activate(v, act); }
 
 struct ConvArgs {
@@ -414,7 +419,10 @@ __global__ __launch_bounds__(256) void conv1x1_softmax(const float *__restrict__
 // channels, so a voxel's output row is written as one contiguous Cout*4-byte segment (the one-thread-per-voxel
 // forms above write 64-128 B per thread at a 64-128 B stride: 64 cache lines per store instruction).
 // conv1x1_vec: the likelihood head (+ softmax across the lane-group with xor-shuffles).
-template <int G>
+// CIN > 0: the input-channel count as a template parameter (multiple of 4, 16-byte aligned rows): the voxel's row is requested
+// as CIN / 4 float4 loads up front (the G lanes of a voxel read the same addresses: one L1 access) and the contraction is fully
+// unrolled; CIN = 0 keeps the run-time loop with one scalar load per input channel (a chain of Cin dependent L1 round trips per voxel)
+template <int G, int CIN = 0>
 __global__ __launch_bounds__(256) void conv1x1_vec(const float *__restrict__ x, const float *__restrict__ w,
                                                    const float *__restrict__ bias, float *__restrict__ y, long long nvox,
                                                    int Cin, int softmax, int act) {
@@ -426,32 +434,126 @@ __global__ __launch_bounds__(256) void conv1x1_vec(const float *__restrict__ x, 
     __syncthreads();
     const int lg = threadIdx.x % G;
     const long long g = threadIdx.x / G;
-    for (long long q = (long long)blockIdx.x * NG + g; q < nvox; q += (long long)gridDim.x * NG) {
-        f32x4 acc = *(const f32x4 *)&wl[Cin * Cout + 4 * lg];
-        const float *xp = x + q * Cin;
-        for (int ci = 0; ci < Cin; ++ci) {
-            const float xv = xp[ci];                       // same address for the G lanes of the voxel (broadcast)
-            const f32x4 wv = *(const f32x4 *)&wl[ci * Cout + 4 * lg];
+    // U voxel groups per wave and iteration when the rows are loaded as float4: their U * CIN / 4 loads are in flight together (one
+    // group per iteration kept 512 bytes per wave in flight -- the kernel ran at the latency of its loads, 4 TB/s)
+    constexpr int U = CIN > 0 ? 4 : 1;
+    const long long stride = (long long)gridDim.x * NG;
+    for (long long q0 = (long long)blockIdx.x * NG + g; q0 < nvox; q0 += U * stride) {
+        f32x4 xr[U][CIN > 0 ? CIN / 4 : 1];
+        if (CIN > 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+            for (int u = 0; u < U; ++u) {
+                const long long qq = q0 + u * stride < nvox ? q0 + u * stride : nvox - 1;
+#pragma unroll
+                for (int k = 0; k < CIN / 4; ++k) xr[u][k] = *(const f32x4 *)(x + qq * CIN + 4 * k);
+            }
         }
-        if (softmax) {
-            float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
 #pragma unroll
-            for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-            float sum = 0.0f;
+        for (int u = 0; u < U; ++u) {
+            const long long q = q0 + u * stride;
+            if (q >= nvox) break;
+            f32x4 acc = *(const f32x4 *)&wl[Cin * Cout + 4 * lg];
+            if (CIN > 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[e] = expf(acc[e] - m); sum += acc[e]; }
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float xv = xr[u][ci >> 2][ci & 3];
+                    const f32x4 wv = *(const f32x4 *)&wl[ci * Cout + 4 * lg];
 #pragma unroll
-            for (int off = 1; off < G; off <<= 1) sum += __shfl_xor(sum, off, 64);
-            const float inv = 1.0f / sum;
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+                }
+            } else {
+                const float *xp = x + q * Cin;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float xv = xp[ci];                       // same address for the G lanes of the voxel (broadcast)
+                    const f32x4 wv = *(const f32x4 *)&wl[ci * Cout + 4 * lg];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] *= inv;
-        } else {
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+                }
+            }
+            if (softmax) {
+                float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = activate(acc[e], act);
+                for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                float sum = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[e] = softmax_exp(acc[e] - m); sum += acc[e]; }
+#pragma unroll
+                for (int off = 1; off < G; off <<= 1) sum += __shfl_xor(sum, off, 64);
+                const float inv = softmax_rcp(sum);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] *= inv;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = activate(acc[e], act);
+            }
+            __builtin_nontemporal_store(acc, (f32x4 *)(y + q * Cout) + lg);
         }
-        __builtin_nontemporal_store(acc, (f32x4 *)(y + q * Cout) + lg);
+    }
+}
+
+// The likelihood layer of the unets (16 features -> 4 G labels, softmax): every lane loads a DISTINCT float4 of the input (64 lanes =
+// 16 voxel rows = 1 KB contiguous per instruction, U instructions in flight per wave), the rows cross to the G lanes of their voxel
+// through a wave-private LDS tile.  (conv1x1_vec lets the G lanes of a voxel load the same row: 512 distinct bytes in flight per
+// wave, and the kernel ran at the latency of its loads -- 4 TB/s on 786 MB.)
+template <int G>
+__global__ __launch_bounds__(256) void conv1x1_rows16(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, float *__restrict__ y, long long nvox,
+                                                      int softmax, int act) {
+    constexpr int CIN = 16, Cout = 4 * G, U = 4, VPP = 64 / G, NPASS = 16 / VPP;      // voxels per pass, passes per 16-voxel load
+    __shared__ __attribute__((aligned(16))) float xs[4][16 * CIN];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lg = lane % G, gv = lane / G;
+    f32x4 wr[CIN];                                                                       // this lane's 4 output channels of every input channel
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) wr[ci] = *(const f32x4 *)(w + ci * Cout + 4 * lg);
+    f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (bias) bv = *(const f32x4 *)(bias + 4 * lg);
+    float *tile = xs[wave];
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long base = ((long long)blockIdx.x * 4 + wave) * (16 * U); base < nvox; base += nwaves * (16 * U)) {
+        f32x4 xq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long v = base + u * 16 + (lane >> 2);
+            xq[u] = *(const f32x4 *)(x + (v < nvox ? v : nvox - 1) * CIN + 4 * (lane & 3));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            *(f32x4 *)(tile + lane * 4) = xq[u];                                          // [voxel][16 floats] as loaded
+            __builtin_amdgcn_wave_barrier();                                              // same wave: LDS operations execute in order
+#pragma unroll
+            for (int p = 0; p < NPASS; ++p) {
+                const long long q = base + u * 16 + p * VPP + gv;
+                const float *row = tile + (p * VPP + gv) * CIN;
+                f32x4 acc = bv;
+#pragma unroll
+                for (int k = 0; k < CIN / 4; ++k) {
+                    const f32x4 xv = *(const f32x4 *)(row + 4 * k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv[j], wr[4 * k + j][e], acc[e]);
+                }
+                if (softmax) {
+                    float m = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+#pragma unroll
+                    for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[e] = softmax_exp(acc[e] - m); sum += acc[e]; }
+#pragma unroll
+                    for (int off = 1; off < G; off <<= 1) sum += __shfl_xor(sum, off, 64);
+                    const float inv = softmax_rcp(sum);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] *= inv;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = activate(acc[e], act);
+                }
+                if (q < nvox) __builtin_nontemporal_store(acc, (f32x4 *)(y + q * Cout) + lg);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
@@ -580,11 +682,11 @@ __global__ __launch_bounds__(256) void softmax_lastdim_vec(const f32x4 *__restri
         for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
         f32x4 e;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = expf(xv[k] - m);
+        for (int k = 0; k < 4; ++k) e[k] = softmax_exp(xv[k] - m);
         float s = (e[0] + e[1]) + (e[2] + e[3]);
 #pragma unroll
         for (int off = 1; off < G; off <<= 1) s += __shfl_xor(s, off, 64);
-        const float inv = 1.0f / s;
+        const float inv = softmax_rcp(s);
 #pragma unroll
         for (int k = 0; k < 4; ++k) e[k] *= inv;
         if (live) y[v * G + lg] = e;
@@ -663,6 +765,38 @@ __global__ __launch_bounds__(256) void add_act_affine(const float *__restrict__ 
         }
         if (scale) v = v * scale[e % C] + shift[e % C];
         y[e] = v;
+    }
+}
+
+// the same on float4 (n, C multiples of 4, 16-byte aligned tensors): the channel of a thread's float4 advances by a fixed step per
+// grid stride, so the per-element 64-bit modulo of the scalar form becomes one per thread
+__global__ __launch_bounds__(256) void add_act_affine_v4(const f32x4 *__restrict__ a, const f32x4 *__restrict__ bsrc,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift,
+                                                         f32x4 *__restrict__ y, long long n4, int C4, int act) {
+    const bool mul = (act & ACT_MUL_B) != 0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned c = (unsigned)(e % C4);
+    const unsigned cstep = (unsigned)(stride % C4);
+    for (; e < n4; e += stride) {
+        f32x4 v = a[e];
+        if (mul) {
+            const f32x4 b = bsrc[e];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = activate_ew(v[k], act & 0xff) * b[k];
+        } else {
+            if (bsrc) v += bsrc[e];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = activate_ew(v[k], act);
+        }
+        if (scale) {
+            const f32x4 sc = *(const f32x4 *)(scale + 4 * c), sh = *(const f32x4 *)(shift + 4 * c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] * sc[k] + sh[k];
+        }
+        y[e] = v;
+        c += cstep;
+        if (c >= (unsigned)C4) c -= (unsigned)C4;
     }
 }
 
@@ -918,6 +1052,22 @@ extern "C" int nrt_conv1x1_softmax_f32(const float *x, const float *weights, con
         const unsigned ng = 256 / G;
         unsigned vb = (unsigned)((nvox + ng - 1) / ng);
         if (vb > 256u * 32u) vb = 256u * 32u;
+        const bool rows16 = (((uintptr_t)x) & 15) == 0;
+        if (cin == 16 && rows16 && (G == 4 || G == 8 || G == 16) && ((((uintptr_t)weights) | ((uintptr_t)bias)) & 15) == 0) {
+            // the likelihood layer of the unets (16 features -> 16 / 32 / 64 labels)
+            unsigned rb = (unsigned)((nvox + 255) / 256);
+            if (rb > 256u * 5u) rb = 256u * 5u;
+            if (G == 4) hipLaunchKernelGGL((conv1x1_rows16<4>), dim3(rb), dim3(256), 0, st, x, weights, bias, y, nvox, softmax, activation);
+            else if (G == 8) hipLaunchKernelGGL((conv1x1_rows16<8>), dim3(rb), dim3(256), 0, st, x, weights, bias, y, nvox, softmax, activation);
+            else hipLaunchKernelGGL((conv1x1_rows16<16>), dim3(rb), dim3(256), 0, st, x, weights, bias, y, nvox, softmax, activation);
+            NRT_CHECK_LAUNCH();
+            return NRT_OK;
+        }
+        if (cin == 32 && rows16 && G == 8) {
+            hipLaunchKernelGGL((conv1x1_vec<8, 32>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation);
+            NRT_CHECK_LAUNCH();
+            return NRT_OK;
+        }
         switch (G) {
             case 1: hipLaunchKernelGGL((conv1x1_vec<1>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation); break;
             case 2: hipLaunchKernelGGL((conv1x1_vec<2>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation); break;
@@ -998,6 +1148,16 @@ extern "C" int nrt_add_act_affine_f32(const float *a, const float *b, const floa
     if ((activation & 0xff) > ACT_LAST || (activation & ~(0xff | ACT_MUL_B)) || activation < 0) return NRT_ERR_INVALID_ARG;
     if ((activation & ACT_MUL_B) && !b) return NRT_ERR_INVALID_ARG;
     if (n == 0) return NRT_OK;
+    const bool v4 = n % 4 == 0 && (!scale || channels % 4 == 0) && channels >= 1 &&
+                    ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)y) | ((uintptr_t)scale) | ((uintptr_t)shift)) & 15) == 0;
+    if (v4) {
+        const long long n4 = n / 4;
+        unsigned blocks4 = (unsigned)((n4 + 255) / 256 < 256 * 16 ? (n4 + 255) / 256 : 256 * 16);
+        hipLaunchKernelGGL(add_act_affine_v4, dim3(blocks4), dim3(256), 0, nrt_stream(stream), (const f32x4 *)a, (const f32x4 *)b, scale,
+                           shift, (f32x4 *)y, n4, scale ? channels / 4 : 1, activation);
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 256u * 32u) blocks = 256u * 32u;
     hipLaunchKernelGGL(add_act_affine, dim3(blocks), dim3(256), 0, nrt_stream(stream), a, b, scale, shift, y, n, channels,
