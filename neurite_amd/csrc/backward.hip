@@ -462,8 +462,9 @@ __global__ __launch_bounds__(256) void dice_soft_bwd_vec(const nrt_f4 *__restric
         ca[k] = 0.0f; cb[k] = 0.0f;
         if (den != 0.0f) { ca[k] = 2.0f * g / den; cb[k] = -2.0f * g * num / (den * den); }
     }
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n4; e += stride) {
+    long long ebeg, eend;                                      // one contiguous range per block (nrt_block_range; G4 | 256 keeps l0 valid)
+    nrt_block_range(n4, 256, ebeg, eend);
+    for (long long e = ebeg + threadIdx.x; e < eend; e += 256) {
         const nrt_f4 tv = tb[e], pv = pb[e];
         if (gp) {
             nrt_f4 o;
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(256) void wcce_bwd_vec(const nrt_f4 *__restrict__ t
     const long long ngroups = (long long)gridDim.x * NG;
     const long long niter = (n + ngroups - 1) / ngroups;
     for (long long it = 0; it < niter; ++it) {
-        const long long vv = (long long)blockIdx.x * NG + threadIdx.x / G + it * ngroups;
+        const long long vv = ((long long)blockIdx.x * niter + it) * NG + threadIdx.x / G;      // a block streams one contiguous range (nrt_block_range)
         const bool live = vv < n;
         const long long v = live ? vv : n - 1;
         const nrt_f4 tv = t[v * G + lg], pv = p[v * G + lg];

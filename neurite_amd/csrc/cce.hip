@@ -58,8 +58,10 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ y
     const float keep = 1.0f - smooth, add = smooth / (float)C;
     float acc = 0.0f;
 
+    long long vbeg, vend;                                      // one contiguous range of voxels per block (nrt_block_range)
+    nrt_block_range(n, NG, vbeg, vend);
 #pragma unroll 2
-    for (long long v = (long long)blockIdx.x * NG + g; v < n; v += stride) {
+    for (long long v = vbeg + g; v < vend; v += NG) {
         const nrt_f4 t = Quad<T>::load(yt, v * G + lg);
         const nrt_f4 p = Quad<T>::load(yp, v * G + lg);
         float lq[4];

@@ -774,11 +774,12 @@ __global__ __launch_bounds__(256) void add_act_affine_v4(const f32x4 *__restrict
                                                          const float *__restrict__ scale, const float *__restrict__ shift,
                                                          f32x4 *__restrict__ y, long long n4, int C4, int act) {
     const bool mul = (act & ACT_MUL_B) != 0;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long ebeg, eend;                                      // one contiguous range per block (nrt_block_range)
+    nrt_block_range(n4, 256, ebeg, eend);
+    long long e = ebeg + threadIdx.x;
     unsigned c = (unsigned)(e % C4);
-    const unsigned cstep = (unsigned)(stride % C4);
-    for (; e < n4; e += stride) {
+    const unsigned cstep = (unsigned)(256 % C4);
+    for (; e < eend; e += 256) {
         f32x4 v = a[e];
         if (mul) {
             const f32x4 b = bsrc[e];

@@ -28,7 +28,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void act_bwd(const nrt_f4 *__restrict__ g, const nrt_f4 *__restrict__ y, int act,
                                                nrt_f4 *__restrict__ d, long long n4) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    long long ibeg, iend;                                      // one contiguous range per block (nrt_block_range)
+    nrt_block_range(n4, 256, ibeg, iend);
+    for (long long i = ibeg + threadIdx.x; i < iend; i += 256) {
         const nrt_f4 gv = g[i], yv = y[i];
         nrt_f4 o;
 #pragma unroll
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_vec(const nrt_f4 *__restrict_
     const long long ngroups = (long long)gridDim.x * NG;
     const long long niter = (nvox + ngroups - 1) / ngroups;
     for (long long it = 0; it < niter; ++it) {
-        const long long vv = (long long)blockIdx.x * NG + threadIdx.x / G + it * ngroups;
+        const long long vv = ((long long)blockIdx.x * niter + it) * NG + threadIdx.x / G;      // a block streams one contiguous range (nrt_block_range)
         const bool live = vv < nvox;
         const long long v = live ? vv : nvox - 1;
         const nrt_f4 yv = y[v * G + lg], gv = g[v * G + lg];

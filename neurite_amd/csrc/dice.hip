@@ -68,8 +68,12 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const void *__restri
     nrt_f4 stp = {0, 0, 0, 0}, stt = {0, 0, 0, 0}, spp = {0, 0, 0, 0};
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
 
+    long long vbeg, vend;                                      // one contiguous range of voxels per block (nrt_block_range)
+    nrt_block_range(nvox, NG, vbeg, vend);
+    vbeg += g;
+    const long long vstep = NG;
 #pragma unroll 4
-    for (long long v = (long long)blockIdx.x * NG + g; v < nvox; v += stride) {
+    for (long long v = vbeg; v < vend; v += vstep) {
         nrt_f4 t = DiceIn<ST>::load4(t4, v * G + lg);
         nrt_f4 p = DiceIn<ST>::load4(p4, v * G + lg);
         if (NORMALIZE) {
@@ -214,8 +218,10 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const void *__restri
     unsigned ntp[4] = {0, 0, 0, 0}, nt[4] = {0, 0, 0, 0}, np_[4] = {0, 0, 0, 0};
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
 
+    long long vbeg, vend;
+    nrt_block_range(nvox, NG, vbeg, vend);
 #pragma unroll 2
-    for (long long v = (long long)blockIdx.x * NG + g; v < nvox; v += stride) {
+    for (long long v = vbeg + g; v < vend; v += NG) {
         const nrt_f4 t = DiceIn<ST>::load4(t4, v * G + lg);
         const nrt_f4 p = DiceIn<ST>::load4(p4, v * G + lg);
         if (MINMAX) {

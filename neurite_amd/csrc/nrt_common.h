@@ -54,6 +54,17 @@ __device__ __forceinline__ unsigned nrt_xcd_block(unsigned bid, unsigned grid) {
     return (bid % NRT_NXCD) * per + bid / NRT_NXCD;
 }
 
+// Contiguous share [beg, end) of n work items for this block (block.x of grid.x), in multiples of `unit` items.  A grid-strided
+// loop makes every block jump by the whole grid each iteration (8 MB apart on the bench tensors): measured on soft Dice 5.2 TB/s
+// against 6.4 TB/s when a block streams through ONE contiguous range (DRAM / TLB page locality), so the streaming kernels use this.
+__device__ __forceinline__ void nrt_block_range(long long n, long long unit, long long &beg, long long &end) {
+    const long long chunk = (long long)gridDim.x * unit;
+    const long long per = ((n + chunk - 1) / chunk) * unit;
+    beg = (long long)blockIdx.x * per;
+    if (beg > n) beg = n;
+    end = beg + per < n ? beg + per : n;
+}
+
 static inline unsigned nrt_xcd_grid(unsigned nblocks) {
     return NRT_NXCD * ((nblocks + NRT_NXCD - 1) / NRT_NXCD);
 }
