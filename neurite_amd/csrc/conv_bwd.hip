@@ -476,6 +476,164 @@ __global__ __launch_bounds__(256) void conv3d_wgrad(WgArgs a) {
     if (a.db && cic == 0 && threadIdx.x < CO && co0 + (int)threadIdx.x < a.Cout) unsafeAtomicAdd(&a.db[co0 + threadIdx.x], bsum);
 }
 
+// Folded weight gradient of a decoder convolution, all 8 parity groups per block (see nrt_conv3d_wgrad_s2d_f32):
+//   dWf[P][t][ci][co] = sum_q lo[q + p + t - 1][ci] * dY'[q][P * Cout + co]
+// x = lo [B, X, Y, Z, Cin] on the low-resolution grid, dp = the space-to-depth gradient [B, X, Y, Z, 8 * Cout].  One block stages the
+// halo tile of lo ONCE and the dY' tile of all 8 groups (128 rows x 8 * 16 channels), wave w owns the taps t = (i, w >> 1, w & 1),
+// i in {0, 1}, of every group: 16 accumulator sets of NA x 1 tiles.  (The grid.z-per-group form of the first version staged the halo
+// tile 8 times per voxel tile and was bound by that traffic.)
+template <int NA>
+__global__ __launch_bounds__(256) void conv3d_wgrad_fold(WgArgs a) {
+    constexpr int CC = 16 * NA, CO = 16, COB = 8 * CO;
+    constexpr int RSA = (CC % 32 == 0) ? CC + 16 : CC, RSB = COB + 16;       // row strides: 16 mod 32 floats
+    constexpr int HX = WT_X + 2, HY = WT_Y + 2, HZ = WT_Z + 2, NROWA = HX * HY * HZ;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *la = lds;                                            // [NROWA][RSA]
+    float *lb = lds + NROWA * RSA;                              // [128][RSB]: column block P = parity group
+    const int cic = blockIdx.y % a.ncic, coc = blockIdx.y / a.ncic;
+    const int ci0 = cic * CC, co0 = coc * CO;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    f32x4 acc[8][2][NA];
+#pragma unroll
+    for (int P = 0; P < 8; ++P)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int na = 0; na < NA; ++na) acc[P][i][na] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    // tap (tx, ty, tz) = (i, wv >> 1, wv & 1) of group P = (px, py, pz) reads halo row offset (px + tx, py + ty, pz + tz)
+    const float *pal[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pal[i] = la + (((i * HY + (wv >> 1)) * HZ + (wv & 1)) + l4) * RSA + l15;
+    const float *pbl = lb + l4 * RSB + l15;
+
+    const long long tiles_per_vol = (long long)a.ntx * a.nty * a.ntz;
+    const long long ntiles = tiles_per_vol * a.B;
+    const unsigned sZ = (unsigned)a.Cin, sY = (unsigned)a.Z * sZ, sX = (unsigned)a.Y * sY;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_vol);
+        const long long tv = tile % tiles_per_vol;
+        const int x0 = (int)(tv / ((long long)a.nty * a.ntz)) * WT_X, y0 = (int)((tv / a.ntz) % a.nty) * WT_Y, z0 = (int)(tv % a.ntz) * WT_Z;
+        const float *xb = a.x + (long long)b * a.X * a.Y * a.Z * a.Cin;
+        const float *pb = a.dp + (long long)b * a.X * a.Y * a.Z * a.dps;
+        __syncthreads();                                        // previous tile fully consumed
+        {   // halo tile of lo: unconditional 16-byte loads from clamped addresses, six in flight per thread, zeroed by select
+            constexpr int QA = CC / 4, TOTA = NROWA * QA, UB = 6;
+            for (int e0 = threadIdx.x; e0 < TOTA; e0 += 256 * UB) {
+                nrt_f4 v[UB];
+                bool ok[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int e = e0 + 256 * u, ee = e < TOTA ? e : 0;
+                    const int r = ee / QA, c4 = (ee % QA) * 4;
+                    const int rz = r % HZ, ry = (r / HZ) % HY, rx = r / (HZ * HY);
+                    const int gx = x0 + rx - 1, gy = y0 + ry - 1, gz = z0 + rz - 1, ch = ci0 + c4;
+                    ok[u] = (e < TOTA) & (gx >= 0) & (gx < a.X) & (gy >= 0) & (gy < a.Y) & (gz >= 0) & (gz < a.Z) & (ch < a.Cin);
+                    const unsigned off = __umul24((unsigned)gx, sX) + __umul24((unsigned)gy, sY) + __umul24((unsigned)gz, sZ) + (unsigned)ch;
+                    v[u] = *(const nrt_f4 *)(xb + (ok[u] ? off : 0u));
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int e = e0 + 256 * u;
+                    if (e < TOTA) *(nrt_f4 *)(la + (e / QA) * RSA + (e % QA) * 4) = ok[u] ? v[u] : (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+        }
+        {   // dY' tile: 128 voxels x 8 groups x 16 channels (this block's cout chunk of every group)
+            constexpr int QB = COB / 4, TOTB = 128 * QB, UBB = 8;
+            for (int e0 = threadIdx.x; e0 < TOTB; e0 += 256 * UBB) {
+                nrt_f4 vb[UBB];
+                bool okb[UBB];
+#pragma unroll
+                for (int u = 0; u < UBB; ++u) {
+                    const int e = e0 + 256 * u;
+                    const int r = e / QB, q = e % QB, P = q / (CO / 4), c4 = (q % (CO / 4)) * 4;
+                    const int rz = r % WT_Z, ry = (r / WT_Z) % WT_Y, rx = r / (WT_Z * WT_Y);
+                    const int gx = x0 + rx, gy = y0 + ry, gz = z0 + rz;
+                    okb[u] = gx < a.X && gy < a.Y && gz < a.Z && co0 + c4 < a.Cout;
+                    const float *src = okb[u] ? pb + (((long long)gx * a.Y + gy) * a.Z + gz) * a.dps + P * a.Cout + co0 + c4 : a.dp;
+                    vb[u] = *(const nrt_f4 *)src;
+                }
+#pragma unroll
+                for (int u = 0; u < UBB; ++u) {
+                    const int e = e0 + 256 * u;
+                    *(nrt_f4 *)(lb + (e / QB) * RSB + (e % QB) * 4) = okb[u] ? vb[u] : (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 32 k-steps of 4 consecutive-z voxels; the operands of step ks + 1 are read while the matrix pipe works on ks ----------
+        auto frag = [&](int ks, float (&af)[8][2][NA], float (&bf)[8]) __attribute__((always_inline)) {
+            const int zh = ks & 1, yy = (ks >> 1) & 3, xx = ks >> 3;
+            const int vrow = (xx * WT_Y + yy) * WT_Z + zh * 4, arow = (xx * HY + yy) * HZ + zh * 4;
+#pragma unroll
+            for (int P = 0; P < 8; ++P) {
+                bf[P] = pbl[vrow * RSB + P * CO];
+                const int poff = (((P >> 2) & 1) * HY + ((P >> 1) & 1)) * HZ + (P & 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int na = 0; na < NA; ++na) af[P][i][na] = pal[i][(arow + poff) * RSA + na * 16];
+            }
+        };
+        auto mma = [&](const float (&af)[8][2][NA], const float (&bf)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int P = 0; P < 8; ++P)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int na = 0; na < NA; ++na)
+                        acc[P][i][na] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[P][i][na], bf[P], acc[P][i][na], 0, 0, 0);
+        };
+        float afA[8][2][NA], afB[8][2][NA], bfA[8], bfB[8];
+        frag(0, afA, bfA);
+#pragma unroll
+        for (int ks = 0; ks < 32; ks += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            frag(ks + 1, afB, bfB);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(afA, bfA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < 32) frag(ks + 2, afA, bfA);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(afB, bfB);
+        }
+    }
+    // ---- accumulate: D row = 4 (lane >> 4) + r (ci), col = lane & 15 (co); tap index t = 4 i + wv ----------------------------------
+#pragma unroll
+    for (int P = 0; P < 8; ++P)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int na = 0; na < NA; ++na) {
+                const int co = co0 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + na * 16 + l4 * 4 + r;
+                    if (ci < a.Cin && co < a.Cout)
+                        unsafeAtomicAdd(&a.dw[((long long)(P * 8 + 4 * i + wv) * a.Cin + ci) * a.Cout + co], acc[P][i][na][r]);
+                }
+            }
+}
+
+template <int NA>
+int launch_wgrad_fold(WgArgs &a, hipStream_t st) {
+    constexpr int CC = 16 * NA, RSA = (CC % 32 == 0) ? CC + 16 : CC, RSB = 8 * 16 + 16;
+    const size_t lds = ((size_t)(WT_X + 2) * (WT_Y + 2) * (WT_Z + 2) * RSA + 128 * RSB) * sizeof(float);
+    a.ncic = (a.Cin + CC - 1) / CC;
+    a.ncoc = (a.Cout + 15) / 16;
+    const long long ntiles = (long long)a.ntx * a.nty * a.ntz * a.B;
+    long long bx = 256ll / (a.ncic * a.ncoc);                   // one block per CU (its LDS), about one resident wave of blocks
+    if (bx < 32) bx = 32;
+    if (bx > ntiles) bx = ntiles;
+    if (hipFuncSetAttribute((const void *)conv3d_wgrad_fold<NA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return NRT_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv3d_wgrad_fold<NA>), dim3((unsigned)bx, a.ncic * a.ncoc), dim3(256), lds, st, a);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
 template <int NA, int NB>
 int launch_wgrad(WgArgs &a, hipStream_t st) {
     constexpr int CC = 16 * NA, CO = 16 * NB;
@@ -699,6 +857,12 @@ extern "C" int nrt_conv3d_wgrad_s2d_f32(const float *x_lo, const float *grad_pre
     a.im2col = 0;
     a.dps = 8 * group; a.fold = 1;
     hipStream_t st = nrt_stream(stream);
+    // all 8 parity groups per block when the staging's assumptions hold (quad-aligned channels, 32-bit offsets, 24-bit strides)
+    const bool foldall = cin % 4 == 0 && group % 4 == 0 && (long long)a.X * a.Y * a.Z * cin < (1ll << 31) &&
+                         (long long)a.Y * a.Z * cin < (1ll << 24) && ((((uintptr_t)x_lo) | ((uintptr_t)grad_pre_s2d)) & 15) == 0;
+    static int kfold = -1;
+    if (kfold < 0) { const char *e = getenv("NRT_WGRAD_FOLDALL"); kfold = e ? atoi(e) : 1; }
+    if (foldall && kfold) return cin <= 16 ? launch_wgrad_fold<1>(a, st) : launch_wgrad_fold<2>(a, st);
     const int na = cin <= 16 ? 1 : (cin <= 32 ? 2 : 3), nb = group <= 16 ? 1 : 2;
     if (na == 1) return nb == 1 ? launch_wgrad<1, 1>(a, st) : launch_wgrad<1, 2>(a, st);
     if (na == 2) return nb == 1 ? launch_wgrad<2, 1>(a, st) : launch_wgrad<2, 2>(a, st);
