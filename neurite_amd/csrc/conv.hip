@@ -491,15 +491,17 @@ __global__ __launch_bounds__(256) void conv1x1_vec(const float *__restrict__ x, 
     }
 }
 
-// The likelihood layer of the unets (16 features -> 4 G labels, softmax): every lane loads a DISTINCT float4 of the input (64 lanes =
-// 16 voxel rows = 1 KB contiguous per instruction, U instructions in flight per wave), the rows cross to the G lanes of their voxel
-// through a wave-private LDS tile.  (conv1x1_vec lets the G lanes of a voxel load the same row: 512 distinct bytes in flight per
-// wave, and the kernel ran at the latency of its loads -- 4 TB/s on 786 MB.)
-template <int G>
-__global__ __launch_bounds__(256) void conv1x1_rows16(const float *__restrict__ x, const float *__restrict__ w,
-                                                      const float *__restrict__ bias, float *__restrict__ y, long long nvox,
-                                                      int softmax, int act) {
-    constexpr int CIN = 16, Cout = 4 * G, U = 4, VPP = 64 / G, NPASS = 16 / VPP;      // voxels per pass, passes per 16-voxel load
+// 1x1x1 convolution (+ channel softmax) with CIN in {16, 32} input channels and 4 G outputs -- the likelihood layer of the unets and
+// its input gradient: every lane loads a DISTINCT float4 of the input (64 lanes = 1 KB contiguous per instruction, U x CIN / 16
+// instructions in flight per wave), the rows of 16 voxels cross to the G lanes of their voxel through a wave-private LDS tile.
+// (conv1x1_vec lets the G lanes of a voxel load the same row: 512 distinct bytes in flight per wave, and the kernel ran at the
+// latency of its loads -- 4 TB/s on 786 MB.)
+template <int G, int CIN>
+__global__ __launch_bounds__(256) void conv1x1_rows(const float *__restrict__ x, const float *__restrict__ w,
+                                                    const float *__restrict__ bias, float *__restrict__ y, long long nvox,
+                                                    int softmax, int act) {
+    constexpr int Cout = 4 * G, U = CIN == 16 ? 4 : 2, LPT = CIN / 16, VPP = 64 / G, NPASS = 16 / VPP;   // loads per 16-voxel tile; voxels per pass
+    static_assert(G == 4 || G == 8 || G == 16, "16 voxels per tile = a whole number of passes");
     __shared__ __attribute__((aligned(16))) float xs[4][16 * CIN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lg = lane % G, gv = lane / G;
@@ -510,16 +512,21 @@ __global__ __launch_bounds__(256) void conv1x1_rows16(const float *__restrict__ 
     if (bias) bv = *(const f32x4 *)(bias + 4 * lg);
     float *tile = xs[wave];
     const long long nwaves = (long long)gridDim.x * 4;
+    const f32x4 *x4 = (const f32x4 *)x;
+    const long long n4 = nvox * (CIN / 4);
     for (long long base = ((long long)blockIdx.x * 4 + wave) * (16 * U); base < nvox; base += nwaves * (16 * U)) {
-        f32x4 xq[U];
+        f32x4 xq[U][LPT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                const long long e = (base + u * 16) * (CIN / 4) + k * 64 + lane;        // float4 index: the tile is 16 * CIN / 4 contiguous float4
+                xq[u][k] = x4[e < n4 ? e : n4 - 1];
+            }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long v = base + u * 16 + (lane >> 2);
-            xq[u] = *(const f32x4 *)(x + (v < nvox ? v : nvox - 1) * CIN + 4 * (lane & 3));
-        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            *(f32x4 *)(tile + lane * 4) = xq[u];                                          // [voxel][16 floats] as loaded
+            for (int k = 0; k < LPT; ++k) *(f32x4 *)(tile + (k * 64 + lane) * 4) = xq[u][k];   // [voxel][CIN floats] as loaded
             __builtin_amdgcn_wave_barrier();                                              // same wave: LDS operations execute in order
 #pragma unroll
             for (int p = 0; p < NPASS; ++p) {
@@ -1054,18 +1061,14 @@ extern "C" int nrt_conv1x1_softmax_f32(const float *x, const float *weights, con
         unsigned vb = (unsigned)((nvox + ng - 1) / ng);
         if (vb > 256u * 32u) vb = 256u * 32u;
         const bool rows16 = (((uintptr_t)x) & 15) == 0;
-        if (cin == 16 && rows16 && (G == 4 || G == 8 || G == 16) && ((((uintptr_t)weights) | ((uintptr_t)bias)) & 15) == 0) {
-            // the likelihood layer of the unets (16 features -> 16 / 32 / 64 labels)
+        if ((cin == 16 || cin == 32) && rows16 && (G == 4 || G == 8 || G == 16) && ((((uintptr_t)weights) | ((uintptr_t)bias)) & 15) == 0) {
+            // the likelihood layer of the unets (16 features -> 16 / 32 / 64 labels) and its input gradient (32 -> 16)
             unsigned rb = (unsigned)((nvox + 255) / 256);
             if (rb > 256u * 5u) rb = 256u * 5u;
-            if (G == 4) hipLaunchKernelGGL((conv1x1_rows16<4>), dim3(rb), dim3(256), 0, st, x, weights, bias, y, nvox, softmax, activation);
-            else if (G == 8) hipLaunchKernelGGL((conv1x1_rows16<8>), dim3(rb), dim3(256), 0, st, x, weights, bias, y, nvox, softmax, activation);
-            else hipLaunchKernelGGL((conv1x1_rows16<16>), dim3(rb), dim3(256), 0, st, x, weights, bias, y, nvox, softmax, activation);
-            NRT_CHECK_LAUNCH();
-            return NRT_OK;
-        }
-        if (cin == 32 && rows16 && G == 8) {
-            hipLaunchKernelGGL((conv1x1_vec<8, 32>), dim3(vb), dim3(256), shm, st, x, weights, bias, y, nvox, cin, softmax, activation);
+#define NRT_ROWS(GG, CC) hipLaunchKernelGGL((conv1x1_rows<GG, CC>), dim3(rb), dim3(256), 0, st, x, weights, bias, y, nvox, softmax, activation)
+            if (cin == 16) { if (G == 4) NRT_ROWS(4, 16); else if (G == 8) NRT_ROWS(8, 16); else NRT_ROWS(16, 16); }
+            else { if (G == 4) NRT_ROWS(4, 32); else if (G == 8) NRT_ROWS(8, 32); else NRT_ROWS(16, 32); }
+#undef NRT_ROWS
             NRT_CHECK_LAUNCH();
             return NRT_OK;
         }

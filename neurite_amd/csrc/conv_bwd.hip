@@ -634,6 +634,161 @@ int launch_wgrad_fold(WgArgs &a, hipStream_t st) {
     return NRT_OK;
 }
 
+// 1x1x1 weight gradient with 16 input channels (the likelihood layer of the unets): D[ci][co] = sum_v x[v][ci] dz[v][co],
+// db[co] = sum_v dz[v][co].  No LDS tiles: the MFMA operand layouts ARE rows of the channels-last tensors -- A[m = ci][k = voxel]
+// is x_flat[16 (v0 + k) + m] (64 consecutive floats per wave instruction), B[k][n] = dz[(v0 + k) Cout + 16 nb + n] -- so a wave
+// streams its own contiguous voxel range with UNR k-steps of loads in flight; the bias gradient is one more MFMA per N-tile with an
+// all-ones A operand.  The four waves of a block meet in LDS, one float atomic per weight and block.  (The tile kernel above stages
+// 24 KB per 128 voxels for 64 MFMAs behind two barriers: 0.40 ms for 786 MB.)
+template <int NB>
+__global__ __launch_bounds__(256) void conv1x1_wgrad16(const float *__restrict__ x, const float *__restrict__ dz, float *__restrict__ dw,
+                                                       float *__restrict__ db, long long nvox, int Cout) {
+    constexpr int UNR = 8;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = lane & 15, k = lane >> 4;
+    f32x4 acc[NB], accb[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { acc[nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; accb[nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+    long long vbeg, vend;                                       // this block's contiguous voxel range, a quarter per wave
+    nrt_block_range(nvox, 4 * 4 * UNR, vbeg, vend);
+    const long long per = (vend - vbeg + 3) / 4, span = ((per + 4 * UNR - 1) / (4 * UNR)) * (4 * UNR);
+    const long long wbeg = vbeg + wv * span, wend = wbeg + span < vend ? wbeg + span : vend;
+    for (long long v0 = wbeg; v0 < wend; v0 += 4 * UNR) {
+        float av[UNR], bvv[UNR][NB];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long long v = v0 + 4 * u + k;
+            const bool ok = v < wend;
+            const long long vv = ok ? v : vbeg;
+            av[u] = x[vv * 16 + m];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bvv[u][nb] = dz[vv * Cout + nb * 16 + m];
+            if (!ok) {
+                av[u] = 0.0f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bvv[u][nb] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bvv[u][nb], acc[nb], 0, 0, 0);
+                if (db) accb[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bvv[u][nb], accb[nb], 0, 0, 0);
+            }
+    }
+    // ---- block: the four waves' partial D tiles (row = 4 (lane >> 4) + r = ci, column = lane & 15 = co) -------------------------
+    __shared__ float red[4][NB][5][64];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][nb][r][lane] = acc[nb][r];
+        red[wv][nb][4][lane] = accb[nb][0];                     // row 0 of the ones-product (lanes 0..15) = column sums
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * 5 * 64; e += 256) {
+        const int nb = e / 320, r = (e / 64) % 5, l = e & 63;
+        const float s = (red[0][nb][r][l] + red[1][nb][r][l]) + (red[2][nb][r][l] + red[3][nb][r][l]);
+        const int co = nb * 16 + (l & 15);
+        if (co >= Cout) continue;
+        if (r < 4) unsafeAtomicAdd(&dw[(long long)(4 * (l >> 4) + r) * Cout + co], s);
+        else if (db && l < 16) unsafeAtomicAdd(&db[co], s);
+    }
+}
+
+// Weight gradient of the single-channel first layer (3x3x3, dilation 1, SAME): D[tap][co] = sum_v x[v + off(tap)] dz[v][co],
+// db[co] = sum_v dz[v][co].  Same idea as conv1x1_wgrad16: no LDS tiles -- A[m = tap][k = voxel] is a gather from the 16 MB
+// single-channel volume (its 9 neighbouring z-rows sit in L1 / L2), B[k][n] = dz rows; a wave walks whole z-rows of its contiguous
+// range of (b, x, y) rows, 4 voxels per k-step, UNR k-steps of loads in flight.  (The im2col tile kernel took 0.41 ms for 278 MB.)
+template <int NB>
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad(const float *__restrict__ x, const float *__restrict__ dz, float *__restrict__ dw,
+                                                       float *__restrict__ db, int B, int X, int Y, int Z, int Cout) {
+    constexpr int UNR = 8;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = lane & 15, k = lane >> 4;
+    f32x4 acc[2][NB], accb[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        acc[0][nb] = acc[1][nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        accb[nb] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    // this lane's two taps (M-tile 0: taps 0..15, M-tile 1: taps 16..26 and 5 dead rows)
+    int tdx[2], tdy[2], tdz[2];
+    bool tlive[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int t = mt * 16 + m;
+        tlive[mt] = t < 27;
+        const int tt = tlive[mt] ? t : 13;
+        tdx[mt] = tt / 9 - 1; tdy[mt] = (tt / 3) % 3 - 1; tdz[mt] = tt % 3 - 1;
+    }
+    long long rbeg, rend;                                       // contiguous range of (b, x, y) rows per block, a quarter per wave
+    const long long nrows = (long long)B * X * Y;
+    nrt_block_range(nrows, 4, rbeg, rend);
+    const long long per = (rend - rbeg + 3) / 4;
+    const long long wbeg = rbeg + wv * per, wend = wbeg + per < rend ? wbeg + per : rend;
+    for (long long row = wbeg; row < wend; ++row) {
+        const unsigned r32 = (unsigned)row, q32 = r32 / (unsigned)Y;       // rows fit 32 bits (launcher)
+        const int y = (int)(r32 - q32 * (unsigned)Y), xx = (int)(q32 % (unsigned)X);
+        const long long bX = (long long)(q32 / (unsigned)X) * X;  // b * X
+        const float *ap[2];
+        bool aok[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int gx = xx + tdx[mt], gy = y + tdy[mt];
+            aok[mt] = tlive[mt] && gx >= 0 && gx < X && gy >= 0 && gy < Y;
+            ap[mt] = x + ((bX + (aok[mt] ? gx : xx)) * Y + (aok[mt] ? gy : y)) * Z + tdz[mt];
+        }
+        const float *bp = dz + row * Z * Cout + m;
+        for (int z0 = 0; z0 < Z; z0 += 4 * UNR) {
+            float av[UNR][2], bvv[UNR][NB];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int z = z0 + 4 * u + k;
+                const bool zin = z < Z;
+                const int zc = zin ? z : 0;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int zz = zc + tdz[mt];
+                    const bool ok = aok[mt] && zin && zz >= 0 && zz < Z;
+                    const float v = ap[mt][ok ? zc : -tdz[mt]];     // (clamped to the row start when masked)
+                    av[u][mt] = ok ? v : 0.0f;
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float v = bp[(long long)zc * Cout + nb * 16];
+                    bvv[u][nb] = zin ? v : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bvv[u][nb], acc[0][nb], 0, 0, 0);
+                    acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bvv[u][nb], acc[1][nb], 0, 0, 0);
+                    if (db) accb[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, bvv[u][nb], accb[nb], 0, 0, 0);
+                }
+        }
+    }
+    __shared__ float red[4][NB][9][64];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[wv][nb][r][lane] = acc[0][nb][r]; red[wv][nb][4 + r][lane] = acc[1][nb][r]; }
+        red[wv][nb][8][lane] = accb[nb][0];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NB * 9 * 64; e += 256) {
+        const int nb = e / 576, r = (e / 64) % 9, l = e & 63;
+        const float s = (red[0][nb][r][l] + red[1][nb][r][l]) + (red[2][nb][r][l] + red[3][nb][r][l]);
+        const int co = nb * 16 + (l & 15);
+        if (r < 8) {
+            const int t = (r >> 2) * 16 + 4 * (l >> 4) + (r & 3);
+            if (t < 27) unsafeAtomicAdd(&dw[(long long)t * Cout + co], s);
+        } else if (db && l < 16) unsafeAtomicAdd(&db[co], s);
+    }
+}
+
 template <int NA, int NB>
 int launch_wgrad(WgArgs &a, hipStream_t st) {
     constexpr int CC = 16 * NA, CO = 16 * NB;
@@ -817,11 +972,39 @@ extern "C" int nrt_conv3d_wgrad2_f32(const float *x, int c0, const float *x_lo, 
     a.ntx = (a.X + WT_X - 1) / WT_X; a.nty = (a.Y + WT_Y - 1) / WT_Y; a.ntz = (a.Z + WT_Z - 1) / WT_Z;
     a.im2col = 0;
     a.dps = cout; a.fold = 0;
+    if (cin == 1 && ksize[0] == 3 && ksize[1] == 3 && ksize[2] == 3 && dilation == 1 && cout % 16 == 0 && cout <= 64 &&
+        (long long)shape[0] * shape[1] * shape[2] < (1ll << 31)) {
+        // the single-channel first layer: gathered straight from the volume (conv3d_c1_wgrad)
+        const long long nrows = (long long)batch * shape[0] * shape[1];
+        const unsigned blocks = nrows / 4 < 512 ? (unsigned)(nrows / 4 > 0 ? nrows / 4 : 1) : 512u;
+        hipStream_t st1 = nrt_stream(stream);
+        switch (cout / 16) {
+            case 1: hipLaunchKernelGGL((conv3d_c1_wgrad<1>), dim3(blocks), dim3(256), 0, st1, x, grad_pre, grad_weights, grad_bias, batch, shape[0], shape[1], shape[2], cout); break;
+            case 2: hipLaunchKernelGGL((conv3d_c1_wgrad<2>), dim3(blocks), dim3(256), 0, st1, x, grad_pre, grad_weights, grad_bias, batch, shape[0], shape[1], shape[2], cout); break;
+            case 3: hipLaunchKernelGGL((conv3d_c1_wgrad<3>), dim3(blocks), dim3(256), 0, st1, x, grad_pre, grad_weights, grad_bias, batch, shape[0], shape[1], shape[2], cout); break;
+            default: hipLaunchKernelGGL((conv3d_c1_wgrad<4>), dim3(blocks), dim3(256), 0, st1, x, grad_pre, grad_weights, grad_bias, batch, shape[0], shape[1], shape[2], cout); break;
+        }
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
     if (cin == 1 && ksize[0] == 3 && ksize[1] == 3 && ksize[2] == 3) {
         a.im2col = 1; a.Cin = 27; a.kx = a.ky = a.kz = 1;
         cin = 27;
     }
     hipStream_t st = nrt_stream(stream);
+    if (ksize[0] == 1 && ksize[1] == 1 && ksize[2] == 1 && c1 == 0 && c0 == 16 && cout % 16 == 0 && cout <= 64 && !a.im2col) {
+        // the likelihood layer: streamed straight from the channels-last rows (conv1x1_wgrad16)
+        const long long nvox = (long long)batch * shape[0] * shape[1] * shape[2];
+        const unsigned blocks = nvox / 128 < 512 ? (unsigned)(nvox / 128 > 0 ? nvox / 128 : 1) : 512u;
+        switch ((cout + 15) / 16) {
+            case 1: hipLaunchKernelGGL((conv1x1_wgrad16<1>), dim3(blocks), dim3(256), 0, st, x, grad_pre, grad_weights, grad_bias, nvox, cout); break;
+            case 2: hipLaunchKernelGGL((conv1x1_wgrad16<2>), dim3(blocks), dim3(256), 0, st, x, grad_pre, grad_weights, grad_bias, nvox, cout); break;
+            case 3: hipLaunchKernelGGL((conv1x1_wgrad16<3>), dim3(blocks), dim3(256), 0, st, x, grad_pre, grad_weights, grad_bias, nvox, cout); break;
+            default: hipLaunchKernelGGL((conv1x1_wgrad16<4>), dim3(blocks), dim3(256), 0, st, x, grad_pre, grad_weights, grad_bias, nvox, cout); break;
+        }
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
     int na = cin <= 16 ? 1 : (cin <= 32 ? 2 : 3);
     const int nb = cout <= 16 ? 1 : 2;
     // dilated kernels have larger halo tiles: shrink the cin chunk until the tiles fit the LDS

@@ -397,6 +397,15 @@ def _conv_dgrad(dpre, wpart, ksize3, dilation):
     dev = dpre.device
     cout, cpart = wpart.shape[-1], wpart.shape[-2]
     wt = wpart.flip(0, 1, 2).transpose(3, 4).contiguous()             # [k, k, k, cout, cpart]; a few KB of glue
+    if tuple(ksize3) == (1, 1, 1) and cpart % 4 == 0 and cpart <= 64:
+        # 1x1x1 (the likelihood layer): a per-voxel matrix product on the streaming kernel, not on the halo-tile convolution
+        dpre = dpre.contiguous()
+        out = torch.empty(list(dpre.shape[:-1]) + [cpart], dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_conv1x1_softmax_f32(_lib.ptr(dpre), _lib.ptr(wt), None, _lib.ptr(out), dpre.numel() // cout, cout, cpart, 0, 0,
+                                             _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv1x1_softmax_f32 (dgrad)')
+        return out
     n = lib.nrt_conv3d_packed_weight_floats(_lib.ints(ksize3), cout, cpart)
     packed = torch.empty(int(n), dtype=torch.float32, device=dev)
     B, S = dpre.shape[0], list(dpre.shape[1:4])
