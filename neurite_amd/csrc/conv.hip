@@ -612,21 +612,15 @@ __global__ __launch_bounds__(256) void conv3d_c1_vec(ConvArgs a, const float *__
 template <int NT>
 __global__ __launch_bounds__(256) void conv3d_c1_mfma(ConvArgs a, const float *__restrict__ w, unsigned nby, unsigned nbz,
                                                       unsigned nblk) {
-    constexpr int HX = 6, HY = 6, HZ = 18;
-    __shared__ float halo[HX * HY * HZ];
-    const unsigned lb = nrt_xcd_block(blockIdx.x, gridDim.x);
-    if (lb >= nblk) return;
+    // persistent blocks (round 3): the weights, bias and tap offsets are loaded once per block instead of once per 4x4x16 tile, and the
+    // halo of tile i + 1 is fetched into registers while tile i is on the matrix cores (one tile per block paid ~150 instructions of
+    // prologue and two exposed memory latencies for 28 MFMAs per wave)
+    constexpr int HX = 6, HY = 6, HZ = 18, NH = HX * HY * HZ, PH = (NH + 255) / 256;
+    __shared__ float halo[NH];
+    __shared__ __attribute__((aligned(16))) float otile[4][16 * 16 * NT];
     const int b = blockIdx.y;
-    const int bz = lb % nbz, by = (lb / nbz) % nby, bx = lb / (nbz * nby);
-    const int x0 = bx * 4, y0 = by * 4, z0 = bz * 16;
     const float *s0 = a.src0 + (long long)b * a.X * a.Y * a.Z;
     float *ob = a.out + (long long)b * a.OX * a.OY * a.OZ * a.Cout;
-    for (int e = threadIdx.x; e < HX * HY * HZ; e += 256) {
-        const int rz = e % HZ, ry = (e / HZ) % HY, rx = e / (HZ * HY);
-        const int gx = x0 + rx - 1, gy = y0 + ry - 1, gz = z0 + rz - 1;
-        halo[e] = (gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z)
-                      ? s0[((long long)gx * a.Y + gy) * a.Z + gz] : 0.0f;
-    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     // B fragments (weights) and the lane's tap offsets, 7 k-steps
@@ -643,31 +637,71 @@ __global__ __launch_bounds__(256) void conv3d_c1_mfma(ConvArgs a, const float *_
     float bias[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias[nt] = a.bias ? a.bias[nt * 16 + l15] : 0.0f;
-    __syncthreads();
-    // wave wv owns x = x0 + wv; its 4 groups are the y rows; a group = 16 consecutive z
+    // the halo elements this thread stages (fixed positions inside the tile)
+    int hrx[PH], hry[PH], hrz[PH];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int base = (wv * HY + g) * HZ + l15;            // halo index of (x, y, z) at tap (0,0,0)
-        f32x4 acc[NT];
+    for (int i = 0; i < PH; ++i) {
+        const int e = threadIdx.x + 256 * i, ee = e < NH ? e : 0;
+        hrz[i] = ee % HZ; hry[i] = (ee / HZ) % HY; hrx[i] = ee / (HZ * HY);
+    }
+    float hv[PH];
+    auto fetch = [&](unsigned lb) __attribute__((always_inline)) {
+        const int bz = lb % nbz, by = (lb / nbz) % nby, bx = lb / (nbz * nby);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int ks = 0; ks < 7; ++ks) {
-            const float af = halo[base + toff[ks]];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[nt][ks], acc[nt], 0, 0, 0);
+        for (int i = 0; i < PH; ++i) {
+            const int gx = bx * 4 + hrx[i] - 1, gy = by * 4 + hry[i] - 1, gz = bz * 16 + hrz[i] - 1;
+            const bool ok = gx >= 0 && gx < a.X && gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z;
+            const float v = s0[ok ? ((long long)gx * a.Y + gy) * a.Z + gz : 0];
+            hv[i] = ok ? v : 0.0f;
         }
-        const int x = x0 + wv, y = y0 + g;
-        if (x < a.OX && y < a.OY) {
+    };
+    // XCD-aware persistent walk: block (xcd, slot) takes tiles slot, slot + J, ... of its XCD's contiguous eighth
+    const unsigned xcd = blockIdx.x % NRT_NXCD, J = gridDim.x / NRT_NXCD;
+    const unsigned T8 = (nblk + NRT_NXCD - 1) / NRT_NXCD;
+    const unsigned tend = (xcd + 1) * T8 < nblk ? (xcd + 1) * T8 : nblk;
+    unsigned lb = xcd * T8 + blockIdx.x / NRT_NXCD;
+    if (lb >= tend) return;
+    fetch(lb);
+    for (; lb < tend; lb += J) {
+        __syncthreads();                                      // the previous tile has been read
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int z = z0 + l4 * 4 + r;
-                if (z < a.OZ) {
-                    float *po = ob + (((long long)x * a.OY + y) * a.OZ + z) * a.Cout + l15;
+        for (int i = 0; i < PH; ++i)
+            if (threadIdx.x + 256 * i < NH) halo[threadIdx.x + 256 * i] = hv[i];
+        __syncthreads();
+        const int bz = lb % nbz, by = (lb / nbz) % nby, bx = lb / (nbz * nby);
+        const int x0 = bx * 4, y0 = by * 4, z0 = bz * 16;
+        if (lb + J < tend) fetch(lb + J);
+        // wave wv owns x = x0 + wv; its 4 groups are the y rows; a group = 16 consecutive z
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) po[nt * 16] = activate(acc[nt][r] + bias[nt], a.act);
+        for (int g = 0; g < 4; ++g) {
+            const int base = (wv * HY + g) * HZ + l15;            // halo index of (x, y, z) at tap (0,0,0)
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < 7; ++ks) {
+                const float af = halo[base + toff[ks]];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[nt][ks], acc[nt], 0, 0, 0);
+            }
+            const int x = x0 + wv, y = y0 + g;
+            // the wave's 16 voxels x Cout outputs are ONE contiguous run of the output tensor: transposed through a wave-private LDS
+            // tile so that every lane stores 16 bytes (1 KB contiguous per store instruction instead of four 64-byte segments)
+            float *ot = otile[wv];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) ot[(l4 * 4 + r) * (16 * NT) + nt * 16 + l15] = activate(acc[nt][r] + bias[nt], a.act);
+            __builtin_amdgcn_wave_barrier();
+            if (x < a.OX && y < a.OY) {
+                f32x4 *po = (f32x4 *)(ob + (((long long)x * a.OY + y) * a.OZ + z0) * a.Cout);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int j = lane + 64 * i;                          // float4 index inside the run: voxel = 4 j / Cout
+                    if (z0 + (4 * j) / (16 * NT) < a.OZ) __builtin_nontemporal_store(*(const f32x4 *)(ot + 4 * j), po + j);
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -1009,11 +1043,12 @@ extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int 
                         (((uintptr_t)out) & 15) == 0);
     if (variant == 3 && !c1_ok) return NRT_ERR_UNSUPPORTED;
     const bool c1_mfma = c0 == 1 && c1 == 0 && padding_same && a.kx == 3 && a.ky == 3 && a.kz == 3 && a.dil == 1 &&
-                         cout % 16 == 0 && cout <= 64;
+                         cout % 16 == 0 && cout <= 64 && (((uintptr_t)out) & 15) == 0;
     if (variant == 1 && c1_mfma) {                         // matrix-core form of the single-channel first layer
         const unsigned nbx = (a.OX + 3) / 4, nby = (a.OY + 3) / 4, nbz = (a.OZ + 15) / 16;
         const unsigned nblk = nbx * nby * nbz;
-        dim3 grid(nrt_xcd_grid(nblk), batch);
+        const unsigned T8c = (nblk + NRT_NXCD - 1) / NRT_NXCD, perx = 8u * (unsigned)nrt_num_cus() / NRT_NXCD;     // 8 persistent blocks per CU
+        dim3 grid(NRT_NXCD * (T8c < perx ? T8c : perx), batch);
         switch (cout / 16) {
             case 1: hipLaunchKernelGGL((conv3d_c1_mfma<1>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk); break;
             case 2: hipLaunchKernelGGL((conv3d_c1_mfma<2>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk); break;
