@@ -257,8 +257,9 @@ int nrt_conv3d_pack_weights_f32(const float *weights /* Keras [kx,ky,kz,cin,cout
  *   src0 [batch, shape, c0]; src1 [batch, shape/up, c1] or NULL with c1 = 0 (plain convolution);
  *   weights Keras layout [kx,ky,kz,c0+c1,cout] (direct kernel), packed_weights from
  *   nrt_conv3d_pack_weights_f32 (MFMA kernel; may be NULL => direct kernel); bias [cout] or NULL.
- * variant 0 = auto (MFMA implicit GEMM when k in {1,3}^3, SAME, dilation <= 2, cout <= 64, cin >= 8),
- * 1 = direct, 2 = MFMA.
+ * variant 0 = auto (MFMA implicit GEMM when k in {1,3}^3, SAME, dilation <= 2, cout <= 64, cin >= 8; its persistent LDS-DMA
+ * schedule for 3x3x3, dilation 1, cin % 16 == 0 when there is more than one tile per CU), 1 = direct, 2 = MFMA (one tile per
+ * block), 5 = MFMA in the persistent schedule.
  */
 int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int c1, const int *up,
                    const float *weights, const float *packed_weights, const float *bias, float *out,

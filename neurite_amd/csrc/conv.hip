@@ -908,6 +908,7 @@ int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t 
 }
 
 #include "conv_up2.h"
+#include "conv_p27.h"
 
 // y[b][q][P * C + c] = x[b][2 q + p][c], P = (px * 2 + py) * 2 + pz: the 8 parity sub-lattices of x as channel groups
 __global__ __launch_bounds__(256) void space_to_depth2(const f32x4 *__restrict__ x, f32x4 *__restrict__ y, int X1, int Y1, int Z1, int C4) {
@@ -1026,6 +1027,20 @@ extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int 
     if (activation < ACT_NONE || activation > ACT_LAST_FUSED) return NRT_ERR_INVALID_ARG;
     hipStream_t st = nrt_stream(stream);
     const bool can_mfma = mfma_ok(a, padding_same) && packed_weights != nullptr;
+    // variant 5: the persistent LDS-DMA schedule (conv_p27.h); auto takes it when there is more than one tile per CU
+    const bool can_p27 = can_mfma && p27_ok(a, padding_same, batch);
+    if (variant == 0 && can_p27 &&
+        (long long)batch * ((a.OX + CT_X - 1) / CT_X) * ((a.OY + CT_Y - 1) / CT_Y) * ((a.OZ + CT_Z - 1) / CT_Z) >= 2ll * nrt_num_cus())
+        variant = 5;
+    if (variant == 5) {
+        if (!can_p27) return NRT_ERR_UNSUPPORTED;
+        switch ((cout + 15) / 16) {
+            case 1: return launch_p27<1>(a, packed_weights, batch, st);
+            case 2: return launch_p27<2>(a, packed_weights, batch, st);
+            case 3: return launch_p27<3>(a, packed_weights, batch, st);
+            default: return launch_p27<4>(a, packed_weights, batch, st);
+        }
+    }
     if (variant == 0) variant = can_mfma ? 2 : 1;
     if (variant == 2) {
         if (!can_mfma) return NRT_ERR_UNSUPPORTED;

@@ -59,13 +59,38 @@ def test_conv3d_mfma_vs_oracle(dev, cin, cout, shape, k, dil, act):
     conv = nm._Conv('c', cin, cout, k, dil, 'same', act).to(dev)
     w, b = set_weights(conv, rng)
     x = rng.standard_normal((2,) + shape + (cin,)).astype(F)
-    for variant in (2, 1):                       # MFMA implicit GEMM, direct
+    variants = [2, 1]                            # MFMA implicit GEMM, direct
+    if k == (3, 3, 3) and dil == 1 and cin % 16 == 0:
+        variants.append(5)                       # MFMA in the persistent LDS-DMA schedule (csrc/conv_p27.h)
+    for variant in variants:
         y = N(conv(G(x, dev), variant=variant))
         for bi in range(2):
             if k == (3, 3, 3) or k == (1, 1, 1) or k == (1, 3, 3):
                 ref = co.conv3d_same(x[bi], w, b, dilation=dil, elu=False).astype(np.float64)
                 ref = uo.elu(ref) if act == 'elu' else (np.maximum(ref, 0) if act == 'relu' else ref)
                 close(y[bi], ref)
+
+
+@pytest.mark.parametrize('cin,cout,shape,act', [
+    (16, 16, (22, 9, 37), 'elu'),             # several tiles per persistent block, ragged on every axis, deferred stores
+    (32, 32, (8, 12, 48), None),              # two chunks per tile, two N-tiles
+    (48, 40, (6, 6, 20), 'relu'),             # three chunks, partial third N-tile (immediate stores)
+    (16, 64, (4, 4, 16), 'elu'),              # one tile
+])
+def test_conv3d_persistent_schedule(dev, cin, cout, shape, act):
+    """nrt_conv3d_f32 variant 5 (persistent blocks, halo by LDS-DMA, deferred stores) against the float64 oracle and the one-tile-per-block
+    MFMA kernel (same accumulation order per output: bit-identical)"""
+    rng = np.random.default_rng(cin + cout)
+    conv = nm._Conv('c', cin, cout, (3, 3, 3), 1, 'same', act).to(dev)
+    w, b = set_weights(conv, rng)
+    x = rng.standard_normal((3,) + shape + (cin,)).astype(F)
+    y5 = N(conv(G(x, dev), variant=5))
+    y2 = N(conv(G(x, dev), variant=2))
+    for bi in range(3):
+        ref = co.conv3d_same(x[bi], w, b, dilation=1, elu=False).astype(np.float64)
+        ref = uo.elu(ref) if act == 'elu' else (np.maximum(ref, 0) if act == 'relu' else ref)
+        close(y5[bi], ref)
+    np.testing.assert_allclose(y5, y2, rtol=1e-6, atol=1e-6 * np.abs(y2).max())
 
 
 def test_conv3d_fused_upsample_concat(dev):
