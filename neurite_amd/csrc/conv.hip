@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
     const int ntap = FAST ? 27 : a.kx * a.ky * a.kz;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
+    // N split (small grids): blockIdx.z takes NT of the ntt 16-channel output blocks, so that 300 tiles of a 40^3 layer become 600 or
+    // 1200 blocks with the same tile shape
+    const int ntt = (a.Cout + 15) >> 4, nt0 = blockIdx.z * NT;
 
     const float *s0 = a.src0 + (long long)b * a.X * a.Y * a.Z * a.c0;
     const float *s1 = a.src1 ? a.src1 + (long long)b * a.X1 * a.Y1 * a.Z1 * a.c1 : nullptr;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
             for (int r = threadIdx.x >> 2; r < nrows; r += 64) *(f32x4 *)&lds[r * LDS_ROW + 4 * q4] = load_row(r, cbase);
         }
         __syncthreads();
-        const f32x4 *wp = (const f32x4 *)wpacked + ((long long)ch * ntap) * NT * 64 + lane;
+        const f32x4 *wp = (const f32x4 *)wpacked + (((long long)ch * ntap) * ntt + nt0) * 64 + lane;
         // vmcnt retires in order: a weight load issued after the halo prefetch can only be waited for together with it.
         // So the weights of the first WPRE taps are requested first, then the next chunk's halo rows, and the first
         // weight load behind them is not needed before WPRE taps (WPRE * 16 NT MFMAs, ~3-4 k cycles) have run
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
                 tt = ((((P & 4) ? 1 : 2) - ((t >> 2) & 1)) * 3 + (((P & 2) ? 1 : 2) - ((t >> 1) & 1))) * 3 + (((P & 1) ? 1 : 2) - (t & 1));
             }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bpre[t][nt] = wp[(tt * NT + nt) * 64];
+            for (int nt = 0; nt < NT; ++nt) bpre[t][nt] = wp[(tt * ntt + nt) * 64];
         }
         if (FAST) {
             if (ch + 1 < nchunk) {
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
                 const int kn = k + 1 < 8 ? k + 1 : k;
                 const int tn = ((ex0 - ((kn >> 2) & 1)) * 3 + (ey0 - ((kn >> 1) & 1))) * 3 + (ez0 - (kn & 1));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bnext[nt] = (kn < WPRE) ? bpre[kn][nt] : wp[(tn * NT + nt) * 64];
+                for (int nt = 0; nt < NT; ++nt) bnext[nt] = (kn < WPRE) ? bpre[kn][nt] : wp[(tn * ntt + nt) * 64];
                 const float *at = abase + ((ex * FHY + ey) * FHZ + ez) * LDS_ROW;
                 f32x4 av[4];
 #pragma unroll
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
                 f32x4 bnext[NT];
                 const int tn = (t + 1 < 27) ? t + 1 : t;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bnext[nt] = (tn < WPRE) ? bpre[tn][nt] : wp[(tn * NT + nt) * 64];
+                for (int nt = 0; nt < NT; ++nt) bnext[nt] = (tn < WPRE) ? bpre[tn][nt] : wp[(tn * ntt + nt) * 64];
                 const int dz = t % 3, dy = (t / 3) % 3, dx = t / 9;
                 f32x4 av[4];
 #pragma unroll
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
             f32x4 bnext[NT];
             const int tn = (t + 1 < ntap) ? t + 1 : t;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bnext[nt] = wp[((long long)tn * NT + nt) * 64];
+            for (int nt = 0; nt < NT; ++nt) bnext[nt] = wp[((long long)tn * ntt + nt) * 64];
             const int dz = t % a.kz, dy = (t / a.kz) % a.ky, dx = t / (a.kz * a.ky);
             const int rx = w + dx * a.dil, rz = li + dz * a.dil;
             f32x4 av[4];
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256) void conv3d_mfma(ConvArgs a, const float *__re
             if (y >= a.OY) continue;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int co = nt * 16 + li;
+                const int co = (nt0 + nt) * 16 + li;
                 if (co >= a.Cout) continue;
                 const float bv = a.bias ? a.bias[co] : 0.0f;
 #pragma unroll
@@ -886,7 +889,7 @@ size_t mfma_lds_bytes(const ConvArgs &a) {
 }
 
 template <int NT>
-int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st) {
+int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st, int nsplit = 1) {
     const unsigned nbx = (a.OX + CT_X - 1) / CT_X, nby = (a.OY + CT_Y - 1) / CT_Y, nbz = (a.OZ + CT_Z - 1) / CT_Z;
     const unsigned nblk = nbx * nby * nbz;
     const size_t shm = mfma_lds_bytes(a);
@@ -897,7 +900,7 @@ int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t 
         if (hipFuncSetAttribute((const void *)conv3d_mfma<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
             return NRT_ERR_LAUNCH;
     }
-    dim3 grid(nrt_xcd_grid(nblk), batch);
+    dim3 grid(nrt_xcd_grid(nblk), batch, nsplit);
     if (a.fold) {
         if (!fast || a.c1 || a.fold % 16 || a.c0 != 8 * a.fold) return NRT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((conv3d_mfma<NT, true, true>), grid, dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
@@ -905,6 +908,25 @@ int launch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t 
     else hipLaunchKernelGGL((conv3d_mfma<NT, false>), grid, dim3(256), shm, st, a, wpacked, nblk, nbx, nby, nbz);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
+}
+
+// all N-tiles in one block, or -- when the grid has fewer than two tiles per CU (40^3 layers: 300 tiles on 256 CUs) -- the 16-channel
+// output blocks split over blockIdx.z so that every CU gets several smaller blocks
+int dispatch_mfma(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st) {
+    const int ntt = (a.Cout + 15) / 16;
+    const long long tiles = (long long)batch * ((a.OX + CT_X - 1) / CT_X) * ((a.OY + CT_Y - 1) / CT_Y) * ((a.OZ + CT_Z - 1) / CT_Z);
+    const long long want = 2ll * nrt_num_cus();
+    int split = 1;
+    if (ntt > 1 && tiles < want) {
+        if (ntt == 4) split = tiles * 2 >= want ? 2 : 4;
+        else split = ntt;                                        // 2 or 3 output blocks: one per block
+    }
+    switch (ntt / split) {
+        case 1: return launch_mfma<1>(a, wpacked, batch, st, split);
+        case 2: return launch_mfma<2>(a, wpacked, batch, st, split);
+        case 3: return launch_mfma<3>(a, wpacked, batch, st, split);
+        default: return launch_mfma<4>(a, wpacked, batch, st, split);
+    }
 }
 
 #include "conv_up2.h"
@@ -1008,12 +1030,7 @@ extern "C" int nrt_conv3d_s2d_taps_f32(const float *x, int group, const float *p
     if (!mfma_ok(a, 1)) return NRT_ERR_UNSUPPORTED;
     a.fold = group;
     hipStream_t st = nrt_stream(stream);
-    switch ((cout + 15) / 16) {
-        case 1: return launch_mfma<1>(a, packed_weights, batch, st);
-        case 2: return launch_mfma<2>(a, packed_weights, batch, st);
-        case 3: return launch_mfma<3>(a, packed_weights, batch, st);
-        default: return launch_mfma<4>(a, packed_weights, batch, st);
-    }
+    return dispatch_mfma(a, packed_weights, batch, st);
 }
 
 extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int c1, const int *up, const float *weights,
@@ -1044,12 +1061,7 @@ extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int 
     if (variant == 0) variant = can_mfma ? 2 : 1;
     if (variant == 2) {
         if (!can_mfma) return NRT_ERR_UNSUPPORTED;
-        switch ((cout + 15) / 16) {
-            case 1: return launch_mfma<1>(a, packed_weights, batch, st);
-            case 2: return launch_mfma<2>(a, packed_weights, batch, st);
-            case 3: return launch_mfma<3>(a, packed_weights, batch, st);
-            default: return launch_mfma<4>(a, packed_weights, batch, st);
-        }
+        return dispatch_mfma(a, packed_weights, batch, st);
     }
     if ((variant != 1 && variant != 3) || !weights) return NRT_ERR_INVALID_ARG;
     const long long nvox = (long long)a.OX * a.OY * a.OZ;
