@@ -40,6 +40,7 @@ def close(got, want, what='', tol=TOL):
 
 @pytest.mark.parametrize('cin,cout,k,dil,act,shape', [
     (16, 16, 3, 1, 'elu', (9, 10, 17)),       # one 16-block each, ragged tiles
+    (16, 16, 3, 1, 'elu', (48, 44, 12)),      # many tiles per persistent block
     (48, 16, 3, 1, 'elu', (8, 8, 16)),        # dec1-like: three cin blocks
     (96, 32, 3, 1, 'elu', (8, 4, 8)),         # dec0-like: two cin chunks of 48, two cout blocks
     (32, 64, 3, 1, 'relu', (4, 8, 8)),        # enc2-like: two cout chunks
