@@ -142,6 +142,13 @@ int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long long nvox, 
 int nrt_dice_soft(const void *y_true, const void *y_pred, int dtype, long long nvox, int nlabels, int batch, int normalize,
                   float laplace_smoothing, float *sums, float *dice, float *minmax, void *workspace, size_t workspace_bytes,
                   void *stream);
+/* Sums of the squared difference of two label maps, per batch entry and label, in ONE pass over the two maps: what
+ * MeanSquaredErrorProb (neurite/tf/metrics.py:653-692: mean of w_l (y_true - y_pred)^2) reduces.  The difference is formed in
+ * registers (exact, no t^2 - 2 t p + p^2 expansion), squared and summed by the nrt_dice_soft_f32 kernels in their order.
+ *   a, b [batch, nvox, nlabels]; sums [batch, 3, nlabels] float32, every one of the three rows = sum_v (a - b)^2;
+ *   scratch [batch, nlabels] float32 (overwritten); workspace as nrt_dice_soft_f32. */
+int nrt_sqdiff_sums_f32(const float *a, const float *b, long long nvox, int nlabels, int batch, float *sums, float *scratch,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 
 /*
@@ -153,7 +160,7 @@ int nrt_dice_hard_prob_f32(const float *y_true, const float *y_pred, long long n
                            float laplace_smoothing, long long *counts, float *dice,
                            void *workspace, size_t workspace_bytes, void *stream);
 /* the same with minmax [4] = min t, max t, min p, max p of the inputs from the same pass (the range asserts of
- * neurite/tf/metrics.py:439-444); nlabels in {4, 8, ..., 256} and 16-byte aligned maps, else NRT_ERR_UNSUPPORTED */
+ * neurite/tf/metrics.py:439-444); nlabels a multiple of 4 up to 256 and 16-byte aligned maps, else NRT_ERR_UNSUPPORTED */
 int nrt_dice_hard_prob_minmax_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
                                   float laplace_smoothing, long long *counts, float *dice, float *minmax,
                                   void *workspace, size_t workspace_bytes, void *stream);

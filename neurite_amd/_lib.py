@@ -39,6 +39,7 @@ _SIGNATURES = {
     'nrt_dice_workspace_bytes': (_sz, [_ll, _i, _i]),
     'nrt_dice_soft_f32': (_i, [_vp, _vp, _ll, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_soft': (_i, [_vp, _vp, _i, _ll, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nrt_sqdiff_sums_f32': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_hard_prob': (_i, [_vp, _vp, _i, _ll, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_hard_prob_f32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_hard_prob_minmax_f32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),

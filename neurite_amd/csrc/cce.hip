@@ -44,16 +44,19 @@ template <> struct Quad<unsigned short> {
 template <int G, typename T, bool LOGITS, bool PERVOX>
 __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ yt, const void *__restrict__ yp,
                                                       const float *__restrict__ w, long long n, float smooth,
-                                                      float *__restrict__ part, float *__restrict__ per_voxel) {
+                                                      float *__restrict__ part, float *__restrict__ per_voxel, int Gr) {
+    // Gr <= G channel quads per voxel are real (channel counts 4 Gr that are no power of two: 12, 20, 24 ...): lanes lg >= Gr of a
+    // lane-group load nothing, enter the soft-max as -inf (the sums as 0) and add nothing to the loss
     constexpr int NG = CCE_BLOCK / G;
-    constexpr int C = 4 * G;
+    const int C = 4 * Gr;
     const int lg = threadIdx.x % G;
     const long long g = threadIdx.x / G;
-    const long long stride = (long long)gridDim.x * NG;
+    const bool real = lg < Gr;
+    const int lgc = real ? lg : 0;
     float wq[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     if (w) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wq[k] = w[4 * lg + k];
+        for (int k = 0; k < 4; ++k) wq[k] = w[4 * lgc + k];
     }
     const float keep = 1.0f - smooth, add = smooth / (float)C;
     float acc = 0.0f;
@@ -62,8 +65,9 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ y
     nrt_block_range(n, NG, vbeg, vend);
 #pragma unroll 2
     for (long long v = vbeg + g; v < vend; v += NG) {
-        const nrt_f4 t = Quad<T>::load(yt, v * G + lg);
-        const nrt_f4 p = Quad<T>::load(yp, v * G + lg);
+        const nrt_f4 t = Quad<T>::load(yt, v * Gr + lgc);
+        nrt_f4 p = Quad<T>::load(yp, v * Gr + lgc);
+        if (!real) { const float pad = LOGITS ? -INFINITY : 0.0f; p = (nrt_f4){pad, pad, pad, pad}; }
         float lq[4];
         if (LOGITS) {
             float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
@@ -93,6 +97,7 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ y
             if (smooth != 0.0f) tt = tt * keep + add;
             l -= tt * lq[k];
         }
+        if (!real) l = 0.0f;
         if (PERVOX) {
             float lv = l;
 #pragma unroll
@@ -199,22 +204,18 @@ __global__ __launch_bounds__(256) void wcce_finalize(const float *__restrict__ p
     }
 }
 
-bool vec_channels(int C) {
-    if (C % 4) return false;
-    const int g = C / 4;
-    return g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64;
-}
+bool vec_channels(int C) { return C % 4 == 0 && C >= 4 && C <= 256; }       // lane-groups of the next power of two >= C / 4 lanes
 
 template <int G, typename T>
 void launch_vec(const void *t, const void *p, const float *w, long long n, int logits, float smooth, unsigned nblk,
-                float *part, float *pv, hipStream_t st) {
+                float *part, float *pv, hipStream_t st, int Gr) {
     dim3 grid(nblk), blk(CCE_BLOCK);
     if (logits) {
-        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, true, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv);
-        else hipLaunchKernelGGL((wcce_vec<G, T, true, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv);
+        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, true, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr);
+        else hipLaunchKernelGGL((wcce_vec<G, T, true, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr);
     } else {
-        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, false, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv);
-        else hipLaunchKernelGGL((wcce_vec<G, T, false, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv);
+        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, false, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr);
+        else hipLaunchKernelGGL((wcce_vec<G, T, false, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr);
     }
 }
 
@@ -222,17 +223,19 @@ template <typename T>
 void launch_any(const void *t, const void *p, const float *w, long long n, int C, int logits, float smooth,
                 bool aligned, unsigned &nblk, float *part, float *pv, hipStream_t st) {
     if (vec_channels(C) && aligned) {
-        const int G = C / 4;
+        const int Gr = C / 4;
+        int G = 1;
+        while (G < Gr) G <<= 1;
         long long nb = (n + (CCE_BLOCK / G) * 4 - 1) / ((CCE_BLOCK / G) * 4);
         nblk = (unsigned)(nb < 1 ? 1 : (nb > CCE_MAX_BLOCKS ? CCE_MAX_BLOCKS : nb));
         switch (G) {
-            case 1: launch_vec<1, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
-            case 2: launch_vec<2, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
-            case 4: launch_vec<4, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
-            case 8: launch_vec<8, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
-            case 16: launch_vec<16, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
-            case 32: launch_vec<32, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
-            default: launch_vec<64, T>(t, p, w, n, logits, smooth, nblk, part, pv, st); break;
+            case 1: launch_vec<1, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
+            case 2: launch_vec<2, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
+            case 4: launch_vec<4, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
+            case 8: launch_vec<8, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
+            case 16: launch_vec<16, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
+            case 32: launch_vec<32, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
+            default: launch_vec<64, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
         }
     } else {
         // rows of VP voxels of both tensors in LDS (48 KB): 256 voxels up to 24 channels, fewer for wider rows, none beyond 768

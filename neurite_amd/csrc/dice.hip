@@ -55,15 +55,22 @@ template <> struct DiceIn<_Float16> {
 template <int G, bool NORMALIZE, typename ST = float>
 __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const void *__restrict__ yt, const void *__restrict__ yp,
                                                             long long nvox, float *__restrict__ fpart,
-                                                            float *__restrict__ mpart) {
+                                                            float *__restrict__ mpart, int Gr, int diff) {
+    // diff: the sums are taken of the difference map d = y_true - y_pred against itself (all three rows = sum d^2 per label: the
+    // label-weighted squared error of metrics.py:653-692 in one pass over the two maps)
+    // Gr <= G label quads per voxel are real (label counts 4 Gr that are no power of two: 12, 20, 24 ...): the lane-group keeps G
+    // lanes, lanes lg >= Gr load nothing and contribute zeros -- rows stay coalesced (Gr x 16 bytes per voxel) and the reductions stay
+    // power-of-two shuffles
     constexpr int NG = DICE_BLOCK / G;           // voxels per block pass
     constexpr int L = 4 * G;
+    const int Lr = 4 * Gr;
     const int b = blockIdx.y;
-    const char *t4 = (const char *)yt + (long long)b * nvox * L * DiceIn<ST>::BYTES;
-    const char *p4 = (const char *)yp + (long long)b * nvox * L * DiceIn<ST>::BYTES;
+    const char *t4 = (const char *)yt + (long long)b * nvox * Lr * DiceIn<ST>::BYTES;
+    const char *p4 = (const char *)yp + (long long)b * nvox * Lr * DiceIn<ST>::BYTES;
     const int lg = threadIdx.x % G;
     const long long g = threadIdx.x / G;
-    const long long stride = (long long)gridDim.x * NG;
+    const bool real = lg < Gr;
+    const int lgc = real ? lg : 0;
 
     nrt_f4 stp = {0, 0, 0, 0}, stt = {0, 0, 0, 0}, spp = {0, 0, 0, 0};
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
@@ -74,8 +81,10 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const void *__restri
     const long long vstep = NG;
 #pragma unroll 4
     for (long long v = vbeg; v < vend; v += vstep) {
-        nrt_f4 t = DiceIn<ST>::load4(t4, v * G + lg);
-        nrt_f4 p = DiceIn<ST>::load4(p4, v * G + lg);
+        nrt_f4 t = DiceIn<ST>::load4(t4, v * Gr + lgc);
+        nrt_f4 p = DiceIn<ST>::load4(p4, v * Gr + lgc);
+        if (!real) { t = (nrt_f4){0.0f, 0.0f, 0.0f, 0.0f}; p = t; }
+        if (diff) { t = t - p; p = t; }
         if (NORMALIZE) {
             // y / sum_l y with divide_no_nan (metrics.py:435-436); the label sum spans the lane-group
             float st = (t[0] + t[1]) + (t[2] + t[3]);
@@ -96,8 +105,10 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const void *__restri
             stp[k] += t[k] * p[k];
             stt[k] += t[k] * t[k];
             spp[k] += p[k] * p[k];
-            mnt = fminf(mnt, t[k]); mxt = fmaxf(mxt, t[k]);
-            mnp = fminf(mnp, p[k]); mxp = fmaxf(mxp, p[k]);
+            if (real) {
+                mnt = fminf(mnt, t[k]); mxt = fmaxf(mxt, t[k]);
+                mnp = fminf(mnp, p[k]); mxp = fmaxf(mxp, p[k]);
+            }
         }
     }
 
@@ -126,11 +137,12 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const void *__restri
     if (lane == 0) { red[wv][3 * L + 0] = mnt; red[wv][3 * L + 1] = mxt; red[wv][3 * L + 2] = mnp; red[wv][3 * L + 3] = mxp; }
     __syncthreads();
     const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
-    for (int i = threadIdx.x; i < 3 * L; i += DICE_BLOCK) {
-        float s = red[0][i];
+    for (int i = threadIdx.x; i < 3 * Lr; i += DICE_BLOCK) {
+        const int ii = (i / Lr) * L + i % Lr;                  // [3][L] in LDS -> [3][Lr] in the partial row
+        float s = red[0][ii];
 #pragma unroll
-        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2) s += red[w2][i];
-        fpart[pbase * 3 * L + i] = s;
+        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2) s += red[w2][ii];
+        fpart[pbase * 3 * Lr + i] = s;
     }
     if (threadIdx.x < 4) {
         float m = red[0][3 * L + threadIdx.x];
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_vec(const void *__restri
 template <bool NORMALIZE, typename ST = float>
 __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const void *__restrict__ yt, const void *__restrict__ yp,
                                                                 long long nvox, int L, float *__restrict__ fpart,
-                                                                float *__restrict__ mpart) {
+                                                                float *__restrict__ mpart, int diff) {
     __shared__ float sh[3 * DICE_BLOCK];
     __shared__ float mm[DICE_BLOCK / NRT_WAVE][4];
     const int b = blockIdx.y;
@@ -161,6 +173,7 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const void *__re
     if (active) {
         for (long long v = (long long)blockIdx.x * R + r; v < nvox; v += (long long)gridDim.x * R) {
             float tv = DiceIn<ST>::load1(t, v * L + l), pv = DiceIn<ST>::load1(p, v * L + l);
+            if (diff) { tv = tv - pv; pv = tv; }
             if (NORMALIZE) {
                 float st = 0.0f, sp = 0.0f;
                 for (int k = 0; k < L; ++k) { st += DiceIn<ST>::load1(t, v * L + k); sp += DiceIn<ST>::load1(p, v * L + k); }
@@ -206,15 +219,17 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_soft_generic(const void *__re
 template <int G, bool MINMAX, typename ST = float>
 __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const void *__restrict__ yt, const void *__restrict__ yp,
                                                             long long nvox, unsigned *__restrict__ ipart,
-                                                            float *__restrict__ mpart) {
+                                                            float *__restrict__ mpart, int Gr) {
     constexpr int NG = DICE_BLOCK / G;
     constexpr int L = 4 * G;
+    const int Lr = 4 * Gr;                         // Gr <= G real label quads per voxel (see dice_soft_vec); padding lanes never win the arg-max
     const int b = blockIdx.y;
-    const char *t4 = (const char *)yt + (long long)b * nvox * L * DiceIn<ST>::BYTES;
-    const char *p4 = (const char *)yp + (long long)b * nvox * L * DiceIn<ST>::BYTES;
+    const char *t4 = (const char *)yt + (long long)b * nvox * Lr * DiceIn<ST>::BYTES;
+    const char *p4 = (const char *)yp + (long long)b * nvox * Lr * DiceIn<ST>::BYTES;
     const int lg = threadIdx.x % G;
     const long long g = threadIdx.x / G;
-    const long long stride = (long long)gridDim.x * NG;
+    const bool real = lg < Gr;
+    const int lgc = real ? lg : 0;
     unsigned ntp[4] = {0, 0, 0, 0}, nt[4] = {0, 0, 0, 0}, np_[4] = {0, 0, 0, 0};
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
 
@@ -222,9 +237,10 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const void *__restri
     nrt_block_range(nvox, NG, vbeg, vend);
 #pragma unroll 2
     for (long long v = vbeg + g; v < vend; v += NG) {
-        const nrt_f4 t = DiceIn<ST>::load4(t4, v * G + lg);
-        const nrt_f4 p = DiceIn<ST>::load4(p4, v * G + lg);
-        if (MINMAX) {
+        nrt_f4 t = DiceIn<ST>::load4(t4, v * Gr + lgc);
+        nrt_f4 p = DiceIn<ST>::load4(p4, v * Gr + lgc);
+        if (!real) { t = (nrt_f4){-INFINITY, -INFINITY, -INFINITY, -INFINITY}; p = t; }
+        if (MINMAX && real) {
             mnt = fminf(mnt, fminf(fminf(t[0], t[1]), fminf(t[2], t[3]))); mxt = fmaxf(mxt, fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])));
             mnp = fminf(mnp, fminf(fminf(p[0], p[1]), fminf(p[2], p[3]))); mxp = fmaxf(mxp, fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));
         }
@@ -277,10 +293,11 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_vec(const void *__restri
     }
     __syncthreads();
     const long long pbase = ((long long)b * gridDim.x + blockIdx.x);
-    for (int i = threadIdx.x; i < 3 * L; i += DICE_BLOCK) {
-        unsigned s = red[0][i];
-        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2) s += red[w2][i];
-        ipart[pbase * 3 * L + i] = s;
+    for (int i = threadIdx.x; i < 3 * Lr; i += DICE_BLOCK) {
+        const int ii = (i / Lr) * L + i % Lr;
+        unsigned s = red[0][ii];
+        for (int w2 = 1; w2 < DICE_BLOCK / NRT_WAVE; ++w2) s += red[w2][ii];
+        ipart[pbase * 3 * Lr + i] = s;
     }
     if (MINMAX && threadIdx.x < 4) {
         float m = redm[0][threadIdx.x];
@@ -538,32 +555,30 @@ __global__ void dice_from_sums(const float *__restrict__ sums, int L, float eps,
     }
 }
 
-bool vec_labels(int L) {
-    if (L % 4) return false;
-    const int g = L / 4;
-    return g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 32 || g == 64;
-}
+bool vec_labels(int L) { return L % 4 == 0 && L >= 4 && L <= 256; }      // lane-groups of the next power of two >= L / 4 lanes
+int vec_group(int L) { int g = 1; while (g < L / 4) g <<= 1; return g; }
 
 template <int G, typename ST>
 void launch_soft_vec(const void *t, const void *p, long long nvox, int batch, int normalize, unsigned nblk,
-                     const DiceWs &w, hipStream_t st) {
+                     const DiceWs &w, hipStream_t st, int Gr) {
     dim3 grid(nblk, batch);
-    if (normalize) hipLaunchKernelGGL((dice_soft_vec<G, true, ST>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart);
-    else hipLaunchKernelGGL((dice_soft_vec<G, false, ST>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart);
+    if (normalize == 1) hipLaunchKernelGGL((dice_soft_vec<G, true, ST>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart, Gr, 0);
+    else hipLaunchKernelGGL((dice_soft_vec<G, false, ST>), grid, dim3(DICE_BLOCK), 0, st, t, p, nvox, w.fpart, w.mpart, Gr, normalize == 2);
 }
 
 template <int G, typename ST>
 void launch_hard_vec(const void *t, const void *p, long long nvox, int batch, unsigned nblk, const DiceWs &w,
-                     bool minmax, hipStream_t st) {
-    if (minmax) hipLaunchKernelGGL((dice_hard_vec<G, true, ST>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart);
-    else hipLaunchKernelGGL((dice_hard_vec<G, false, ST>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart);
+                     bool minmax, hipStream_t st, int Gr) {
+    if (minmax) hipLaunchKernelGGL((dice_hard_vec<G, true, ST>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart, Gr);
+    else hipLaunchKernelGGL((dice_hard_vec<G, false, ST>), dim3(nblk, batch), dim3(DICE_BLOCK), 0, st, t, p, nvox, w.ipart, w.mpart, Gr);
 }
 
+// normalize: 0 plain, 1 y / sum_l y first, 2 the difference map against itself (nrt_sqdiff_sums_f32)
 template <typename ST>
 int dice_soft_impl(const void *y_true, const void *y_pred, long long nvox, int nlabels, int batch, int normalize, float laplace_smoothing,
                    float *sums, float *dice, float *minmax, void *workspace, size_t workspace_bytes, void *stream) {
     if (!y_true || !y_pred || !sums || !dice) return NRT_ERR_INVALID_ARG;
-    if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (nvox < 0 || nlabels < 1 || batch < 1 || batch > 65535 || normalize < 0 || normalize > 2) return NRT_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < dice_ws_bytes(nlabels, batch)) return NRT_ERR_WORKSPACE;
     if (nlabels > 4096) return NRT_ERR_UNSUPPORTED;
     hipStream_t st = nrt_stream(stream);
@@ -571,16 +586,16 @@ int dice_soft_impl(const void *y_true, const void *y_pred, long long nvox, int n
     unsigned nblk, gz = 1;
     const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & (4 * DiceIn<ST>::BYTES - 1)) == 0;      // 4 labels per lane access
     if (vec_labels(nlabels) && aligned) {
-        const int G = nlabels / 4;
+        const int G = vec_group(nlabels), Gr = nlabels / 4;
         nblk = dice_num_blocks(nvox, (DICE_BLOCK / G) * 4);
         switch (G) {
-            case 1: launch_soft_vec<1, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 2: launch_soft_vec<2, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 4: launch_soft_vec<4, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 8: launch_soft_vec<8, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 16: launch_soft_vec<16, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            case 32: launch_soft_vec<32, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
-            default: launch_soft_vec<64, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st); break;
+            case 1: launch_soft_vec<1, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st, Gr); break;
+            case 2: launch_soft_vec<2, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st, Gr); break;
+            case 4: launch_soft_vec<4, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st, Gr); break;
+            case 8: launch_soft_vec<8, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st, Gr); break;
+            case 16: launch_soft_vec<16, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st, Gr); break;
+            case 32: launch_soft_vec<32, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st, Gr); break;
+            default: launch_soft_vec<64, ST>(y_true, y_pred, nvox, batch, normalize, nblk, w, st, Gr); break;
         }
     } else {
         const int Lc = nlabels < DICE_BLOCK ? nlabels : DICE_BLOCK;
@@ -588,8 +603,8 @@ int dice_soft_impl(const void *y_true, const void *y_pred, long long nvox, int n
         nblk = dice_num_blocks(nvox, DICE_BLOCK / Lc);
         if (nblk > DICE_MAX_BLOCKS / gz) nblk = DICE_MAX_BLOCKS / gz;
         dim3 grid(nblk, batch, gz);
-        if (normalize) hipLaunchKernelGGL((dice_soft_generic<true, ST>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
-        else hipLaunchKernelGGL((dice_soft_generic<false, ST>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart);
+        if (normalize == 1) hipLaunchKernelGGL((dice_soft_generic<true, ST>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart, 0);
+        else hipLaunchKernelGGL((dice_soft_generic<false, ST>), grid, dim3(DICE_BLOCK), 0, st, y_true, y_pred, nvox, nlabels, w.fpart, w.mpart, normalize == 2);
     }
     NRT_CHECK_LAUNCH();
     return dice_finalize_soft(w, nblk, gz, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
@@ -605,16 +620,16 @@ int dice_hard_prob_impl(const void *y_true, const void *y_pred, long long nvox, 
     DiceWs w = dice_ws_carve(workspace, nlabels, batch);
     const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & (4 * DiceIn<ST>::BYTES - 1)) == 0;
     if (vec_labels(nlabels) && aligned) {
-        const int G = nlabels / 4;
+        const int G = vec_group(nlabels), Gr = nlabels / 4;
         const unsigned nblk = dice_num_blocks(nvox, (DICE_BLOCK / G) * 4);
         switch (G) {
-            case 1: launch_hard_vec<1, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 2: launch_hard_vec<2, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 4: launch_hard_vec<4, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 8: launch_hard_vec<8, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 16: launch_hard_vec<16, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            case 32: launch_hard_vec<32, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
-            default: launch_hard_vec<64, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st); break;
+            case 1: launch_hard_vec<1, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st, Gr); break;
+            case 2: launch_hard_vec<2, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st, Gr); break;
+            case 4: launch_hard_vec<4, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st, Gr); break;
+            case 8: launch_hard_vec<8, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st, Gr); break;
+            case 16: launch_hard_vec<16, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st, Gr); break;
+            case 32: launch_hard_vec<32, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st, Gr); break;
+            default: launch_hard_vec<64, ST>(y_true, y_pred, nvox, batch, nblk, w, minmax != nullptr, st, Gr); break;
         }
         NRT_CHECK_LAUNCH();
         const int ngrp = ((int)nblk + RED_ROWS - 1) / RED_ROWS;
@@ -664,13 +679,19 @@ extern "C" size_t nrt_dice_workspace_bytes(long long nvox, int nlabels, int batc
 extern "C" int nrt_dice_soft_f32(const float *y_true, const float *y_pred, long long nvox, int nlabels, int batch,
                                  int normalize, float laplace_smoothing, float *sums, float *dice, float *minmax,
                                  void *workspace, size_t workspace_bytes, void *stream) {
-    return dice_soft_impl<float>(y_true, y_pred, nvox, nlabels, batch, normalize, laplace_smoothing, sums, dice, minmax, workspace,
+    return dice_soft_impl<float>(y_true, y_pred, nvox, nlabels, batch, normalize != 0, laplace_smoothing, sums, dice, minmax, workspace,
                                  workspace_bytes, stream);
+}
+
+extern "C" int nrt_sqdiff_sums_f32(const float *a, const float *b, long long nvox, int nlabels, int batch, float *sums, float *scratch,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    return dice_soft_impl<float>(a, b, nvox, nlabels, batch, 2, 0.0f, sums, scratch, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int nrt_dice_soft(const void *y_true, const void *y_pred, int dtype, long long nvox, int nlabels, int batch, int normalize,
                              float laplace_smoothing, float *sums, float *dice, float *minmax, void *workspace, size_t workspace_bytes,
                              void *stream) {
+    normalize = normalize != 0;
     switch (dtype) {
         case NRT_DT_F32: return dice_soft_impl<float>(y_true, y_pred, nvox, nlabels, batch, normalize, laplace_smoothing, sums, dice, minmax,
                                                       workspace, workspace_bytes, stream);

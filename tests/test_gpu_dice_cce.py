@@ -124,7 +124,7 @@ def test_dice_on_16bit_probability_maps(dev):
         ne.metrics.Dice().dice(t.double(), t.double())
 
 
-@pytest.mark.parametrize('L', [1, 3, 4, 5, 8, 16, 32, 64, 128, 256, 300])
+@pytest.mark.parametrize('L', [1, 3, 4, 5, 8, 12, 16, 20, 24, 32, 36, 64, 100, 128, 132, 252, 256, 260, 300])
 def test_soft_dice_label_counts(dev, L):
     rng = np.random.default_rng(L)
     B, V = 2, 3001
@@ -192,11 +192,16 @@ def test_hard_dice_single_pass_paths(dev):
     bad[0, 3, 3, 3, 5] = 1.5
     with pytest.raises(ne.metrics.InvalidArgumentError):
         ne.metrics.HardDice(8, input_type='prob').dice(G(bad, dev), G(np.abs(bad) / 2, dev))
-    # 20 labels: not a vector-kernel count, the extrema come from the soft pass as before
-    t = rng.random((2, 9, 9, 9, 20)).astype(F)
-    p = rng.random((2, 9, 9, 9, 20)).astype(F)
-    assert bits_equal(N(ne.metrics.HardDice(20, input_type='prob').dice(G(t, dev), G(p, dev))),
-                      npo.dice(t, p, dice_type='hard', input_type='prob', nb_labels=20))
+    # 20 / 24 labels: lane-groups of 8 with 5 / 6 real lanes (the extrema come from the counting pass too); 22: the generic kernel
+    for L in (20, 24, 22):
+        t = rng.random((2, 9, 9, 9, L)).astype(F)
+        p = rng.random((2, 9, 9, 9, L)).astype(F)
+        assert bits_equal(N(ne.metrics.HardDice(L, input_type='prob').dice(G(t, dev), G(p, dev))),
+                          npo.dice(t, p, dice_type='hard', input_type='prob', nb_labels=L))
+        bad = p.copy()
+        bad[1, 8, 8, 8, L - 1] = 1.25
+        with pytest.raises(ne.metrics.InvalidArgumentError):
+            ne.metrics.HardDice(L, input_type='prob').dice(G(t, dev), G(bad, dev))
     # ---- label maps ----
     blobs = synth.one_hot_volume(5, 48, 8, dev).argmax(-1).to(torch.int32)
     other = synth.one_hot_volume(6, 48, 8, dev).argmax(-1).to(torch.int32)
@@ -327,7 +332,7 @@ def test_cce_golden(dev):
     np.testing.assert_allclose(N(C(label_weights=w, reduction='sum')(t, p)), pv.sum(), rtol=RTOL)
 
 
-@pytest.mark.parametrize('C', [2, 4, 6, 16, 32, 64, 100])
+@pytest.mark.parametrize('C', [2, 4, 6, 12, 16, 20, 32, 64, 100, 252, 260])
 def test_cce_channel_counts_and_bf16(dev, C):
     rng = np.random.default_rng(C)
     N_ = (2, 13, 11, 7)

@@ -32,11 +32,14 @@ row('hard Dice from int32 label maps, 8 labels', timeit(lambda: ne.metrics.HardD
 m20, f20 = mov[..., :20].contiguous(), fix[..., :20].contiguous()
 with __import__('warnings').catch_warnings():
     __import__('warnings').simplefilter('ignore')
-    row('hard Dice from probabilities, 20 labels (generic kernel)', timeit(lambda: ne.metrics.HardDice(20, input_type='prob').dice(f20, m20), n=3), nvox * 160)
-row('soft Dice, 20 labels (generic kernel)', timeit(lambda: ne.metrics.Dice().dice(f20, m20)), nvox * 160)
+    row('hard Dice from probabilities, 20 labels (lane-groups of 8, 5 real)', timeit(lambda: ne.metrics.HardDice(20, input_type='prob').dice(f20, m20), n=3), nvox * 160)
+row('soft Dice, 20 labels (lane-groups of 8, 5 real)', timeit(lambda: ne.metrics.Dice().dice(f20, m20)), nvox * 160)
 w = torch.rand(L, device=dev) + 0.5
 p = torch.softmax(torch.randn(B, S, S, S, L, device=dev), -1)
 row('weighted CCE [4,160^3,32]', timeit(lambda: ne.metrics.CategoricalCrossentropy(label_weights=w)(fix, p)), nvox * 256)
+p20 = p[..., :20].contiguous()
+row('weighted CCE, 20 labels (lane-groups of 8, 5 real)', timeit(lambda: ne.metrics.CategoricalCrossentropy(label_weights=w[:20])(f20, p20)), nvox * 160)
+del p20
 logits = torch.randn(B, S, S, S, L, device=dev)
 row('weighted CCE from logits (softmax in registers, one pass) [4,160^3,32]',
     timeit(lambda: ne.metrics.CategoricalCrossentropy(label_weights=w, from_logits=True)(fix, logits)), nvox * 256)
