@@ -18,6 +18,7 @@ GROUPS_=(
 )
 for g in "${GROUPS_[@]}"; do
   gname="${g%%:*}"; ctrs="${g#*:}"
+  if [ -n "${PMC_ONLY:-}" ] && [[ " $PMC_ONLY " != *" $gname "* ]]; then continue; fi      # PMC_ONLY="l1 l2": just these groups
   ( cd "$ROOT" && timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$OUT/$gname" -o p -- "$@" > /dev/null 2> "$OUT/$gname.log" )
   echo "$gname rc=$?"
 done
