@@ -12,7 +12,8 @@ SpatialTransformer defers the warp and Dice launches the fused kernel on (moving
 warped volume is consumed in registers, never written -- SURVEY.md 8d anticipates this form).  --direct times the same kernel
 through neurite_amd.fused.warp_dice, --unfused the eager two-kernel pipeline (deferral off: `warped` written and read back).
 The JSON line always carries all three (`fused_pipeline` = the timed one, `fused_direct_pipeline`, `dropin_pipeline`) plus
-`roofline_dropin` (the stand-alone interpn kernel), `config2_batch1` and `bf16_storage`, measured in the same process.
+`roofline_dropin` (the stand-alone interpn kernel), `config2_batch1`, `bf16_storage` and `default_args_pipeline` (the reference's
+default range asserts on), measured in the same process.
 Workload: BASELINE config 2 (SpatialTransformer + Dice, 160^3 x 32 one-hot, fp32); every GPU holds
 `--batch-per-gpu` volumes (default 4 = config 4's sharding of B=32 over 8 GPUs), so scaling is weak
 and N=8 is exactly config 4.  1 voxel = 1 spatial output location.
@@ -745,6 +746,28 @@ def main():
         except Exception as e:   # noqa
             log('bf16-storage run failed: %s' % e)
             r_bf16 = None
+    # the reference's default arguments (check_input_limits=True, metrics.py:439-444).  On one-hot maps the reference's own assert
+    # fires (a tri-linear blend of ones exceeds 1.0 by an ulp: tests/test_gpu_dice_cce.py), so the default path is timed on the
+    # same maps scaled by 1/2: same kernels, same bytes, plus the read-back of the four extrema the assert looks at
+    r_def = None
+    if dist is None and not args.no_batch1:
+        try:
+            movh, fixh = mov * 0.5, fix * 0.5
+            dice_def = ne.metrics.Dice()
+
+            def step_default(events=None):
+                if events is not None:
+                    events[0].record()
+                d = dice_def.dice(fixh, st([movh, trf]))
+                if events is not None:
+                    events[1].record()
+                    events[2].record()
+                return nd.all_reduce_mean_dice(d, async_op=True)
+            r_def = timed(step_default, o_steps, 2, None, dev)
+            del movh, fixh
+        except Exception as e:   # noqa
+            log('default-argument run failed: %s' % e)
+            r_def = None
     unet_multi = None
     if dist is not None and not args.no_unet:
         # "3D UNet fwd ms at 1/2/4/8 GPU": every rank runs the config-3 forward on its own volume (data parallel inference);
@@ -884,6 +907,13 @@ def main():
             'dropin': {'ms': round(ru['elapsed'] / o_steps * 1e3, 4), 'Mvoxels_per_s': round(V * o_steps / ru['elapsed'] / 1e6, 1),
                        'interpn_ms': round(ru['k0_ms'], 4), 'dice_ms': round(ru['k1_ms'], 4),
                        'interpn_frac': round(INTERPN_BYTES_PER_VOXEL(L, 3) * V / (ru['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    if r_def is not None:
+        out['default_args_pipeline'] = {
+            'what': 'SpatialTransformer -> metrics.Dice() with the reference defaults (check_input_limits=True: the range asserts read '
+                    'the extrema the fused kernel returns, one host read-back per step) on the bench maps scaled by 1/2 (on one-hot '
+                    'maps the reference assert itself fires, see tests); %d steps' % o_steps,
+            'value': round(B * V * o_steps / r_def['elapsed'] / 1e6, 2), 'unit': 'Mvoxels/s',
+            'ms_per_step': round(r_def['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(r_def['k0_ms'], 4)}
     if r_bf16 is not None:
         b16 = (2 * L + 12 + 2 * L) * V * B
         out['bf16_storage'] = {
