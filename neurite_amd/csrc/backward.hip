@@ -667,6 +667,172 @@ __global__ __launch_bounds__(256) void warp_dice_bwd_rows(InterpBwdArgs ba, cons
     }
 }
 
+// The same backward for 32 labels on the x-march schedule, software-pipelined like the fused forward (fused.hip): the rows of
+// x-plane p + 1 are requested before the gradient of plane p is formed, the location of plane p + 2 before those rows, the
+// voxel's position comes from the block's patch (no division), so the queue of the memory pipeline never drains.  The
+// gradient is the same sum as warp_dice_bwd_rows', associated differently: the eight inner products first, then per axis four
+// weighted differences of corner pairs (the un-pipelined kernel spends 350 VALU instructions per voxel step, twice the forward).
+// DICE = false: the plain d out / d loc of the warp (interpn_bwd_rows' grad_loc at 32 channels): `fixed` is then grad_out, whose row
+// takes the place of d dice / d warped, and the warped row is not needed.
+template <int MODE, bool DICE = true>
+__global__ __launch_bounds__(256, 3) void warp_dice_bwd_xm(InterpBwdArgs ba, const float *__restrict__ fixed,
+                                                           const float *__restrict__ sums,
+                                                           const float *__restrict__ gdice, float eps) {
+    constexpr int G = 8, L = 32;
+    const InterpArgs &a = ba.f;
+    int b, x0, y0, z0, xlen;
+    unsigned prow;
+    if (!xmarch_block(ba.tg, a.O[0], b, prow, x0, y0, z0, xlen)) return;
+    const char *volb = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const char *locb = (const char *)(a.loc + (long long)b * a.loc_bs);
+    const char *fix = (const char *)(fixed + (long long)b * a.out_bs);
+    float *gl = ba.gloc + (long long)b * a.nout * 3;
+    const int lg = threadIdx.x % G;
+    const unsigned g = threadIdx.x / G;
+    const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
+    float ca[4] = {0.0f, 0.0f, 0.0f, 0.0f}, cb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (DICE) {
+        const float *sm = sums + (long long)b * 3 * L;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int l = lg * 4 + k;
+            const float num = 2.0f * sm[l] + eps, den = sm[L + l] + sm[2 * L + l] + eps;
+            const float gd = gdice[(long long)b * L + l];
+            ca[k] = 0.0f; cb[k] = 0.0f;
+            if (den != 0.0f) { ca[k] = 2.0f * gd / den; cb[k] = -2.0f * gd * num / (den * den); }
+        }
+    }
+    const int y = y0 + (int)(g >> ba.tg.ltz), z = z0 + (int)(g & ((1u << ba.tg.ltz) - 1u));
+    const bool inyz = y < a.O[1] && z < a.O[2];
+    const int yc = min(y, a.O[1] - 1), zc = min(z, a.O[2] - 1);
+    const unsigned plane = (unsigned)(a.O[1] * a.O[2]), qyz = (unsigned)(yc * a.O[2] + zc);
+    const int last = xlen - 1;
+
+    auto fetch_loc = [&](int pass, float (&pr)[3]) {
+        const unsigned q = (unsigned)(x0 + min(pass, last)) * plane + qyz;
+        const float *lp = (const float *)(locb + (size_t)(q * 12u));
+        pr[0] = lp[0]; pr[1] = lp[1]; pr[2] = lp[2];
+    };
+    auto prepare = [&](int pass, const float (&pr)[3], float &W0x, float &W0y, float &W0z, float &Mx, float &My, float &Mz,
+                       unsigned &Q, bool &LIVE, bool &DEAD, unsigned (&off)[8]) {
+        const int x = x0 + min(pass, last);
+        Q = (unsigned)x * plane + qyz;
+        LIVE = inyz && pass < xlen;
+        float p[3];
+        const int qd[3] = {x, yc, zc};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) p[d] = (MODE == NRT_LOC_ABSOLUTE) ? pr[d] : nrt_add((float)qd[d], pr[d]);
+        bool oob = false;
+        if (a.has_fill) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) oob = oob || (p[d] < 0.0f) || (p[d] > (float)(a.S[d] - 1));
+        }
+        DEAD = oob || !LIVE;
+        int i0x, i1x, i0y, i1y, i0z, i1z;
+        float w1;
+        corner_1d(p[0], a.S[0], i0x, i1x, W0x, w1);
+        corner_1d(p[1], a.S[1], i0y, i1y, W0y, w1);
+        corner_1d(p[2], a.S[2], i0z, i1z, W0z, w1);
+        Mx = (p[0] >= 0.0f && p[0] <= (float)(a.S[0] - 1)) ? 1.0f : 0.0f;
+        My = (p[1] >= 0.0f && p[1] <= (float)(a.S[1] - 1)) ? 1.0f : 0.0f;
+        Mz = (p[2] >= 0.0f && p[2] <= (float)(a.S[2] - 1)) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const unsigned ix = (corner & 4) ? i1x : i0x, iy = (corner & 2) ? i1y : i0y, iz = (corner & 1) ? i1z : i0z;
+            off[corner] = (((ix * SY + iy) * SZ + iz) * (unsigned)G + (unsigned)lg) * 16u;
+        }
+    };
+    auto load_rows = [&](const unsigned (&off)[8], unsigned q, nrt_f4 (&R)[8], nrt_f4 &T) {
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) R[corner] = *(const nrt_f4 *)(volb + (size_t)off[corner]);
+        T = __builtin_nontemporal_load((const nrt_f4 *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * 16u)));
+    };
+    auto finish = [&](float W0x, float W0y, float W0z, float Mx, float My, float Mz, unsigned Q, bool LIVE, bool DEAD,
+                      const nrt_f4 (&v)[8], const nrt_f4 &t) {
+        const float W1x = nrt_sub(1.0f, W0x), W1y = nrt_sub(1.0f, W0y), W1z = nrt_sub(1.0f, W0z);       // corner_1d's w1
+        // the warped row, blended as the forward blends it ((wx wy) wz per corner, corners in order), two channels per packed op
+        const nrt_f2 wy2 = {W0y, W1y}, wz2 = {W0z, W1z};
+        const nrt_f2 wxy0 = (nrt_f2){W0x, W0x} * wy2, wxy1 = (nrt_f2){W1x, W1x} * wy2;     // wx wy: [x0y0, x0y1], [x1y0, x1y1]
+        nrt_f2 wt2[4];
+        wt2[0] = (nrt_f2){wxy0[0], wxy0[0]} * wz2;
+        wt2[1] = (nrt_f2){wxy0[1], wxy0[1]} * wz2;
+        wt2[2] = (nrt_f2){wxy1[0], wxy1[0]} * wz2;
+        wt2[3] = (nrt_f2){wxy1[1], wxy1[1]} * wz2;
+        nrt_f2 gl2 = {t[0], t[1]}, gh2 = {t[2], t[3]};                 // DICE = false: the incoming gradient row itself
+        if (DICE) {
+            nrt_f2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const float wt = wt2[corner >> 1][corner & 1];
+                const nrt_f2 w2 = {wt, wt};
+                al = al + w2 * (nrt_f2){v[corner][0], v[corner][1]};
+                ah = ah + w2 * (nrt_f2){v[corner][2], v[corner][3]};
+            }
+            // d dice / d warped for this lane's four labels
+            gl2 = (nrt_f2){ca[0], ca[1]} * gl2 + (nrt_f2){cb[0], cb[1]} * al;
+            gh2 = (nrt_f2){ca[2], ca[3]} * gh2 + (nrt_f2){cb[2], cb[3]} * ah;
+        }
+        if (DEAD) { gl2 = (nrt_f2){0.0f, 0.0f}; gh2 = gl2; }
+        // its inner product with every corner row, then d warped / d loc as differences of corner pairs:
+        //   d/dx = m_x sum_{y,z} (wy wz) (dot[1,y,z] - dot[0,y,z])   and likewise for y and z   (m = 0 outside the volume: clipped)
+        float dot[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const nrt_f2 s2 = gl2 * (nrt_f2){v[corner][0], v[corner][1]} + gh2 * (nrt_f2){v[corner][2], v[corner][3]};
+            dot[corner] = s2[0] + s2[1];
+        }
+        const nrt_f2 wyz0 = (nrt_f2){W0y, W0y} * wz2, wyz1 = (nrt_f2){W1y, W1y} * wz2;     // wy wz: [y0z0, y0z1], [y1z0, y1z1]
+        const nrt_f2 wxz0 = (nrt_f2){W0x, W0x} * wz2, wxz1 = (nrt_f2){W1x, W1x} * wz2;     // wx wz
+        float gacc[3];
+        gacc[0] = Mx * ((wyz0[0] * (dot[4] - dot[0]) + wyz0[1] * (dot[5] - dot[1])) + (wyz1[0] * (dot[6] - dot[2]) + wyz1[1] * (dot[7] - dot[3])));
+        gacc[1] = My * ((wxz0[0] * (dot[2] - dot[0]) + wxz0[1] * (dot[3] - dot[1])) + (wxz1[0] * (dot[6] - dot[4]) + wxz1[1] * (dot[7] - dot[5])));
+        gacc[2] = Mz * ((wxy0[0] * (dot[1] - dot[0]) + wxy0[1] * (dot[3] - dot[2])) + (wxy1[0] * (dot[5] - dot[4]) + wxy1[1] * (dot[7] - dot[6])));
+        // sum over the voxel's 8 lanes on the DPP network (quad xor 1, quad xor 2, then the mirrored half: after the two quad steps a
+        // quad's lanes hold the same value, so i <-> 7 - i adds the other quad exactly as xor 4 would); no LDS round trips
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float r = gacc[d];
+            r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0xB1, 0xF, 0xF, true));
+            r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x4E, 0xF, 0xF, true));
+            r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x141, 0xF, 0xF, true));
+            gacc[d] = r;
+        }
+        if (LIVE && lg == 0) {
+            float *dst = gl + (size_t)Q * 3;
+            dst[0] = gacc[0]; dst[1] = gacc[1]; dst[2] = gacc[2];
+        }
+    };
+
+    nrt_f4 Ra[8], Rb[8], Ta, Tb;
+    float Ax, Ay, Az, Amx, Amy, Amz, Bx, By, Bz, Bmx, Bmy, Bmz;
+    unsigned Aq, Bq;
+    bool Al, Ad, Bl, Bd;
+    unsigned off[8];
+    float pn[3];
+    fetch_loc(0, pn);
+    prepare(0, pn, Ax, Ay, Az, Amx, Amy, Amz, Aq, Al, Ad, off);
+    fetch_loc(1, pn);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(off, Aq, Ra, Ta);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int pass = 0; pass < xlen; pass += 2) {
+        prepare(pass + 1, pn, Bx, By, Bz, Bmx, Bmy, Bmz, Bq, Bl, Bd, off);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_loc(pass + 2, pn);
+        load_rows(off, Bq, Rb, Tb);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(Ax, Ay, Az, Amx, Amy, Amz, Aq, Al, Ad, Ra, Ta);
+        __builtin_amdgcn_sched_barrier(0);
+        prepare(pass + 2, pn, Ax, Ay, Az, Amx, Amy, Amz, Aq, Al, Ad, off);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_loc(pass + 3, pn);
+        load_rows(off, Aq, Ra, Ta);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(Bx, By, Bz, Bmx, Bmy, Bmz, Bq, Bl, Bd, Rb, Tb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // d out / d vol at C = 32 with the duplicate rows merged on chip before they reach L2.
 //
@@ -1197,6 +1363,16 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
                 ba.gvol = nullptr;
             }
         }
+        if (G == 8 && ba.tg.x_march && !ba.gvol && ba.gloc && loc_mode != NRT_LOC_LINSPACE &&
+            (unsigned long long)vol_batch_stride * 4ull < (1ull << 32) && (unsigned long long)ba.f.nout * channels * 4ull < (1ull << 32)) {
+            // d loc alone at 32 channels: the software-pipelined x-march kernel (warp_dice_bwd_xm with grad_out in place of d dice / d warped)
+            if (loc_mode == NRT_LOC_SHIFT)
+                hipLaunchKernelGGL((warp_dice_bwd_xm<NRT_LOC_SHIFT, false>), grid, dim3(256), 0, st, ba, grad_out, (const float *)nullptr, (const float *)nullptr, 0.0f);
+            else
+                hipLaunchKernelGGL((warp_dice_bwd_xm<NRT_LOC_ABSOLUTE, false>), grid, dim3(256), 0, st, ba, grad_out, (const float *)nullptr, (const float *)nullptr, 0.0f);
+            NRT_CHECK_LAUNCH();
+            return NRT_OK;
+        }
         switch (G) {
             case 1: NRT_BWD_MODE(interpn_bwd_rows, 1) break;
             case 2: NRT_BWD_MODE(interpn_bwd_rows, 2) break;
@@ -1413,6 +1589,25 @@ extern "C" int nrt_warp_dice_bwd_f32(const float *moving, const float *loc, cons
     else                                                                                                         \
         hipLaunchKernelGGL((warp_dice_bwd_rows<GG, NRT_LOC_ABSOLUTE>), grid, dim3(256), 0, st, ba, fixed, sums,  \
                            grad_dice, laplace_smoothing);
+    static int xm_pipe = -1;                       // NRT_BWD_XM=0: the un-pipelined kernel on the same schedule (A/B runs)
+    if (xm_pipe < 0) { const char *e = getenv("NRT_BWD_XM"); xm_pipe = e ? atoi(e) : 1; }
+    // the pipelined kernel forms 32-bit byte offsets of rows and locations
+    const bool xm_fits = (unsigned long long)nin * nlabels * 4ull < (1ull << 32) &&
+                         (unsigned long long)ba.f.nout * nlabels * 4ull < (1ull << 32);
+    if (G == 8 && ba.tg.x_march && xm_pipe && xm_fits) {
+        static int lds_kb = -1;                    // NRT_BWD_LDS_KB (experiments): unused dynamic LDS per block caps the blocks per CU
+        if (lds_kb < 0) { const char *e = getenv("NRT_BWD_LDS_KB"); lds_kb = e ? atoi(e) : 0; }
+        const unsigned dyn = (unsigned)lds_kb * 1024u;
+        if (loc_mode == NRT_LOC_SHIFT) {
+            if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)warp_dice_bwd_xm<NRT_LOC_SHIFT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            hipLaunchKernelGGL((warp_dice_bwd_xm<NRT_LOC_SHIFT>), grid, dim3(256), dyn, st, ba, fixed, sums, grad_dice, laplace_smoothing);
+        } else {
+            if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)warp_dice_bwd_xm<NRT_LOC_ABSOLUTE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+            hipLaunchKernelGGL((warp_dice_bwd_xm<NRT_LOC_ABSOLUTE>), grid, dim3(256), dyn, st, ba, fixed, sums, grad_dice, laplace_smoothing);
+        }
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
     switch (G) {
         case 1: NRT_WDB(1) break;
         case 2: NRT_WDB(2) break;
