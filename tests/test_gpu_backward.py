@@ -410,6 +410,27 @@ def test_backward_x_march_schedule_ragged(dev):
         close(N(f.grad[b]), lo.grad.numpy(), 'grad_flow b%d' % b)
 
 
+@pytest.mark.parametrize('fill', [None, 0.0])
+def test_grad_loc_x_march_absolute_locations(dev, fill):
+    """d out / d loc of utils.interpn at 32 channels on the x-march schedule (one volume, 23 x 23 patches >= 512): absolute
+    locations, a source volume of another shape, locations outside the volume (clipped: zero gradient on that axis; with a
+    fill value the voxel is dead), odd x extent -- the software-pipelined kernel (warp_dice_bwd_xm<ABSOLUTE, false>) against
+    the float64 oracle"""
+    rng = np.random.default_rng(77)
+    S, C = (17, 92, 180), 32
+    mov = rng.standard_normal((19, 40, 33, C)).astype(F)
+    w = rng.standard_normal(S + (C,)).astype(F)
+    scale = np.array([18.0 / 16, 39.0 / 91, 32.0 / 179], F)
+    grid = np.stack(np.meshgrid(*[np.arange(n, dtype=F) for n in S], indexing='ij'), -1) * scale
+    loc = (grid + rng.standard_normal(S + (3,)).astype(F) * 1.5).astype(F)       # some locations leave the volume
+    l = G(loc, dev, True)
+    out = ne.utils.interpn(G(mov, dev), l, fill_value=fill)
+    (out * G(w, dev)).sum().backward()
+    vo, lo = D64(mov), D64(loc, True)
+    (go.interpn(vo, lo, fill) * D64(w)).sum().backward()
+    close(N(l.grad), lo.grad.numpy(), 'grad_loc absolute fill=%r' % (fill,))
+
+
 @pytest.mark.parametrize('C', [1, 3, 5, 8])
 @pytest.mark.parametrize('mode', ['1', '0'])
 def test_grad_vol_few_channels(dev, C, mode, monkeypatch):
