@@ -13,7 +13,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libneurite_amd.so')
+LIB_PATH = os.environ.get('NEURITE_AMD_LIB') or os.path.join(_HERE, 'lib', 'libneurite_amd.so')      # NEURITE_AMD_LIB: another build of the same ABI
 HEADER_PATH = os.path.join(_HERE, '..', 'include', 'neurite_amd.h')
 
 NRT_OK = 0

@@ -155,9 +155,33 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             W0x = m.w0x; W0y = m.w0y; W0z = m.w0z; Q = m.q; VALID = m.valid; OOB = m.oob;
         };
         auto load_rows = [&](const unsigned (&off)[8], unsigned q, Row (&R)[8], Row &T) {
+#ifndef NRT_FUSED_EXP
+#define NRT_FUSED_EXP 0        // lab builds only (tools/fused_variants.py): cache-policy hints / request order of the corner rows
+#endif
+#if NRT_FUSED_EXP == 1          // x0 plane (last use along the march) streaming, x1 plane normal
+#pragma unroll
+            for (int corner = 0; corner < 4; ++corner) R[corner] = __builtin_nontemporal_load((const Row *)(volb + (size_t)off[corner]));
+#pragma unroll
+            for (int corner = 4; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
+#elif NRT_FUSED_EXP == 2        // all rows streaming
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) R[corner] = __builtin_nontemporal_load((const Row *)(volb + (size_t)off[corner]));
+#elif NRT_FUSED_EXP == 3        // x1 plane requested first
+#pragma unroll
+            for (int corner = 4; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
+#pragma unroll
+            for (int corner = 0; corner < 4; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
+#else
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
+#endif
+#if NRT_FUSED_EXP == 4          // fixed row as an ordinary load
+            T = *(const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB));
+#elif NRT_FUSED_EXP == 5        // fixed row requested before the corner rows
             T = __builtin_nontemporal_load((const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB)));
+#else
+            T = __builtin_nontemporal_load((const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB)));
+#endif
         };
         auto finish = [&](float W0x, float W0y, float W0z, unsigned Q, bool VALID, bool OOB, const Row (&Rraw)[8], const Row &Traw) {
             nrt_f4 R[8];
