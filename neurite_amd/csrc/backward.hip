@@ -816,6 +816,7 @@ __global__ __launch_bounds__(256, 3) void warp_dice_bwd_xm(InterpBwdArgs ba, con
     load_rows(off, Aq, Ra, Ta);
     __builtin_amdgcn_sched_barrier(0);
     for (int pass = 0; pass < xlen; pass += 2) {
+        if (ba.tg.depth_sync > 0 && (pass & (ba.tg.depth_sync - 1)) == 0) __builtin_amdgcn_s_barrier();     // see NRT_FUSED_SYNC (fused.hip)
         prepare(pass + 1, pn, Bx, By, Bz, Bmx, Bmy, Bmz, Bq, Bl, Bd, off);
         __builtin_amdgcn_sched_barrier(0);
         fetch_loc(pass + 2, pn);
@@ -1326,6 +1327,7 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
             tile_geometry(out_shape, G, t, t, ba.tg, nt);
             const unsigned per_batch = xmarch_setup(out_shape, batch, t, ba.tg);
             grid = dim3(nrt_xcd_grid(per_batch * (unsigned)batch), 1);
+            { const char *e = getenv("NRT_BWD_SYNC"); ba.tg.depth_sync = e ? atoi(e) : 8; }
             const char *dedup_env = getenv("NRT_BWD_VOL_DEDUP");          // read per call: tests switch it
             const int use_dedup = dedup_env ? atoi(dedup_env) : 2;       // 0 plain scatter, 1 LDS accumulator table, 2 counting-sort merge
             unsigned long long rows = 1;
@@ -1581,6 +1583,7 @@ extern "C" int nrt_warp_dice_bwd_f32(const float *moving, const float *loc, cons
         tile_geometry(out_shape, G, t, t, ba.tg, nt);
         const unsigned per_batch = xmarch_setup(out_shape, batch, t, ba.tg);
         grid = dim3(nrt_xcd_grid(per_batch * (unsigned)batch), 1);
+        { const char *e = getenv("NRT_BWD_SYNC"); ba.tg.depth_sync = e ? atoi(e) : 8; }
     }
 #define NRT_WDB(GG)                                                                                              \
     if (loc_mode == NRT_LOC_SHIFT)                                                                               \

@@ -155,6 +155,13 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             W0x = m.w0x; W0y = m.w0y; W0z = m.w0z; Q = m.q; VALID = m.valid; OOB = m.oob;
         };
         auto load_rows = [&](const unsigned (&off)[8], unsigned q, Row (&R)[8], Row &T) {
+#ifndef NRT_FUSED_SYNC
+// passes between block barriers (power of two; 0 = none).  The four waves of a block are y-neighbours: half of a wave's corner rows
+// are its neighbour's, and they merge in L1 only while the waves request them at about the same time.  Left alone the waves drift
+// apart; a barrier every 8 passes keeps them together at no measurable cost: 1.174 -> 1.157 ms on one box, 1.148 -> 1.109 on another
+// (every 2 passes: slower; 16: the same; 32: less), profiles/r03_lab/fused_occupancy_depth.jsonl
+#define NRT_FUSED_SYNC 8
+#endif
 #ifndef NRT_FUSED_EXP
 #define NRT_FUSED_EXP 0        // lab builds only (tools/fused_variants.py): cache-policy hints / request order of the corner rows
 #endif
@@ -240,6 +247,9 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
         load_rows(off, Aq, Ra, Ta);
         __builtin_amdgcn_sched_barrier(0);
         for (int pass = 0; pass < npass; pass += 2) {
+#if NRT_FUSED_SYNC > 0          // the block's four waves (their y-neighbour rows meet in L1) kept loosely in step
+            if ((pass & (NRT_FUSED_SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
+#endif
             prepare(min(pass + 1, last), pn, Bx, By, Bz, Bq, Bv, Bo, off);
             Bv = Bv && (pass + 1 < npass);
             __builtin_amdgcn_sched_barrier(0);

@@ -95,6 +95,7 @@ struct TileGeom {
     unsigned ncol, nseg, seglen;   // (y,z) patches per volume, x segments, x planes per segment
     unsigned nbatch;
     int lry, lrz;                  // log2 of the region extent in patches: consecutive blocks fill a (2^lry x 2^lrz) patch region
+    int depth_sync;                // backward x-march kernels: passes between block barriers (power of two), 0 = none
 };
 
 // tune word of the tiled kernels: ltx | lty << 4 | ltz << 8 | z_outer << 12 | plane_major << 13 | x_march << 14 | LZ << 16
@@ -104,7 +105,7 @@ inline void tile_geometry(const int *out_shape, int G, int tune, int default_tun
     if (tune <= 0) tune = default_tune;
     tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
     tg.plane_major = ((tune >> 13) & 1) && G == 8;
-    tg.x_march = 0; tg.ncol = 0; tg.nseg = 1; tg.seglen = 0; tg.nbatch = 1; tg.lry = 0; tg.lrz = 0;
+    tg.x_march = 0; tg.ncol = 0; tg.nseg = 1; tg.seglen = 0; tg.nbatch = 1; tg.lry = 0; tg.lrz = 0; tg.depth_sync = 0;
     if (tg.plane_major) {
         tg.ltx = 2; tg.lty = 3; tg.ltz = 0;
         tg.tz = (tune >> 16) & 0xfff;
