@@ -32,7 +32,7 @@ def timeit(fn, n=30):
 XM = 1 << 14
 REG = (3 << 24) | (2 << 27)
 ref = ne.fused.warp_dice(mov, trf, fix)
-for (sy, sz) in ((160, 160), (160, 161), (161, 161), (162, 176), (160, 176), (164, 168), (160, 192)):
+for (sy, sz) in (((160, 160), (160, 161), (161, 161), (162, 176), (160, 176), (164, 168), (160, 192)) if '--shapes' in sys.argv else ()):
     big = torch.zeros((B, S, sy, sz, L), dtype=torch.float32, device=dev)
     big[:, :, :S, :S] = mov
     t = timeit(lambda: ne.fused.warp_dice(big, trf, fix))
@@ -40,10 +40,10 @@ for (sy, sz) in ((160, 160), (160, 161), (161, 161), (162, 176), (160, 176), (16
     print(json.dumps({'vol_shape': [S, sy, sz], 'y_stride_mod64': sz % 64, 'x_stride_mod64': (sy * sz) % 64, 'ms': round(t, 4),
                       'same_dice_as_160': bool(torch.equal(d, ref)) if (sy, sz) == (160, 160) else float((d - ref).abs().max())}), flush=True)
     del big
-for lty, ltz in ((2, 3), (1, 4), (0, 5), (3, 2)):
-    tune = 3 | (lty << 4) | (ltz << 8) | XM | REG
+for lty, ltz, lry, lrz in ((2, 3, 3, 2), (3, 2, 2, 3), (3, 2, 3, 2), (2, 3, 2, 3), (2, 3, 2, 2), (2, 3, 3, 3), (2, 3, 3, 2)):
+    tune = 3 | (lty << 4) | (ltz << 8) | XM | (lry << 24) | (lrz << 27)
     try:
         t = timeit(lambda: ne.fused.warp_dice(mov, trf, fix, _tune=tune))
-        print(json.dumps({'patch_yz': [1 << lty, 1 << ltz], 'ms': round(t, 4)}), flush=True)
+        print(json.dumps({'patch_yz': [1 << lty, 1 << ltz], 'region_patches_yz': [1 << lry, 1 << lrz], 'ms': round(t, 4)}), flush=True)
     except Exception as ex:
         print(json.dumps({'patch_yz': [1 << lty, 1 << ltz], 'error': str(ex)[:100]}), flush=True)
