@@ -162,6 +162,12 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
 // (every 2 passes: slower; 16: the same; 32: less), profiles/r03_lab/fused_occupancy_depth.jsonl
 #define NRT_FUSED_SYNC 8
 #endif
+#ifndef NRT_FUSED_MINW
+// waves per SIMD the x-march instance is compiled for (register budget 512 / MINW).  Two blocks of four waves run per CU (the LDS
+// padding below), so 4 only squeezed the kernel into 128 registers with three of them spilled; at 3 it takes 130, nothing spills:
+// 1.158 -> 1.140 ms (two alternating repeats, profiles/r03_lab/fused_occupancy_depth.jsonl)
+#define NRT_FUSED_MINW 3
+#endif
 #ifndef NRT_FUSED_EXP
 #define NRT_FUSED_EXP 0        // lab builds only (tools/fused_variants.py): cache-policy hints / request order of the corner rows
 #endif
@@ -345,15 +351,15 @@ void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int
     if (tg.x_march) {
         grid = dim3(nrt_xcd_grid(nblocks * (unsigned)batch), 1);
 #define NRT_FUSED_X(MODE)                                                                                           \
-    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, 4, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
+    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, NRT_FUSED_MINW, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
     else {                                                                                                          \
         static unsigned attr_dyn = 0;                                                                               \
         if (dyn > 48 * 1024 && attr_dyn != dyn) {                                                                   \
-            (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, 4, ST>,                          \
+            (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, NRT_FUSED_MINW, ST>,                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                        \
             attr_dyn = dyn;                                                                                         \
         }                                                                                                           \
-        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 4, ST>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
+        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, NRT_FUSED_MINW, ST>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
     }
         switch (mode) {
             case NRT_LOC_ABSOLUTE: NRT_FUSED_X(NRT_LOC_ABSOLUTE); break;
