@@ -62,6 +62,24 @@ __device__ __forceinline__ T wave_xor_add(T v, int from) {
 // division.  Fixed partition + fixed order => bit-reproducible.
 constexpr int RED_ROWS = 64;
 
+// extrema quadruples (min t, max t, min p, max p): thread t holds a partial of component t & 3; 256 threads; the combined value
+// comes back in threads 0..3.  (Threads 0..3 walking the rows themselves was a chain of dependent-issue loads: ~0.3 us per row.)
+__device__ __forceinline__ float combine_minmax4(float m, float *smm /* [16] */) {
+    const int i = threadIdx.x & 3;
+#pragma unroll
+    for (int off = 4; off < NRT_WAVE; off <<= 1) {
+        const float o = __shfl_xor(m, off, NRT_WAVE);
+        m = (i & 1) ? fmaxf(m, o) : fminf(m, o);
+    }
+    if ((threadIdx.x & (NRT_WAVE - 1)) < 4) smm[(threadIdx.x / NRT_WAVE) * 4 + i] = m;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        m = smm[i];
+        for (int w = 1; w < 256 / NRT_WAVE; ++w) m = (i & 1) ? fmaxf(m, smm[w * 4 + i]) : fminf(m, smm[w * 4 + i]);
+    }
+    return m;
+}
+
 template <typename TIN, typename TACC>
 __global__ __launch_bounds__(256) void reduce_rows(const TIN *__restrict__ in, int rows, int ncol, TACC *__restrict__ out,
                                                     const float *__restrict__ mm_in, float *__restrict__ mm_out, int mm_rows) {
@@ -76,15 +94,16 @@ __global__ __launch_bounds__(256) void reduce_rows(const TIN *__restrict__ in, i
         if (sidx < S) {
             // 8 independent loads in flight per thread, then a fixed-order add (a dependent load-add chain
             // cost ~0.6 us per row here: the partials sit in another XCD's L2)
-            for (int k = r0 + sidx; k < r1; k += 8 * S) {
-                TIN v[8];
+            constexpr int U = 8;                                 // loads in flight per thread (16: no faster; same order of additions for any U)
+            for (int k = r0 + sidx; k < r1; k += U * S) {
+                TIN v[U];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < U; ++u) {
                     const int kk = k + u * S;
                     v[u] = kk < r1 ? in[((long long)b * rows + kk) * ncol + c0 + i] : (TIN)0;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += (TACC)v[u];
+                for (int u = 0; u < U; ++u) acc += (TACC)v[u];
             }
         }
         sl[threadIdx.x] = acc;
@@ -96,15 +115,17 @@ __global__ __launch_bounds__(256) void reduce_rows(const TIN *__restrict__ in, i
         }
         __syncthreads();
     }
-    if (mm_in && threadIdx.x < 4) {            // min t, max t, min p, max p of this group's partials
-        const int i = threadIdx.x;
+    if (mm_in) {                               // min t, max t, min p, max p of this group's partials (block-uniform branch)
+        __shared__ float smm[16];
+        const int i = threadIdx.x & 3;
         const int q0 = (int)((long long)r0 * mm_rows / rows), q1 = (int)((long long)r1 * mm_rows / rows);
         float m = (i & 1) ? -INFINITY : INFINITY;
-        for (int k = q0; k < q1; ++k) {
+        for (int k = q0 + (int)(threadIdx.x >> 2); k < q1; k += 64) {
             const float v = mm_in[((long long)b * mm_rows + k) * 4 + i];
             m = (i & 1) ? fmaxf(m, v) : fminf(m, v);
         }
-        mm_out[((long long)b * gridDim.y + grp) * 4 + i] = m;
+        m = combine_minmax4(m, smm);
+        if (threadIdx.x < 4) mm_out[((long long)b * gridDim.y + grp) * 4 + i] = m;
     }
 }
 
@@ -136,14 +157,16 @@ __global__ __launch_bounds__(256) void dice_soft_finalize(const double *__restri
         else d = (bottom == 0.0f) ? 0.0f : top / bottom;                // :482 divide_no_nan
         dice[(long long)b * L + l] = d;
     }
-    if (minmax && b == 0 && threadIdx.x < 4) {
-        const int i = threadIdx.x;
+    if (minmax && b == 0) {
+        __shared__ float smm[16];
+        const int i = threadIdx.x & 3;
         float m = (i & 1) ? -INFINITY : INFINITY;
-        for (int k = 0; k < (int)gridDim.x * ngrp; ++k) {
+        for (int k = (int)(threadIdx.x >> 2); k < (int)gridDim.x * ngrp; k += 64) {
             const float v = gmm[(long long)k * 4 + i];
             m = (i & 1) ? fmaxf(m, v) : fminf(m, v);
         }
-        minmax[i] = m;
+        m = combine_minmax4(m, smm);
+        if (threadIdx.x < 4) minmax[i] = m;
     }
 }
 
