@@ -247,7 +247,10 @@ int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *lab
  * All tensors channels-last float32 [batch, X, Y, Z, C]; `shape`, `ksize`, `pool`, `up` are host int[3].
  * ------------------------------------------------------------------------------------------ */
 /* element-wise activations as tf.keras.activations defines them (elu alpha 1, hard_sigmoid = clip(0.2 x + 0.5, 0, 1), leaky_relu slope
- * 0.2); accepted by every `activation` argument below.  The channel softmax is a kernel of its own (nrt_softmax_lastdim_f32). */
+ * 0.2).  The convolution / LocallyConnected3D entry points (nrt_conv3d_f32, nrt_conv3d_up2_f32, nrt_conv1x1_softmax_f32,
+ * nrt_lc3d_f) fuse NONE / ELU / RELU into their epilogues and return NRT_ERR_INVALID_ARG for the other codes: run those as an
+ * element-wise pass over the layer output (nrt_add_act_affine_f32, which accepts all of them, as do nrt_act_bwd_f32 and the
+ * backward entry points).  The channel softmax is a kernel of its own (nrt_softmax_lastdim_f32). */
 typedef enum { NRT_ACT_NONE = 0, NRT_ACT_ELU = 1, NRT_ACT_RELU = 2, NRT_ACT_SIGMOID = 3, NRT_ACT_TANH = 4, NRT_ACT_SOFTPLUS = 5,
                NRT_ACT_SOFTSIGN = 6, NRT_ACT_SELU = 7, NRT_ACT_EXPONENTIAL = 8, NRT_ACT_HARD_SIGMOID = 9, NRT_ACT_LEAKY_RELU = 10 } nrt_activation;
 /* nrt_add_act_affine_f32 only: or-ed into `activation`, y = act(a) * b instead of act(a + b) (models.add_prior, use_logp=False) */

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get('NEURITE_AMD_LIB') or os.path.join(_HERE, 'lib', 'libn
 HEADER_PATH = os.path.join(_HERE, '..', 'include', 'neurite_amd.h')
 
 NRT_OK = 0
+NRT_ERR_INVALID_ARG, NRT_ERR_UNSUPPORTED, NRT_ERR_LAUNCH, NRT_ERR_WORKSPACE = -1, -2, -3, -4
 LOC_ABSOLUTE, LOC_SHIFT, LOC_LINSPACE = 0, 1, 2
 INTERP_LINEAR, INTERP_NEAREST = 0, 1
 DT_F32, DT_BF16, DT_F16, DT_F64, DT_I32 = 0, 1, 2, 3, 4

@@ -1112,6 +1112,7 @@ extern "C" int nrt_conv1x1_softmax_f32(const float *x, const float *weights, con
                                        long long nvox, int cin, int cout, int softmax, int activation, void *stream) {
     if (!x || !weights || !y || nvox < 0 || cin < 1 || cout < 1) return NRT_ERR_INVALID_ARG;
     if (cout > 64 || (size_t)(cin + 1) * cout * sizeof(float) > 64 * 1024) return NRT_ERR_UNSUPPORTED;
+    if (activation < ACT_NONE || activation > ACT_LAST_FUSED) return NRT_ERR_INVALID_ARG;   // the kernels fuse none / elu / relu only
     if (nvox == 0) return NRT_OK;
     unsigned blocks = (unsigned)((nvox + 255) / 256);
     if (blocks > 256u * 16u) blocks = 256u * 16u;

@@ -222,7 +222,9 @@ const float *p27_zero_block(hipStream_t st) {
     if (!blocks[dev]) {
         float *p = nullptr;
         if (hipMalloc((void **)&p, 256) != hipSuccess) return nullptr;
-        if (hipMemsetAsync(p, 0, 256, st) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        // zeroed synchronously (once per device): a memset queued on the first caller's stream could still be pending when another
+        // stream's first launch reads the block
+        if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
         blocks[dev] = p;
     }
     return blocks[dev];

@@ -749,11 +749,10 @@ extern "C" int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_p
         const size_t shm_private = (size_t)3 * nlabels * DICE_BLOCK * sizeof(unsigned);
         if (shm_private <= 120 * 1024 && nvox >= 65536) {
             // lane-private histograms: one block per CU is resident (LDS), so size the grid to the chip
-            static bool attr = false;
-            if (!attr) {
-                (void)hipFuncSetAttribute((const void *)dice_hard_label_private, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-                attr = true;
-            }
+            // (function attributes are per device and this may be called from several host threads: set on every launch, as the
+            // other large-LDS kernels do)
+            if (hipFuncSetAttribute((const void *)dice_hard_label_private, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess)
+                return NRT_ERR_LAUNCH;
             const unsigned per_batch = (unsigned)max(1, (int)(512 / batch));
             nblk = min(nblk, per_batch);
             hipLaunchKernelGGL(dice_hard_label_private, dim3(nblk, batch), dim3(DICE_BLOCK), shm_private, st, (const int *)y_true,

@@ -184,12 +184,29 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             for (int corner = 4; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
 #pragma unroll
             for (int corner = 0; corner < 4; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
+#elif NRT_FUSED_EXP >= 6 && NRT_FUSED_EXP <= 8
+            // PROBES (wrong results on purpose): only the first 4 / 2 / 1 corner rows are requested, the others re-use them --
+            // the time against L1 accesses per voxel, everything else unchanged (profiles/r04_lab/l1_access_curve.jsonl)
+            constexpr int NLD = NRT_FUSED_EXP == 6 ? 4 : (NRT_FUSED_EXP == 7 ? 2 : 1);
+#pragma unroll
+            for (int corner = 0; corner < NLD; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
+#pragma unroll
+            for (int corner = NLD; corner < 8; ++corner) R[corner] = R[corner % NLD];
+#elif NRT_FUSED_EXP == 11 || NRT_FUSED_EXP == 12 || NRT_FUSED_EXP == 13
+            // PROBES: all 8 loads issued, but they address 1 (11) / 2 (12: the z pair) / 4 (13: the x0 plane) distinct rows --
+            // L1 accesses without the misses.  a.fill_i is 0 at run time; it keeps the compiler from merging the loads.
+            constexpr int MSK = NRT_FUSED_EXP == 11 ? 0 : (NRT_FUSED_EXP == 12 ? 1 : 3);
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner)
+                R[corner] = *(const Row *)(volb + (size_t)(off[corner & MSK] + (unsigned)(a.fill_i * corner)));
 #else
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
 #endif
 #if NRT_FUSED_EXP == 4          // fixed row as an ordinary load
             T = *(const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB));
+#elif NRT_FUSED_EXP == 9        // PROBE: no fixed row at all (what the compulsory second stream costs)
+            T = R[0];
 #elif NRT_FUSED_EXP == 5        // fixed row requested before the corner rows
             T = __builtin_nontemporal_load((const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB)));
 #else

@@ -77,7 +77,6 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
     const int part = wave % SPLIT, itb = part * MAXIT;                        // this wave's row groups: itb .. itb + MAXIT - 1
     const long long nwaves = (long long)gridDim.x * ((blockDim.x >> 6) / SPLIT);
     const T *xb = (const T *)a.x;
-    __shared__ float red[SPLIT > 1 ? 3 * 4 * 64 : 1];                         // [positions of a block x other parts <= 3][NB][Cout <= 64]
     // staged patches: [wave][NB][stage_chunks * 16 bytes], private to the wave (its LDS operations execute in order: no barrier)
     extern __shared__ __attribute__((aligned(16))) char lc_patch[];
     typedef unsigned u32x4z __attribute__((ext_vector_type(4)));
@@ -85,6 +84,10 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
     constexpr bool staged = STAGED;
     const unsigned pbytes = (unsigned)a.stage_chunks * 16u + 16u;             // + a zero slot: what the dead row groups of a lane read
     char *mypatch = lc_patch + (size_t)(threadIdx.x >> 6) * NB * pbytes;
+    // SPLIT > 1: [positions of a block x other parts <= 3][4][Cout] partial sums behind the four waves' patches (dynamic LDS sized by
+    // the launcher: Cout reaches 256 in float32 and 512 in bfloat16 -- a fixed 64-column row overlapped the batch entries)
+    float *red = (float *)(lc_patch + (size_t)4 * NB * pbytes);
+    const int rstride = a.Cout;
     unsigned loff[MAXIT];                                                     // byte offset of this lane's element of row group it in the staged patch
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -223,12 +226,12 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
                 for (int e = 0; e < VEC; ++e) acc[b][e] += other[b][e];
         }
         if (SPLIT > 1) {                                 // the other waves' shares of the sum go through LDS
-            float *rp = red + (wave / SPLIT) * ((SPLIT - 1) * 4 * 64);
+            float *rp = red + (wave / SPLIT) * ((SPLIT - 1) * 4 * rstride);
             if (part > 0 && lane < LPR) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) rp[((part - 1) * 4 + b) * 64 + sl * VEC + e] = acc[b][e];
+                    for (int e = 0; e < VEC; ++e) rp[((part - 1) * 4 + b) * rstride + sl * VEC + e] = acc[b][e];
             }
             __syncthreads();
             if (part == 0 && lane < LPR) {
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
 #pragma unroll
                     for (int b = 0; b < NB; ++b)
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) acc[b][e] += rp[(q * 4 + b) * 64 + sl * VEC + e];
+                        for (int e = 0; e < VEC; ++e) acc[b][e] += rp[(q * 4 + b) * rstride + sl * VEC + e];
             }
             __syncthreads();
         }
@@ -298,9 +301,10 @@ void launch_vec_st(const LcArgs &a, unsigned blocks, hipStream_t st) {
     for (int b0 = 0; b0 < a.B; b0 += 4) {
         const int nb = a.B - b0 < 4 ? a.B - b0 : 4;
         const size_t ps = ((size_t)a.stage_chunks * 16 + 16) * 4;               // per batch entry: 4 waves, + the zero slot
-        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), ps, st, a, b0, nb);
-        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), 2 * ps, st, a, b0, nb);
-        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), 4 * ps, st, a, b0, nb);
+        const size_t rs = SPLIT > 1 ? (size_t)3 * 4 * a.Cout * sizeof(float) : 0;  // the SPLIT partial sums (<= 24 KB; total < 64 KB)
+        if (nb == 1) hipLaunchKernelGGL((lc3d_fwd<T, 1, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), ps + rs, st, a, b0, nb);
+        else if (nb == 2) hipLaunchKernelGGL((lc3d_fwd<T, 2, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), 2 * ps + rs, st, a, b0, nb);
+        else hipLaunchKernelGGL((lc3d_fwd<T, 4, MAXIT, STAGED, SPLIT>), dim3(blocks), dim3(256), 4 * ps + rs, st, a, b0, nb);
     }
 }
 
@@ -601,6 +605,7 @@ extern "C" int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, v
     if (!x || !kernel || !y || !in_shape || !ksize || !strides) return NRT_ERR_INVALID_ARG;
     if (batch < 1 || cin < 1 || cout < 1) return NRT_ERR_INVALID_ARG;
     if (dtype != NRT_DT_F32 && dtype != NRT_DT_BF16) return NRT_ERR_UNSUPPORTED;
+    if (activation < ACT_NONE || activation > ACT_LAST_FUSED) return NRT_ERR_INVALID_ARG;   // the epilogue fuses none / elu / relu only
     LcArgs a;
     a.x = x; a.k = kernel; a.bias = bias; a.y = y; a.B = batch;
     a.R = in_shape[0]; a.C = in_shape[1]; a.Z = in_shape[2]; a.Cin = cin;

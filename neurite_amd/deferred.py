@@ -12,8 +12,8 @@ DeferredWarp as one of its arguments and launches the fused warp + Dice kernel o
 consumer simply triggers the stand-alone interpn kernel, exactly as an eager call would have.
 
 Deferral happens only for: linear interpolation, float32 3-D volumes with 4 * 2^k labels, dense displacement fields, no
-gradient being recorded (training graphs stay eager: autograd needs the real tensor), and `deferred.enabled` (env
-NRT_DEFER_WARP, default on).  The values are bit-identical to the eager path whenever they are materialised.
+gradient being recorded (training graphs stay eager: autograd needs the real tensor), not under `torch.inference_mode()` (inference
+tensors have no version counter, see Immutability), and `deferred.enabled` (env NRT_DEFER_WARP, default on).  The values are bit-identical to the eager path whenever they are materialised.
 
 Immutability.  TensorFlow tensors are immutable, so in the reference the value of `warped` is fixed when SpatialTransformer
 returns.  A deferred warp reads its inputs when it is first used, and PyTorch lets a program overwrite them in between
@@ -37,7 +37,8 @@ class DeferredWarpError(RuntimeError):
 
 
 def _stamp(t):
-    return (t._version, t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+    # (inference tensors have no version counter -- reading it raises; SpatialTransformer does not defer them, this is the backstop)
+    return (None if t.is_inference() else t._version, t.data_ptr(), tuple(t.shape), tuple(t.stride()))
 
 
 class DeferredWarp(torch.Tensor):

@@ -215,7 +215,9 @@ class SpatialTransformer(_Layer):
         if (deferred.enabled and self.interp_method == 'linear' and D == 3 and vol.dtype == torch.float32
                 and self._variant == 0 and self._tune == 0 and L % 4 == 0 and (L // 4) in (1, 2, 4, 8, 16, 32, 64)
                 and shift.numel() > 0 and vol.numel() > 0
-                and not (torch.is_grad_enabled() and (vol.requires_grad or shift.requires_grad))):
+                and not (torch.is_grad_enabled() and (vol.requires_grad or shift.requires_grad))
+                # inference tensors carry no version counter: an in-place change could not be detected, so they warp eagerly
+                and not (vol32.is_inference() or shift.is_inference() or torch.is_inference_mode_enabled())):
             vol_c, shift_c = vol32.contiguous(), shift.contiguous()
             return deferred.DeferredWarp([B] + list(shift.shape[1:-1]) + [L], vol.dtype, vol.device, run,
                                          dict(vol=vol_c, shift=shift_c, single_transform=self.single_transform,
@@ -1001,5 +1003,10 @@ class LocallyConnected3D(_Layer):
         if self.activation == 'softmax':            # Keras softmax: over the channel axis of the layer's data format
             from .models import _softmax, _SoftmaxFn
             sm = _SoftmaxFn.apply if (torch.is_grad_enabled() and out.requires_grad) else _softmax
+            if self.data_format == 'channels_first':
+                # layers.py:1100 applies self.activation to the channels_first tensor and Keras' softmax runs over ITS last axis: the
+                # last spatial one, not the filters (a quirk of the reference, kept)
+                out = out.permute(0, 4, 1, 2, 3).contiguous()
+                return sm(out.float()).to(out.dtype) if out.dtype != torch.float32 else sm(out)
             out = sm(out.float()).to(out.dtype) if out.dtype != torch.float32 else sm(out)
         return out.permute(0, 4, 1, 2, 3) if self.data_format == 'channels_first' else out

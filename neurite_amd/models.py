@@ -244,7 +244,10 @@ class _Conv(nn.Module):
         # low-resolution grid (variant 0 = auto, 4 = required; 2 keeps the plain implicit GEMM over all 27 taps)
         folded = (variant in (0, 4) and lo is not None and tuple(up) == (2, 2, 2) and self.ksize3 == (3, 3, 3)
                   and self.dilation == 1 and self.padding == 'same'
-                  and lib.nrt_conv3d_up2_supported(c0, c1, self.cout, _lib.ints(S)) == 1)
+                  and lib.nrt_conv3d_up2_supported(c0, c1, self.cout, _lib.ints(S)) == 1
+                  # the folded kernel forms 32-bit output offsets over the whole batch (conv_up2.h launch_up2); the shape query
+                  # does not see the batch, and nrt_conv3d_f32 has no such limit
+                  and B * S[0] * S[1] * S[2] * self.cout < (1 << 30))
         if variant == 4 and not folded:
             raise NotImplementedError('%s: shapes outside the folded decoder kernel' % self.layer_name)
         if folded:
@@ -252,10 +255,11 @@ class _Conv(nn.Module):
                 rc = lib.nrt_conv3d_up2_f32(_lib.ptr(x), c0, _lib.ptr(lo), c1, _lib.ptr(self._packed_weights_up2(c0)),
                                             _lib.ptr(self.bias.detach()), _lib.ptr(out), B, _lib.ints(S), self.cout,
                                             self.act if self.act <= _ACT_LAST_FUSED else 0, _lib.stream_ptr(dev))
-            _lib.check(rc, 'nrt_conv3d_up2_f32')
-            if self.act > _ACT_LAST_FUSED:
-                out = _elementwise(out, act=self.act)
-            return out
+            if not (rc == _lib.NRT_ERR_UNSUPPORTED and variant == 0):       # auto: anything the folded form declines takes the plain GEMM
+                _lib.check(rc, 'nrt_conv3d_up2_f32')
+                if self.act > _ACT_LAST_FUSED:
+                    out = _elementwise(out, act=self.act)
+                return out
         with torch.cuda.device(dev):
             rc = lib.nrt_conv3d_f32(_lib.ptr(x), c0, _lib.ptr(lo), c1, _lib.ints(up) if lo is not None else None,
                                     _lib.ptr(w), _lib.ptr(self._packed_weights()), _lib.ptr(self.bias.detach()),
@@ -341,11 +345,14 @@ def _conv1x1_softmax(x, kernel, bias, softmax, act):
     cin, cout = kernel.shape[-2], kernel.shape[-1]
     y = torch.empty(list(x.shape[:-1]) + [cout], dtype=torch.float32, device=dev)
     w = kernel.detach().reshape(cin, cout).contiguous()
+    fused = int(act) if int(act) <= _ACT_LAST_FUSED else 0       # elu / relu ride in the epilogue, the others as a pass of their own
+    if softmax and fused != int(act):
+        raise NotImplementedError('a 1x1x1 convolution with a non-fused activation followed by the channel softmax')
     with torch.cuda.device(dev):
         rc = lib.nrt_conv1x1_softmax_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(bias.detach()), _lib.ptr(y),
-                                         x.numel() // cin, cin, cout, int(softmax), int(act), _lib.stream_ptr(dev))
+                                         x.numel() // cin, cin, cout, int(softmax), fused, _lib.stream_ptr(dev))
     _lib.check(rc, 'nrt_conv1x1_softmax_f32')
-    return y
+    return y if fused == int(act) else _elementwise(y, act=int(act))
 
 
 def _softmax(x):

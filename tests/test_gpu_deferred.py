@@ -109,6 +109,24 @@ def test_deferred_respects_semantics(dev, batch):
     assert st([mov, trf]).cpu().numpy().shape == tuple(fix.shape)
 
 
+def test_spatial_transformer_under_inference_mode(dev, batch):
+    """torch.inference_mode(): inference tensors carry no version counter, so an in-place change could not be detected -- the layer
+    warps eagerly there (bit-identical values, no DeferredWarp, no exception)."""
+    mov, fix, trf = batch
+    st = ne.layers.SpatialTransformer()
+    dice = ne.metrics.Dice(check_input_limits=False)
+    ref = eager(lambda: st([mov, trf]))
+    d_ref = eager(lambda: dice.dice(fix, ref))
+    with torch.inference_mode():
+        flow = trf * 1.0                                             # an inference tensor, as a network's output would be
+        w = st([mov, flow])
+        assert not isinstance(w, ne.deferred.DeferredWarp)
+        assert bits_equal(N(w), N(ref))
+        np.testing.assert_allclose(N(dice.dice(fix, w)), N(d_ref), rtol=1e-6, atol=1e-7)
+    w2 = st([mov, flow])                                             # inference tensor used outside the mode: still eager
+    assert not isinstance(w2, ne.deferred.DeferredWarp) and bits_equal(N(w2), N(ref))
+
+
 def test_deferred_warp_is_safe_against_buffer_reuse(dev, batch):
     """warped = st([buf, trf]); buf.copy_(next); dice(fixed, warped): the eager path (and TF's immutable tensors) give the Dice of the
     ORIGINAL data.  The deferred path must give the same or refuse loudly -- never the Dice of the new data."""

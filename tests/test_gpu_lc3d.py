@@ -57,7 +57,10 @@ def test_lc3d_golden(dev):
 
 @pytest.mark.parametrize('cin,cout,S,ks,st', [(16, 16, (12, 12, 12), (3, 3, 3), (1, 1, 1)), (3, 5, (7, 8, 9), (2, 3, 2), (1, 2, 1)),
                                                (8, 32, (6, 9, 7), (3, 3, 3), (1, 1, 1)), (4, 8, (9, 9, 9), (3, 3, 3), (2, 2, 2)),
-                                               (16, 64, (5, 5, 6), (3, 3, 3), (1, 1, 1))])
+                                               (16, 64, (5, 5, 6), (3, 3, 3), (1, 1, 1)),
+                                               # more than 64 filters on few input channels: 27 / 54 row groups per lane, the forms in
+                                               # which two / four waves share a position and meet in LDS (rows of Cout floats)
+                                               (2, 128, (4, 5, 4), (3, 3, 3), (1, 1, 1)), (4, 128, (4, 4, 5), (3, 3, 3), (1, 1, 1))])
 def test_lc3d_vs_oracle(dev, cin, cout, S, ks, st):
     rng = np.random.default_rng(cin + cout)
     osh = tuple((S[d] - ks[d]) // st[d] + 1 for d in range(3))
@@ -86,6 +89,50 @@ def test_lc3d_vs_oracle(dev, cin, cout, S, ks, st):
                           data_format='channels_first')
     ycf = layer_cf(G(x, dev).permute(0, 4, 1, 2, 3).contiguous())
     close(N(ycf.permute(0, 2, 3, 4, 1)), ref, 1e-5)
+
+
+@pytest.mark.parametrize('batch', [3, 4])
+def test_lc3d_many_filters_batch(dev, batch):
+    """Cout > 64 with 2 .. 4 batch entries per pass (the split forms' LDS rows are Cout wide, one per batch entry)."""
+    rng = np.random.default_rng(batch)
+    cin, cout, S, ks = 3, 128, (4, 4, 6), (3, 3, 3)
+    osh = tuple(S[d] - ks[d] + 1 for d in range(3))
+    O, Fd = int(np.prod(osh)), 27 * cin
+    x = rng.standard_normal((batch,) + S + (cin,)).astype(F)
+    k = (rng.standard_normal((O, Fd, cout)) / np.sqrt(Fd)).astype(F)
+    b = rng.standard_normal(osh + (cout,)).astype(F)
+    layer = make_layer(dev, G(x, dev), cout, ks, (1, 1, 1), G(k, dev), G(b, dev))
+    close(N(layer(G(x, dev))), npo.lc3d(x, k, b, ks, (1, 1, 1)), 1e-5)
+    xb, kb, bb = G(x, dev).bfloat16(), G(k, dev).bfloat16(), G(b, dev).bfloat16()
+    layer = make_layer(dev, xb, cout, ks, (1, 1, 1), kb, bb)
+    close(N(layer(xb)), npo.lc3d(N(xb), N(kb), N(bb), ks, (1, 1, 1)), 2.0 ** -8)
+
+
+def test_lc3d_softmax_axis_follows_the_data_format(dev):
+    """layers.py:1100 hands the layer output to Keras' softmax, which runs over the LAST axis of that tensor: the filters for
+    channels_last, the last spatial axis for channels_first."""
+    rng = np.random.default_rng(11)
+    cin, cout, S, ks = 3, 8, (5, 4, 6), (2, 2, 2)
+    osh = tuple(S[d] - ks[d] + 1 for d in range(3))
+    O, Fd = int(np.prod(osh)), 8 * cin
+    x = rng.standard_normal((2,) + S + (cin,)).astype(F)
+    k = (rng.standard_normal((O, Fd, cout)) / np.sqrt(Fd)).astype(F)
+    b = rng.standard_normal(osh + (cout,)).astype(F)
+    pre = npo.lc3d(x, k, b, ks, (1, 1, 1)).astype(np.float64)               # [B, r, c, z, cout]
+
+    def softmax(v, axis):
+        e = np.exp(v - v.max(axis=axis, keepdims=True))
+        return e / e.sum(axis=axis, keepdims=True)
+    layer = make_layer(dev, G(x, dev), cout, ks, (1, 1, 1), G(k, dev), G(b, dev), act='softmax')
+    close(N(layer(G(x, dev))), softmax(pre, -1), 1e-5)
+    T = 8
+    k_cf = np.ascontiguousarray(k.reshape(O, T, cin, cout).transpose(0, 2, 1, 3).reshape(O, Fd, cout))
+    b_cf = np.ascontiguousarray(b.transpose(3, 0, 1, 2)).reshape(osh + (cout,))
+    x_cf = G(x, dev).permute(0, 4, 1, 2, 3).contiguous()
+    layer_cf = make_layer(dev, x_cf, cout, ks, (1, 1, 1), G(k_cf, dev), G(b_cf, dev), act='softmax', data_format='channels_first')
+    y = layer_cf(x_cf)
+    assert tuple(y.shape) == (2, cout) + osh
+    close(N(y), softmax(pre.transpose(0, 4, 1, 2, 3), -1), 1e-5)
 
 
 def test_lc3d_contract():

@@ -45,6 +45,13 @@ def test_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.nrt_wcce(None, None, 0, None, 10, 4, 0, 0.0, None, None, None, 0, None) == -1
     assert lib.nrt_dice_workspace_bytes(100, 32, 2) > 0
     assert lib.nrt_wcce_workspace_bytes(100, 16) > 0
+    # the conv / LocallyConnected3D epilogues fuse none / elu / relu only: any other activation code is an error, never a silent
+    # linear result (include/neurite_amd.h "element-wise activations")
+    p16 = ctypes.c_void_p(16)
+    for act in (3, 4, 10, -1):
+        assert lib.nrt_conv1x1_softmax_f32(p16, p16, p16, p16, 64, 16, 32, 0, act, None) == -1
+        assert lib.nrt_lc3d_f(p16, p16, p16, p16, 0, 1, shp, 2, ne._lib.ints([3, 3, 3]), ne._lib.ints([1, 1, 1]), 4, act, 0, None) == -1
+        assert lib.nrt_conv3d_up2_f32(p16, 16, p16, 16, p16, p16, p16, 1, shp, 16, act, None) == -1
 
 
 def test_no_cpu_fallback():
@@ -703,6 +710,12 @@ def test_deferred_warp_detects_modified_inputs_cpu():
     _ = vol + 1                                                          # out-of-place uses of the inputs are fine
     _ = shift * 2
     d.check_sources()
+    # inference tensors have no version counter (reading it raises): the stamp must not; SpatialTransformer warps them eagerly
+    with torch.inference_mode():
+        vi = torch.ones(1, 2, 3, 4)
+        di = deferred.DeferredWarp((1, 2, 3, 4), torch.float32, torch.device('cpu'), lambda: vi.clone(),
+                                   dict(vol=vi, shift=torch.zeros(1, 2, 3, 3), single_transform=False, fill_value=None))
+        assert torch.equal(di.materialize(), vi)
     assert torch.equal(d.materialize(), vol)
     vol.mul_(3.0)                                                        # after the evaluation the result is its own tensor
     assert torch.equal(d.materialize(), torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4))
