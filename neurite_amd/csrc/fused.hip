@@ -21,6 +21,7 @@
 
 #include "dice_reduce.h"
 #include "interpn_core.h"
+#include "fused_wc.h"
 
 namespace {
 
@@ -83,6 +84,9 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
     // sums as float2 halves: the blend and the Dice accumulation run on v_pk_mul_f32 / v_pk_add_f32 (two IEEE fp32 operations
     // per issue slot, no fusion -> bit-identical to the scalar sequence); the kernel is bound by VALU issue, not by memory
     nrt_f2 stp_l = {0, 0}, stp_h = {0, 0}, stt_l = {0, 0}, stt_h = {0, 0}, spp_l = {0, 0}, spp_h = {0, 0};
+#if NRT_FUSED_EXP == 20 || NRT_FUSED_EXP == 21
+    __shared__ nrt_f4 wcache[4][64][8];        // probe: 64 rows of 128 bytes per wave
+#endif
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
 
     for (unsigned j = jb; j < per; j += nb) {
@@ -192,6 +196,14 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             for (int corner = 0; corner < NLD; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
 #pragma unroll
             for (int corner = NLD; corner < 8; ++corner) R[corner] = R[corner % NLD];
+#elif NRT_FUSED_EXP == 20 || NRT_FUSED_EXP == 21
+            // PROBE: the data path of a wave-private LDS row cache without its management -- 2 (20) / 4 (21) rows per voxel come through
+            // L1, finish() stores them into the wave's LDS rows and reads all 8 corners back from pseudo-random rows of it
+            constexpr int NNEW = NRT_FUSED_EXP == 20 ? 2 : 4;
+#pragma unroll
+            for (int i = 0; i < NNEW; ++i) R[i] = *(const Row *)(volb + (size_t)off[(i * 7) & 7]);
+#pragma unroll
+            for (int corner = NNEW; corner < 8; ++corner) R[corner] = R[0];
 #elif NRT_FUSED_EXP == 11 || NRT_FUSED_EXP == 12 || NRT_FUSED_EXP == 13
             // PROBES: all 8 loads issued, but they address 1 (11) / 2 (12: the z pair) / 4 (13: the x0 plane) distinct rows --
             // L1 accesses without the misses.  a.fill_i is 0 at run time; it keeps the compiler from merging the loads.
@@ -217,6 +229,16 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             nrt_f4 R[8];
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) R[corner] = RowT<ST>::widen(Rraw[corner]);
+#if NRT_FUSED_EXP == 20 || NRT_FUSED_EXP == 21
+            {
+                constexpr int NNEW = NRT_FUSED_EXP == 20 ? 2 : 4;
+                nrt_f4 (*wc)[8] = wcache[threadIdx.x >> 6];
+#pragma unroll
+                for (int i = 0; i < NNEW; ++i) wc[(Q * 13u + (unsigned)i * 21u) & 63u][lg] = R[i];
+#pragma unroll
+                for (int corner = 0; corner < 8; ++corner) R[corner] = wc[(Q * 13u + (unsigned)corner * 7u) & 63u][lg];
+            }
+#endif
             const nrt_f4 T = RowT<ST>::widen(Traw);
             FM m;
             m.w0x = W0x; m.w0y = W0y; m.w0z = W0z; m.q = Q; m.valid = VALID; m.oob = OOB;
@@ -248,11 +270,13 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
                 stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
                 stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
                 spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
+#if NRT_FUSED_EXP != 30              // PROBE 30: no range tracking (what 16-24 VALU instructions per pass are worth)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     mnt = fminf(mnt, T[c]); mxt = fmaxf(mxt, T[c]);
                     mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
                 }
+#endif
             }
         };
 
@@ -355,9 +379,27 @@ void fused_geom(const int *out_shape, int G, int batch, int tune, TileGeom &tg, 
     if (((t >> 14) & 1) && !tg.plane_major && out_shape[0] > 0) nblocks = xmarch_setup(out_shape, batch, t, tg);
 }
 
+// tune bit 29: take the wave-cache kernel (fused_wc.h) where it applies; bit 30: keep the register kernel; neither: the default below
+// (environment variable NRT_FUSED_WC = 0 / 1 overrides it)
+constexpr int FUSED_TUNE_WC = 1 << 29, FUSED_TUNE_NO_WC = 1 << 30;
+#ifndef NRT_FUSED_WC_DEFAULT
+#define NRT_FUSED_WC_DEFAULT 0
+#endif
+inline bool fused_wc_enabled() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("NRT_FUSED_WC"); on = e ? (atoi(e) != 0) : NRT_FUSED_WC_DEFAULT; }
+    return on != 0;
+}
+
 template <int G, typename ST>
 void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store,
-                  const void *fixed, float *fpart, float *mpart, hipStream_t st) {
+                  const void *fixed, float *fpart, float *mpart, hipStream_t st, bool use_wc, bool want_minmax) {
+    if constexpr (G == 8 && std::is_same<ST, float>::value) {
+        if (use_wc && wc_applies(tg, G, a)) {
+            (void)launch_wc(a, tg, nblocks, batch, mode, store, want_minmax, (const float *)fixed, fpart, mpart, st);
+            return;
+        }
+    }
     dim3 grid(nblocks, batch), blk(256);
     // experiment knob: NRT_FUSED_LDS_KB pads every block with unused dynamic LDS to cap the blocks per CU
     // NRT_FUSED_LDS_KB (experiments): unused dynamic LDS per block, caps the blocks per CU.  The x-march default is
@@ -407,7 +449,7 @@ extern "C" size_t nrt_warp_dice_workspace_bytes(const int *out_shape, int nlabel
     if (!out_shape || nlabels < 4 || nlabels % 4 || batch < 1) return 0;
     TileGeom tg;
     unsigned nblocks;
-    fused_geom(out_shape, nlabels / 4, batch, tune, tg, nblocks);
+    fused_geom(out_shape, nlabels / 4, batch, tune > 0 ? (tune & ~(FUSED_TUNE_NO_WC | FUSED_TUNE_WC)) : tune, tg, nblocks);
     return fused_ws_bytes(nblocks, nlabels, batch);
 }
 
@@ -440,6 +482,8 @@ int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed,
     if (a.nout == 0) return NRT_ERR_INVALID_ARG;
     TileGeom tg;
     unsigned nblocks;
+    const bool use_wc = !(tune > 0 && (tune & FUSED_TUNE_NO_WC)) && (fused_wc_enabled() || (tune > 0 && (tune & FUSED_TUNE_WC)));
+    if (tune > 0) tune &= ~(FUSED_TUNE_NO_WC | FUSED_TUNE_WC);
     fused_geom(out_shape, G, batch, tune, tg, nblocks);
     if (!workspace || workspace_bytes < fused_ws_bytes(nblocks, nlabels, batch)) return NRT_ERR_WORKSPACE;
     // carve: fpart, mpart, gsum, gmm
@@ -455,13 +499,13 @@ int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed,
     hipStream_t st = nrt_stream(stream);
     const bool store = warped != nullptr;
     switch (G) {
-        case 1: launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 2: launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 4: launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 8: launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 16: launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        case 32: launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
-        default: launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st); break;
+        case 1: launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
+        case 2: launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
+        case 4: launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
+        case 8: launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
+        case 16: launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
+        case 32: launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
+        default: launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
     }
     NRT_CHECK_LAUNCH();
     return dice_finalize_soft(w, nblocks, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);

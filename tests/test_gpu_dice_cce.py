@@ -397,6 +397,46 @@ def test_fused_x_march_schedule_ragged(dev):
         assert bits_equal(N(d2), N(d)), tune
 
 
+def test_fused_wave_cache_kernel(dev):
+    """The wave-private LDS row cache form of the fused kernel (csrc/fused_wc.h: default for 32 float32 labels on the x-march schedule)
+    against the oracle and against the register kernel (tune bit 30) on coherent fields (cache hits across passes), moderately rough
+    ones (orphans in the overflow rows), incoherent ones (more orphans than the overflow holds: register path per pass), locations
+    outside the volume, fill values, shapes that are not multiples of the patch, x segments."""
+    rng = np.random.default_rng(404)
+    NO_WC, WC = 1 << 30, 1 << 29
+    xm = 3 | (2 << 4) | (3 << 8) | (1 << 14) | WC
+    for (B, S, So) in ((2, (21, 18, 29), (21, 18, 29)), (1, (40, 33, 47), (37, 30, 41)), (3, (16, 8, 8), (16, 5, 9))):
+        mov = rng.random((B,) + S + (32,)).astype(F)             # (positive maps: no cancellation in the Dice sums)
+        fix = rng.random((B,) + So + (32,)).astype(F)
+        fields = {
+            'zero': np.zeros((B,) + So + (3,), F),
+            'smooth': np.stack([N(synth.smooth_displacement(11 + b, max(So), sigma=2.0, coarse=4, device='cpu'))[:So[0], :So[1], :So[2]]
+                                for b in range(B)]),
+            'steep': np.stack([N(synth.smooth_displacement(31 + b, max(So), sigma=4.0, coarse=max(2, max(So) // 4), device='cpu'))
+                               [:So[0], :So[1], :So[2]] for b in range(B)]),
+            'iid0.7': rng.normal(0, 0.7, (B,) + So + (3,)).astype(F),
+            'iid3': rng.normal(0, 3.0, (B,) + So + (3,)).astype(F),
+            'incoherent': rng.uniform(-max(S), max(S), (B,) + So + (3,)).astype(F),
+        }
+        for name, trf in fields.items():
+            trf = np.ascontiguousarray(trf, F)
+            for fill in (None, 0.25):
+                w_ref = npo.spatial_transformer(mov, trf, fill_value=fill)
+                d_ref = npo.dice(fix, w_ref, check_input_limits=False)
+                for tune in (xm, xm | (3 << 16) | (1 << 24) | (1 << 27)):
+                    d, w, s = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, return_warped=True,
+                                                 return_sums=True, _tune=tune)
+                    assert bits_equal(N(w), w_ref), (S, name, fill, tune)
+                    np.testing.assert_allclose(N(d), d_ref, rtol=RTOL, err_msg=str((S, name, fill, tune)))
+                    d2, s2 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, return_sums=True, _tune=tune)
+                    assert bits_equal(N(d2), N(d)) and bits_equal(N(s2), N(s)), (S, name, fill, tune)
+                    # the register kernel on the same schedule: same warped bits, same sums up to the order of the additions
+                    d0, w0, s0 = ne.fused.warp_dice(G(mov, dev), G(trf, dev), G(fix, dev), fill_value=fill, return_warped=True,
+                                                    return_sums=True, _tune=(tune & ~WC) | NO_WC)
+                    assert bits_equal(N(w0), N(w)), (S, name, fill, tune)
+                    np.testing.assert_allclose(N(s0), N(s), rtol=2e-5, atol=1e-4)
+
+
 def test_mean_squared_error_prob(dev):
     """metrics.MeanSquaredErrorProb (neurite/tf/metrics.py:653-692): Keras MSE with label weights as per-element sample weights;
     value and gradients against float64 NumPy / torch"""
