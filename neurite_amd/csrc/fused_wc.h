@@ -50,8 +50,15 @@ constexpr unsigned WC_BLOCK_BYTES = 4 * WC_WAVE_BYTES;          // 80832: two bl
 static_assert(WC_LISTR_OFF % 16 == 0 && WC_LISTD_OFF % 16 == 0 && WC_BC_OFF % 16 == 0 && WC_WAVE_BYTES % 16 == 0, "LDS layout");
 static_assert(2 * WC_BLOCK_BYTES <= 160 * 1024, "two blocks per CU");
 
+#ifndef NRT_FUSED_WCLOADS
+#define NRT_FUSED_WCLOADS 0
+#endif
+#define WC_FIXED_LOADS NRT_FUSED_WCLOADS
+#ifndef NRT_FUSED_WCSYNC
+#define NRT_FUSED_WCSYNC 0
+#endif
 #ifndef NRT_WC_SYNC
-#define NRT_WC_SYNC 8          // passes between block barriers (the four waves' rows meet in L1 while they are in step); 0 = none
+#define NRT_WC_SYNC NRT_FUSED_WCSYNC          // passes between block barriers; 0 = none (measured: 1.093 none, 1.15 / 1.12 / 1.10 for 2 / 8 / 32)
 #endif
 
 // LDS pointers carry their address space explicitly: a volatile access through a generic pointer compiles to flat_load / flat_store
@@ -239,8 +246,14 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
             s.fd_lo = (unsigned)dd; s.fd_hi = (unsigned)(dd >> 32);
 #pragma unroll
             for (int c = 0; c < 4; ++c) { s.sl[c] = (unsigned)sa[c]; s.sl[4 + c] = (unsigned)sb[c]; }
+            // The first WC_FIXED_LOADS row loads are issued whatever n is (entries past n address bytes past the volume: no memory
+            // access): the compiler's vmcnt bookkeeping takes the path with the FEWEST loads as what may be in flight, and with every
+            // load under a condition that path has none -- it then waited for all but the last two operations at every use, i.e. for
+            // the other state's pass as well (v3: 1.37 ms).
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < WC_FIXED_LOADS; ++i) s.F[i] = fetch_row((unsigned)(i < 4 ? ra[i & 3] : rb[i & 3]));
+#pragma unroll
+            for (int i = WC_FIXED_LOADS; i < 8; ++i) {
                 if (8 * i < s.n) s.F[i] = fetch_row((unsigned)(i < 4 ? ra[i & 3] : rb[i & 3]));      // wave-uniform condition
             }
         }

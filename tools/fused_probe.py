@@ -21,6 +21,7 @@ from neurite_amd import _lib, synth        # noqa: E402
 LAB = os.path.join(ROOT, 'tools', 'lab')
 VARIANTS = os.environ.get('FUSED_VARIANTS', 'EXP=0').split()
 batch = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 4
+TUNE = int(os.environ.get('PROBE_TUNE', '0'))          # e.g. 1 << 29: the wave-cache kernel
 size = int(sys.argv[sys.argv.index('--size') + 1]) if '--size' in sys.argv else 160
 dev = torch.device('cuda:0')
 mov, fix, trf = synth.cfg2_batch(batch, size, 32, device=dev)
@@ -52,13 +53,13 @@ for rep in range(2):
         for name in ('nrt_warp_dice_workspace_bytes', 'nrt_warp_dice_soft_f32'):
             res, args = _lib._SIGNATURES[name]
             getattr(h, name).restype, getattr(h, name).argtypes = res, args
-        nws = h.nrt_warp_dice_workspace_bytes(S, 32, batch, 0)
+        nws = h.nrt_warp_dice_workspace_bytes(S, 32, batch, TUNE)
         ws = torch.empty(int(nws), dtype=torch.uint8, device=dev)
         row = {'variant': k, 'batch': batch, 'rep': rep}
         for fname, f in fields.items():
             def run():
                 rc = h.nrt_warp_dice_soft_f32(_lib.ptr(mov), _lib.ptr(f), _lib.ptr(fix), None, S, S, 32, batch, f[0].numel(), 1, 0, 0.0, 0.0,
-                                              _lib.ptr(sums), _lib.ptr(dice), None, 0, _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+                                              _lib.ptr(sums), _lib.ptr(dice), None, TUNE, _lib.ptr(ws), nws, _lib.stream_ptr(dev))
                 assert rc == 0, rc
             row['ms_' + fname] = round(timeit(run), 4)
         print(json.dumps(row), flush=True)
