@@ -19,8 +19,12 @@ Workload: BASELINE config 2 (SpatialTransformer + Dice, 160^3 x 32 one-hot, fp32
 and N=8 is exactly config 4.  1 voxel = 1 spatial output location.
 
     python bench.py                       # 1 GPU
+    python bench.py --gpus N              # N GPUs of this node: re-launches itself under torch.distributed.run, one rank per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W            # the same, launched by the driver
+    python bench.py --gpus N --global-batch 32    # BASELINE config 4 as SURVEY 8(d) defines it: B = 32 fixed, 32 / N volumes per GPU,
+                                                  # "scaling": "strong" (the default line is weak: 4 volumes per GPU whatever N is, and
+                                                  # carries the strong figure of the same run as `cfg4_strong`)
 
 Rank 0 prints ONE JSON line on stdout.  `roofline` is the dominant kernel: achieved = algorithmic bytes per
 launch / its average duration measured with HIP events inside the timed region.  Algorithmic bytes per
@@ -60,6 +64,13 @@ def parse():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch-per-gpu', type=int, default=4)
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong scaling (BASELINE config 4: 32): the global batch is fixed and split over the ranks; 0 = weak scaling '
+                         'with --batch-per-gpu volumes on every GPU')
+    ap.add_argument('--no-strong', action='store_true', help='skip the cfg4_strong measurement of the default (weak) run')
+    ap.add_argument('--stub-step', action='store_true',
+                    help='CPU-only self-test of the launch / timing / JSON plumbing: gloo ranks, a stub step instead of the kernels '
+                         '(tests/test_distributed_cpu.py); never a measurement')
     ap.add_argument('--size', type=int, default=160)
     ap.add_argument('--labels', type=int, default=32)
     ap.add_argument('--rough', action='store_true', help='worst-case incoherent field U(-80,80)')
@@ -584,11 +595,70 @@ def timed(step, steps, warmup, dist=None, dev=None):
             'mean': None if m is None else float(m)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run this file under torch.distributed.run, one rank per GPU, and hand rank 0's
+    JSON line on (the launcher's and RCCL's chatter stays on stderr).  The reference's only multi-device code is
+    neurite/tf/utils/model.py:298-321 (Keras multi_gpu_model); here every rank is its own process with its own GPU."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, NRT_BENCH_CHILD='1', NRT_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('bench.py: launching %d ranks: %s' % (n, ' '.join(cmd)))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in p.stdout.decode(errors='replace').splitlines() if ln.strip().startswith('{')]
+    if p.returncode != 0 or not lines:
+        raise SystemExit('bench.py: the %d-rank launch failed (exit code %d, %d JSON lines)' % (n, p.returncode, len(lines)))
+    print(lines[-1], flush=True)
+
+
+def stub_main(args, rank, world):
+    """--stub-step: the launch, the timed region and the one-JSON-line discipline on CPU ranks (gloo), with a stub in place of the
+    kernels.  What it prints is shaped like the real line and says "data": "stub"."""
+    import torch.distributed as dist
+    from neurite_amd import distributed as nd
+    group = None
+    if world > 1 or os.environ.get('NRT_FORCE_DIST'):
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        group = dist
+    B = args.global_batch // world if args.global_batch else args.batch_per_gpu
+    if args.global_batch and args.global_batch % world:
+        raise SystemExit('--global-batch %d is not a multiple of the %d ranks' % (args.global_batch, world))
+
+    def step(events):
+        time.sleep(0.002 * B)
+        return nd.all_reduce_mean_dice(torch.full((B, 8), float(rank + 1)), async_op=True)
+    r = timed(step, args.steps, args.warmup, group, None)
+    if rank == 0:
+        V = args.size ** 3
+        print(json.dumps({'metric': 'Mvoxels/sec interpn+Dice on 160^3 x 32-label', 'value': round(world * B * V * args.steps / r['elapsed'] / 1e6, 2),
+                          'unit': 'Mvoxels/s', 'n_gpus': world, 'rccl_ranks': r['ranks'], 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(r['elapsed'] / args.steps * 1e3, 4), 'higher_is_better': True,
+                          'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'stub',
+                          'config': {'workload': 'stub step (no kernels): plumbing self-test', 'volumes_per_gpu': B, 'global_batch': B * world,
+                                     'mean_dice': r['mean']}}), flush=True)
+    if group is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if ('WORLD_SIZE' not in os.environ and not os.environ.get('NRT_BENCH_CHILD')
+            and (args.gpus > 1 or os.environ.get('NRT_FORCE_SPAWN'))):
+        return self_launch(args.gpus)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.stub_step:
+        return stub_main(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (MI355X); there is no CPU path.')
     dev = torch.device('cuda', local_rank)
@@ -610,7 +680,12 @@ def main():
     from neurite_amd import distributed as nd
     from neurite_amd import synth
 
-    B = args.batch_per_gpu
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit('--global-batch %d is not a multiple of the %d ranks' % (args.global_batch, world))
+        B = args.global_batch // world                 # strong scaling: BASELINE config 4, the global batch is fixed
+    else:
+        B = args.batch_per_gpu                         # weak scaling: every GPU holds the same number of volumes
     S, L = args.size, args.labels
     V = S ** 3
     # rank r owns global batch entries [r*B, (r+1)*B): seeds follow the global entry index
@@ -768,6 +843,23 @@ def main():
         except Exception as e:   # noqa
             log('default-argument run failed: %s' % e)
             r_def = None
+    # BASELINE config 4 as SURVEY 8(d) words it -- B = 32 FIXED, 32 / N volumes per rank -- measured in the same run next to the weak
+    # line: the 8-vs-1 ratio of these values is the strong-scaling figure (32 volumes on one GPU: 35 GB of its 288)
+    r_strong, Bs = None, 0
+    if not args.global_batch and not args.no_strong and not args.unfused and not args.rough and 32 % world == 0 and S == 160:
+        try:
+            Bs = 32 // world
+            if Bs == B:
+                smov, sfix, strf = mov, fix, trf
+            else:
+                smov, sfix, strf = synth.cfg2_batch(Bs, S, L, device=dev, seed0=100 + 3 * rank * Bs)
+            s_refsig = make_steps(smov, sfix, strf)[2]
+            r_strong = timed(s_refsig, o_steps, 2, dist, dev)
+            del smov, sfix, strf, s_refsig
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa
+            log('cfg4_strong run failed on rank %d: %s' % (rank, e))
+            r_strong = None
     unet_multi = None
     if dist is not None and not args.no_unet:
         # "3D UNet fwd ms at 1/2/4/8 GPU": every rank runs the config-3 forward on its own volume (data parallel inference);
@@ -846,7 +938,7 @@ def main():
         'ms_per_step': round(elapsed / args.steps * 1e3, 4),
         'ms_per_step_per_rank': [round(t / args.steps * 1e3, 4) for t in r_main['per_rank_s']],
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': 'strong' if args.global_batch else 'weak',
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
@@ -861,6 +953,7 @@ def main():
             'pipeline': ('reference_api' if not args.direct else 'fused_direct') if fused else 'unfused',
             'step_launch': 'one hipGraph replay per step (--graph)' if args.graph else 'direct kernel launches',
             'parallelism': 'dp%d (batch-sharded, one RCCL all-reduce of 2 floats per step)' % world,
+            'scaling_mode': 'strong: --global-batch %d split over the ranks' % args.global_batch if args.global_batch else 'weak: --batch-per-gpu %d on every rank' % B,
             'mean_dice': round(float(m), 6),
         },
         'roofline': {
@@ -897,6 +990,14 @@ def main():
         'fused_pipeline': fusedb,
         'other_pipeline': dropin if fused else fusedb,
     }
+    if r_strong is not None:
+        out['cfg4_strong'] = {
+            'what': 'BASELINE config 4 with the global batch FIXED at 32 (SURVEY 8d): %d volumes on each of %d GPUs, the reference-signature '
+                    'pipeline, one all-reduce per step; %d steps.  value(N) / value(1) is the strong-scaling ratio' % (Bs, world, o_steps),
+            'scaling': 'strong', 'global_batch': 32, 'volumes_per_gpu': Bs, 'n_gpus': world, 'rccl_ranks': r_strong['ranks'],
+            'value': round(32 * V * o_steps / r_strong['elapsed'] / 1e6, 2), 'unit': 'Mvoxels/s',
+            'ms_per_step': round(r_strong['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(r_strong['k0_ms'], 4),
+            'mean_dice': round(r_strong['mean'], 6)}
     if r_b1 is not None:
         rf, ru = r_b1
         out['config2_batch1'] = {

@@ -150,3 +150,27 @@ def test_bench_timed_loop_world4():
     import bench
     r = bench.timed(lambda ev: None, 3, 1)
     assert r['ranks'] == 1 and r['mean'] is None and len(r['per_rank_s']) == 1
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_its_ranks_cpu_stub():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-runs itself under torch.distributed.run (one process per rank),
+    and exactly ONE JSON line comes out of the parent.  --stub-step swaps the kernels for a stub so that the launch, the timed region,
+    the collective and the stdout discipline run on CPU ranks (gloo).  Weak (default) and strong (--global-batch) modes."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'NRT_BENCH_CHILD')}
+    for extra, scaling, per_gpu in (([], 'weak', 4), (['--global-batch', '6'], 'strong', 3)):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--stub-step'] + extra,
+                           cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280, text=True)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, lines
+        j = json.loads(lines[0])
+        assert j['n_gpus'] == 2 and j['rccl_ranks'] == 2 and j['steps'] == 3 and j['warmup'] == 1
+        assert j['scaling'] == scaling and j['config']['volumes_per_gpu'] == per_gpu and j['config']['global_batch'] == 2 * per_gpu
+        assert abs(j['config']['mean_dice'] - 1.5) < 1e-6 and j['data'] == 'stub'
+    # a global batch that the ranks do not divide is an error, not a silent truncation
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--stub-step',
+                        '--global-batch', '5'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280, text=True)
+    assert p.returncode != 0 and not p.stdout.strip()

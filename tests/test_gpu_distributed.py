@@ -40,3 +40,21 @@ def test_bench_under_torchrun_with_rccl_world_size_one(dev):
     assert p1.returncode == 0, p1.stderr[-3000:]
     j1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.strip()][-1])
     assert abs(j['config']['mean_dice'] - j1['config']['mean_dice']) <= 2e-6
+
+
+def test_bench_self_spawn_forced_on_one_gpu(dev):
+    """`python bench.py --gpus 1` with NRT_FORCE_SPAWN=1 takes the path `--gpus N > 1` takes without a launcher: bench.py starts its own
+    ranks under torch.distributed.run, the rank builds an RCCL group, ONE JSON line comes back through the parent; --global-batch makes
+    the line a strong-scaling one."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'NRT_BENCH_CHILD')}
+    env.update(NRT_FORCE_SPAWN='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--size', '64', '--global-batch', '2',
+           '--no-cpu-baseline', '--no-unet', '--no-batch1']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, 'exactly one JSON line on stdout, got %r' % (lines,)
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 1 and j['rccl_ranks'] == 1 and j['steps'] == 3
+    assert j['scaling'] == 'strong' and j['config']['volumes_per_gpu'] == 2 and j['config']['global_batch'] == 2 and j['value'] > 0
+    assert 'bench.py: launching 1 ranks' in p.stderr
