@@ -374,6 +374,45 @@ def unet_fwd_ms(dev, size=160, labels=32, reps=20, warmup=5):
     return float(np.median(times))
 
 
+def conv_layer_error(m, src, lo, up, out, nsamp=2048):
+    """Element-wise error of one Conv3D layer of the timed network on `nsamp` sampled output voxels (all output channels): the
+    layer's own input tensors, gathered and contracted in float64 with torch on the device -- a plain PyTorch reference of the same op,
+    not the oracle.  Reported as tests/test_gpu_unet.py states the tolerance: `max_rel_err` over the well-conditioned outputs
+    (sum of absolute terms <= 25 |result|, in the identity range of the activation) and the largest error of ANY sampled output in
+    units of 2^-24 of the sum of its absolute terms (a float32 dot product: a few units whatever its length)."""
+    import torch.nn.functional as TF
+    from neurite_amd import models as nm
+    g = torch.Generator(device='cpu')
+    g.manual_seed(11)
+    xin = src if lo is None else nm._upsample_concat(src, lo, tuple(up))
+    X, Y, Z, C = xin.shape[1:]
+    k = m.ksize3
+    pb = [((kk - 1) * m.dilation) // 2 for kk in k]
+    pe = [(kk - 1) * m.dilation - b0 for kk, b0 in zip(k, pb)]
+    xp = TF.pad(xin[0], (0, 0, pb[2], pe[2], pb[1], pe[1], pb[0], pe[0]))
+    ix = torch.randint(0, X, (nsamp,), generator=g).to(xin.device)
+    iy = torch.randint(0, Y, (nsamp,), generator=g).to(xin.device)
+    iz = torch.randint(0, Z, (nsamp,), generator=g).to(xin.device)
+    taps = []
+    for dx in range(k[0]):
+        for dy in range(k[1]):
+            for dz in range(k[2]):
+                taps.append(xp[ix + dx * m.dilation, iy + dy * m.dilation, iz + dz * m.dilation, :])
+    patches = torch.stack(taps, 1).reshape(nsamp, -1).double()
+    w = m.kernel.detach().reshape(-1, m.cout).double()
+    b = m.bias.detach().double()
+    pre = patches @ w + b
+    absref = patches.abs() @ w.abs() + b.abs()
+    act = m.act
+    want = torch.where(pre > 0, pre, torch.exp(pre) - 1) if act == 1 else (pre.clamp_min(0) if act == 2 else pre)
+    got = out[0, ix, iy, iz, :].double()
+    err = (got - want).abs()
+    well = (absref <= 25.0 * pre.abs()) & ((pre > 0) | (act == 0))
+    rel = float((err[well] / want[well].abs()).max()) if bool(well.any()) else None
+    return {'max_rel_err': rel, 'max_rel_err_over': 'sampled outputs with sum|terms| <= 25 |result|: %.3f of %d' % (float(well.double().mean()), err.numel()),
+            'max_err_in_2^-24_of_abs_sum': round(float((err / (absref * 2.0 ** -24)).max()), 2)}
+
+
 def unet_bench(dev, size=160, labels=32, nb_conv_per_level=1, reps=20, warmup=5):
     """BASELINE config 3: unet(16, (160,160,160,1), 3, 3, nb_labels, feat_mult=2) forward on one fp32 volume.
     Returns total forward ms (median) and per-conv-layer time / TFLOP/s / fraction of the fp32 MFMA peak."""
@@ -437,6 +476,10 @@ def unet_bench(dev, size=160, labels=32, nb_conv_per_level=1, reps=20, warmup=5)
         gfx = l.get('gflop_executed', l['gflop'])
         l['tflops'] = round(gfx / ms, 2)
         l['frac_of_fp32_mfma_peak'] = round(gfx / ms / MFMA_F32_PEAK_TFLOPS, 4)
+        try:
+            l.update(conv_layer_error(m, src, lo, op.get('up'), inter[l['name']]))
+        except Exception as e:   # noqa
+            l['max_rel_err'] = 'failed: %s' % e
     mf = [l for l in layers if l['cin'] >= 8]
     gf = sum(l.get('gflop_executed', l['gflop']) for l in mf)
     ms = sum(l['ms'] for l in mf)

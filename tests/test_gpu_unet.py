@@ -1,7 +1,20 @@
 """
 GPU parity tests of the unet layers (Conv3D on MFMA, pooling, fused upsample+concat, 1x1+softmax head) and of
-the assembled models.unet against the CPU oracle.  Tolerance (floating point, north_star): 1e-5 relative --
-written as allclose(rtol=1e-5, atol=1e-5 * max|ref|) per tensor (fp32 accumulation over K <= 2592 vs float64).
+the assembled models.unet against the CPU oracle.
+
+Tolerance of the convolutions (north_star: "conv floats within 1e-5 relative"), stated ELEMENT-WISE (`close_conv`):
+  * every output:  |gpu - ref| <= 8 * 2^-24 * S,  S = |b| + sum_i |x_i| |w_i|  (the float64 sum of the absolute terms of that output,
+    computed by the same oracle on |x|, |w|, |b|) -- the bound of a float32 dot product whatever its length K <= 2592; measured
+    2.1e-7 .. 3.4e-7 = 3.5 .. 5.7 units of 2^-24 for every kernel (MFMA implicit GEMM, persistent LDS-DMA schedule, folded decoder,
+    direct), profiles/r04_lab/conv_elementwise_error.jsonl;
+  * every output whose condition number S / |ref| is at most 25:  |gpu - ref| <= 1e-5 |ref|  (measured <= 4.1e-6 on the layers of
+    BASELINE config 3, bench.py `unet_fwd.layers[*].max_rel_err`).  With random-sign data S / |ref| is about sqrt(K), so this
+    covers 10 % .. 50 % of the outputs of these layers; for the rest the first bound IS the statement: relative error <=
+    8 * 2^-24 * (S / |ref|).
+  An element-wise 1e-5 for ALL outputs above 1e-3 max|ref| is not what float32 accumulation gives -- in ANY order, TensorFlow's
+  included: an output that is 1000 times smaller than its terms carries their rounding (measured 1.6e-4 .. 3.9e-4 there, the same
+  for the direct kernel as for the MFMA ones).
+Whole networks (errors of one layer feed the next) keep the per-tensor form allclose(rtol=1e-5, atol=1e-5 * max|ref|) (`close`).
 """
 
 import numpy as np
@@ -37,6 +50,34 @@ def close(got, ref, tol=1e-5):
     np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * max(1e-30, np.abs(ref).max()))
 
 
+def close_conv(got, ref, absref, act=None, rel=1e-5, cond=25.0, ulps=8.0):
+    """element-wise criterion of the module docstring.  ref / absref: float64 pre-activation reference and the sum of absolute
+    terms; act: the layer's activation (slope <= 1: the bound on the pre-activation carries over; elu adds the 2e-6 of the
+    hardware exponential the epilogue uses)"""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    absref = np.asarray(absref, np.float64)
+    want = uo.elu(ref) if act == 'elu' else (np.maximum(ref, 0) if act == 'relu' else ref)
+    err = np.abs(got - want)
+    bound = ulps * 2.0 ** -24 * absref + (3e-6 if act == 'elu' else 0.0) + 1e-30
+    worst = float((err / bound).max())
+    assert worst <= 1.0, 'error %.2f x the float32 dot-product bound (%g units of 2^-24 of the absolute sum)' % (worst, ulps)
+    if act is None:
+        well = absref <= cond * np.abs(ref)
+        assert well.any()
+        r = float((err[well] / np.abs(ref[well])).max())
+        assert r <= rel, 'relative error %.3g on a well-conditioned output' % r
+        return r
+    return None
+
+
+def conv_refs(x, w, b, dilation=1):
+    """float64 reference of one batch entry and the sum of the absolute terms of every output"""
+    ref = co.conv3d_same(x, w, b, dilation=dilation, elu=False).astype(np.float64)
+    absref = co.conv3d_same(np.abs(x), np.abs(w), np.abs(b), dilation=dilation, elu=False).astype(np.float64)
+    return ref, absref
+
+
 def set_weights(conv, rng, scale=None):
     k = conv.kernel.shape
     fan = int(np.prod(k[:-1]))
@@ -66,9 +107,8 @@ def test_conv3d_mfma_vs_oracle(dev, cin, cout, shape, k, dil, act):
         y = N(conv(G(x, dev), variant=variant))
         for bi in range(2):
             if k == (3, 3, 3) or k == (1, 1, 1) or k == (1, 3, 3):
-                ref = co.conv3d_same(x[bi], w, b, dilation=dil, elu=False).astype(np.float64)
-                ref = uo.elu(ref) if act == 'elu' else (np.maximum(ref, 0) if act == 'relu' else ref)
-                close(y[bi], ref)
+                ref, absref = conv_refs(x[bi], w, b, dil)
+                close_conv(y[bi], ref, absref, act)
 
 
 @pytest.mark.parametrize('cin,cout,shape,act', [
@@ -87,9 +127,8 @@ def test_conv3d_persistent_schedule(dev, cin, cout, shape, act):
     y5 = N(conv(G(x, dev), variant=5))
     y2 = N(conv(G(x, dev), variant=2))
     for bi in range(3):
-        ref = co.conv3d_same(x[bi], w, b, dilation=1, elu=False).astype(np.float64)
-        ref = uo.elu(ref) if act == 'elu' else (np.maximum(ref, 0) if act == 'relu' else ref)
-        close(y5[bi], ref)
+        ref, absref = conv_refs(x[bi], w, b)
+        close_conv(y5[bi], ref, absref, act)
     np.testing.assert_allclose(y5, y2, rtol=1e-6, atol=1e-6 * np.abs(y2).max())
 
 
@@ -131,8 +170,9 @@ def test_conv3d_folded_decoder_kernel(dev, c0, c1, cout, S, act):
     y = N(conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2), variant=4))
     y27 = N(conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2), variant=2))
     for bi in range(2):
-        ref = uo.conv(cat[bi], w, b, 'elu' if act == 'elu' else None)
-        close(y[bi], np.maximum(ref, 0) if act == 'relu' else ref)
+        ref, absref = conv_refs(cat[bi], w, b)
+        close_conv(y[bi], ref, absref, act)              # the folded taps are pre-summed weights: same bound, other summation order
+        close_conv(y27[bi], ref, absref, act)
     np.testing.assert_allclose(y, y27, rtol=1e-5, atol=1e-5 * np.abs(y27).max())
     # auto picks the folded kernel for these shapes: identical bits
     assert np.array_equal(N(conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2))), y)
@@ -168,9 +208,9 @@ def test_direct_conv_shapes(dev):
             for tpad in reversed(tot):                       # F.pad order: last dim first; TF pads floor before
                 padding += [tpad // 2, tpad - tpad // 2]
             xt = torch.nn.functional.pad(xt, padding)
-        ref = torch.nn.functional.conv3d(xt, wt, torch.from_numpy(b).double(), dilation=dil)
-        ref = torch.where(ref > 0, ref, torch.exp(ref) - 1)[0].permute(1, 2, 3, 0).numpy()
-        close(y, ref)
+        ref = torch.nn.functional.conv3d(xt, wt, torch.from_numpy(b).double(), dilation=dil)[0].permute(1, 2, 3, 0).numpy()
+        absref = torch.nn.functional.conv3d(xt.abs(), wt.abs(), torch.from_numpy(b).double().abs(), dilation=dil)[0].permute(1, 2, 3, 0).numpy()
+        close_conv(y, ref, absref, 'elu')
 
 
 def test_pool_softmax_head_elementwise(dev):
