@@ -638,6 +638,20 @@ def timed(step, steps, warmup, dist=None, dev=None):
             'mean': None if m is None else float(m)}
 
 
+def lookup_traffic(tfile, timed_kernel, B):
+    """HBM bytes per launch recorded for EXACTLY this kernel instantiation and batch (profiles/hbm_traffic.json, written by
+    tools/update_hbm_traffic.py from rocprofv3 --pmc passes), or (None, why).  Counters of another instantiation are never quoted."""
+    if not timed_kernel:
+        return None, 'not recorded for the unfused pipeline (see roofline_dropin; profiles/hbm_traffic.json lists interpn_zrun_c32)'
+    try:
+        ent = json.load(open(tfile)).get('kernels', {}).get(timed_kernel, {}).get('B%d' % B)
+    except Exception:   # noqa
+        ent = None
+    if ent is None:
+        return None, 'no counter pass recorded under profiles/hbm_traffic.json for the timed kernel %r at batch %d' % (timed_kernel, B)
+    return ent['bytes_per_launch'], 'static: profiles/hbm_traffic.json[%r][B%d] (%s)' % (timed_kernel, B, ent.get('source', 'rocprofv3 --pmc pass'))
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: run this file under torch.distributed.run, one rank per GPU, and hand rank 0's
     JSON line on (the launcher's and RCCL's chatter stays on stderr).  The reference's only multi-device code is
@@ -937,16 +951,14 @@ def main():
     achieved = alg_bytes / (kms * 1e-3) / 1e9
     # HBM-side bytes per launch are NOT measured in this process (PMC counters need a rocprofv3 pass of their own): the figure
     # is the FETCH_SIZE + WRITE_SIZE of the rocprofv3 --pmc pass recorded in profiles/hbm_traffic.json for this kernel and batch
-    traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            traffic = tj.get(('fused' if fused else 'interpn') + '_bytes_per_launch_B%d' % B)
-            if traffic is not None:
-                traffic_src = 'static: profiles/hbm_traffic.json (%s)' % tj.get('source', 'rocprofv3 --pmc pass')
-        except Exception:   # noqa
-            traffic = None
+    # ... and only for the kernel instantiation that was timed: the library names it (nrt_warp_dice_kernel_name), the file is keyed by
+    # the names rocprofv3 printed; another instantiation's counters are not quoted (traffic stays null and says why)
+    traffic, traffic_src, timed_kernel = None, None, None
+    if fused:
+        from neurite_amd import _lib
+        timed_kernel = _lib.lib().nrt_warp_dice_kernel_name(_lib.ints([S] * 3), _lib.ints([S] * 3), L, B, _lib.LOC_SHIFT, 0, 0, 0,
+                                                            int(args.tune)).decode()
+    traffic, traffic_src = lookup_traffic(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'), timed_kernel, B)
 
     # drop-in (reference-signature) pipeline figures, whichever form was the timed one
     d_elapsed, d_steps, d_k0, d_k1, d_m = (o_elapsed, o_steps, o_k0, o_k1, o_m) if fused else (elapsed, args.steps, k0_ms, k1_ms, m)
@@ -1008,6 +1020,7 @@ def main():
             'frac': round(achieved / HBM_PEAK_GBS, 4),
             'traffic': traffic,
             'traffic_source': traffic_src,
+            'timed_kernel': timed_kernel,
             'algorithmic_bytes_per_launch': alg_bytes,
             'avg_launch_ms': round(kms, 4),
             'avg_launch_ms_covers': ('HIP events around the gather launch and, for the fused form, the two launches of its Dice second '

@@ -218,6 +218,12 @@ int nrt_warp_dice_soft_bf16(const void *moving, const float *loc, const void *fi
                             int has_fill, float fill_value, float laplace_smoothing, float *sums, float *dice,
                             float *minmax, int tune, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Name of the kernel instantiation nrt_warp_dice_soft_f32 launches for these arguments, as a profiler prints it (e.g.
+ * "warp_dice_tile<8, 1, false, 3, float>"); "" for arguments the entry point rejects.  The returned buffer is thread-local.
+ * Measurement plumbing (bench.py joins its timing with the counter passes under profiles/ by this name); no reference counterpart. */
+const char *nrt_warp_dice_kernel_name(const int *out_shape, const int *vol_shape, int nlabels, int batch, int loc_mode, int has_fill,
+                                      int store, int want_minmax, int tune);
+
 /* ------------------------------------------------------------------------------------------
  * Label-weighted categorical cross-entropy
  * replaces: neurite/tf/metrics.py:640-650 + tf.keras.losses.CategoricalCrossentropy

@@ -50,6 +50,7 @@ _SIGNATURES = {
     'nrt_wcce_workspace_bytes': (_sz, [_ll, _i]),
     'nrt_warp_dice_workspace_bytes': (_sz, [_ip, _i, _i, _i]),
     'nrt_warp_dice_soft_f32': (_i, [_vp, _vp, _vp, _vp, _ip, _ip, _i, _i, _ll, _i, _i, _f, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    'nrt_warp_dice_kernel_name': (C.c_char_p, [_ip, _ip, _i, _i, _i, _i, _i, _i, _i]),
     'nrt_warp_dice_soft_bf16': (_i, [_vp, _vp, _vp, _ip, _ip, _i, _i, _ll, _i, _i, _f, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     'nrt_conv3d_packed_weight_floats': (_sz, [_ip, _i, _i]),
     'nrt_conv3d_pack_weights_f32': (_i, [_vp, _ip, _i, _i, _vp, _vp]),

@@ -15,6 +15,7 @@
 // Structure = interpn_tile (3-D output tiles, XCD-contiguous slabs, depth-2 software pipeline with
 // unconditional loads); the `fixed` row rides along as a ninth load of every pass.
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -511,6 +512,30 @@ int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed,
     return dice_finalize_soft(w, nblocks, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
 }
 }  // namespace
+
+// The kernel (template instantiation, spelled as rocprofv3 prints it without its namespace) that nrt_warp_dice_soft_f32 launches for
+// these arguments: bench.py joins its timing with the counter passes under profiles/ by this name and refuses to quote HBM traffic
+// that was measured on another instantiation.
+extern "C" const char *nrt_warp_dice_kernel_name(const int *out_shape, const int *vol_shape, int nlabels, int batch, int loc_mode,
+                                                 int has_fill, int store, int want_minmax, int tune) {
+    static thread_local char name[96];
+    name[0] = 0;
+    if (!out_shape || !vol_shape || nlabels < 4 || nlabels % 4 || batch < 1) return name;
+    const int G = nlabels / 4;
+    const bool use_wc = !(tune > 0 && (tune & FUSED_TUNE_NO_WC)) && (fused_wc_enabled() || (tune > 0 && (tune & FUSED_TUNE_WC)));
+    if (tune > 0) tune &= ~(FUSED_TUNE_NO_WC | FUSED_TUNE_WC);
+    TileGeom tg;
+    unsigned nblocks;
+    fused_geom(out_shape, G, batch, tune, tg, nblocks);
+    InterpArgs a;
+    for (int d = 0; d < 3; ++d) a.S[d] = vol_shape[d];
+    const char *tf[2] = {"false", "true"};
+    if (G == 8 && use_wc && wc_applies(tg, G, a))
+        snprintf(name, sizeof(name), "warp_dice_wc<%d, %s, %s, %s>", loc_mode, tf[store != 0], tf[want_minmax != 0], tf[has_fill != 0]);
+    else
+        snprintf(name, sizeof(name), "warp_dice_tile<%d, %d, %s, %d, float>", G, loc_mode, tf[store != 0], tg.x_march ? NRT_FUSED_MINW : 1);
+    return name;
+}
 
 extern "C" int nrt_warp_dice_soft_f32(const float *moving, const float *loc, const float *fixed, float *warped,
                                       const int *vol_shape, const int *out_shape, int nlabels, int batch,

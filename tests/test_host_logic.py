@@ -7,6 +7,7 @@ No kernel is launched here.
 
 import ctypes
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -781,3 +782,31 @@ def test_folded_decoder_backward_matrices_cpu():
             xs = lop[0, e[0]:e[0] + X1, e[1]:e[1] + Y1, e[2]:e[2] + Z1]
             dwf[P, k] = torch.einsum('xyzi,xyzo->io', xs, s2d[0, :, :, :, P])
     assert float((nm._unfold_wgrad(dwf) - W.grad).abs().max()) < 1e-12
+
+
+def test_bench_quotes_traffic_only_for_the_timed_kernel(tmp_path):
+    """bench.py's roofline.traffic comes from a rocprofv3 --pmc pass recorded in profiles/hbm_traffic.json; it is keyed by the exact
+    kernel name (the library names the instantiation it launches) and the batch, and another instantiation's counters are refused
+    (the round-3 counters were taken on warp_dice_tile<8, 1, false, 4, float>, the timed kernel was <..., 3, float>)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    f = tmp_path / 't.json'
+    f.write_text(json.dumps({'kernels': {'warp_dice_tile<8, 1, false, 4, float>': {'B4': {'bytes_per_launch': 123, 'source': 'x'}}}}))
+    t, why = bench.lookup_traffic(str(f), 'warp_dice_tile<8, 1, false, 3, float>', 4)
+    assert t is None and "warp_dice_tile<8, 1, false, 3, float>" in why
+    t, why = bench.lookup_traffic(str(f), 'warp_dice_tile<8, 1, false, 4, float>', 4)
+    assert t == 123 and 'B4' in why
+    assert bench.lookup_traffic(str(f), 'warp_dice_tile<8, 1, false, 4, float>', 1)[0] is None          # another batch
+    assert bench.lookup_traffic(str(f), None, 4)[0] is None
+    # the library names what it launches (no GPU needed: geometry only)
+    lib = ne._lib.lib()
+    n160 = ne._lib.ints([160] * 3)
+    assert lib.nrt_warp_dice_kernel_name(n160, n160, 32, 4, 1, 0, 0, 0, 0) in (b'warp_dice_tile<8, 1, false, 3, float>',
+                                                                              b'warp_dice_wc<1, false, false, false>')
+    assert lib.nrt_warp_dice_kernel_name(n160, n160, 32, 4, 1, 0, 0, 0, 1 << 30) == b'warp_dice_tile<8, 1, false, 3, float>'
+    assert lib.nrt_warp_dice_kernel_name(n160, n160, 32, 4, 1, 0, 0, 0, 1 << 29) == b'warp_dice_wc<1, false, false, false>'
+    # the committed file itself has the keyed layout
+    tj = json.load(open(os.path.join(root, 'profiles', 'hbm_traffic.json')))
+    assert 'kernels' in tj and all('<' in k for k in tj['kernels'])
