@@ -93,8 +93,8 @@ int nrt_interpn_nearest_i32(const int32_t *vol, const float *loc, int32_t *out,
                             int loc_mode, int has_fill, int32_t fill_value, void *stream);
 
 /* interpn for every other dtype / rank the reference accepts (neurite/tf/utils/utils.py:106-127, 137-213 are dtype- and
- * rank-generic): float16, bfloat16 and float64 volumes in 1..6 dimensions, float32 and (nearest only) int32 volumes in
- * 4..6 dimensions.  `dtype` is an nrt_dtype value (below).  loc is cast to the volume dtype and the arithmetic runs in that
+ * rank-generic): float16, bfloat16 and float64 volumes in 1..8 dimensions, float32 and (nearest only) int32 volumes in
+ * 4..8 dimensions (TensorFlow itself stops at rank-8 tensors).  `dtype` is an nrt_dtype value (below).  loc is cast to the volume dtype and the arithmetic runs in that
  * dtype, one rounding per operation, as TensorFlow evaluates it.  loc: float32 [batch, out_shape, ndim] (float64 when
  * loc_is_f64, float64 volumes with NRT_LOC_ABSOLUTE only), NULL for NRT_LOC_LINSPACE.  vol / out are `dtype`. */
 int nrt_interpn_any(const void *vol, const void *loc, void *out, int dtype, int ndim, const int *vol_shape,

@@ -22,6 +22,7 @@
 
 #include "dice_reduce.h"
 #include "interpn_core.h"
+#include "wc.h"
 #include "fused_wc.h"
 
 namespace {
@@ -47,6 +48,15 @@ template <> struct RowT<unsigned short> {
     }
 };
 
+#ifdef NRT_FUSED_TRACE
+// lab builds (tools/fused_variants.py TRACE=1, tools/block_trace.py): every block records {start, end} of the 100 MHz wall clock, its
+// XCC id and its x range -- how the blocks of a launch really fill the chip
+__device__ unsigned long long *nrt_trace_buf = nullptr;
+extern "C" int nrt_debug_set_trace(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(nrt_trace_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
+
 template <int G, int MODE, bool STORE, int MINW, typename ST = float>
 __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGeom tg, const void *__restrict__ fixed,
                                                       float *__restrict__ fpart, float *__restrict__ mpart) {
@@ -60,16 +70,14 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
     unsigned per = tg.per2 * tg.nTz;                           // tiles per XCD
     unsigned nb = gridDim.x / NRT_NXCD;
     int b = blockIdx.y;
-    unsigned ucol = 0, useg = 0, prow = blockIdx.x;            // x-march: patch, segment, partial row inside the batch
+#ifdef NRT_FUSED_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
+    unsigned ucol = 0, prow = blockIdx.x;                      // x-march: patch, partial row inside the batch
+    XmWork xw = {};
     if (tg.x_march) {
-        // one tile per block: XCD k owns the contiguous range [k * perU, (k + 1) * perU) of (batch, segment, patch)
-        const unsigned per_batch = tg.ncol * tg.nseg, U = per_batch * tg.nbatch;
-        const unsigned perU = gridDim.x / NRT_NXCD;
-        const unsigned u = k * perU + jb;
-        if (jb >= perU || u >= U) return;
-        b = (int)(u / per_batch);
-        prow = u % per_batch;
-        useg = prow / tg.ncol; ucol = prow % tg.ncol;
+        if (!xmarch_work(tg, a.O[0], xw)) return;              // one column (or piece of one) per block
+        b = xw.b; prow = xw.prow; ucol = xw.ucol;
         per = jb + 1; nb = 1;                                  // the tile loop below runs exactly once
     }
 
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
         if (!tg.x_march && t2 >= tg.nT2) continue;
         int x0 = (int)(t2 / tg.nTy) << tg.ltx, y0 = (int)(t2 % tg.nTy) << tg.lty, z0 = (int)tzi * tg.tz;
         if (tg.x_march) {
-            x0 = (int)(useg * tg.seglen);
+            x0 = xw.x0;
             // patches are enumerated region by region (2^lry x 2^lrz patches, row-major inside and across regions) so
             // that the blocks resident on an XCD at one time cover a compact (y,z) window
             const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             y0 = (int)cy << tg.lty;
             z0 = (int)cz << tg.ltz;
             if (cy >= tg.nTy || cz >= tg.nTz) npass = 0;
-            const int xlen = min((int)tg.seglen, a.O[0] - x0);
+            const int xlen = xw.xlen;
             if (npass) npass = (xlen << (tg.lty + tg.ltz)) / NG;
             if (npass <= 0) continue;
         }
@@ -355,9 +363,28 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             m = (threadIdx.x & 1) ? fmaxf(m, red[w2][3 * L + threadIdx.x]) : fminf(m, red[w2][3 * L + threadIdx.x]);
         mpart[pbase * 4 + threadIdx.x] = m;
     }
+    if (tg.x_march) xmarch_zero_rows(tg, xw, 3 * L, fpart, mpart);
+#ifdef NRT_FUSED_TRACE
+    if (threadIdx.x == 0 && nrt_trace_buf) {
+        unsigned long long *t = nrt_trace_buf + 4ull * blockIdx.x;
+        t[0] = trace_t0; t[1] = wall_clock64();
+        t[2] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);      // HW_REG_XCC_ID
+        t[3] = ((unsigned long long)(unsigned)xw.x0 << 32) | (unsigned)xw.xlen;
+    }
+#endif
 }
 
 // the fused kernel writes one partial per block: size the workspace for its grid
+// NRT_FUSED_MIXED=0: equal pieces per column as before round 4 (experiments)
+inline bool fused_mixed_enabled() {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("NRT_FUSED_MIXED"); on = (e && atoi(e) == 0) ? 0 : 1; }
+    return on != 0;
+}
+inline unsigned fused_xmarch_grid(const TileGeom &tg, unsigned nblocks, int batch) {
+    return tg.het_cpx ? NRT_NXCD * (tg.het_full + (tg.het_cpx - tg.het_full) * tg.nseg) : nrt_xcd_grid(nblocks * (unsigned)batch);
+}
+
 size_t fused_ws_bytes(unsigned nblocks, int L, int batch) {
     const size_t rows = (size_t)batch * nblocks;
     const size_t grp = (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS);
@@ -377,7 +404,12 @@ void fused_geom(const int *out_shape, int G, int batch, int tune, TileGeom &tg, 
         t = xmarch_default_tune();
         tile_geometry(out_shape, G, t, t, tg, nblocks);
     }
-    if (((t >> 14) & 1) && !tg.plane_major && out_shape[0] > 0) nblocks = xmarch_setup(out_shape, batch, t, tg);
+    if (((t >> 14) & 1) && !tg.plane_major && out_shape[0] > 0) {
+        // segments left to us (bits 16-23 zero): whole columns + pieces for the last round; an explicit count: equal pieces
+        unsigned grid;
+        if (((t >> 16) & 0xff) == 0 && fused_mixed_enabled()) nblocks = xmarch_setup_mixed(out_shape, batch, t, tg, grid);
+        else nblocks = xmarch_setup(out_shape, batch, t, tg);
+    }
 }
 
 // tune bit 29: take the wave-cache kernel (fused_wc.h) where it applies; bit 30: keep the register kernel; neither: the default below
@@ -409,7 +441,7 @@ void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int
     if (lds_kb == -2) { const char *e = getenv("NRT_FUSED_LDS_KB"); lds_kb = e ? atoi(e) : -1; }
     const unsigned dyn = (unsigned)(lds_kb >= 0 ? lds_kb : (tg.x_march ? 75 : 0)) * 1024u;
     if (tg.x_march) {
-        grid = dim3(nrt_xcd_grid(nblocks * (unsigned)batch), 1);
+        grid = dim3(fused_xmarch_grid(tg, nblocks, batch), 1);
 #define NRT_FUSED_X(MODE)                                                                                           \
     if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, NRT_FUSED_MINW, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
     else {                                                                                                          \

@@ -86,26 +86,23 @@ __device__ __forceinline__ void wc_corner(float pv, float mx, int &i0, int &i1, 
     w0 = nrt_sub(l1, cl);
 }
 
-template <int MODE, bool STORE, bool MM, bool FILL>
+// DICE = false: the warp alone (nrt_interpn_f32 variant 10): no fixed map, no sums, no partials -- the same gather and blend
+template <int MODE, bool STORE, bool MM, bool FILL, bool DICE = true>
 __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
                                                         float *__restrict__ fpart, float *__restrict__ mpart) {
     constexpr int G = 8, L = 32;
     extern __shared__ __attribute__((aligned(16))) char wc_smem[];
     // ---- which (batch, patch, x segment): the enumeration of warp_dice_tile's x-march ---------------------------------
-    const unsigned k = blockIdx.x % NRT_NXCD, jb = blockIdx.x / NRT_NXCD;
-    const unsigned per_batch = tg.ncol * tg.nseg, U = per_batch * tg.nbatch;
-    const unsigned perU = gridDim.x / NRT_NXCD;
-    const unsigned u = k * perU + jb;
-    if (jb >= perU || u >= U) return;
-    const int b = (int)(u / per_batch);
-    const unsigned prow = u % per_batch;
-    const unsigned useg = prow / tg.ncol, ucol = prow % tg.ncol;
+    XmWork xw;
+    if (!xmarch_work(tg, a.O[0], xw)) return;
+    const int b = xw.b;
+    const unsigned prow = xw.prow, ucol = xw.ucol;
     const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
     const unsigned nRz = (tg.nTz + RZ - 1) / RZ;
     const unsigned reg = ucol / (RY * RZ), wr = ucol % (RY * RZ);
     const unsigned cy = (reg / nRz) * RY + wr / RZ, cz = (reg % nRz) * RZ + wr % RZ;
-    const int x0 = (int)(useg * tg.seglen), y0 = (int)cy << 2, z0 = (int)cz << 3;
-    int npass = min((int)tg.seglen, a.O[0] - x0);                // one x-plane of the patch per pass
+    const int x0 = xw.x0, y0 = (int)cy << 2, z0 = (int)cz << 3;
+    int npass = xw.xlen;                                         // one x-plane of the patch per pass
     if (cy >= tg.nTy || cz >= tg.nTz || npass < 0) npass = 0;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -186,6 +183,18 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
         return __builtin_bit_cast(nrt_f4, __builtin_amdgcn_raw_buffer_load_b128(vres, (rid * 8u + (unsigned)p) * 16u, 0, 0));
     };
 
+    // Incoherent fields: a pass with more colliding rows than the overflow holds takes the register path (its 8 corner rows straight
+    // from memory).  NRT_WC_SKIP > 0 would also skip the probing of the next passes; measured it only hurts: on the bench field 0.85 %
+    // of the passes overflow and each skip leaves the cache cold (1.26 ms with 15 against 1.09), on U(-80, 80) displacements nothing
+    // is gained (1.886 / 1.874 ms, register kernel 1.85): profiles/r04_lab/wc_skip_variants.jsonl.
+#ifndef NRT_FUSED_WCSKIP
+#define NRT_FUSED_WCSKIP 0
+#endif
+#define NRT_WC_SKIP NRT_FUSED_WCSKIP
+#ifndef NRT_FUSED_WCBLENDF
+#define NRT_FUSED_WCBLENDF 0      // 1: a register-path pass is blended straight from its registers (a second copy of the blend in the loop)
+#endif
+    int skip = 0;                                                // wave-uniform
     // geometry + cache management + fetch of pass `pass` (its location is in s.pn); leaves the pass in s
     auto manage = [&](int pass, Pass &s) {
         const int xq = x0 + pass;
@@ -198,6 +207,20 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
         wc_corner(py, mxy, i0y, i1y, s.w0y);
         wc_corner(pz, mxz, i0z, i1z, s.w0z);
         if (FILL) s.oob = (px < 0.0f) || (px > mxx) || (py < 0.0f) || (py > mxy) || (pz < 0.0f) || (pz > mxz);
+        auto direct = [&]() {                                     // this voxel's 8 corner rows straight into F (corner order)
+            s.n = -1;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const unsigned jx = (corner & 4) ? i1x : i0x, jy = (corner & 2) ? i1y : i0y, jz = (corner & 1) ? i1z : i0z;
+                s.F[corner] = fetch_row(nrt_mad24(nrt_mad24(jx, SY, jy), SZ, jz));
+            }
+        };
+        if (__builtin_expect(skip > 0, 0)) {
+            --skip;
+            direct();
+            if (DICE) s.T = __builtin_nontemporal_load((const nrt_f4 *)(fixb + (size_t)((unsigned)xq * qstep) * 128u + row_lane));
+            return;
+        }
         // this lane's reference: corner p of the group's voxel
         const unsigned ix = cx1 ? i1x : i0x, iy = cy1 ? i1y : i0y, iz = cz1 ? i1z : i0z;
         const unsigned rid = nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz);
@@ -213,16 +236,11 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
         const int nl = __builtin_popcountll(Ml), no = __builtin_popcountll(Mo);
         if (__builtin_expect(no > WC_OVF, 0)) {
             // incoherent field: more rows collide than the overflow holds.  Forget the cache (the tags written above name rows that
-            // will not be fetched) and fetch this voxel's 8 corner rows; deliver() puts them into rows 8 g .. 8 g + 7.
-            tags[lane] = ~0ull;
+            // will not be fetched) and fetch this voxel's 8 corner rows directly
+            tags[lane] = ~0ull;                                   // (all of it: deliver() parks the pass's 64 corner rows in rows 0 .. 63)
             tags[lane + 64] = ~0ull;
-            s.n = -1;
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const unsigned jx = (corner & 4) ? i1x : i0x, jy = (corner & 2) ? i1y : i0y, jz = (corner & 1) ? i1z : i0z;
-                s.F[corner] = fetch_row(nrt_mad24(nrt_mad24(jx, SY, jy), SZ, jz));
-                s.sl[corner] = (unsigned)(g * 8 + corner) * 128u;
-            }
+            skip = NRT_WC_SKIP;
+            direct();
         } else {
             // EVERY lane writes one entry of the fetch list: loaders and orphans their row and its destination at positions 0 .. n - 1,
             // the others a row id past the volume (reads as zeros, touches no memory) with the trash row as destination at n .. 63 --
@@ -257,27 +275,28 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
                 if (8 * i < s.n) s.F[i] = fetch_row((unsigned)(i < 4 ? ra[i & 3] : rb[i & 3]));      // wave-uniform condition
             }
         }
-        s.T = __builtin_nontemporal_load((const nrt_f4 *)(fixb + (size_t)((unsigned)xq * qstep) * 128u + row_lane));
+        if (DICE) s.T = __builtin_nontemporal_load((const nrt_f4 *)(fixb + (size_t)((unsigned)xq * qstep) * 128u + row_lane));
     };
 
     // rows fetched for the pass -> their cache / overflow rows
     auto deliver = [&](Pass &s) {
-        if (__builtin_expect(s.n < 0, 0)) {
+#if !NRT_FUSED_WCBLENDF
+        if (__builtin_expect(s.n < 0, 0)) {                        // register path: the voxel's 8 corner rows go to rows 8 g .. 8 g + 7
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) *(wc_lds_f4 *)(lrow + (g * 8 + corner) * 128) = s.F[corner];
+            for (int corner = 0; corner < 8; ++corner) {
+                *(wc_lds_f4 *)(lrow + (g * 8 + corner) * 128) = s.F[corner];
+                s.sl[corner] = (unsigned)(g * 8 + corner) * 128u;
+            }
             return;
         }
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (8 * i < s.n) *(wc_lds_f4 *)(lrow + wc_byte(s.fd_lo, s.fd_hi, i) * 128u) = s.F[i];     // wave-uniform condition
         }
     };
 
-    auto blend = [&](int pass, Pass &s, bool live) {
-        nrt_f4 R[8];
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) R[corner] = *(const wc_lds_f4 *)(lrow + s.sl[corner]);
-        __builtin_amdgcn_sched_barrier(0);                         // all eight reads in flight before the first product: one LDS round trip
+    auto blend = [&](int pass, Pass &s, bool live, const nrt_f4 (&R)[8]) {
         const float w1x = nrt_sub(1.0f, s.w0x), w1y = nrt_sub(1.0f, s.w0y), w1z = nrt_sub(1.0f, s.w0z);      // corner_1d's w1
         const nrt_f2 wy2 = {s.w0y, w1y}, wz2 = {s.w0z, w1z};
         const nrt_f2 wxy0 = (nrt_f2){s.w0x, s.w0x} * wy2, wxy1 = (nrt_f2){w1x, w1x} * wy2;
@@ -302,10 +321,12 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
         if (yzvalid && live) {
             if (STORE) __builtin_nontemporal_store(acc, (nrt_f4 *)(outb + (size_t)((unsigned)(x0 + pass) * qstep) * 128u + row_lane));
             const nrt_f2 pl = {acc[0], acc[1]}, ph = {acc[2], acc[3]}, tl = {s.T[0], s.T[1]}, th = {s.T[2], s.T[3]};
-            stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
-            stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
-            spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
-            if (MM) {
+            if (DICE) {
+                stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
+                stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
+                spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
+            }
+            if (DICE && MM) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     mnt = fminf(mnt, s.T[c]); mxt = fmaxf(mxt, s.T[c]);
@@ -320,8 +341,19 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
     // waits for everything in flight.
     const int last = npass - 1;
     auto step = [&](int pass, Pass &s) {
-        deliver(s);
-        blend(pass, s, pass <= last);
+#if NRT_FUSED_WCBLENDF
+        if (__builtin_expect(s.n < 0, 0)) {
+            blend(pass, s, pass <= last, s.F);                     // register path: F holds the voxel's 8 corner rows
+        } else
+#endif
+        {
+            deliver(s);
+            nrt_f4 R[8];
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) R[corner] = *(const wc_lds_f4 *)(lrow + s.sl[corner]);
+            __builtin_amdgcn_sched_barrier(0);                     // all eight reads in flight before the first product: one LDS round trip
+            blend(pass, s, pass <= last, R);
+        }
         manage(min(pass + 2, last), s);
         fetch_loc(min(pass + 4, last), s);
     };
@@ -342,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
         }
     }
 
+    if (!DICE) return;
     nrt_f4 stp = {stp_l[0], stp_l[1], stp_h[0], stp_h[1]}, stt = {stt_l[0], stt_l[1], stt_h[0], stt_h[1]},
            spp = {spp_l[0], spp_l[1], spp_h[0], spp_h[1]};
     // ---- block reduction (identical tree to warp_dice_tile / dice_soft_vec) ---------------------------------------------------
@@ -380,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
             m = (threadIdx.x & 1) ? fmaxf(m, red[w2][3 * L + threadIdx.x]) : fminf(m, red[w2][3 * L + threadIdx.x]);
         mpart[pbase * 4 + threadIdx.x] = m;
     }
+    xmarch_zero_rows(tg, xw, 3 * L, fpart, mpart);
 }
 
 template <int MODE, bool STORE, bool MM, bool FILL>
@@ -387,8 +421,8 @@ int launch_wc_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, in
                    hipStream_t st) {
     if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, STORE, MM, FILL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_BLOCK_BYTES) != hipSuccess)
         return NRT_ERR_LAUNCH;
-    hipLaunchKernelGGL((warp_dice_wc<MODE, STORE, MM, FILL>), dim3(nrt_xcd_grid(nblocks * (unsigned)batch)), dim3(256), WC_BLOCK_BYTES, st, a, tg, fixed,
-                       fpart, mpart);
+    const unsigned grid = tg.het_cpx ? NRT_NXCD * (tg.het_full + (tg.het_cpx - tg.het_full) * tg.nseg) : nrt_xcd_grid(nblocks * (unsigned)batch);
+    hipLaunchKernelGGL((warp_dice_wc<MODE, STORE, MM, FILL>), dim3(grid), dim3(256), WC_BLOCK_BYTES, st, a, tg, fixed, fpart, mpart);
     return NRT_OK;
 }
 
@@ -426,4 +460,50 @@ inline int launch_wc(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, 
     }
 }
 
+// the warp alone through the same kernel (interpn.hip, variant 10): x-march geometry of the fused default
+template <int MODE, bool FILL>
+int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, hipStream_t st) {
+    if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, true, false, FILL, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)WC_BLOCK_BYTES) != hipSuccess)
+        return NRT_ERR_LAUNCH;
+    hipLaunchKernelGGL((warp_dice_wc<MODE, true, false, FILL, false>), dim3(nrt_xcd_grid(nblocks * (unsigned)batch)), dim3(256), WC_BLOCK_BYTES, st,
+                       a, tg, (const float *)nullptr, (float *)nullptr, (float *)nullptr);
+    return NRT_OK;
+}
+
 }  // namespace
+
+bool nrt_wc_interpn_supported(const void *args, int batch) {
+    const InterpArgs &a = *(const InterpArgs *)args;
+    if (a.C != 32 || !xmarch_applies(a.O, batch)) return false;
+    if ((unsigned long long)a.nout * 128ull >= (1ull << 32)) return false;                 // 32-bit output offsets
+    if ((long long)a.S[0] * a.S[1] >= (1 << 24) || a.S[2] >= (1 << 24) || (long long)a.O[0] * a.O[1] >= (1 << 24) || a.O[2] >= (1 << 24)) return false;
+    TileGeom tg;
+    unsigned nblocks;
+    const int t = xmarch_default_tune();
+    tile_geometry(a.O, 8, t, t, tg, nblocks);
+    xmarch_setup(a.O, batch, t, tg);
+    return wc_applies(tg, 8, a);
+}
+
+int nrt_wc_interpn_launch(const void *args, int batch, int mode, void *stream) {
+    const InterpArgs &a = *(const InterpArgs *)args;
+    TileGeom tg;
+    unsigned nblocks;
+    const int t = xmarch_default_tune();
+    tile_geometry(a.O, 8, t, t, tg, nblocks);
+    nblocks = xmarch_setup(a.O, batch, t, tg);
+    hipStream_t st = nrt_stream(stream);
+    int rc;
+    switch (mode) {
+        case NRT_LOC_ABSOLUTE: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_ABSOLUTE, true>(a, tg, nblocks, batch, st)
+                                               : launch_wc_interpn_inst<NRT_LOC_ABSOLUTE, false>(a, tg, nblocks, batch, st); break;
+        case NRT_LOC_SHIFT: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_SHIFT, true>(a, tg, nblocks, batch, st)
+                                            : launch_wc_interpn_inst<NRT_LOC_SHIFT, false>(a, tg, nblocks, batch, st); break;
+        default: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_LINSPACE, true>(a, tg, nblocks, batch, st)
+                                 : launch_wc_interpn_inst<NRT_LOC_LINSPACE, false>(a, tg, nblocks, batch, st); break;
+    }
+    if (rc != NRT_OK) return rc;
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}

@@ -27,6 +27,7 @@
 
 #include "interpn_core.h"
 #include "lean.h"
+#include "wc.h"
 
 namespace {
 
@@ -715,6 +716,9 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 8:
             if (!can_lean) return NRT_ERR_UNSUPPORTED;
             return nrt_lean_launch(&a, batch, loc_mode, method == NRT_INTERP_NEAREST ? 1 : 0, st);
+        case 10:                            // wave-private LDS row cache (fused_wc.h) without the Dice half
+            if (!can_zrun || !nrt_wc_interpn_supported(&a, batch)) return NRT_ERR_UNSUPPORTED;
+            return nrt_wc_interpn_launch(&a, batch, loc_mode, st);
         default: return NRT_ERR_INVALID_ARG;
     }
     NRT_CHECK_LAUNCH();

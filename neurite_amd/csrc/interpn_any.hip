@@ -1,5 +1,5 @@
 // interpn for the volume dtypes and ranks the float32 1-3-D kernels of interpn.hip do not take:
-// float16 / bfloat16 / float64 volumes in 1..6 dimensions, and float32 / int32 volumes in 4..6 dimensions.
+// float16 / bfloat16 / float64 volumes in 1..8 dimensions, and float32 / int32 volumes in 4..8 dimensions.
 //
 // neurite/tf/utils/utils.py:73-220 is dtype- and rank-generic: `loc` is cast to the volume's float dtype (:123-127) and
 // every operation of the linear branch (:137-191) -- floor, the three clips, the weight differences, prod_n, the
@@ -12,7 +12,7 @@
 // volumes), SHIFT forms float32(index) + shift in float32 (vxm transform()), LINSPACE is tf.linspace in float32; the result
 // is then cast to T, as interpn does with whatever it is handed.
 //
-// 4..6 dimensions: one thread per output ELEMENT (voxel, channel), channel fastest (interpn_any); 1..3 dimensions: the rank is a
+// 4..8 dimensions: one thread per output ELEMENT (voxel, channel), channel fastest (interpn_any); 1..3 dimensions: the rank is a
 // template parameter and a thread owns a group of channels (interpn_any_nd).  This is the coverage path -- the bandwidth-tuned
 // kernels are the float32 ones.
 
@@ -20,7 +20,7 @@
 
 namespace {
 
-constexpr int ANY_MAXD = 6;
+constexpr int ANY_MAXD = 8;          // (TensorFlow itself stops at rank-8 tensors: 7 spatial dimensions + channels is what the reference can be fed)
 
 struct AnyArgs {
     const void *vol;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void interpn_any_nd(AnyArgs a) {
     }
 }
 
-// int32 volumes, nearest only (4..6-D; the 1-3-D case lives in interpn.hip)
+// int32 volumes, nearest only (4..8-D; the 1-3-D case lives in interpn.hip)
 __global__ __launch_bounds__(256) void interpn_any_nearest_i32(AnyArgs a, int fill_i) {
     const int b = blockIdx.y;
     for (unsigned long long e = (unsigned long long)blockIdx.x * 256u + threadIdx.x; e < a.nelem;

@@ -96,6 +96,10 @@ struct TileGeom {
     unsigned nbatch;
     int lry, lrz;                  // log2 of the region extent in patches: consecutive blocks fill a (2^lry x 2^lrz) patch region
     int depth_sync;                // backward x-march kernels: passes between block barriers (power of two), 0 = none
+    // mixed block lengths (fused forward kernels, xmarch_setup_mixed): of the het_cpx columns an XCD owns, the first het_full are
+    // marched whole by one block each and the others in nseg pieces of seglen planes, the pieces LAST in launch order: the last round
+    // of blocks is short, so the chip drains in a fraction of a march.  het_cpx = 0: every column in nseg equal pieces (xmarch_setup).
+    unsigned het_cpx, het_full;
 };
 
 // tune word of the tiled kernels: ltx | lty << 4 | ltz << 8 | z_outer << 12 | plane_major << 13 | x_march << 14 | LZ << 16
@@ -106,6 +110,7 @@ inline void tile_geometry(const int *out_shape, int G, int tune, int default_tun
     tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
     tg.plane_major = ((tune >> 13) & 1) && G == 8;
     tg.x_march = 0; tg.ncol = 0; tg.nseg = 1; tg.seglen = 0; tg.nbatch = 1; tg.lry = 0; tg.lrz = 0; tg.depth_sync = 0;
+    tg.het_cpx = 0; tg.het_full = 0;
     if (tg.plane_major) {
         tg.ltx = 2; tg.lty = 3; tg.ltz = 0;
         tg.tz = (tune >> 16) & 0xfff;
@@ -150,17 +155,101 @@ inline unsigned xmarch_setup(const int *out_shape, int batch, int t, TileGeom &t
     const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;             // regions are padded; out-of-range patches are empty blocks
     tg.ncol = ((tg.nTy + RY - 1) / RY) * ((tg.nTz + RZ - 1) / RZ) * RY * RZ;
     unsigned nseg = (unsigned)(t >> 16) & 0xffu;
-    if (nseg == 0) {                                                 // auto: at least twelve blocks per CU over the launch
-        // (one block is resident per CU, so a launch runs in rounds of 256 blocks: 800 blocks = one 160^3 volume leave the
-        // fourth round 12 % full; measured at batch 1: 0.358 ms with 1 segment, 0.328 with 2-4, tools/b1_nseg_sweep.sh)
-        // (round 3, tools/b1_sweep.py: 0.326 ms with 4 segments at batch 1 whatever the blocks per CU and the region shape, 0.330 with 2)
-        nseg = (3072u + tg.ncol * batch - 1) / (tg.ncol * batch);
+    if (nseg == 0) {
+        // auto: at least twelve blocks per CU over the launch, and a last round that is nearly full.  Two blocks are resident per CU,
+        // so a launch runs in rounds of 2 x CUs blocks of (about) equal length: the 3200 full-length marches of 4 x 160^3 are 6.25
+        // rounds -- the seventh is a quarter full.  Measured (tools/nseg_probe.py, profiles/r04_lab/nseg_probe.jsonl), register
+        // kernel / wave-cache kernel: batch 4 1.133 / 1.110 ms with 1 segment, 1.109 / 1.074 with 2, 1.144 / 1.122 with 4 (short
+        // marches re-fetch their first planes); batch 1 0.347 / 0.339 with 1, 0.312 / 0.313 with 4 or 5.
+        const unsigned cols = tg.ncol * (unsigned)batch, slots = 2u * (unsigned)nrt_num_cus();
+        nseg = (3072u + cols - 1) / cols;
         if (nseg < 1) nseg = 1;
+        for (; nseg < 8; ++nseg) {
+            const unsigned blocks = cols * nseg, rounds = (blocks + slots - 1) / slots;
+            if ((unsigned long long)(rounds * slots - blocks) * 20ull <= blocks) break;             // idle slots of the last round <= 5 %
+        }
     }
     if (nseg > (unsigned)out_shape[0]) nseg = (unsigned)out_shape[0];
     tg.seglen = ((unsigned)out_shape[0] + nseg - 1) / nseg;
     tg.nseg = ((unsigned)out_shape[0] + tg.seglen - 1) / tg.seglen;
     return tg.ncol * tg.nseg;
+}
+
+// host: mixed block lengths for the fused forward kernels when the tune word leaves the segments to us.  Blocks of (about) equal
+// length run in rounds of `slots` = 2 x CUs; with C columns per launch the last round is C mod slots full and costs a whole march:
+// 4 x 160^3 = 3200 columns = 6.25 rounds, and 32 x 160^3 (100 rounds) runs at 0.248 ms per volume where 4 volumes take 0.277.
+// Equal pieces (xmarch_setup) shorten the last round but every piece re-fetches its first planes: measured +7 % / +15 % / +22 % for
+// 2 / 4 / 8 pieces per column (tools/nseg_probe.py).  So: whole columns for the full rounds, pieces only for the remainder, launched
+// last.  The model below picks the number of whole columns per XCD (a multiple of its slots) and the pieces per remaining column;
+// returns the partial rows per batch entry (ncol x pieces) and the grid size in `grid`.
+inline unsigned xmarch_setup_mixed(const int *out_shape, int batch, int t, TileGeom &tg, unsigned &grid) {
+    tg.x_march = 1;
+    tg.nbatch = (unsigned)batch;
+    tg.lry = (t >> 24) & 7; tg.lrz = (t >> 27) & 7;
+    const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
+    tg.ncol = ((tg.nTy + RY - 1) / RY) * ((tg.nTz + RZ - 1) / RZ) * RY * RZ;
+    const unsigned cols = tg.ncol * (unsigned)batch, cpx = (cols + NRT_NXCD - 1) / NRT_NXCD;
+    const unsigned slots = (unsigned)(2 * nrt_num_cus() / NRT_NXCD);
+    static const int PS[7] = {1, 2, 3, 4, 5, 6, 8};
+    static const float OVH[7] = {0.f, 0.07f, 0.11f, 0.15f, 0.17f, 0.19f, 0.22f};
+    float best = 1e30f;
+    unsigned bF = 0, bP = 1;
+    for (unsigned F = 0; F <= cpx; F += slots) {
+        const unsigned rem = cpx - F;
+        for (int i = 0; i < 7; ++i) {
+            const unsigned P = (unsigned)PS[i];
+            if (P > (unsigned)out_shape[0]) break;
+            const float cost = (float)(F / slots) + (rem ? (float)((rem * P + slots - 1) / slots) / (float)P * (1.0f + OVH[i]) : 0.0f);
+            if (cost < best - 1e-6f) { best = cost; bF = F; bP = P; }
+            if (!rem) break;
+        }
+    }
+    tg.het_cpx = cpx; tg.het_full = bF;
+    tg.nseg = bP;
+    tg.seglen = ((unsigned)out_shape[0] + bP - 1) / bP;
+    grid = NRT_NXCD * (bF + (cpx - bF) * bP);
+    return tg.ncol * bP;
+}
+
+// device: the work of this block under either schedule.  false: nothing (the block exits; it owns no partial row)
+struct XmWork { int b; unsigned ucol, prow; int x0, xlen; bool whole; };
+__device__ __forceinline__ bool xmarch_work(const TileGeom &tg, int O0, XmWork &w) {
+    const unsigned k = blockIdx.x % NRT_NXCD, jb = blockIdx.x / NRT_NXCD;
+    if (tg.het_cpx) {
+        unsigned cl, piece = 0;
+        w.whole = jb < tg.het_full;
+        if (w.whole) cl = jb;
+        else { const unsigned r = jb - tg.het_full; cl = tg.het_full + r / tg.nseg; piece = r % tg.nseg; }
+        const unsigned c = k * tg.het_cpx + cl;
+        if (cl >= tg.het_cpx || c >= tg.ncol * tg.nbatch) return false;
+        w.b = (int)(c / tg.ncol);
+        w.ucol = c % tg.ncol;
+        w.prow = piece * tg.ncol + w.ucol;
+        w.x0 = w.whole ? 0 : (int)(piece * tg.seglen);
+        w.xlen = w.whole ? O0 : min((int)tg.seglen, O0 - w.x0);
+        return true;
+    }
+    // one piece per block: XCD k owns the contiguous range [k * perU, (k + 1) * perU) of (batch, segment, patch)
+    const unsigned per_batch = tg.ncol * tg.nseg, U = per_batch * tg.nbatch;
+    const unsigned perU = gridDim.x / NRT_NXCD;
+    const unsigned u = k * perU + jb;
+    if (jb >= perU || u >= U) return false;
+    w.b = (int)(u / per_batch);
+    w.prow = u % per_batch;
+    w.ucol = w.prow % tg.ncol;
+    w.x0 = (int)((w.prow / tg.ncol) * tg.seglen);
+    w.xlen = min((int)tg.seglen, O0 - w.x0);
+    w.whole = false;
+    return true;
+}
+// a block that marched a whole column owns the column's other partial rows too: they hold zeros (and neutral extrema)
+__device__ __forceinline__ void xmarch_zero_rows(const TileGeom &tg, const XmWork &w, int L3, float *fpart, float *mpart) {
+    if (!w.whole) return;
+    for (unsigned piece = 1; piece < tg.nseg; ++piece) {
+        const long long row = (long long)w.b * (tg.ncol * tg.nseg) + piece * tg.ncol + w.ucol;
+        for (int i = threadIdx.x; i < L3; i += blockDim.x) fpart[row * L3 + i] = 0.0f;
+        if (threadIdx.x < 4) mpart[row * 4 + threadIdx.x] = (threadIdx.x & 1) ? -INFINITY : INFINITY;
+    }
 }
 
 // default x-march tune for 32-channel volumes: 4 x 8 (y,z) patches, regions of 8 x 4 patches

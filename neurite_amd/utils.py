@@ -176,7 +176,7 @@ def _launch_interpn(vol, loc, out_spatial, loc_mode, method, fill_value, batched
     st = _lib.stream_ptr(dev)
     with torch.cuda.device(dev):
         if vol.dtype in _ANY_DTYPES and (D > 3 or vol.dtype not in (torch.float32, torch.int32)):
-            # float16 / bfloat16 / float64 volumes, and ranks 4-6: the dtype- and rank-generic kernel (csrc/interpn_any.hip);
+            # float16 / bfloat16 / float64 volumes, and ranks 4-8: the dtype- and rank-generic kernel (csrc/interpn_any.hip);
             # arithmetic in the volume dtype, one rounding per op, as TensorFlow evaluates utils.py:137-213
             if vol.dtype == torch.int32:
                 assert method == _lib.INTERP_NEAREST
@@ -201,7 +201,7 @@ def _launch_interpn(vol, loc, out_spatial, loc_mode, method, fill_value, batched
     return out
 
 
-_ANY_MAXD = 6
+_ANY_MAXD = 8
 _ANY_DTYPES = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16,
                torch.float64: _lib.DT_F64, torch.int32: _lib.DT_I32}
 

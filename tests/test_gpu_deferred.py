@@ -164,14 +164,18 @@ def test_deferred_warp_is_safe_against_buffer_reuse(dev, batch):
 
 def test_full_size_reference_api_pipeline_and_few_channel_warps(dev):
     """BASELINE config 2 size (160^3 x 32 one-hot, sigma = 3 field): the reference-signature pipeline with the deferred warp against
-    the C oracle's warp + Dice; the same maps stored as bfloat16 give the same Dice bit for bit; and the few-channel kernels
+    the C oracle's warp + Dice; the same maps stored as bfloat16 give the same Dice (bit for bit against the same kernel structure); and the few-channel kernels
     (variant 8) at 160^3: a C = 1 image and a C = 3 flow warped by the field, bit-exact against the C oracle"""
     mov, fix, trf = synth.cfg2_batch(1, 160, 32, device=dev, seed0=1)
     d = ne.metrics.Dice(check_input_limits=False).dice(fix, ne.layers.SpatialTransformer()([mov, trf]))
     w = co.interpn(N(mov)[0], N(trf)[0], 'linear', None, loc_mode=1)
     sums, _ = co.dice_sums(N(fix), w[None])
     np.testing.assert_allclose(N(d), co.dice_from_sums(sums), rtol=1e-5)
-    assert bits_equal(N(ne.fused.warp_dice(mov.bfloat16(), trf, fix.bfloat16())), N(ne.fused.warp_dice(mov, trf, fix)))
+    # bfloat16 storage, float32 arithmetic: the warped rows are the same values; against the same kernel structure (register kernel,
+    # tune bit 30) the Dice is the same bit for bit, against the default float32 kernel (wave-cache: another summation order) to 1e-6
+    d16 = N(ne.fused.warp_dice(mov.bfloat16(), trf, fix.bfloat16()))
+    assert bits_equal(d16, N(ne.fused.warp_dice(mov, trf, fix, _tune=1 << 30)))
+    np.testing.assert_allclose(d16, N(ne.fused.warp_dice(mov, trf, fix)), rtol=1e-6)
     del mov, fix, w
     rng = np.random.default_rng(2)
     for C in (1, 3):

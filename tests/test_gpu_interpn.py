@@ -278,6 +278,36 @@ def test_backward_is_loud(dev):
             d.sum().backward()
 
 
+def test_wave_cache_warp_variant(dev):
+    """nrt_interpn_f32 variant 10: the wave-private LDS row cache kernel (csrc/fused_wc.h) as a stand-alone warp, in the three location
+    modes (SpatialTransformer, interpn, Resize), with and without fill, coherent and incoherent fields, ragged shapes."""
+    rng = np.random.default_rng(1010)
+    B, S = 5, (17, 61, 67)
+    vol = rng.standard_normal((B,) + S + (32,)).astype(F)
+    for name, trf in (('smooth', np.stack([N(synth.smooth_displacement(3 + b, 67, sigma=2.5, coarse=5, device='cpu'))[:17, :61, :67] for b in range(B)])),
+                      ('iid', rng.normal(0, 1.5, (B,) + S + (3,)).astype(F)), ('far', rng.uniform(-70, 70, (B,) + S + (3,)).astype(F))):
+        trf = np.ascontiguousarray(trf, F)
+        for fill in (None, -1.5):
+            st = ne.layers.SpatialTransformer(fill_value=fill)
+            st._variant = 10
+            got = N(st([G(vol, dev), G(trf, dev)]))
+            assert bits_equal(got, npo.spatial_transformer(vol, trf, fill_value=fill)), (name, fill)
+    # absolute locations through the un-batched API (one volume: enough patches for the schedule)
+    S1 = (16, 92, 180)
+    v1 = rng.standard_normal(S1 + (32,)).astype(F)
+    loc = (ijk(S1) + rng.normal(0, 0.8, S1 + (3,))).astype(F)
+    got = N(ne.utils.interpn(G(v1, dev), G(loc, dev), fill_value=0.0, _variant=10))
+    assert bits_equal(got, npo.interpn(v1, loc, 'linear', 0.0))
+    # regular grid (Resize: tf.linspace locations)
+    half = rng.standard_normal((5, 8, 30, 32, 32)).astype(F)
+    from neurite_amd import utils as U, _lib as L
+    got = U._interp_op(G(half, dev), None, [16, 60, 64], L.LOC_LINSPACE, U._METHODS['linear'], None, batched=True, variant=10)
+    assert bits_equal(N(got), npo.resize_layer(half, 2))
+    # shapes the schedule does not take are refused, not silently routed elsewhere
+    with pytest.raises(ne.errors.NeuriteAmdError):
+        ne.utils.interpn(G(v1[:8, :8, :8], dev), G(loc[:4, :4, :4], dev), _variant=10)
+
+
 def test_full_size_cfg2_spatial_transformer(dev):
     """BASELINE config 2 size: 160^3 x 32-label one-hot, smooth and worst-case fields, vs the C oracle."""
     mov, _, trf = synth.cfg2_batch(1, 160, 32, device=dev, seed0=1)
@@ -288,7 +318,7 @@ def test_full_size_cfg2_spatial_transformer(dev):
     assert bits_equal(got, want)
     # warped one-hot stays a partition of unity up to rounding
     assert np.abs(got.sum(-1) - 1).max() < 1e-5
-    for variant, tune in ((2, 0), (3, 0), (3, 40), (4, 40), (5, 0), (5, _tile(3, 3, 3, 1))):
+    for variant, tune in ((2, 0), (3, 0), (3, 40), (4, 40), (5, 0), (5, _tile(3, 3, 3, 1)), (10, 0)):
         st._variant, st._tune = variant, tune
         assert bits_equal(N(st([mov, trf]))[0], want), (variant, tune)
     gotn = N(ne.layers.SpatialTransformer('nearest', fill_value=0)([mov, trf]))[0]
@@ -414,7 +444,23 @@ def test_spatial_transformer_and_resize_in_other_dtypes(dev, dt):
     assert np.array_equal(cmp(out), ref_rs, equal_nan=True)
 
 
+def test_interpn_seven_and_eight_dimensional_volumes(dev):
+    """the reference's corner loop is itertools.product([0, 1], repeat=D) for any D (utils.py:159); TensorFlow itself stops at rank-8
+    tensors.  7- and 8-D float32 / float64 volumes against the oracle, linear (128 / 256 corners per output) and nearest."""
+    rng = np.random.default_rng(78)
+    for S in ((3, 2, 3, 2, 3, 2, 3), (2, 3, 2, 2, 3, 2, 2, 3)):
+        D = len(S)
+        for dt, tdt in ((F, torch.float32), (np.float64, torch.float64)):
+            vol = rng.standard_normal(S + (2,)).astype(dt)
+            loc = rng.uniform(-0.7, max(S) - 0.3, (11, D)).astype(dt)
+            for method in ('linear', 'nearest'):
+                for fill in (None, 0.5):
+                    got = N(ne.utils.interpn(G(vol, dev), G(loc, dev), interp_method=method, fill_value=fill))
+                    ref = npo.interpn(vol, loc, method, fill)
+                    assert got.dtype == dt and np.array_equal(got, ref, equal_nan=True), (D, dt, method, fill)
+
+
 def test_interpn_rank_limit_is_stated(dev):
-    v = torch.zeros((2,) * 7 + (1,), device=dev)
-    with pytest.raises(NotImplementedError, match='1- to 6-D'):
-        ne.utils.interpn(v, torch.zeros(3, 7, device=dev))
+    v = torch.zeros((2,) * 9 + (1,), device=dev)
+    with pytest.raises(NotImplementedError, match='1- to 8-D'):
+        ne.utils.interpn(v, torch.zeros(3, 9, device=dev))

@@ -28,6 +28,8 @@ mov, fix, trf = synth.cfg2_batch(batch, size, 32, device=dev)
 fields = {'bench': trf}
 if '--zero' in sys.argv:
     fields['zero'] = torch.zeros_like(trf)
+if '--rough' in sys.argv:
+    fields['rough'] = synth.cfg2_batch(batch, size, 32, device=dev, rough=True)[2]
 S = _lib.ints(list(mov.shape[1:-1]))
 sums = torch.empty((batch, 3, 32), dtype=torch.float32, device=dev)
 dice = torch.empty((batch, 32), dtype=torch.float32, device=dev)
@@ -48,7 +50,7 @@ def timeit(fn, n=30, warm=5):
 
 for rep in range(2):
     for k in VARIANTS:
-        path = os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', ''))
+        path = os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '').replace(',', '_'))
         h = C.CDLL(path)
         for name in ('nrt_warp_dice_workspace_bytes', 'nrt_warp_dice_soft_f32'):
             res, args = _lib._SIGNATURES[name]

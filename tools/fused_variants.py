@@ -18,13 +18,13 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=o
 if '--build' in sys.argv:
     objs = [o for o in sorted(glob.glob(os.path.join(LIBDIR, '*.o'))) if os.path.basename(o) != 'fused.o']
     for k in VARIANTS:
-        o = os.path.join(LAB, 'fused_exp%s.o' % k.replace('=', ''))
-        subprocess.check_call(['hipcc'] + FLAGS + ['-DNRT_FUSED_%s' % k, '-c', os.path.join(ROOT, 'neurite_amd', 'csrc', 'fused.hip'), '-o', o])
-        subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + [o, '-o', os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', ''))])
+        o = os.path.join(LAB, 'fused_exp%s.o' % k.replace('=', '').replace(',', '_'))
+        subprocess.check_call(['hipcc'] + FLAGS + ['-DNRT_FUSED_%s' % m for m in k.split(',')] + ['-c', os.path.join(ROOT, 'neurite_amd', 'csrc', 'fused.hip'), '-o', o])
+        subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + [o, '-o', os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '').replace(',', '_'))])
     print('built', VARIANTS)
     sys.exit(0)
 for k in VARIANTS:
-    env = dict(os.environ, NEURITE_AMD_LIB=os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '')))
+    env = dict(os.environ, NEURITE_AMD_LIB=os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '').replace(',', '_')))
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '40', '--warmup', '10', '--no-cpu-baseline', '--no-batch1', '--no-unet'],
                        env=env, capture_output=True, text=True)
     try:

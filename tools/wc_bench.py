@@ -43,6 +43,14 @@ for batch in batches:
                 row['ms_' + key] = round(timeit(lambda: ne.fused.warp_dice(mov, f, fix, return_warped=store, _tune=tune)), 4)
             d[name] = ne.fused.warp_dice(mov, f, fix, _tune=tune)
         row['max_abs_dice_diff'] = float((d['wc'] - d['reg']).abs().max())
+        # the stand-alone warp: the library default (z-run register kernel) against the wave-cache kernel (variant 10)
+        from neurite_amd import deferred
+        keep, deferred.enabled = deferred.enabled, False
+        for name, variant in (('interpn_default', 0), ('interpn_wc', 10)):
+            st = ne.layers.SpatialTransformer()
+            st._variant = variant
+            row['ms_' + name] = round(timeit(lambda: st([mov, f])), 4)
+        deferred.enabled = keep
         nvox = batch * 160 ** 3
         row['frac_wc'] = round(nvox * 268 / row['ms_wc'] / 1e9 / 8.0, 4)
         row['frac_reg'] = round(nvox * 268 / row['ms_reg'] / 1e9 / 8.0, 4)
