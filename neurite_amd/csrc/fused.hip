@@ -389,7 +389,7 @@ size_t fused_ws_bytes(unsigned nblocks, int L, int batch) {
     const size_t rows = (size_t)batch * nblocks;
     const size_t grp = (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS);
     return rows * 3 * L * sizeof(float) + rows * 4 * sizeof(float) + 16 + grp * 3 * L * sizeof(double) +
-           grp * 4 * sizeof(float) + 256;
+           grp * 4 * sizeof(float) + 256 + 64 + NRT_NXCD * 64;       // (+ the work counters of the persistent wave-cache kernel)
 }
 
 // nblocks = partial rows per batch entry
@@ -416,7 +416,7 @@ void fused_geom(const int *out_shape, int G, int batch, int tune, TileGeom &tg, 
 // (environment variable NRT_FUSED_WC = 0 / 1 overrides it)
 constexpr int FUSED_TUNE_WC = 1 << 29, FUSED_TUNE_NO_WC = 1 << 30;
 #ifndef NRT_FUSED_WC_DEFAULT
-#define NRT_FUSED_WC_DEFAULT 0
+#define NRT_FUSED_WC_DEFAULT 1
 #endif
 inline bool fused_wc_enabled() {
     static int on = -1;
@@ -426,10 +426,10 @@ inline bool fused_wc_enabled() {
 
 template <int G, typename ST>
 void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store,
-                  const void *fixed, float *fpart, float *mpart, hipStream_t st, bool use_wc, bool want_minmax) {
+                  const void *fixed, float *fpart, float *mpart, hipStream_t st, bool use_wc, bool want_minmax, unsigned *queue) {
     if constexpr (G == 8 && std::is_same<ST, float>::value) {
         if (use_wc && wc_applies(tg, G, a)) {
-            (void)launch_wc(a, tg, nblocks, batch, mode, store, want_minmax, (const float *)fixed, fpart, mpart, st);
+            (void)launch_wc(a, tg, nblocks, batch, mode, store, want_minmax, (const float *)fixed, fpart, mpart, queue, st);
             return;
         }
     }
@@ -527,18 +527,19 @@ int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed,
     w.mpart = (float *)p; p += rows * 4 * sizeof(float);
     p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     w.gsum = (double *)p; p += (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS) * 3 * nlabels * sizeof(double);
-    w.gmm = (float *)p;
+    w.gmm = (float *)p; p += (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS) * 4 * sizeof(float);
+    unsigned *queue = (unsigned *)(((uintptr_t)p + 63) & ~(uintptr_t)63);
     w.ipart = nullptr;
     hipStream_t st = nrt_stream(stream);
     const bool store = warped != nullptr;
     switch (G) {
-        case 1: launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
-        case 2: launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
-        case 4: launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
-        case 8: launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
-        case 16: launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
-        case 32: launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
-        default: launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr); break;
+        case 1: launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
+        case 2: launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
+        case 4: launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
+        case 8: launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
+        case 16: launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
+        case 32: launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
+        default: launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
     }
     NRT_CHECK_LAUNCH();
     return dice_finalize_soft(w, nblocks, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
@@ -563,7 +564,8 @@ extern "C" const char *nrt_warp_dice_kernel_name(const int *out_shape, const int
     for (int d = 0; d < 3; ++d) a.S[d] = vol_shape[d];
     const char *tf[2] = {"false", "true"};
     if (G == 8 && use_wc && wc_applies(tg, G, a))
-        snprintf(name, sizeof(name), "warp_dice_wc<%d, %s, %s, %s>", loc_mode, tf[store != 0], tf[want_minmax != 0], tf[has_fill != 0]);
+        snprintf(name, sizeof(name), "warp_dice_wc<%d, %s, %s, %s, true, %s>", loc_mode, tf[store != 0], tf[want_minmax != 0], tf[has_fill != 0],
+                 tf[NRT_FUSED_WCPERSIST && NRT_NXCD * tg.items_x > 2u * (unsigned)nrt_num_cus()]);
     else
         snprintf(name, sizeof(name), "warp_dice_tile<%d, %d, %s, %d, float>", G, loc_mode, tf[store != 0], tg.x_march ? NRT_FUSED_MINW : 1);
     return name;

@@ -86,15 +86,12 @@ __device__ __forceinline__ void wc_corner(float pv, float mx, int &i0, int &i1, 
     w0 = nrt_sub(l1, cl);
 }
 
+// one work item (a column of a 4 x 8 patch, or a piece of one) by one block.
 // DICE = false: the warp alone (nrt_interpn_f32 variant 10): no fixed map, no sums, no partials -- the same gather and blend
-template <int MODE, bool STORE, bool MM, bool FILL, bool DICE = true>
-__global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
-                                                        float *__restrict__ fpart, float *__restrict__ mpart) {
+template <int MODE, bool STORE, bool MM, bool FILL, bool DICE>
+__device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg, const float *__restrict__ fixed, float *__restrict__ fpart,
+                                        float *__restrict__ mpart, const XmWork &xw, char *wc_smem) {
     constexpr int G = 8, L = 32;
-    extern __shared__ __attribute__((aligned(16))) char wc_smem[];
-    // ---- which (batch, patch, x segment): the enumeration of warp_dice_tile's x-march ---------------------------------
-    XmWork xw;
-    if (!xmarch_work(tg, a.O[0], xw)) return;
     const int b = xw.b;
     const unsigned prow = xw.prow, ucol = xw.ucol;
     const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
@@ -416,30 +413,80 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
     xmarch_zero_rows(tg, xw, 3 * L, fpart, mpart);
 }
 
+// PERSIST: 2 blocks per CU stay resident and take items from per-XCD lists (atomic counters in `queue`, zeroed before the launch):
+// first their own XCD's (its L2 holds the neighbouring columns), then the others'.  With one block per item the XCDs finish up to
+// 5 % apart (tools/block_trace.py: last block of an XCD at 1044 .. 1097 us) and the slots of a finished XCD idle; the items are the
+// same either way, every item writes its own partial row, so the sums do not depend on who computed what.
+template <int MODE, bool STORE, bool MM, bool FILL, bool DICE = true, bool PERSIST = false>
+__global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
+                                                        float *__restrict__ fpart, float *__restrict__ mpart, unsigned *__restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) char wc_smem[];
+    if (!PERSIST) {
+        XmWork xw;
+        if (!xmarch_work(tg, a.O[0], xw)) return;
+        wc_item<MODE, STORE, MM, FILL, DICE>(a, tg, fixed, fpart, mpart, xw, wc_smem);
+        return;
+    }
+    __shared__ unsigned s_next[2];
+    const unsigned home = blockIdx.x % NRT_NXCD;
+    for (;;) {
+        __syncthreads();                                          // the previous item's LDS (cache rows, reduction scratch) is done with
+        if (threadIdx.x == 0) {
+            unsigned kk = home, jb = 0xffffffffu;
+            for (unsigned t = 0; t < NRT_NXCD; ++t) {
+                const unsigned q = (home + t) % NRT_NXCD;
+                const unsigned v = atomicAdd(&queue[q * 16u], 1u);                 // (the counters sit 64 bytes apart)
+                if (v < tg.items_x) { kk = q; jb = v; break; }
+            }
+            s_next[0] = kk; s_next[1] = jb;
+        }
+        __syncthreads();
+        const unsigned kk = s_next[0], jb = s_next[1];
+        if (jb == 0xffffffffu) break;
+        XmWork xw;
+        if (!xmarch_work_at(tg, a.O[0], kk, jb, xw)) continue;
+        wc_item<MODE, STORE, MM, FILL, DICE>(a, tg, fixed, fpart, mpart, xw, wc_smem);
+    }
+}
+
+#ifndef NRT_FUSED_WCPERSIST
+#define NRT_FUSED_WCPERSIST 1
+#endif
 template <int MODE, bool STORE, bool MM, bool FILL>
 int launch_wc_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, const float *fixed, float *fpart, float *mpart,
-                   hipStream_t st) {
+                   unsigned *queue, hipStream_t st) {
+    const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
+    if (NRT_FUSED_WCPERSIST && queue && items > slots) {
+        if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, STORE, MM, FILL, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)WC_BLOCK_BYTES) != hipSuccess)
+            return NRT_ERR_LAUNCH;
+        if (hipMemsetAsync(queue, 0, NRT_NXCD * 64, st) != hipSuccess) return NRT_ERR_LAUNCH;
+        hipLaunchKernelGGL((warp_dice_wc<MODE, STORE, MM, FILL, true, true>), dim3(nrt_xcd_grid(slots)), dim3(256), WC_BLOCK_BYTES, st, a, tg, fixed,
+                           fpart, mpart, queue);
+        return NRT_OK;
+    }
     if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, STORE, MM, FILL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_BLOCK_BYTES) != hipSuccess)
         return NRT_ERR_LAUNCH;
-    const unsigned grid = tg.het_cpx ? NRT_NXCD * (tg.het_full + (tg.het_cpx - tg.het_full) * tg.nseg) : nrt_xcd_grid(nblocks * (unsigned)batch);
-    hipLaunchKernelGGL((warp_dice_wc<MODE, STORE, MM, FILL>), dim3(grid), dim3(256), WC_BLOCK_BYTES, st, a, tg, fixed, fpart, mpart);
+    hipLaunchKernelGGL((warp_dice_wc<MODE, STORE, MM, FILL>), dim3(items), dim3(256), WC_BLOCK_BYTES, st, a, tg, fixed, fpart, mpart,
+                       (unsigned *)nullptr);
+    (void)nblocks; (void)batch;
     return NRT_OK;
 }
 
 template <int MODE, bool FILL>
 int launch_wc_fill(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, bool store, bool minmax, const float *fixed,
-                   float *fpart, float *mpart, hipStream_t st) {
-    if (store) return minmax ? launch_wc_inst<MODE, true, true, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, st)
-                             : launch_wc_inst<MODE, true, false, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, st);
-    return minmax ? launch_wc_inst<MODE, false, true, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, st)
-                  : launch_wc_inst<MODE, false, false, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, st);
+                   float *fpart, float *mpart, unsigned *queue, hipStream_t st) {
+    if (store) return minmax ? launch_wc_inst<MODE, true, true, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, queue, st)
+                             : launch_wc_inst<MODE, true, false, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, queue, st);
+    return minmax ? launch_wc_inst<MODE, false, true, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, queue, st)
+                  : launch_wc_inst<MODE, false, false, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, queue, st);
 }
 
 template <int MODE>
 int launch_wc_mode(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, bool store, bool minmax, const float *fixed,
-                   float *fpart, float *mpart, hipStream_t st) {
-    return a.has_fill ? launch_wc_fill<MODE, true>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st)
-                      : launch_wc_fill<MODE, false>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st);
+                   float *fpart, float *mpart, unsigned *queue, hipStream_t st) {
+    return a.has_fill ? launch_wc_fill<MODE, true>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st)
+                      : launch_wc_fill<MODE, false>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st);
 }
 
 // the wave-cache form applies to: 32 float32 labels, x-march geometry with 4 x 8 patches
@@ -452,11 +499,11 @@ inline bool wc_applies(const TileGeom &tg, int G, const InterpArgs &a) {
 // minmax: the caller wants the value range of both maps (check_input_limits); without it the kernel does not track it (the partial
 // rows then carry +-inf, which nothing reads)
 inline int launch_wc(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store, bool minmax,
-                     const float *fixed, float *fpart, float *mpart, hipStream_t st) {
+                     const float *fixed, float *fpart, float *mpart, unsigned *queue, hipStream_t st) {
     switch (mode) {
-        case NRT_LOC_ABSOLUTE: return launch_wc_mode<NRT_LOC_ABSOLUTE>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st);
-        case NRT_LOC_SHIFT: return launch_wc_mode<NRT_LOC_SHIFT>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st);
-        default: return launch_wc_mode<NRT_LOC_LINSPACE>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st);
+        case NRT_LOC_ABSOLUTE: return launch_wc_mode<NRT_LOC_ABSOLUTE>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st);
+        case NRT_LOC_SHIFT: return launch_wc_mode<NRT_LOC_SHIFT>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st);
+        default: return launch_wc_mode<NRT_LOC_LINSPACE>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st);
     }
 }
 
@@ -467,7 +514,7 @@ int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, unsigned nbl
                             (int)WC_BLOCK_BYTES) != hipSuccess)
         return NRT_ERR_LAUNCH;
     hipLaunchKernelGGL((warp_dice_wc<MODE, true, false, FILL, false>), dim3(nrt_xcd_grid(nblocks * (unsigned)batch)), dim3(256), WC_BLOCK_BYTES, st,
-                       a, tg, (const float *)nullptr, (float *)nullptr, (float *)nullptr);
+                       a, tg, (const float *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned *)nullptr);
     return NRT_OK;
 }
 

@@ -100,6 +100,7 @@ struct TileGeom {
     // marched whole by one block each and the others in nseg pieces of seglen planes, the pieces LAST in launch order: the last round
     // of blocks is short, so the chip drains in a fraction of a march.  het_cpx = 0: every column in nseg equal pieces (xmarch_setup).
     unsigned het_cpx, het_full;
+    unsigned items_x;              // work items (blocks of the non-persistent launch) per XCD
 };
 
 // tune word of the tiled kernels: ltx | lty << 4 | ltz << 8 | z_outer << 12 | plane_major << 13 | x_march << 14 | LZ << 16
@@ -110,7 +111,7 @@ inline void tile_geometry(const int *out_shape, int G, int tune, int default_tun
     tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
     tg.plane_major = ((tune >> 13) & 1) && G == 8;
     tg.x_march = 0; tg.ncol = 0; tg.nseg = 1; tg.seglen = 0; tg.nbatch = 1; tg.lry = 0; tg.lrz = 0; tg.depth_sync = 0;
-    tg.het_cpx = 0; tg.het_full = 0;
+    tg.het_cpx = 0; tg.het_full = 0; tg.items_x = 0;
     if (tg.plane_major) {
         tg.ltx = 2; tg.lty = 3; tg.ltz = 0;
         tg.tz = (tune >> 16) & 0xfff;
@@ -172,6 +173,7 @@ inline unsigned xmarch_setup(const int *out_shape, int batch, int t, TileGeom &t
     if (nseg > (unsigned)out_shape[0]) nseg = (unsigned)out_shape[0];
     tg.seglen = ((unsigned)out_shape[0] + nseg - 1) / nseg;
     tg.nseg = ((unsigned)out_shape[0] + tg.seglen - 1) / tg.seglen;
+    tg.items_x = (tg.ncol * tg.nseg * (unsigned)batch + NRT_NXCD - 1) / NRT_NXCD;
     return tg.ncol * tg.nseg;
 }
 
@@ -207,14 +209,19 @@ inline unsigned xmarch_setup_mixed(const int *out_shape, int batch, int t, TileG
     tg.het_cpx = cpx; tg.het_full = bF;
     tg.nseg = bP;
     tg.seglen = ((unsigned)out_shape[0] + bP - 1) / bP;
-    grid = NRT_NXCD * (bF + (cpx - bF) * bP);
+    tg.items_x = bF + (cpx - bF) * bP;
+    grid = NRT_NXCD * tg.items_x;
     return tg.ncol * bP;
 }
 
 // device: the work of this block under either schedule.  false: nothing (the block exits; it owns no partial row)
 struct XmWork { int b; unsigned ucol, prow; int x0, xlen; bool whole; };
+__device__ __forceinline__ bool xmarch_work_at(const TileGeom &tg, int O0, unsigned k, unsigned jb, XmWork &w);
 __device__ __forceinline__ bool xmarch_work(const TileGeom &tg, int O0, XmWork &w) {
-    const unsigned k = blockIdx.x % NRT_NXCD, jb = blockIdx.x / NRT_NXCD;
+    return xmarch_work_at(tg, O0, blockIdx.x % NRT_NXCD, blockIdx.x / NRT_NXCD, w);
+}
+// item jb of XCD k's list (a persistent block may take items of another XCD's list when its own is empty)
+__device__ __forceinline__ bool xmarch_work_at(const TileGeom &tg, int O0, unsigned k, unsigned jb, XmWork &w) {
     if (tg.het_cpx) {
         unsigned cl, piece = 0;
         w.whole = jb < tg.het_full;
@@ -231,7 +238,7 @@ __device__ __forceinline__ bool xmarch_work(const TileGeom &tg, int O0, XmWork &
     }
     // one piece per block: XCD k owns the contiguous range [k * perU, (k + 1) * perU) of (batch, segment, patch)
     const unsigned per_batch = tg.ncol * tg.nseg, U = per_batch * tg.nbatch;
-    const unsigned perU = gridDim.x / NRT_NXCD;
+    const unsigned perU = tg.items_x ? tg.items_x : gridDim.x / NRT_NXCD;
     const unsigned u = k * perU + jb;
     if (jb >= perU || u >= U) return false;
     w.b = (int)(u / per_batch);

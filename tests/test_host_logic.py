@@ -804,9 +804,9 @@ def test_bench_quotes_traffic_only_for_the_timed_kernel(tmp_path):
     lib = ne._lib.lib()
     n160 = ne._lib.ints([160] * 3)
     assert lib.nrt_warp_dice_kernel_name(n160, n160, 32, 4, 1, 0, 0, 0, 0) in (b'warp_dice_tile<8, 1, false, 3, float>',
-                                                                              b'warp_dice_wc<1, false, false, false>')
+                                                                              b'warp_dice_wc<1, false, false, false, true, true>')
     assert lib.nrt_warp_dice_kernel_name(n160, n160, 32, 4, 1, 0, 0, 0, 1 << 30) == b'warp_dice_tile<8, 1, false, 3, float>'
-    assert lib.nrt_warp_dice_kernel_name(n160, n160, 32, 4, 1, 0, 0, 0, 1 << 29) == b'warp_dice_wc<1, false, false, false>'
+    assert lib.nrt_warp_dice_kernel_name(n160, n160, 32, 4, 1, 0, 0, 0, 1 << 29) == b'warp_dice_wc<1, false, false, false, true, true>'
     # the committed file itself has the keyed layout
     tj = json.load(open(os.path.join(root, 'profiles', 'hbm_traffic.json')))
     assert 'kernels' in tj and all('<' in k for k in tj['kernels'])
