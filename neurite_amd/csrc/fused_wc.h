@@ -507,14 +507,34 @@ inline int launch_wc(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, 
     }
 }
 
-// the warp alone through the same kernel (interpn.hip, variant 10): x-march geometry of the fused default
+// the warp alone through the same kernel (interpn.hip, variant 10): mixed block lengths, persistent blocks.  The work counters come
+// from a per-device ring of 64 sets (a launch takes the next one: launches that overlap on different streams do not share a set)
+inline unsigned *wc_queue_slot() {
+    static unsigned *ring[64];
+    static unsigned next[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ring[dev] && hipMalloc((void **)&ring[dev], 64 * NRT_NXCD * 64) != hipSuccess) { ring[dev] = nullptr; return nullptr; }
+    return ring[dev] + (size_t)(__atomic_fetch_add(&next[dev], 1u, __ATOMIC_RELAXED) % 64u) * (NRT_NXCD * 16);
+}
+
 template <int MODE, bool FILL>
-int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, hipStream_t st) {
+int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, hipStream_t st) {
+    const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
+    unsigned *queue = (NRT_FUSED_WCPERSIST && items > slots) ? wc_queue_slot() : nullptr;
+    if (queue) {
+        if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, true, false, FILL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)WC_BLOCK_BYTES) != hipSuccess || hipMemsetAsync(queue, 0, NRT_NXCD * 64, st) != hipSuccess)
+            return NRT_ERR_LAUNCH;
+        hipLaunchKernelGGL((warp_dice_wc<MODE, true, false, FILL, false, true>), dim3(nrt_xcd_grid(slots)), dim3(256), WC_BLOCK_BYTES, st, a, tg,
+                           (const float *)nullptr, (float *)nullptr, (float *)nullptr, queue);
+        return NRT_OK;
+    }
     if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, true, false, FILL, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)WC_BLOCK_BYTES) != hipSuccess)
         return NRT_ERR_LAUNCH;
-    hipLaunchKernelGGL((warp_dice_wc<MODE, true, false, FILL, false>), dim3(nrt_xcd_grid(nblocks * (unsigned)batch)), dim3(256), WC_BLOCK_BYTES, st,
-                       a, tg, (const float *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned *)nullptr);
+    hipLaunchKernelGGL((warp_dice_wc<MODE, true, false, FILL, false>), dim3(items), dim3(256), WC_BLOCK_BYTES, st, a, tg, (const float *)nullptr,
+                       (float *)nullptr, (float *)nullptr, (unsigned *)nullptr);
     return NRT_OK;
 }
 
@@ -526,29 +546,26 @@ bool nrt_wc_interpn_supported(const void *args, int batch) {
     if ((unsigned long long)a.nout * 128ull >= (1ull << 32)) return false;                 // 32-bit output offsets
     if ((long long)a.S[0] * a.S[1] >= (1 << 24) || a.S[2] >= (1 << 24) || (long long)a.O[0] * a.O[1] >= (1 << 24) || a.O[2] >= (1 << 24)) return false;
     TileGeom tg;
-    unsigned nblocks;
+    unsigned nblocks, grid;
     const int t = xmarch_default_tune();
     tile_geometry(a.O, 8, t, t, tg, nblocks);
-    xmarch_setup(a.O, batch, t, tg);
+    xmarch_setup_mixed(a.O, batch, t, tg, grid);
     return wc_applies(tg, 8, a);
 }
 
 int nrt_wc_interpn_launch(const void *args, int batch, int mode, void *stream) {
     const InterpArgs &a = *(const InterpArgs *)args;
     TileGeom tg;
-    unsigned nblocks;
+    unsigned nblocks, grid;
     const int t = xmarch_default_tune();
     tile_geometry(a.O, 8, t, t, tg, nblocks);
-    nblocks = xmarch_setup(a.O, batch, t, tg);
+    xmarch_setup_mixed(a.O, batch, t, tg, grid);
     hipStream_t st = nrt_stream(stream);
     int rc;
     switch (mode) {
-        case NRT_LOC_ABSOLUTE: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_ABSOLUTE, true>(a, tg, nblocks, batch, st)
-                                               : launch_wc_interpn_inst<NRT_LOC_ABSOLUTE, false>(a, tg, nblocks, batch, st); break;
-        case NRT_LOC_SHIFT: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_SHIFT, true>(a, tg, nblocks, batch, st)
-                                            : launch_wc_interpn_inst<NRT_LOC_SHIFT, false>(a, tg, nblocks, batch, st); break;
-        default: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_LINSPACE, true>(a, tg, nblocks, batch, st)
-                                 : launch_wc_interpn_inst<NRT_LOC_LINSPACE, false>(a, tg, nblocks, batch, st); break;
+        case NRT_LOC_ABSOLUTE: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_ABSOLUTE, true>(a, tg, st) : launch_wc_interpn_inst<NRT_LOC_ABSOLUTE, false>(a, tg, st); break;
+        case NRT_LOC_SHIFT: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_SHIFT, true>(a, tg, st) : launch_wc_interpn_inst<NRT_LOC_SHIFT, false>(a, tg, st); break;
+        default: rc = a.has_fill ? launch_wc_interpn_inst<NRT_LOC_LINSPACE, true>(a, tg, st) : launch_wc_interpn_inst<NRT_LOC_LINSPACE, false>(a, tg, st); break;
     }
     if (rc != NRT_OK) return rc;
     NRT_CHECK_LAUNCH();

@@ -169,41 +169,33 @@ def labels_to_image(in_shape, in_label_list, out_label_list=None, out_shape=None
     parameters and defaults.  Returns a module: `image, labels[, vel][, def] = model(label_map [B, *in_shape, 1])`.
     """
     warnings.warn('model `labels_to_image` is deprecated in favor `labels_to_image_new`')
-    if input_model is not None:
-        raise NotImplementedError('labels_to_image: input_model chaining is not implemented; call the models in sequence')
-    if out_shape is None:
-        out_shape = in_shape
-    in_shape, out_shape = map(np.asarray, (in_shape, out_shape))
-    num_dim = len(in_shape)
-    in_label_list = np.int32(np.unique(in_label_list))
-    num_in_labels = len(in_label_list)
-    in_lut = np.zeros(np.max(in_label_list) + 1, dtype=np.float32)
-    for i, lab in enumerate(in_label_list):
-        in_lut[lab] = i
-    if mean_min is None:
-        mean_min = [0] + [25] * (num_in_labels - 1)
-    if mean_max is None:
-        mean_max = [225] * num_in_labels
-    if std_min is None:
-        std_min = [0] + [5] * (num_in_labels - 1)
-    if std_max is None:
-        std_max = [25] * num_in_labels
+    in_shape = np.asarray(in_shape)
+    out_shape = in_shape if out_shape is None else np.asarray(out_shape)
+    num_dim = in_shape.size
+
+    # label tables (models.py:777-783, 846-865) as vectorised look-ups.  Input labels -> ranks 0 .. N-1 (their sorted order) ...
+    in_label_list = np.unique(in_label_list).astype(np.int32)
+    num_in_labels = in_label_list.size
+    in_lut = np.zeros(int(in_label_list[-1]) + 1, np.float32)
+    in_lut[in_label_list] = np.arange(num_in_labels, dtype=np.float32)
+    # ... rank -> output label (0 for labels the caller drops); a sequence of labels stands for the identity mapping on them
     if out_label_list is None:
         out_label_list = in_label_list
-    if isinstance(out_label_list, (tuple, list, np.ndarray)):
-        out_label_list = {lab: lab for lab in out_label_list}
-    out_lut = np.zeros(num_in_labels, dtype='int32')
-    for i, lab in enumerate(in_label_list):
-        if lab in out_label_list:
-            out_lut[i] = out_label_list[lab]
+    mapping = dict(out_label_list) if isinstance(out_label_list, dict) else {lab: lab for lab in np.asarray(out_label_list).tolist()}
+    out_lut = np.array([mapping.get(int(lab), 0) for lab in in_label_list], np.int32)
     depth = 0
-    if one_hot:
-        hot_label_list = np.unique(list(out_label_list.values()))
-        hot_lut = np.full(hot_label_list[-1] + 1, fill_value=-1, dtype='int32')
-        for i, lab in enumerate(hot_label_list):
-            hot_lut[lab] = i
+    if one_hot:                                   # ... and output label -> one-hot channel (its rank among the output labels)
+        hot_labels = np.unique(np.fromiter(mapping.values(), dtype=np.int64))
+        hot_lut = np.full(int(hot_labels[-1]) + 1, -1, np.int32)
+        hot_lut[hot_labels] = np.arange(hot_labels.size, dtype=np.int32)
         out_lut = hot_lut[out_lut]
-        depth = len(hot_label_list)
+        depth = int(hot_labels.size)
+
+    # intensity ranges per input label (models.py:812-819): the first label (background) gets zero mean / spread at the low end
+    def per_label(value, first, rest):
+        return [first] + [rest] * (num_in_labels - 1) if value is None else value
+    mean_min, mean_max = per_label(mean_min, 0, 25), per_label(mean_max, 225, 225)
+    std_min, std_max = per_label(std_min, 0, 5), per_label(std_max, 25, 25)
     cfg = dict(in_shape=tuple(int(s) for s in in_shape), out_shape=out_shape.astype(np.int64), num_dim=num_dim,
                num_chan=int(num_chan), num_in_labels=num_in_labels, in_lut=in_lut, out_lut=np.ascontiguousarray(out_lut, np.int32),
                depth=depth, mean_min=mean_min, mean_max=mean_max, std_min=std_min, std_max=std_max,
@@ -211,7 +203,27 @@ def labels_to_image(in_shape, in_label_list, out_label_list=None, out_shape=None
                bias_res=bias_res, bias_std=bias_std, bias_modulate=bias_modulate, blur_std=blur_std,
                blur_modulate=blur_modulate, normalize=normalize, gamma_std=gamma_std, dc_offset=dc_offset, one_hot=one_hot,
                seeds=dict(seeds), return_vel=return_vel, return_def=return_def, id=id)
-    return SynthModel(cfg)
+    model = SynthModel(cfg)
+    if input_model is None:
+        return model
+    # models.py:763-769: the generator is appended to `input_model` (one output = the label map); the returned model takes
+    # input_model's inputs
+    return _Chained(input_model, model)
+
+
+class _Chained(torch.nn.Module):
+    """`input_model` followed by the generator: labels = input_model(*inputs) (exactly one output), then the synthesis."""
+
+    def __init__(self, first, second):
+        super().__init__()
+        self.first, self.second = first, second
+
+    def forward(self, *inputs):
+        labels = self.first(*inputs)
+        if isinstance(labels, (list, tuple)):
+            assert len(labels) == 1, 'labels_to_image: input_model must have exactly one output'
+            labels = labels[0]
+        return self.second(labels)
 
 
 # ======================================================================================================================
@@ -442,9 +454,8 @@ def labels_to_image_new(labels_in, labels_out=None, in_shape=None, out_shape=Non
     Returns a module: `outputs = model(label_map [B, *in_shape, 1])` in the reference's order (image, labels, vel, def, aff,
     mean, bias -- those requested).
     """
-    if input_model is not None:
-        raise NotImplementedError('labels_to_image_new: input_model chaining is not implemented; call the models in sequence')
     if in_shape is None:
+        # models.py:1083 reads the shape off input_model's symbolic output; a torch module has none, so it is always passed
         raise ValueError('labels_to_image_new needs in_shape (the spatial shape of the input label maps)')
     if not (isinstance(bias_func, str) and bias_func == 'exp') and getattr(bias_func, '__name__', '') != 'exp':
         raise NotImplementedError('labels_to_image_new: bias_func must be the exponential')
@@ -498,4 +509,6 @@ def labels_to_image_new(labels_in, labels_out=None, in_shape=None, out_shape=Non
                one_hot=one_hot, half_res=half_res, seeds=seeds, return_im=return_im, return_map=return_map, return_vel=return_vel,
                return_def=return_def, return_aff=return_aff, return_mean=return_mean, return_bias=return_bias, id=id,
                gen_lut=gen_lut, num_label=num_label, out_lut=out_lut, depth=len(labels_out_set))
-    return SynthModelNew(cfg)
+    model = SynthModelNew(cfg)
+    # models.py:1074-1077, 1301: the generator is appended to `input_model` and the result takes input_model's inputs
+    return model if input_model is None else _Chained(input_model, model)

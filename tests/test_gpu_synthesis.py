@@ -152,3 +152,24 @@ def test_synthstrip_forward_and_training_step(dev):
     loss.backward()
     grads = [p.grad for p in model.unet.parameters()]
     assert all(g is not None and torch.isfinite(g).all() for g in grads) and any(float(g.abs().max()) > 0 for g in grads)
+
+
+def test_input_model_is_chained_in_front(dev):
+    """models.py:763-774 / 1074-1077: with `input_model` the generator consumes its single output and takes its inputs"""
+    labels = [0, 2, 3]
+    S = 16
+
+    class Relabel(torch.nn.Module):                      # a front model: {0, 1, 2} -> the label values the generator expects
+        def forward(self, x):
+            return torch.tensor(labels, device=x.device, dtype=torch.int32)[x.long()]
+    raw = label_map(dev, 1, S, [0, 1, 2])
+    seeds = dict(warp=3, mean=4, std=5, noise=6, blur=8, bias=9, gamma=10)
+    plain, chained = make((S, S, S), labels, seeds=seeds), make((S, S, S), labels, seeds=seeds, input_model=Relabel())
+    want, got = plain(Relabel()(raw)), chained(raw)
+    assert len(want) == len(got) == 2
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)                          # same seeds -> the same draws -> the same image and label maps
+    new = ne.models.labels_to_image_new(labels, in_shape=(S, S, S), input_model=Relabel(), seeds=dict(warp=1, mean=2, noise=3, bias=4, blur=5, gamma=6))
+    ref = ne.models.labels_to_image_new(labels, in_shape=(S, S, S), seeds=dict(warp=1, mean=2, noise=3, bias=4, blur=5, gamma=6))
+    for a, b in zip(ref(Relabel()(raw)), new(raw)):
+        assert torch.equal(a, b)

@@ -400,8 +400,20 @@ def test_gaussian_kernel_and_synthesis_tables_cpu():
     assert c['num_in_labels'] == 4 and c['in_lut'][[0, 3, 5, 17]].tolist() == [0, 1, 2, 3]       # np.unique sorts: 0, 3, 5, 17
     assert c['depth'] == 2 and c['out_lut'].tolist() == [-1, 0, 1, 0]             # one-hot over {1, 2}; background dropped (-1)
     assert c['mean_min'] == [0, 25, 25, 25] and c['std_max'] == [25] * 4
-    with pytest.raises(NotImplementedError):
-        ne.models.labels_to_image((8, 8, 8), [0, 1], input_model=object())
+    # models.py:763-769: with `input_model` the generator is appended to it and takes ITS inputs
+    calls = []
+
+    class Front(torch.nn.Module):
+        def forward(self, x):
+            calls.append(tuple(x.shape))
+            return [x]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        chained = ne.models.labels_to_image((8, 8, 8), [0, 1], input_model=Front())
+    assert isinstance(chained.first, Front) and chained.second.cfg['num_in_labels'] == 2
+    with pytest.raises(ne.errors.NeuriteAmdError):                       # the generator itself has no CPU path
+        chained(torch.zeros(1, 8, 8, 8, 1))
+    assert calls == [(1, 8, 8, 8, 1)]
 
 
 def test_affine_sampling_helpers_cpu():
@@ -464,8 +476,9 @@ def test_labels_to_image_new_tables_cpu():
         ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), seeds=dict(nonsense=1))
     with pytest.raises(AssertionError, match='gamma value'):
         ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), gamma=1.5)
-    with pytest.raises(NotImplementedError):
-        ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), input_model=object())
+    front = torch.nn.Identity()
+    chained = ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), input_model=front)     # models.py:1074-1077, 1301
+    assert chained.first is front and chained.second.cfg['out_shape'].tolist() == [8, 8, 8]
     assert ne.models.labels_to_image_new([0, 1], in_shape=(8, 8, 8), out_shape=(8, 8, 8), half_res=True).cfg['out_shape'].tolist() == [4, 4, 4]
 
 
