@@ -163,13 +163,15 @@ def test_input_model_is_chained_in_front(dev):
         def forward(self, x):
             return torch.tensor(labels, device=x.device, dtype=torch.int32)[x.long()]
     raw = label_map(dev, 1, S, [0, 1, 2])
-    seeds = dict(warp=3, mean=4, std=5, noise=6, blur=8, bias=9, gamma=10)
+    seeds = dict(warp=3, mean=4, std=5, noise=6, background=7, blur=8, bias=9, gamma=10, dc_offset=11)
     plain, chained = make((S, S, S), labels, seeds=seeds), make((S, S, S), labels, seeds=seeds, input_model=Relabel())
     want, got = plain(Relabel()(raw)), chained(raw)
     assert len(want) == len(got) == 2
     for a, b in zip(want, got):
         assert torch.equal(a, b)                          # same seeds -> the same draws -> the same image and label maps
-    new = ne.models.labels_to_image_new(labels, in_shape=(S, S, S), input_model=Relabel(), seeds=dict(warp=1, mean=2, noise=3, bias=4, blur=5, gamma=6))
-    ref = ne.models.labels_to_image_new(labels, in_shape=(S, S, S), seeds=dict(warp=1, mean=2, noise=3, bias=4, blur=5, gamma=6))
+    every = {k: i + 1 for i, k in enumerate(('shift', 'rot', 'scale', 'shear', 'flip', 'swap', 'warp', 'crop', 'mean', 'bias', 'noise',
+                                             'background', 'blur', 'slice', 'gamma'))}
+    new = ne.models.labels_to_image_new(labels, in_shape=(S, S, S), input_model=Relabel(), seeds=every)
+    ref = ne.models.labels_to_image_new(labels, in_shape=(S, S, S), seeds=every)
     for a, b in zip(ref(Relabel()(raw)), new(raw)):
         assert torch.equal(a, b)
