@@ -559,18 +559,57 @@ def unet_train_bench(dev, size=160, labels=32, reps=3):
     net.train()
     x = torch.randn(1, size, size, size, 1, device=dev)
     t = torch.nn.functional.one_hot(torch.randint(0, labels, (1, size, size, size), device=dev), labels).float()
-    cce, dice = ne.losses.CategoricalCrossentropy(), ne.metrics.Dice(check_input_limits=False)
+    cce, dice = ne.losses.CategoricalCrossentropy(), ne.losses.Dice(check_input_limits=False)
+    # neurite/tf/losses.py:225-246: the pair goes through one joint pass per direction (csrc/segloss.hip).  dice.loss is the [B, L]
+    # negative Dice (losses.py:68-80); its mean is taken here so that the step holds no device->host read (mean_loss's finite check)
+    seg_loss = ne.losses.multiple_losses_decorator([cce.loss, dice.loss])
     params = list(net.parameters())
 
-    def seg_step():
-        y = net(x)
-        (cce(t, y) - dice.mean_dice(t, y)).backward()
+    def sgd():
+        with torch.no_grad():
+            torch._foreach_add_(params, [p.grad for p in params], alpha=-1e-4)
+
+    def step_with(loss_fn, update=sgd):
+        def seg_step():
+            for p in params:
+                p.grad = None
+            loss_fn(t, net(x)).mean().backward()
+            update()
+        return seg_step
+
+    def sgd_per_tensor():
         with torch.no_grad():
             for p in params:
                 p -= 1e-4 * p.grad
-                p.grad = None
-    seg_ms = _timeit(seg_step, reps)
-    return {'what': 'BASELINE config 3 unet, forward + backward + SGD, batch 1', 'ms': round(seg_ms, 3)}
+    out = {'what': 'BASELINE config 3 unet, forward + backward + SGD, batch 1; loss = multiple_losses_decorator([CCE, -Dice]).mean()'}
+    out['ms'] = round(_timeit(step_with(seg_loss), reps), 3)
+    out['ms_two_losses_separately'] = round(_timeit(step_with(lambda a, b: cce.loss(a, b) + dice.loss(a, b)), reps), 3)
+    out['ms_round3_form'] = round(_timeit(step_with(lambda a, b: cce.loss(a, b) + dice.mean_loss(a, b), sgd_per_tensor), reps), 3)
+    # the same step as ONE hipGraph launch: about 300 kernel launches of 4 us .. 0.8 ms, a third of them shorter than their own launch
+    # cost, so the eager step is partly bound by the host
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step_with(seg_loss)()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in params:
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = seg_loss(t, net(x)).mean()
+            loss.backward()
+            sgd()
+        graph.replay()
+        first = float(loss)
+        out['ms_as_one_hipgraph'] = round(_timeit(graph.replay, max(reps, 5)), 3)
+        out['hipgraph_loss_first_and_last_replay'] = [round(first, 6), round(float(loss), 6)]
+    except Exception as e:       # noqa
+        out['ms_as_one_hipgraph'] = None
+        out['hipgraph_error'] = str(e)[:200]
+    return out
 
 
 def timed(step, steps, warmup, dist=None, dev=None):

@@ -442,6 +442,26 @@ int nrt_wcce_bwd_f32(const float *y_true, const float *y_pred, const float *labe
                      int from_logits, float label_smoothing, float scale, float *grad_pred, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Segmentation training loss: soft Dice (neurite/tf/metrics.py:415-482) AND the label-weighted categorical cross-entropy
+ * (metrics.py:619-650, probabilities, not logits) of the same pair of maps [batch, nvox, nlabels] float32 in one pass per direction --
+ * what neurite/tf/losses.py:225-246 (multiple_losses_decorator) evaluates as two losses over the unet's soft-max output
+ * (models.py:1545-1555).  nlabels = 4, 8, ..., 256 (a power of two; nrt_seg_loss_supported), 16-byte aligned maps.
+ *   nrt_seg_loss_f32       sums [batch, 3, L], dice [batch, L], minmax [4] or NULL exactly as nrt_dice_soft_f32 (normalize = 0);
+ *                          cce_sum [1] exactly as nrt_wcce (from_logits = 0, no per-voxel output).
+ *   nrt_seg_loss_bwd_f32   grad = d( sum_bl grad_dice[b,l] dice[b,l] + grad_cce[0] cce_sum ) / d y_pred (either upstream pointer may
+ *                          be NULL = 0); through_softmax != 0: y_pred = softmax(z) over the labels and grad = d / d z (what the
+ *                          head's nrt_softmax_bwd_f32 would make of it).
+ * ------------------------------------------------------------------------------------------ */
+int nrt_seg_loss_supported(int nlabels);
+size_t nrt_seg_loss_workspace_bytes(long long nvox, int nlabels, int batch);
+int nrt_seg_loss_f32(const float *y_true, const float *y_pred, const float *label_weights, long long nvox, int nlabels, int batch,
+                     float label_smoothing, float laplace_smoothing, float *sums, float *dice, float *minmax, float *cce_sum,
+                     void *workspace, size_t workspace_bytes, void *stream);
+int nrt_seg_loss_bwd_f32(const float *y_true, const float *y_pred, const float *label_weights, const float *sums,
+                         const float *grad_dice, const float *grad_cce, long long nvox, int nlabels, int batch,
+                         float label_smoothing, float laplace_smoothing, int through_softmax, float *grad, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Synthesis front-end: separable filtering and min-max normalisation
  *   nrt_conv1d_axis_f32   one pass of utils.separable_conv (neurite/tf/utils/utils.py:665-751) / layers.GaussianBlur
  *                         (layers.py:251-364): the tensor viewed as [outer, axis_len, inner] around the filtered axis,

@@ -48,6 +48,10 @@ _SIGNATURES = {
     'nrt_dice_from_sums_f32': (_i, [_vp, _i, _i, _f, _vp, _vp]),
     'nrt_dice_mean_pair_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'nrt_wcce_workspace_bytes': (_sz, [_ll, _i]),
+    'nrt_seg_loss_supported': (_i, [_i]),
+    'nrt_seg_loss_workspace_bytes': (_sz, [_ll, _i, _i]),
+    'nrt_seg_loss_f32': (_i, [_vp, _vp, _vp, _ll, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nrt_seg_loss_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _f, _f, _i, _vp, _vp]),
     'nrt_warp_dice_workspace_bytes': (_sz, [_ip, _i, _i, _i]),
     'nrt_warp_dice_soft_f32': (_i, [_vp, _vp, _vp, _vp, _ip, _ip, _i, _i, _ll, _i, _i, _f, _f, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     'nrt_warp_dice_kernel_name': (C.c_char_p, [_ip, _ip, _i, _i, _i, _i, _i, _i, _i]),

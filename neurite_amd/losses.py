@@ -59,15 +59,34 @@ class MeanSquaredErrorProb(metrics.MeanSquaredErrorProb):
         return self.mse(*args, **kwargs)
 
 
+def _owner(fn, cls, names):
+    """the `cls` instance a loss callable belongs to (a bound method named in `names`, or the callable object itself)"""
+    if isinstance(fn, cls):
+        return fn
+    obj = getattr(fn, '__self__', None)
+    return obj if isinstance(obj, cls) and getattr(fn, '__name__', '') in names else None
+
+
 def multiple_losses_decorator(losses, weights=None):
-    """neurite/tf/losses.py:225-246."""
-    if weights is None:
-        weights = np.ones(len(losses))
+    """
+    Weighted sum of several losses of one output (neurite/tf/losses.py:225-246): returns loss(y_true, y_pred).
+    When the list holds exactly one soft-Dice method and one CategoricalCrossentropy method of this package -- the segmentation
+    pair -- both take their numbers from one pass over the maps, and one pass back that also runs through the soft-max that made
+    y_pred (metrics.JointSegLoss, csrc/segloss.hip); every value is what the two losses return on their own.
+    """
+    scale = np.ones(len(losses)) if weights is None else weights
+    dice_objs = [o for o in (_owner(f, metrics.Dice, ('loss', 'mean_loss', 'dice', 'mean_dice')) for f in losses) if o is not None]
+    cce_objs = [o for o in (_owner(f, metrics.CategoricalCrossentropy, ('loss', 'cce', '__call__')) for f in losses) if o is not None]
+    pair = (dice_objs[0], cce_objs[0]) if len(dice_objs) == 1 and len(cce_objs) == 1 else None
+
+    def weighted_sum(y_true, y_pred):
+        return sum(scale[k] * fn(y_true, y_pred) for k, fn in enumerate(losses))
 
     def loss(y_true, y_pred):
-        total_val = 0
-        for idx, los in enumerate(losses):
-            total_val += weights[idx] * los(y_true, y_pred)
-        return total_val
+        joint = metrics.JointSegLoss.open(*pair, y_true, y_pred) if pair is not None else None
+        if joint is None:
+            return weighted_sum(y_true, y_pred)
+        with joint:
+            return weighted_sum(y_true, y_pred)
 
     return loss

@@ -20,7 +20,7 @@ from . import utils
 from .errors import InvalidArgumentError
 
 __all__ = ['Dice', 'SoftDice', 'HardDice', 'CategoricalCrossentropy', 'WeightedCategoricalCrossentropy',
-           'dice_partial_sums', 'MutualInformation', 'MeanSquaredErrorProb']
+           'dice_partial_sums', 'MutualInformation', 'MeanSquaredErrorProb', 'JointSegLoss']
 
 _INT_DTYPES = (torch.int8, torch.uint8, torch.int16, torch.int32, torch.int64, torch.bool)
 
@@ -175,6 +175,133 @@ class _WcceFn(torch.autograd.Function):
         return None, gp, None, None, None, None
 
 
+class _SegLossFn(torch.autograd.Function):
+    """
+    Soft Dice [B, L] and the weighted CCE sum [1] of one pair of float32 maps from ONE pass over them (csrc/segloss.hip), and one
+    pass back.  `src` (models.SoftmaxSource or None): y_pred is the untouched soft-max output of a producer whose autograd inputs
+    are `src_inputs`; the backward then forms d loss / d logits itself and hands it to the producer's gradient routine, and y_pred
+    enters detached -- no gradient wrt the probabilities and no separate soft-max backward pass exist.
+    """
+
+    @staticmethod
+    def forward(ctx, t, p, w, cfg, src, *src_inputs):
+        eps, smoothing, check_limits = cfg
+        lib = _lib.lib()
+        dev = p.device
+        B, L = p.shape[0], p.shape[-1]
+        V = p.numel() // (B * L)
+        sums = torch.empty((B, 3, L), dtype=torch.float32, device=dev)
+        dice = torch.empty((B, L), dtype=torch.float32, device=dev)
+        minmax = torch.empty((4,), dtype=torch.float32, device=dev)
+        cce_sum = torch.empty((1,), dtype=torch.float32, device=dev)
+        nws = lib.nrt_seg_loss_workspace_bytes(V, L, B)
+        ws = _lib.workspace(dev, nws)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_seg_loss_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(w), V, L, B, float(smoothing), float(eps), _lib.ptr(sums),
+                                      _lib.ptr(dice), _lib.ptr(minmax), _lib.ptr(cce_sum), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_seg_loss_f32')
+        if check_limits:
+            _check_limits(minmax)
+        ctx.save_for_backward(t, p, w, sums)
+        ctx.cfg, ctx.src = cfg, src
+        return cce_sum, dice
+
+    @staticmethod
+    def backward(ctx, g_cce, g_dice):
+        t, p, w, sums = ctx.saved_tensors
+        eps, smoothing, _ = ctx.cfg
+        src = ctx.src
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError('neurite_amd: the joint Dice + CCE loss has no gradient wrt y_true')
+        lib = _lib.lib()
+        dev = p.device
+        B, L = p.shape[0], p.shape[-1]
+        V = p.numel() // (B * L)
+        g_cce = g_cce.to(torch.float32).contiguous()
+        g_dice = g_dice.to(torch.float32).contiguous()
+        grad = torch.empty_like(p)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_seg_loss_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(w), _lib.ptr(sums), _lib.ptr(g_dice), _lib.ptr(g_cce), V, L, B,
+                                          float(smoothing), float(eps), int(src is not None), _lib.ptr(grad), _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_seg_loss_bwd_f32')
+        if src is None:
+            return (None, grad, None, None, None)
+        return (None, None, None, None, None) + tuple(src.grads_from_dz(grad, ctx.needs_input_grad[5:]))
+
+
+class JointSegLoss:
+    """
+    One evaluation of a soft Dice object and a CategoricalCrossentropy object on the same (y_true, y_pred) -- the pair of losses
+    neurite/tf/losses.py:225-246 (multiple_losses_decorator) sums for a segmentation net.  While a JointSegLoss is open (a `with`
+    block on this thread), `dice_obj.dice(y_true, y_pred)` and `cce_obj.cce(y_true, y_pred)` called with THESE tensor objects take
+    their numbers from one shared _SegLossFn application; everything else those methods do (weights, means, reductions, the finite
+    check) is unchanged.  `JointSegLoss.open(...)` returns None when the pair does not qualify (then nothing is intercepted).
+    """
+    _tls = __import__('threading').local()
+    applications = 0            # _SegLossFn evaluations so far (tests check that the joint path really ran)
+    through_softmax = 0         # ... of which attached to the producer of the soft-max
+
+    def __init__(self, dice_obj, cce_obj, y_true, y_pred):
+        self.dice_obj, self.cce_obj, self.y_true, self.y_pred = dice_obj, cce_obj, y_true, y_pred
+        self._result = None
+
+    @classmethod
+    def open(cls, dice_obj, cce_obj, y_true, y_pred):
+        from .deferred import DeferredWarp
+        if not (isinstance(y_true, torch.Tensor) and isinstance(y_pred, torch.Tensor)) or \
+                isinstance(y_true, DeferredWarp) or isinstance(y_pred, DeferredWarp):
+            return None
+        if dice_obj.dice_type != 'soft' or dice_obj.normalize or cce_obj.from_logits or cce_obj.reduction == 'none':
+            return None
+        if not y_pred.is_cuda or y_true.device != y_pred.device or y_pred.dtype != torch.float32 or y_true.shape != y_pred.shape:
+            return None
+        if y_pred.dim() < 2 or y_pred.numel() == 0 or not y_true.dtype.is_floating_point or y_true.dtype == torch.float64:
+            return None
+        if y_true.requires_grad and torch.is_grad_enabled():
+            return None
+        L = y_pred.shape[-1]
+        if cce_obj.label_weights is not None and cce_obj.label_weights.shape[-1] != L:
+            return None                                      # the CCE raises its own error on the ordinary path
+        if not _lib.lib().nrt_seg_loss_supported(L) or y_pred.shape[0] > 65535:
+            return None
+        return cls(dice_obj, cce_obj, y_true, y_pred)
+
+    def __enter__(self):
+        self._prev = getattr(self._tls, 'current', None)
+        self._tls.current = self
+        return self
+
+    def __exit__(self, *exc):
+        self._tls.current = self._prev
+        return False
+
+    @classmethod
+    def lookup(cls, owner, y_true, y_pred):
+        j = getattr(cls._tls, 'current', None)
+        if j is not None and (owner is j.dice_obj or owner is j.cce_obj) and y_true is j.y_true and y_pred is j.y_pred:
+            return j
+        return None
+
+    def result(self):
+        """(cce_sum [1], dice [B, L]); computed at the first request"""
+        if self._result is None:
+            p = self.y_pred.contiguous()
+            t = self.y_true.detach().to(torch.float32).contiguous()
+            if p.data_ptr() % 16 or t.data_ptr() % 16:
+                p, t = p.clone(), t.clone()
+            lw = self.cce_obj.label_weights
+            w = None if lw is None else lw.to(p.device, torch.float32).contiguous()
+            cfg = (float(self.dice_obj.laplace_smoothing), float(self.cce_obj.label_smoothing), bool(self.dice_obj.check_input_limits))
+            src = getattr(self.y_pred, '_nrt_softmax_src', None)
+            JointSegLoss.applications += 1
+            if src is not None and p is self.y_pred and src.valid_for(self.y_pred):
+                JointSegLoss.through_softmax += 1
+                self._result = _SegLossFn.apply(t, p.detach(), w, cfg, src, *src.inputs)
+            else:
+                self._result = _SegLossFn.apply(t, p, w, cfg, None)
+        return self._result
+
+
 def _check_limits(minmax):
     mn_t, mx_t, mn_p, mx_p = [float(v) for v in minmax.tolist()]      # one device->host sync
     msg = 'value outside range'
@@ -242,6 +369,9 @@ class Dice:
         eps = float(self.laplace_smoothing)
 
         if self.dice_type != 'hard':
+            joint = JointSegLoss.lookup(self, y_true, y_pred)
+            if joint is not None:
+                return joint.result()[1]
             if torch.is_grad_enabled() and (y_true.requires_grad or y_pred.requires_grad):
                 from .deferred import materialize
                 return _SoftDiceFn.apply(materialize(y_true), materialize(y_pred), eps, bool(self.normalize),
@@ -403,7 +533,8 @@ class CategoricalCrossentropy:
         w = None if self.label_weights is None else self.label_weights.to(dev, torch.float32).contiguous()
         N = p.numel() // max(yf, 1)
         need_pv = sample_weight is not None or self.reduction == 'none'
-        res = _WcceFn.apply(t, p, w, self.from_logits, self.label_smoothing, need_pv)
+        joint = None if need_pv else JointSegLoss.lookup(self, y_true, y_pred)
+        res = joint.result()[0] if joint is not None else _WcceFn.apply(t, p, w, self.from_logits, self.label_smoothing, need_pv)
         if not need_pv:
             return res[0] if self.reduction == 'sum' else res[0] / N
         losses = res

@@ -215,7 +215,7 @@ class _Conv(nn.Module):
         else:
             y = self._run(x, lo, up, variant)
         if self.post_softmax:
-            return _SoftmaxFn.apply(y) if (torch.is_grad_enabled() and y.requires_grad) else _softmax(y)
+            return _softmax_with_grad(y) if (torch.is_grad_enabled() and y.requires_grad) else _softmax(y)
         return y
 
     def _run(self, x, lo=None, up=None, variant=0):
@@ -434,18 +434,31 @@ _FOLD_A = ((( 1, 0, 0), (0, 1, 1)), ((1, 1, 0), (0, 0, 1)))
 _FOLD_B = (((0, 0, 0), (0, 1, 1), (1, 0, 0)), ((0, 0, 1), (1, 1, 0), (0, 0, 0)))
 
 
+_FOLD_ON_DEVICE = {}
+
+
+def _fold_table(table, like):
+    """_FOLD_A / _FOLD_B as a tensor on `like`'s device, uploaded once (a host->device copy per step would also keep the training
+    step out of a hipGraph: copies from pageable memory are not capturable)"""
+    key = (table is _FOLD_A, like.device, like.dtype)
+    m = _FOLD_ON_DEVICE.get(key)
+    if m is None:
+        m = _FOLD_ON_DEVICE[key] = torch.tensor(table, dtype=like.dtype, device=like.device)
+    return m
+
+
 def _fold_dgrad_weights(k_lo):
     """kernel rows of the up-sampled channels [3,3,3,c1,cout] -> the 3x3x3 kernel [3,3,3, 8 * cout, c1] that maps the
     space-to-depth gradient (parity group P = (px*2 + py)*2 + pz, channels P*cout + co) to the gradient of the
     low-resolution tensor; only 2 x 2 x 2 taps per parity group are non-zero."""
-    Bm = torch.tensor(_FOLD_B, dtype=k_lo.dtype, device=k_lo.device)
+    Bm = _fold_table(_FOLD_B, k_lo)
     c1, cout = k_lo.shape[3], k_lo.shape[4]
     return torch.einsum('xea,yfb,zgc,abcio->efgxyzoi', Bm, Bm, Bm, k_lo).reshape(3, 3, 3, 8 * cout, c1).contiguous()
 
 
 def _unfold_wgrad(dwf):
     """folded weight gradient [8 parity groups, 8 taps, c1, cout] -> [3,3,3,c1,cout]"""
-    Am = torch.tensor(_FOLD_A, dtype=dwf.dtype, device=dwf.device)
+    Am = _fold_table(_FOLD_A, dwf)
     c1, cout = dwf.shape[2], dwf.shape[3]
     return torch.einsum('xta,yub,zvc,xyztuvio->abcio', Am, Am, Am, dwf.reshape(2, 2, 2, 2, 2, 2, c1, cout))
 
@@ -632,6 +645,47 @@ class _MergeFn(torch.autograd.Function):
         return dskip, dlo, None
 
 
+def _head_grads(x, kernel, mod, dz, needs):
+    """(dx, dw, db) of the likelihood conv from dz = d loss / d logits; needs = which of the three are wanted"""
+    lib = _lib.lib()
+    dev = dz.device
+    dx = dw = db = None
+    if needs[1] or needs[2]:
+        xin = x.contiguous()
+        dw = torch.zeros_like(kernel, dtype=torch.float32)
+        db = torch.zeros(mod.cout, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xin), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(db), xin.shape[0],
+                                          _lib.ints(list(xin.shape[1:4])), mod.cin, mod.cout, _lib.ints(mod.ksize3), 1,
+                                          _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv3d_wgrad_f32')
+    if needs[0]:
+        dx = _conv_dgrad(dz, kernel.detach(), mod.ksize3, 1)
+    return dx, dw, db
+
+
+class SoftmaxSource:
+    """
+    Stamp (`y._nrt_softmax_src`) on a channel soft-max output that is still its producer's untouched result: `inputs` are the
+    autograd inputs of the producer and `grads_from_dz(dz, needs)` turns d loss / d logits into their gradients.  A loss that can
+    form dz itself (metrics._SegLossFn: Dice + CCE of the prediction) attaches to `inputs` directly, and the gradient wrt the
+    probabilities -- with the separate soft-max backward pass over it -- is never materialised.
+    """
+
+    def __init__(self, y, inputs, grads_from_dz):
+        self.inputs, self.grads_from_dz = tuple(inputs), grads_from_dz
+        self.version = y._version
+
+    def valid_for(self, y):
+        return y._version == self.version and torch.is_grad_enabled() and y.requires_grad
+
+
+def _stamp_softmax(y, inputs, grads_from_dz):
+    if torch.is_grad_enabled() and y.requires_grad:
+        y._nrt_softmax_src = SoftmaxSource(y, inputs, grads_from_dz)
+    return y
+
+
 class _HeadFn(torch.autograd.Function):
     """likelihood 1x1 conv + channel softmax in one pass (no logits tensor); backward from the prediction alone."""
 
@@ -646,7 +700,6 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, kernel, y = ctx.saved_tensors
-        mod = ctx.mod
         lib = _lib.lib()
         dev = g.device
         g = g.contiguous()
@@ -655,19 +708,16 @@ class _HeadFn(torch.autograd.Function):
             rc = lib.nrt_softmax_bwd_f32(_lib.ptr(y), _lib.ptr(g), _lib.ptr(dz), y.numel() // y.shape[-1], y.shape[-1],
                                          _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_softmax_bwd_f32')
-        dx = dw = db = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            xin = x.contiguous()
-            dw = torch.zeros_like(kernel, dtype=torch.float32)
-            db = torch.zeros(mod.cout, dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
-                rc = lib.nrt_conv3d_wgrad_f32(_lib.ptr(xin), _lib.ptr(dz), _lib.ptr(dw), _lib.ptr(db), xin.shape[0],
-                                              _lib.ints(list(xin.shape[1:4])), mod.cin, mod.cout, _lib.ints(mod.ksize3), 1,
-                                              _lib.stream_ptr(dev))
-            _lib.check(rc, 'nrt_conv3d_wgrad_f32')
-        if ctx.needs_input_grad[0]:
-            dx = _conv_dgrad(dz, kernel.detach(), mod.ksize3, 1)
-        return dx, dw, db, None
+        return _head_grads(x, kernel, ctx.mod, dz, ctx.needs_input_grad) + (None,)
+
+
+def _head(x, kernel, bias, mod):
+    y = _HeadFn.apply(x, kernel, bias, mod)
+    return _stamp_softmax(y, (x, kernel, bias), lambda dz, needs: _head_grads(x, kernel, mod, dz, needs))
+
+
+def _softmax_with_grad(z):
+    return _stamp_softmax(_SoftmaxFn.apply(z), (z,), lambda dz, needs: (dz,))
 
 
 class _ChannelScaleFn(torch.autograd.Function):
@@ -1208,7 +1258,7 @@ class ConvNet(nn.Module):
                 m = self.layers_by_name[name]
                 if op.get('fuse_softmax') and name not in keep and m.cout <= 64 and tuple(m.ksize3) == (1, 1, 1):
                     t[name] = None
-                    t[op['pred_name']] = _HeadFn.apply(t[op['src']], m.kernel, m.bias, m)
+                    t[op['pred_name']] = _head(t[op['src']], m.kernel, m.bias, m)
                 elif m.cout <= 64:
                     t[name] = _ConvFn.apply(t[op['src']], None, m.kernel, m.bias, m, None, 0, True)
                 else:
@@ -1217,7 +1267,7 @@ class ConvNet(nn.Module):
                 if name in t and t[name] is not None:
                     pass                                    # produced by the fused head
                 elif op['activation'] == 'softmax':
-                    t[name] = _SoftmaxFn.apply(t[op['src']])
+                    t[name] = _softmax_with_grad(t[op['src']])
                 elif op['activation'] in (None, 'linear'):
                     t[name] = t[op['src']]
                 else:
