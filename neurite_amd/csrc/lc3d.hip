@@ -270,6 +270,314 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batches of 3 .. 8 entries: the products on the matrix cores (round 4).
+// The streaming kernel above multiplies every weight by NB patch values on the vector ALU: at NB = 4 it is issue-bound (0.51-0.72 of
+// the weight stream), and 8 entries were two passes over the weights.  Here a wave instruction is v_mfma_f32_4x4x1_16b_f32: 16
+// independent 4 x 4 outer products, block blk = lane / 4:  D[blk][r][n] += A[lane 4 blk + r] * B[lane 4 blk + n]  (layout checked on
+// hardware by tools/lab/csrc/mfma4x4_layout.hip).  Block blk is weight row f = 16 c + blk of chunk c; its four lanes n hold the
+// row's Cout = 4 CPL filters as CPL consecutive elements each (so the 64 lanes of a chunk load still read one contiguous piece of 512 B
+// or 1 KiB), A = the patch value of batch entry 4 s + (lane % 4) for that f.  One MFMA = 256 multiply-adds for one issue slot;
+// register jj of the weight slice against batch set s accumulates acc[s][jj] (rows r = batch entries 4 s + r, column n = filter
+// n CPL + jj).  The weights are still read exactly once per launch of <= 8 entries; the sum over the 16 row blocks of a chunk and
+// over the chunks ends in a cross-lane reduction (2 DPP rotations inside a 16-lane row, then two xor-shuffles over the rows).
+// Same arithmetic as the vector kernel up to the order of the float32 sums.
+// ---------------------------------------------------------------------------------------------
+#ifndef NRT_LC_EXP
+#define NRT_LC_EXP 0                  // lab builds only: parts of the matrix-core kernel switched off (wrong results), see tools/lc3d_batch_bench.py
+#endif
+#ifndef NRT_LC_WAUX
+#define NRT_LC_WAUX 2                 // cache policy bits of the weight loads in the matrix-core kernel (2 = nt; lab builds try others)
+#endif
+typedef float lc_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lc_row_ror(float v, const int ctrl_is_8) {
+    // v of the lane (i + n) % 16 inside each row of 16 lanes (DPP row_ror:n)
+    return ctrl_is_8 ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false))
+                     : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+}
+
+// CPL = Cout / 4 filters per lane (CPL * sizeof(T) = 8 or 16 bytes), S = batch sets of 4 entries, NCMAX = most chunks of 16 weight rows,
+// NPC = 16-byte patch pieces per lane and batch entry (stage_chunks <= 64 NPC).
+// Software pipeline ACROSS positions: the weight chunks travel in groups of GC chunks through a ring of two register buffers; when
+// group g of a position has been multiplied, group g + 2 is requested into its buffer -- past the end of the position that is the
+// next position's group 0 / 1, preceded by the next position's patch pieces.  A wave therefore always has two groups (14 KB) in flight,
+// also while it reduces and stores a position: without this the kernel alternated between a memory phase and a compute phase
+// (batch 8: 7900 clk per position and SIMD = 4250 of stream + 3700 of issue, measured; profiles/r04_lab/lc3d_batch_*.jsonl).
+// Every iteration issues the same loads in the same order (the last position re-requests itself), so the in-order vmcnt counts are fixed.
+template <typename T, int CPL, int S, int NCMAX, int NPC>
+__global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb) {
+    constexpr int BPL = CPL * (int)sizeof(T);                  // bytes per lane and chunk
+    constexpr int WPL = BPL / 4;                               // dwords per lane and chunk
+    static_assert(BPL == 8 || BPL == 16, "lane slices of 8 or 16 bytes");
+    constexpr int NB = 4 * S;
+    constexpr int GC = 7;                                      // chunks per group; two buffers of GC * WPL registers (28 / 56 in all)
+    constexpr int NG = (NCMAX + GC - 1) / GC;                  // groups per position
+    static_assert(NG % 2 == 0, "the ring alternates two buffers and must close on a position");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const int F = a.kr * a.kc * a.kz * a.Cin;
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    const int lane = threadIdx.x & 63;
+    const int blk = lane >> 2, n = lane & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Positions by XCD (blocks are dealt to the 8 XCDs round-robin; the grid is a multiple of 8): XCD x owns the contiguous eighth
+    // [olo, ohi) of the positions and its waves walk it side by side, so the positions an XCD works on at one time are ~11 whole
+    // z-columns of neighbouring y -- the patches of z- and y-neighbours overlap by 2/3 each and now meet in ONE 4 MB L2.  With positions
+    // dealt round-robin over the whole chip the patch pieces missed L2 half of the time and were a fifth of the kernel's fabric
+    // traffic at batch 8 (FETCH_SIZE 1.71 GB for 1.35 GB of weights; profiles/r04_lab/lc3d_fetch_size.txt).
+    const int xcd = (int)(blockIdx.x % NRT_NXCD);
+    const long long nwaves = (long long)(gridDim.x / NRT_NXCD) * 4;                  // waves of this XCD
+    const long long oper = (O + NRT_NXCD - 1) / NRT_NXCD;
+    const long long olo = (long long)xcd * oper, ohi = olo + oper < O ? olo + oper : O;
+    extern __shared__ __attribute__((aligned(16))) char lc_patch[];
+    // a batch entry's patch in LDS: NCMAX chunks of 16 elements; what lies behind the layer's F elements is zeroed once and never
+    // written again, so the chunks c >= F / 16 (whose weights, loaded past num_records, are zeros too) need no branch and every A read
+    // has a compile-time offset
+    // (+ one chunk of padding: the four batch rows a ds_read touches then fall on different banks -- with a stride of 896 bytes
+    // all four hit the same one: SQ_LDS_BANK_CONFLICT was 58 % of the LDS cycles, profiles/r04_lab/pmc_lc3d_mfma_b8_v1.json)
+    constexpr unsigned pbytes = (unsigned)(NCMAX + 1) * 16u * (unsigned)sizeof(T);
+    char *mypatch = lc_patch + (size_t)wave * NB * pbytes;
+    for (unsigned i = (unsigned)a.stage_chunks * 16u + (unsigned)lane * 16u; i < pbytes; i += 64u * 16u)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) *(u32x4 *)(mypatch + b * pbytes + i) = (u32x4){0u, 0u, 0u, 0u};
+    // staging: this lane's 16-byte pieces of the patch
+    unsigned choff[NPC];
+    {
+        const unsigned cpr = (unsigned)(a.kz * a.Cin) * (unsigned)sizeof(T) / 16u;
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) {
+            const unsigned c = (unsigned)k * 64u + (unsigned)lane;
+            const unsigned cc = c < (unsigned)a.stage_chunks ? c : 0u;
+            const unsigned run = cc / cpr, j = cc % cpr;
+            const unsigned dr = run / (unsigned)a.kc, dc = run % (unsigned)a.kc;
+            choff[k] = ((dr * (unsigned)a.C + dc) * (unsigned)a.Z) * (unsigned)a.Cin * (unsigned)sizeof(T) + j * 16u;
+        }
+    }
+    // A operand: patch value f = 16 c + blk of batch entry 4 s + n  (the lane index inside the block is the batch row)
+    unsigned aoff[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) aoff[s] = (unsigned)(4 * s + n) * pbytes + (unsigned)blk * (unsigned)sizeof(T);
+    const unsigned w0 = (unsigned)lane * (unsigned)BPL;
+    const unsigned wbytes = (unsigned)F * (unsigned)a.Cout * (unsigned)sizeof(T);
+    const long long xbs = (long long)a.R * a.C * a.Z * a.Cin;
+    // ONE descriptor for the nb input volumes of this launch (nb * volume bytes < 2^31: launcher); the batch entry goes into the offset
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((const T *)a.x + (long long)b0 * xbs), 0, (int)((long long)nb * xbs * (long long)sizeof(T)), 0x00020000);
+    const unsigned xbs_bytes = (unsigned)(xbs * (long long)sizeof(T));
+
+    struct Pos { long long o; unsigned xbase; bool live; };
+    auto decode = [&](long long oreal) {
+        Pos p;
+        p.live = oreal < ohi;
+        p.o = p.live ? oreal : ohi - 1;
+        const unsigned o32 = (unsigned)p.o, q32 = o32 / (unsigned)a.ozz;
+        const int oz = (int)(o32 - q32 * (unsigned)a.ozz), oc = (int)(q32 % (unsigned)a.occ), orr = (int)(q32 / (unsigned)a.occ);
+        p.xbase = (unsigned)((((long long)(orr * a.sr) * a.C + oc * a.sc) * a.Z + oz * a.sz) * a.Cin * (long long)sizeof(T));
+        return p;
+    };
+    auto weights_of = [&](long long o) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)((const T *)a.k + o * (long long)F * a.Cout)), 0, (int)wbytes, 0x00020000);
+    };
+    u32x4 pc[NB][NPC];
+    unsigned w[2][GC][WPL];
+#if NRT_LC_EXP == 3
+    for (int i = 0; i < 2 * GC * WPL; ++i) (&w[0][0][0])[i] = 0x3f803f80u;
+#endif
+    auto issue_patch = [&](const Pos &p) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int k = 0; k < NPC; ++k)
+                pc[b][k] = __builtin_amdgcn_raw_buffer_load_b128(xres, choff[k], p.xbase + (unsigned)(b < nb ? b : 0) * xbs_bytes, 0);
+    };
+    auto issue_group = [&](const __amdgpu_buffer_rsrc_t wr, const int buf, const int g) {
+#pragma unroll
+        for (int i = 0; i < (NRT_LC_EXP == 3 ? 1 : GC); ++i) {
+            const int c = g * GC + i;                          // chunks past the last one lie past num_records: zeros
+            if constexpr (WPL == 2) {
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(wr, w0, c * 64 * BPL, NRT_LC_WAUX);
+                w[buf][i][0] = raw[0]; w[buf][i][1] = raw[1];
+            } else {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, c * 64 * BPL, NRT_LC_WAUX);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[buf][i][k] = raw[k];
+            }
+        }
+    };
+
+    // the bias slice of a position travels with its patch pieces (requested before the weights: vmcnt retires in order, a bias load
+    // issued in the epilogue could only be waited for by draining the next position's 28 weight loads)
+    typedef T vec_t __attribute__((ext_vector_type(CPL)));
+    auto bias_of = [&](long long o) {
+        vec_t z;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) z[e] = (T)0;
+        return a.bias ? *(const vec_t *)((const T *)a.bias + o * a.Cout + n * CPL) : z;
+    };
+    const long long ofirst = olo + (long long)(blockIdx.x / NRT_NXCD) * 4 + wave;
+    if (ofirst >= ohi) return;                                 // (no block barrier in this kernel: a wave may leave alone)
+    Pos cur = decode(ofirst);
+    __amdgpu_buffer_rsrc_t wcur = weights_of(cur.o);
+    issue_patch(cur);
+    vec_t bcur = bias_of(cur.o), bnext = bcur;
+    __builtin_amdgcn_sched_barrier(0);
+    issue_group(wcur, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_group(wcur, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (;;) {
+        const long long onext = cur.o + nwaves;
+        const Pos nxt = decode(onext);                         // past the end: the last position again (loads only, never stored)
+        const __amdgpu_buffer_rsrc_t wnext = weights_of(nxt.o);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int k = 0; k < NPC; ++k)
+                if (k * 64 + lane < a.stage_chunks) *(u32x4 *)(mypatch + b * pbytes + (k * 64 + lane) * 16) = pc[b][k];
+        __builtin_amdgcn_wave_barrier();
+
+        lc_f4 acc[S][CPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) acc[s][jj] = (lc_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int i = 0; i < GC; ++i) {
+                const int c = g * GC + i;
+                if (c < NCMAX) {                               // compile-time
+                    const unsigned coff = (unsigned)c * 16u * (unsigned)sizeof(T);
+                    float av[S];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+#if NRT_LC_EXP == 4
+                        av[s] = __uint_as_float(aoff[s] + coff);
+#else
+                        av[s] = to_f32(*(const T *)(mypatch + aoff[s] + coff));
+#endif
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < CPL; ++jj) {
+                        float bw;
+                        if constexpr (sizeof(T) == 2) {
+                            const unsigned d = w[g & 1][i][jj >> 1];
+                            bw = __uint_as_float((jj & 1) ? (d & 0xffff0000u) : (d << 16));
+                        } else {
+                            bw = __uint_as_float(w[g & 1][i][jj]);
+                        }
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+#if NRT_LC_EXP == 2
+                            acc[s][jj][0] += av[s] * bw;
+#else
+                            acc[s][jj] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s], bw, acc[s][jj], 0, 0, 0);
+#endif
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // this buffer is free: the group two ahead, which past the end of the position belongs to the next one
+            if (g == NG - 2) { issue_patch(nxt); bnext = bias_of(nxt.o); __builtin_amdgcn_sched_barrier(0); }   // AHEAD of the weights in the queue
+            if (g + 2 < NG) issue_group(wcur, g & 1, g + 2);
+            else issue_group(wnext, g & 1, g + 2 - NG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- sum over the 16 row blocks: inside a row of 16 lanes (4 blocks) two rotations; lane (row R, block q of the row, n)
+        // then keeps batch row r = q, and two xor-shuffles add the four rows of lanes ------------------------------------------
+        const int q = blk & 3, R = lane >> 4;
+        float val[S][CPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) {
+                lc_f4 v = acc[s][jj];
+#pragma unroll
+                for (int r = 0; r < (NRT_LC_EXP == 1 ? 0 : 4); ++r) {
+                    v[r] += lc_row_ror(v[r], 1);
+                    v[r] += lc_row_ror(v[r], 0);
+                }
+                const float lo = (q & 1) ? v[1] : v[0], hi = (q & 1) ? v[3] : v[2];
+                val[s][jj] = (q & 2) ? hi : lo;
+            }
+#pragma unroll
+        for (int off = 16; off < (NRT_LC_EXP == 1 ? 16 : 64); off <<= 1) {
+            float other[S][CPL];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int jj = 0; jj < CPL; ++jj) other[s][jj] = __shfl_xor(val[s][jj], off, 64);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int jj = 0; jj < CPL; ++jj) val[s][jj] += other[s][jj];
+        }
+        // lanes of row R < S write batch entry 4 R + q: CPL consecutive filters per lane, the four lanes n of a block one output row
+        const int b = 4 * R + q;
+        if (R < S && b < nb) {
+            const vec_t bv = bcur;
+            vec_t ov;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                float v = val[0][e];
+#pragma unroll
+                for (int s = 1; s < S; ++s) v = (R == s) ? val[s][e] : v;
+                if (a.bias) v += to_f32(bv[e]);
+                T qv;
+                store_out(&qv, lc_act(v, a.act));
+                ov[e] = qv;
+            }
+            *(vec_t *)((T *)a.y + ((long long)(b0 + b) * O + cur.o) * a.Cout + n * CPL) = ov;
+        }
+        if (!nxt.live) break;
+        cur = nxt;
+        wcur = wnext;
+        bcur = bnext;
+    }
+}
+
+template <typename T, int CPL>
+bool launch_mfma(const LcArgs &a, hipStream_t st) {
+    // experiment knob: NRT_LC_MFMA = 0 keeps the vector kernel for every batch size
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("NRT_LC_MFMA"); on = e ? atoi(e) : 1; }
+    constexpr int NCMAX = 28;
+    const int F = a.kr * a.kc * a.kz * a.Cin;
+    if (!on || a.B < 3 || a.Cout != 4 * CPL || F % 16 || F / 16 > NCMAX || a.stage_chunks < 1 || a.stage_chunks > 128) return false;
+    if ((size_t)a.stage_chunks * 16 != (size_t)F * sizeof(T)) return false;      // the staged pieces are exactly the patch
+    if ((((uintptr_t)a.k) & 15) || (((uintptr_t)a.y) & 15) || (a.bias && (((uintptr_t)a.bias) & 15))) return false;
+    if ((long long)a.R * a.C * a.Z * a.Cin * (long long)sizeof(T) * 8 >= (1ll << 31)) return false;      // 8 volumes behind one descriptor
+    static int kblocks = -1;
+    if (kblocks < 0) { const char *e = getenv("NRT_LC_BLOCKS"); kblocks = e ? atoi(e) : 0; }
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    const size_t pb = (size_t)(NCMAX + 1) * 16 * sizeof(T);
+    const bool two = a.stage_chunks > 64;
+    // the grid is exactly the resident blocks (a wave's load pipeline runs across its positions; a second round of blocks would run
+    // on a nearly empty machine: 1024 blocks on 768 slots cost 25 % at batch 8)
+    auto run = [&](auto kernel, int sets, int b0, int nb) {
+        const size_t shm = (size_t)4 * 4 * sets * pb;
+        static int per_cu = 0;                                 // per instantiation (the LDS size is a function of it)
+        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, shm) != hipSuccess || per_cu < 1)) per_cu = 2;
+        unsigned blocks = nrt_xcd_grid((unsigned)((O + 3) / 4));
+        const unsigned cap = nrt_xcd_grid(kblocks > 0 ? (unsigned)kblocks : (unsigned)per_cu * (unsigned)nrt_num_cus());
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), shm, st, a, b0, nb);
+    };
+    for (int b0 = 0; b0 < a.B; b0 += 8) {
+        const int nb = a.B - b0 < 8 ? a.B - b0 : 8;
+        if (nb <= 4) {
+            if (two) run(lc3d_fwd_mfma<T, CPL, 1, NCMAX, 2>, 1, b0, nb);
+            else run(lc3d_fwd_mfma<T, CPL, 1, NCMAX, 1>, 1, b0, nb);
+        } else {
+            if (two) run(lc3d_fwd_mfma<T, CPL, 2, NCMAX, 2>, 2, b0, nb);
+            else run(lc3d_fwd_mfma<T, CPL, 2, NCMAX, 1>, 2, b0, nb);
+        }
+    }
+    return true;
+}
+
 // any Cout / F: one thread per (position, cout)
 template <typename T>
 __global__ __launch_bounds__(256) void lc3d_generic(LcArgs a) {
@@ -343,6 +651,10 @@ int launch_any(const LcArgs &a_in, int variant, hipStream_t st) {
         if (kstage < 0) { const char *e = getenv("NRT_LC_STAGE"); kstage = e ? atoi(e) : 1; }
         a.stage_chunks = (kstage && runb % 16 == 0 && ((long long)a.Cin * (long long)sizeof(T)) % 16 == 0 && chunks <= 128 &&
                           (((uintptr_t)a.x) & 15) == 0 && chunks * 16 * 4 * 4 <= 48 * 1024) ? (int)chunks : 0;
+        bool done = false;
+        if constexpr (sizeof(T) == 2) done = a.Cout == 16 ? launch_mfma<T, 4>(a, st) : (a.Cout == 32 ? launch_mfma<T, 8>(a, st) : false);
+        else done = a.Cout == 16 ? launch_mfma<T, 4>(a, st) : (a.Cout == 8 ? launch_mfma<T, 2>(a, st) : false);
+        if (done) { NRT_CHECK_LAUNCH(); return NRT_OK; }
         if (nit <= 8) launch_vec<T, 8>(a, st);
         else if (nit <= 14) launch_vec<T, 14>(a, st);
         else if (nit <= 16) launch_vec<T, 16>(a, st);

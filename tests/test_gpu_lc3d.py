@@ -108,6 +108,33 @@ def test_lc3d_many_filters_batch(dev, batch):
     close(N(layer(xb)), npo.lc3d(N(xb), N(kb), N(bb), ks, (1, 1, 1)), 2.0 ** -8)
 
 
+@pytest.mark.parametrize('batch', [3, 4, 5, 8, 9])
+@pytest.mark.parametrize('cin,cout,ks,st,S', [(16, 16, (3, 3, 3), (1, 1, 1), (6, 7, 9)), (16, 32, (3, 3, 3), (1, 1, 1), (5, 6, 7)),
+                                               (16, 16, (3, 3, 3), (2, 1, 2), (7, 6, 9)), (8, 16, (2, 2, 2), (1, 1, 1), (5, 5, 6)),
+                                               (16, 8, (3, 3, 3), (1, 1, 1), (5, 5, 7))])
+def test_lc3d_matrix_core_batches(dev, batch, cin, cout, ks, st, S, monkeypatch):
+    """3 .. 8 batch entries per weight pass on v_mfma_f32_4x4x1 (csrc/lc3d.hip: lc3d_fwd_mfma; 9 entries = 8 + 1): against the oracle
+    and against the vector kernel (NRT_LC_MFMA=0 is read once per process, so the comparison kernel is asked for per entry pair:
+    batches of 2 never take the matrix form)"""
+    rng = np.random.default_rng(batch * 100 + cin + cout)
+    osh = tuple((S[d] - ks[d]) // st[d] + 1 for d in range(3))
+    O, Fd = int(np.prod(osh)), int(np.prod(ks)) * cin
+    x = rng.standard_normal((batch,) + S + (cin,)).astype(F)
+    k = (rng.standard_normal((O, Fd, cout)) / np.sqrt(Fd)).astype(F)
+    b = rng.standard_normal(osh + (cout,)).astype(F)
+    for act, fn in ((None, lambda v: v), ('relu', lambda v: np.maximum(v, 0))):
+        layer = make_layer(dev, G(x, dev), cout, ks, st, G(k, dev), G(b, dev), act=act)
+        y = layer(G(x, dev))
+        close(N(y), fn(npo.lc3d(x, k, b, ks, st)), 1e-5)
+        pairs = torch.cat([layer(G(x[i:i + 2], dev)) for i in range(0, batch, 2)], 0)        # vector kernel, 2 entries per pass
+        close(N(y), N(pairs).astype(np.float64), 2e-6)
+    xb, kb, bb = G(x, dev).bfloat16(), G(k, dev).bfloat16(), G(b, dev).bfloat16()
+    layer = make_layer(dev, xb, cout, ks, st, kb, bb)
+    yb = layer(xb)
+    assert yb.dtype == torch.bfloat16
+    close(N(yb), npo.lc3d(N(xb), N(kb), N(bb), ks, st), 2.0 ** -8)
+
+
 def test_lc3d_softmax_axis_follows_the_data_format(dev):
     """layers.py:1100 hands the layer output to Keras' softmax, which runs over the LAST axis of that tensor: the filters for
     channels_last, the last spatial axis for channels_first."""
