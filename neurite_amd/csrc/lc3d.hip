@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
 // Same arithmetic as the vector kernel up to the order of the float32 sums.
 // ---------------------------------------------------------------------------------------------
 #ifndef NRT_LC_EXP
-#define NRT_LC_EXP 0                  // lab builds only: parts of the matrix-core kernel switched off (wrong results), see tools/lc3d_batch_bench.py
+#define NRT_LC_EXP 0                  // lab builds only (wrong results): 3 = one weight load per group, 5 = no MFMA, 6 = one patch load per position
+                                      // (profiles/r04_lab/lc3d_mfma_parts_off.txt: the patch gathers, not the matrix work, are what batch 8 pays for)
 #endif
 #ifndef NRT_LC_WAUX
 #define NRT_LC_WAUX 2                 // cache policy bits of the weight loads in the matrix-core kernel (2 = nt; lab builds try others)
@@ -311,9 +312,12 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
     constexpr int WPL = BPL / 4;                               // dwords per lane and chunk
     static_assert(BPL == 8 || BPL == 16, "lane slices of 8 or 16 bytes");
     constexpr int NB = 4 * S;
-    constexpr int GC = 7;                                      // chunks per group; two buffers of GC * WPL registers (28 / 56 in all)
+    // ring of RD register buffers of GC chunks each: 8-byte lane slices keep a whole position (3 x 9 chunks, 54 registers) in flight --
+    // a buffer is re-requested for the next position the moment it has been multiplied --, 16-byte slices two groups of 7 (56 registers)
+    constexpr int RD = WPL == 2 ? 3 : 2;
+    constexpr int GC = WPL == 2 ? 9 : 7;
     constexpr int NG = (NCMAX + GC - 1) / GC;                  // groups per position
-    static_assert(NG % 2 == 0, "the ring alternates two buffers and must close on a position");
+    static_assert(NG % RD == 0 && NG * GC == NCMAX, "the ring must close on a position");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int F = a.kr * a.kc * a.kz * a.Cin;
@@ -380,15 +384,18 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
         return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)((const T *)a.k + o * (long long)F * a.Cout)), 0, (int)wbytes, 0x00020000);
     };
     u32x4 pc[NB][NPC];
-    unsigned w[2][GC][WPL];
+    unsigned w[RD][GC][WPL];
 #if NRT_LC_EXP == 3
-    for (int i = 0; i < 2 * GC * WPL; ++i) (&w[0][0][0])[i] = 0x3f803f80u;
+    for (int i = 0; i < RD * GC * WPL; ++i) (&w[0][0][0])[i] = 0x3f803f80u;
 #endif
     auto issue_patch = [&](const Pos &p) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int k = 0; k < NPC; ++k)
+#if NRT_LC_EXP == 6
+                if (b > 0) pc[b][k] = pc[0][k]; else
+#endif
                 pc[b][k] = __builtin_amdgcn_raw_buffer_load_b128(xres, choff[k], p.xbase + (unsigned)(b < nb ? b : 0) * xbs_bytes, 0);
     };
     auto issue_group = [&](const __amdgpu_buffer_rsrc_t wr, const int buf, const int g) {
@@ -422,10 +429,11 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
     issue_patch(cur);
     vec_t bcur = bias_of(cur.o), bnext = bcur;
     __builtin_amdgcn_sched_barrier(0);
-    issue_group(wcur, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    issue_group(wcur, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < RD; ++g) {
+        issue_group(wcur, g, g);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (;;) {
         const long long onext = cur.o + nwaves;
         const Pos nxt = decode(onext);                         // past the end: the last position again (loads only, never stored)
@@ -452,25 +460,21 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
                     float av[S];
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-#if NRT_LC_EXP == 4
-                        av[s] = __uint_as_float(aoff[s] + coff);
-#else
                         av[s] = to_f32(*(const T *)(mypatch + aoff[s] + coff));
-#endif
                     }
 #pragma unroll
                     for (int jj = 0; jj < CPL; ++jj) {
                         float bw;
                         if constexpr (sizeof(T) == 2) {
-                            const unsigned d = w[g & 1][i][jj >> 1];
+                            const unsigned d = w[g % RD][i][jj >> 1];
                             bw = __uint_as_float((jj & 1) ? (d & 0xffff0000u) : (d << 16));
                         } else {
-                            bw = __uint_as_float(w[g & 1][i][jj]);
+                            bw = __uint_as_float(w[g % RD][i][jj]);
                         }
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
-#if NRT_LC_EXP == 2
-                            acc[s][jj][0] += av[s] * bw;
+#if NRT_LC_EXP == 5
+                            asm volatile("" :: "v"(av[s]), "v"(bw));      // operands formed, nothing multiplied
 #else
                             acc[s][jj] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s], bw, acc[s][jj], 0, 0, 0);
 #endif
@@ -479,10 +483,10 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // this buffer is free: the group two ahead, which past the end of the position belongs to the next one
-            if (g == NG - 2) { issue_patch(nxt); bnext = bias_of(nxt.o); __builtin_amdgcn_sched_barrier(0); }   // AHEAD of the weights in the queue
-            if (g + 2 < NG) issue_group(wcur, g & 1, g + 2);
-            else issue_group(wnext, g & 1, g + 2 - NG);
+            // this buffer is free: the group RD ahead, which past the end of the position belongs to the next one
+            if (g == NG - RD) { issue_patch(nxt); bnext = bias_of(nxt.o); __builtin_amdgcn_sched_barrier(0); }   // AHEAD of the weights in the queue
+            if (g + RD < NG) issue_group(wcur, g % RD, g + RD);
+            else issue_group(wnext, g % RD, g + RD - NG);
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- sum over the 16 row blocks: inside a row of 16 lanes (4 blocks) two rotations; lane (row R, block q of the row, n)
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
             for (int jj = 0; jj < CPL; ++jj) {
                 lc_f4 v = acc[s][jj];
 #pragma unroll
-                for (int r = 0; r < (NRT_LC_EXP == 1 ? 0 : 4); ++r) {
+                for (int r = 0; r < 4; ++r) {
                     v[r] += lc_row_ror(v[r], 1);
                     v[r] += lc_row_ror(v[r], 0);
                 }
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
                 val[s][jj] = (q & 2) ? hi : lo;
             }
 #pragma unroll
-        for (int off = 16; off < (NRT_LC_EXP == 1 ? 16 : 64); off <<= 1) {
+        for (int off = 16; off < 64; off <<= 1) {
             float other[S][CPL];
 #pragma unroll
             for (int s = 0; s < S; ++s)
@@ -543,7 +547,7 @@ bool launch_mfma(const LcArgs &a, hipStream_t st) {
     // experiment knob: NRT_LC_MFMA = 0 keeps the vector kernel for every batch size
     static int on = -1;
     if (on < 0) { const char *e = getenv("NRT_LC_MFMA"); on = e ? atoi(e) : 1; }
-    constexpr int NCMAX = 28;
+    constexpr int NCMAX = CPL * (int)sizeof(T) == 8 ? 27 : 28;          // chunks of 16 weight rows a position may have (ring geometry of the kernel)
     const int F = a.kr * a.kc * a.kz * a.Cin;
     if (!on || a.B < 3 || a.Cout != 4 * CPL || F % 16 || F / 16 > NCMAX || a.stage_chunks < 1 || a.stage_chunks > 128) return false;
     if ((size_t)a.stage_chunks * 16 != (size_t)F * sizeof(T)) return false;      // the staged pieces are exactly the patch
