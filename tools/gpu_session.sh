@@ -53,10 +53,10 @@ bench)
 prof)
   stage prof
   ( cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -o bench -- \
-      python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-batch1 --no-unet > "$OUT/prof_bench.json" 2> "$OUT/prof.log" < /dev/null )
+      python "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-batch1 --no-unet --no-strong > "$OUT/prof_bench.json" 2> "$OUT/prof.log" < /dev/null )
   echo "prof rc=$?" | tee -a "$OUT/session.log"
   ( cd /tmp && timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_unfused" -o bench -- \
-      python "$ROOT/bench.py" --unfused --steps 20 --warmup 5 --no-cpu-baseline --no-batch1 --no-unet > "$OUT/prof_bench_unfused.json" 2>> "$OUT/prof.log" < /dev/null )
+      python "$ROOT/bench.py" --unfused --steps 20 --warmup 5 --no-cpu-baseline --no-batch1 --no-unet --no-strong > "$OUT/prof_bench_unfused.json" 2>> "$OUT/prof.log" < /dev/null )
   find "$OUT/prof" -name "*kernel_stats.csv" | head -3 | while read f; do echo "$f"; head -12 "$f"; done | tee -a "$OUT/session.log"
   ;;
 dist1)
@@ -91,7 +91,7 @@ pmc)
   stage pmc
   for c in FETCH_SIZE WRITE_SIZE; do
     ( cd /tmp && timeout -k 5 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o bench -- \
-        python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-unet > /dev/null 2> "$OUT/pmc_$c.log" < /dev/null )
+        python "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --no-unet --no-strong > /dev/null 2> "$OUT/pmc_$c.log" < /dev/null )
     echo "pmc $c rc=$?" | tee -a "$OUT/session.log"
   done
   python tools/summarize_pmc.py "$OUT" 2>&1 | tee -a "$OUT/session.log"
