@@ -53,7 +53,11 @@ static_assert(2 * WC_BLOCK_BYTES <= 160 * 1024, "two blocks per CU");
 #ifndef NRT_FUSED_WCLOADS
 #define NRT_FUSED_WCLOADS 0
 #endif
-#define WC_FIXED_LOADS NRT_FUSED_WCLOADS
+// fused form (the sums stay in registers): row loads only as far as the fetch list goes.  Stand-alone warp (the blended row is STORED):
+// always eight loads -- with a conditional number the compiler's in-order vmcnt count must assume none was issued, every wait then
+// also covered the store of the previous pass, and the write acknowledgement sat in the wave's critical path every pass
+// (stand-alone warp 1.305 -> 1.222 ms; the fused kernel is slower with fixed loads: 1.068 -> 1.143, profiles/r04_lab/wc_fixed8.txt)
+#define WC_FIXED_LOADS (DICE ? NRT_FUSED_WCLOADS : 8)
 #ifndef NRT_FUSED_WCSYNC
 #define NRT_FUSED_WCSYNC 0
 #endif

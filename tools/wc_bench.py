@@ -43,12 +43,12 @@ for batch in batches:
                 row['ms_' + key] = round(timeit(lambda: ne.fused.warp_dice(mov, f, fix, return_warped=store, _tune=tune)), 4)
             d[name] = ne.fused.warp_dice(mov, f, fix, _tune=tune)
         row['max_abs_dice_diff'] = float((d['wc'] - d['reg']).abs().max())
-        # the stand-alone warp: the library default (z-run register kernel) against the wave-cache kernel (variant 10)
+        # the stand-alone warp: the z-run register kernel (variant 3, the default until round 4), the wave-cache kernel (variant 10), the library default
         from neurite_amd import deferred
         keep, deferred.enabled = deferred.enabled, False
-        for name, variant in (('interpn_default', 0), ('interpn_wc', 10)):
+        for name, variant, tune in (('interpn_zrun', 3, 20 | (1 << 16)), ('interpn_wc', 10, 0), ('interpn_default', 0, 0)):
             st = ne.layers.SpatialTransformer()
-            st._variant = variant
+            st._variant, st._tune = variant, tune
             row['ms_' + name] = round(timeit(lambda: st([mov, f])), 4)
         deferred.enabled = keep
         nvox = batch * 160 ** 3
