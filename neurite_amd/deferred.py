@@ -103,6 +103,15 @@ class DeferredWarp(torch.Tensor):
     def __reduce_ex__(self, proto):
         return self.materialize().__reduce_ex__(proto)
 
+    def __deepcopy__(self, memo):
+        # (torch.Tensor.__deepcopy__ rebuilds the subclass through new_empty(): a copy of a warp is simply a copy of its values)
+        import copy
+        return copy.deepcopy(self.materialize(), memo)
+
+    def __copy__(self):
+        import copy
+        return copy.copy(self.materialize())
+
     def untyped_storage(self):
         return self.materialize().untyped_storage()
 

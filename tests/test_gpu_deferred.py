@@ -188,3 +188,59 @@ def test_full_size_reference_api_pipeline_and_few_channel_warps(dev):
     got = N(ne.layers.Resize(2)(torch.from_numpy(half[None]).to(dev)))[0]
     lin = [npo.tf_linspace(0., 79., 160) for _ in range(3)]
     assert bits_equal(got, co.interpn(half, lin, 'linear', None, loc_mode=2))
+
+
+def test_deferred_warp_behaves_like_its_tensor_everywhere_else(dev, batch):
+    """a pending warp handed to code that knows nothing about it -- pickling, copies, .to(), saving, views, in-place operations, stacking,
+    printing -- is evaluated on first use and from then on IS the eager result ('fragile under pickling and .to()')"""
+    import copy
+    import io
+    import pickle
+    mov, fix, trf = batch
+    st = ne.layers.SpatialTransformer()
+    want = eager(lambda: st([mov, trf]))
+
+    def pending():
+        w = st([mov, trf])
+        assert isinstance(w, ne.deferred.DeferredWarp) and w.pending
+        return w
+
+    back = pickle.loads(pickle.dumps(pending()))
+    assert torch.equal(torch.as_tensor(back).to(dev), want)
+    assert torch.equal(copy.deepcopy(pending()), want) and torch.equal(copy.copy(pending()), want)
+    buf = io.BytesIO()
+    torch.save(pending(), buf)
+    buf.seek(0)
+    assert torch.equal(torch.load(buf, weights_only=False).to(dev), want)
+    for conv in (lambda w: w.to('cpu'), lambda w: w.cpu(), lambda w: w.to(torch.float64), lambda w: w.to(dev, torch.float16), lambda w: w.double(),
+                 lambda w: w.contiguous(), lambda w: w.clone(), lambda w: w.detach(), lambda w: w.to(dev)):
+        got = conv(pending())
+        assert torch.equal(got.to(dev, torch.float32), conv(want).to(dev, torch.float32))
+    # views, reductions, stacking, arithmetic with ordinary tensors on either side
+    w = pending()
+    assert torch.equal(w[1, 3:9, ..., 2], want[1, 3:9, ..., 2]) and not w.pending
+    assert torch.equal(pending().permute(0, 4, 1, 2, 3), want.permute(0, 4, 1, 2, 3))
+    assert torch.equal(pending().reshape(2, -1, 8), want.reshape(2, -1, 8))
+    assert float(pending().sum()) == float(want.sum()) and float(pending().max()) == float(want.max())
+    assert torch.equal(torch.stack([pending(), pending()]), torch.stack([want, want]))
+    assert torch.equal(fix - pending(), fix - want) and torch.equal(pending() * 2, want * 2)
+    assert torch.equal(torch.where(pending() > 0.5, fix, mov), torch.where(want > 0.5, fix, mov))
+    # in-place operations act on the evaluated values
+    w = pending()
+    w += 1
+    assert torch.equal(w, want + 1)
+    w = pending()
+    w.clamp_(0.2, 0.8)
+    assert torch.equal(w, want.clamp(0.2, 0.8))
+    # as the OUT / source of copies, as a module input
+    dst = torch.empty_like(want)
+    dst.copy_(pending())
+    assert torch.equal(dst, want)
+    assert torch.equal(torch.nn.Identity()(pending()), want)
+    assert torch.equal(torch.nn.functional.avg_pool3d(pending().permute(0, 4, 1, 2, 3), 2), torch.nn.functional.avg_pool3d(want.permute(0, 4, 1, 2, 3), 2))
+    # metadata never evaluates
+    w = pending()
+    assert tuple(w.shape) == tuple(want.shape) and w.dtype == want.dtype and w.device == want.device and w.dim() == 5 and w.numel() == want.numel()
+    assert w.is_contiguous() and not w.requires_grad and w.pending
+    assert 'pending' in repr(w) and w.pending                     # printing a pending warp says so instead of computing it
+    assert 'tensor' in repr(w.materialize()) and 'tensor' in repr(w)
