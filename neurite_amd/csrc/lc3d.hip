@@ -542,6 +542,225 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same kernel with the patches staged ONCE PER BLOCK (the form the launcher prefers: 3 x 3 x 3 kernels over 16 input channels,
+// unit z stride).  lc3d_fwd_mfma lets every wave gather its own position's patches: 8 gathers of 54 x 16 bytes per position at batch
+// 8, as many L1 -> L2 requests as the position's weights, and they -- not the matrix work -- were what batches of 6-8 paid for
+// (profiles/r04_lab/lc3d_mfma_parts_off.txt).  Here the four waves of a block take four z-CONSECUTIVE positions of one (row, column)
+// and the block stages the union of their patches: per batch entry kr * kc runs of (kz + 3) voxels x 16 channels (192 contiguous
+// bytes in bfloat16) instead of four times kr * kc runs of 96 bytes -- half the bytes, a third of the cache lines, half the load
+// instructions.  The patch lives in LDS twice (the next group's pieces are written while slower waves still read this group's);
+// one block barrier per group.  Wave w reads its window at a z offset of w voxels; everything else is lc3d_fwd_mfma.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int CPL, int S, int NCMAX, int NPT>
+__global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma_blk(LcArgs a, int b0, int nb) {
+    constexpr int BPL = CPL * (int)sizeof(T);
+    constexpr int WPL = BPL / 4;
+    static_assert(BPL == 8 || BPL == 16, "lane slices of 8 or 16 bytes");
+    constexpr int NB = 4 * S;
+    constexpr int RD = WPL == 2 ? 3 : 2;
+    constexpr int GC = WPL == 2 ? 9 : 7;
+    constexpr int NG = (NCMAX + GC - 1) / GC;
+    static_assert(NG % RD == 0 && NG * GC == NCMAX, "the ring must close on a position");
+    constexpr int KZ = 3;                                      // taps along z (launcher): chunk c = tap (c / KZ, c % KZ), 16 channels
+    constexpr unsigned CINB = 16u * (unsigned)sizeof(T);       // bytes of one input voxel
+    constexpr unsigned RUNB = (KZ + 3) * CINB;                 // one (kr, kc) run of the union patch
+    constexpr unsigned PB = 9u * RUNB + 5u * CINB;             // patch of one batch entry: <= 9 runs, + zeros that the padded chunks and the
+                                                               // last wave's window read (also staggers the four batch rows over the banks)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef T vec_t __attribute__((ext_vector_type(CPL)));
+    const int F = a.kr * a.kc * a.kz * a.Cin;
+    const long long O = (long long)a.orr * a.occ * a.ozz;
+    const int lane = threadIdx.x & 63;
+    const int blk = lane >> 2, n = lane & 3;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // groups of four z-consecutive positions; XCD x owns a contiguous eighth of the groups (see lc3d_fwd_mfma)
+    const unsigned ZG = ((unsigned)a.ozz + 3u) >> 2;
+    const long long ngrp = (long long)a.orr * a.occ * ZG;
+    const int xcd = (int)(blockIdx.x % NRT_NXCD);
+    const long long gstep = (long long)(gridDim.x / NRT_NXCD);
+    const long long gper = (ngrp + NRT_NXCD - 1) / NRT_NXCD;
+    const long long glo = (long long)xcd * gper, ghi = glo + gper < ngrp ? glo + gper : ngrp;
+    extern __shared__ __attribute__((aligned(16))) char lc_patch[];
+    for (unsigned i = threadIdx.x * 16u; i < 2u * NB * PB; i += 256u * 16u) *(u32x4 *)(lc_patch + i) = (u32x4){0u, 0u, 0u, 0u};
+    // this thread's pieces of the union patch: (entry, run, 16-byte piece of the run)
+    const unsigned ppr = RUNB / 16u, runs = (unsigned)(a.kr * a.kc), ppe = runs * ppr;
+    unsigned goff[NPT], loff[NPT];
+    bool pval[NPT];
+    const long long xbs = (long long)a.R * a.C * a.Z * a.Cin;
+    const unsigned xbs_bytes = (unsigned)(xbs * (long long)sizeof(T));
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+        const unsigned p = threadIdx.x + 256u * (unsigned)k;
+        pval[k] = p < (unsigned)NB * ppe;
+        const unsigned pp = pval[k] ? p : 0u;
+        const unsigned e = pp / ppe, q = pp % ppe, run = q / ppr, j = q % ppr;
+        const unsigned dr = run / (unsigned)a.kc, dc = run % (unsigned)a.kc;
+        goff[k] = (e < (unsigned)nb ? e : 0u) * xbs_bytes + ((dr * (unsigned)a.C + dc) * (unsigned)a.Z) * (unsigned)a.Cin * (unsigned)sizeof(T) + j * 16u;
+        loff[k] = e * PB + run * RUNB + j * 16u;
+    }
+    unsigned aoff[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) aoff[s] = (unsigned)(4 * s + n) * PB + (unsigned)wave * CINB + (unsigned)blk * (unsigned)sizeof(T);
+    const unsigned w0 = (unsigned)lane * (unsigned)BPL;
+    const unsigned wbytes = (unsigned)F * (unsigned)a.Cout * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((const T *)a.x + (long long)b0 * xbs), 0, (int)((long long)nb * xbs * (long long)sizeof(T)), 0x00020000);
+
+    struct Grp { long long o; unsigned xbase; bool live, act; };     // live: the group exists; act: this wave's position exists
+    auto decode = [&](long long greal) {
+        Grp p;
+        p.live = greal < ghi;
+        const unsigned g32 = (unsigned)(p.live ? greal : ghi - 1);
+        const unsigned col = g32 / ZG, zg = g32 - col * ZG;
+        const unsigned orr = col / (unsigned)a.occ, oc = col - orr * (unsigned)a.occ;
+        const unsigned oz = 4u * zg + (unsigned)wave;
+        p.act = p.live && oz < (unsigned)a.ozz;
+        p.o = (long long)col * a.ozz + (oz < (unsigned)a.ozz ? oz : (unsigned)a.ozz - 1u);
+        p.xbase = (unsigned)((((long long)(orr * (unsigned)a.sr) * a.C + oc * (unsigned)a.sc) * a.Z + 4u * zg) * a.Cin * (long long)sizeof(T));
+        return p;
+    };
+    auto weights_of = [&](const Grp &p) {                      // a wave without a position streams nothing: zero records
+        return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)((const T *)a.k + p.o * (long long)F * a.Cout)), 0,
+                                                 p.act ? (int)wbytes : 0, 0x00020000);
+    };
+    auto bias_of = [&](long long o) {
+        vec_t z;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) z[e] = (T)0;
+        return a.bias ? *(const vec_t *)((const T *)a.bias + o * a.Cout + n * CPL) : z;
+    };
+    u32x4 pc[NPT];
+    unsigned w[RD][GC][WPL];
+    auto issue_patch = [&](const Grp &p) {
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) pc[k] = __builtin_amdgcn_raw_buffer_load_b128(xres, goff[k], p.xbase, 0);
+    };
+    auto issue_group = [&](const __amdgpu_buffer_rsrc_t wr, const int buf, const int g) {
+#pragma unroll
+        for (int i = 0; i < GC; ++i) {
+            const int c = g * GC + i;
+            if constexpr (WPL == 2) {
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(wr, w0, c * 64 * BPL, NRT_LC_WAUX);
+                w[buf][i][0] = raw[0]; w[buf][i][1] = raw[1];
+            } else {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, c * 64 * BPL, NRT_LC_WAUX);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[buf][i][k] = raw[k];
+            }
+        }
+    };
+
+    const long long gfirst = glo + (long long)(blockIdx.x / NRT_NXCD);
+    if (gfirst >= ghi) return;                                 // the whole block
+    Grp cur = decode(gfirst);
+    __amdgpu_buffer_rsrc_t wcur = weights_of(cur);
+    issue_patch(cur);
+    vec_t bcur = bias_of(cur.o), bnext = bcur;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < RD; ++g) {
+        issue_group(wcur, g, g);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                                           // the zero fill of both patch buffers
+    unsigned par = 0;                                          // which patch buffer this group uses
+    for (long long gi = gfirst;; gi += gstep) {
+        const Grp nxt = decode(gi + gstep);
+        const __amdgpu_buffer_rsrc_t wnext = weights_of(nxt);
+        char *patch = lc_patch + (size_t)par * NB * PB;
+#pragma unroll
+        for (int k = 0; k < NPT; ++k)
+            if (pval[k]) *(u32x4 *)(patch + loff[k]) = pc[k];
+        __syncthreads();                                       // also: every wave is done with the OTHER buffer's previous contents
+
+        lc_f4 acc[S][CPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) acc[s][jj] = (lc_f4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int i = 0; i < GC; ++i) {
+                const int c = g * GC + i;
+                if (c < NCMAX) {
+                    const unsigned coff = (unsigned)(c / KZ) * RUNB + (unsigned)(c % KZ) * CINB;       // chunks past the layer's: zeros
+                    float av[S];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) av[s] = to_f32(*(const T *)(patch + aoff[s] + coff));
+#pragma unroll
+                    for (int jj = 0; jj < CPL; ++jj) {
+                        float bw;
+                        if constexpr (sizeof(T) == 2) {
+                            const unsigned d = w[g % RD][i][jj >> 1];
+                            bw = __uint_as_float((jj & 1) ? (d & 0xffff0000u) : (d << 16));
+                        } else {
+                            bw = __uint_as_float(w[g % RD][i][jj]);
+                        }
+#pragma unroll
+                        for (int s = 0; s < S; ++s) acc[s][jj] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s], bw, acc[s][jj], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == NG - RD) { issue_patch(nxt); bnext = bias_of(nxt.o); __builtin_amdgcn_sched_barrier(0); }
+            if (g + RD < NG) issue_group(wcur, g % RD, g + RD);
+            else issue_group(wnext, g % RD, g + RD - NG);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int q = blk & 3, R = lane >> 4;
+        float val[S][CPL];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int jj = 0; jj < CPL; ++jj) {
+                lc_f4 v = acc[s][jj];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] += lc_row_ror(v[r], 1);
+                    v[r] += lc_row_ror(v[r], 0);
+                }
+                const float lo = (q & 1) ? v[1] : v[0], hi = (q & 1) ? v[3] : v[2];
+                val[s][jj] = (q & 2) ? hi : lo;
+            }
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            float other[S][CPL];
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int jj = 0; jj < CPL; ++jj) other[s][jj] = __shfl_xor(val[s][jj], off, 64);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int jj = 0; jj < CPL; ++jj) val[s][jj] += other[s][jj];
+        }
+        const int b = 4 * R + q;
+        if (R < S && b < nb && cur.act) {
+            const vec_t bv = bcur;
+            vec_t ov;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                float v = val[0][e];
+#pragma unroll
+                for (int s = 1; s < S; ++s) v = (R == s) ? val[s][e] : v;
+                if (a.bias) v += to_f32(bv[e]);
+                T qv;
+                store_out(&qv, lc_act(v, a.act));
+                ov[e] = qv;
+            }
+            *(vec_t *)((T *)a.y + ((long long)(b0 + b) * O + cur.o) * a.Cout + n * CPL) = ov;
+        }
+        if (!nxt.live) break;
+        cur = nxt;
+        wcur = wnext;
+        bcur = bnext;
+        par ^= 1u;
+    }
+}
+
 template <typename T, int CPL>
 bool launch_mfma(const LcArgs &a, hipStream_t st) {
     // experiment knob: NRT_LC_MFMA = 0 keeps the vector kernel for every batch size
@@ -569,8 +788,30 @@ bool launch_mfma(const LcArgs &a, hipStream_t st) {
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), shm, st, a, b0, nb);
     };
+    // the block-staged form: 3 taps along z over exactly 16 input channels, unit z stride, <= 9 (kr, kc) runs
+    static int kblk = -1;
+    if (kblk < 0) { const char *e = getenv("NRT_LC_BLK"); kblk = e ? atoi(e) : 1; }
+    const bool blk_ok = kblk && a.kz == 3 && a.Cin == 16 && a.sz == 1 && a.kr * a.kc <= 9 && (((uintptr_t)a.x) & 15) == 0;
+    constexpr size_t CINB = 16 * sizeof(T), PBB = 9 * 6 * CINB + 5 * CINB;
+    auto run_blk = [&](auto kernel, int sets, int b0, int nb) {
+        const size_t shm = (size_t)2 * 4 * sets * PBB;
+        static int per_cu = 0;
+        if (per_cu == 0 && (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
+                            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, shm) != hipSuccess || per_cu < 1)) per_cu = 2;
+        const long long ngrp = (long long)a.orr * a.occ * ((a.ozz + 3) / 4);
+        unsigned blocks = nrt_xcd_grid((unsigned)ngrp);
+        const unsigned cap = nrt_xcd_grid(kblocks > 0 ? (unsigned)kblocks : (unsigned)per_cu * (unsigned)nrt_num_cus());
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), shm, st, a, b0, nb);
+    };
+    constexpr int NPT1 = (int)((4 * 9 * 6 * CINB / 16 + 255) / 256), NPT2 = (int)((8 * 9 * 6 * CINB / 16 + 255) / 256);
     for (int b0 = 0; b0 < a.B; b0 += 8) {
         const int nb = a.B - b0 < 8 ? a.B - b0 : 8;
+        if (blk_ok) {
+            if (nb <= 4) run_blk(lc3d_fwd_mfma_blk<T, CPL, 1, NCMAX, NPT1>, 1, b0, nb);
+            else run_blk(lc3d_fwd_mfma_blk<T, CPL, 2, NCMAX, NPT2>, 2, b0, nb);
+            continue;
+        }
         if (nb <= 4) {
             if (two) run(lc3d_fwd_mfma<T, CPL, 1, NCMAX, 2>, 1, b0, nb);
             else run(lc3d_fwd_mfma<T, CPL, 1, NCMAX, 1>, 1, b0, nb);
