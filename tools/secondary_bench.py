@@ -64,3 +64,16 @@ def warp_onehot():
     rc = _lib.lib().nrt_synth_labels_out(_lib.ptr(idx), _lib.ptr(lut), L, L, _lib.ptr(oh), None, nvox, _lib.stream_ptr(dev))
     assert rc == 0
 row('nearest warp of a label map + LUT / one-hot (labels_to_image output stage)', timeit(warp_onehot), nvox * (4 + 12 + 4 + 4 + 4 * L))
+# the segmentation loss pair (neurite/tf/losses.py:225-246) on one prediction: one joint pass each way (csrc/segloss.hip) against the
+# two losses on their own; algorithmic bytes: forward 2 maps read once (8 L per voxel), forward + backward + 4 L written
+del logits, oh
+cce_o, dice_o = ne.losses.CategoricalCrossentropy(label_weights=w), ne.losses.Dice(check_input_limits=False)
+joint = ne.losses.multiple_losses_decorator([cce_o.loss, dice_o.loss])
+row('Dice + weighted CCE of one prediction, joint forward [4,160^3,32]', timeit(lambda: joint(fix, p)), nvox * 256)
+row('Dice + weighted CCE, the two losses separately (forward)', timeit(lambda: cce_o.loss(fix, p) + dice_o.loss(fix, p)), nvox * 256)
+pg = p.clone().requires_grad_()
+def fb(fn):
+    pg.grad = None
+    fn(fix, pg).mean().backward()
+row('Dice + weighted CCE, joint forward + backward wrt the prediction', timeit(lambda: fb(joint)), nvox * (256 + 256 + 128))
+row('Dice + weighted CCE, separately, forward + backward', timeit(lambda: fb(lambda a, b: cce_o.loss(a, b) + dice_o.loss(a, b))), nvox * (256 + 256 + 128))
