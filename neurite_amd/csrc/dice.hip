@@ -466,7 +466,7 @@ __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_label(const int *__restr
 // (counter (kind, label) of lane j at word (kind * L + label) * 256 + j: the lanes of an instruction hit different banks whatever
 // their labels are), so counting is three conflict-free ds_add per voxel and no ballot / shuffle / same-address queue -- blob-like
 // label maps put whole waves on one label, which made the shared-histogram form above run at 0.15 of the HBM roof
-// (profiles/r02_smallc/secondary_bench.jsonl).  Each lane streams 16-byte quads of both maps, four quads in flight.
+// (profiles/archive/r02_smallc/secondary_bench.jsonl).  Each lane streams 16-byte quads of both maps, four quads in flight.
 __global__ __launch_bounds__(DICE_BLOCK) void dice_hard_label_private(const int *__restrict__ yt, const int *__restrict__ yp,
                                                                       long long nvox, int L, unsigned *__restrict__ ipart) {
     extern __shared__ unsigned hist[];      // [3 * L][256]

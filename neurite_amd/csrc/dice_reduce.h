@@ -57,7 +57,7 @@ __device__ __forceinline__ T wave_xor_add(T v, int from) {
 }
 
 // Second stage, two levels so that no thread walks a long dependent chain (a single-level version took
-// 63 us for 2048 partials, profiles/r01_session1): level 1 reduces groups of RED_ROWS block partials in
+// 63 us for 2048 partials, profiles/archive/r01_session1): level 1 reduces groups of RED_ROWS block partials in
 // float64 (one block per group), level 2 adds the <= 32 group sums in a fixed order and does the
 // division.  Fixed partition + fixed order => bit-reproducible.
 constexpr int RED_ROWS = 64;

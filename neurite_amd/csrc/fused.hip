@@ -172,13 +172,13 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
 // passes between block barriers (power of two; 0 = none).  The four waves of a block are y-neighbours: half of a wave's corner rows
 // are its neighbour's, and they merge in L1 only while the waves request them at about the same time.  Left alone the waves drift
 // apart; a barrier every 8 passes keeps them together at no measurable cost: 1.174 -> 1.157 ms on one box, 1.148 -> 1.109 on another
-// (every 2 passes: slower; 16: the same; 32: less), profiles/r03_lab/fused_occupancy_depth.jsonl
+// (every 2 passes: slower; 16: the same; 32: less), profiles/archive/r03_lab/fused_occupancy_depth.jsonl
 #define NRT_FUSED_SYNC 8
 #endif
 #ifndef NRT_FUSED_MINW
 // waves per SIMD the x-march instance is compiled for (register budget 512 / MINW).  Two blocks of four waves run per CU (the LDS
 // padding below), so 4 only squeezed the kernel into 128 registers with three of them spilled; at 3 it takes 130, nothing spills:
-// 1.158 -> 1.140 ms (two alternating repeats, profiles/r03_lab/fused_occupancy_depth.jsonl)
+// 1.158 -> 1.140 ms (two alternating repeats, profiles/archive/r03_lab/fused_occupancy_depth.jsonl)
 #define NRT_FUSED_MINW 3
 #endif
 #ifndef NRT_FUSED_EXP

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WX * WY * 64) void interpn_zrun_c32(InterpArgs a, i
 // ============================================================================================
 // tile: G = C/4 lanes per voxel, 3-D output tiles, two voxels per lane-group in flight.
 //
-// Measured on MI355X (profiles/r01_session1): the one-voxel-at-a-time kernels above run at ~3.3 TB/s
+// Measured on MI355X (profiles/archive/r01_session1): the one-voxel-at-a-time kernels above run at ~3.3 TB/s
 // although the chip moves 9 TB/s of rows in the incoherent worst case -- they are bound by the
 // dependent chain  loc load -> address -> 8 row loads -> blend  (two HBM latencies per voxel), and a
 // z-line traversal re-fetches every row for its x-neighbour line (FETCH_SIZE 1.9x algorithmic).  So:
@@ -699,7 +699,7 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         else if (can_lean) variant = 8;
         else if (can_rows && method == NRT_INTERP_LINEAR && vol_bytes < (1ull << 32) && a.nout >= 4096) {
             // 8 / 16 / 64 ... channels (feature maps): the pipelined 3-D tiles beat the row kernel at 4 x 160^3 -- C = 8 0.490 vs
-            // 0.636 ms, C = 16 0.787 vs 0.907, C = 64 2.70 vs 3.09 (tools/midc_sweep.py, profiles/r02_smallc/midc_sweep.jsonl)
+            // 0.636 ms, C = 16 0.787 vs 0.907, C = 64 2.70 vs 3.09 (tools/midc_sweep.py, profiles/archive/r02_smallc/midc_sweep.jsonl)
             variant = 5;
             if (tune == 0) tune = channels <= 16 ? (2 | (3 << 4) | (4 << 8) | (1 << 12)) : 0;
         }

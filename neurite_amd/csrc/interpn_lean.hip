@@ -3,7 +3,7 @@
 // With 4..16 bytes per voxel the warp of an image or of a flow field (SpatialTransformer on C = 1 images, Resize(2) of the
 // C = 3 deformation at neurite/tf/models.py:804, VecInt / compose) is not bound by HBM but by instruction issue: the
 // LDS-staged kernel (variant 6) spends ~450 issue slots per voxel on bounding boxes, the box copy with its divisions and
-// 64-bit addresses (0.23-0.25 of the HBM roof at 160^3, profiles/r01_session50).  Here nothing is staged: the source of a
+// 64-bit addresses (0.23-0.25 of the HBM roof at 160^3, profiles/archive/r01_session50).  Here nothing is staged: the source of a
 // few-channel volume is small (16 MB at 160^3 x 1) and neighbouring lanes read neighbouring addresses, so the 8 corner
 // reads are L1 / L2 hits; what is left is the reference's arithmetic, strength-reduced:
 //   * a lane owns VPL consecutive-z output voxels (4 at C = 1, 2 at C = 2): x, y and their corner arithmetic are
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void interpn_lean_tile(InterpArgs a, int ltz, 
         if constexpr (C <= 2) paired = a.S[2] >= 2;                      // uniform; a 1-voxel z extent has no pair to load
         if (paired) {
             // The texture-address unit spends ~1 cycle per LANE of a gather whose lanes are not consecutive (measured: 8.07 cache
-            // accesses per voxel, TA busy 88 %, profiles/r02_smallc): the two z corners of an (x, y) row are neighbours in
+            // accesses per voxel, TA busy 88 %, profiles/archive/r02_smallc): the two z corners of an (x, y) row are neighbours in
             // memory, so ONE load of 2 C floats fetches both -- 4 lane accesses per voxel instead of 8.  At the upper border
             // (z1 == z0 == SZ - 1) the pair starts one voxel earlier and both corners take its second half.
             const unsigned izp = (unsigned)min(iz, a.S[2] - 2);

@@ -3,7 +3,7 @@
 //
 // Why: the register kernels (interpn.hip, fused.hip) pull 8 corner rows + 1 fixed row = 1152 B per voxel through the
 // texture path (TA -> L1 -> VGPR, 64 B/clk/CU); of those only ~2.3 rows are HBM misses, the rest are L1 / L2 hits that still
-// occupy the path (profiles/r02_lab: hits and misses issued by one CU cost additively).  On the SURVEY 8d field a voxel shares
+// occupy the path (profiles/archive/r02_lab: hits and misses issued by one CU cost additively).  On the SURVEY 8d field a voxel shares
 // its corner rows with its (y,z) neighbours and with the next x plane: an x-marching 4 x 8 patch needs only ~2.0 NEW rows per
 // voxel.  So a workgroup keeps a software cache of source rows in LDS and the texture path carries each row once:
 //
@@ -112,7 +112,7 @@ struct LcPrep {
 
 // MODE = location mode; DICE = accumulate the soft-Dice sums against `fixed`; STORE = write the warped rows; FILL = fill_value
 // given.  DIAG: 0 = product; 1 = no tag protocol (every corner "hits" slot id % 256, 32 arbitrary rows fetched per wave and step):
-// the cost of the data path alone; 2 = product + phase clocks (profiles/r03_lc).
+// the cost of the data path alone; 2 = product + phase clocks (profiles/archive/r03_lc).
 template <int MODE, bool DICE, bool STORE, bool FILL, int DIAG>
 __global__ __launch_bounds__(384, 3) void gather_lc(LcK a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
