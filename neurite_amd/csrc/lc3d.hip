@@ -781,7 +781,10 @@ bool launch_mfma(const LcArgs &a, hipStream_t st) {
     // on a nearly empty machine: 1024 blocks on 768 slots cost 25 % at batch 8)
     auto run = [&](auto kernel, int sets, int b0, int nb) {
         const size_t shm = (size_t)4 * 4 * sets * pb;
-        static int per_cu = 0;                                 // per instantiation (the LDS size is a function of it)
+        static int per_cu_dev[64];                             // per instantiation (the LDS size is a function of it) and device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        int &per_cu = per_cu_dev[dev];
         if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, shm) != hipSuccess || per_cu < 1)) per_cu = 2;
         unsigned blocks = nrt_xcd_grid((unsigned)((O + 3) / 4));
         const unsigned cap = nrt_xcd_grid(kblocks > 0 ? (unsigned)kblocks : (unsigned)per_cu * (unsigned)nrt_num_cus());
@@ -795,21 +798,27 @@ bool launch_mfma(const LcArgs &a, hipStream_t st) {
     constexpr size_t CINB = 16 * sizeof(T), PBB = 9 * 6 * CINB + 5 * CINB;
     auto run_blk = [&](auto kernel, int sets, int b0, int nb) {
         const size_t shm = (size_t)2 * 4 * sets * PBB;
-        static int per_cu = 0;
-        if (per_cu == 0 && (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess ||
-                            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, shm) != hipSuccess || per_cu < 1)) per_cu = 2;
+        static int per_cu_dev[64];                             // per instantiation and device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        int &per_cu = per_cu_dev[dev];
+        // (function attributes are per device: set at every launch that needs more than the default 64 KB -- none does today)
+        if (shm > 64 * 1024 && hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return false;
+        if (per_cu == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, shm) != hipSuccess || per_cu < 1)) per_cu = 2;
         const long long ngrp = (long long)a.orr * a.occ * ((a.ozz + 3) / 4);
         unsigned blocks = nrt_xcd_grid((unsigned)ngrp);
         const unsigned cap = nrt_xcd_grid(kblocks > 0 ? (unsigned)kblocks : (unsigned)per_cu * (unsigned)nrt_num_cus());
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), shm, st, a, b0, nb);
+        return true;
     };
     constexpr int NPT1 = (int)((4 * 9 * 6 * CINB / 16 + 255) / 256), NPT2 = (int)((8 * 9 * 6 * CINB / 16 + 255) / 256);
     for (int b0 = 0; b0 < a.B; b0 += 8) {
         const int nb = a.B - b0 < 8 ? a.B - b0 : 8;
         if (blk_ok) {
-            if (nb <= 4) run_blk(lc3d_fwd_mfma_blk<T, CPL, 1, NCMAX, NPT1>, 1, b0, nb);
-            else run_blk(lc3d_fwd_mfma_blk<T, CPL, 2, NCMAX, NPT2>, 2, b0, nb);
+            // (false: nothing was launched for this chunk -- the caller's vector kernels then compute the whole batch)
+            if (!(nb <= 4 ? run_blk(lc3d_fwd_mfma_blk<T, CPL, 1, NCMAX, NPT1>, 1, b0, nb) : run_blk(lc3d_fwd_mfma_blk<T, CPL, 2, NCMAX, NPT2>, 2, b0, nb)))
+                return false;
             continue;
         }
         if (nb <= 4) {
