@@ -10,6 +10,7 @@ reference.  All voxel-sized work runs in csrc/dice.hip and csrc/cce.hip through 
 what remains here is argument handling and arithmetic on [B, L]-sized results.
 """
 
+import threading
 import warnings
 
 import numpy as np
@@ -237,7 +238,7 @@ class JointSegLoss:
     their numbers from one shared _SegLossFn application; everything else those methods do (weights, means, reductions, the finite
     check) is unchanged.  `JointSegLoss.open(...)` returns None when the pair does not qualify (then nothing is intercepted).
     """
-    _tls = __import__('threading').local()
+    _tls = threading.local()
     applications = 0            # _SegLossFn evaluations so far (tests check that the joint path really ran)
     through_softmax = 0         # ... of which attached to the producer of the soft-max
 
