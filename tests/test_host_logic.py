@@ -823,3 +823,33 @@ def test_bench_quotes_traffic_only_for_the_timed_kernel(tmp_path):
     # the committed file itself has the keyed layout
     tj = json.load(open(os.path.join(root, 'profiles', 'hbm_traffic.json')))
     assert 'kernels' in tj and all('<' in k for k in tj['kernels'])
+
+
+def test_multiple_losses_decorator_host_side():
+    """neurite/tf/losses.py:225-246: weighted sum of callables; the Dice + CCE pairing logic of this package (no device work here)"""
+    from neurite_amd import losses, metrics
+    f = ne.losses.multiple_losses_decorator([lambda a, b: a + b, lambda a, b: a * b], [1, 2])
+    assert f(1.0, 3.0) == 10.0
+    assert ne.losses.multiple_losses_decorator([lambda a, b: a - b])(5.0, 3.0) == 2.0                     # weights default to ones
+    c, d, h = ne.losses.CategoricalCrossentropy(), ne.losses.Dice(), ne.losses.HardDice(4)
+    assert losses._owner(c.loss, metrics.CategoricalCrossentropy, ('loss', 'cce', '__call__')) is c
+    assert losses._owner(c, metrics.CategoricalCrossentropy, ('loss',)) is c                              # the object itself is callable
+    assert losses._owner(d.mean_loss, metrics.Dice, ('loss', 'mean_loss', 'dice', 'mean_dice')) is d
+    assert losses._owner(lambda a, b: d.loss(a, b), metrics.Dice, ('loss',)) is None                      # hidden behind a lambda: not paired
+    assert losses._owner(d.loss, metrics.CategoricalCrossentropy, ('loss',)) is None
+    # CPU tensors never open a joint evaluation: the two losses run on their own and refuse the host tensors as always
+    t = torch.zeros(1, 4, 4, 4, 8)
+    assert metrics.JointSegLoss.open(d, c, t, t) is None and metrics.JointSegLoss.open(h, c, t, t) is None
+    joint = ne.losses.multiple_losses_decorator([c.loss, d.mean_loss])
+    with pytest.raises(ne.errors.NeuriteAmdError, match='no CPU fallback'):
+        joint(t, t)
+    assert getattr(metrics.JointSegLoss._tls, 'current', None) is None
+    # a joint evaluation that raises leaves no context behind
+    class Boom(metrics.JointSegLoss):
+        def result(self):
+            raise RuntimeError('boom')
+    with pytest.raises(RuntimeError, match='boom'):
+        with Boom(d, c, t, t) as j:
+            assert metrics.JointSegLoss.lookup(d, t, t) is j and metrics.JointSegLoss.lookup(d, t, t.clone()) is None
+            j.result()
+    assert getattr(metrics.JointSegLoss._tls, 'current', None) is None
