@@ -902,7 +902,7 @@ extern "C" int nrt_maxpool3d_bwd_f32(const float *x, const float *grad_out, floa
     const int OZ = padding_same ? (Z + pool[2] - 1) / pool[2] : Z / pool[2];
     hipStream_t st = nrt_stream(stream);
     if (!padding_same && (X % pool[0] || Y % pool[1] || Z % pool[2]))       // voxels outside every window get zero
-        if (hipMemsetAsync(grad_x, 0, (size_t)batch * X * Y * Z * channels * sizeof(float), st) != hipSuccess) return NRT_ERR_LAUNCH;
+        if (nrt_zero_async(grad_x, (size_t)batch * X * Y * Z * channels * sizeof(float), st) != hipSuccess) return NRT_ERR_LAUNCH;
     const long long total = (long long)OX * OY * OZ * channels;
     if (total == 0) return NRT_OK;
     hipLaunchKernelGGL(maxpool_bwd, dim3(ew_blocks(total, 256), batch), dim3(256), 0, st, x, grad_out, grad_x, X, Y, Z, channels,

@@ -645,7 +645,7 @@ int dice_hard_prob_impl(const void *y_true, const void *y_pred, long long nvox, 
         }
     } else {
         if (minmax) return NRT_ERR_UNSUPPORTED;       // the generic kernel has no extrema: the caller runs the soft pass for them
-        if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
+        if (nrt_zero_async(counts, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
             return NRT_ERR_LAUNCH;
         // rows of VP voxels in LDS: VP = 256 while 256 * L floats + the histogram fit in 48 KB, fewer voxels for wide rows
         int VP = DICE_BLOCK;
@@ -769,7 +769,7 @@ extern "C" int nrt_dice_hard_label_i32(const int32_t *y_true, const int32_t *y_p
         hipLaunchKernelGGL(dice_counts_reduce, dim3(batch), dim3(256), 0, st, (const long long *)w.gsum, ngrp,
                            nlabels, counts);
     } else {
-        if (hipMemsetAsync(counts, 0, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
+        if (nrt_zero_async(counts, sizeof(long long) * (size_t)batch * 3 * nlabels, st) != hipSuccess)
             return NRT_ERR_LAUNCH;
         hipLaunchKernelGGL((dice_hard_label<false>), dim3(nblk, batch), dim3(DICE_BLOCK), shm, st, (const int *)y_true,
                            (const int *)y_pred, nvox, nlabels, use_lds, counts, (unsigned *)nullptr);

@@ -417,6 +417,11 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     xmarch_zero_rows(tg, xw, 3 * L, fpart, mpart);
 }
 
+// The work counters of a persistent launch are zeroed by a KERNEL on the launch stream (nrt_zero_async), not by hipMemsetAsync: inside
+// a captured hipGraph the memset node did not take effect between replays (ROCm 7.2) -- every replay after the first found the lists
+// exhausted, its blocks left at once and the second stage re-reduced the previous replay's partial sums: stale results in 0.03 ms
+// (tools/graph_fused_probe.py; tests/test_gpu_dice_cce.py::test_fused_kernels_recompute_under_graph_replay).
+
 // PERSIST: 2 blocks per CU stay resident and take items from per-XCD lists (atomic counters in `queue`, zeroed before the launch):
 // first their own XCD's (its L2 holds the neighbouring columns), then the others'.  With one block per item the XCDs finish up to
 // 5 % apart (tools/block_trace.py: last block of an XCD at 1044 .. 1097 us) and the slots of a finished XCD idle; the items are the
@@ -464,7 +469,7 @@ int launch_wc_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, in
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, STORE, MM, FILL, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WC_BLOCK_BYTES) != hipSuccess)
             return NRT_ERR_LAUNCH;
-        if (hipMemsetAsync(queue, 0, NRT_NXCD * 64, st) != hipSuccess) return NRT_ERR_LAUNCH;
+        if (nrt_zero_async(queue, NRT_NXCD * 64, st) != hipSuccess) return NRT_ERR_LAUNCH;
         hipLaunchKernelGGL((warp_dice_wc<MODE, STORE, MM, FILL, true, true>), dim3(nrt_xcd_grid(slots)), dim3(256), WC_BLOCK_BYTES, st, a, tg, fixed,
                            fpart, mpart, queue);
         return NRT_OK;
@@ -528,8 +533,9 @@ int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, hipStream_t 
     unsigned *queue = (NRT_FUSED_WCPERSIST && items > slots) ? wc_queue_slot() : nullptr;
     if (queue) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, true, false, FILL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)WC_BLOCK_BYTES) != hipSuccess || hipMemsetAsync(queue, 0, NRT_NXCD * 64, st) != hipSuccess)
+                                (int)WC_BLOCK_BYTES) != hipSuccess)
             return NRT_ERR_LAUNCH;
+        if (nrt_zero_async(queue, NRT_NXCD * 64, st) != hipSuccess) return NRT_ERR_LAUNCH;
         hipLaunchKernelGGL((warp_dice_wc<MODE, true, false, FILL, false, true>), dim3(nrt_xcd_grid(slots)), dim3(256), WC_BLOCK_BYTES, st, a, tg,
                            (const float *)nullptr, (float *)nullptr, (float *)nullptr, queue);
         return NRT_OK;

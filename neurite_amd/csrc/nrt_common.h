@@ -71,6 +71,26 @@ static inline unsigned nrt_xcd_grid(unsigned nblocks) {
 
 static inline hipStream_t nrt_stream(void *s) { return (hipStream_t)s; }
 
+// Zero fill on a stream by a KERNEL.  hipMemsetAsync is not used on paths that may run inside a captured hipGraph: the memset node of the
+// persistent gather's work counters did not take effect between replays (ROCm 7.2; tools/graph_fused_probe.py, fused_wc.h).
+// `bytes` is a multiple of 4 and `p` 4-byte aligned (every caller zeroes float / int / int64 tensors).
+static __global__ void nrt_zero_words(unsigned *__restrict__ p, size_t nwords) {
+    const size_t n4 = (((uintptr_t)p & 15) == 0) ? nwords >> 2 : 0;            // 16-byte stores where the pointer allows
+    typedef unsigned nrt_zu4 __attribute__((ext_vector_type(4)));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        ((nrt_zu4 *)p)[i] = (nrt_zu4){0u, 0u, 0u, 0u};
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t nrt_zero_async(void *p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    const size_t nwords = bytes >> 2;
+    size_t blocks = (nwords / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(nrt_zero_words, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned *)p, nwords);
+    return hipGetLastError();
+}
+
 // compute units of the current device (persistent kernels size their grid with it)
 static inline int nrt_num_cus() {
     static int cached[64];

@@ -532,3 +532,46 @@ def test_fused_bf16_storage(dev):
     # smaller label counts take the same template
     m8, f8, t8 = synth.cfg2_batch(1, 24, 8, device=dev, seed0=9)
     assert bits_equal(N(ne.fused.warp_dice(m8.bfloat16(), t8, f8.bfloat16())), N(ne.fused.warp_dice(m8, t8, f8)))
+
+
+def test_fused_kernels_recompute_under_graph_replay(dev):
+    """a captured hipGraph of the fused warp + Dice (persistent wave-cache kernel with its work counters, and the register kernel) and
+    of the stand-alone wave-cache warp must RECOMPUTE on every replay: the inputs are changed between replays.  (With the counters
+    reset by a memset node the replays left at once and the second stage re-reduced stale partial sums -- identical inputs hid it.)"""
+    mov, fix, trf = synth.cfg2_batch(2, 96, 32, device=dev, seed0=31)
+    fix_a, fix_b = fix.clone(), torch.roll(fix, 5, dims=-1).contiguous()
+    trf_a, trf_b = trf.clone(), (trf * 0.5).contiguous()
+
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
+    st10 = ne.layers.SpatialTransformer()
+    st10._variant = 10
+    keep = ne.deferred.enabled
+    ne.deferred.enabled = False
+    try:
+        cases = [('wave cache', lambda: ne.fused.warp_dice(mov, trf, fix, _tune=1 << 29)),
+                 ('register', lambda: ne.fused.warp_dice(mov, trf, fix, _tune=1 << 30)),
+                 ('wave-cache warp', lambda: st10([mov, trf]))]
+        for name, fn in cases:
+            g, out = capture(fn)
+            for fsrc, tsrc in ((fix_a, trf_a), (fix_b, trf_a), (fix_b, trf_b), (fix_a, trf_a)):
+                fix.copy_(fsrc)
+                trf.copy_(tsrc)
+                g.replay()
+                torch.cuda.synchronize()
+                got = out.clone()
+                assert torch.equal(got, fn()), name
+    finally:
+        ne.deferred.enabled = keep
+        fix.copy_(fix_a)
+        trf.copy_(trf_a)
