@@ -113,3 +113,37 @@ def test_layers_under_graph_replay(dev):
     vs = [v.clone(), torch.roll(v, 3, dims=2).contiguous()]
     check('unet forward', lambda: net(v), [v], [(vs[0],), (vs[1],)])
     assert rng is not None
+
+
+def test_two_streams_do_not_share_scratch(dev):
+    """the same ops issued on two streams at once (different inputs): reductions keep their partial sums in a per-(device, stream)
+    workspace, the persistent gathers their work counters in that workspace / in a ring of counter sets -- results equal the serial ones"""
+    a = synth.cfg2_batch(2, 96, 32, device=dev, seed0=51)
+    b = synth.cfg2_batch(2, 96, 32, device=dev, seed0=77)
+    dice = ne.metrics.Dice(check_input_limits=False)
+    w = torch.rand(32, device=dev) + 0.5
+    cce = ne.losses.CategoricalCrossentropy(label_weights=w)
+    st10 = ne.layers.SpatialTransformer()
+    st10._variant = 10
+
+    def ops(mov, fix, trf):
+        keep = ne.deferred.enabled
+        ne.deferred.enabled = False
+        try:
+            return [ne.fused.warp_dice(mov, trf, fix), dice.dice(fix, mov), cce.loss(fix, mov.clamp_min(1e-3)), st10([mov, trf])]
+        finally:
+            ne.deferred.enabled = keep
+    want_a, want_b = ops(*a), ops(*b)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            got_a = ops(*a)
+        with torch.cuda.stream(s2):
+            got_b = ops(*b)
+        with torch.cuda.stream(s1):
+            got_a2 = ops(*a)
+        torch.cuda.synchronize()
+        for got, want in ((got_a, want_a), (got_b, want_b), (got_a2, want_a)):
+            for x, y in zip(got, want):
+                assert torch.equal(x, y)
