@@ -62,6 +62,11 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
         raise ValueError('batch size of the transform does not match the volume')
     mov = moving.contiguous()
     fix = fixed.contiguous()
+    # the kernels read whole 16-byte row pieces: a view whose storage offset is not a multiple of 16 bytes is copied once
+    if mov.data_ptr() % 16:
+        mov = mov.clone()
+    if fix.data_ptr() % 16:
+        fix = fix.clone()
     shift = trf.to(torch.float32)
     if indexing == 'xy':
         shift = torch.cat([shift[..., 1:2], shift[..., 0:1], shift[..., 2:]], -1)

@@ -147,3 +147,65 @@ def test_two_streams_do_not_share_scratch(dev):
         for got, want in ((got_a, want_a), (got_b, want_b), (got_a2, want_a)):
             for x, y in zip(got, want):
                 assert torch.equal(x, y)
+
+
+def test_views_and_misaligned_storage(dev):
+    """inputs that are views with a 4-byte storage offset (not 16-byte aligned) or non-contiguous: every op gives the numbers it gives
+    on aligned contiguous copies (the vector kernels need 16-byte rows; the entry points must notice, not fault)"""
+    mov, fix, trf = synth.cfg2_batch(2, 48, 32, device=dev, seed0=61)
+
+    def shifted(t):                                # same values, storage offset of one element
+        flat = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+        v = flat[1:].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+        return v
+
+    def strided(t):                                # same values, channel-last view of a channel-first buffer
+        v = t.permute(0, 4, 1, 2, 3).contiguous().permute(0, 2, 3, 4, 1)
+        assert not v.is_contiguous()
+        return v
+    keep = ne.deferred.enabled
+    ne.deferred.enabled = False
+    try:
+        dice = ne.metrics.Dice(check_input_limits=False)
+        w = torch.rand(32, device=dev) + 0.5
+        cce = ne.losses.CategoricalCrossentropy(label_weights=w)
+        st, stn = ne.layers.SpatialTransformer(), ne.layers.SpatialTransformer(interp_method='nearest')
+        p = mov.clamp_min(1e-3)
+        ref = dict(warp=st([mov, trf]), nearest=stn([mov, trf]), dice=dice.dice(fix, mov), cce=cce.loss(fix, p),
+                   fused=ne.fused.warp_dice(mov, trf, fix), resize=ne.layers.Resize(2)(mov[:, ::2, ::2, ::2].contiguous()))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ref['hard'] = ne.metrics.HardDice(32, input_type='prob', check_input_limits=False).dice(fix, mov)
+        for name, f in (('offset', shifted), ('strided', strided)):
+            m, fx, pp = f(mov), f(fix), f(p)
+            t = f(trf) if name == 'offset' else trf.permute(0, 4, 1, 2, 3).contiguous().permute(0, 2, 3, 4, 1)
+            assert torch.equal(st([m, t]), ref['warp']), name
+            assert torch.equal(stn([m, t]), ref['nearest']), name
+            assert torch.equal(dice.dice(fx, m), ref['dice']), name
+            assert torch.equal(ne.fused.warp_dice(m, t, fx), ref['fused']), name
+            np.testing.assert_allclose(float(cce.loss(fx, pp)), float(ref['cce']), rtol=1e-6)
+            assert torch.equal(ne.layers.Resize(2)(f(mov[:, ::2, ::2, ::2].contiguous())), ref['resize']), name
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                assert torch.equal(ne.metrics.HardDice(32, input_type='prob', check_input_limits=False).dice(fx, m), ref['hard']), name
+    finally:
+        ne.deferred.enabled = keep
+    # layers: a unet and a LocallyConnected3D on a view with a 4-byte storage offset
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ne.models.unet(8, (16, 16, 16, 2), 2, 3, 4, feat_mult=2).to(dev)
+    v = torch.randn(1, 16, 16, 16, 2, device=dev)
+    assert torch.equal(net(shifted(v)), net(v)) and torch.equal(net(strided(v)), net(v))
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn(3, 7, 8, 9, 16, device=dev).to(dtype)
+        layer = ne.layers.LocallyConnected3D(16, (3, 3, 3)).to(dev)
+        with torch.no_grad():
+            layer(x.float())
+            layer.to(dtype)
+            want = layer(x)
+            # (a misaligned volume takes the un-staged vector kernel: same products, another summation order)
+            tol = 1e-5 if dtype == torch.float32 else 2e-2
+            for got in (layer(shifted(x)), layer(strided(x))):
+                np.testing.assert_allclose(got.float().cpu().numpy(), want.float().cpu().numpy(), rtol=tol, atol=tol)
+
