@@ -78,7 +78,9 @@ int nrt_interpn_f32(const float *vol, const float *loc, float *out,
  *   0 auto | 1 generic element-per-thread | 2 row-per-lane-group (C%4==0)
  *   3 z-run with register reuse of the shared corner rows (ndim 3, C==32)
  *   5 3-D tiles with a depth-2 software pipeline (C%4==0, linear)
- *   6 LDS-staged source box per 8x8x16 tile (ndim 3, C<=4, linear, >= 1024 outputs)
+ *   8 few-channel kernel: one voxel per lane, z corners of a row by one load (ndim 3, C<=4; the auto choice there)
+ *   10 wave-private LDS row cache on the x-march schedule (ndim 3, C==32, linear; flat over field steepness: the better kernel on
+ *      steep or incoherent fields, the auto choice with NRT_INTERPN_WC=1)
  * tune: variant-specific knob (variant 3: z-chunk length | order | patch | region bits; variant 5: tile geometry). */
 int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out,
                        int ndim, const int *vol_shape, const int *out_shape, int channels,
@@ -373,8 +375,9 @@ int nrt_channel_axpby_f32(const float *a, const float *b, const float *coef_a, c
  * bias / activation of :1098-1101.
  *   x [batch, in_shape, cin]; kernel [O, kr*kc*kz*cin, cout] (feature order kr,kc,kz,cin; O = output
  *   positions row-major); bias [O, cout] or NULL; y [batch, out_shape, cout]; all of `dtype`
- *   (NRT_DT_F32 or NRT_DT_BF16), accumulation in float32.  Weights are read exactly once.
- * variant 0 auto | 1 generic | 2 weight-streaming wave-per-position kernel.
+ *   (NRT_DT_F32 or NRT_DT_BF16), accumulation in float32.  Weights are read exactly once per 1-2 batch entries (vector kernel) or per
+ *   <= 8 entries (batches of 3 and more: matrix-core kernel, v_mfma_f32_4x4x1; 16-channel 3x3x3 layers stage their patches per block).
+ * variant 0 auto | 1 generic | 2 weight-streaming wave-per-position kernels.
  * ------------------------------------------------------------------------------------------ */
 int nrt_lc3d_f(const void *x, const void *kernel, const void *bias, void *y, int dtype, int batch,
                const int *in_shape, int cin, const int *ksize, const int *strides, int cout,
