@@ -111,7 +111,10 @@ def test_lc3d_many_filters_batch(dev, batch):
 @pytest.mark.parametrize('batch', [3, 4, 5, 8, 9])
 @pytest.mark.parametrize('cin,cout,ks,st,S', [(16, 16, (3, 3, 3), (1, 1, 1), (6, 7, 9)), (16, 32, (3, 3, 3), (1, 1, 1), (5, 6, 7)),
                                                (16, 16, (3, 3, 3), (2, 1, 2), (7, 6, 9)), (8, 16, (2, 2, 2), (1, 1, 1), (5, 5, 6)),
-                                               (16, 8, (3, 3, 3), (1, 1, 1), (5, 5, 7))])
+                                               (16, 8, (3, 3, 3), (1, 1, 1), (5, 5, 7)),
+                                               # block-staged patches with fewer than 9 (kr, kc) runs, and with row / column strides
+                                               (16, 16, (1, 3, 3), (1, 1, 1), (4, 6, 9)), (16, 16, (3, 2, 3), (1, 2, 1), (6, 7, 10)),
+                                               (16, 32, (2, 1, 3), (2, 1, 1), (6, 4, 8))])
 def test_lc3d_matrix_core_batches(dev, batch, cin, cout, ks, st, S, monkeypatch):
     """3 .. 8 batch entries per weight pass on v_mfma_f32_4x4x1 (csrc/lc3d.hip: lc3d_fwd_mfma; 9 entries = 8 + 1): against the oracle
     and against the vector kernel (NRT_LC_MFMA=0 is read once per process, so the comparison kernel is asked for per entry pair:
