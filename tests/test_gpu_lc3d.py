@@ -138,6 +138,43 @@ def test_lc3d_matrix_core_batches(dev, batch, cin, cout, ks, st, S, monkeypatch)
     close(N(yb), npo.lc3d(N(xb), N(kb), N(bb), ks, st), 2.0 ** -8)
 
 
+@pytest.mark.parametrize('cout,dtype,batch', [(16, torch.bfloat16, 8), (32, torch.bfloat16, 5), (16, torch.float32, 6), (16, torch.bfloat16, 3)])
+def test_lc3d_matrix_core_many_positions(dev, cout, dtype, batch):
+    """enough positions (32^3) that every block of the matrix-core kernels walks several groups: the software pipeline across positions,
+    the double-buffered patches and the per-XCD ranges all turn over.  Against the vector kernel (two entries per pass) everywhere and
+    against float64 arithmetic on sampled positions; also without a bias."""
+    torch.manual_seed(cout + batch)
+    S, cin = 34, 16
+    x = torch.randn(batch, S, S, S, cin, device=dev).to(dtype)
+    for use_bias in (True, False):
+        layer = ne.layers.LocallyConnected3D(cout, (3, 3, 3), activation='elu', use_bias=use_bias).to(dev)
+        with torch.no_grad():
+            layer(x[:1].float())
+            layer.to(dtype)
+            if use_bias:
+                layer.bias.copy_(torch.randn_like(layer.bias))
+            y = layer(x)
+            pairs = torch.cat([layer(x[i:i + 2]) for i in range(0, batch, 2)], 0)
+        tol = 2e-6 if dtype == torch.float32 else 2.0 ** -7            # bfloat16 outputs: one rounding of sums in a different order
+        np.testing.assert_allclose(N(y), N(pairs), rtol=tol, atol=tol * float(pairs.float().abs().max()))
+        # float64 on sampled positions (first / last of every XCD's range included)
+        O = (S - 2) ** 3
+        k = layer.kernel.detach().double().cpu().numpy().reshape(O, 27 * cin, cout)
+        b = layer.bias.detach().double().cpu().numpy().reshape(O, cout) if use_bias else np.zeros((O, cout))
+        xs = x.double().cpu().numpy()
+        per = -(-(O // 1) // 8)
+        picks = sorted(set([0, O - 1] + [min(O - 1, j * (O // 8) + d) for j in range(8) for d in (0, 1, O // 8 - 1)] +
+                           list(np.random.default_rng(3).integers(0, O, 40))))
+        for o in picks:
+            oz, oc, orr = o % (S - 2), (o // (S - 2)) % (S - 2), o // ((S - 2) ** 2)
+            patch = xs[:, orr:orr + 3, oc:oc + 3, oz:oz + 3, :].reshape(batch, -1)
+            want = patch @ k[o] + b[o]
+            want = np.where(want > 0, want, np.exp(np.minimum(want, 0)) - 1)
+            got = N(y)[:, orr, oc, oz, :]
+            np.testing.assert_allclose(got, want, rtol=1e-5 if dtype == torch.float32 else 2.0 ** -7, atol=1e-5 if dtype == torch.float32 else 2.0 ** -6)
+        assert per > 0
+
+
 def test_lc3d_softmax_axis_follows_the_data_format(dev):
     """layers.py:1100 hands the layer output to Keras' softmax, which runs over the LAST axis of that tensor: the filters for
     channels_last, the last spatial axis for channels_first."""
