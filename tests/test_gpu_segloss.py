@@ -271,3 +271,27 @@ def test_training_step_captures_into_one_hipgraph(dev):
     np.testing.assert_allclose(replayed, eager, rtol=1e-4)
     for a, b in zip(par_e, par_g):
         close(N(b), N(a).astype(np.float64), 'parameters after 4 steps', 1e-4)
+
+
+def test_joint_loss_full_size_equals_the_separate_kernels(dev):
+    """BASELINE config 3 output size (1 x 160^3 x 32): every block of the joint kernels walks its whole voxel range (2048 blocks x 2000
+    voxels); forward and the gradient through a soft-max against the separate kernels"""
+    torch.manual_seed(3)
+    z = torch.randn(1, 160, 160, 160, 32, device=dev)
+    t = torch.nn.functional.one_hot(torch.randint(0, 32, (1, 160, 160, 160), device=dev), 32).float()
+    w = torch.rand(32, device=dev) + 0.5
+    gd = torch.randn(1, 32, device=dev)
+    n = 160 ** 3
+    zj = z.clone().requires_grad_()
+    y = M._softmax_with_grad(zj)
+    src = y._nrt_softmax_src
+    cce_sum, dice = MT._SegLossFn.apply(t, y.detach(), w, (0.0, 0.0, False), src, *src.inputs)
+    (1.3 * cce_sum[0] / n + (gd * dice).sum()).backward()
+    zs = z.clone().requires_grad_()
+    ys = M._SoftmaxFn.apply(zs)
+    cce_sep = MT._WcceFn.apply(t, ys, w, False, 0.0, False)
+    dice_sep = MT._SoftDiceFn.apply(t, ys, 0.0, False, False)
+    (1.3 * cce_sep[0] / n + (gd * dice_sep).sum()).backward()
+    assert torch.equal(dice, dice_sep)
+    np.testing.assert_allclose(N(cce_sum), N(cce_sep), rtol=1e-6)
+    close(N(zj.grad), N(zs.grad).astype(np.float64), 'd / d logits at full size', 2e-6)
