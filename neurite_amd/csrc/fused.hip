@@ -565,7 +565,7 @@ extern "C" const char *nrt_warp_dice_kernel_name(const int *out_shape, const int
     const char *tf[2] = {"false", "true"};
     if (G == 8 && use_wc && wc_applies(tg, G, a))
         snprintf(name, sizeof(name), "warp_dice_wc<%d, %s, %s, %s, true, %s>", loc_mode, tf[store != 0], tf[want_minmax != 0], tf[has_fill != 0],
-                 tf[NRT_FUSED_WCPERSIST && NRT_NXCD * tg.items_x > 2u * (unsigned)nrt_num_cus()]);
+                 tf[NRT_NXCD * tg.items_x > 2u * (unsigned)nrt_num_cus()]);
     else
         snprintf(name, sizeof(name), "warp_dice_tile<%d, %d, %s, %d, float>", G, loc_mode, tf[store != 0], tg.x_march ? NRT_FUSED_MINW : 1);
     return name;

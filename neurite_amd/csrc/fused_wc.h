@@ -3,34 +3,45 @@
 // Why (profiles/r04_lab/l1_access_curve.jsonl): the register kernel (warp_dice_tile) requests all 8 corner rows
 // of every voxel from L1.  Dropping corner requests from 8 to 4 / 2 / 1 per voxel with everything else unchanged takes the
 // launch from 1.085 ms to 0.843 / 0.788 / 0.755: the cost is the NUMBER OF ROW REQUESTS that pass the texture-address / L1
-// pipe (hit or miss), not HBM.  Reading the 8 corners from LDS instead (ds_read_b128: 256 B/clk/CU, its own pipe) with 2 rows
-// per voxel through L1 measures 0.88 ms (EXP=20 probe).  So: fetch every DISTINCT row once per wave and pass, keep it across
-// passes, blend from LDS.
+// pipe (hit or miss), not HBM.  So: fetch every DISTINCT row once per wave and pass, keep it across passes, blend from LDS.
 //
 // Structure.  The x-march schedule of warp_dice_tile is kept (a block of four waves owns a 4 x 8 (y,z) patch and walks x, one
 // x-plane per pass; blocks dealt to the XCDs region by region).  A wave owns a 2 x 4 sub-patch: 8 voxels per pass = one voxel
 // per 8-lane group, lane p of a group holds labels 4p..4p+3 (16 bytes of every row).  Each wave has its own direct-mapped cache
 // of 128 rows (16 KB) + 16 overflow rows in LDS; NOTHING is shared between waves, so there is no barrier, no claim protocol and
-// no atomic anywhere: a wave's LDS operations execute in program order.  Per pass:
-//   1. every lane computes the corner geometry of its group's voxel (as the register kernel does) and takes ONE of the 64
-//      (voxel, corner) references of the pass: row id `rid`, slot = (ix & 3, iy & 3, iz & 7);
-//   2. probe: read tag[slot]; references that miss write {rid, lane}; everybody reads the tag back.  tag.rid == rid: the row is
-//      (or will be) in the slot -- `served`; the missing lane whose lane id came back is its `loader`; a reference whose slot now
-//      names another row of this same pass is an `orphan` (about 2 % of the references on the bench field): it gets an overflow
-//      row for this pass only;
-//   3. loaders + orphans are compacted (ballot / mbcnt) into a fetch list in LDS; the list is read back so that 8-lane groups
-//      fetch one 128-byte row each: ceil(n / 8) load instructions per pass instead of 8 (n = 21 on the bench field), into
-//      registers;
-//   4. the fetched rows are stored to their slots at the top of the NEXT loop iteration (the loads of pass p + 1 fly while pass p is
-//      blended: the registers are the double buffer, the cache needs none);
-//   5. blend: 8 ds_read_b128 per lane from the slots recorded in step 2 (broadcast through 64 bytes of LDS), then exactly the
-//      arithmetic of warp_dice_tile / interpn.hip (same op order: bit-identical warped rows).
-// A pass with more than 16 orphans (incoherent fields) invalidates the cache and takes the register path for that pass.
+// no atomic anywhere: a wave's LDS operations execute in program order.  The work of a pass:
+//   M1a  every lane computes the corner geometry of its group's voxel and takes ONE of the 64 (voxel, corner) references of the
+//        pass: row id `rid`, slot = (ix & 3, iy & 3, iz & 7); reads tag[slot];
+//   M1b  references that miss write {rid, lane}; everybody reads the tag back;
+//   M1c  tag.rid == rid: the row is (or will be) in the slot -- `served`; the missing lane whose own tag came back is its `loader`;
+//        a reference whose slot now names another row of this same pass is an `orphan` (about 2 % of the references on the bench
+//        field): it gets an overflow row for this pass only.  Loaders + orphans are compacted (ballot / mbcnt) into a fetch list
+//        in LDS (one word per entry: row id | destination row << 24), transposed so that 8-lane groups read their entries back
+//        with one ds_read_b128 and fetch one 128-byte row each: ceil(n / 8) load instructions per pass instead of 8 (n = 23 on
+//        the bench field); the source row of every reference is broadcast to its group through 256 bytes of LDS;
+//   M2   the row loads (four always -- entries past n address bytes past the volume: no memory access -- and four more under a
+//        wave-uniform branch when n > 32: 19 % of the passes), the fixed row;
+//   D    the fetched rows are stored to their slots;
+//   B    blend: 8 ds_read_b128 per lane from the slots recorded in M1c, then exactly the arithmetic of warp_dice_tile /
+//        interpn.hip (same op order: bit-identical warped rows).
+// A pass with more than 16 orphans (incoherent fields) invalidates the cache and fetches its 64 references as they are.
+//
+// Round 5: the SCHEDULE.  Counters of the round-4 form (profiles/r04_lab/pmc_wc_vs_reg.json): 581 wave quad-cycles per pass of which
+// 218 wait on counters and 60 on issue, VALU 62 % busy at 2 waves per SIMD, 20 branch instructions per pass -- the management chain
+// (tag read -> write -> read -> ballots -> list write -> list read -> loads) was four serial LDS round trips per pass, cut into ~20
+// basic blocks the compiler cannot schedule across.  Now a step is (nearly) one basic block and the chain of pass p + 2 is threaded
+// through the blend of pass p:  D(p), B-reads(p) | M2(p + 1) | M1a(p + 2) | blend corners 0..3 | M1b | corners 4..7 + Dice | M1c.
+// Every LDS round trip of the management has a stretch of the blend's arithmetic to hide behind; the row loads of pass p + 1 are
+// issued one step before they are stored.  The fixed row, the locations and the stored row go through buffer descriptors with the
+// pass offset in an SGPR (no per-pass address arithmetic); tags are 32-bit (row id | lane << 24).
 //
 // Model of the request stream (tools/wc_sim.py, bench field): 4.8 distinct rows per voxel inside a pass, 2.7 fetched per voxel with
 // the cache (8 through L1 in the register kernel), 0.16 orphan references per voxel.
 
 #pragma once
+
+#include <mutex>
+#include <type_traits>
 
 #include "dice_reduce.h"
 #include "interpn_core.h"
@@ -39,46 +50,26 @@ namespace {
 
 constexpr int WC_SLOTS = 128;                                   // direct-mapped rows per wave
 constexpr int WC_OVF = 16;                                      // overflow rows (orphans of the current pass)
-constexpr int WC_TRASH_ROW = WC_SLOTS + WC_OVF;                 // where the lanes without a row of their own store (branch-free masking)
+constexpr int WC_TRASH_ROW = WC_SLOTS + WC_OVF;                 // where the list entries without a row store (branch-free masking)
 constexpr int WC_ROWS = WC_TRASH_ROW + 1;
-constexpr unsigned WC_TAGS_OFF = WC_ROWS * 128;                 // {rid, lane} per slot, + one trash entry
-constexpr unsigned WC_LISTR_OFF = WC_TAGS_OFF + (WC_SLOTS + 2) * 8;   // fetch list: row ids, transposed (entry e at (e & 7) * 8 + (e >> 3)), + trash
-constexpr unsigned WC_LISTD_OFF = WC_LISTR_OFF + 68 * 4;        // fetch list: destination rows (bytes), same order, + trash
-constexpr unsigned WC_BC_OFF = WC_LISTD_OFF + 80;               // byte offset of the source row of every (voxel, corner) reference (words)
-constexpr unsigned WC_WAVE_BYTES = WC_BC_OFF + 256;             // 20208
-constexpr unsigned WC_BLOCK_BYTES = 4 * WC_WAVE_BYTES;          // 80832: two blocks per CU
-static_assert(WC_LISTR_OFF % 16 == 0 && WC_LISTD_OFF % 16 == 0 && WC_BC_OFF % 16 == 0 && WC_WAVE_BYTES % 16 == 0, "LDS layout");
+constexpr unsigned WC_NOROW = 0x01ffffffu;                      // row id of "no row": its bytes lie past every volume this kernel takes (wc_applies)
+constexpr unsigned WC_TAGS_OFF = WC_ROWS * 128;                 // u32 tag per slot (row id | lane << 24), + one trash entry
+constexpr unsigned WC_LIST_OFF = WC_TAGS_OFF + 528;             // fetch list: 64 x {row offset in the volume, LDS row offset}, transposed (entry e at (e & 7) * 8 + (e >> 3))
+constexpr unsigned WC_BC_OFF = WC_LIST_OFF + 512;               // byte offset of the source row of every (voxel, corner) reference
+constexpr unsigned WC_WAVE_BYTES = WC_BC_OFF + 256;             // 19856
+constexpr unsigned WC_BLOCK_BYTES = 4 * WC_WAVE_BYTES;          // 79424: two blocks per CU
+static_assert(WC_LIST_OFF % 16 == 0 && WC_BC_OFF % 16 == 0 && WC_WAVE_BYTES % 16 == 0, "LDS layout");
+static_assert((WC_SLOTS + 1) * 4 <= 528 && WC_ROWS <= 256, "LDS layout");
 static_assert(2 * WC_BLOCK_BYTES <= 160 * 1024, "two blocks per CU");
-
-#ifndef NRT_FUSED_WCLOADS
-#define NRT_FUSED_WCLOADS 0
-#endif
-// fused form (the sums stay in registers): row loads only as far as the fetch list goes.  Stand-alone warp (the blended row is STORED):
-// always eight loads -- with a conditional number the compiler's in-order vmcnt count must assume none was issued, every wait then
-// also covered the store of the previous pass, and the write acknowledgement sat in the wave's critical path every pass
-// (stand-alone warp 1.305 -> 1.222 ms; the fused kernel is slower with fixed loads: 1.068 -> 1.143, profiles/r04_lab/wc_fixed8.txt)
-#define WC_FIXED_LOADS (DICE ? NRT_FUSED_WCLOADS : 8)
-#ifndef NRT_FUSED_WCSYNC
-#define NRT_FUSED_WCSYNC 0
-#endif
-#ifndef NRT_WC_SYNC
-#define NRT_WC_SYNC NRT_FUSED_WCSYNC          // passes between block barriers; 0 = none (measured: 1.093 none, 1.15 / 1.12 / 1.10 for 2 / 8 / 32)
-#endif
 
 // LDS pointers carry their address space explicitly: a volatile access through a generic pointer compiles to flat_load / flat_store
 // with a full vmcnt(0) wait around it
 typedef __attribute__((address_space(3))) char wc_lds_char;
 typedef __attribute__((address_space(3))) nrt_f4 wc_lds_f4;
 typedef __attribute__((address_space(3))) volatile nrt_i4 wc_lds_vi4;
-typedef __attribute__((address_space(3))) volatile unsigned long long wc_lds_vu64;
 typedef __attribute__((address_space(3))) volatile unsigned wc_lds_vu32;
-typedef __attribute__((address_space(3))) volatile unsigned char wc_lds_vu8;
+typedef unsigned wc_u3 __attribute__((ext_vector_type(3)));
 typedef unsigned wc_u4 __attribute__((ext_vector_type(4)));
-typedef float wc_f3 __attribute__((ext_vector_type(3)));
-
-__device__ __forceinline__ unsigned wc_byte(unsigned lo, unsigned hi, int i) {
-    return ((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xffu;
-}
 
 // utils.py:139-153 for one dimension with three operations less than corner_1d and the same bits: l0 = floor(clip(p)) is
 // clip(floor(p)) for every float (the bounds are integers; NaN clips to 0 either way), and l0 + 1 >= 1 needs no lower clip
@@ -90,20 +81,31 @@ __device__ __forceinline__ void wc_corner(float pv, float mx, int &i0, int &i1, 
     w0 = nrt_sub(l1, cl);
 }
 
+// a buffer descriptor has to be wave-uniform FOR THE COMPILER too (else every access becomes a waterfall loop): the base is rebuilt
+// from readfirstlane'd halves (readfirstlane returns int: widen through unsigned).  Offsets at or past `bytes` read zeros without
+// touching memory.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wc_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)base;
+    const void *u = (const void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) |
+                                   (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)v));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
 // one work item (a column of a 4 x 8 patch, or a piece of one) by one block.
 // DICE = false: the warp alone (nrt_interpn_f32 variant 10): no fixed map, no sums, no partials -- the same gather and blend
 template <int MODE, bool STORE, bool MM, bool FILL, bool DICE>
 __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg, const float *__restrict__ fixed, float *__restrict__ fpart,
                                         float *__restrict__ mpart, const XmWork &xw, char *wc_smem) {
     constexpr int G = 8, L = 32;
-    const int b = xw.b;
-    const unsigned prow = xw.prow, ucol = xw.ucol;
+    // the work item came through LDS (persistent blocks): tell the compiler that it is wave-uniform, the pass offsets below are SGPRs
+    const int b = __builtin_amdgcn_readfirstlane(xw.b);
+    const unsigned prow = (unsigned)__builtin_amdgcn_readfirstlane((int)xw.prow), ucol = (unsigned)__builtin_amdgcn_readfirstlane((int)xw.ucol);
     const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
     const unsigned nRz = (tg.nTz + RZ - 1) / RZ;
     const unsigned reg = ucol / (RY * RZ), wr = ucol % (RY * RZ);
     const unsigned cy = (reg / nRz) * RY + wr / RZ, cz = (reg % nRz) * RZ + wr % RZ;
-    const int x0 = xw.x0, y0 = (int)cy << 2, z0 = (int)cz << 3;
-    int npass = xw.xlen;                                         // one x-plane of the patch per pass
+    const int x0 = __builtin_amdgcn_readfirstlane(xw.x0), y0 = (int)cy << 2, z0 = (int)cz << 3;
+    int npass = __builtin_amdgcn_readfirstlane(xw.xlen);         // one x-plane of the patch per pass
     if (cy >= tg.nTy || cz >= tg.nTz || npass < 0) npass = 0;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,181 +125,175 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     const float ly = (yc == 0) ? 0.0f : ((yc == a.O[1] - 1) ? mxy : nrt_mul(a.delta[1], fyc));
     const float lz = (zc == 0) ? 0.0f : ((zc == a.O[2] - 1) ? mxz : nrt_mul(a.delta[2], fzc));
 
-    // wave-uniform bases advance with the pass, the lane contributes constant 32-bit offsets
+    // wave-uniform descriptors; a pass contributes an SGPR offset, the lane a constant 32-bit one
     const char *volb = (const char *)a.vol + (long long)b * a.vol_bs * 4ll;
-    const char *locb = (const char *)(a.loc ? a.loc + (long long)b * a.loc_bs : nullptr);
-    char *outb = (char *)((float *)a.out + (long long)b * a.out_bs);
-    const char *fixb = (const char *)fixed + (long long)b * a.out_bs * 4ll;
+    const unsigned long long volbytes = (unsigned long long)a.S[0] * SY * SZ * 128ull;       // < 0xffffff00 (wc_applies)
+    const unsigned outbytes = a.nout * 128u;                                                 // < 2^32 (checked by the C entries)
+    const __amdgpu_buffer_rsrc_t vres = wc_rsrc(volb, (unsigned)volbytes);
+    const __amdgpu_buffer_rsrc_t lres = wc_rsrc(MODE != NRT_LOC_LINSPACE ? (const char *)(a.loc + (long long)b * a.loc_bs) : volb, a.nout * 12u);
+    const __amdgpu_buffer_rsrc_t fres = wc_rsrc(DICE ? (const char *)fixed + (long long)b * a.out_bs * 4ll : volb, outbytes);
+    const __amdgpu_buffer_rsrc_t ores = wc_rsrc(STORE ? (const char *)a.out + (long long)b * a.out_bs * 4ll : volb, outbytes);
     const unsigned loc_lane = qyz * 12u, row_lane = (qyz * 8u + (unsigned)p) * 16u;
-    const unsigned long long volbytes = (unsigned long long)a.S[0] * SY * SZ * 128ull;       // < 2^32 (checked by the C entry)
-    // (the descriptor has to be wave-uniform for the compiler too: built from readfirstlane'd halves, or every load becomes a waterfall loop)
-    const unsigned long long vb64 = (unsigned long long)volb;
-    const void *volb_u = (const void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(vb64 >> 32)) << 32) |
-                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)vb64));   // (it returns int)
-    // offsets at or past num_records read zeros without touching memory: that is how lanes (and list entries) without a row are masked
-    const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc((void *)volb_u, 0, __builtin_amdgcn_readfirstlane((int)(unsigned)volbytes),
-                                                                           0x00020000);
+    const unsigned out_lane = yzvalid ? row_lane : 0xffffffffu;   // a store past the descriptor's size is dropped: edge patches need no branch
+    const unsigned loc_step = qstep * 12u, row_step = qstep * 128u;
+    const unsigned p16 = (unsigned)p * 16u;
 
     wc_lds_char *wl = (wc_lds_char *)wc_smem + wave * WC_WAVE_BYTES;
-    wc_lds_vu64 *tags = (wc_lds_vu64 *)(wl + WC_TAGS_OFF);
-    wc_lds_vu32 *listR = (wc_lds_vu32 *)(wl + WC_LISTR_OFF);
-    wc_lds_vu8 *listD = (wc_lds_vu8 *)(wl + WC_LISTD_OFF);
+    wc_lds_vu32 *tags = (wc_lds_vu32 *)(wl + WC_TAGS_OFF);
     wc_lds_vu32 *bc = (wc_lds_vu32 *)(wl + WC_BC_OFF);
     wc_lds_char *lrow = wl + p * 16;                              // this lane's piece of row 0
-    tags[lane] = ~0ull;                                          // no row id is 0xffffffff
-    tags[lane + 64] = ~0ull;
-    const unsigned long long lane_hi = (unsigned long long)lane << 32;
+    tags[lane] = ~0u;                                            // no row id is 0x3ffffff
+    tags[lane + 64] = ~0u;
     const bool cx1 = (p & 4) != 0, cy1 = (p & 2) != 0, cz1 = (p & 1) != 0;
 
     nrt_f2 stp_l = {0, 0}, stp_h = {0, 0}, stt_l = {0, 0}, stt_h = {0, 0}, spp_l = {0, 0}, spp_h = {0, 0};
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
 
     // ---- per-pass state.  Two passes are in flight: the loop is unrolled by two and the passes alternate between the states A and B
-    // (deliver(X) -> blend(X) -> manage(X <- pass + 2): the rows of pass p + 1 and p + 2 fly while pass p is blended)
     struct Pass {
         float w0x, w0y, w0z;         // lower-corner weights
         unsigned sl[8];              // byte offset (row * 128) of the source row of the 8 corners in this wave's LDS rows
-        unsigned fd_lo, fd_hi;       // destination row of fetch-list entries g, 8 + g, ...
-        int n;                       // wave-uniform: entries of the fetch list; -1: register path (F = the voxel's 8 corner rows)
+        unsigned lr[4], ld[4];       // fetch-list entries g, 8 + g, 16 + g, 24 + g: byte offset of the row in the volume, of its LDS row
+        unsigned xr[4], xd[4];       // entries 32 + g ... (n > 32 only)
+        int n;                       // wave-uniform: entries of the fetch list
+        int xq;                      // wave-uniform: output x-plane of the pass
         bool oob;
         nrt_f4 T;                    // the fixed row
-        nrt_f4 F[8];                 // rows in flight
+        nrt_f4 F[4], Fx[4];          // rows in flight
         float pn[3];                 // location of the pass that will use this state next
     };
+    // a pass under management: from the tag read (m1a) to the fetch list (m1c)
+    struct Mg { float w0x, w0y, w0z; bool oob, miss; unsigned rid, slot, t1, t2, mytag; };
     Pass A, B;
     auto reset = [&](Pass &s) {
-        s.w0x = s.w0y = s.w0z = 0.f; s.fd_lo = s.fd_hi = 0; s.n = 0; s.oob = false;
+        s.w0x = s.w0y = s.w0z = 0.f; s.n = 0; s.xq = x0; s.oob = false;
         s.T = (nrt_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s.F[i] = (nrt_f4){0.f, 0.f, 0.f, 0.f}; s.sl[i] = 0; }
+        for (int i = 0; i < 4; ++i) { s.F[i] = s.Fx[i] = (nrt_f4){0.f, 0.f, 0.f, 0.f}; s.lr[i] = s.xr[i] = WC_NOROW << 7; s.ld[i] = s.xd[i] = WC_TRASH_ROW * 128u; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s.sl[i] = 0;
         s.pn[0] = s.pn[1] = s.pn[2] = 0.f;
     };
     reset(A); reset(B);
 
     auto fetch_loc = [&](int pass, Pass &s) {
         if (MODE != NRT_LOC_LINSPACE) {
-            const float *lp = (const float *)(locb + (size_t)((unsigned)(x0 + pass) * qstep) * 12u + loc_lane);
-            s.pn[0] = lp[0]; s.pn[1] = lp[1]; s.pn[2] = lp[2];
+            const wc_u3 v = __builtin_bit_cast(wc_u3, __builtin_amdgcn_raw_buffer_load_b96(lres, loc_lane, (unsigned)(x0 + pass) * loc_step, 0));
+            s.pn[0] = __uint_as_float(v[0]); s.pn[1] = __uint_as_float(v[1]); s.pn[2] = __uint_as_float(v[2]);
         }
     };
-    auto fetch_row = [&](unsigned rid) -> nrt_f4 {
-        return __builtin_bit_cast(nrt_f4, __builtin_amdgcn_raw_buffer_load_b128(vres, (rid * 8u + (unsigned)p) * 16u, 0, 0));
+    auto fetch_row = [&](unsigned rowoff) -> nrt_f4 {
+        return __builtin_bit_cast(nrt_f4, __builtin_amdgcn_raw_buffer_load_b128(vres, rowoff | p16, 0, 0));
     };
 
-    // Incoherent fields: a pass with more colliding rows than the overflow holds takes the register path (its 8 corner rows straight
-    // from memory).  NRT_WC_SKIP > 0 would also skip the probing of the next passes; measured it only hurts: on the bench field 0.85 %
-    // of the passes overflow and each skip leaves the cache cold (1.26 ms with 15 against 1.09), on U(-80, 80) displacements nothing
-    // is gained (1.886 / 1.874 ms, register kernel 1.85): profiles/r04_lab/wc_skip_variants.jsonl.
-#ifndef NRT_FUSED_WCSKIP
-#define NRT_FUSED_WCSKIP 0
-#endif
-#define NRT_WC_SKIP NRT_FUSED_WCSKIP
-#ifndef NRT_FUSED_WCBLENDF
-#define NRT_FUSED_WCBLENDF 0      // 1: a register-path pass is blended straight from its registers (a second copy of the blend in the loop)
-#endif
-    int skip = 0;                                                // wave-uniform
-    // geometry + cache management + fetch of pass `pass` (its location is in s.pn); leaves the pass in s
-    auto manage = [&](int pass, Pass &s) {
+    // M1a: geometry of pass `pass` (its location is in s.pn), this lane's reference, first tag read
+    auto m1a = [&](int pass, const Pass &s, Mg &m) {
         const int xq = x0 + pass;
         float px, py, pz;
         if (MODE == NRT_LOC_ABSOLUTE) { px = s.pn[0]; py = s.pn[1]; pz = s.pn[2]; }
         else if (MODE == NRT_LOC_SHIFT) { px = nrt_add((float)xq, s.pn[0]); py = nrt_add(fyc, s.pn[1]); pz = nrt_add(fzc, s.pn[2]); }
         else { px = (xq == 0) ? 0.0f : ((xq == a.O[0] - 1) ? mxx : nrt_mul(a.delta[0], (float)xq)); py = ly; pz = lz; }
         int i0x, i1x, i0y, i1y, i0z, i1z;
-        wc_corner(px, mxx, i0x, i1x, s.w0x);
-        wc_corner(py, mxy, i0y, i1y, s.w0y);
-        wc_corner(pz, mxz, i0z, i1z, s.w0z);
-        if (FILL) s.oob = (px < 0.0f) || (px > mxx) || (py < 0.0f) || (py > mxy) || (pz < 0.0f) || (pz > mxz);
-        auto direct = [&]() {                                     // this voxel's 8 corner rows straight into F (corner order)
-            s.n = -1;
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                const unsigned jx = (corner & 4) ? i1x : i0x, jy = (corner & 2) ? i1y : i0y, jz = (corner & 1) ? i1z : i0z;
-                s.F[corner] = fetch_row(nrt_mad24(nrt_mad24(jx, SY, jy), SZ, jz));
-            }
-        };
-        if (__builtin_expect(skip > 0, 0)) {
-            --skip;
-            direct();
-            if (DICE) s.T = __builtin_nontemporal_load((const nrt_f4 *)(fixb + (size_t)((unsigned)xq * qstep) * 128u + row_lane));
-            return;
-        }
-        // this lane's reference: corner p of the group's voxel
-        const unsigned ix = cx1 ? i1x : i0x, iy = cy1 ? i1y : i0y, iz = cz1 ? i1z : i0z;
-        const unsigned rid = nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz);
-        const unsigned slot = ((ix & 3u) << 5) | ((iy & 3u) << 3) | (iz & 7u);
-        const unsigned long long t1 = tags[slot];
-        const bool miss = (unsigned)t1 != rid;
-        tags[miss ? slot : (unsigned)WC_SLOTS] = (unsigned long long)rid | lane_hi;       // hits store to the trash entry
-        const unsigned long long t2 = tags[slot];
-        const bool served = (unsigned)t2 == rid;
-        const bool loader = miss && served && (unsigned)(t2 >> 32) == (unsigned)lane;
+        wc_corner(px, mxx, i0x, i1x, m.w0x);
+        wc_corner(py, mxy, i0y, i1y, m.w0y);
+        wc_corner(pz, mxz, i0z, i1z, m.w0z);
+        m.oob = FILL ? ((px < 0.0f) || (px > mxx) || (py < 0.0f) || (py > mxy) || (pz < 0.0f) || (pz > mxz)) : false;
+        const unsigned ix = cx1 ? i1x : i0x, iy = cy1 ? i1y : i0y, iz = cz1 ? i1z : i0z;      // corner p of the group's voxel
+        m.rid = nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz);
+        m.slot = ((ix & 3u) << 5) | ((iy & 3u) << 3) | (iz & 7u);
+        m.mytag = (m.rid << 6) | (unsigned)lane;
+        m.t1 = tags[m.slot];
+    };
+    // M1b: references that miss claim their slot (hits store to the trash entry), everybody reads the tag back
+    auto m1b = [&](Mg &m) {
+        m.miss = (m.t1 ^ m.mytag) >= 64u;
+        tags[m.miss ? m.slot : (unsigned)WC_SLOTS] = m.mytag;
+        m.t2 = tags[m.slot];
+    };
+    // M1c: roles, fetch list, source rows of the group's 8 corners; leaves the pass in s (its row loads are issue(s))
+    auto m1c = [&](int pass, const Mg &m, Pass &s) {
+        const unsigned x2 = m.t2 ^ m.mytag;
+        const bool served = x2 < 64u;
+        const bool loader = m.miss && x2 == 0u;
         const bool orphan = !served;
         const unsigned long long Ml = __builtin_amdgcn_ballot_w64(loader), Mo = __builtin_amdgcn_ballot_w64(orphan);
-        const int nl = __builtin_popcountll(Ml), no = __builtin_popcountll(Mo);
+        const unsigned long long Mf = Ml | Mo;
+        const int no = __builtin_popcountll(Mo);
+        int n = __builtin_popcountll(Mf);
+        const unsigned ro = __builtin_amdgcn_mbcnt_hi((unsigned)(Mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Mo, 0u));
+        const unsigned rf = __builtin_amdgcn_mbcnt_hi((unsigned)(Mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Mf, 0u));
+        bool fetcher = loader || orphan;
+        unsigned src = orphan ? (unsigned)WC_SLOTS + ro : m.slot;
+        // EVERY lane writes one entry of the fetch list: loaders and orphans their row and its destination at positions 0 .. n - 1,
+        // the others a row past the volume (reads as zeros, touches no memory) with the trash row as destination at n .. 63 -- so
+        // fetching and delivering need no per-lane condition
+        unsigned e = fetcher ? rf : (unsigned)n + ((unsigned)lane - rf);
         if (__builtin_expect(no > WC_OVF, 0)) {
             // incoherent field: more rows collide than the overflow holds.  Forget the cache (the tags written above name rows that
-            // will not be fetched) and fetch this voxel's 8 corner rows directly
-            tags[lane] = ~0ull;                                   // (all of it: deliver() parks the pass's 64 corner rows in rows 0 .. 63)
-            tags[lane + 64] = ~0ull;
-            skip = NRT_WC_SKIP;
-            direct();
-        } else {
-            // EVERY lane writes one entry of the fetch list: loaders and orphans their row and its destination at positions 0 .. n - 1,
-            // the others a row id past the volume (reads as zeros, touches no memory) with the trash row as destination at n .. 63 --
-            // so fetching and delivering need no per-lane condition, only the wave-uniform count of load instructions
-            const unsigned long long Mf = Ml | Mo;
-            const unsigned rl = __builtin_amdgcn_mbcnt_hi((unsigned)(Ml >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Ml, 0u));
-            const unsigned ro = __builtin_amdgcn_mbcnt_hi((unsigned)(Mo >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Mo, 0u));
-            const unsigned rf = __builtin_amdgcn_mbcnt_hi((unsigned)(Mf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Mf, 0u));
-            s.n = nl + no;
-            const unsigned src = orphan ? (unsigned)WC_SLOTS + ro : slot;
-            const unsigned e = loader ? rl : (orphan ? (unsigned)nl + ro : (unsigned)s.n + ((unsigned)lane - rf));
-            const bool fetcher = loader || orphan;
-            const unsigned tp = ((e & 7u) << 3) | (e >> 3);
-            listR[tp] = fetcher ? rid : 0x01ffffffu;
-            listD[tp] = (unsigned char)(fetcher ? src : (unsigned)WC_TRASH_ROW);
-            bc[lane] = src * 128u;
-            // group g fetches entries g, 8 + g, 16 + g ...: 8 consecutive words / bytes of the transposed list
-            const nrt_i4 ra = *(wc_lds_vi4 *)(wl + WC_LISTR_OFF + g * 32), rb = *(wc_lds_vi4 *)(wl + WC_LISTR_OFF + g * 32 + 16);
-            const unsigned long long dd = *(wc_lds_vu64 *)(wl + WC_LISTD_OFF + g * 8);
-            const nrt_i4 sa = *(wc_lds_vi4 *)(wl + WC_BC_OFF + g * 32), sb = *(wc_lds_vi4 *)(wl + WC_BC_OFF + g * 32 + 16);
-            s.fd_lo = (unsigned)dd; s.fd_hi = (unsigned)(dd >> 32);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { s.sl[c] = (unsigned)sa[c]; s.sl[4 + c] = (unsigned)sb[c]; }
-            // The first WC_FIXED_LOADS row loads are issued whatever n is (entries past n address bytes past the volume: no memory
-            // access): the compiler's vmcnt bookkeeping takes the path with the FEWEST loads as what may be in flight, and with every
-            // load under a condition that path has none -- it then waited for all but the last two operations at every use, i.e. for
-            // the other state's pass as well (v3: 1.37 ms).
-#pragma unroll
-            for (int i = 0; i < WC_FIXED_LOADS; ++i) s.F[i] = fetch_row((unsigned)(i < 4 ? ra[i & 3] : rb[i & 3]));
-#pragma unroll
-            for (int i = WC_FIXED_LOADS; i < 8; ++i) {
-                if (8 * i < s.n) s.F[i] = fetch_row((unsigned)(i < 4 ? ra[i & 3] : rb[i & 3]));      // wave-uniform condition
-            }
+            // will not be fetched) and fetch the 64 references as they are, into rows 0 .. 63
+            tags[lane] = ~0u;
+            tags[lane + 64] = ~0u;
+            e = (unsigned)lane; fetcher = true; src = (unsigned)lane; n = 64;
         }
-        if (DICE) s.T = __builtin_nontemporal_load((const nrt_f4 *)(fixb + (size_t)((unsigned)xq * qstep) * 128u + row_lane));
+        const unsigned src128 = src * 128u;
+        const unsigned tp = ((e & 7u) << 3) | (e >> 3);
+        typedef unsigned wc_u2 __attribute__((ext_vector_type(2)));
+        *(__attribute__((address_space(3))) volatile wc_u2 *)(wl + WC_LIST_OFF + tp * 8u) =
+            (wc_u2){fetcher ? (m.rid << 7) : (WC_NOROW << 7), fetcher ? src128 : (unsigned)WC_TRASH_ROW * 128u};
+        bc[lane] = src128;
+        // group g fetches entries g, 8 + g, 16 + g ...: consecutive entries of the transposed list
+        const nrt_i4 la = *(wc_lds_vi4 *)(wl + WC_LIST_OFF + g * 64), lb = *(wc_lds_vi4 *)(wl + WC_LIST_OFF + g * 64 + 16);
+        const nrt_i4 sa = *(wc_lds_vi4 *)(wl + WC_BC_OFF + g * 32), sb = *(wc_lds_vi4 *)(wl + WC_BC_OFF + g * 32 + 16);
+        s.lr[0] = (unsigned)la[0]; s.ld[0] = (unsigned)la[1]; s.lr[1] = (unsigned)la[2]; s.ld[1] = (unsigned)la[3];
+        s.lr[2] = (unsigned)lb[0]; s.ld[2] = (unsigned)lb[1]; s.lr[3] = (unsigned)lb[2]; s.ld[3] = (unsigned)lb[3];
+        if (__builtin_expect(n > 32, 0)) {
+            const nrt_i4 lc = *(wc_lds_vi4 *)(wl + WC_LIST_OFF + g * 64 + 32), le = *(wc_lds_vi4 *)(wl + WC_LIST_OFF + g * 64 + 48);
+            s.xr[0] = (unsigned)lc[0]; s.xd[0] = (unsigned)lc[1]; s.xr[1] = (unsigned)lc[2]; s.xd[1] = (unsigned)lc[3];
+            s.xr[2] = (unsigned)le[0]; s.xd[2] = (unsigned)le[1]; s.xr[3] = (unsigned)le[2]; s.xd[3] = (unsigned)le[3];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s.sl[c] = (unsigned)sa[c]; s.sl[4 + c] = (unsigned)sb[c]; }
+        s.w0x = m.w0x; s.w0y = m.w0y; s.w0z = m.w0z; s.oob = m.oob; s.n = n; s.xq = x0 + pass;
     };
-
-    // rows fetched for the pass -> their cache / overflow rows
+    // M2: the row loads of the pass in s.  Four whatever n is (entries past n address bytes past the volume: no memory access): with
+    // every load under a condition the compiler's in-order vmcnt count assumes none was issued and each wait covers the other state's
+    // pass as well (round 4, v3: 1.37 ms); four more when the list is longer than 32 (19 % of the passes on the bench field)
+    auto issue = [&](Pass &s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.F[i] = fetch_row(s.lr[i]);
+        if (__builtin_expect(s.n > 32, 0)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.Fx[i] = fetch_row(s.xr[i]);
+        }
+        if (DICE) s.T = __builtin_bit_cast(nrt_f4, __builtin_amdgcn_raw_buffer_load_b128(fres, row_lane, (unsigned)s.xq * row_step, 2));
+    };
+    // D: rows fetched for the pass -> their cache / overflow rows
     auto deliver = [&](Pass &s) {
-#if !NRT_FUSED_WCBLENDF
-        if (__builtin_expect(s.n < 0, 0)) {                        // register path: the voxel's 8 corner rows go to rows 8 g .. 8 g + 7
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
-                *(wc_lds_f4 *)(lrow + (g * 8 + corner) * 128) = s.F[corner];
-                s.sl[corner] = (unsigned)(g * 8 + corner) * 128u;
-            }
-            return;
-        }
-#endif
+        for (int i = 0; i < 4; ++i) *(wc_lds_f4 *)(lrow + s.ld[i]) = s.F[i];
+        if (__builtin_expect(s.n > 32, 0)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (8 * i < s.n) *(wc_lds_f4 *)(lrow + wc_byte(s.fd_lo, s.fd_hi, i) * 128u) = s.F[i];     // wave-uniform condition
+            for (int i = 0; i < 4; ++i) *(wc_lds_f4 *)(lrow + s.xd[i]) = s.Fx[i];
         }
     };
 
-    auto blend = [&](int pass, Pass &s, bool live, const nrt_f4 (&R)[8]) {
+    // One pass.  `s` holds pass `pass` (managed two steps ago, rows in flight since the last step), `o` pass + 1 (managed in the last
+    // step, its loads go out here); the management of pass + 2 is threaded through the blend so that each of its LDS round trips has
+    // arithmetic to hide behind.  MASKED: the wave has voxels outside the volume (edge patches) whose sums must not count.
+    const int last = npass - 1;
+    auto step = [&](int pass, Pass &s, Pass &o, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+        deliver(s);
+        nrt_f4 R[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) R[corner] = *(const wc_lds_f4 *)(lrow + s.sl[corner]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(o);
+        __builtin_amdgcn_sched_barrier(0);
+        Mg m;
+        m1a(min(pass + 2, last), s, m);
+        __builtin_amdgcn_sched_barrier(0);
+        // corner weights (wx * wy) * wz in the reference's order, two corners per packed multiply
         const float w1x = nrt_sub(1.0f, s.w0x), w1y = nrt_sub(1.0f, s.w0y), w1z = nrt_sub(1.0f, s.w0z);      // corner_1d's w1
         const nrt_f2 wy2 = {s.w0y, w1y}, wz2 = {s.w0z, w1z};
         const nrt_f2 wxy0 = (nrt_f2){s.w0x, s.w0x} * wy2, wxy1 = (nrt_f2){w1x, w1x} * wy2;
@@ -308,7 +304,20 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         wt2[3] = (nrt_f2){wxy1[1], wxy1[1]} * wz2;
         nrt_f2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
+        for (int corner = 0; corner < 4; ++corner) {
+            const float wt = wt2[corner >> 1][corner & 1];
+            const nrt_f2 w2 = {wt, wt};
+            al = al + w2 * (nrt_f2){R[corner][0], R[corner][1]};
+            ah = ah + w2 * (nrt_f2){R[corner][2], R[corner][3]};
+        }
+        // (pure arithmetic is not ordered against the barriers by itself -- the compiler had sunk the whole blend below M1c: the
+        // empty asm statements pin it, they take part in the chain of side effects the barriers are on)
+        asm volatile("" : "+v"(al), "+v"(ah));
+        __builtin_amdgcn_sched_barrier(0);
+        m1b(m);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int corner = 4; corner < 8; ++corner) {
             const float wt = wt2[corner >> 1][corner & 1];
             const nrt_f2 w2 = {wt, wt};
             al = al + w2 * (nrt_f2){R[corner][0], R[corner][1]};
@@ -319,60 +328,55 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], s.oob, a.fill_f);
         }
-        if (yzvalid && live) {
-            if (STORE) __builtin_nontemporal_store(acc, (nrt_f4 *)(outb + (size_t)((unsigned)(x0 + pass) * qstep) * 128u + row_lane));
-            const nrt_f2 pl = {acc[0], acc[1]}, ph = {acc[2], acc[3]}, tl = {s.T[0], s.T[1]}, th = {s.T[2], s.T[3]};
-            if (DICE) {
-                stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
-                stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
-                spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
-            }
-            if (DICE && MM) {
+        if (STORE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wc_u4, acc), ores, out_lane, (unsigned)s.xq * row_step, 2);
+        if (DICE) {
+            nrt_f4 T = s.T;
+            if (MASKED) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    mnt = fminf(mnt, s.T[c]); mxt = fmaxf(mxt, s.T[c]);
-                    mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
+                for (int c = 0; c < 4; ++c) { T[c] = yzvalid ? T[c] : 0.0f; acc[c] = yzvalid ? acc[c] : 0.0f; }
+            }
+            const nrt_f2 pl = {acc[0], acc[1]}, ph = {acc[2], acc[3]}, tl = {T[0], T[1]}, th = {T[2], T[3]};
+            stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
+            stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
+            spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
+            if (MM) {
+                if (!MASKED || yzvalid) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        mnt = fminf(mnt, s.T[c]); mxt = fmaxf(mxt, s.T[c]);
+                        mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
+                    }
                 }
             }
         }
-    };
-    // one pass: store its rows, blend it, then re-use its state and row registers for the pass two ahead.  The loop body is the
-    // same straight sequence for every pair of passes (past the end of the march the last pass is managed and blended again with its
-    // sums masked): with a conditional half-step the compiler has to assume that the other state's loads may not have been issued and
-    // waits for everything in flight.
-    const int last = npass - 1;
-    auto step = [&](int pass, Pass &s) {
-#if NRT_FUSED_WCBLENDF
-        if (__builtin_expect(s.n < 0, 0)) {
-            blend(pass, s, pass <= last, s.F);                     // register path: F holds the voxel's 8 corner rows
-        } else
-#endif
-        {
-            deliver(s);
-            nrt_f4 R[8];
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) R[corner] = *(const wc_lds_f4 *)(lrow + s.sl[corner]);
-            __builtin_amdgcn_sched_barrier(0);                     // all eight reads in flight before the first product: one LDS round trip
-            blend(pass, s, pass <= last, R);
-        }
-        manage(min(pass + 2, last), s);
+        if (DICE) asm volatile("" : "+v"(stp_l), "+v"(stp_h), "+v"(stt_l), "+v"(stt_h), "+v"(spp_l), "+v"(spp_h));
+        else asm volatile("" :: "v"(acc));
+        __builtin_amdgcn_sched_barrier(0);
+        m1c(min(pass + 2, last), m, s);
         fetch_loc(min(pass + 4, last), s);
+        __builtin_amdgcn_sched_barrier(0);
     };
-
-    if (npass > 0) {
+    auto march = [&](auto masked) {
+        Mg m;
         fetch_loc(0, A);
         fetch_loc(min(1, last), B);
-        manage(0, A);
+        m1a(0, A, m); m1b(m); m1c(0, m, A);
+        issue(A);
         fetch_loc(min(2, last), A);
-        manage(min(1, last), B);
+        m1a(min(1, last), B, m); m1b(m); m1c(min(1, last), m, B);
         fetch_loc(min(3, last), B);
-        for (int pass = 0; pass < npass; pass += 2) {
-#if NRT_WC_SYNC > 0
-            if ((pass & (NRT_WC_SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
-#endif
-            step(pass, A);
-            step(pass + 1, B);
+        __builtin_amdgcn_sched_barrier(0);
+        int pass = 0;
+        for (; pass + 1 < npass; pass += 2) {
+            step(pass, A, B, masked);
+            step(pass + 1, B, A, masked);
         }
+        if (pass < npass) step(pass, A, B, masked);               // odd march: one more pass (what it prepares beyond the end is not used)
+    };
+    if (npass > 0) {
+        // (wave-uniform) edge patches mask the sums of the lanes whose voxel lies outside the volume
+        if (DICE && __builtin_amdgcn_ballot_w64(!yzvalid) != 0ull) march(std::true_type());
+        else march(std::false_type());
     }
 
     if (!DICE) return;
@@ -458,14 +462,11 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
     }
 }
 
-#ifndef NRT_FUSED_WCPERSIST
-#define NRT_FUSED_WCPERSIST 1
-#endif
 template <int MODE, bool STORE, bool MM, bool FILL>
 int launch_wc_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, const float *fixed, float *fpart, float *mpart,
                    unsigned *queue, hipStream_t st) {
     const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
-    if (NRT_FUSED_WCPERSIST && queue && items > slots) {
+    if (queue && items > slots) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, STORE, MM, FILL, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WC_BLOCK_BYTES) != hipSuccess)
             return NRT_ERR_LAUNCH;
@@ -518,19 +519,25 @@ inline int launch_wc(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, 
 
 // the warp alone through the same kernel (interpn.hip, variant 10): mixed block lengths, persistent blocks.  The work counters come
 // from a per-device ring of 64 sets (a launch takes the next one: launches that overlap on different streams do not share a set)
+// (so at most 64 launches of this kernel may be in flight or captured at a time; the ring is allocated once per device, under a lock,
+// and NOT during a stream capture -- hipMalloc fails there and the launch takes the non-persistent grid)
 inline unsigned *wc_queue_slot() {
     static unsigned *ring[64];
     static unsigned next[64];
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!ring[dev] && hipMalloc((void **)&ring[dev], 64 * NRT_NXCD * 64) != hipSuccess) { ring[dev] = nullptr; return nullptr; }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ring[dev] && hipMalloc((void **)&ring[dev], 64 * NRT_NXCD * 64) != hipSuccess) { ring[dev] = nullptr; return nullptr; }
+    }
     return ring[dev] + (size_t)(__atomic_fetch_add(&next[dev], 1u, __ATOMIC_RELAXED) % 64u) * (NRT_NXCD * 16);
 }
 
 template <int MODE, bool FILL>
 int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, hipStream_t st) {
     const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
-    unsigned *queue = (NRT_FUSED_WCPERSIST && items > slots) ? wc_queue_slot() : nullptr;
+    unsigned *queue = (items > slots) ? wc_queue_slot() : nullptr;
     if (queue) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, true, false, FILL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WC_BLOCK_BYTES) != hipSuccess)
