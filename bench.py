@@ -1106,6 +1106,13 @@ def main():
             'dropin': {'ms': round(ru['elapsed'] / o_steps * 1e3, 4), 'Mvoxels_per_s': round(V * o_steps / ru['elapsed'] / 1e6, 1),
                        'interpn_ms': round(ru['k0_ms'], 4), 'dice_ms': round(ru['k1_ms'], 4),
                        'interpn_frac': round(INTERPN_BYTES_PER_VOXEL(L, 3) * V / (ru['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        # BASELINE config 2 names batch = 1: its figures also sit in the two objects a reader of the line's head keeps (`roofline`, `config`)
+        out['roofline']['batch1'] = {'what': 'the same fused kernel on ONE volume per launch (BASELINE config 2 as written)',
+                                     'avg_launch_ms': out['config2_batch1']['fused']['kernel_ms'],
+                                     'frac': out['config2_batch1']['fused']['frac'],
+                                     'standalone_interpn_frac': out['config2_batch1']['dropin']['interpn_frac']}
+        out['config']['batch1_ms_per_step'] = out['config2_batch1']['fused']['ms']
+        out['config']['batch1_Mvoxels_per_s'] = out['config2_batch1']['fused']['Mvoxels_per_s']
     if r_def is not None:
         out['default_args_pipeline'] = {
             'what': 'SpatialTransformer -> metrics.Dice() with the reference defaults (check_input_limits=True: the range asserts read '
@@ -1123,6 +1130,9 @@ def main():
             'algorithmic_bytes_per_voxel': 2 * L + 12 + 2 * L,
             'frac_of_peak': round(b16 / (r_bf16['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'same_dice': r_bf16['same_dice'],
             'max_abs_diff_vs_default_f32_kernel': r_bf16['max_abs_diff_vs_default_f32_kernel']}
+    # the stand-alone op (the drop-in `interpn` / SpatialTransformer call that WRITES the warped volume; 268 B per voxel as well)
+    out['roofline']['standalone_interpn'] = {'frac': dropin['interpn_frac_of_peak'], 'avg_launch_ms': dropin['interpn_ms'],
+                                             'achieved': dropin['interpn_GBs'], 'volumes_per_launch': B}
     if fused:
         out['roofline']['unfused_api_accounting_524B_per_voxel_GBs'] = round(
             (INTERPN_BYTES_PER_VOXEL(L, 3) + DICE_BYTES_PER_VOXEL(L)) * V * B / (kms * 1e-3) / 1e9, 1)

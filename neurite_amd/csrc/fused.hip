@@ -48,14 +48,16 @@ template <> struct RowT<unsigned short> {
     }
 };
 
-#ifdef NRT_FUSED_TRACE
-// lab builds (tools/fused_variants.py TRACE=1, tools/block_trace.py): every block records {start, end} of the 100 MHz wall clock, its
-// XCC id and its x range -- how the blocks of a launch really fill the chip
-__device__ unsigned long long *nrt_trace_buf = nullptr;
-extern "C" int nrt_debug_set_trace(void *buf) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(nrt_trace_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
-}
-#endif
+
+// Passes between block barriers (power of two).  The four waves of a block are y-neighbours: half of a wave's corner rows are its
+// neighbour's, and they merge in L1 only while the waves request them at about the same time.  Left alone the waves drift apart; a
+// barrier every 8 passes keeps them together at no measurable cost: 1.174 -> 1.157 ms on one box, 1.148 -> 1.109 on another (every 2
+// passes: slower; 16: the same; 32: less), profiles/archive/r03_lab/fused_occupancy_depth.jsonl
+constexpr int FUSED_SYNC = 8;
+// Waves per SIMD the x-march instance is compiled for (register budget 512 / MINW).  Two blocks of four waves run per CU (the LDS
+// padding below), so 4 only squeezed the kernel into 128 registers with three of them spilled; at 3 it takes 130, nothing spills:
+// 1.158 -> 1.140 ms (two alternating repeats, profiles/archive/r03_lab/fused_occupancy_depth.jsonl)
+constexpr int FUSED_MINW = 3;
 
 template <int G, int MODE, bool STORE, int MINW, typename ST = float>
 __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGeom tg, const void *__restrict__ fixed,
@@ -70,9 +72,6 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
     unsigned per = tg.per2 * tg.nTz;                           // tiles per XCD
     unsigned nb = gridDim.x / NRT_NXCD;
     int b = blockIdx.y;
-#ifdef NRT_FUSED_TRACE
-    const unsigned long long trace_t0 = wall_clock64();
-#endif
     unsigned ucol = 0, prow = blockIdx.x;                      // x-march: patch, partial row inside the batch
     XmWork xw = {};
     if (tg.x_march) {
@@ -93,9 +92,6 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
     // sums as float2 halves: the blend and the Dice accumulation run on v_pk_mul_f32 / v_pk_add_f32 (two IEEE fp32 operations
     // per issue slot, no fusion -> bit-identical to the scalar sequence); the kernel is bound by VALU issue, not by memory
     nrt_f2 stp_l = {0, 0}, stp_h = {0, 0}, stt_l = {0, 0}, stt_h = {0, 0}, spp_l = {0, 0}, spp_h = {0, 0};
-#if NRT_FUSED_EXP == 20 || NRT_FUSED_EXP == 21
-    __shared__ nrt_f4 wcache[4][64][8];        // probe: 64 rows of 128 bytes per wave
-#endif
     float mnt = INFINITY, mxt = -INFINITY, mnp = INFINITY, mxp = -INFINITY;
 
     for (unsigned j = jb; j < per; j += nb) {
@@ -168,86 +164,14 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
             W0x = m.w0x; W0y = m.w0y; W0z = m.w0z; Q = m.q; VALID = m.valid; OOB = m.oob;
         };
         auto load_rows = [&](const unsigned (&off)[8], unsigned q, Row (&R)[8], Row &T) {
-#ifndef NRT_FUSED_SYNC
-// passes between block barriers (power of two; 0 = none).  The four waves of a block are y-neighbours: half of a wave's corner rows
-// are its neighbour's, and they merge in L1 only while the waves request them at about the same time.  Left alone the waves drift
-// apart; a barrier every 8 passes keeps them together at no measurable cost: 1.174 -> 1.157 ms on one box, 1.148 -> 1.109 on another
-// (every 2 passes: slower; 16: the same; 32: less), profiles/archive/r03_lab/fused_occupancy_depth.jsonl
-#define NRT_FUSED_SYNC 8
-#endif
-#ifndef NRT_FUSED_MINW
-// waves per SIMD the x-march instance is compiled for (register budget 512 / MINW).  Two blocks of four waves run per CU (the LDS
-// padding below), so 4 only squeezed the kernel into 128 registers with three of them spilled; at 3 it takes 130, nothing spills:
-// 1.158 -> 1.140 ms (two alternating repeats, profiles/archive/r03_lab/fused_occupancy_depth.jsonl)
-#define NRT_FUSED_MINW 3
-#endif
-#ifndef NRT_FUSED_EXP
-#define NRT_FUSED_EXP 0        // lab builds only (tools/fused_variants.py): cache-policy hints / request order of the corner rows
-#endif
-#if NRT_FUSED_EXP == 1          // x0 plane (last use along the march) streaming, x1 plane normal
-#pragma unroll
-            for (int corner = 0; corner < 4; ++corner) R[corner] = __builtin_nontemporal_load((const Row *)(volb + (size_t)off[corner]));
-#pragma unroll
-            for (int corner = 4; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
-#elif NRT_FUSED_EXP == 2        // all rows streaming
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner) R[corner] = __builtin_nontemporal_load((const Row *)(volb + (size_t)off[corner]));
-#elif NRT_FUSED_EXP == 3        // x1 plane requested first
-#pragma unroll
-            for (int corner = 4; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
-#pragma unroll
-            for (int corner = 0; corner < 4; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
-#elif NRT_FUSED_EXP >= 6 && NRT_FUSED_EXP <= 8
-            // PROBES (wrong results on purpose): only the first 4 / 2 / 1 corner rows are requested, the others re-use them --
-            // the time against L1 accesses per voxel, everything else unchanged (profiles/r04_lab/l1_access_curve.jsonl)
-            constexpr int NLD = NRT_FUSED_EXP == 6 ? 4 : (NRT_FUSED_EXP == 7 ? 2 : 1);
-#pragma unroll
-            for (int corner = 0; corner < NLD; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
-#pragma unroll
-            for (int corner = NLD; corner < 8; ++corner) R[corner] = R[corner % NLD];
-#elif NRT_FUSED_EXP == 20 || NRT_FUSED_EXP == 21
-            // PROBE: the data path of a wave-private LDS row cache without its management -- 2 (20) / 4 (21) rows per voxel come through
-            // L1, finish() stores them into the wave's LDS rows and reads all 8 corners back from pseudo-random rows of it
-            constexpr int NNEW = NRT_FUSED_EXP == 20 ? 2 : 4;
-#pragma unroll
-            for (int i = 0; i < NNEW; ++i) R[i] = *(const Row *)(volb + (size_t)off[(i * 7) & 7]);
-#pragma unroll
-            for (int corner = NNEW; corner < 8; ++corner) R[corner] = R[0];
-#elif NRT_FUSED_EXP == 11 || NRT_FUSED_EXP == 12 || NRT_FUSED_EXP == 13
-            // PROBES: all 8 loads issued, but they address 1 (11) / 2 (12: the z pair) / 4 (13: the x0 plane) distinct rows --
-            // L1 accesses without the misses.  a.fill_i is 0 at run time; it keeps the compiler from merging the loads.
-            constexpr int MSK = NRT_FUSED_EXP == 11 ? 0 : (NRT_FUSED_EXP == 12 ? 1 : 3);
-#pragma unroll
-            for (int corner = 0; corner < 8; ++corner)
-                R[corner] = *(const Row *)(volb + (size_t)(off[corner & MSK] + (unsigned)(a.fill_i * corner)));
-#else
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) R[corner] = *(const Row *)(volb + (size_t)off[corner]);
-#endif
-#if NRT_FUSED_EXP == 4          // fixed row as an ordinary load
-            T = *(const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB));
-#elif NRT_FUSED_EXP == 9        // PROBE: no fixed row at all (what the compulsory second stream costs)
-            T = R[0];
-#elif NRT_FUSED_EXP == 5        // fixed row requested before the corner rows
             T = __builtin_nontemporal_load((const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB)));
-#else
-            T = __builtin_nontemporal_load((const Row *)(fix + (size_t)((q * (unsigned)G + (unsigned)lg) * RB)));
-#endif
         };
         auto finish = [&](float W0x, float W0y, float W0z, unsigned Q, bool VALID, bool OOB, const Row (&Rraw)[8], const Row &Traw) {
             nrt_f4 R[8];
 #pragma unroll
             for (int corner = 0; corner < 8; ++corner) R[corner] = RowT<ST>::widen(Rraw[corner]);
-#if NRT_FUSED_EXP == 20 || NRT_FUSED_EXP == 21
-            {
-                constexpr int NNEW = NRT_FUSED_EXP == 20 ? 2 : 4;
-                nrt_f4 (*wc)[8] = wcache[threadIdx.x >> 6];
-#pragma unroll
-                for (int i = 0; i < NNEW; ++i) wc[(Q * 13u + (unsigned)i * 21u) & 63u][lg] = R[i];
-#pragma unroll
-                for (int corner = 0; corner < 8; ++corner) R[corner] = wc[(Q * 13u + (unsigned)corner * 7u) & 63u][lg];
-            }
-#endif
             const nrt_f4 T = RowT<ST>::widen(Traw);
             FM m;
             m.w0x = W0x; m.w0y = W0y; m.w0z = W0z; m.q = Q; m.valid = VALID; m.oob = OOB;
@@ -279,13 +203,11 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
                 stp_l = stp_l + tl * pl; stp_h = stp_h + th * ph;
                 stt_l = stt_l + tl * tl; stt_h = stt_h + th * th;
                 spp_l = spp_l + pl * pl; spp_h = spp_h + ph * ph;
-#if NRT_FUSED_EXP != 30              // PROBE 30: no range tracking (what 16-24 VALU instructions per pass are worth)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     mnt = fminf(mnt, T[c]); mxt = fmaxf(mxt, T[c]);
                     mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
                 }
-#endif
             }
         };
 
@@ -303,9 +225,7 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
         load_rows(off, Aq, Ra, Ta);
         __builtin_amdgcn_sched_barrier(0);
         for (int pass = 0; pass < npass; pass += 2) {
-#if NRT_FUSED_SYNC > 0          // the block's four waves (their y-neighbour rows meet in L1) kept loosely in step
-            if ((pass & (NRT_FUSED_SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();
-#endif
+            if ((pass & (FUSED_SYNC - 1)) == 0) __builtin_amdgcn_s_barrier();     // the block's four waves kept loosely in step
             prepare(min(pass + 1, last), pn, Bx, By, Bz, Bq, Bv, Bo, off);
             Bv = Bv && (pass + 1 < npass);
             __builtin_amdgcn_sched_barrier(0);
@@ -364,23 +284,9 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
         mpart[pbase * 4 + threadIdx.x] = m;
     }
     if (tg.x_march) xmarch_zero_rows(tg, xw, 3 * L, fpart, mpart);
-#ifdef NRT_FUSED_TRACE
-    if (threadIdx.x == 0 && nrt_trace_buf) {
-        unsigned long long *t = nrt_trace_buf + 4ull * blockIdx.x;
-        t[0] = trace_t0; t[1] = wall_clock64();
-        t[2] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20);      // HW_REG_XCC_ID
-        t[3] = ((unsigned long long)(unsigned)xw.x0 << 32) | (unsigned)xw.xlen;
-    }
-#endif
 }
 
 // the fused kernel writes one partial per block: size the workspace for its grid
-// NRT_FUSED_MIXED=0: equal pieces per column as before round 4 (experiments)
-inline bool fused_mixed_enabled() {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("NRT_FUSED_MIXED"); on = (e && atoi(e) == 0) ? 0 : 1; }
-    return on != 0;
-}
 inline unsigned fused_xmarch_grid(const TileGeom &tg, unsigned nblocks, int batch) {
     return tg.het_cpx ? NRT_NXCD * (tg.het_full + (tg.het_cpx - tg.het_full) * tg.nseg) : nrt_xcd_grid(nblocks * (unsigned)batch);
 }
@@ -407,51 +313,46 @@ void fused_geom(const int *out_shape, int G, int batch, int tune, TileGeom &tg, 
     if (((t >> 14) & 1) && !tg.plane_major && out_shape[0] > 0) {
         // segments left to us (bits 16-23 zero): whole columns + pieces for the last round; an explicit count: equal pieces
         unsigned grid;
-        if (((t >> 16) & 0xff) == 0 && fused_mixed_enabled()) nblocks = xmarch_setup_mixed(out_shape, batch, t, tg, grid);
+        if (((t >> 16) & 0xff) == 0) nblocks = xmarch_setup_mixed(out_shape, batch, t, tg, grid);
         else nblocks = xmarch_setup(out_shape, batch, t, tg);
     }
 }
 
-// tune bit 29: take the wave-cache kernel (fused_wc.h) where it applies; bit 30: keep the register kernel; neither: the default below
-// (environment variable NRT_FUSED_WC = 0 / 1 overrides it)
+// tune bit 30: keep the register kernel where the wave-cache kernel (fused_wc.h, the default for 32 float32 labels) would apply;
+// bit 29 (historical: ask for the wave-cache kernel) is accepted and ignored
 constexpr int FUSED_TUNE_WC = 1 << 29, FUSED_TUNE_NO_WC = 1 << 30;
-#ifndef NRT_FUSED_WC_DEFAULT
-#define NRT_FUSED_WC_DEFAULT 1
-#endif
-inline bool fused_wc_enabled() {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("NRT_FUSED_WC"); on = e ? (atoi(e) != 0) : NRT_FUSED_WC_DEFAULT; }
-    return on != 0;
+
+// Which kernel a call launches -- ONE decision, used by the launch and by nrt_warp_dice_kernel_name (bench.py keys its counter
+// evidence on that name)
+struct FusedChoice { bool wc, persist; };
+inline FusedChoice fused_choose(const InterpArgs &a, const TileGeom &tg, int G, bool f32_storage, bool allow_wc) {
+    FusedChoice c = {false, false};
+    if (G == 8 && f32_storage && allow_wc && wc_applies(tg, G, a)) {
+        c.wc = true;
+        c.persist = wc_persistent(tg);
+    }
+    return c;
 }
 
 template <int G, typename ST>
-void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store,
-                  const void *fixed, float *fpart, float *mpart, hipStream_t st, bool use_wc, bool want_minmax, unsigned *queue) {
+int launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store,
+                 const void *fixed, float *fpart, float *mpart, hipStream_t st, bool allow_wc, bool want_minmax, unsigned *queue) {
     if constexpr (G == 8 && std::is_same<ST, float>::value) {
-        if (use_wc && wc_applies(tg, G, a)) {
-            (void)launch_wc(a, tg, nblocks, batch, mode, store, want_minmax, (const float *)fixed, fpart, mpart, queue, st);
-            return;
-        }
+        if (fused_choose(a, tg, G, true, allow_wc).wc)
+            return launch_wc(a, tg, nblocks, batch, mode, store, want_minmax, (const float *)fixed, fpart, mpart, queue, st);
     }
     dim3 grid(nblocks, batch), blk(256);
-    // experiment knob: NRT_FUSED_LDS_KB pads every block with unused dynamic LDS to cap the blocks per CU
-    // NRT_FUSED_LDS_KB (experiments): unused dynamic LDS per block, caps the blocks per CU.  The x-march default is
-    // 75 KB = one block per CU, so that the 32 blocks an XCD runs together are one region whose rows stay in its L2.
-    static int lds_kb = -2;
-    if (lds_kb == -2) { const char *e = getenv("NRT_FUSED_LDS_KB"); lds_kb = e ? atoi(e) : -1; }
-    const unsigned dyn = (unsigned)(lds_kb >= 0 ? lds_kb : (tg.x_march ? 75 : 0)) * 1024u;
+    // x-march: 75 KB of unused dynamic LDS per block = two blocks per CU, so that the blocks an XCD runs together are one region whose
+    // rows stay in its L2
+    const unsigned dyn = tg.x_march ? 75u * 1024u : 0u;
     if (tg.x_march) {
         grid = dim3(fused_xmarch_grid(tg, nblocks, batch), 1);
 #define NRT_FUSED_X(MODE)                                                                                           \
-    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, NRT_FUSED_MINW, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
+    if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, FUSED_MINW, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
     else {                                                                                                          \
-        static unsigned attr_dyn = 0;                                                                               \
-        if (dyn > 48 * 1024 && attr_dyn != dyn) {                                                                   \
-            (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, NRT_FUSED_MINW, ST>,                          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);                        \
-            attr_dyn = dyn;                                                                                         \
-        }                                                                                                           \
-        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, NRT_FUSED_MINW, ST>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
+        if (hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, FUSED_MINW, ST>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return NRT_ERR_LAUNCH; \
+        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, FUSED_MINW, ST>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
     }
         switch (mode) {
             case NRT_LOC_ABSOLUTE: NRT_FUSED_X(NRT_LOC_ABSOLUTE); break;
@@ -459,21 +360,18 @@ void launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int
             default: NRT_FUSED_X(NRT_LOC_LINSPACE); break;
         }
 #undef NRT_FUSED_X
-        return;
+        return NRT_OK;
     }
 #define NRT_FUSED(MODE)                                                                                          \
     if (store) hipLaunchKernelGGL((warp_dice_tile<G, MODE, true, 1, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart); \
-    else {                                                                                                       \
-        if (dyn > 48 * 1024) (void)hipFuncSetAttribute((const void *)warp_dice_tile<G, MODE, false, 1, ST>,            \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);    \
-        hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 1, ST>), grid, blk, dyn, st, a, tg, fixed, fpart, mpart); \
-    }
+    else hipLaunchKernelGGL((warp_dice_tile<G, MODE, false, 1, ST>), grid, blk, 0, st, a, tg, fixed, fpart, mpart);
     switch (mode) {
         case NRT_LOC_ABSOLUTE: NRT_FUSED(NRT_LOC_ABSOLUTE); break;
         case NRT_LOC_SHIFT: NRT_FUSED(NRT_LOC_SHIFT); break;
         default: NRT_FUSED(NRT_LOC_LINSPACE); break;
     }
 #undef NRT_FUSED
+    return NRT_OK;
 }
 
 }  // namespace
@@ -515,7 +413,7 @@ int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed,
     if (a.nout == 0) return NRT_ERR_INVALID_ARG;
     TileGeom tg;
     unsigned nblocks;
-    const bool use_wc = !(tune > 0 && (tune & FUSED_TUNE_NO_WC)) && (fused_wc_enabled() || (tune > 0 && (tune & FUSED_TUNE_WC)));
+    const bool allow_wc = !(tune > 0 && (tune & FUSED_TUNE_NO_WC));
     if (tune > 0) tune &= ~(FUSED_TUNE_NO_WC | FUSED_TUNE_WC);
     fused_geom(out_shape, G, batch, tune, tg, nblocks);
     if (!workspace || workspace_bytes < fused_ws_bytes(nblocks, nlabels, batch)) return NRT_ERR_WORKSPACE;
@@ -533,14 +431,15 @@ int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed,
     hipStream_t st = nrt_stream(stream);
     const bool store = warped != nullptr;
     switch (G) {
-        case 1: launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
-        case 2: launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
-        case 4: launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
-        case 8: launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
-        case 16: launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
-        case 32: launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
-        default: launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, use_wc, minmax != nullptr, queue); break;
+        case 1: rc = launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
+        case 2: rc = launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
+        case 4: rc = launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
+        case 8: rc = launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
+        case 16: rc = launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
+        case 32: rc = launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
+        default: rc = launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
     }
+    if (rc != NRT_OK) return rc;              // nothing (or not everything) was launched: do not reduce stale partial sums
     NRT_CHECK_LAUNCH();
     return dice_finalize_soft(w, nblocks, 1, batch, nlabels, laplace_smoothing, sums, dice, minmax, st);
 }
@@ -553,21 +452,32 @@ extern "C" const char *nrt_warp_dice_kernel_name(const int *out_shape, const int
                                                  int has_fill, int store, int want_minmax, int tune) {
     static thread_local char name[96];
     name[0] = 0;
-    if (!out_shape || !vol_shape || nlabels < 4 || nlabels % 4 || batch < 1) return name;
+    // (the float32 entry point; "" for arguments it would reject)
+    if (!out_shape || !vol_shape || nlabels < 4 || nlabels % 4 || batch < 1 || loc_mode < 0 || loc_mode > 2) return name;
     const int G = nlabels / 4;
-    const bool use_wc = !(tune > 0 && (tune & FUSED_TUNE_NO_WC)) && (fused_wc_enabled() || (tune > 0 && (tune & FUSED_TUNE_WC)));
+    if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64)) return name;
+    unsigned long long nout = 1, nvol = 1;
+    for (int d = 0; d < 3; ++d) {
+        if (out_shape[d] < 1 || vol_shape[d] < 1) return name;
+        nout *= (unsigned long long)out_shape[d]; nvol *= (unsigned long long)vol_shape[d];
+    }
+    if (nvol * nlabels * 4ull >= (1ull << 32) || nout * nlabels * 4ull >= (1ull << 32)) return name;
+    if ((long long)vol_shape[0] * vol_shape[1] >= (1 << 24) || vol_shape[2] >= (1 << 24) ||
+        (long long)out_shape[0] * out_shape[1] >= (1 << 24) || out_shape[2] >= (1 << 24)) return name;
+    const bool allow_wc = !(tune > 0 && (tune & FUSED_TUNE_NO_WC));
     if (tune > 0) tune &= ~(FUSED_TUNE_NO_WC | FUSED_TUNE_WC);
     TileGeom tg;
     unsigned nblocks;
     fused_geom(out_shape, G, batch, tune, tg, nblocks);
-    InterpArgs a;
-    for (int d = 0; d < 3; ++d) a.S[d] = vol_shape[d];
+    InterpArgs a = {};
+    for (int d = 0; d < 3; ++d) { a.S[d] = vol_shape[d]; a.O[d] = out_shape[d]; }
     const char *tf[2] = {"false", "true"};
-    if (G == 8 && use_wc && wc_applies(tg, G, a))
+    const FusedChoice c = fused_choose(a, tg, G, true, allow_wc);
+    if (c.wc)
         snprintf(name, sizeof(name), "warp_dice_wc<%d, %s, %s, %s, true, %s>", loc_mode, tf[store != 0], tf[want_minmax != 0], tf[has_fill != 0],
-                 tf[NRT_NXCD * tg.items_x > 2u * (unsigned)nrt_num_cus()]);
+                 tf[c.persist]);
     else
-        snprintf(name, sizeof(name), "warp_dice_tile<%d, %d, %s, %d, float>", G, loc_mode, tf[store != 0], tg.x_march ? NRT_FUSED_MINW : 1);
+        snprintf(name, sizeof(name), "warp_dice_tile<%d, %d, %s, %d, float>", G, loc_mode, tf[store != 0], tg.x_march ? FUSED_MINW : 1);
     return name;
 }
 

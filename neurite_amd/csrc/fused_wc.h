@@ -16,9 +16,10 @@
 //   M1c  tag.rid == rid: the row is (or will be) in the slot -- `served`; the missing lane whose own tag came back is its `loader`;
 //        a reference whose slot now names another row of this same pass is an `orphan` (about 2 % of the references on the bench
 //        field): it gets an overflow row for this pass only.  Loaders + orphans are compacted (ballot / mbcnt) into a fetch list
-//        in LDS (one word per entry: row id | destination row << 24), transposed so that 8-lane groups read their entries back
-//        with one ds_read_b128 and fetch one 128-byte row each: ceil(n / 8) load instructions per pass instead of 8 (n = 23 on
-//        the bench field); the source row of every reference is broadcast to its group through 256 bytes of LDS;
+//        in LDS (two words per entry: byte offset of the row in the volume, of its LDS row), transposed so that 8-lane groups read their entries back
+//        with two ds_read_b128 and fetch one 128-byte row each: ceil(n / 8) load instructions per pass instead of 8 (n = 23 on
+//        the bench field); the source row of every reference is broadcast to its group through 128 bytes
+//        of LDS (16-bit offsets, one ds_read_b128, unpacked by the SDWA operands of the address additions);
 //   M2   the row loads (four always -- entries past n address bytes past the volume: no memory access -- and four more under a
 //        wave-uniform branch when n > 32: 19 % of the passes), the fixed row;
 //   D    the fetched rows are stored to their slots;
@@ -33,7 +34,7 @@
 // through the blend of pass p:  D(p), B-reads(p) | M2(p + 1) | M1a(p + 2) | blend corners 0..3 | M1b | corners 4..7 + Dice | M1c.
 // Every LDS round trip of the management has a stretch of the blend's arithmetic to hide behind; the row loads of pass p + 1 are
 // issued one step before they are stored.  The fixed row, the locations and the stored row go through buffer descriptors with the
-// pass offset in an SGPR (no per-pass address arithmetic); tags are 32-bit (row id | lane << 24).
+// pass offset in an SGPR (no per-pass address arithmetic); tags are 32-bit (row id << 6 | lane).
 //
 // Model of the request stream (tools/wc_sim.py, bench field): 4.8 distinct rows per voxel inside a pass, 2.7 fetched per voxel with
 // the cache (8 through L1 in the register kernel), 0.16 orphan references per voxel.
@@ -53,11 +54,12 @@ constexpr int WC_OVF = 16;                                      // overflow rows
 constexpr int WC_TRASH_ROW = WC_SLOTS + WC_OVF;                 // where the list entries without a row store (branch-free masking)
 constexpr int WC_ROWS = WC_TRASH_ROW + 1;
 constexpr unsigned WC_NOROW = 0x01ffffffu;                      // row id of "no row": its bytes lie past every volume this kernel takes (wc_applies)
-constexpr unsigned WC_TAGS_OFF = WC_ROWS * 128;                 // u32 tag per slot (row id | lane << 24), + one trash entry
-constexpr unsigned WC_LIST_OFF = WC_TAGS_OFF + 528;             // fetch list: 64 x {row offset in the volume, LDS row offset}, transposed (entry e at (e & 7) * 8 + (e >> 3))
-constexpr unsigned WC_BC_OFF = WC_LIST_OFF + 512;               // byte offset of the source row of every (voxel, corner) reference
-constexpr unsigned WC_WAVE_BYTES = WC_BC_OFF + 256;             // 19856
-constexpr unsigned WC_BLOCK_BYTES = 4 * WC_WAVE_BYTES;          // 79424: two blocks per CU
+constexpr unsigned WC_TAGS_OFF = WC_ROWS * 128;                 // u32 tag per slot (row id << 6 | lane), + one trash entry
+constexpr unsigned WC_LIST_OFF = WC_TAGS_OFF + 528;             // fetch list: 64 x {row offset in the volume, LDS row offset}, transposed
+                                                                // (entry e at (e & 7) * 8 + (e >> 3))
+constexpr unsigned WC_BC_OFF = WC_LIST_OFF + 512;               // u16 byte offset of the source row of every (voxel, corner) reference
+constexpr unsigned WC_WAVE_BYTES = WC_BC_OFF + 128;             // 19728
+constexpr unsigned WC_BLOCK_BYTES = 4 * WC_WAVE_BYTES;          // 78912: two blocks per CU
 static_assert(WC_LIST_OFF % 16 == 0 && WC_BC_OFF % 16 == 0 && WC_WAVE_BYTES % 16 == 0, "LDS layout");
 static_assert((WC_SLOTS + 1) * 4 <= 528 && WC_ROWS <= 256, "LDS layout");
 static_assert(2 * WC_BLOCK_BYTES <= 160 * 1024, "two blocks per CU");
@@ -140,7 +142,6 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
 
     wc_lds_char *wl = (wc_lds_char *)wc_smem + wave * WC_WAVE_BYTES;
     wc_lds_vu32 *tags = (wc_lds_vu32 *)(wl + WC_TAGS_OFF);
-    wc_lds_vu32 *bc = (wc_lds_vu32 *)(wl + WC_BC_OFF);
     wc_lds_char *lrow = wl + p * 16;                              // this lane's piece of row 0
     tags[lane] = ~0u;                                            // no row id is 0x3ffffff
     tags[lane + 64] = ~0u;
@@ -240,10 +241,10 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         typedef unsigned wc_u2 __attribute__((ext_vector_type(2)));
         *(__attribute__((address_space(3))) volatile wc_u2 *)(wl + WC_LIST_OFF + tp * 8u) =
             (wc_u2){fetcher ? (m.rid << 7) : (WC_NOROW << 7), fetcher ? src128 : (unsigned)WC_TRASH_ROW * 128u};
-        bc[lane] = src128;
+        ((__attribute__((address_space(3))) volatile unsigned short *)(wl + WC_BC_OFF))[lane] = (unsigned short)src128;
         // group g fetches entries g, 8 + g, 16 + g ...: consecutive entries of the transposed list
         const nrt_i4 la = *(wc_lds_vi4 *)(wl + WC_LIST_OFF + g * 64), lb = *(wc_lds_vi4 *)(wl + WC_LIST_OFF + g * 64 + 16);
-        const nrt_i4 sa = *(wc_lds_vi4 *)(wl + WC_BC_OFF + g * 32), sb = *(wc_lds_vi4 *)(wl + WC_BC_OFF + g * 32 + 16);
+        const nrt_i4 sh = *(wc_lds_vi4 *)(wl + WC_BC_OFF + g * 16);
         s.lr[0] = (unsigned)la[0]; s.ld[0] = (unsigned)la[1]; s.lr[1] = (unsigned)la[2]; s.ld[1] = (unsigned)la[3];
         s.lr[2] = (unsigned)lb[0]; s.ld[2] = (unsigned)lb[1]; s.lr[3] = (unsigned)lb[2]; s.ld[3] = (unsigned)lb[3];
         if (__builtin_expect(n > 32, 0)) {
@@ -252,7 +253,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
             s.xr[2] = (unsigned)le[0]; s.xd[2] = (unsigned)le[1]; s.xr[3] = (unsigned)le[2]; s.xd[3] = (unsigned)le[3];
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { s.sl[c] = (unsigned)sa[c]; s.sl[4 + c] = (unsigned)sb[c]; }
+        for (int c = 0; c < 4; ++c) { s.sl[2 * c] = (unsigned)sh[c] & 0xffffu; s.sl[2 * c + 1] = (unsigned)sh[c] >> 16; }
         s.w0x = m.w0x; s.w0y = m.w0y; s.w0z = m.w0z; s.oob = m.oob; s.n = n; s.xq = x0 + pass;
     };
     // M2: the row loads of the pass in s.  Four whatever n is (entries past n address bytes past the volume: no memory access): with
@@ -462,11 +463,14 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
     }
 }
 
+// persistent blocks pay off when there are more work items than resident blocks
+inline bool wc_persistent(const TileGeom &tg) { return NRT_NXCD * tg.items_x > 2u * (unsigned)nrt_num_cus(); }
+
 template <int MODE, bool STORE, bool MM, bool FILL>
 int launch_wc_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, const float *fixed, float *fpart, float *mpart,
                    unsigned *queue, hipStream_t st) {
     const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
-    if (queue && items > slots) {
+    if (queue && wc_persistent(tg)) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, STORE, MM, FILL, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WC_BLOCK_BYTES) != hipSuccess)
             return NRT_ERR_LAUNCH;

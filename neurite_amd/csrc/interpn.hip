@@ -684,16 +684,11 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
                           nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride);
     if (variant == 0) {
         if (can_zrun) {
-            // The z-run register kernel stays the default: it re-uses corner planes along z and wins on every field gentler than the
-            // bench's (0.91 ms per 4 x 160^3 x 32 on an identity field, 1.11 at half the bench field's steepness, 1.24 on the bench
-            // field, 2.15 on an incoherent one); the wave-cache kernel (variant 10) takes 1.17-1.20 whatever the field, i.e. it wins
-            // from a displacement gradient of ~0.35 voxel per voxel on (tools/interpn_field_sweep.py,
-            // profiles/r04_lab/interpn_field_sweep*.jsonl).  A per-call field probe that launched both kernels gated on its verdict was
-            // built and measured: the two extra dependent launches cost 15-45 us, more than the choice gains at 4 volumes -- removed.
-            // NRT_INTERPN_WC=1 makes the wave-cache kernel the choice wherever its schedule applies (steep or incoherent fields).
-            static int use_wc = -1;
-            if (use_wc < 0) { const char *e = getenv("NRT_INTERPN_WC"); use_wc = e ? (atoi(e) != 0) : 0; }
-            if (use_wc && tune == 0 && nrt_wc_interpn_supported(&a, batch)) variant = 10;
+            // Displacement fields and absolute locations: the wave-cache kernel (variant 10, fused_wc.h) since its round-5 schedule --
+            // per 4 x 160^3 x 32 on the bench field 0.96 ms against 1.25 for the z-run register kernel, 0.89 / 0.89 on an identity
+            // field, 1.87 / 2.15 on an incoherent one (tools/wc_bench.py, profiles/r05_lab/wc_schedule_ab.jsonl).  Regular grids
+            // (Resize) keep the z-run kernel: consecutive outputs share their corner planes there, which is what it is built for.
+            if (loc_mode != NRT_LOC_LINSPACE && tune == 0 && nrt_wc_interpn_supported(&a, batch)) variant = 10;
             else { variant = g_auto_c32_variant; if (tune == 0) tune = (variant >= 3) ? g_auto_c32_tune : 0; }
         }
         else if (can_lean) variant = 8;

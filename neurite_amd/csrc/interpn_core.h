@@ -191,7 +191,7 @@ inline unsigned xmarch_setup_mixed(const int *out_shape, int batch, int t, TileG
     const unsigned RY = 1u << tg.lry, RZ = 1u << tg.lrz;
     tg.ncol = ((tg.nTy + RY - 1) / RY) * ((tg.nTz + RZ - 1) / RZ) * RY * RZ;
     const unsigned cols = tg.ncol * (unsigned)batch, cpx = (cols + NRT_NXCD - 1) / NRT_NXCD;
-    const unsigned slots = (unsigned)(2 * nrt_num_cus() / NRT_NXCD);
+    const unsigned slots = (unsigned)max(1, 2 * nrt_num_cus() / NRT_NXCD);      // (a partition reporting fewer than 4 CUs: never 0)
     static const int PS[7] = {1, 2, 3, 4, 5, 6, 8};
     static const float OVH[7] = {0.f, 0.07f, 0.11f, 0.15f, 0.17f, 0.19f, 0.22f};
     float best = 1e30f;

@@ -283,13 +283,9 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd(LcArgs a, int b0, int nb) {
 // over the chunks ends in a cross-lane reduction (2 DPP rotations inside a 16-lane row, then two xor-shuffles over the rows).
 // Same arithmetic as the vector kernel up to the order of the float32 sums.
 // ---------------------------------------------------------------------------------------------
-#ifndef NRT_LC_EXP
-#define NRT_LC_EXP 0                  // lab builds only (wrong results): 3 = one weight load per group, 5 = no MFMA, 6 = one patch load per position
-                                      // (profiles/r04_lab/lc3d_mfma_parts_off.txt: the patch gathers, not the matrix work, are what batch 8 pays for)
-#endif
-#ifndef NRT_LC_WAUX
-#define NRT_LC_WAUX 2                 // cache policy bits of the weight loads in the matrix-core kernel (2 = nt; lab builds try others)
-#endif
+// (probe builds of round 4 -- one weight load per group, no MFMA, one patch load per position -- showed that the patch gathers, not the
+// matrix work, are what batch 8 pays for: profiles/r04_lab/lc3d_mfma_parts_off.txt; the switches are gone from this file, see e0b416e)
+constexpr int LC_WAUX = 2;            // cache policy bits of the weight loads in the matrix-core kernels: nt (others made no difference)
 typedef float lc_f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lc_row_ror(float v, const int ctrl_is_8) {
@@ -385,28 +381,22 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
     };
     u32x4 pc[NB][NPC];
     unsigned w[RD][GC][WPL];
-#if NRT_LC_EXP == 3
-    for (int i = 0; i < RD * GC * WPL; ++i) (&w[0][0][0])[i] = 0x3f803f80u;
-#endif
     auto issue_patch = [&](const Pos &p) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int k = 0; k < NPC; ++k)
-#if NRT_LC_EXP == 6
-                if (b > 0) pc[b][k] = pc[0][k]; else
-#endif
                 pc[b][k] = __builtin_amdgcn_raw_buffer_load_b128(xres, choff[k], p.xbase + (unsigned)(b < nb ? b : 0) * xbs_bytes, 0);
     };
     auto issue_group = [&](const __amdgpu_buffer_rsrc_t wr, const int buf, const int g) {
 #pragma unroll
-        for (int i = 0; i < (NRT_LC_EXP == 3 ? 1 : GC); ++i) {
+        for (int i = 0; i < GC; ++i) {
             const int c = g * GC + i;                          // chunks past the last one lie past num_records: zeros
             if constexpr (WPL == 2) {
-                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(wr, w0, c * 64 * BPL, NRT_LC_WAUX);
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(wr, w0, c * 64 * BPL, LC_WAUX);
                 w[buf][i][0] = raw[0]; w[buf][i][1] = raw[1];
             } else {
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, c * 64 * BPL, NRT_LC_WAUX);
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, c * 64 * BPL, LC_WAUX);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) w[buf][i][k] = raw[k];
             }
@@ -473,11 +463,7 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma(LcArgs a, int b0, int nb
                         }
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
-#if NRT_LC_EXP == 5
-                            asm volatile("" :: "v"(av[s]), "v"(bw));      // operands formed, nothing multiplied
-#else
                             acc[s][jj] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s], bw, acc[s][jj], 0, 0, 0);
-#endif
                         }
                     }
                 }
@@ -642,10 +628,10 @@ __global__ __launch_bounds__(256, 2) void lc3d_fwd_mfma_blk(LcArgs a, int b0, in
         for (int i = 0; i < GC; ++i) {
             const int c = g * GC + i;
             if constexpr (WPL == 2) {
-                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(wr, w0, c * 64 * BPL, NRT_LC_WAUX);
+                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(wr, w0, c * 64 * BPL, LC_WAUX);
                 w[buf][i][0] = raw[0]; w[buf][i][1] = raw[1];
             } else {
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, c * 64 * BPL, NRT_LC_WAUX);
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(wr, w0, c * 64 * BPL, LC_WAUX);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) w[buf][i][k] = raw[k];
             }

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""Macro variants of neurite_amd/csrc/fused.hip as separate libraries (tools/lab/libnrt_fused_<k>.so = the product's objects with
-fused.o rebuilt under -DNRT_FUSED_EXP=<k>), timed through bench.py with NEURITE_AMD_LIB pointing at each.
-    python tools/fused_variants.py --build          (here, no GPU)
-    python tools/fused_variants.py                  (GPU box)"""
+"""A/B harness for working copies of neurite_amd/csrc/fused.hip + fused_wc.h: each variant is a separate library
+(tools/lab/libnrt_fused_<k>.so = the product's objects with fused.o rebuilt under -DNRT_FUSED_<NAME>=<value> ...), timed through
+bench.py with NEURITE_AMD_LIB pointing at it.  The product sources carry NO such switches (round 5): a lab session adds its
+`#if NRT_FUSED_<NAME>` blocks to a working copy, measures, and removes them before the commit -- the probe builds behind
+profiles/r04_lab/l1_access_curve.jsonl (NRT_FUSED_EXP) are in the history at commit e0b416e, those behind
+profiles/r05_lab/wc_probes.jsonl were never committed with the sources.
+    FUSED_VARIANTS="A=1 A=1,B=2" python tools/fused_variants.py --build          (here, no GPU)
+    FUSED_VARIANTS="A=1 A=1,B=2" FUSED_REPS=3 python tools/fused_variants.py      (GPU box; variants alternate REPS times)"""
 import glob
 import json
 import os
@@ -12,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAB = os.path.join(ROOT, 'tools', 'lab')
 LIBDIR = os.path.join(ROOT, 'neurite_amd', 'lib')
-VARIANTS = os.environ.get('FUSED_VARIANTS', 'EXP=0 EXP=1 EXP=2 EXP=3 EXP=4').split()        # NAME=value macros NRT_FUSED_<NAME>
+VARIANTS = os.environ.get('FUSED_VARIANTS', 'BASE=0').split()        # NAME=value macros NRT_FUSED_<NAME>
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize', '-Wno-unused-function', '-Wno-pass-failed']
 
 if '--build' in sys.argv:
@@ -23,9 +27,11 @@ if '--build' in sys.argv:
         subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + [o, '-o', os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '').replace(',', '_'))])
     print('built', VARIANTS)
     sys.exit(0)
-for k in VARIANTS:
+REPS = int(os.environ.get('FUSED_REPS', '1'))
+STEPS = os.environ.get('FUSED_STEPS', '40')
+for k in VARIANTS * REPS:
     env = dict(os.environ, NEURITE_AMD_LIB=os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '').replace(',', '_')))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '40', '--warmup', '10', '--no-cpu-baseline', '--no-batch1', '--no-unet'],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', STEPS, '--warmup', '10', '--no-cpu-baseline', '--no-batch1', '--no-unet'],
                        env=env, capture_output=True, text=True)
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
