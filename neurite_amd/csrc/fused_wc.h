@@ -31,9 +31,10 @@
 // 218 wait on counters and 60 on issue, VALU 62 % busy at 2 waves per SIMD, 20 branch instructions per pass -- the management chain
 // (tag read -> write -> read -> ballots -> list write -> list read -> loads) was four serial LDS round trips per pass, cut into ~20
 // basic blocks the compiler cannot schedule across.  Now a step is (nearly) one basic block and the chain of pass p + 2 is threaded
-// through the blend of pass p:  D(p), B-reads(p) | M2(p + 1) | M1a(p + 2) | blend corners 0..3 | M1b | corners 4..7 + Dice | M1c.
-// Every LDS round trip of the management has a stretch of the blend's arithmetic to hide behind; the row loads of pass p + 1 are
-// issued one step before they are stored.  The fixed row, the locations and the stored row go through buffer descriptors with the
+// through the blend of pass p:  M2(p + 1) | D(p), B-reads(p) | M1a(p + 2) | blend corners 0..3 | M1b | corners 4..7 | M1c | Dice sums.
+// Every LDS round trip of the management has a stretch of the blend's arithmetic to hide behind; the row loads of pass p + 1 go out
+// first thing in step p, BEFORE the wait for pass p's own rows (a late row does not hold back the next requests), one step before they
+// are stored -- the lead matters: requested half a step later the launch takes 12 % longer (profiles/r05_lab/wc_probes.jsonl).  The fixed row, the locations and the stored row go through buffer descriptors with the
 // pass offset in an SGPR (no per-pass address arithmetic); tags are 32-bit (row id << 6 | lane).
 //
 // Model of the request stream (tools/wc_sim.py, bench field): 4.8 distinct rows per voxel inside a pass, 2.7 fetched per voxel with
@@ -279,17 +280,19 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     };
 
     // One pass.  `s` holds pass `pass` (managed two steps ago, rows in flight since the last step), `o` pass + 1 (managed in the last
-    // step, its loads go out here); the management of pass + 2 is threaded through the blend so that each of its LDS round trips has
-    // arithmetic to hide behind.  MASKED: the wave has voxels outside the volume (edge patches) whose sums must not count.
+    // step, its loads go out first thing here); the management of pass + 2 is threaded through the blend so that each of its LDS round
+    // trips has arithmetic to hide behind.  MASKED: the wave has voxels outside the volume (edge patches) whose sums must not count.
+    // (Tried and measured slower, profiles/r05_lab/wc_probes.jsonl: the management BEFORE the row stores with the requests of pass + 2
+    // leaving in the same step, 1.10 ms against 0.95; three management states with the requests two steps ahead: 256 registers, spills.)
     const int last = npass - 1;
     auto step = [&](int pass, Pass &s, Pass &o, auto masked) {
         constexpr bool MASKED = decltype(masked)::value;
+        issue(o);                    // (before the wait for this pass's rows: a late row must not hold back the next pass's requests)
+        __builtin_amdgcn_sched_barrier(0);
         deliver(s);
         nrt_f4 R[8];
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) R[corner] = *(const wc_lds_f4 *)(lrow + s.sl[corner]);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(o);
         __builtin_amdgcn_sched_barrier(0);
         Mg m;
         m1a(min(pass + 2, last), s, m);
@@ -330,8 +333,14 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
             for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], s.oob, a.fill_f);
         }
         if (STORE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wc_u4, acc), ores, out_lane, (unsigned)s.xq * row_step, 2);
+        // the Dice sums wait behind M1c: they cover the round trip of its list
+        const nrt_f4 Tcur = s.T;
+        asm volatile("" : "+v"(acc));
+        __builtin_amdgcn_sched_barrier(0);
+        m1c(min(pass + 2, last), m, s);
+        __builtin_amdgcn_sched_barrier(0);
         if (DICE) {
-            nrt_f4 T = s.T;
+            nrt_f4 T = Tcur;
             if (MASKED) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { T[c] = yzvalid ? T[c] : 0.0f; acc[c] = yzvalid ? acc[c] : 0.0f; }
@@ -344,7 +353,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
                 if (!MASKED || yzvalid) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        mnt = fminf(mnt, s.T[c]); mxt = fmaxf(mxt, s.T[c]);
+                        mnt = fminf(mnt, Tcur[c]); mxt = fmaxf(mxt, Tcur[c]);
                         mnp = fminf(mnp, acc[c]); mxp = fmaxf(mxp, acc[c]);
                     }
                 }
@@ -353,7 +362,6 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         if (DICE) asm volatile("" : "+v"(stp_l), "+v"(stp_h), "+v"(stt_l), "+v"(stt_h), "+v"(spp_l), "+v"(spp_h));
         else asm volatile("" :: "v"(acc));
         __builtin_amdgcn_sched_barrier(0);
-        m1c(min(pass + 2, last), m, s);
         fetch_loc(min(pass + 4, last), s);
         __builtin_amdgcn_sched_barrier(0);
     };
