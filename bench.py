@@ -715,6 +715,17 @@ def self_launch(n):
     print(lines[-1], flush=True)
 
 
+def batch_plan(global_batch, batch_per_gpu, world):
+    """(volumes per rank, global batch, scaling) of a run: `--global-batch G` is BASELINE config 4 as written (G volumes in total,
+    G / N per rank, "strong"); otherwise every rank holds `--batch-per-gpu` volumes ("weak").  A global batch the ranks do not divide
+    is an error, never a silent truncation."""
+    if global_batch:
+        if global_batch % world:
+            raise SystemExit('--global-batch %d is not a multiple of the %d ranks' % (global_batch, world))
+        return global_batch // world, global_batch, 'strong'
+    return batch_per_gpu, batch_per_gpu * world, 'weak'
+
+
 def stub_main(args, rank, world):
     """--stub-step: the launch, the timed region and the one-JSON-line discipline on CPU ranks (gloo), with a stub in place of the
     kernels.  What it prints is shaped like the real line and says "data": "stub"."""
@@ -725,9 +736,7 @@ def stub_main(args, rank, world):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
         group = dist
-    B = args.global_batch // world if args.global_batch else args.batch_per_gpu
-    if args.global_batch and args.global_batch % world:
-        raise SystemExit('--global-batch %d is not a multiple of the %d ranks' % (args.global_batch, world))
+    B, global_batch, scaling = batch_plan(args.global_batch, args.batch_per_gpu, world)
 
     def step(events):
         time.sleep(0.002 * B)
@@ -738,8 +747,8 @@ def stub_main(args, rank, world):
         print(json.dumps({'metric': 'Mvoxels/sec interpn+Dice on 160^3 x 32-label', 'value': round(world * B * V * args.steps / r['elapsed'] / 1e6, 2),
                           'unit': 'Mvoxels/s', 'n_gpus': world, 'rccl_ranks': r['ranks'], 'steps': args.steps, 'warmup': args.warmup,
                           'ms_per_step': round(r['elapsed'] / args.steps * 1e3, 4), 'higher_is_better': True,
-                          'scaling': 'strong' if args.global_batch else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'stub',
-                          'config': {'workload': 'stub step (no kernels): plumbing self-test', 'volumes_per_gpu': B, 'global_batch': B * world,
+                          'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'stub',
+                          'config': {'workload': 'stub step (no kernels): plumbing self-test', 'volumes_per_gpu': B, 'global_batch': global_batch,
                                      'mean_dice': r['mean']}}), flush=True)
     if group is not None:
         dist.destroy_process_group()
@@ -776,12 +785,8 @@ def main():
     from neurite_amd import distributed as nd
     from neurite_amd import synth
 
-    if args.global_batch:
-        if args.global_batch % world:
-            raise SystemExit('--global-batch %d is not a multiple of the %d ranks' % (args.global_batch, world))
-        B = args.global_batch // world                 # strong scaling: BASELINE config 4, the global batch is fixed
-    else:
-        B = args.batch_per_gpu                         # weak scaling: every GPU holds the same number of volumes
+    # strong scaling: BASELINE config 4, the global batch is fixed; weak: every GPU holds the same number of volumes
+    B = batch_plan(args.global_batch, args.batch_per_gpu, world)[0]
     S, L = args.size, args.labels
     V = S ** 3
     # rank r owns global batch entries [r*B, (r+1)*B): seeds follow the global entry index

@@ -6,7 +6,8 @@ Data-parallel training of neurite's unet on MI355X: one process per GPU, RCCL gr
 
 Every rank synthesises its own (image, one-hot segmentation) pairs on the device with the label-to-image model
 (`ne.models.labels_to_image`), runs forward + backward of `ne.models.unet` on the HIP kernels (`model.train()`), averages
-the gradients over the ranks with ONE flat-bucket all-reduce (`ne.distributed.all_reduce_gradients`) and applies SGD.
+the gradients over the ranks with ONE all-reduce of the flat buffer the gradients live in (`ne.distributed.GradientBucket`: no packing,
+no copy back) and applies SGD.
 """
 
 import argparse
@@ -49,6 +50,7 @@ def main():
         gen = ne.models.labels_to_image((S, S, S), label_values, warp_std=1.0, seeds={})
     net.train()
     params = list(net.parameters())
+    bucket = ne.distributed.GradientBucket(params)                   # every p.grad is now a view into ONE flat float32 buffer
     cce = ne.losses.CategoricalCrossentropy()
     dice = ne.metrics.Dice(check_input_limits=False)
     losses = []
@@ -59,11 +61,11 @@ def main():
         pred = net(image)
         loss = cce(onehot, pred) - dice.mean_dice(onehot, pred)
         loss.backward()
-        ne.distributed.all_reduce_gradients(params)                  # one RCCL all-reduce; no-op at world size 1
+        bucket.all_reduce()                                          # one RCCL all-reduce of that buffer; no-op at world size 1
         with torch.no_grad():
             for p in params:
                 p -= args.lr * p.grad
-                p.grad = None
+            bucket.zero_()                                           # (not p.grad = None: the views are the point)
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -39,6 +39,10 @@ typedef enum {
 const char *nrt_status_string(int status);
 /* ABI version, bumped when a signature changes. */
 int nrt_abi_version(void);
+/* Identity of the sources the library was built from (16 hex digits of a sha256 over flags, headers and kernels; "unknown" for a
+ * build outside neurite_amd/build.py).  The reference is pure Python and has no counterpart; __graft_entry__.build() uses it to
+ * refuse a shipped binary that does not match the tree. */
+const char *nrt_build_id(void);
 /* Name of the GPU architecture the library was compiled for ("gfx950"). */
 const char *nrt_target_arch(void);
 

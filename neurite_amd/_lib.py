@@ -31,6 +31,7 @@ _SIGNATURES = {
     'nrt_status_string': (C.c_char_p, [_i]),
     'nrt_abi_version': (_i, []),
     'nrt_target_arch': (C.c_char_p, []),
+    'nrt_build_id': (C.c_char_p, []),
     'nrt_interpn_f32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _vp]),
     'nrt_interpn_f32_ex': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _i, _i, _vp]),
     'nrt_interpn_add_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _ll, _i, _i, _f, _vp]),

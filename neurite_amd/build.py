@@ -8,6 +8,7 @@ travels with the source snapshot; it is git-ignored.
 """
 
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -31,43 +32,89 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
-def _newest_input():
-    files = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
-        [os.path.join(HERE, '..', 'include', 'neurite_amd.h'), os.path.abspath(__file__)]
-    return max(os.path.getmtime(f) for f in files)
+def _headers():
+    return sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(HERE, '..', 'include', 'neurite_amd.h')]
+
+
+def _sha(*chunks):
+    h = hashlib.sha256()
+    for c in chunks:
+        h.update(c if isinstance(c, bytes) else c.encode())
+        h.update(b'\0')
+    return h.hexdigest()
+
+
+def _read(path):
+    with open(path, 'rb') as f:
+        return f.read()
+
+
+def _common_hash():
+    """what every object depends on besides its own source: the headers and the compile flags"""
+    return _sha(' '.join(FLAGS), *[_read(h) for h in _headers()])
+
+
+def build_id():
+    """Identity of the sources the library SHOULD be built from: sha256 over flags, headers and every .hip file (16 hex digits).
+    The library carries the id it was built from (`nrt_build_id()`, a string constant in api.o); mtimes play no part -- a git checkout,
+    a copied tree or a shipped binary newer than the sources it does not match are all told apart by content."""
+    return _sha(_common_hash(), *[_read(s) for s in sources()])[:16]
+
+
+_ID_MARK = b'NRT_BUILD_ID='
+
+
+def library_build_id(path=None):
+    """the id embedded in an existing library (read from the file, nothing is loaded), or None"""
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    blob = _read(path)
+    k = blob.find(_ID_MARK)
+    if k < 0:
+        return None
+    return blob[k + len(_ID_MARK):k + len(_ID_MARK) + 16].decode('ascii', 'replace')
 
 
 def is_stale():
-    return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < _newest_input()
+    return library_build_id() != build_id()
 
 
 def build(force=False, verbose=False):
     """Compile every .hip under csrc/ into one shared library.  Returns the library path."""
-    if not force and not is_stale():
+    bid = build_id()
+    if not force and library_build_id() == bid:
         return LIB
     hipcc = os.environ.get('HIPCC', 'hipcc')
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     procs = []
-    # an object is reused when it is newer than its source, every header and this file (the flags)
-    common = max(os.path.getmtime(f) for f in glob.glob(os.path.join(CSRC, '*.h')) +
-                 [os.path.join(HERE, '..', 'include', 'neurite_amd.h'), os.path.abspath(__file__)])
+    common = _common_hash()
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(common, os.path.getmtime(src)):
+        # an object is reused when the hash of what it was compiled from (source, headers, flags; for api.o also the library id) matches
+        is_api = os.path.basename(src) == 'api.hip'
+        want = _sha(common, _read(src), bid if is_api else '')
+        stamp = obj + '.sha'
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and _read(stamp).decode() == want:
             continue
-        cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + (['-DNRT_BUILD_ID_STRING="%s"' % bid] if is_api else []) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
-        procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+        procs.append((src, stamp, want, subprocess.Popen(cmd)))
+    for src, stamp, want, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on ' + src)
+        with open(stamp, 'w') as f:
+            f.write(want)
     cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', LIB]
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
+    got = library_build_id()
+    if got != bid:
+        raise RuntimeError('the library just built reports build id %r, expected %r' % (got, bid))
     return LIB
 
 

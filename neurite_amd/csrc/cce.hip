@@ -40,11 +40,38 @@ template <> struct Quad<unsigned short> {
     }
 };
 
+// The sum of the block partials, by the LAST block of the same launch (round 5; a second launch cost more than it computed at
+// config 5's 53 MB: three launches -- zero, kernel, finalize -- for 10 us of streaming).  A block publishes its partial, fences and
+// takes a ticket from a self-cleaning counter (api.hip: nrt_ring_slot); the block that draws the last ticket adds the partials in a
+// FIXED order in float64 (what wcce_finalize did: run-to-run bit-identical) and zeroes the counter for the slot's next launch.
+struct WcceFin { float *loss_sum; unsigned *counter; };
+__device__ __forceinline__ void wcce_finish(const float *part, const WcceFin &fin) {
+    __shared__ bool s_last;
+    __shared__ double s_acc[CCE_BLOCK];
+    if (threadIdx.x == 0) {
+        __threadfence();                                       // the partial is visible device-wide (the XCDs have their own L2s) ...
+        s_last = atomicAdd(fin.counter, 1u) == gridDim.x - 1;  // ... before the ticket says so
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double a = 0.0;
+    for (unsigned k = threadIdx.x; k < gridDim.x; k += CCE_BLOCK) a += (double)__builtin_nontemporal_load(part + k);
+    s_acc[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < CCE_BLOCK; ++i) t += s_acc[i];      // fixed order
+        fin.loss_sum[0] = (float)t;
+        *fin.counter = 0u;
+    }
+}
+
 // per-lane contribution -sum_k t'_k * logq_k for this lane's channels
 template <int G, typename T, bool LOGITS, bool PERVOX>
 __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ yt, const void *__restrict__ yp,
                                                       const float *__restrict__ w, long long n, float smooth,
-                                                      float *__restrict__ part, float *__restrict__ per_voxel, int Gr) {
+                                                      float *__restrict__ part, float *__restrict__ per_voxel, int Gr, WcceFin fin) {
     // Gr <= G channel quads per voxel are real (channel counts 4 Gr that are no power of two: 12, 20, 24 ...): lanes lg >= Gr of a
     // lane-group load nothing, enter the soft-max as -inf (the sums as 0) and add nothing to the loss
     constexpr int NG = CCE_BLOCK / G;
@@ -115,6 +142,7 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ y
         for (int i = 1; i < CCE_BLOCK / NRT_WAVE; ++i) s += red[i];
         part[blockIdx.x] = s;
     }
+    wcce_finish(part, fin);
 }
 
 // any C: one thread per voxel
@@ -125,7 +153,7 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ y
 template <typename T, bool LOGITS>
 __global__ __launch_bounds__(CCE_BLOCK) void wcce_generic(const void *__restrict__ yt, const void *__restrict__ yp,
                                                           const float *__restrict__ w, long long n, int C, float smooth, int VP,
-                                                          float *__restrict__ part, float *__restrict__ per_voxel) {
+                                                          float *__restrict__ part, float *__restrict__ per_voxel, WcceFin fin) {
     extern __shared__ float cg_lds[];      // [2][VP * C]
     const float keep = 1.0f - smooth, add = smooth / (float)C;
     float acc = 0.0f;
@@ -189,39 +217,27 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_generic(const void *__restrict
         for (int i = 1; i < CCE_BLOCK / NRT_WAVE; ++i) s += red[i];
         part[blockIdx.x] = s;
     }
-}
-
-__global__ __launch_bounds__(256) void wcce_finalize(const float *__restrict__ part, int nblk, float *__restrict__ loss_sum) {
-    __shared__ double sl[256];
-    double a = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += 256) a += (double)part[k];
-    sl[threadIdx.x] = a;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < 256; ++i) s += sl[i];      // fixed order
-        loss_sum[0] = (float)s;
-    }
+    wcce_finish(part, fin);
 }
 
 bool vec_channels(int C) { return C % 4 == 0 && C >= 4 && C <= 256; }       // lane-groups of the next power of two >= C / 4 lanes
 
 template <int G, typename T>
 void launch_vec(const void *t, const void *p, const float *w, long long n, int logits, float smooth, unsigned nblk,
-                float *part, float *pv, hipStream_t st, int Gr) {
+                float *part, float *pv, hipStream_t st, int Gr, WcceFin fin) {
     dim3 grid(nblk), blk(CCE_BLOCK);
     if (logits) {
-        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, true, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr);
-        else hipLaunchKernelGGL((wcce_vec<G, T, true, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr);
+        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, true, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr, fin);
+        else hipLaunchKernelGGL((wcce_vec<G, T, true, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr, fin);
     } else {
-        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, false, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr);
-        else hipLaunchKernelGGL((wcce_vec<G, T, false, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr);
+        if (pv) hipLaunchKernelGGL((wcce_vec<G, T, false, true>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr, fin);
+        else hipLaunchKernelGGL((wcce_vec<G, T, false, false>), grid, blk, 0, st, t, p, w, n, smooth, part, pv, Gr, fin);
     }
 }
 
 template <typename T>
 void launch_any(const void *t, const void *p, const float *w, long long n, int C, int logits, float smooth,
-                bool aligned, unsigned &nblk, float *part, float *pv, hipStream_t st) {
+                bool aligned, unsigned &nblk, float *part, float *pv, hipStream_t st, WcceFin fin) {
     if (vec_channels(C) && aligned) {
         const int Gr = C / 4;
         int G = 1;
@@ -229,13 +245,13 @@ void launch_any(const void *t, const void *p, const float *w, long long n, int C
         long long nb = (n + (CCE_BLOCK / G) * 4 - 1) / ((CCE_BLOCK / G) * 4);
         nblk = (unsigned)(nb < 1 ? 1 : (nb > CCE_MAX_BLOCKS ? CCE_MAX_BLOCKS : nb));
         switch (G) {
-            case 1: launch_vec<1, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
-            case 2: launch_vec<2, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
-            case 4: launch_vec<4, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
-            case 8: launch_vec<8, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
-            case 16: launch_vec<16, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
-            case 32: launch_vec<32, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
-            default: launch_vec<64, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr); break;
+            case 1: launch_vec<1, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr, fin); break;
+            case 2: launch_vec<2, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr, fin); break;
+            case 4: launch_vec<4, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr, fin); break;
+            case 8: launch_vec<8, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr, fin); break;
+            case 16: launch_vec<16, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr, fin); break;
+            case 32: launch_vec<32, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr, fin); break;
+            default: launch_vec<64, T>(t, p, w, n, logits, smooth, nblk, part, pv, st, Gr, fin); break;
         }
     } else {
         // rows of VP voxels of both tensors in LDS (48 KB): 256 voxels up to 24 channels, fewer for wider rows, none beyond 768
@@ -246,8 +262,8 @@ void launch_any(const void *t, const void *p, const float *w, long long n, int C
         long long nb = (n + per - 1) / per;
         nblk = (unsigned)(nb < 1 ? 1 : (nb > CCE_MAX_BLOCKS ? CCE_MAX_BLOCKS : nb));
         const size_t shm = (size_t)2 * VP * C * 4;
-        if (logits) hipLaunchKernelGGL((wcce_generic<T, true>), dim3(nblk), dim3(CCE_BLOCK), shm, st, t, p, w, n, C, smooth, VP, part, pv);
-        else hipLaunchKernelGGL((wcce_generic<T, false>), dim3(nblk), dim3(CCE_BLOCK), shm, st, t, p, w, n, C, smooth, VP, part, pv);
+        if (logits) hipLaunchKernelGGL((wcce_generic<T, true>), dim3(nblk), dim3(CCE_BLOCK), shm, st, t, p, w, n, C, smooth, VP, part, pv, fin);
+        else hipLaunchKernelGGL((wcce_generic<T, false>), dim3(nblk), dim3(CCE_BLOCK), shm, st, t, p, w, n, C, smooth, VP, part, pv, fin);
     }
 }
 
@@ -268,15 +284,15 @@ extern "C" int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const
     hipStream_t st = nrt_stream(stream);
     float *part = (float *)workspace;
     unsigned nblk = 1;
+    WcceFin fin = {loss_sum, nrt_ring_slot()};
+    if (!fin.counter) return NRT_ERR_LAUNCH;
     const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
     if (dtype == NRT_DT_F32)
         launch_any<float>(y_true, y_pred, label_weights, nvox_total, channels, from_logits, label_smoothing, aligned,
-                          nblk, part, per_voxel, st);
+                          nblk, part, per_voxel, st, fin);
     else
         launch_any<unsigned short>(y_true, y_pred, label_weights, nvox_total, channels, from_logits, label_smoothing,
-                                   aligned, nblk, part, per_voxel, st);
-    NRT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wcce_finalize, dim3(1), dim3(256), 0, st, (const float *)part, (int)nblk, loss_sum);
+                                   aligned, nblk, part, per_voxel, st, fin);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

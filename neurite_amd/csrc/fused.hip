@@ -295,7 +295,7 @@ size_t fused_ws_bytes(unsigned nblocks, int L, int batch) {
     const size_t rows = (size_t)batch * nblocks;
     const size_t grp = (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS);
     return rows * 3 * L * sizeof(float) + rows * 4 * sizeof(float) + 16 + grp * 3 * L * sizeof(double) +
-           grp * 4 * sizeof(float) + 256 + 64 + NRT_NXCD * 64;       // (+ the work counters of the persistent wave-cache kernel)
+           grp * 4 * sizeof(float) + 256;
 }
 
 // nblocks = partial rows per batch entry
@@ -336,10 +336,10 @@ inline FusedChoice fused_choose(const InterpArgs &a, const TileGeom &tg, int G, 
 
 template <int G, typename ST>
 int launch_fused(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store,
-                 const void *fixed, float *fpart, float *mpart, hipStream_t st, bool allow_wc, bool want_minmax, unsigned *queue) {
+                 const void *fixed, float *fpart, float *mpart, hipStream_t st, bool allow_wc, bool want_minmax) {
     if constexpr (G == 8 && std::is_same<ST, float>::value) {
         if (fused_choose(a, tg, G, true, allow_wc).wc)
-            return launch_wc(a, tg, nblocks, batch, mode, store, want_minmax, (const float *)fixed, fpart, mpart, queue, st);
+            return launch_wc(a, tg, nblocks, batch, mode, store, want_minmax, (const float *)fixed, fpart, mpart, st);
     }
     dim3 grid(nblocks, batch), blk(256);
     // x-march: 75 KB of unused dynamic LDS per block = two blocks per CU, so that the blocks an XCD runs together are one region whose
@@ -426,18 +426,17 @@ int warp_dice_soft_impl(const void *moving, const float *loc, const void *fixed,
     p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
     w.gsum = (double *)p; p += (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS) * 3 * nlabels * sizeof(double);
     w.gmm = (float *)p; p += (size_t)batch * ((nblocks + RED_ROWS - 1) / RED_ROWS) * 4 * sizeof(float);
-    unsigned *queue = (unsigned *)(((uintptr_t)p + 63) & ~(uintptr_t)63);
     w.ipart = nullptr;
     hipStream_t st = nrt_stream(stream);
     const bool store = warped != nullptr;
     switch (G) {
-        case 1: rc = launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
-        case 2: rc = launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
-        case 4: rc = launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
-        case 8: rc = launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
-        case 16: rc = launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
-        case 32: rc = launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
-        default: rc = launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr, queue); break;
+        case 1: rc = launch_fused<1, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr); break;
+        case 2: rc = launch_fused<2, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr); break;
+        case 4: rc = launch_fused<4, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr); break;
+        case 8: rc = launch_fused<8, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr); break;
+        case 16: rc = launch_fused<16, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr); break;
+        case 32: rc = launch_fused<32, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr); break;
+        default: rc = launch_fused<64, ST>(a, tg, nblocks, batch, loc_mode, store, fixed, w.fpart, w.mpart, st, allow_wc, minmax != nullptr); break;
     }
     if (rc != NRT_OK) return rc;              // nothing (or not everything) was launched: do not reduce stale partial sums
     NRT_CHECK_LAUNCH();

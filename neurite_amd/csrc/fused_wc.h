@@ -42,7 +42,6 @@
 
 #pragma once
 
-#include <mutex>
 #include <type_traits>
 
 #include "dice_reduce.h"
@@ -430,12 +429,13 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     xmarch_zero_rows(tg, xw, 3 * L, fpart, mpart);
 }
 
-// The work counters of a persistent launch are zeroed by a KERNEL on the launch stream (nrt_zero_async), not by hipMemsetAsync: inside
-// a captured hipGraph the memset node did not take effect between replays (ROCm 7.2) -- every replay after the first found the lists
-// exhausted, its blocks left at once and the second stage re-reduced the previous replay's partial sums: stale results in 0.03 ms
-// (tools/graph_fused_probe.py; tests/test_gpu_dice_cce.py::test_fused_kernels_recompute_under_graph_replay).
+// The work counters of a persistent launch live in a self-cleaning slot of the library's counter ring (api.hip: nrt_ring_slot): zero when
+// the launch starts, zeroed again by its last block.  History: hipMemsetAsync in front of the launch did not take effect between the
+// replays of a captured hipGraph (ROCm 7.2) -- every replay after the first found the lists exhausted, its blocks left at once and the
+// second stage re-reduced the previous replay's partial sums, stale results in 0.03 ms (tools/graph_fused_probe.py;
+// tests/test_gpu_dice_cce.py::test_fused_kernels_recompute_under_graph_replay); a zeroing KERNEL in front (round 4) cost a launch.
 
-// PERSIST: 2 blocks per CU stay resident and take items from per-XCD lists (atomic counters in `queue`, zeroed before the launch):
+// PERSIST: 2 blocks per CU stay resident and take items from per-XCD lists (atomic counters in `queue`, zero at the start):
 // first their own XCD's (its L2 holds the neighbouring columns), then the others'.  With one block per item the XCDs finish up to
 // 5 % apart (tools/block_trace.py: last block of an XCD at 1044 .. 1097 us) and the slots of a finished XCD idle; the items are the
 // same either way, every item writes its own partial row, so the sums do not depend on who computed what.
@@ -469,20 +469,26 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
         if (!xmarch_work_at(tg, a.O[0], kk, jb, xw)) continue;
         wc_item<MODE, STORE, MM, FILL, DICE>(a, tg, fixed, fpart, mpart, xw, wc_smem);
     }
+    // a block comes here once every list is exhausted and never touches the counters again: the last one to arrive zeroes them for the
+    // slot's next launch (nrt_ring_slot)
+    if (threadIdx.x == 0 && atomicAdd(&queue[NRT_NXCD * 16u], 1u) == gridDim.x - 1) {
+        for (unsigned q = 0; q <= NRT_NXCD; ++q) queue[q * 16u] = 0u;
+    }
 }
 
 // persistent blocks pay off when there are more work items than resident blocks
 inline bool wc_persistent(const TileGeom &tg) { return NRT_NXCD * tg.items_x > 2u * (unsigned)nrt_num_cus(); }
+static_assert((NRT_NXCD + 1) * 16 <= NRT_RING_WORDS, "work counters of a launch fit one ring slot");
 
 template <int MODE, bool STORE, bool MM, bool FILL>
 int launch_wc_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, const float *fixed, float *fpart, float *mpart,
-                   unsigned *queue, hipStream_t st) {
+                   hipStream_t st) {
     const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
-    if (queue && wc_persistent(tg)) {
+    unsigned *queue = wc_persistent(tg) ? nrt_ring_slot() : nullptr;
+    if (queue) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, STORE, MM, FILL, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WC_BLOCK_BYTES) != hipSuccess)
             return NRT_ERR_LAUNCH;
-        if (nrt_zero_async(queue, NRT_NXCD * 64, st) != hipSuccess) return NRT_ERR_LAUNCH;
         hipLaunchKernelGGL((warp_dice_wc<MODE, STORE, MM, FILL, true, true>), dim3(nrt_xcd_grid(slots)), dim3(256), WC_BLOCK_BYTES, st, a, tg, fixed,
                            fpart, mpart, queue);
         return NRT_OK;
@@ -497,18 +503,18 @@ int launch_wc_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, in
 
 template <int MODE, bool FILL>
 int launch_wc_fill(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, bool store, bool minmax, const float *fixed,
-                   float *fpart, float *mpart, unsigned *queue, hipStream_t st) {
-    if (store) return minmax ? launch_wc_inst<MODE, true, true, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, queue, st)
-                             : launch_wc_inst<MODE, true, false, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, queue, st);
-    return minmax ? launch_wc_inst<MODE, false, true, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, queue, st)
-                  : launch_wc_inst<MODE, false, false, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, queue, st);
+                   float *fpart, float *mpart, hipStream_t st) {
+    if (store) return minmax ? launch_wc_inst<MODE, true, true, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, st)
+                             : launch_wc_inst<MODE, true, false, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, st);
+    return minmax ? launch_wc_inst<MODE, false, true, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, st)
+                  : launch_wc_inst<MODE, false, false, FILL>(a, tg, nblocks, batch, fixed, fpart, mpart, st);
 }
 
 template <int MODE>
 int launch_wc_mode(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, bool store, bool minmax, const float *fixed,
-                   float *fpart, float *mpart, unsigned *queue, hipStream_t st) {
-    return a.has_fill ? launch_wc_fill<MODE, true>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st)
-                      : launch_wc_fill<MODE, false>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st);
+                   float *fpart, float *mpart, hipStream_t st) {
+    return a.has_fill ? launch_wc_fill<MODE, true>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st)
+                      : launch_wc_fill<MODE, false>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st);
 }
 
 // the wave-cache form applies to: 32 float32 labels, x-march geometry with 4 x 8 patches
@@ -521,40 +527,23 @@ inline bool wc_applies(const TileGeom &tg, int G, const InterpArgs &a) {
 // minmax: the caller wants the value range of both maps (check_input_limits); without it the kernel does not track it (the partial
 // rows then carry +-inf, which nothing reads)
 inline int launch_wc(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, int mode, bool store, bool minmax,
-                     const float *fixed, float *fpart, float *mpart, unsigned *queue, hipStream_t st) {
+                     const float *fixed, float *fpart, float *mpart, hipStream_t st) {
     switch (mode) {
-        case NRT_LOC_ABSOLUTE: return launch_wc_mode<NRT_LOC_ABSOLUTE>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st);
-        case NRT_LOC_SHIFT: return launch_wc_mode<NRT_LOC_SHIFT>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st);
-        default: return launch_wc_mode<NRT_LOC_LINSPACE>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, queue, st);
+        case NRT_LOC_ABSOLUTE: return launch_wc_mode<NRT_LOC_ABSOLUTE>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st);
+        case NRT_LOC_SHIFT: return launch_wc_mode<NRT_LOC_SHIFT>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st);
+        default: return launch_wc_mode<NRT_LOC_LINSPACE>(a, tg, nblocks, batch, store, minmax, fixed, fpart, mpart, st);
     }
 }
 
-// the warp alone through the same kernel (interpn.hip, variant 10): mixed block lengths, persistent blocks.  The work counters come
-// from a per-device ring of 64 sets (a launch takes the next one: launches that overlap on different streams do not share a set)
-// (so at most 64 launches of this kernel may be in flight or captured at a time; the ring is allocated once per device, under a lock,
-// and NOT during a stream capture -- hipMalloc fails there and the launch takes the non-persistent grid)
-inline unsigned *wc_queue_slot() {
-    static unsigned *ring[64];
-    static unsigned next[64];
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!ring[dev] && hipMalloc((void **)&ring[dev], 64 * NRT_NXCD * 64) != hipSuccess) { ring[dev] = nullptr; return nullptr; }
-    }
-    return ring[dev] + (size_t)(__atomic_fetch_add(&next[dev], 1u, __ATOMIC_RELAXED) % 64u) * (NRT_NXCD * 16);
-}
-
+// the warp alone through the same kernel (interpn.hip, variant 10): mixed block lengths, persistent blocks
 template <int MODE, bool FILL>
 int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, hipStream_t st) {
     const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
-    unsigned *queue = (items > slots) ? wc_queue_slot() : nullptr;
+    unsigned *queue = (items > slots) ? nrt_ring_slot() : nullptr;
     if (queue) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, true, false, FILL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WC_BLOCK_BYTES) != hipSuccess)
             return NRT_ERR_LAUNCH;
-        if (nrt_zero_async(queue, NRT_NXCD * 64, st) != hipSuccess) return NRT_ERR_LAUNCH;
         hipLaunchKernelGGL((warp_dice_wc<MODE, true, false, FILL, false, true>), dim3(nrt_xcd_grid(slots)), dim3(256), WC_BLOCK_BYTES, st, a, tg,
                            (const float *)nullptr, (float *)nullptr, (float *)nullptr, queue);
         return NRT_OK;

@@ -91,6 +91,10 @@ static inline hipError_t nrt_zero_async(void *p, size_t bytes, hipStream_t st) {
     return hipGetLastError();
 }
 
+// a slot of NRT_RING_WORDS zeroed device words for the atomic counters of ONE launch; the kernel's last block leaves it zeroed (api.hip)
+constexpr unsigned NRT_RING_SLOTS = 64, NRT_RING_WORDS = 256;
+unsigned *nrt_ring_slot();
+
 // compute units of the current device (persistent kernels size their grid with it)
 static inline int nrt_num_cus() {
     static int cached[64];

@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ['shard_range', 'PendingMean', 'all_reduce_mean_dice', 'mean_dice_pair', 'all_reduce_mean_pair', 'all_reduce_mean', 'reduce_dice_sums', 'dice_from_sums',
-           'all_reduce_gradients']
+           'all_reduce_gradients', 'GradientBucket']
 
 
 def _world(group=None):
@@ -175,13 +175,77 @@ def dice_from_sums(sums, laplace_smoothing=0.):
     return out
 
 
+class GradientBucket:
+    """
+    ONE flat float32 buffer that IS the gradient storage of a set of parameters: every `p.grad` is a view into it, so the
+    data-parallel step is `bucket.all_reduce()` -- one RCCL all-reduce of the whole buffer, no packing, no copy back, no allocation,
+    and therefore capturable into the same hipGraph as the step itself.  xGMI is point-to-point (7 links x ~153 GB/s): a ring
+    all-reduce of a small buffer is latency-bound, so a unet (a few MB of weights) goes out as one message.
+
+        bucket = GradientBucket(net.parameters())        # once, after the optimizer exists; p.grad now alias the bucket
+        loss.backward(); bucket.all_reduce(); opt.step(); bucket.zero_()
+
+    (The reference's only multi-device code is neurite/tf/utils/model.py:298-321, Keras multi_gpu_model.)  Autograd accumulates into
+    an existing .grad in place, so the views survive backward passes; `optimizer.zero_grad(set_to_none=True)` would drop them -- use
+    `bucket.zero_()` (or zero_grad(set_to_none=False)).
+    """
+
+    def __init__(self, params, group=None, average=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group, self.average = group, average
+        if not self.params:
+            raise ValueError('GradientBucket: no parameter requires a gradient')
+        dev = self.params[0].device
+        if any(p.device != dev for p in self.params):
+            raise ValueError('GradientBucket: all parameters must live on one device')
+        self.sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            view = self.flat[off:off + n].view_as(p)
+            if p.grad is not None:
+                view.copy_(p.grad.to(torch.float32))
+            if p.dtype != torch.float32:
+                raise ValueError('GradientBucket: float32 parameters only (got %s)' % p.dtype)
+            p.grad = view
+            off += n
+
+    def intact(self):
+        """every p.grad still aliases the bucket (False after zero_grad(set_to_none=True) or a re-assigned .grad)"""
+        off = 0
+        for p, n in zip(self.params, self.sizes):
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat.data_ptr() + 4 * off or g.numel() != n:
+                return False
+            off += n
+        return True
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def all_reduce(self, async_op=False):
+        """sum (average) over the ranks, in place; returns the number of collective calls issued (0 at world size 1) or, with
+        async_op, the work handle (None at world size 1)"""
+        rank, world = _world(self.group)
+        if world == 1:
+            return None if async_op else 0
+        if not self.intact():
+            raise RuntimeError('GradientBucket: a parameter gradient no longer aliases the bucket (zero_grad(set_to_none=True)?)')
+        if self.average:
+            # pre-divide: sum of g / W; one pass, and the collective's result needs no second kernel
+            self.flat.div_(world)
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return work if async_op else 1
+
+
 def all_reduce_gradients(params, group=None, bucket_mb=256, average=True):
     """
     Data-parallel training step of the conv stack: sum (or average) the gradients of `params` over the ranks.
     Gradients are packed into flat float32 buckets so that a unet (a few MB of weights) is ONE RCCL all-reduce --
     xGMI is point-to-point (7 links x ~153 GB/s), a ring all-reduce of a small buffer is latency-bound, so fewer and
     larger messages win; `bucket_mb` only matters for models larger than a bucket.  In place; returns the number of
-    all-reduce calls issued (0 at world size 1).
+    all-reduce calls issued (0 at world size 1).  This form packs and unpacks (three passes and an allocation per step): for a
+    training loop build a `GradientBucket` once instead -- the gradients then live in the flat buffer and nothing is copied.
     """
     rank, world = _world(group)
     grads = [p.grad for p in params if getattr(p, 'grad', None) is not None]

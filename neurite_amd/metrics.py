@@ -291,7 +291,7 @@ class JointSegLoss:
             if p.data_ptr() % 16 or t.data_ptr() % 16:
                 p, t = p.clone(), t.clone()
             lw = self.cce_obj.label_weights
-            w = None if lw is None else lw.to(p.device, torch.float32).contiguous()
+            w = None if lw is None else self.cce_obj._weights_on(p.device)
             cfg = (float(self.dice_obj.laplace_smoothing), float(self.cce_obj.label_smoothing), bool(self.dice_obj.check_input_limits))
             src = getattr(self.y_pred, '_nrt_softmax_src', None)
             JointSegLoss.applications += 1
@@ -517,6 +517,18 @@ class CategoricalCrossentropy:
     def __call__(self, y_true, y_pred, sample_weight=None):
         return self.cce(y_true, y_pred, sample_weight=sample_weight)
 
+    def _weights_on(self, dev):
+        """label_weights as a float32 tensor on `dev`, copied once per device (and again if the tensor was modified in place or replaced):
+        a host-resident weight vector used to cost one pageable host-to-device copy per call, more than the kernel at config 5's size."""
+        lw = self.label_weights
+        if lw is None:
+            return None
+        key = (str(dev), id(lw), lw._version)
+        if getattr(self, '_w_cache_key', None) != key:
+            self._w_cache = lw.detach().to(dev, torch.float32).contiguous()
+            self._w_cache_key = key
+        return self._w_cache
+
     def cce(self, y_true, y_pred, sample_weight=None):
         yf = y_pred.shape[-1]
         if self.label_weights is not None:
@@ -531,7 +543,7 @@ class CategoricalCrossentropy:
             raise NotImplementedError('CategoricalCrossentropy: float32 or bfloat16 inputs, got %s' % y_pred.dtype)
         p = y_pred.contiguous()
         t = y_true.to(p.dtype).contiguous()           # keras casts y_true to y_pred's dtype
-        w = None if self.label_weights is None else self.label_weights.to(dev, torch.float32).contiguous()
+        w = self._weights_on(dev)
         N = p.numel() // max(yf, 1)
         need_pv = sample_weight is not None or self.reduction == 'none'
         joint = None if need_pv else JointSegLoss.lookup(self, y_true, y_pred)

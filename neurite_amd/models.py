@@ -673,11 +673,26 @@ class SoftmaxSource:
     """
 
     def __init__(self, y, inputs, grads_from_dz):
-        self.inputs, self.grads_from_dz = tuple(inputs), grads_from_dz
+        self.inputs, self._grads_from_dz = tuple(inputs), grads_from_dz
         self.version = y._version
+        # the closure keeps the producer's inputs alive outside save_for_backward: the in-place check autograd would do is done here
+        self.input_versions = tuple(None if t is None else t._version for t in self.inputs)
 
     def valid_for(self, y):
-        return y._version == self.version and torch.is_grad_enabled() and y.requires_grad
+        """The shortcut replaces y's own autograd node: it must not be taken when somebody observes the gradient AT y (a hook on the
+        prediction, retain_grad) -- those would silently see nothing -- nor when y was modified since the producer wrote it."""
+        if y._version != self.version or not torch.is_grad_enabled() or not y.requires_grad:
+            return False
+        if y.retains_grad or getattr(y, '_backward_hooks', None):
+            return False
+        return True
+
+    def grads_from_dz(self, dz, needs):
+        for t, v in zip(self.inputs, self.input_versions):
+            if t is not None and t._version != v:
+                raise RuntimeError('neurite_amd: an input of the soft-max head was modified in place after the forward pass; its '
+                                   'gradient through the joint segmentation loss would be computed from the modified values')
+        return self._grads_from_dz(dz, needs)
 
 
 def _stamp_softmax(y, inputs, grads_from_dz):

@@ -59,6 +59,26 @@ def _worker(rank, world, port, q):
         ncalls = nd.all_reduce_gradients(params)
         gerr = max(float(np.abs(prm.grad.numpy() - ga.mean(0)).max()) for prm, ga in zip(params, g_all))
         ncalls2 = nd.all_reduce_gradients(params, bucket_mb=1e-4, average=False)     # tiny buckets: [216] and [4, 20] floats
+        # the persistent form: the gradients LIVE in one flat buffer (views), one collective, nothing packed or copied back
+        params_b = [torch.nn.Parameter(torch.zeros(ga.shape[1:])) for ga in g_all]
+        params_b[1].grad = torch.from_numpy(g_all[1][rank].copy())          # a gradient that exists already is adopted
+        bucket = nd.GradientBucket(params_b)
+        assert bucket.intact() and all(prm.grad.data_ptr() >= bucket.flat.data_ptr() for prm in params_b)
+        for k, (prm, ga) in enumerate(zip(params_b, g_all)):
+            if k != 1:
+                prm.grad += torch.from_numpy(ga[rank])                       # what backward() does: accumulate in place
+        ptrs = [prm.grad.data_ptr() for prm in params_b]
+        assert bucket.all_reduce() == 1
+        assert ptrs == [prm.grad.data_ptr() for prm in params_b] and bucket.intact()
+        gerr = max(gerr, max(float(np.abs(prm.grad.numpy() - ga.mean(0)).max()) for prm, ga in zip(params_b, g_all)))
+        bucket.zero_()
+        assert all(float(prm.grad.abs().max()) == 0.0 for prm in params_b)
+        params_b[0].grad = None
+        try:
+            bucket.all_reduce()
+            raise AssertionError('a dropped gradient view must be refused')
+        except RuntimeError:
+            pass
         q.put((rank, float(got), float(want), np.abs(tot.numpy() - full).max() / np.abs(full).max(),
                float(ce), float(npo.cce(t, p)), gerr, ncalls, ncalls2))
     finally:
@@ -96,6 +116,10 @@ def test_world1_is_identity():
     prm = torch.nn.Parameter(torch.zeros(3))
     prm.grad = torch.ones(3)
     assert nd.all_reduce_gradients([prm]) == 0 and torch.equal(prm.grad, torch.ones(3))
+    b = nd.GradientBucket([prm])
+    assert b.all_reduce() == 0 and b.all_reduce(async_op=True) is None and torch.equal(prm.grad, torch.ones(3)) and b.intact()
+    (prm * 2).sum().backward()                                   # autograd accumulates INTO the view
+    assert b.intact() and torch.equal(b.flat, torch.full((3,), 3.0))
 
 
 def _bench_worker(rank, world, port, q):
@@ -174,3 +198,41 @@ def test_bench_self_launches_its_ranks_cpu_stub():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--stub-step',
                         '--global-batch', '5'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280, text=True)
     assert p.returncode != 0 and not p.stdout.strip()
+
+
+def test_scaling_bookkeeping_worlds_1_2_4_8():
+    """What the driver's N = 1, 2, 4, 8 runs will divide: BASELINE config 4 (`--global-batch 32`, strong) keeps 32 volumes in total with
+    32 / N per rank; the default (weak) keeps 4 per rank; the shard of rank r is the contiguous range batch entry b -> rank b * W // B,
+    every entry exactly once; a batch the ranks do not divide is refused."""
+    import bench
+    from neurite_amd import distributed as nd
+    for world in (1, 2, 4, 8):
+        per, total, scaling = bench.batch_plan(32, 4, world)
+        assert (per, total, scaling) == (32 // world, 32, 'strong')
+        assert bench.batch_plan(0, 4, world) == (4, 4 * world, 'weak')
+        seen = []
+        for rank in range(world):
+            lo, hi = nd.shard_range(32, rank, world)
+            assert hi - lo == per
+            seen += list(range(lo, hi))
+            assert all(b * world // 32 == rank for b in range(lo, hi))
+        assert seen == list(range(32))
+    with pytest.raises(SystemExit):
+        bench.batch_plan(32, 4, 3)
+
+
+@pytest.mark.timeout(300)
+def test_bench_strong_mode_world4_cpu_stub():
+    """the strong-scaling line of a 4-rank run (self-launched, gloo, stub step): global batch 32, 8 volumes per rank"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'NRT_BENCH_CHILD')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1', '--stub-step',
+                        '--global-batch', '32'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 4 and j['rccl_ranks'] == 4 and j['scaling'] == 'strong'
+    assert j['config']['volumes_per_gpu'] == 8 and j['config']['global_batch'] == 32
+    assert abs(j['config']['mean_dice'] - 2.5) < 1e-6                  # mean of the ranks' constants 1, 2, 3, 4

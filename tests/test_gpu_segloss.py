@@ -186,6 +186,57 @@ def test_decorator_pairs_dice_and_cce_through_the_unet_head(dev):
     np.testing.assert_allclose(float(v), float(separate), rtol=2e-6)
 
 
+def test_observers_of_the_prediction_keep_their_gradient(dev):
+    """the through-soft-max shortcut replaces the prediction's own autograd node, so it must step aside when somebody
+    watches the gradient AT the prediction -- a hook, retain_grad -- (they used to receive nothing) and must refuse inputs that were
+    modified in place after the forward pass (the closure holds them outside save_for_backward)."""
+    rng = np.random.default_rng(11)
+    L, B = 4, 1
+    net = _small_unet(dev, rng, L)
+    x = G(rng.standard_normal((B, 16, 8, 16, 1)).astype(F), dev)
+    t = G(np.eye(L, dtype=F)[rng.integers(0, L, (B, 16, 8, 16))], dev)
+    cce = ne.losses.CategoricalCrossentropy(rng.uniform(0.5, 2, L).astype(F))
+    dice = ne.losses.Dice(laplace_smoothing=0.01)
+    joint = ne.losses.multiple_losses_decorator([cce.loss, dice.mean_loss], [1.0, 2.0])
+
+    y = net(x)
+    (1.0 * cce.loss(t, y) + 2.0 * dice.mean_loss(t, y)).backward()
+    want = {k: m.kernel.grad.clone() for k, m in net.layers_by_name.items()}
+    net.zero_grad()
+
+    # a hook on the prediction: called with the gradient wrt the probabilities; the joint FORWARD kernel still runs
+    seen = []
+    y = net(x)
+    y.register_hook(lambda g: seen.append(g.clone()))
+    before = (MT.JointSegLoss.applications, MT.JointSegLoss.through_softmax)
+    joint(t, y).backward()
+    assert (MT.JointSegLoss.applications, MT.JointSegLoss.through_softmax) == (before[0] + 1, before[1])
+    assert len(seen) == 1 and seen[0].shape == y.shape and float(seen[0].abs().max()) > 0
+    for k, m in net.layers_by_name.items():
+        close(N(m.kernel.grad), N(want[k]).astype(np.float64), k + ' kernel (hook)', 2e-5)
+    net.zero_grad()
+
+    # retain_grad and autograd.grad(loss, y)
+    y = net(x)
+    y.retain_grad()
+    loss = joint(t, y)
+    (gy,) = torch.autograd.grad(loss, y, retain_graph=True)
+    loss.backward()
+    np.testing.assert_array_equal(N(y.grad), N(gy))
+    np.testing.assert_allclose(N(gy), N(seen[0]), rtol=1e-6, atol=1e-9)
+    net.zero_grad()
+
+    # an input of the head modified in place between forward and backward: refused, not silently differentiated
+    y = net(x)
+    src = y._nrt_softmax_src
+    loss = joint(t, y)
+    with torch.no_grad():
+        src.inputs[1].mul_(1.0)                                  # the head's kernel: same values, new version
+    with pytest.raises(RuntimeError, match='modified in place'):
+        loss.backward()
+    net.zero_grad()
+
+
 def test_decorator_leaves_other_cases_alone(dev):
     rng = np.random.default_rng(9)
     before = MT.JointSegLoss.applications

@@ -88,3 +88,40 @@ def test_residual_tail_conv_has_no_dilation_and_no_activation():
     assert g['unet_conv_downarm_1_1']['config']['activation'] == 'linear'
     assert g['unet_conv_uparm_3_1']['config']['dilation_rate'] == [1, 1, 1]
     assert g['unet_expand_down_merge_2']['config']['dilation_rate'] == [4, 4, 4]
+
+
+# variables a Keras layer owns, in `layer.weights` order (Conv*: kernel[, bias]; BatchNormalization with the reference's defaults
+# center = scale = True: gamma, beta, moving_mean, moving_variance)
+def _keras_variables(layer):
+    if layer['class'] in ('Conv1D', 'Conv2D', 'Conv3D'):
+        return ['kernel'] + (['bias'] if layer['config'].get('use_bias', True) else [])
+    if layer['class'] == 'BatchNormalization':
+        return ['gamma', 'beta', 'moving_mean', 'moving_variance']
+    return []
+
+
+@pytest.mark.parametrize('tag', sorted(GRAPHS))
+def test_npz_keys_are_the_keras_variable_names(tag, tmp_path):
+    """f-3 without h5py: what can be pinned of the Keras weight import.  tools/export_keras_weights.py stores
+    `model.get_weights()` under `layer.name/variable` on the TensorFlow side; the archive our `load_weights` wants must have exactly
+    those keys in exactly that order for every graph recorded from the reference's builders (neurite/tf/modelio.py:111-143 is what the
+    pair replaces).  A save -> load round trip through an archive WRITTEN UNDER THE RECORDED NAMES closes the loop on this side."""
+    import numpy as np
+    case = GRAPHS[tag]
+    expected = ['%s/%s' % (l['name'], v) for l in case['graph']['layers'] for v in _keras_variables(l)]
+    net = _build(case)
+    ours = [n for n, _, _ in net._weight_tensors()]
+    assert ours == expected
+    # an archive keyed by the recorded Keras names, filled with recognisable values, loads into the network slot by slot
+    rng = np.random.default_rng(3)
+    arrays = {}
+    for n, t, nd in net._weight_tensors():
+        shape = tuple(t.shape)
+        if nd is not None and nd < 3:
+            shape = shape[3 - nd:]                     # Conv1D / Conv2D kernels are stored with their own rank in Keras
+        arrays[n] = rng.standard_normal(shape).astype(np.float32)
+    path = str(tmp_path / 'keras_export.npz')
+    np.savez(path, **{k: arrays[k] for k in expected})
+    net.load_weights(path)
+    for (n, t, nd), w in zip(net._weight_tensors(), net.get_weights()):
+        np.testing.assert_array_equal(np.asarray(w).reshape(arrays[n].shape), arrays[n], err_msg=n)
