@@ -41,29 +41,33 @@ template <> struct Quad<unsigned short> {
 };
 
 // The sum of the block partials, by the LAST block of the same launch (round 5; a second launch cost more than it computed at
-// config 5's 53 MB: three launches -- zero, kernel, finalize -- for 10 us of streaming).  A block publishes its partial, fences and
-// takes a ticket from a self-cleaning counter (api.hip: nrt_ring_slot); the block that draws the last ticket adds the partials in a
-// FIXED order in float64 (what wcce_finalize did: run-to-run bit-identical) and zeroes the counter for the slot's next launch.
+// config 5's 53 MB).  A block publishes its partial with a device-scope store (sc1: written through, the eight XCDs have their own
+// L2s), waits for the acknowledgement and takes a ticket from a self-cleaning counter (api.hip: nrt_ring_slot); the block that
+// draws the last ticket reads the partials with device-scope loads and adds them in a FIXED order in float64 (what wcce_finalize
+// did: run-to-run bit-identical), then zeroes the counter for the slot's next launch.  NOT __threadfence(): at agent scope it is
+// buffer_wbl2 + buffer_inv -- every block invalidating its XCD's L2 under the other blocks' streams cost 35 us at config 5.
 struct WcceFin { float *loss_sum; unsigned *counter; };
-__device__ __forceinline__ void wcce_finish(const float *part, const WcceFin &fin) {
+__device__ __forceinline__ void wcce_finish(float *part, float block_sum, const WcceFin &fin) {
     __shared__ bool s_last;
     __shared__ double s_acc[CCE_BLOCK];
     if (threadIdx.x == 0) {
-        __threadfence();                                       // the partial is visible device-wide (the XCDs have their own L2s) ...
-        s_last = atomicAdd(fin.counter, 1u) == gridDim.x - 1;  // ... before the ticket says so
+        __hip_atomic_store(part + blockIdx.x, block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);                         // the store is acknowledged ...
+        asm volatile("" ::: "memory");
+        s_last = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;   // ... before the ticket says so
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     double a = 0.0;
-    for (unsigned k = threadIdx.x; k < gridDim.x; k += CCE_BLOCK) a += (double)__builtin_nontemporal_load(part + k);
+    for (unsigned k = threadIdx.x; k < gridDim.x; k += CCE_BLOCK)
+        a += (double)__hip_atomic_load(part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_acc[threadIdx.x] = a;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < CCE_BLOCK; ++i) t += s_acc[i];      // fixed order
         fin.loss_sum[0] = (float)t;
-        *fin.counter = 0u;
+        __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -137,12 +141,12 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ y
     __shared__ float red[CCE_BLOCK / NRT_WAVE];
     if ((threadIdx.x & (NRT_WAVE - 1)) == 0) red[threadIdx.x / NRT_WAVE] = acc;
     __syncthreads();
+    float bsum = 0.0f;
     if (threadIdx.x == 0) {
-        float s = red[0];
-        for (int i = 1; i < CCE_BLOCK / NRT_WAVE; ++i) s += red[i];
-        part[blockIdx.x] = s;
+        bsum = red[0];
+        for (int i = 1; i < CCE_BLOCK / NRT_WAVE; ++i) bsum += red[i];
     }
-    wcce_finish(part, fin);
+    wcce_finish(part, bsum, fin);
 }
 
 // any C: one thread per voxel
@@ -212,12 +216,12 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_generic(const void *__restrict
     __shared__ float red[CCE_BLOCK / NRT_WAVE];
     if ((threadIdx.x & (NRT_WAVE - 1)) == 0) red[threadIdx.x / NRT_WAVE] = acc;
     __syncthreads();
+    float bsum = 0.0f;
     if (threadIdx.x == 0) {
-        float s = red[0];
-        for (int i = 1; i < CCE_BLOCK / NRT_WAVE; ++i) s += red[i];
-        part[blockIdx.x] = s;
+        bsum = red[0];
+        for (int i = 1; i < CCE_BLOCK / NRT_WAVE; ++i) bsum += red[i];
     }
-    wcce_finish(part, fin);
+    wcce_finish(part, bsum, fin);
 }
 
 bool vec_channels(int C) { return C % 4 == 0 && C >= 4 && C <= 256; }       // lane-groups of the next power of two >= C / 4 lanes

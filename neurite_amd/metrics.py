@@ -128,28 +128,33 @@ class _SoftDiceFn(torch.autograd.Function):
         return gt, gp, None, None, None
 
 
+def _wcce_launch(t, p, w, from_logits, label_smoothing, per_voxel):
+    """one launch of the weighted-CCE kernel: the sum of the per-voxel losses [1], or the per-voxel losses"""
+    lib = _lib.lib()
+    dev = p.device
+    yf = p.shape[-1]
+    N = p.numel() // max(yf, 1)
+    loss_sum = torch.empty((1,), dtype=torch.float32, device=dev)
+    pv = torch.empty(p.shape[:-1], dtype=torch.float32, device=dev) if per_voxel else None
+    nws = lib.nrt_wcce_workspace_bytes(N, yf)
+    ws = _lib.workspace(dev, nws)
+    dt = _lib.DT_F32 if p.dtype == torch.float32 else _lib.DT_BF16
+    with torch.cuda.device(dev):
+        rc = lib.nrt_wcce(_lib.ptr(t), _lib.ptr(p), dt, _lib.ptr(w), N, yf, int(from_logits),
+                          float(label_smoothing), _lib.ptr(loss_sum), _lib.ptr(pv), _lib.ptr(ws), nws,
+                          _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_wcce')
+    return pv if per_voxel else loss_sum
+
+
 class _WcceFn(torch.autograd.Function):
     """Weighted CCE: returns (sum of the per-voxel losses [1]) or the per-voxel losses; backward wrt y_pred."""
 
     @staticmethod
     def forward(ctx, t, p, w, from_logits, label_smoothing, per_voxel):
-        lib = _lib.lib()
-        dev = p.device
-        yf = p.shape[-1]
-        N = p.numel() // max(yf, 1)
-        loss_sum = torch.empty((1,), dtype=torch.float32, device=dev)
-        pv = torch.empty(p.shape[:-1], dtype=torch.float32, device=dev) if per_voxel else None
-        nws = lib.nrt_wcce_workspace_bytes(N, yf)
-        ws = _lib.workspace(dev, nws)
-        dt = _lib.DT_F32 if p.dtype == torch.float32 else _lib.DT_BF16
-        with torch.cuda.device(dev):
-            rc = lib.nrt_wcce(_lib.ptr(t), _lib.ptr(p), dt, _lib.ptr(w), N, yf, int(from_logits),
-                              float(label_smoothing), _lib.ptr(loss_sum), _lib.ptr(pv), _lib.ptr(ws), nws,
-                              _lib.stream_ptr(dev))
-        _lib.check(rc, 'nrt_wcce')
         ctx.save_for_backward(t, p, w)
         ctx.cfg = (from_logits, label_smoothing, per_voxel)
-        return pv if per_voxel else loss_sum
+        return _wcce_launch(t, p, w, from_logits, label_smoothing, per_voxel)
 
     @staticmethod
     def backward(ctx, grad):
@@ -547,7 +552,12 @@ class CategoricalCrossentropy:
         N = p.numel() // max(yf, 1)
         need_pv = sample_weight is not None or self.reduction == 'none'
         joint = None if need_pv else JointSegLoss.lookup(self, y_true, y_pred)
-        res = joint.result()[0] if joint is not None else _WcceFn.apply(t, p, w, self.from_logits, self.label_smoothing, need_pv)
+        if joint is not None:
+            res = joint.result()[0]
+        elif torch.is_grad_enabled() and (p.requires_grad or t.requires_grad):
+            res = _WcceFn.apply(t, p, w, self.from_logits, self.label_smoothing, need_pv)
+        else:
+            res = _wcce_launch(t, p, w, self.from_logits, self.label_smoothing, need_pv)     # nothing to differentiate: no autograd node
         if not need_pv:
             return res[0] if self.reduction == 'sum' else res[0] / N
         losses = res
