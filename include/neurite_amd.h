@@ -304,6 +304,21 @@ int nrt_conv3d_up2_pack_weights_f32(const float *weights, int c0, int c1, int co
 int nrt_conv3d_up2_f32(const float *skip /* [batch, shape, c0] */, int c0, const float *lo /* [batch, shape/2, c1] */, int c1,
                        const float *packed_weights, const float *bias, float *out, int batch, const int *shape, int cout,
                        int activation, void *stream);
+/*
+ * The LAST decoder convolution of models.unet with the network's head folded in (neurite/tf/models.py:1545-1555 the convolution,
+ * :1596 the 1x1x1 "likelihood" convolution, :1601-1605 the channel soft-max): out = softmax(act(conv_up2(skip, lo)) @ head_weights
+ * + head_bias) [batch, shape, labels]; the 16-channel feature tensor between the two convolutions is never written.  Inference
+ * only (the backward of a training step needs that tensor).  cout == 16, labels 16 or 32, shape a multiple of (4, 4, 16), c0 < c1;
+ * the head's kernel packed by nrt_conv3d_up2_head_pack_f32 (Keras layout [16, labels] -> 16 * labels floats in matrix-core
+ * fragment order), both head arrays 16-byte aligned.  Same values as nrt_conv3d_up2_f32 followed by nrt_conv1x1_softmax_f32 up
+ * to the float32 summation order of the 16-term head products.
+ */
+int nrt_conv3d_up2_head_supported(int c0, int c1, int cout, int labels, const int *shape);
+int nrt_conv3d_up2_head_pack_f32(const float *head_weights /* [16, labels] */, int labels, float *packed /* [16 * labels] */, void *stream);
+int nrt_conv3d_up2_head_f32(const float *skip, int c0, const float *lo, int c1, const float *packed_weights, const float *bias,
+                            const float *packed_head_weights, const float *head_bias /* [labels] */, int labels,
+                            float *out /* [batch, shape, labels] */, int batch, const int *shape, int cout, int activation,
+                            void *stream);
 
 /*
  * Backward of the folded decoder convolution with respect to its low-resolution input (what tf.GradientTape derives through

@@ -64,6 +64,9 @@ _SIGNATURES = {
     'nrt_conv3d_up2_packed_weight_floats': (_sz, [_i, _i, _i]),
     'nrt_conv3d_up2_pack_weights_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),
     'nrt_conv3d_up2_f32': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _ip, _i, _i, _vp]),
+    'nrt_conv3d_up2_head_supported': (_i, [_i, _i, _i, _i, _ip]),
+    'nrt_conv3d_up2_head_pack_f32': (_i, [_vp, _i, _vp, _vp]),
+    'nrt_conv3d_up2_head_f32': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _ip, _i, _i, _vp]),
     'nrt_space_to_depth2_f32': (_i, [_vp, _vp, _i, _ip, _i, _vp]),
     'nrt_conv3d_s2d_taps_f32': (_i, [_vp, _i, _vp, _vp, _i, _ip, _i, _vp]),
     'nrt_conv1x1_softmax_f32': (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _vp]),

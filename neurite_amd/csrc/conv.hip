@@ -1006,6 +1006,38 @@ extern "C" int nrt_conv3d_up2_f32(const float *skip, int c0, const float *lo, in
     }
 }
 
+extern "C" int nrt_conv3d_up2_head_supported(int c0, int c1, int cout, int labels, const int *shape) {
+    if (!shape) return 0;
+    ConvArgs a;
+    const int k3[3] = {3, 3, 3}, up[3] = {2, 2, 2};
+    float dummy;
+    if (conv_args(a, &dummy, c0, &dummy, c1, up, nullptr, &dummy, shape, k3, cout, 1, 1, ACT_NONE) != NRT_OK) return 0;
+    return up2_head_ok(a, labels) ? 1 : 0;
+}
+
+extern "C" int nrt_conv3d_up2_head_pack_f32(const float *head_weights, int labels, float *packed, void *stream) {
+    if (!head_weights || !packed || (labels != 16 && labels != 32)) return NRT_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(conv3d_pack_head_up2, dim3(2), dim3(256), 0, nrt_stream(stream), head_weights, labels, packed);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_conv3d_up2_head_f32(const float *skip, int c0, const float *lo, int c1, const float *packed_weights, const float *bias,
+                                       const float *head_weights, const float *head_bias, int labels, float *out, int batch,
+                                       const int *shape, int cout, int activation, void *stream) {
+    ConvArgs a;
+    const int k3[3] = {3, 3, 3}, up[3] = {2, 2, 2};
+    int rc = conv_args(a, skip, c0, lo, c1, up, bias, out, shape, k3, cout, 1, 1, activation);
+    if (rc != NRT_OK) return rc;
+    if (!packed_weights || !head_weights || !head_bias || batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if ((((uintptr_t)head_weights) | ((uintptr_t)head_bias)) & 15) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_LAST_FUSED) return NRT_ERR_INVALID_ARG;
+    if (!up2_head_ok(a, labels)) return NRT_ERR_UNSUPPORTED;
+    const U2Head head = {head_weights, head_bias, labels};
+    hipStream_t st = nrt_stream(stream);
+    return labels == 16 ? launch_up2<1, 1>(a, packed_weights, batch, st, head) : launch_up2<1, 2>(a, packed_weights, batch, st, head);
+}
+
 extern "C" int nrt_space_to_depth2_f32(const float *x, float *y, int batch, const int *shape, int channels, void *stream) {
     if (!x || !y || !shape || batch < 1 || batch > 65535 || channels < 4 || channels % 4) return NRT_ERR_INVALID_ARG;
     if (shape[0] < 2 || shape[1] < 2 || shape[2] < 2 || shape[0] % 2 || shape[1] % 2 || shape[2] % 2) return NRT_ERR_INVALID_ARG;

@@ -23,6 +23,14 @@
 // The outputs of a tile are kept in registers and stored behind the first DMA of the NEXT tile; a block never drains.
 // All vector-memory instructions are inline asm in a fixed order with hand-counted s_waitcnt vmcnt(N) immediates (vmcnt
 // retires in order; the compiler would have to wait for the DMA whenever it waits for a weight fragment).
+//
+// HNT > 0 (round 5): the LAST decoder convolution with the network's head folded in -- models.py:1596-1605, the 1 x 1 x 1 "likelihood"
+// convolution to 16 HNT labels and the channel soft-max.  The tile's 16 activated feature channels never leave the block: while the
+// next tile's first chunk is landing, each wave transposes its four 16 x 16 accumulator tiles through (its own 5 KB of) the idle
+// skip-halo buffer into A-operand order, multiplies them by the head's [16, 16 HNT] matrix on the matrix cores (4 HNT MFMAs per
+// tile of 16 voxels), takes the soft-max across the 16 lanes x HNT registers that hold a voxel's labels (DPP row rotations) and
+// stores the probabilities in the deferred-store slot.  Saved at 160^3 x 16 -> 32: the 262 MB feature tensor written and read back,
+// and the head kernel itself (0.167 ms of a 1.78 ms forward).  Inference only: training needs the feature tensor for the backward.
 
 constexpr int U2_SY = 2 * 9 * LDS_ROW + 8, U2_SX = 6 * U2_SY;        // skip halo: [6][6][parity][9] rows, y-stride padded (floats)
 constexpr int U2_SYA = 10 * LDS_ROW + 24, U2_SXA = 4 * U2_SYA;       // low-resolution halo: [4][4][10] rows
@@ -52,6 +60,23 @@ __device__ __forceinline__ f32x4 u2_ldw(const void *sbase, unsigned voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase));
     return r;
 }
+// The same load with five wait states in front: an SGPR written by a VALU instruction (v_readlane: that is how the compiler brings back a
+// spilled scalar) may not be the address of a vector-memory instruction for five cycles, and the compiler cannot see that the asm
+// statement is one.  The head's pointers are used twice per tile, long after they were loaded: in the 16-label instantiation they came
+// back from their spill lanes right in front of the load and it faulted on a garbage address.  (The weight-fragment loads of the
+// chunks take SALU-computed bases; twice per tile the nops cost nothing.)
+__device__ __forceinline__ f32x4 u2_ldw_s(const void *sbase, unsigned voff) {
+    f32x4 r;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase));
+    return r;
+}
+// (s_nop on both sides: a vector-memory store of more than 64 bits reads its data registers over several cycles -- a VALU instruction
+// may neither have written them in the two cycles before nor overwrite them in the two cycles after.  The compiler's hazard recogniser
+// keeps those distances for its own stores and cannot see into an asm statement: without the nops the first component of the
+// quadruple reached memory corrupted in a few lanes, differently from run to run.)
+__device__ __forceinline__ void u2_store4(const void *sbase, unsigned voff, f32x4 v) {
+    asm volatile("s_nop 1\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ void u2_store(const void *sbase, unsigned voff, float v) {
     asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
@@ -73,9 +98,22 @@ __host__ __device__ constexpr int u2_newer(int s, int P, int F, int D, int S, in
     return (hi - s) * F;
 }
 
-template <int NT>
+__device__ __forceinline__ float u2_row_ror(float v, const int n) {      // v of lane (i + n) % 16 inside each row of 16 lanes
+    switch (n) {
+        case 8: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+        case 4: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));
+        case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));
+        default: return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+    }
+}
+
+struct U2Head { const float *w, *bias; int labels; };     // the 1x1x1 head: kernel in fragment order [labels / 16][64 lanes][4], bias [labels]
+
+template <int NT, int HNT = 0>
 __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void conv3d_up2_mfma(ConvArgs a, const float *__restrict__ wpacked, const float *__restrict__ zeros,
-                                                       unsigned ntiles, unsigned nbx, unsigned nby, unsigned nbz) {
+                                                       unsigned ntiles, unsigned nbx, unsigned nby, unsigned nbz, U2Head head) {
+    static_assert(HNT == 0 || NT == 1, "the folded head takes the 16 feature channels of one N-tile");
+    constexpr int OC = HNT ? 16 * HNT : 0;                              // output channels per voxel when the head is folded in
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -134,9 +172,10 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void conv3d_up2_mfma(ConvArgs
         T.x0 = bx * CT_X; T.y0 = by * CT_Y; T.z0 = bz * CT_Z;
         T.pB = a.src0 + ((long long)b * a.X * a.Y * a.Z + ((long long)T.x0 * a.Y + T.y0) * a.Z + T.z0) * a.c0;
         T.pA = a.src1 + ((long long)b * a.X1 * a.Y1 * a.Z1 + ((long long)(T.x0 >> 1) * a.Y1 + (T.y0 >> 1)) * a.Z1 + (T.z0 >> 1)) * a.c1;
-        T.out = (unsigned)((((long long)b * a.OX + T.x0) * a.OY + T.y0) * a.OZ + T.z0) * (unsigned)a.Cout * 4u;
-        T.full = T.x0 + CT_X <= a.OX && T.y0 + CT_Y <= a.OY && T.z0 + CT_Z <= a.OZ && (a.Cout & 15) == 0 &&
-                 NT <= U2_DEFER_MAXNT;                                  // 16 NT deferred stores must fit the 6-bit vmcnt with the loads around them
+        T.out = (unsigned)((((long long)b * a.OX + T.x0) * a.OY + T.y0) * a.OZ + T.z0) * (unsigned)(HNT ? OC : a.Cout) * 4u;
+        T.full = HNT ? 1u : (T.x0 + CT_X <= a.OX && T.y0 + CT_Y <= a.OY && T.z0 + CT_Z <= a.OZ && (a.Cout & 15) == 0 &&
+                 NT <= U2_DEFER_MAXNT);                                 // 16 NT deferred stores must fit the 6-bit vmcnt with the loads around them
+                                                                        // (head folded in: launch_up2_head only takes volumes of whole tiles)
         const bool inner = T.x0 >= 1 && T.y0 >= 1 && T.z0 >= 1 && T.x0 + CT_X + 1 <= a.X && T.y0 + CT_Y + 1 <= a.Y && T.z0 + CT_Z + 1 <= a.Z;
         T.okB = validB; T.okA = validA;
         if (!inner) {
@@ -173,25 +212,90 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void conv3d_up2_mfma(ConvArgs
     float bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bv[nt] = (a.bias && nt * 16 + li < a.Cout) ? a.bias[nt * 16 + li] : 0.0f;
+    // the head's fragments: step s of the 16-channel contraction takes channels 4 kq + s (so that a lane's four feature values are ONE
+    // ds_read_b128), rows = labels 16 j + li.  They are (re)loaded at the top of the chunk that runs the head -- asm loads issued
+    // BEFORE that chunk's weight fragments, so the hand-counted waits behind them are unchanged -- and are dead everywhere else: held
+    // across the skip chunk (108 fragment registers) they pushed the 32-label kernel over 256 registers
+    constexpr int HN = HNT ? HNT : 1;
+    f32x4 hw[HN], hb[HN];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bv[nt]));      // the only compiler-visible load: settled here
-
+    auto head_request = [&]() __attribute__((always_inline)) {
+        if constexpr (HNT != 0) {
+#pragma unroll
+            for (int j = 0; j < HN; ++j) {
+                // (whole 16-byte registers straight from the asm loads: a value assembled from four scalar loads is COPIED by the
+                // compiler right behind the load instructions, before the data is there -- the first version of this did that)
+                hw[j] = u2_ldw_s(head.w, (unsigned)((j * 64 + lane) * 16));                              // fragment order (nrt_conv3d_up2_head_pack_f32)
+                hb[j] = u2_ldw_s(head.bias, (unsigned)((16 * j + 4 * kq) * 4));                          // labels 16 j + 4 kq .. + 3: this lane's rows
+            }
+        }
+    };
     f32x4 acc[4][NT];
     float outv[4][NT][4];                                               // the previous tile's outputs until they are stored
     unsigned outBase = 0;
     bool pending = false;
     // output offsets of this lane inside a tile (bytes): rows = (y pair member, z of the parity), columns = channels
-    const unsigned oY = (unsigned)a.OZ * a.Cout * 4u, oX = (unsigned)a.OY * oY;
-    const unsigned outLane = px * oX + (py + 2 * (kq >> 1)) * oY + (2 * (kq & 1) * 4) * (unsigned)a.Cout * 4u + li * 4u;
+    const unsigned ocb = (unsigned)(HNT ? OC : a.Cout) * 4u;            // bytes of an output voxel's row
+    const unsigned oY = (unsigned)a.OZ * ocb, oX = (unsigned)a.OY * oY;
+    const unsigned outLane = px * oX + (py + 2 * (kq >> 1)) * oY + (2 * (kq & 1) * 4) * ocb + li * 4u;
+    // the head's scratch: 4 x [16 voxels][20 floats] per wave at the start of the skip-halo buffer, which nobody reads between the
+    // last chunk of a tile (a B chunk) and the DMA of the next tile's first B chunk -- the head runs inside that window
+    float *hscr = &lds[w * 4 * 16 * LDS_ROW];
+    static_assert(4 * 4 * 16 * LDS_ROW <= U2_B_FLOATS, "head scratch fits the skip-halo buffer");
     auto stores = [&]() __attribute__((always_inline)) {
+        if constexpr (HNT == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    u2_store(a.out, outBase + outLane + 2 * (mt & 1) * oX + (2 * r + (mt >> 1)) * (unsigned)a.Cout * 4u + nt * 64u,
-                             outv[mt][nt][r]);
+                    for (int r = 0; r < 4; ++r)
+                        u2_store(a.out, outBase + outLane + 2 * (mt & 1) * oX + (2 * r + (mt >> 1)) * ocb + nt * 64u, outv[mt][nt][r]);
+        } else {
+            // features [voxel 4 kq + r][channel li] -> LDS rows of 20 floats -> fragments [voxel li][channels 4 kq .. 4 kq + 3]
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hscr[(mt * 16 + 4 * kq + r) * LDS_ROW + li] = outv[mt][0][r];
+            // logits TRANSPOSED: D[label 16 j + 4 kq + r][voxel li] = sum_c W[c][label] Y[voxel][c] -- the head's matrix is the A operand,
+            // the features the B operand.  A voxel's labels then sit in 4 HN registers of the 4 lanes li, li + 16, li + 32, li + 48:
+            // the soft-max is 4 HN - 1 in-lane operations and two cross-row steps instead of a 16-lane reduction per row (a third of
+            // the VALU work), and a lane's four labels are consecutive in memory: one 16-byte store
+            const unsigned outLaneT = px * oX + (py + 2 * (li >> 3)) * oY + 2 * (li & 7) * ocb + 16u * kq;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                // (one tile at a time: the stores below are asm with a memory clobber, so the read of tile mt + 1 stays behind them
+                // and the four fragments are never live together -- the kernel sits at the 256-register limit of two blocks per CU)
+                const f32x4 ya = *(const f32x4 *)&hscr[(mt * 16 + li) * LDS_ROW + 4 * kq];
+                f32x4 d[HN];
+#pragma unroll
+                for (int j = 0; j < HN; ++j) d[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                    for (int j = 0; j < HN; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hw[j][sidx], ya[sidx], d[j], 0, 0, 0);
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < HN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { d[j][r] += hb[j][r]; m = fmaxf(m, d[j][r]); }
+                m = fmaxf(m, __shfl_xor(m, 16, NRT_WAVE));
+                m = fmaxf(m, __shfl_xor(m, 32, NRT_WAVE));
+                float se = 0.0f;
+#pragma unroll
+                for (int j = 0; j < HN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { d[j][r] = softmax_exp(d[j][r] - m); se += d[j][r]; }
+                se += __shfl_xor(se, 16, NRT_WAVE);
+                se += __shfl_xor(se, 32, NRT_WAVE);
+                const float inv = softmax_rcp(se);
+#pragma unroll
+                for (int j = 0; j < HN; ++j)
+                    u2_store4(a.out, outBase + outLaneT + 2 * (mt & 1) * oX + (mt >> 1) * ocb + j * 64u,
+                              (f32x4){d[j][0] * inv, d[j][1] * inv, d[j][2] * inv, d[j][3] * inv});
+            }
+        }
     };
 
     const unsigned wlane = lane * 16u;
@@ -210,10 +314,18 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void conv3d_up2_mfma(ConvArgs
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bq[q][pz][nt] = u2_ldw(wp + ((q * 2 + pz) * NT + nt) * 1024, wlane);
         };
+        if (S) head_request();
 #pragma unroll
         for (int q = 0; q < P; ++q) request(q);
         issue_next();
-        if (S) stores();
+        if (S) {
+            if constexpr (HNT != 0) {                                    // the head's fragments: everything issued behind them may stay in flight
+                u2_wait<P * F + D>(hw[0]);
+#pragma unroll
+                for (int j = 0; j < HN; ++j) { u2_tie(hw[j]); u2_tie(hb[j]); }
+            }
+            stores();
+        }
         const float *abase = &lds[U2_OFF_A + buf * U2_A_FLOATS + px * U2_SXA + (py + iy) * U2_SYA + iz * LDS_ROW + 4 * kq];
         f32x4 avq[2][4];
         auto read = [&](int s) __attribute__((always_inline)) {
@@ -294,7 +406,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void conv3d_up2_mfma(ConvArgs
     using I0 = std::integral_constant<int, 0>;
     using IA = std::integral_constant<int, U2_NDA>;
     using IB = std::integral_constant<int, U2_NDB>;
-    using IS = std::integral_constant<int, 16 * NT>;
+    using IS = std::integral_constant<int, HNT ? 4 * HNT : 16 * NT>;
 
     Tile cur = decode(tile);
     unsigned aIss = 0, aUse = 0;                                        // A chunks requested / consumed: buffer = count & 1
@@ -372,7 +484,15 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void conv3d_up2_mfma(ConvArgs
         tile = ntile;
         cur = nxt;
     }
-    if (pending) stores();
+    if (pending) {
+        if constexpr (HNT != 0) {
+            head_request();
+            u2_chunk_barrier();                                         // (vmcnt(0):) the fragments are here, and the last tile's skip halo has been
+#pragma unroll
+            for (int j = 0; j < HN; ++j) { u2_tie(hw[j]); u2_tie(hb[j]); }       // read by every wave: it becomes the scratch
+        }
+        stores();
+    }
 }
 
 // folded + fragment-ordered weights of conv3d_up2_mfma:
@@ -409,6 +529,14 @@ __global__ void conv3d_pack_weights_up2(const float *__restrict__ w, int c0, int
     }
 }
 
+// head kernel [16][labels] (Keras layout) -> fragment order [labels / 16][lane][s] = W[4 (lane / 16) + s][16 j + lane % 16]
+__global__ void conv3d_pack_head_up2(const float *__restrict__ w, int labels, float *__restrict__ packed) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 16 * labels; e += gridDim.x * blockDim.x) {
+        const int sidx = e & 3, lane = (e >> 2) & 63, j = e >> 8;
+        packed[e] = w[(4 * (lane >> 4) + sidx) * labels + 16 * j + (lane & 15)];
+    }
+}
+
 size_t up2_weight_floats(int c0, int c1, int cout) {
     const size_t NT = (size_t)(cout + 15) / 16;
     return ((size_t)(c1 / 16) * 4 * 16 + (size_t)(c0 / 16) * 27) * NT * 256;
@@ -420,17 +548,25 @@ bool up2_ok(const ConvArgs &a, int padding_same) {
            (long long)a.X * a.Y * a.Z * a.c0 < (1ll << 30) && (long long)a.X * a.Y * a.Z * a.Cout < (1ll << 30);
 }
 
-template <int NT>
-int launch_up2(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st) {
-    if ((long long)batch * a.X * a.Y * a.Z * a.Cout >= (1ll << 30)) return NRT_ERR_UNSUPPORTED;     // 32-bit output offsets
+template <int NT, int HNT = 0>
+int launch_up2(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st, U2Head head = U2Head{nullptr, nullptr, 0}) {
+    const long long oc = HNT ? 16 * HNT : a.Cout;
+    if ((long long)batch * a.X * a.Y * a.Z * oc >= (1ll << 30)) return NRT_ERR_UNSUPPORTED;     // 32-bit output offsets
     const unsigned nbx = (a.OX + CT_X - 1) / CT_X, nby = (a.OY + CT_Y - 1) / CT_Y, nbz = (a.OZ + CT_Z - 1) / CT_Z;
     const unsigned ntiles = nbx * nby * nbz * (unsigned)batch;
-    if (hipFuncSetAttribute((const void *)conv3d_up2_mfma<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, U2_LDS_FLOATS * 4) != hipSuccess)
+    if (hipFuncSetAttribute((const void *)conv3d_up2_mfma<NT, HNT>, hipFuncAttributeMaxDynamicSharedMemorySize, U2_LDS_FLOATS * 4) != hipSuccess)
         return NRT_ERR_LAUNCH;
     const unsigned T8 = (ntiles + NRT_NXCD - 1) / NRT_NXCD, per_xcd = 2u * (unsigned)nrt_num_cus() / NRT_NXCD;
     const unsigned J = T8 < per_xcd ? T8 : per_xcd;
     const float *zeros = wpacked + up2_weight_floats(a.c0, a.c1, a.Cout);
-    hipLaunchKernelGGL((conv3d_up2_mfma<NT>), dim3(NRT_NXCD * J), dim3(256), U2_LDS_FLOATS * 4, st, a, wpacked, zeros, ntiles, nbx, nby, nbz);
+    hipLaunchKernelGGL((conv3d_up2_mfma<NT, HNT>), dim3(NRT_NXCD * J), dim3(256), U2_LDS_FLOATS * 4, st, a, wpacked, zeros, ntiles, nbx, nby, nbz, head);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
+}
+
+// the head can be folded in when: 16 feature channels, 16 or 32 labels, volumes of whole 4 x 4 x 16 tiles, and more up-sampled than skip
+// channels (the chunk order of a tile is then A A .. B: the skip-halo buffer is idle while the head uses it as scratch)
+bool up2_head_ok(const ConvArgs &a, int labels) {
+    return up2_ok(a, 1) && a.Cout == 16 && (labels == 16 || labels == 32) && a.OX % CT_X == 0 && a.OY % CT_Y == 0 && a.OZ % CT_Z == 0 &&
+           a.c0 < a.c1;
 }

@@ -218,6 +218,37 @@ class _Conv(nn.Module):
             return _softmax_with_grad(y) if (torch.is_grad_enabled() and y.requires_grad) else _softmax(y)
         return y
 
+    def _packed_head(self, head_kernel, labels, dev):
+        """the head's kernel in matrix-core fragment order, repacked when the parameter changes (version counter)"""
+        key = (head_kernel.data_ptr(), head_kernel._version, str(dev))
+        if getattr(self, '_head_pack_key', None) != key:
+            lib = _lib.lib()
+            src = head_kernel.detach().reshape(-1, labels).contiguous()
+            packed = torch.empty(16 * labels, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.nrt_conv3d_up2_head_pack_f32(_lib.ptr(src), labels, _lib.ptr(packed), _lib.stream_ptr(dev)),
+                           'nrt_conv3d_up2_head_pack_f32')
+            self._head_pack, self._head_pack_key = packed, key
+        return self._head_pack
+
+    def run_with_head(self, x, lo, head_kernel, head_bias):
+        """softmax(act(this decoder convolution) @ head_kernel + head_bias) in one kernel (nrt_conv3d_up2_head_f32); the caller has
+        checked ConvNet._head_foldable.  Inference only."""
+        lib = _lib.lib()
+        dev = _lib.require_device(x, lo, self.kernel)
+        x, lo = x.contiguous(), lo.contiguous()
+        c0, c1 = x.shape[-1], lo.shape[-1]
+        B, S = x.shape[0], list(x.shape[1:4])
+        labels = head_kernel.shape[-1]
+        out = torch.empty([B] + S + [labels], dtype=torch.float32, device=dev)
+        hw = self._packed_head(head_kernel, labels, dev)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_conv3d_up2_head_f32(_lib.ptr(x), c0, _lib.ptr(lo), c1, _lib.ptr(self._packed_weights_up2(c0)),
+                                             _lib.ptr(self.bias.detach()), _lib.ptr(hw), _lib.ptr(head_bias.detach()), labels,
+                                             _lib.ptr(out), B, _lib.ints(S), self.cout, self.act, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv3d_up2_head_f32')
+        return out
+
     def _run(self, x, lo=None, up=None, variant=0):
         lib = _lib.lib()
         dev = _lib.require_device(x, lo, self.kernel)
@@ -882,6 +913,13 @@ class _SoftmaxFn(torch.autograd.Function):
         return dz
 
 
+class _PendingConv:
+    """inputs of a decoder convolution whose only consumer is the soft-max head: both run as one kernel at the head's op"""
+
+    def __init__(self, x, lo):
+        self.x, self.lo = x, lo
+
+
 class ConvNet(nn.Module):
     """
     A built conv_enc / conv_dec / unet graph: an ordered list of named Keras-equivalent layers
@@ -901,7 +939,36 @@ class ConvNet(nn.Module):
         self.layer_names = [op['name'] for op in ops]
         self.output_shape = ops[-1].get('shape') if ops else None
         self.conv_variant = 0                       # 0 auto, 1 direct, 2 MFMA (tests / tuning)
+        self.fold_head = True                       # inference: last decoder convolution + likelihood + soft-max as ONE kernel where it applies
+        # {conv layer: the soft-max likelihood that is its ONLY consumer}: candidates for nrt_conv3d_up2_head_f32 (models.py:1545-1605)
+        uses = {}
+        for op in ops:
+            for key in ('src', 'lo', 'skip', 'a', 'b'):
+                v = op.get(key)
+                for n in (v if isinstance(v, (list, tuple)) else [v]):
+                    if isinstance(n, str):
+                        uses.setdefault(n, []).append(op)
+        self._head_of = {}
+        for op in ops:
+            if op['kind'] == 'conv' and op.get('lo') and op['name'] != output:
+                u = uses.get(op['name'], [])
+                if len(u) == 1 and u[0]['kind'] == 'likelihood' and u[0].get('fuse_softmax') and u[0].get('src') == op['name']:
+                    self._head_of[op['name']] = u[0]['name']
         self.eval()                                 # Keras predict semantics; model.train() records the graph for autograd
+
+    def _head_foldable(self, conv_name, head_name, x, lo, up):
+        """run-time half of the test: shapes and settings the folded kernel takes (csrc/conv_up2.h: up2_head_ok)"""
+        c, h = self.layers_by_name[conv_name], self.layers_by_name[head_name]
+        if lo is None or up is None or tuple(up) != (2, 2, 2) or self.conv_variant not in (0, 4):
+            return False
+        if c.ksize3 != (3, 3, 3) or c.dilation != 1 or c.padding != 'same' or c.act > _ACT_LAST_FUSED or c.post_softmax:
+            return False
+        if tuple(h.ksize3) != (1, 1, 1) or h.cin != c.cout:
+            return False
+        B, S = x.shape[0], list(x.shape[1:4])
+        if B * S[0] * S[1] * S[2] * h.cout >= (1 << 30):
+            return False
+        return _lib.lib().nrt_conv3d_up2_head_supported(x.shape[-1], lo.shape[-1], c.cout, h.cout, _lib.ints(S)) == 1
 
     # ---- Keras Model weight API (modelio: neurite/tf/modelio.py:111-143 saves/loads `model.get_weights()` lists) ----
     def _weight_tensors(self):
@@ -1181,8 +1248,12 @@ class ConvNet(nn.Module):
                     t[name] = torch.cat([t[s] for s in op['src']], -1).contiguous()      # host glue (rare)
                 elif kind == 'conv':
                     lo = t[op['lo']] if op.get('lo') else None
-                    t[name] = self.layers_by_name[name](t[op['src']], lo=lo, up=op.get('up'),
-                                                        variant=self.conv_variant)
+                    head = self._head_of.get(name) if self.fold_head and name not in keep else None
+                    if head is not None and head not in keep and self._head_foldable(name, head, t[op['src']], lo, op.get('up')):
+                        t[name] = _PendingConv(t[op['src']], lo)      # runs inside the likelihood op below: one kernel, no feature tensor
+                    else:
+                        t[name] = self.layers_by_name[name](t[op['src']], lo=lo, up=op.get('up'),
+                                                            variant=self.conv_variant)
                 elif kind == 'dropout':
                     t[name] = t[op['src']]                                                # inference: identity
                 elif kind == 'maxpool':
@@ -1205,7 +1276,12 @@ class ConvNet(nn.Module):
                     t[name] = _elementwise(t[op['src']], scale=scale, shift=shift)
                 elif kind == 'likelihood':
                     m = self.layers_by_name[name]
-                    if op.get('fuse_softmax'):
+                    if isinstance(t[op['src']], _PendingConv):
+                        pc = t[op['src']]
+                        t[name] = None
+                        t[op['pred_name']] = self.layers_by_name[op['src']].run_with_head(pc.x, pc.lo, m.kernel, m.bias)
+                        t[op['src']] = None
+                    elif op.get('fuse_softmax'):
                         t[name] = _conv1x1_softmax(t[op['src']], m.kernel, m.bias, False, 0) if name in keep else None
                         t[op['pred_name']] = _conv1x1_softmax(t[op['src']], m.kernel, m.bias, True, 0)
                     else:

@@ -22,6 +22,7 @@ import pytest
 import torch
 
 import neurite_amd as ne
+from neurite_amd import _lib
 from neurite_amd import models as nm
 import contextlib
 import io
@@ -176,6 +177,74 @@ def test_conv3d_folded_decoder_kernel(dev, c0, c1, cout, S, act):
     np.testing.assert_allclose(y, y27, rtol=1e-5, atol=1e-5 * np.abs(y27).max())
     # auto picks the folded kernel for these shapes: identical bits
     assert np.array_equal(N(conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2))), y)
+
+
+@pytest.mark.parametrize('labels,S,B', [(32, (8, 8, 32), 2), (16, (4, 12, 16), 1), (32, (12, 4, 48), 3), (16, (8, 8, 32), 2),
+                                        (32, (64, 64, 64), 1), (16, (32, 64, 64), 2)])   # the last two: several tiles per block
+def test_decoder_conv_with_folded_head(dev, labels, S, B):
+    """nrt_conv3d_up2_head_f32 (round 5): the last decoder convolution + the 1x1x1 likelihood convolution + the channel soft-max as
+    ONE kernel, against the two kernels it replaces (same float32 sums up to the order of the head's 16 products) and against the
+    float64 oracle of conv -> ELU -> matmul -> softmax (models.py:1545-1555, :1596, :1601-1605).  (The first versions failed this
+    test in two instructive ways, both invisible to the compiler because the instructions sit in asm statements: 16-byte stores
+    whose data registers were rewritten two cycles later, and loads whose address SGPRs had just come back from a spill lane.)"""
+    rng = np.random.default_rng(labels + S[2])
+    c0, c1 = 16, 32
+    conv = nm._Conv('c', c0 + c1, 16, (3, 3, 3), 1, 'same', 'elu').to(dev)
+    w, b = set_weights(conv, rng)
+    head = nm._Conv('h', 16, labels, (1, 1, 1), 1, 'same', None).to(dev)
+    hw, hb = set_weights(head, rng)
+    skip = rng.standard_normal((B,) + S + (c0,)).astype(F)
+    lo = rng.standard_normal((B,) + tuple(s // 2 for s in S) + (c1,)).astype(F)
+    assert _lib.lib().nrt_conv3d_up2_head_supported(c0, c1, 16, labels, _lib.ints(list(S))) == 1
+    got = N(conv.run_with_head(G(skip, dev), G(lo, dev), head.kernel, head.bias))
+    feat = conv(G(skip, dev), lo=G(lo, dev), up=(2, 2, 2), variant=4)
+    two = N(nm._conv1x1_softmax(feat, head.kernel, head.bias, True, 0))
+    assert got.shape == (B,) + S + (labels,)
+    np.testing.assert_allclose(got, two, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(got.sum(-1), 1.0, rtol=0, atol=2e-6)
+    # float64 oracle of the whole chain (small volumes; the large ones are there for the blocks that walk several tiles, where the
+    # head of tile t runs inside the first chunk of tile t + 1)
+    cat = np.concatenate([skip, lo.repeat(2, 1).repeat(2, 2).repeat(2, 3)], -1).astype(np.float64)
+    for bi in range(B if S[0] * S[1] * S[2] <= 8192 else 0):
+        ref, _ = conv_refs(cat[bi].astype(F), w, b)
+        f = np.where(ref > 0, ref, np.expm1(ref))
+        z = f @ hw.reshape(16, labels).astype(np.float64) + hb.astype(np.float64)
+        z -= z.max(-1, keepdims=True)
+        p = np.exp(z)
+        p /= p.sum(-1, keepdims=True)
+        np.testing.assert_allclose(got[bi], p, rtol=1e-4, atol=1e-6)
+    # shapes the folded head does not take
+    for args in ((16, 32, 16, 32, [8, 8, 24]), (16, 32, 16, 8, [8, 8, 32]), (32, 16, 16, 32, [8, 8, 32]), (16, 32, 32, 32, [8, 8, 32])):
+        assert _lib.lib().nrt_conv3d_up2_head_supported(args[0], args[1], args[2], args[3], _lib.ints(args[4])) == 0
+
+
+def test_unet_forward_folds_the_head(dev):
+    """a unet whose last decoder convolution has 16 features and whose volume is made of whole tiles takes the folded head in
+    inference (and only there); the prediction equals the layer-by-layer forward, intermediate tensors can still be requested"""
+    rng = np.random.default_rng(12)
+    model = ne.models.unet(16, (16, 16, 32, 1), 2, 3, 32, feat_mult=2).to(dev)
+    _randomise(model, rng)
+    x = G(rng.standard_normal((2, 16, 16, 32, 1)).astype(F), dev)
+    assert list(model._head_of.values()) == ['unet_likelihood']
+    last = list(model._head_of)[0]
+    calls = []
+    conv = model.layers_by_name[last]
+    orig = conv.run_with_head
+    conv.run_with_head = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    y = N(model(x))
+    assert calls == [1]
+    model.fold_head = False
+    y2 = N(model(x))
+    assert calls == [1]
+    np.testing.assert_allclose(y, y2, rtol=2e-5, atol=2e-7)
+    model.fold_head = True
+    out = model(x, return_tensors=[last, 'unet_prediction'])                            # the feature tensor is wanted: no folding
+    assert calls == [1] and out[last].shape[-1] == 16
+    np.testing.assert_allclose(N(out['unet_prediction']), y2, rtol=1e-6, atol=1e-8)
+    model.train()
+    yt = model(x)                                                                       # training graph: every tensor exists
+    assert calls == [1] and yt.requires_grad
+    model.eval()
 
 
 def test_conv3d_folded_decoder_kernel_falls_back(dev):
