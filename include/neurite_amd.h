@@ -289,6 +289,17 @@ int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int c1, const i
                    int padding_same, int activation, int variant, void *stream);
 
 /*
+ * The single-channel first encoder convolution with the 2x2x2 MaxPooling3D behind it (neurite/tf/models.py:1378-1388 and
+ * :1436-1438) in one kernel: `out` [batch, shape, cout] exactly as nrt_conv3d_f32 writes it (the decoder's skip connection reads
+ * it), and `pool_out` [batch, shape / 2, cout] = MaxPooling3D(2)(out) in addition -- the pooled values are taken from the tile
+ * while it is in LDS instead of reading the full-resolution tensor back.  3x3x3 SAME, weights in Keras layout [3,3,3,1,cout],
+ * cout 16 or 32, shape a multiple of (4, 4, 16); bit-identical to nrt_conv3d_f32 followed by nrt_maxpool3d_f32.
+ */
+int nrt_conv3d_c1_pool_supported(const int *shape, int cout);
+int nrt_conv3d_c1_pool_f32(const float *src /* [batch, shape, 1] */, const float *weights, const float *bias, float *out,
+                           float *pool_out, int batch, const int *shape, int cout, int activation, void *stream);
+
+/*
  * The decoder convolution of models.unet (neurite/tf/models.py:1531-1555: UpSampling3D(2) -> concatenate([skip, up]) ->
  * Conv3D 3x3x3 SAME) with the up-sampled half FOLDED: on a nearest-up-sampled tensor the 27 taps collapse to 8 taps
  * on the low-resolution grid, with one of 8 pre-summed weight sets chosen by the parity of the output voxel

@@ -612,15 +612,20 @@ __global__ __launch_bounds__(256) void conv3d_c1_vec(ConvArgs a, const float *__
 // LDS (2.6 KB) and lane l of a wave reads A[i = voxel z = l & 15][k = tap 4 ks + (l >> 4)] = halo[voxel + offset(tap)]
 // for 7 k-steps (taps 27 is padded with a zero weight).  The scalar-FMA version (conv3d_c1_vec) spends ~800 lane
 // instructions per voxel on 27 x Cout FMAs; here it is 7 MFMAs per 16 voxels and the layer becomes a 262 MB write.
-template <int NT>
+// POOL (round 5): the 2 x 2 x 2 MaxPooling3D that follows the first encoder convolution (models.py:1436-1438) computed from the tile while
+// it is still in LDS -- the full-resolution output is written as before (the decoder's skip connection reads it), the pooled tensor
+// in addition: 33 MB more to write at 160^3 x 16 instead of a second kernel that reads 262 MB back.  z pairs and y pairs are a wave's
+// own (rows of its LDS tile, consecutive y iterations), x pairs meet in LDS after one block barrier per tile.
+template <int NT, bool POOL = false>
 __global__ __launch_bounds__(256) void conv3d_c1_mfma(ConvArgs a, const float *__restrict__ w, unsigned nby, unsigned nbz,
-                                                      unsigned nblk) {
+                                                      unsigned nblk, float *__restrict__ pool_out) {
     // persistent blocks (round 3): the weights, bias and tap offsets are loaded once per block instead of once per 4x4x16 tile, and the
     // halo of tile i + 1 is fetched into registers while tile i is on the matrix cores (one tile per block paid ~150 instructions of
     // prologue and two exposed memory latencies for 28 MFMAs per wave)
     constexpr int HX = 6, HY = 6, HZ = 18, NH = HX * HY * HZ, PH = (NH + 255) / 256;
     __shared__ float halo[NH];
     __shared__ __attribute__((aligned(16))) float otile[4][16 * 16 * NT];
+    __shared__ __attribute__((aligned(16))) float ptile[POOL ? 4 : 1][2][8 * 16 * NT];     // per wave (x): [y pair][z pair][channel]
     const int b = blockIdx.y;
     const float *s0 = a.src0 + (long long)b * a.X * a.Y * a.Z;
     float *ob = a.out + (long long)b * a.OX * a.OY * a.OZ * a.Cout;
@@ -704,7 +709,39 @@ __global__ __launch_bounds__(256) void conv3d_c1_mfma(ConvArgs a, const float *_
                     if (z0 + (4 * j) / (16 * NT) < a.OZ) __builtin_nontemporal_store(*(const f32x4 *)(ot + 4 * j), po + j);
                 }
             }
+            if (POOL) {
+                // z pairs of this y row: 8 x 16 NT values, lane = (z pair, 4 channels) -- 2 NT float4 per lane
+                constexpr int C4 = 4 * NT;                                // float4 per voxel row
+                float *pt = ptile[wv][g >> 1];
+#pragma unroll
+                for (int i = 0; i < (8 * C4 + 63) / 64; ++i) {
+                    const int j = lane + 64 * i;
+                    if (j < 8 * C4) {
+                        const int zp = j / C4, c4 = j % C4;
+                        const f32x4 v0 = *(const f32x4 *)(ot + (2 * zp) * (16 * NT) + 4 * c4), v1 = *(const f32x4 *)(ot + (2 * zp + 1) * (16 * NT) + 4 * c4);
+                        f32x4 m = (f32x4){fmaxf(v0[0], v1[0]), fmaxf(v0[1], v1[1]), fmaxf(v0[2], v1[2]), fmaxf(v0[3], v1[3])};
+                        if (g & 1) {                                      // the second row of a y pair: fold the first one in
+                            const f32x4 q = *(const f32x4 *)(pt + 4 * j);
+                            m = (f32x4){fmaxf(m[0], q[0]), fmaxf(m[1], q[1]), fmaxf(m[2], q[2]), fmaxf(m[3], q[3])};
+                        }
+                        *(f32x4 *)(pt + 4 * j) = m;
+                    }
+                }
+            }
             __builtin_amdgcn_wave_barrier();
+        }
+        if (POOL) {
+            __syncthreads();                                          // the four x planes of the tile are pooled over y and z
+            // 2 x pairs x 2 y pairs x 8 z pairs x 4 NT float4 = 128 NT float4: one (or NT / 2 ...) per thread
+            constexpr int C4 = 4 * NT, PER = 2 * 2 * 8 * C4;
+            float *pb = pool_out + (long long)b * (a.OX / 2) * (a.OY / 2) * (a.OZ / 2) * a.Cout;
+            for (int j = threadIdx.x; j < PER; j += 256) {
+                const int c4 = j % C4, zp = (j / C4) % 8, yp = (j / (8 * C4)) % 2, xp = j / (16 * C4);
+                const f32x4 u = *(const f32x4 *)&ptile[2 * xp][yp][(zp * C4 + c4) * 4], v = *(const f32x4 *)&ptile[2 * xp + 1][yp][(zp * C4 + c4) * 4];
+                const f32x4 m = (f32x4){fmaxf(u[0], v[0]), fmaxf(u[1], v[1]), fmaxf(u[2], v[2]), fmaxf(u[3], v[3])};
+                const int px_ = x0 / 2 + xp, py_ = y0 / 2 + yp, pz_ = z0 / 2 + zp;
+                __builtin_nontemporal_store(m, (f32x4 *)(pb + (((long long)px_ * (a.OY / 2) + py_) * (a.OZ / 2) + pz_) * a.Cout) + c4);
+            }
         }
     }
 }
@@ -1109,10 +1146,10 @@ extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int 
         const unsigned T8c = (nblk + NRT_NXCD - 1) / NRT_NXCD, perx = 8u * (unsigned)nrt_num_cus() / NRT_NXCD;     // 8 persistent blocks per CU
         dim3 grid(NRT_NXCD * (T8c < perx ? T8c : perx), batch);
         switch (cout / 16) {
-            case 1: hipLaunchKernelGGL((conv3d_c1_mfma<1>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk); break;
-            case 2: hipLaunchKernelGGL((conv3d_c1_mfma<2>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk); break;
-            case 3: hipLaunchKernelGGL((conv3d_c1_mfma<3>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk); break;
-            default: hipLaunchKernelGGL((conv3d_c1_mfma<4>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk); break;
+            case 1: hipLaunchKernelGGL((conv3d_c1_mfma<1>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk, (float *)nullptr); break;
+            case 2: hipLaunchKernelGGL((conv3d_c1_mfma<2>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk, (float *)nullptr); break;
+            case 3: hipLaunchKernelGGL((conv3d_c1_mfma<3>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk, (float *)nullptr); break;
+            default: hipLaunchKernelGGL((conv3d_c1_mfma<4>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk, (float *)nullptr); break;
         }
         NRT_CHECK_LAUNCH();
         return NRT_OK;
@@ -1136,6 +1173,33 @@ extern "C" int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int 
     unsigned blocks = (unsigned)((nvox + 255) / 256);
     if (blocks > 256u * 32u) blocks = 256u * 32u;
     hipLaunchKernelGGL(conv3d_direct, dim3(blocks, batch), dim3(256), 0, st, a, weights);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+// the single-channel first layer + the 2x2x2 max-pooling behind it (models.py:1378-1388, 1436-1438) in one kernel: `out` as nrt_conv3d_f32
+// writes it, `pool_out` [batch, shape / 2, cout] in addition.  shape a multiple of (4, 4, 16), cout 16 or 32, 3x3x3 SAME.
+extern "C" int nrt_conv3d_c1_pool_supported(const int *shape, int cout) {
+    return shape && shape[0] > 0 && shape[1] > 0 && shape[2] > 0 && shape[0] % 4 == 0 && shape[1] % 4 == 0 && shape[2] % 16 == 0 &&
+           (cout == 16 || cout == 32) ? 1 : 0;
+}
+extern "C" int nrt_conv3d_c1_pool_f32(const float *src, const float *weights, const float *bias, float *out, float *pool_out, int batch,
+                                      const int *shape, int cout, int activation, void *stream) {
+    if (!pool_out || !weights || !nrt_conv3d_c1_pool_supported(shape, cout)) return NRT_ERR_UNSUPPORTED;
+    ConvArgs a;
+    const int k3[3] = {3, 3, 3};
+    int rc = conv_args(a, src, 1, nullptr, 0, nullptr, bias, out, shape, k3, cout, 1, 1, activation);
+    if (rc != NRT_OK) return rc;
+    if (batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_LAST_FUSED) return NRT_ERR_INVALID_ARG;
+    if ((((uintptr_t)out) | ((uintptr_t)pool_out)) & 15) return NRT_ERR_INVALID_ARG;
+    hipStream_t st = nrt_stream(stream);
+    const unsigned nbx = (a.OX + 3) / 4, nby = (a.OY + 3) / 4, nbz = (a.OZ + 15) / 16;
+    const unsigned nblk = nbx * nby * nbz;
+    const unsigned T8c = (nblk + NRT_NXCD - 1) / NRT_NXCD, perx = 8u * (unsigned)nrt_num_cus() / NRT_NXCD;
+    dim3 grid(NRT_NXCD * (T8c < perx ? T8c : perx), batch);
+    if (cout == 16) hipLaunchKernelGGL((conv3d_c1_mfma<1, true>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk, pool_out);
+    else hipLaunchKernelGGL((conv3d_c1_mfma<2, true>), grid, dim3(256), 0, st, a, weights, nby, nbz, nblk, pool_out);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

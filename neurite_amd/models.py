@@ -218,6 +218,28 @@ class _Conv(nn.Module):
             return _softmax_with_grad(y) if (torch.is_grad_enabled() and y.requires_grad) else _softmax(y)
         return y
 
+    def pool_foldable(self, x, variant):
+        """the single-channel first layer whose 2x2x2 max-pooling can come out of the same kernel (csrc/conv.hip: conv3d_c1_mfma<NT, true>)"""
+        if variant not in (0, 1) or self.cin != 1 or x.shape[-1] != 1 or self.ksize3 != (3, 3, 3) or self.dilation != 1:
+            return False
+        if self.padding != 'same' or self.act > _ACT_LAST_FUSED or self.post_softmax or x.dtype != torch.float32:
+            return False
+        return _lib.lib().nrt_conv3d_c1_pool_supported(_lib.ints(list(x.shape[1:4])), self.cout) == 1
+
+    def run_with_pool(self, x):
+        """(act(conv(x)), MaxPooling3D(2) of it) from one kernel (nrt_conv3d_c1_pool_f32).  Inference only."""
+        lib = _lib.lib()
+        dev = _lib.require_device(x, self.kernel)
+        x = x.contiguous()
+        B, S = x.shape[0], list(x.shape[1:4])
+        out = torch.empty([B] + S + [self.cout], dtype=torch.float32, device=dev)
+        pooled = torch.empty([B] + [v // 2 for v in S] + [self.cout], dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.nrt_conv3d_c1_pool_f32(_lib.ptr(x), _lib.ptr(self.kernel.detach().contiguous()), _lib.ptr(self.bias.detach()),
+                                            _lib.ptr(out), _lib.ptr(pooled), B, _lib.ints(S), self.cout, self.act, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv3d_c1_pool_f32')
+        return out, pooled
+
     def _packed_head(self, head_kernel, labels, dev):
         """the head's kernel in matrix-core fragment order, repacked when the parameter changes (version counter)"""
         key = (head_kernel.data_ptr(), head_kernel._version, str(dev))
@@ -948,6 +970,13 @@ class ConvNet(nn.Module):
                 for n in (v if isinstance(v, (list, tuple)) else [v]):
                     if isinstance(n, str):
                         uses.setdefault(n, []).append(op)
+        # {single-channel first convolution: the 2x2x2 max-pooling that reads it}: candidates for nrt_conv3d_c1_pool_f32 (models.py:1378-1438)
+        self._pool_of = {}
+        for op in ops:
+            if op['kind'] == 'maxpool' and tuple(op.get('pool', ())) == (2, 2, 2) and isinstance(op.get('src'), str):
+                src = next((o for o in ops if o['name'] == op['src']), None)
+                if src is not None and src['kind'] == 'conv' and not src.get('lo') and op['src'] not in self._pool_of:
+                    self._pool_of[op['src']] = op['name']
         self._head_of = {}
         for op in ops:
             if op['kind'] == 'conv' and op.get('lo') and op['name'] != output:
@@ -1249,15 +1278,19 @@ class ConvNet(nn.Module):
                 elif kind == 'conv':
                     lo = t[op['lo']] if op.get('lo') else None
                     head = self._head_of.get(name) if self.fold_head and name not in keep else None
+                    pool = self._pool_of.get(name) if self.fold_head else None
                     if head is not None and head not in keep and self._head_foldable(name, head, t[op['src']], lo, op.get('up')):
                         t[name] = _PendingConv(t[op['src']], lo)      # runs inside the likelihood op below: one kernel, no feature tensor
+                    elif pool is not None and lo is None and self.layers_by_name[name].pool_foldable(t[op['src']], self.conv_variant):
+                        t[name], t[pool] = self.layers_by_name[name].run_with_pool(t[op['src']])   # the pooled tensor from the same kernel
                     else:
                         t[name] = self.layers_by_name[name](t[op['src']], lo=lo, up=op.get('up'),
                                                             variant=self.conv_variant)
                 elif kind == 'dropout':
                     t[name] = t[op['src']]                                                # inference: identity
                 elif kind == 'maxpool':
-                    t[name] = _maxpool(t[op['src']], op['pool'], op['padding'])
+                    if t.get(name) is None:                                               # (else: produced by the convolution in front of it)
+                        t[name] = _maxpool(t[op['src']], op['pool'], op['padding'])
                 elif kind == 'upsample':
                     t[name] = _upsample_concat(None, t[op['src']], op['up'])
                 elif kind == 'merge':

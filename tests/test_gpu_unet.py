@@ -218,6 +218,23 @@ def test_decoder_conv_with_folded_head(dev, labels, S, B):
         assert _lib.lib().nrt_conv3d_up2_head_supported(args[0], args[1], args[2], args[3], _lib.ints(args[4])) == 0
 
 
+@pytest.mark.parametrize('cout,S,B', [(16, (8, 8, 32), 2), (32, (4, 12, 16), 1), (16, (32, 32, 64), 1)])
+def test_first_conv_with_folded_pooling(dev, cout, S, B):
+    """nrt_conv3d_c1_pool_f32 (round 5): the single-channel first encoder convolution also emits MaxPooling3D(2) of its output
+    (models.py:1378-1388, 1436-1438): both tensors bit-identical to the two kernels it replaces"""
+    rng = np.random.default_rng(cout + S[0])
+    conv = nm._Conv('c', 1, cout, (3, 3, 3), 1, 'same', 'elu').to(dev)
+    set_weights(conv, rng)
+    x = G(rng.standard_normal((B,) + S + (1,)).astype(F), dev)
+    assert conv.pool_foldable(x, 0)
+    y, p = conv.run_with_pool(x)
+    y2 = conv(x)
+    p2 = nm._maxpool(y2, (2, 2, 2), 'valid')
+    assert np.array_equal(N(y), N(y2)) and np.array_equal(N(p), N(p2))
+    assert not conv.pool_foldable(G(rng.standard_normal((1, 6, 8, 16, 1)).astype(F), dev), 0)          # not whole tiles
+    assert not nm._Conv('d', 1, 8, (3, 3, 3), 1, 'same', 'elu').to(dev).pool_foldable(x, 0)             # 8 features
+
+
 def test_unet_forward_folds_the_head(dev):
     """a unet whose last decoder convolution has 16 features and whose volume is made of whole tiles takes the folded head in
     inference (and only there); the prediction equals the layer-by-layer forward, intermediate tensors can still be requested"""
