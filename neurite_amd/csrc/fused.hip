@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, MINW) void warp_dice_tile(InterpArgs a, TileGe
     }
     if (lane == 0) { red[wv][3 * L + 0] = mnt; red[wv][3 * L + 1] = mxt; red[wv][3 * L + 2] = mnp; red[wv][3 * L + 3] = mxp; }
     __syncthreads();
-    const long long pbase = tg.x_march ? ((long long)b * (tg.ncol * tg.nseg) + prow) : ((long long)b * gridDim.x + blockIdx.x);
+    const long long pbase = tg.x_march ? ((long long)b * tg.prows + prow) : ((long long)b * gridDim.x + blockIdx.x);
     for (int i = threadIdx.x; i < 3 * L; i += 256) {
         float s = red[0][i];
 #pragma unroll

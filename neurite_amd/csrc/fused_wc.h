@@ -413,7 +413,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     }
     if (lane == 0) { red[wave][3 * L + 0] = mnt; red[wave][3 * L + 1] = mxt; red[wave][3 * L + 2] = mnp; red[wave][3 * L + 3] = mxp; }
     __syncthreads();
-    const long long pbase = (long long)b * (tg.ncol * tg.nseg) + prow;
+    const long long pbase = (long long)b * tg.prows + prow;
     for (int i = threadIdx.x; i < 3 * L; i += 256) {
         float s = red[0][i];
 #pragma unroll

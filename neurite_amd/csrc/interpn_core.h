@@ -101,6 +101,10 @@ struct TileGeom {
     // of blocks is short, so the chip drains in a fraction of a march.  het_cpx = 0: every column in nseg equal pieces (xmarch_setup).
     unsigned het_cpx, het_full;
     unsigned items_x;              // work items (blocks of the non-persistent launch) per XCD
+    // partial rows per batch entry.  Equal pieces: ncol x nseg.  Mixed lengths: ONE row per column (whole columns, first pieces) followed
+    // by nseg - 1 rows per SPLIT column of the entry, padded to the entry with the most split columns -- with a row per (column, piece)
+    // four fifths of the rows of a 4-volume launch were zeros written by the gather and read back by the second stage (15 us of 915)
+    unsigned prows;
 };
 
 // tune word of the tiled kernels: ltx | lty << 4 | ltz << 8 | z_outer << 12 | plane_major << 13 | x_march << 14 | LZ << 16
@@ -111,7 +115,7 @@ inline void tile_geometry(const int *out_shape, int G, int tune, int default_tun
     tg.ltx = tune & 15; tg.lty = (tune >> 4) & 15; tg.ltz = (tune >> 8) & 15; tg.z_outer = (tune >> 12) & 1;
     tg.plane_major = ((tune >> 13) & 1) && G == 8;
     tg.x_march = 0; tg.ncol = 0; tg.nseg = 1; tg.seglen = 0; tg.nbatch = 1; tg.lry = 0; tg.lrz = 0; tg.depth_sync = 0;
-    tg.het_cpx = 0; tg.het_full = 0; tg.items_x = 0;
+    tg.het_cpx = 0; tg.het_full = 0; tg.items_x = 0; tg.prows = 0;
     if (tg.plane_major) {
         tg.ltx = 2; tg.lty = 3; tg.ltz = 0;
         tg.tz = (tune >> 16) & 0xfff;
@@ -174,7 +178,14 @@ inline unsigned xmarch_setup(const int *out_shape, int batch, int t, TileGeom &t
     tg.seglen = ((unsigned)out_shape[0] + nseg - 1) / nseg;
     tg.nseg = ((unsigned)out_shape[0] + tg.seglen - 1) / tg.seglen;
     tg.items_x = (tg.ncol * tg.nseg * (unsigned)batch + NRT_NXCD - 1) / NRT_NXCD;
-    return tg.ncol * tg.nseg;
+    tg.prows = tg.ncol * tg.nseg;
+    return tg.prows;
+}
+
+// columns c' < c (c = XCD * het_cpx + position in the XCD's list) that are marched in pieces
+__host__ __device__ inline unsigned xmarch_split_before(const TileGeom &tg, unsigned c) {
+    const unsigned cl = c % tg.het_cpx;
+    return (c / tg.het_cpx) * (tg.het_cpx - tg.het_full) + (cl > tg.het_full ? cl - tg.het_full : 0u);
 }
 
 // host: mixed block lengths for the fused forward kernels when the tune word leaves the segments to us.  Blocks of (about) equal
@@ -211,7 +222,14 @@ inline unsigned xmarch_setup_mixed(const int *out_shape, int batch, int t, TileG
     tg.seglen = ((unsigned)out_shape[0] + bP - 1) / bP;
     tg.items_x = bF + (cpx - bF) * bP;
     grid = NRT_NXCD * tg.items_x;
-    return tg.ncol * bP;
+    unsigned maxsplit = 0;
+    for (unsigned b = 0; b < (unsigned)batch; ++b) {
+        const unsigned c1 = (b + 1) * tg.ncol < cols ? (b + 1) * tg.ncol : cols;
+        const unsigned sp = xmarch_split_before(tg, c1) - xmarch_split_before(tg, b * tg.ncol);
+        if (sp > maxsplit) maxsplit = sp;
+    }
+    tg.prows = tg.ncol + maxsplit * (bP - 1);
+    return tg.prows;
 }
 
 // device: the work of this block under either schedule.  false: nothing (the block exits; it owns no partial row)
@@ -231,7 +249,9 @@ __device__ __forceinline__ bool xmarch_work_at(const TileGeom &tg, int O0, unsig
         if (cl >= tg.het_cpx || c >= tg.ncol * tg.nbatch) return false;
         w.b = (int)(c / tg.ncol);
         w.ucol = c % tg.ncol;
-        w.prow = piece * tg.ncol + w.ucol;
+        // one row per column, then nseg - 1 rows per split column of the batch entry (TileGeom::prows)
+        w.prow = piece == 0 ? w.ucol
+                            : tg.ncol + (xmarch_split_before(tg, c) - xmarch_split_before(tg, (unsigned)w.b * tg.ncol)) * (tg.nseg - 1) + (piece - 1);
         w.x0 = w.whole ? 0 : (int)(piece * tg.seglen);
         w.xlen = w.whole ? O0 : min((int)tg.seglen, O0 - w.x0);
         return true;
@@ -249,11 +269,15 @@ __device__ __forceinline__ bool xmarch_work_at(const TileGeom &tg, int O0, unsig
     w.whole = false;
     return true;
 }
-// a block that marched a whole column owns the column's other partial rows too: they hold zeros (and neutral extrema)
+// Mixed lengths: the rows of a batch entry are padded to the entry with the most split columns; the block that marches the entry's first
+// column (from x = 0) fills the entry's padding rows with zeros (and neutral extrema).  Every other row is written by its own item.
 __device__ __forceinline__ void xmarch_zero_rows(const TileGeom &tg, const XmWork &w, int L3, float *fpart, float *mpart) {
-    if (!w.whole) return;
-    for (unsigned piece = 1; piece < tg.nseg; ++piece) {
-        const long long row = (long long)w.b * (tg.ncol * tg.nseg) + piece * tg.ncol + w.ucol;
+    if (!tg.het_cpx || w.ucol != 0 || w.x0 != 0) return;
+    const unsigned c0 = (unsigned)w.b * tg.ncol, cols = tg.ncol * tg.nbatch;
+    const unsigned c1 = c0 + tg.ncol < cols ? c0 + tg.ncol : cols;
+    const unsigned used = tg.ncol + (xmarch_split_before(tg, c1) - xmarch_split_before(tg, c0)) * (tg.nseg - 1);
+    for (unsigned r = used; r < tg.prows; ++r) {
+        const long long row = (long long)w.b * tg.prows + r;
         for (int i = threadIdx.x; i < L3; i += blockDim.x) fpart[row * L3 + i] = 0.0f;
         if (threadIdx.x < 4) mpart[row * 4 + threadIdx.x] = (threadIdx.x & 1) ? -INFINITY : INFINITY;
     }
