@@ -283,8 +283,11 @@ __device__ __forceinline__ void xmarch_zero_rows(const TileGeom &tg, const XmWor
     }
 }
 
-// default x-march tune for 32-channel volumes: 4 x 8 (y,z) patches, regions of 8 x 4 patches
-inline int xmarch_default_tune() { return 3 | (2 << 4) | (3 << 8) | (1 << 14) | (3 << 24) | (2 << 27); }
+// default x-march tune for 32-channel volumes: 4 x 8 (y,z) patches, regions of 8 x 2 patches = 32 x 16 voxels.  (8 x 4 until round 5:
+// with the round-5 gather the region shape is worth < 0.5 % at 4 volumes -- 16 x 2, 8 x 2, 4 x 4 within noise of each other -- but at
+// ONE volume an XCD owns 100 columns, and regions of 16 patches lose fewer neighbours at the XCD boundaries than regions of 32:
+// 0.275 -> 0.251 ms; tools/region_sweep.py, profiles/r05_lab/region_sweep.jsonl)
+inline int xmarch_default_tune() { return 3 | (2 << 4) | (3 << 8) | (1 << 14) | (3 << 24) | (1 << 27); }
 inline bool xmarch_applies(const int *out_shape, int batch) {
     const unsigned cols = ((unsigned)(out_shape[1] + 3) / 4) * ((unsigned)(out_shape[2] + 7) / 8);
     return out_shape[0] >= 16 && cols * (unsigned)batch >= 512;
