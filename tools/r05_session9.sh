@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp PYTHONUNBUFFERED=1
-FUSED_VARIANTS="BASE=0 TAUX=0 TAUX=3 TAUX=18 RAUX=2 RAUX=1" FUSED_REPS=2 FUSED_STEPS=60 python tools/fused_variants.py 2>&1 | tee gpurun_out/s9_variants.jsonl
-for v in BASE0 TAUX0 TAUX3 TAUX18 RAUX2 RAUX1; do
+FUSED_VARIANTS="BASE=0 STAGGER=1 STAGGER=2 STAGGER=4" FUSED_REPS=2 FUSED_STEPS=60 python tools/fused_variants.py 2>&1 | tee gpurun_out/s9_variants.jsonl
+for v in BASE0 STAGGER1 STAGGER2 STAGGER4; do
   ( cd /tmp && NEURITE_AMD_LIB=$GRAFT_REPO_ROOT/tools/lab/libnrt_fused_$v.so timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/s9_fetch_$v -o f -- python $GRAFT_REPO_ROOT/tools/fused_small.py 4 > /dev/null 2>&1 )
   python - $v <<'PY'
 import csv, glob, sys
