@@ -480,6 +480,18 @@ def unet_bench(dev, size=160, labels=32, nb_conv_per_level=1, reps=20, warmup=5)
             l.update(conv_layer_error(m, src, lo, op.get('up'), inter[l['name']]))
         except Exception as e:   # noqa
             l['max_rel_err'] = 'failed: %s' % e
+    # matrix-core counters of a rocprofv3 --pmc pass of this forward (profiles/r05_unet/mfma_counters.json, written by
+    # tools/unet_mfma_summary.py from SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_VALU_MFMA_MOPS_F32 / GRBM_GUI_ACTIVE), keyed by layer name:
+    # a static figure of the profiled session next to the live flops / (time x peak), as the traffic figure of the gather is
+    try:
+        ctr = json.load(open(os.path.join(ROOT, 'profiles', 'r05_unet', 'mfma_counters.json'))).get('layers', {})
+    except Exception:   # noqa
+        ctr = {}
+    for l in layers:
+        c = ctr.get(l['name'])
+        l['mfma_busy_from_counters'] = None if c is None else c['mfma_busy']
+        if c is not None:
+            l['counter_kernel'] = c['kernel']
     mf = [l for l in layers if l['cin'] >= 8]
     gf = sum(l.get('gflop_executed', l['gflop']) for l in mf)
     ms = sum(l['ms'] for l in mf)
