@@ -250,6 +250,12 @@ int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *lab
              long long nvox_total, int channels, int from_logits, float label_smoothing,
              float *loss_sum, float *per_voxel,
              void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the division of the default reduction ('sum_over_batch_size': metrics.py:650 -> Keras CategoricalCrossentropy) done by
+ * the block that finishes the sum: loss_mean[0] = float32(sum) / float32(divide_by); one launch, nothing for the caller to divide. */
+int nrt_wcce_mean(const void *y_true, const void *y_pred, int dtype, const float *label_weights,
+                  long long nvox_total, int channels, int from_logits, float label_smoothing, double divide_by,
+                  float *loss_mean, float *per_voxel,
+                  void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * unet layers

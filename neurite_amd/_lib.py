@@ -108,6 +108,7 @@ _SIGNATURES = {
     'nrt_synth_noise_add_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     'nrt_synth_bg_clear_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
     'nrt_wcce': (_i, [_vp, _vp, _i, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    'nrt_wcce_mean': (_i, [_vp, _vp, _i, _vp, _ll, _i, _i, _f, C.c_double, _vp, _vp, _vp, _sz, _vp]),
     'nrt_interpn_bwd_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _vp]),
     'nrt_interpn_nearest_bwd_f32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _vp]),
     'nrt_soft_quantize_bwd_f32': (_i, [_vp, _vp, _f, _f, _f, _i, _vp, _vp, _ll, _i, _vp]),

@@ -23,6 +23,14 @@ typedef unsigned short nrt_us4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 
+// exp(d), d = x - max <= 0, and log(s), s = a sum of such terms that contains exp(0) = 1, so s in [1, C]: one v_exp_f32 / v_log_f32 on
+// scaled arguments instead of the ~20-instruction libm expansions -- the from-logits kernel was bound by VALU issue (4 expf + 1 logf per
+// lane and voxel: 14 us of arithmetic for config 5's 10 us of streaming).  Relative error of exp <= 2^-23 + |d| 2^-24, absolute error of
+// log on [1, C] <= 2^-22: per-voxel loss within 3e-7 absolute, far inside the 1e-5 of the tests (bf16 inputs: 1e-4).  The
+// probabilities branch keeps logf: its argument runs up to 1 - 1e-7, where the result itself is ~1e-7.
+__device__ __forceinline__ float lse_exp(float d) { return __builtin_amdgcn_exp2f(d * 1.44269504088896341f); }
+__device__ __forceinline__ float lse_log(float s) { return __builtin_amdgcn_logf(s) * 0.693147180559945309f; }
+
 template <typename T> struct Quad;
 template <> struct Quad<float> {
     static __device__ __forceinline__ nrt_f4 load(const void *base, long long i) {
@@ -42,11 +50,11 @@ template <> struct Quad<unsigned short> {
 
 // The sum of the block partials, by the LAST block of the same launch (round 5; a second launch cost more than it computed at
 // config 5's 53 MB).  A block publishes its partial with a device-scope store (sc1: written through, the eight XCDs have their own
-// L2s), waits for the acknowledgement and takes a ticket from a self-cleaning counter (api.hip: nrt_ring_slot); the block that
+// L2s), waits for the acknowledgement and takes a ticket from self-cleaning counters (api.hip: nrt_ring_slot; two levels, see below); the block that
 // draws the last ticket reads the partials with device-scope loads and adds them in a FIXED order in float64 (what wcce_finalize
 // did: run-to-run bit-identical), then zeroes the counter for the slot's next launch.  NOT __threadfence(): at agent scope it is
 // buffer_wbl2 + buffer_inv -- every block invalidating its XCD's L2 under the other blocks' streams cost 35 us at config 5.
-struct WcceFin { float *loss_sum; unsigned *counter; };
+struct WcceFin { float *loss_sum; unsigned *counter; double divide_by; };     // loss_sum[0] = sum / divide_by (1: the sum; N: the mean)
 __device__ __forceinline__ void wcce_finish(float *part, float block_sum, const WcceFin &fin) {
     __shared__ bool s_last;
     __shared__ double s_acc[CCE_BLOCK];
@@ -54,7 +62,16 @@ __device__ __forceinline__ void wcce_finish(float *part, float block_sum, const 
         __hip_atomic_store(part + blockIdx.x, block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_s_waitcnt(0);                         // the store is acknowledged ...
         asm volatile("" ::: "memory");
-        s_last = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;   // ... before the ticket says so
+        // ... before the ticket says so.  Two levels: 2048 tickets on ONE address are 2048 serialised device-scope atomics (~20 us at
+        // config 5, more than the streaming); a block draws from the counter of its residue class mod 8 (64 bytes apart), the last of a
+        // class draws from the ninth counter, the last of those finishes
+        const unsigned k = blockIdx.x & 7u, in_class = (gridDim.x + 7u - k) >> 3, classes = gridDim.x < 8u ? gridDim.x : 8u;
+        bool last = false;
+        if (__hip_atomic_fetch_add(fin.counter + 16u * k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_class - 1u) {
+            __hip_atomic_store(fin.counter + 16u * k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(fin.counter + 16u * 8u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == classes - 1u;
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -66,8 +83,8 @@ __device__ __forceinline__ void wcce_finish(float *part, float block_sum, const 
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < CCE_BLOCK; ++i) t += s_acc[i];      // fixed order
-        fin.loss_sum[0] = (float)t;
-        __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fin.loss_sum[0] = fin.divide_by == 1.0 ? (float)t : (float)t / (float)fin.divide_by;      // float32 sum, float32 division: as the two-op form
+        __hip_atomic_store(fin.counter + 16u * 8u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -104,10 +121,10 @@ __global__ __launch_bounds__(CCE_BLOCK) void wcce_vec(const void *__restrict__ y
             float m = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
 #pragma unroll
             for (int off = 1; off < G; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, NRT_WAVE));
-            float se = (expf(p[0] - m) + expf(p[1] - m)) + (expf(p[2] - m) + expf(p[3] - m));
+            float se = (lse_exp(p[0] - m) + lse_exp(p[1] - m)) + (lse_exp(p[2] - m) + lse_exp(p[3] - m));
 #pragma unroll
             for (int off = 1; off < G; off <<= 1) se += __shfl_xor(se, off, NRT_WAVE);
-            const float lse = logf(se);
+            const float lse = lse_log(se);
 #pragma unroll
             for (int k = 0; k < 4; ++k) lq[k] = (p[k] - m) - lse;
         } else {
@@ -278,17 +295,17 @@ extern "C" size_t nrt_wcce_workspace_bytes(long long nvox_total, int channels) {
     return (size_t)CCE_MAX_BLOCKS * sizeof(float) + 256;
 }
 
-extern "C" int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *label_weights,
-                        long long nvox_total, int channels, int from_logits, float label_smoothing, float *loss_sum,
-                        float *per_voxel, void *workspace, size_t workspace_bytes, void *stream) {
+namespace {
+int wcce_impl(const void *y_true, const void *y_pred, int dtype, const float *label_weights, long long nvox_total, int channels, int from_logits,
+              float label_smoothing, double divide_by, float *loss_sum, float *per_voxel, void *workspace, size_t workspace_bytes, void *stream) {
     if (!y_true || !y_pred || !loss_sum) return NRT_ERR_INVALID_ARG;
-    if (nvox_total < 0 || channels < 1) return NRT_ERR_INVALID_ARG;
+    if (nvox_total < 0 || channels < 1 || !(divide_by > 0.0)) return NRT_ERR_INVALID_ARG;
     if (dtype != NRT_DT_F32 && dtype != NRT_DT_BF16) return NRT_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < nrt_wcce_workspace_bytes(nvox_total, channels)) return NRT_ERR_WORKSPACE;
     hipStream_t st = nrt_stream(stream);
     float *part = (float *)workspace;
     unsigned nblk = 1;
-    WcceFin fin = {loss_sum, nrt_ring_slot()};
+    WcceFin fin = {loss_sum, nrt_ring_slot(), divide_by};
     if (!fin.counter) return NRT_ERR_LAUNCH;
     const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
     if (dtype == NRT_DT_F32)
@@ -299,4 +316,21 @@ extern "C" int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const
                                    aligned, nblk, part, per_voxel, st, fin);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
+}
+}  // namespace
+
+extern "C" int nrt_wcce(const void *y_true, const void *y_pred, int dtype, const float *label_weights,
+                        long long nvox_total, int channels, int from_logits, float label_smoothing, float *loss_sum,
+                        float *per_voxel, void *workspace, size_t workspace_bytes, void *stream) {
+    return wcce_impl(y_true, y_pred, dtype, label_weights, nvox_total, channels, from_logits, label_smoothing, 1.0, loss_sum, per_voxel,
+                     workspace, workspace_bytes, stream);
+}
+
+// the same with the reduction of Keras' default ('sum_over_batch_size', metrics.py:650 -> tf.keras.losses.CategoricalCrossentropy):
+// loss_sum[0] = float32(sum) / float32(divide_by), formed by the block that finishes the sum -- no second launch for the division
+extern "C" int nrt_wcce_mean(const void *y_true, const void *y_pred, int dtype, const float *label_weights,
+                             long long nvox_total, int channels, int from_logits, float label_smoothing, double divide_by,
+                             float *loss_mean, float *per_voxel, void *workspace, size_t workspace_bytes, void *stream) {
+    return wcce_impl(y_true, y_pred, dtype, label_weights, nvox_total, channels, from_logits, label_smoothing, divide_by, loss_mean, per_voxel,
+                     workspace, workspace_bytes, stream);
 }

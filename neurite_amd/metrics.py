@@ -128,8 +128,9 @@ class _SoftDiceFn(torch.autograd.Function):
         return gt, gp, None, None, None
 
 
-def _wcce_launch(t, p, w, from_logits, label_smoothing, per_voxel):
-    """one launch of the weighted-CCE kernel: the sum of the per-voxel losses [1], or the per-voxel losses"""
+def _wcce_launch(t, p, w, from_logits, label_smoothing, per_voxel, divide_by=None):
+    """one launch of the weighted-CCE kernel: the sum of the per-voxel losses [1] (divided by `divide_by` inside the kernel when given),
+    or the per-voxel losses"""
     lib = _lib.lib()
     dev = p.device
     yf = p.shape[-1]
@@ -140,9 +141,14 @@ def _wcce_launch(t, p, w, from_logits, label_smoothing, per_voxel):
     ws = _lib.workspace(dev, nws)
     dt = _lib.DT_F32 if p.dtype == torch.float32 else _lib.DT_BF16
     with torch.cuda.device(dev):
-        rc = lib.nrt_wcce(_lib.ptr(t), _lib.ptr(p), dt, _lib.ptr(w), N, yf, int(from_logits),
-                          float(label_smoothing), _lib.ptr(loss_sum), _lib.ptr(pv), _lib.ptr(ws), nws,
-                          _lib.stream_ptr(dev))
+        if divide_by is None:
+            rc = lib.nrt_wcce(_lib.ptr(t), _lib.ptr(p), dt, _lib.ptr(w), N, yf, int(from_logits),
+                              float(label_smoothing), _lib.ptr(loss_sum), _lib.ptr(pv), _lib.ptr(ws), nws,
+                              _lib.stream_ptr(dev))
+        else:
+            rc = lib.nrt_wcce_mean(_lib.ptr(t), _lib.ptr(p), dt, _lib.ptr(w), N, yf, int(from_logits),
+                                   float(label_smoothing), float(divide_by), _lib.ptr(loss_sum), _lib.ptr(pv), _lib.ptr(ws), nws,
+                                   _lib.stream_ptr(dev))
     _lib.check(rc, 'nrt_wcce')
     return pv if per_voxel else loss_sum
 
@@ -557,7 +563,11 @@ class CategoricalCrossentropy:
         elif torch.is_grad_enabled() and (p.requires_grad or t.requires_grad):
             res = _WcceFn.apply(t, p, w, self.from_logits, self.label_smoothing, need_pv)
         else:
-            res = _wcce_launch(t, p, w, self.from_logits, self.label_smoothing, need_pv)     # nothing to differentiate: no autograd node
+            # nothing to differentiate: no autograd node, and the mean's division happens in the kernel (one launch per call)
+            mean = not need_pv and self.reduction != 'sum' and N > 0
+            res = _wcce_launch(t, p, w, self.from_logits, self.label_smoothing, need_pv, divide_by=N if mean else None)
+            if mean:
+                return res[0]
         if not need_pv:
             return res[0] if self.reduction == 'sum' else res[0] / N
         losses = res
