@@ -80,11 +80,11 @@ int nrt_interpn_f32(const float *vol, const float *loc, float *out,
 
 /* Same, selecting a specific kernel (for tuning / benchmarking).  variant:
  *   0 auto | 1 generic element-per-thread | 2 row-per-lane-group (C%4==0)
- *   3 z-run with register reuse of the shared corner rows (ndim 3, C==32)
+ *   3 z-run with register reuse of the shared corner rows (ndim 3, C==32; the auto choice on regular grids: NRT_LOC_LINSPACE)
  *   5 3-D tiles with a depth-2 software pipeline (C%4==0, linear)
  *   8 few-channel kernel: one voxel per lane, z corners of a row by one load (ndim 3, C<=4; the auto choice there)
- *   10 wave-private LDS row cache on the x-march schedule (ndim 3, C==32, linear; flat over field steepness: the better kernel on
- *      steep or incoherent fields, the auto choice with NRT_INTERPN_WC=1)
+ *   10 wave-private LDS row cache on the x-march schedule (ndim 3, C==32, linear; the auto choice for displacement fields and
+ *      absolute locations since round 5: at least as fast as variant 3 on every field measured)
  * tune: variant-specific knob (variant 3: z-chunk length | order | patch | region bits; variant 5: tile geometry). */
 int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out,
                        int ndim, const int *vol_shape, const int *out_shape, int channels,
