@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "interpn_core.h"
+#include "wc.h"
 
 namespace {
 
@@ -769,24 +770,12 @@ __global__ __launch_bounds__(256, 3) void warp_dice_bwd_xm(InterpBwdArgs ba, con
                 ah = ah + w2 * (nrt_f2){v[corner][2], v[corner][3]};
             }
             // d dice / d warped for this lane's four labels
-            gl2 = (nrt_f2){ca[0], ca[1]} * gl2 + (nrt_f2){cb[0], cb[1]} * al;
-            gh2 = (nrt_f2){ca[2], ca[3]} * gh2 + (nrt_f2){cb[2], cb[3]} * ah;
+            gl2 = __builtin_elementwise_fma((nrt_f2){cb[0], cb[1]}, al, (nrt_f2){ca[0], ca[1]} * gl2);
+            gh2 = __builtin_elementwise_fma((nrt_f2){cb[2], cb[3]}, ah, (nrt_f2){ca[2], ca[3]} * gh2);
         }
         if (DEAD) { gl2 = (nrt_f2){0.0f, 0.0f}; gh2 = gl2; }
-        // its inner product with every corner row, then d warped / d loc as differences of corner pairs:
-        //   d/dx = m_x sum_{y,z} (wy wz) (dot[1,y,z] - dot[0,y,z])   and likewise for y and z   (m = 0 outside the volume: clipped)
-        float dot[8];
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const nrt_f2 s2 = gl2 * (nrt_f2){v[corner][0], v[corner][1]} + gh2 * (nrt_f2){v[corner][2], v[corner][3]};
-            dot[corner] = s2[0] + s2[1];
-        }
-        const nrt_f2 wyz0 = (nrt_f2){W0y, W0y} * wz2, wyz1 = (nrt_f2){W1y, W1y} * wz2;     // wy wz: [y0z0, y0z1], [y1z0, y1z1]
-        const nrt_f2 wxz0 = (nrt_f2){W0x, W0x} * wz2, wxz1 = (nrt_f2){W1x, W1x} * wz2;     // wx wz
         float gacc[3];
-        gacc[0] = Mx * ((wyz0[0] * (dot[4] - dot[0]) + wyz0[1] * (dot[5] - dot[1])) + (wyz1[0] * (dot[6] - dot[2]) + wyz1[1] * (dot[7] - dot[3])));
-        gacc[1] = My * ((wxz0[0] * (dot[2] - dot[0]) + wxz0[1] * (dot[3] - dot[1])) + (wxz1[0] * (dot[6] - dot[4]) + wxz1[1] * (dot[7] - dot[5])));
-        gacc[2] = Mz * ((wxy0[0] * (dot[1] - dot[0]) + wxy0[1] * (dot[3] - dot[2])) + (wxy1[0] * (dot[5] - dot[4]) + wxy1[1] * (dot[7] - dot[6])));
+        loc_grad_rows(v, gl2, gh2, W0x, W1x, W0y, W1y, W0z, W1z, Mx, My, Mz, gacc);
         // sum over the voxel's 8 lanes on the DPP network (quad xor 1, quad xor 2, then the mirrored half: after the two quad steps a
         // quad's lanes hold the same value, so i <-> 7 - i adds the other quad exactly as xor 4 would); no LDS round trips
 #pragma unroll
@@ -1291,6 +1280,12 @@ __global__ __launch_bounds__(256) void interpn_nearest_bwd(InterpBwdArgs ba) {
 
 }  // namespace
 
+// NRT_BWD_WC=0: d loc by the register-pipelined kernel (warp_dice_bwd_xm) instead of the wave-cache gather (A/B runs, tests)
+static bool nrt_bwd_wc() {
+    const char *e = getenv("NRT_BWD_WC");         // read per call: the tests run both kernels in one process
+    return !(e && e[0] == '0');
+}
+
 extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const float *grad_out, float *grad_vol,
                                    float *grad_loc, int ndim, const int *vol_shape, const int *out_shape, int channels,
                                    int batch, long long vol_batch_stride, long long loc_batch_stride, int loc_mode,
@@ -1367,7 +1362,10 @@ extern "C" int nrt_interpn_bwd_f32(const float *vol, const float *loc, const flo
         }
         if (G == 8 && ba.tg.x_march && !ba.gvol && ba.gloc && loc_mode != NRT_LOC_LINSPACE &&
             (unsigned long long)vol_batch_stride * 4ull < (1ull << 32) && (unsigned long long)ba.f.nout * channels * 4ull < (1ull << 32)) {
-            // d loc alone at 32 channels: the software-pipelined x-march kernel (warp_dice_bwd_xm with grad_out in place of d dice / d warped)
+            // d loc alone at 32 channels: the wave-cache gather (fused_wc.h, round 5) where it applies,
+            if (nrt_bwd_wc() && (((uintptr_t)vol | (uintptr_t)grad_out) & 15) == 0 && nrt_wc_interpn_supported(&ba.f, batch))
+                return nrt_wc_bwd_launch(&ba.f, batch, loc_mode, grad_out, nullptr, nullptr, 0.0f, ba.gloc, stream);
+            // else the software-pipelined x-march kernel (warp_dice_bwd_xm with grad_out in place of d dice / d warped)
             if (loc_mode == NRT_LOC_SHIFT)
                 hipLaunchKernelGGL((warp_dice_bwd_xm<NRT_LOC_SHIFT, false>), grid, dim3(256), 0, st, ba, grad_out, (const float *)nullptr, (const float *)nullptr, 0.0f);
             else
@@ -1592,6 +1590,8 @@ extern "C" int nrt_warp_dice_bwd_f32(const float *moving, const float *loc, cons
     else                                                                                                         \
         hipLaunchKernelGGL((warp_dice_bwd_rows<GG, NRT_LOC_ABSOLUTE>), grid, dim3(256), 0, st, ba, fixed, sums,  \
                            grad_dice, laplace_smoothing);
+    if (G == 8 && ba.tg.x_march && nrt_bwd_wc() && nrt_wc_interpn_supported(&ba.f, batch))
+        return nrt_wc_bwd_launch(&ba.f, batch, loc_mode, fixed, sums, grad_dice, laplace_smoothing, grad_loc, stream);
     static int xm_pipe = -1;                       // NRT_BWD_XM=0: the un-pipelined kernel on the same schedule (A/B runs)
     if (xm_pipe < 0) { const char *e = getenv("NRT_BWD_XM"); xm_pipe = e ? atoi(e) : 1; }
     // the pipelined kernel forms 32-bit byte offsets of rows and locations

@@ -72,6 +72,7 @@ typedef __attribute__((address_space(3))) volatile nrt_i4 wc_lds_vi4;
 typedef __attribute__((address_space(3))) volatile unsigned wc_lds_vu32;
 typedef unsigned wc_u3 __attribute__((ext_vector_type(3)));
 typedef unsigned wc_u4 __attribute__((ext_vector_type(4)));
+typedef float wc_f3 __attribute__((ext_vector_type(3)));
 
 // utils.py:139-153 for one dimension with three operations less than corner_1d and the same bits: l0 = floor(clip(p)) is
 // clip(floor(p)) for every float (the bounds are integers; NaN clips to 0 either way), and l0 + 1 >= 1 needs no lower clip
@@ -93,12 +94,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wc_rsrc(const void *base, unsi
     return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
+// what the backward form needs besides the forward's arguments
+struct WcBwd {
+    const float *sums, *gdice;   // BWD == 1: the forward's [B, 3, L] sums and d loss / d dice [B, L]
+    float eps;
+    float *gloc;                 // [B, nout, 3]
+};
+
 // one work item (a column of a 4 x 8 patch, or a piece of one) by one block.
-// DICE = false: the warp alone (nrt_interpn_f32 variant 10): no fixed map, no sums, no partials -- the same gather and blend
-template <int MODE, bool STORE, bool MM, bool FILL, bool DICE>
+// DICE = false: the warp alone (nrt_interpn_f32 variant 10): no fixed map, no sums, no partials -- the same gather and blend.
+// BWD (round 5): d loss / d loc on the same gather (what TF autodiff yields for utils.py:137-191 -- `floor` no gradient, `clip` on the
+// closed range -- composed with the soft Dice of metrics.py:476-482).  1: `fixed` is the fixed map and the gradient of the Dice wrt the
+// warped row is formed from the forward's sums; 2: `fixed` IS the incoming gradient row (the plain warp).  Same arithmetic, same order
+// as warp_dice_bwd_xm (backward.hip), which it replaces at 32 float32 channels.
+template <int MODE, bool STORE, bool MM, bool FILL, bool DICE, int BWD = 0>
 __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg, const float *__restrict__ fixed, float *__restrict__ fpart,
-                                        float *__restrict__ mpart, const XmWork &xw, char *wc_smem) {
+                                        float *__restrict__ mpart, const XmWork &xw, char *wc_smem, const WcBwd &bw = WcBwd{nullptr, nullptr, 0.0f, nullptr}) {
     constexpr int G = 8, L = 32;
+    static_assert(BWD == 0 || (DICE && !STORE && !MM), "the backward form reads a second row per voxel and stores the location gradient only");
     // the work item came through LDS (persistent blocks): tell the compiler that it is wave-uniform, the pass offsets below are SGPRs
     const int b = __builtin_amdgcn_readfirstlane(xw.b);
     const unsigned prow = (unsigned)__builtin_amdgcn_readfirstlane((int)xw.prow), ucol = (unsigned)__builtin_amdgcn_readfirstlane((int)xw.ucol);
@@ -135,6 +148,20 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     const __amdgpu_buffer_rsrc_t lres = wc_rsrc(MODE != NRT_LOC_LINSPACE ? (const char *)(a.loc + (long long)b * a.loc_bs) : volb, a.nout * 12u);
     const __amdgpu_buffer_rsrc_t fres = wc_rsrc(DICE ? (const char *)fixed + (long long)b * a.out_bs * 4ll : volb, outbytes);
     const __amdgpu_buffer_rsrc_t ores = wc_rsrc(STORE ? (const char *)a.out + (long long)b * a.out_bs * 4ll : volb, outbytes);
+    const __amdgpu_buffer_rsrc_t gres = wc_rsrc(BWD ? (const char *)(bw.gloc + (long long)b * a.nout * 3) : volb, a.nout * 12u);
+    const unsigned gl_lane = (p == 0 && yzvalid) ? qyz * 12u : 0xffffffffu;     // one lane of a voxel's eight stores its three components
+    // d dice / d warped = ca t + cb p for this lane's four labels (metrics.py:476-482 differentiated; divide_no_nan: zero)
+    float ca[4] = {0.0f, 0.0f, 0.0f, 0.0f}, cb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (BWD == 1) {
+        const float *sm = bw.sums + (long long)b * 3 * L;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int l = p * 4 + k;
+            const float num = 2.0f * sm[l] + bw.eps, den = sm[L + l] + sm[2 * L + l] + bw.eps;
+            const float gd = bw.gdice[(long long)b * L + l];
+            if (den != 0.0f) { ca[k] = 2.0f * gd / den; cb[k] = -2.0f * gd * num / (den * den); }
+        }
+    }
     const unsigned loc_lane = qyz * 12u, row_lane = (qyz * 8u + (unsigned)p) * 16u;
     const unsigned out_lane = yzvalid ? row_lane : 0xffffffffu;   // a store past the descriptor's size is dropped: edge patches need no branch
     const unsigned loc_step = qstep * 12u, row_step = qstep * 128u;
@@ -158,16 +185,17 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         unsigned xr[4], xd[4];       // entries 32 + g ... (n > 32 only)
         int n;                       // wave-uniform: entries of the fetch list
         int xq;                      // wave-uniform: output x-plane of the pass
+        float mk[3];                 // BWD: 1 where the location lies inside the closed range of the axis, else 0 (the slope of `clip`)
         bool oob;
         nrt_f4 T;                    // the fixed row
         nrt_f4 F[4], Fx[4];          // rows in flight
         float pn[3];                 // location of the pass that will use this state next
     };
     // a pass under management: from the tag read (m1a) to the fetch list (m1c)
-    struct Mg { float w0x, w0y, w0z; bool oob, miss; unsigned rid, slot, t1, t2, mytag; };
+    struct Mg { float w0x, w0y, w0z; bool oob, miss; unsigned rid, slot, t1, t2, mytag; float mk[3]; };
     Pass A, B;
     auto reset = [&](Pass &s) {
-        s.w0x = s.w0y = s.w0z = 0.f; s.n = 0; s.xq = x0; s.oob = false;
+        s.w0x = s.w0y = s.w0z = 0.f; s.n = 0; s.xq = x0; s.oob = false; s.mk[0] = s.mk[1] = s.mk[2] = 0.f;
         s.T = (nrt_f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s.F[i] = s.Fx[i] = (nrt_f4){0.f, 0.f, 0.f, 0.f}; s.lr[i] = s.xr[i] = WC_NOROW << 7; s.ld[i] = s.xd[i] = WC_TRASH_ROW * 128u; }
@@ -199,6 +227,11 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         wc_corner(py, mxy, i0y, i1y, m.w0y);
         wc_corner(pz, mxz, i0z, i1z, m.w0z);
         m.oob = FILL ? ((px < 0.0f) || (px > mxx) || (py < 0.0f) || (py > mxy) || (pz < 0.0f) || (pz > mxz)) : false;
+        if (BWD) {               // inside the closed range <=> clipping leaves the value alone (NaN: outside, as the comparisons have it)
+            m.mk[0] = (fminf(fmaxf(px, 0.0f), mxx) == px) ? 1.0f : 0.0f;
+            m.mk[1] = (fminf(fmaxf(py, 0.0f), mxy) == py) ? 1.0f : 0.0f;
+            m.mk[2] = (fminf(fmaxf(pz, 0.0f), mxz) == pz) ? 1.0f : 0.0f;
+        }
         const unsigned ix = cx1 ? i1x : i0x, iy = cy1 ? i1y : i0y, iz = cz1 ? i1z : i0z;      // corner p of the group's voxel
         m.rid = nrt_mad24(nrt_mad24(ix, SY, iy), SZ, iz);
         m.slot = ((ix & 3u) << 5) | ((iy & 3u) << 3) | (iz & 7u);
@@ -254,7 +287,9 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) { s.sl[2 * c] = (unsigned)sh[c] & 0xffffu; s.sl[2 * c + 1] = (unsigned)sh[c] >> 16; }
-        s.w0x = m.w0x; s.w0y = m.w0y; s.w0z = m.w0z; s.oob = m.oob; s.n = n; s.xq = x0 + pass;
+        s.w0x = m.w0x; s.w0y = m.w0y; s.w0z = m.w0z; s.oob = m.oob; s.n = n;
+        if (BWD) { s.mk[0] = m.mk[0]; s.mk[1] = m.mk[1]; s.mk[2] = m.mk[2]; }
+        s.xq = x0 + pass;
     };
     // M2: the row loads of the pass in s.  Four whatever n is (entries past n address bytes past the volume: no memory access): with
     // every load under a condition the compiler's in-order vmcnt count assumes none was issued and each wait covers the other state's
@@ -306,8 +341,9 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         wt2[2] = (nrt_f2){wxy1[0], wxy1[0]} * wz2;
         wt2[3] = (nrt_f2){wxy1[1], wxy1[1]} * wz2;
         nrt_f2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
+        constexpr bool BLEND = BWD != 2;                          // (the gradient of the plain warp does not need the warped row)
 #pragma unroll
-        for (int corner = 0; corner < 4; ++corner) {
+        for (int corner = 0; corner < (BLEND ? 4 : 0); ++corner) {
             const float wt = wt2[corner >> 1][corner & 1];
             const nrt_f2 w2 = {wt, wt};
             al = al + w2 * (nrt_f2){R[corner][0], R[corner][1]};
@@ -320,25 +356,51 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         m1b(m);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int corner = 4; corner < 8; ++corner) {
+        for (int corner = 4; corner < (BLEND ? 8 : 4); ++corner) {
             const float wt = wt2[corner >> 1][corner & 1];
             const nrt_f2 w2 = {wt, wt};
             al = al + w2 * (nrt_f2){R[corner][0], R[corner][1]};
             ah = ah + w2 * (nrt_f2){R[corner][2], R[corner][3]};
         }
         nrt_f4 acc = {al[0], al[1], ah[0], ah[1]};
-        if (FILL) {
+        float gacc[3] = {0.0f, 0.0f, 0.0f};
+        const unsigned xqcur = (unsigned)s.xq;
+        if (BWD) {
+            // d loss / d warped for this lane's four labels, then its slope along the three axes (interpn_core.h: loc_grad_rows)
+            nrt_f2 gl2 = {s.T[0], s.T[1]}, gh2 = {s.T[2], s.T[3]};           // BWD == 2: the incoming gradient row itself
+            if (BWD == 1) {
+                gl2 = __builtin_elementwise_fma((nrt_f2){cb[0], cb[1]}, al, (nrt_f2){ca[0], ca[1]} * gl2);
+                gh2 = __builtin_elementwise_fma((nrt_f2){cb[2], cb[3]}, ah, (nrt_f2){ca[2], ca[3]} * gh2);
+            }
+            if (FILL && s.oob) { gl2 = (nrt_f2){0.0f, 0.0f}; gh2 = gl2; }
+            loc_grad_rows(R, gl2, gh2, s.w0x, w1x, s.w0y, w1y, s.w0z, w1z, s.mk[0], s.mk[1], s.mk[2], gacc);
+            asm volatile("" : "+v"(gacc[0]), "+v"(gacc[1]), "+v"(gacc[2]));
+        } else {
+            if (FILL) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], s.oob, a.fill_f);
+                for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], s.oob, a.fill_f);
+            }
+            if (STORE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wc_u4, acc), ores, out_lane, (unsigned)s.xq * row_step, 2);
         }
-        if (STORE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wc_u4, acc), ores, out_lane, (unsigned)s.xq * row_step, 2);
-        // the Dice sums wait behind M1c: they cover the round trip of its list
+        // the Dice sums (the cross-lane sum of the gradient) wait behind M1c: they cover the round trip of its list
         const nrt_f4 Tcur = s.T;
         asm volatile("" : "+v"(acc));
         __builtin_amdgcn_sched_barrier(0);
         m1c(min(pass + 2, last), m, s);
         __builtin_amdgcn_sched_barrier(0);
-        if (DICE) {
+        if (BWD) {
+            // sum over the voxel's 8 lanes on the DPP network (quad xor 1, quad xor 2, then the mirrored half: after the two quad steps a
+            // quad's lanes hold the same value, so i <-> 7 - i adds the other quad exactly as xor 4 would)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float r = gacc[d];
+                r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0xB1, 0xF, 0xF, true));
+                r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x4E, 0xF, 0xF, true));
+                r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x141, 0xF, 0xF, true));
+                gacc[d] = r;
+            }
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(wc_u3, (wc_f3){gacc[0], gacc[1], gacc[2]}), gres, gl_lane, xqcur * loc_step, 0);
+        } else if (DICE) {
             nrt_f4 T = Tcur;
             if (MASKED) {
 #pragma unroll
@@ -358,7 +420,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
                 }
             }
         }
-        if (DICE) asm volatile("" : "+v"(stp_l), "+v"(stp_h), "+v"(stt_l), "+v"(stt_h), "+v"(spp_l), "+v"(spp_h));
+        if (DICE && !BWD) asm volatile("" : "+v"(stp_l), "+v"(stp_h), "+v"(stt_l), "+v"(stt_h), "+v"(spp_l), "+v"(spp_h));
         else asm volatile("" :: "v"(acc));
         __builtin_amdgcn_sched_barrier(0);
         fetch_loc(min(pass + 4, last), s);
@@ -383,11 +445,11 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     };
     if (npass > 0) {
         // (wave-uniform) edge patches mask the sums of the lanes whose voxel lies outside the volume
-        if (DICE && __builtin_amdgcn_ballot_w64(!yzvalid) != 0ull) march(std::true_type());
+        if (DICE && !BWD && __builtin_amdgcn_ballot_w64(!yzvalid) != 0ull) march(std::true_type());
         else march(std::false_type());
     }
 
-    if (!DICE) return;
+    if (!DICE || BWD) return;
     nrt_f4 stp = {stp_l[0], stp_l[1], stp_h[0], stp_h[1]}, stt = {stt_l[0], stt_l[1], stt_h[0], stt_h[1]},
            spp = {spp_l[0], spp_l[1], spp_h[0], spp_h[1]};
     // ---- block reduction (identical tree to warp_dice_tile / dice_soft_vec) ---------------------------------------------------
@@ -439,16 +501,9 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
 // first their own XCD's (its L2 holds the neighbouring columns), then the others'.  With one block per item the XCDs finish up to
 // 5 % apart (tools/block_trace.py: last block of an XCD at 1044 .. 1097 us) and the slots of a finished XCD idle; the items are the
 // same either way, every item writes its own partial row, so the sums do not depend on who computed what.
-template <int MODE, bool STORE, bool MM, bool FILL, bool DICE = true, bool PERSIST = false>
-__global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
-                                                        float *__restrict__ fpart, float *__restrict__ mpart, unsigned *__restrict__ queue) {
-    extern __shared__ __attribute__((aligned(16))) char wc_smem[];
-    if (!PERSIST) {
-        XmWork xw;
-        if (!xmarch_work(tg, a.O[0], xw)) return;
-        wc_item<MODE, STORE, MM, FILL, DICE>(a, tg, fixed, fpart, mpart, xw, wc_smem);
-        return;
-    }
+// the loop of a persistent block: ITEM(xw) computes one work item
+template <typename ITEM>
+__device__ __forceinline__ void wc_persistent_loop(const TileGeom &tg, int O0, unsigned *__restrict__ queue, ITEM item) {
     __shared__ unsigned s_next[2];
     const unsigned home = blockIdx.x % NRT_NXCD;
     for (;;) {
@@ -466,14 +521,41 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg
         const unsigned kk = s_next[0], jb = s_next[1];
         if (jb == 0xffffffffu) break;
         XmWork xw;
-        if (!xmarch_work_at(tg, a.O[0], kk, jb, xw)) continue;
-        wc_item<MODE, STORE, MM, FILL, DICE>(a, tg, fixed, fpart, mpart, xw, wc_smem);
+        if (!xmarch_work_at(tg, O0, kk, jb, xw)) continue;
+        item(xw);
     }
     // a block comes here once every list is exhausted and never touches the counters again: the last one to arrive zeroes them for the
     // slot's next launch (nrt_ring_slot)
     if (threadIdx.x == 0 && atomicAdd(&queue[NRT_NXCD * 16u], 1u) == gridDim.x - 1) {
         for (unsigned q = 0; q <= NRT_NXCD; ++q) queue[q * 16u] = 0u;
     }
+}
+
+template <int MODE, bool STORE, bool MM, bool FILL, bool DICE = true, bool PERSIST = false>
+__global__ __launch_bounds__(256, 2) void warp_dice_wc(InterpArgs a, TileGeom tg, const float *__restrict__ fixed,
+                                                        float *__restrict__ fpart, float *__restrict__ mpart, unsigned *__restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) char wc_smem[];
+    if (!PERSIST) {
+        XmWork xw;
+        if (!xmarch_work(tg, a.O[0], xw)) return;
+        wc_item<MODE, STORE, MM, FILL, DICE>(a, tg, fixed, fpart, mpart, xw, wc_smem);
+        return;
+    }
+    wc_persistent_loop(tg, a.O[0], queue, [&](const XmWork &xw) { wc_item<MODE, STORE, MM, FILL, DICE>(a, tg, fixed, fpart, mpart, xw, wc_smem); });
+}
+
+// d loss / d loc on the same gather (wc_item's BWD): `rows` = the fixed map (BWD 1) or the gradient arriving at the warped map (BWD 2)
+template <int MODE, bool FILL, int BWD, bool PERSIST>
+__global__ __launch_bounds__(256, 2) void warp_dice_wc_bwd(InterpArgs a, TileGeom tg, const float *__restrict__ rows, WcBwd bw,
+                                                            unsigned *__restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) char wc_smem[];
+    if (!PERSIST) {
+        XmWork xw;
+        if (!xmarch_work(tg, a.O[0], xw)) return;
+        wc_item<MODE, false, false, FILL, true, BWD>(a, tg, rows, nullptr, nullptr, xw, wc_smem, bw);
+        return;
+    }
+    wc_persistent_loop(tg, a.O[0], queue, [&](const XmWork &xw) { wc_item<MODE, false, false, FILL, true, BWD>(a, tg, rows, nullptr, nullptr, xw, wc_smem, bw); });
 }
 
 // persistent blocks pay off when there are more work items than resident blocks
@@ -556,7 +638,47 @@ int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, hipStream_t 
     return NRT_OK;
 }
 
+template <int MODE, bool FILL, int BWD>
+int launch_wc_bwd_inst(const InterpArgs &a, const TileGeom &tg, const float *rows, const WcBwd &bw, hipStream_t st) {
+    const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
+    unsigned *queue = (items > slots) ? nrt_ring_slot() : nullptr;
+    if (queue) {
+        if (hipFuncSetAttribute((const void *)warp_dice_wc_bwd<MODE, FILL, BWD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_BLOCK_BYTES) != hipSuccess)
+            return NRT_ERR_LAUNCH;
+        hipLaunchKernelGGL((warp_dice_wc_bwd<MODE, FILL, BWD, true>), dim3(nrt_xcd_grid(slots)), dim3(256), WC_BLOCK_BYTES, st, a, tg, rows, bw, queue);
+        return NRT_OK;
+    }
+    if (hipFuncSetAttribute((const void *)warp_dice_wc_bwd<MODE, FILL, BWD, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_BLOCK_BYTES) != hipSuccess)
+        return NRT_ERR_LAUNCH;
+    hipLaunchKernelGGL((warp_dice_wc_bwd<MODE, FILL, BWD, false>), dim3(items), dim3(256), WC_BLOCK_BYTES, st, a, tg, rows, bw, (unsigned *)nullptr);
+    return NRT_OK;
+}
+
+template <int MODE, bool FILL>
+int launch_wc_bwd_mode(const InterpArgs &a, const TileGeom &tg, const float *rows, const WcBwd &bw, hipStream_t st) {
+    return bw.sums ? launch_wc_bwd_inst<MODE, FILL, 1>(a, tg, rows, bw, st) : launch_wc_bwd_inst<MODE, FILL, 2>(a, tg, rows, bw, st);
+}
+
 }  // namespace
+
+int nrt_wc_bwd_launch(const void *args, int batch, int mode, const float *rows, const float *sums, const float *grad_dice, float eps,
+                      float *grad_loc, void *stream) {
+    const InterpArgs &a = *(const InterpArgs *)args;
+    if (mode != NRT_LOC_ABSOLUTE && mode != NRT_LOC_SHIFT) return NRT_ERR_INVALID_ARG;
+    TileGeom tg;
+    unsigned nblocks, grid;
+    const int t = xmarch_default_tune();
+    tile_geometry(a.O, 8, t, t, tg, nblocks);
+    xmarch_setup_mixed(a.O, batch, t, tg, grid);
+    hipStream_t st = nrt_stream(stream);
+    const WcBwd bw = {sums, grad_dice, eps, grad_loc};
+    int rc;
+    if (mode == NRT_LOC_ABSOLUTE) rc = a.has_fill ? launch_wc_bwd_mode<NRT_LOC_ABSOLUTE, true>(a, tg, rows, bw, st) : launch_wc_bwd_mode<NRT_LOC_ABSOLUTE, false>(a, tg, rows, bw, st);
+    else rc = a.has_fill ? launch_wc_bwd_mode<NRT_LOC_SHIFT, true>(a, tg, rows, bw, st) : launch_wc_bwd_mode<NRT_LOC_SHIFT, false>(a, tg, rows, bw, st);
+    if (rc != NRT_OK) return rc;
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
 
 bool nrt_wc_interpn_supported(const void *args, int batch) {
     const InterpArgs &a = *(const InterpArgs *)args;

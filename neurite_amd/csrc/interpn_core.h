@@ -283,6 +283,40 @@ __device__ __forceinline__ void xmarch_zero_rows(const TileGeom &tg, const XmWor
     }
 }
 
+// d (sum_c g_c warped_c) / d loc for one lane's four channels, from its pieces of the eight corner rows (corner = 4 cx + 2 cy + cz):
+// the inner product of g with every corner row, then per axis the weighted differences of corner pairs
+//   d/dx = m_x sum_{y,z} (wy wz) (dot[1,y,z] - dot[0,y,z])   and likewise for y and z   (m = 0 outside the volume: `clip` has no slope)
+// TF's autodiff of utils.py:137-191 fixes no order for this sum, so (unlike the forward blend) multiply-adds are fused and the pairs
+// of z-neighbours ride the packed instructions: 46 VALU instructions against 76 for the scalar form of rounds 2-4.
+// The caller sums the three components over the lanes of the voxel.
+__device__ __forceinline__ void loc_grad_rows(const nrt_f4 (&v)[8], nrt_f2 gl2, nrt_f2 gh2, float W0x, float W1x, float W0y, float W1y,
+                                              float W0z, float W1z, float Mx, float My, float Mz, float (&gacc)[3]) {
+    nrt_f2 D[4];                                                  // D[2 cx + cy] = {dot of corner cz = 0, of corner cz = 1}
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const nrt_f2 s0 = __builtin_elementwise_fma(gh2, (nrt_f2){v[2 * j][2], v[2 * j][3]}, gl2 * (nrt_f2){v[2 * j][0], v[2 * j][1]});
+        const nrt_f2 s1 = __builtin_elementwise_fma(gh2, (nrt_f2){v[2 * j + 1][2], v[2 * j + 1][3]}, gl2 * (nrt_f2){v[2 * j + 1][0], v[2 * j + 1][1]});
+        float d0 = s0[0] + s0[1], d1 = s1[0] + s1[1];
+        asm("" : "+v"(d0), "+v"(d1));                             // (two adds: the compiler's packed form of them costs three moves)
+        D[j] = (nrt_f2){d0, d1};
+    }
+    const nrt_f2 wz2 = {W0z, W1z};
+    const nrt_f2 wyz0 = (nrt_f2){W0y, W0y} * wz2, wyz1 = (nrt_f2){W1y, W1y} * wz2;     // wy wz: [y0z0, y0z1], [y1z0, y1z1]
+    const nrt_f2 wxz0 = (nrt_f2){W0x, W0x} * wz2, wxz1 = (nrt_f2){W1x, W1x} * wz2;     // wx wz
+    const nrt_f2 ax = __builtin_elementwise_fma(D[3] - D[1], wyz1, (D[2] - D[0]) * wyz0);
+    const nrt_f2 ay = __builtin_elementwise_fma(D[3] - D[2], wxz1, (D[1] - D[0]) * wxz0);
+    // z: sum_j (wx wy)[j] (D[j][1] - D[j][0]) = the difference of the halves of sum_j (wx wy)[j] D[j]
+    const float w00 = W0x * W0y, w01 = W0x * W1y, w10 = W1x * W0y, w11 = W1x * W1y;
+    nrt_f2 az = (nrt_f2){w00, w00} * D[0];
+    az = __builtin_elementwise_fma((nrt_f2){w01, w01}, D[1], az);
+    az = __builtin_elementwise_fma((nrt_f2){w10, w10}, D[2], az);
+    az = __builtin_elementwise_fma((nrt_f2){w11, w11}, D[3], az);
+    gacc[0] = Mx * (ax[0] + ax[1]);
+    gacc[1] = My * (ay[0] + ay[1]);
+    gacc[2] = Mz * (az[1] - az[0]);
+}
+
+
 // default x-march tune for 32-channel volumes: 4 x 8 (y,z) patches, regions of 8 x 2 patches = 32 x 16 voxels.  (8 x 4 until round 5:
 // with the round-5 gather the region shape is worth < 0.5 % at 4 volumes -- 16 x 2, 8 x 2, 4 x 4 within noise of each other -- but at
 // ONE volume an XCD owns 100 columns, and regions of 16 patches lose fewer neighbours at the XCD boundaries than regions of 32:

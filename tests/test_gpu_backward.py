@@ -431,6 +431,41 @@ def test_grad_loc_x_march_absolute_locations(dev, fill):
     close(N(l.grad), lo.grad.numpy(), 'grad_loc absolute fill=%r' % (fill,))
 
 
+@pytest.mark.parametrize('fill', [None, 0.0])
+def test_grad_loc_wave_cache_and_register_kernels_agree(dev, fill, monkeypatch):
+    """d loss / d loc at 32 channels on the x-march schedule has two kernels: the wave-cache gather (fused_wc.h, BWD; default) and
+    the register-pipelined one (warp_dice_bwd_xm; NRT_BWD_WC=0).  Same arithmetic in the same order: identical bits, for the fused
+    warp + Dice and for the plain warp, on a ragged shape with locations outside the volume, and both agree with the oracle"""
+    rng = np.random.default_rng(91)
+    B, S, L = 3, (21, 50, 117), 32
+    mov = rng.random((B,) + S + (L,)).astype(F)
+    fix = rng.random((B,) + S + (L,)).astype(F)
+    flow = (rng.standard_normal((B,) + S + (3,)) * 2.5).astype(F)
+    flow[1, 5:9] = 0                                                     # whole planes on the grid (weights exactly 0 / 1)
+    wl = rng.uniform(0.5, 1.5, (B, L)).astype(F)
+    w = rng.standard_normal((B,) + S + (L,)).astype(F)
+    got = {}
+    for wc in ('1', '0'):
+        monkeypatch.setenv('NRT_BWD_WC', wc)
+        f = G(flow, dev, True)
+        d = ne.fused.warp_dice(G(mov, dev), f, G(fix, dev), fill_value=fill, laplace_smoothing=0.05)
+        (-(d * G(wl, dev)).mean()).backward()
+        f2 = G(flow, dev, True)
+        out = ne.layers.SpatialTransformer(fill_value=fill)([G(mov, dev), f2])
+        (out * G(w, dev)).sum().backward()
+        got[wc] = (N(f.grad), N(f2.grad))
+    assert np.array_equal(got['1'][0], got['0'][0]), 'fused: %g' % np.abs(got['1'][0] - got['0'][0]).max()
+    assert np.array_equal(got['1'][1], got['0'][1]), 'plain: %g' % np.abs(got['1'][1] - got['0'][1]).max()
+    for b in (0, 1):
+        ref, vo, lo = _shift_oracle(mov[b], flow[b], fill)
+        dd = go.soft_dice(D64(fix[b:b + 1]), ref[None], 0.05)
+        (-(dd * D64(wl[b:b + 1])).sum() / (B * L)).backward()
+        close(got['1'][0][b], lo.grad.numpy(), 'fused grad_flow b%d' % b)
+        ref, vo, lo = _shift_oracle(mov[b], flow[b], fill)
+        (ref * D64(w[b])).sum().backward()
+        close(got['1'][1][b], lo.grad.numpy(), 'plain grad_flow b%d' % b)
+
+
 @pytest.mark.parametrize('C', [1, 3, 5, 8])
 @pytest.mark.parametrize('mode', ['1', '0'])
 def test_grad_vol_few_channels(dev, C, mode, monkeypatch):
