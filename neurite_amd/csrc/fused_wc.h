@@ -363,32 +363,34 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
             ah = ah + w2 * (nrt_f2){R[corner][2], R[corner][3]};
         }
         nrt_f4 acc = {al[0], al[1], ah[0], ah[1]};
-        float gacc[3] = {0.0f, 0.0f, 0.0f};
         const unsigned xqcur = (unsigned)s.xq;
-        if (BWD) {
-            // d loss / d warped for this lane's four labels, then its slope along the three axes (interpn_core.h: loc_grad_rows)
-            nrt_f2 gl2 = {s.T[0], s.T[1]}, gh2 = {s.T[2], s.T[3]};           // BWD == 2: the incoming gradient row itself
-            if (BWD == 1) {
-                gl2 = __builtin_elementwise_fma((nrt_f2){cb[0], cb[1]}, al, (nrt_f2){ca[0], ca[1]} * gl2);
-                gh2 = __builtin_elementwise_fma((nrt_f2){cb[2], cb[3]}, ah, (nrt_f2){ca[2], ca[3]} * gh2);
-            }
-            if (FILL && s.oob) { gl2 = (nrt_f2){0.0f, 0.0f}; gh2 = gl2; }
-            loc_grad_rows(R, gl2, gh2, s.w0x, w1x, s.w0y, w1y, s.w0z, w1z, s.mk[0], s.mk[1], s.mk[2], gacc);
-            asm volatile("" : "+v"(gacc[0]), "+v"(gacc[1]), "+v"(gacc[2]));
-        } else {
+        // (M1c below replaces the pass in s: what the gradient needs of this one)
+        const float cw0x = s.w0x, cw0y = s.w0y, cw0z = s.w0z, cmx = s.mk[0], cmy = s.mk[1], cmz = s.mk[2];
+        const bool coob = s.oob;
+        if (!BWD) {
             if (FILL) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = apply_fill(acc[c], s.oob, a.fill_f);
             }
             if (STORE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wc_u4, acc), ores, out_lane, (unsigned)s.xq * row_step, 2);
         }
-        // the Dice sums (the cross-lane sum of the gradient) wait behind M1c: they cover the round trip of its list
+        // the Dice sums / the gradient wait behind M1c: they cover the round trip of its list, and the fixed row (a stream from HBM, the
+        // slowest load of the pass, requested at the start of the last step) is first touched here
         const nrt_f4 Tcur = s.T;
         asm volatile("" : "+v"(acc));
         __builtin_amdgcn_sched_barrier(0);
         m1c(min(pass + 2, last), m, s);
         __builtin_amdgcn_sched_barrier(0);
         if (BWD) {
+            // d loss / d warped for this lane's four labels, then its slope along the three axes (interpn_core.h: loc_grad_rows)
+            nrt_f2 gl2 = {Tcur[0], Tcur[1]}, gh2 = {Tcur[2], Tcur[3]};       // BWD == 2: the incoming gradient row itself
+            if (BWD == 1) {
+                gl2 = __builtin_elementwise_fma((nrt_f2){cb[0], cb[1]}, (nrt_f2){acc[0], acc[1]}, (nrt_f2){ca[0], ca[1]} * gl2);
+                gh2 = __builtin_elementwise_fma((nrt_f2){cb[2], cb[3]}, (nrt_f2){acc[2], acc[3]}, (nrt_f2){ca[2], ca[3]} * gh2);
+            }
+            if (FILL && coob) { gl2 = (nrt_f2){0.0f, 0.0f}; gh2 = gl2; }
+            float gacc[3];
+            loc_grad_rows(R, gl2, gh2, cw0x, w1x, cw0y, w1y, cw0z, w1z, cmx, cmy, cmz, gacc);
             // sum over the voxel's 8 lanes on the DPP network (quad xor 1, quad xor 2, then the mirrored half: after the two quad steps a
             // quad's lanes hold the same value, so i <-> 7 - i adds the other quad exactly as xor 4 would)
 #pragma unroll
@@ -399,6 +401,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
                 r += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x141, 0xF, 0xF, true));
                 gacc[d] = r;
             }
+            // (one store per 8 passes with all lanes active, lane p keeping the sums of pass 8 k + p, measured the same 1.19 ms)
             __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(wc_u3, (wc_f3){gacc[0], gacc[1], gacc[2]}), gres, gl_lane, xqcur * loc_step, 0);
         } else if (DICE) {
             nrt_f4 T = Tcur;

@@ -8,7 +8,7 @@ B, S, L = int(os.environ.get('BB', 4)), (160, 160, 160), 32
 from neurite_amd import synth
 mov, fix, flow = synth.cfg2_batch(B, S[0], L, device=dev, seed0=100)     # bench.py's maps and field
 flow = flow.clone().requires_grad_(True)
-for wc in ('1', '0', '1', '0'):
+for wc in os.environ.get('WCS', '1 0 1 0').split():
     os.environ['NRT_BWD_WC'] = wc
     d = ne.fused.warp_dice(mov, flow, fix)
     loss = -d.mean()
