@@ -471,7 +471,9 @@ int nrt_dice_soft_bwd_norm_f32(const float *y_true, const float *y_pred, const f
                                float *grad_true, void *stream);
 /* Fused backward of nrt_warp_dice_soft_f32 wrt the displacement / location field: rebuilds the warped row in
  * registers, forms d dice / d warped from `sums` (as returned by the forward) and grad_dice [batch, L], and writes
- * grad_loc [batch, out_shape, 3] only.  `warped` and its gradient never touch HBM. */
+ * grad_loc [batch, out_shape, 3] only.  `warped` and its gradient never touch HBM.  At 32 float32 labels on volumes that take the
+ * forward's x-march schedule it runs on the forward's wave-cache gather (csrc/fused_wc.h, BWD; environment NRT_BWD_WC=0 selects the
+ * register-pipelined kernel of rounds 2-4: same bits); the grad_loc of nrt_interpn_bwd_f32 at 32 channels likewise. */
 int nrt_warp_dice_bwd_f32(const float *moving, const float *loc, const float *fixed, const float *sums,
                           const float *grad_dice, float *grad_loc, const int *vol_shape, const int *out_shape,
                           int nlabels, int batch, long long loc_batch_stride, int loc_mode, int has_fill,
