@@ -466,6 +466,47 @@ def test_grad_loc_wave_cache_and_register_kernels_agree(dev, fill, monkeypatch):
         close(got['1'][1][b], lo.grad.numpy(), 'plain grad_flow b%d' % b)
 
 
+def test_fused_backward_at_bench_size(dev, monkeypatch):
+    """BASELINE config 2 / 4 size (160^3 x 32 one-hot maps, the bench's smooth field), two volumes: properties of d (-mean Dice) / d field
+    that do not need the (slow) oracle -- (i) the wave-cache and the register-pipelined kernels give the same bits; (ii) the directional
+    derivative along a random +-1 direction matches the central difference of the FORWARD kernel (the loss is piecewise smooth in the
+    field: 2 h = 2 % of the voxels cross a cell face per axis, hence the 2 % tolerance), also along the gradient itself; (iii) the gradient of the plain warp is linear in
+    the incoming gradient"""
+    B, S, L = 2, 160, 32
+    mov, fix, trf = synth.cfg2_batch(B, S, L, device=dev, seed0=100)
+    got = {}
+    for wc in ('1', '0'):
+        monkeypatch.setenv('NRT_BWD_WC', wc)
+        f = trf.clone().requires_grad_(True)
+        (-ne.fused.warp_dice(mov, f, fix).mean()).backward()
+        got[wc] = f.grad.clone()
+    monkeypatch.delenv('NRT_BWD_WC')
+    assert torch.equal(got['1'], got['0']), float((got['1'] - got['0']).abs().max())
+    g = got['1']
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    d = (torch.randint(0, 2, trf.shape, device=dev, generator=gen).float() * 2 - 1)
+    h = 1e-2
+    for direction in (d, g / g.abs().max()):                       # (measured: 0.35 % and 0.25 % apart)
+        with torch.no_grad():
+            lp = -ne.fused.warp_dice(mov, trf + h * direction, fix).double().mean()
+            lm = -ne.fused.warp_dice(mov, trf - h * direction, fix).double().mean()
+        fd = float((lp - lm) / (2 * h))
+        an = float((g.double() * direction.double()).sum())
+        assert abs(an) > 1e-6 and abs(fd - an) <= 0.02 * abs(an), (fd, an)
+    # plain warp: d out / d field is linear in grad_out (a location outside the volume has gradient 0 either way)
+    w1 = torch.randn(mov.shape, device=dev, generator=gen)
+    w2 = torch.randn(mov.shape, device=dev, generator=gen)
+    st = ne.layers.SpatialTransformer()
+    grads = []
+    for w in (w1, w2, w1 + 2 * w2):
+        f = trf.clone().requires_grad_(True)
+        (st([mov, f]) * w).sum().backward()
+        grads.append(f.grad)
+    lin = grads[0] + 2 * grads[1]
+    assert float((grads[2] - lin).abs().max()) <= 1e-4 * float(lin.abs().max())
+
+
 @pytest.mark.parametrize('C', [1, 3, 5, 8])
 @pytest.mark.parametrize('mode', ['1', '0'])
 def test_grad_vol_few_channels(dev, C, mode, monkeypatch):
