@@ -194,6 +194,11 @@ int nrt_dice_from_sums_f32(const float *sums, int nlabels, int batch, float lapl
 int nrt_dice_mean_pair_f32(const float *dice, const float *weights, int nlabels, int batch,
                            int weights_per_batch, float *out2, void *stream);
 
+/* The same launch writing three floats: [sum, count, sum / count] -- a process that is alone (no collective to wait for) reads the mean
+ * K.mean(dice * weights) of neurite/tf/metrics.py:499-510 from out3[2] without launching the division. */
+int nrt_dice_mean_f32(const float *dice, const float *weights, int nlabels, int batch, int weights_per_batch, float *out3,
+                      void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused SpatialTransformer + soft Dice  (the BASELINE "interpn+Dice" pipeline in one pass)
  * replaces: SpatialTransformer (see nrt_interpn_f32, NRT_LOC_SHIFT) immediately followed by

@@ -48,6 +48,7 @@ _SIGNATURES = {
     'nrt_dice_hard_label_i32': (_i, [_vp, _vp, _ll, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'nrt_dice_from_sums_f32': (_i, [_vp, _i, _i, _f, _vp, _vp]),
     'nrt_dice_mean_pair_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'nrt_dice_mean_f32': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'nrt_wcce_workspace_bytes': (_sz, [_ll, _i]),
     'nrt_seg_loss_supported': (_i, [_i]),
     'nrt_seg_loss_workspace_bytes': (_sz, [_ll, _i, _i]),

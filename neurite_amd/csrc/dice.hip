@@ -794,7 +794,7 @@ extern "C" int nrt_dice_from_sums_f32(const float *sums, int nlabels, int batch,
 // One block, fixed order (thread i owns entries i, i + 256, ...; LDS tree) => bit-reproducible.
 namespace {
 __global__ __launch_bounds__(256) void dice_mean_pair(const float *__restrict__ dice, const float *__restrict__ weights,
-                                                      int n, int wmod, float *__restrict__ out2) {
+                                                      int n, int wmod, float *__restrict__ out2, int with_mean) {
     __shared__ double sl[256];
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -808,7 +808,10 @@ __global__ __launch_bounds__(256) void dice_mean_pair(const float *__restrict__ 
         if ((int)threadIdx.x < s) sl[threadIdx.x] += sl[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out2[0] = (float)sl[0]; out2[1] = (float)n; }
+    if (threadIdx.x == 0) {
+        out2[0] = (float)sl[0]; out2[1] = (float)n;
+        if (with_mean) out2[2] = (float)sl[0] / (float)n;       // the float32 division a single rank would otherwise launch for
+    }
 }
 }  // namespace
 
@@ -818,7 +821,18 @@ extern "C" int nrt_dice_mean_pair_f32(const float *dice, const float *weights, i
     const long long n = (long long)nlabels * batch;
     if (n >= (1ll << 31)) return NRT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(dice_mean_pair, dim3(1), dim3(256), 0, nrt_stream(stream), dice, weights, (int)n,
-                       weights_per_batch ? (int)n : nlabels, out2);
+                       weights_per_batch ? (int)n : nlabels, out2, 0);
+    NRT_CHECK_LAUNCH();
+    return NRT_OK;
+}
+
+extern "C" int nrt_dice_mean_f32(const float *dice, const float *weights, int nlabels, int batch, int weights_per_batch,
+                                 float *out3, void *stream) {
+    if (!dice || !out3 || nlabels < 1 || batch < 1) return NRT_ERR_INVALID_ARG;
+    const long long n = (long long)nlabels * batch;
+    if (n >= (1ll << 31)) return NRT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dice_mean_pair, dim3(1), dim3(256), 0, nrt_stream(stream), dice, weights, (int)n,
+                       weights_per_batch ? (int)n : nlabels, out3, 1);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
 }

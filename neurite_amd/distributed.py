@@ -82,7 +82,11 @@ def all_reduce_mean_dice(local_dice, weights=None, group=None, async_op=False):
     if d.device.type == 'cuda' and d.dim() == 2 and not (torch.is_grad_enabled() and d.requires_grad):
         # one launch writes [sum of dice * weights, number of entries] (csrc/dice.hip: dice_mean_pair) -- the buffer the
         # collective reduces; no sum / cat / scale launches around a ~1 ms step
-        buf = _mean_pair(d, weights)
+        buf3 = _mean3(d, weights)
+        if w == 1 and not (dist.is_available() and dist.is_initialized()):
+            # alone: no collective to wait for, and the kernel has already divided
+            return PendingMean(buf3[:2], None, value=buf3[2]) if async_op else buf3[2]
+        buf = buf3[:2]
     else:
         # host tensors (the gloo tests of the collective logic), inputs of another rank than [B, L], and values a gradient is being
         # recorded for (the kernel's output carries no autograd graph): plain torch arithmetic
@@ -96,7 +100,7 @@ def mean_dice_pair(local_dice, weights=None):
     """[sum of dice * weights, number of entries] of this rank's [B_local, L] Dice values as a 2-float device buffer
     (one kernel launch, csrc/dice.hip: dice_mean_pair) -- the operand of `all_reduce_mean_pair`.  Split from the
     collective so that the compute part of a step can be captured in a hipGraph (bench.py --graph)."""
-    return _mean_pair(local_dice, weights)
+    return _mean3(local_dice, weights)[:2]
 
 
 def all_reduce_mean_pair(buf, group=None, async_op=False):
@@ -112,7 +116,8 @@ def all_reduce_mean_pair(buf, group=None, async_op=False):
     return buf[0] / buf[1]
 
 
-def _mean_pair(dice, weights):
+def _mean3(dice, weights):
+    """[sum of dice * weights, number of entries, their quotient] as a 3-float device buffer, one launch"""
     from . import _lib
     lib = _lib.lib()
     dev = _lib.require_device(dice)
@@ -129,11 +134,10 @@ def _mean_pair(dice, weights):
             per_batch = 1
         else:
             raise ValueError('weights must be [L], [1, L] or [B, L]; got %s for dice %s' % (tuple(wt.shape), (B, L)))
-    buf = torch.empty(2, dtype=torch.float32, device=dev)
+    buf = torch.empty(3, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.nrt_dice_mean_pair_f32(_lib.ptr(d), _lib.ptr(wt), int(L), int(B), per_batch, _lib.ptr(buf),
-                                        _lib.stream_ptr(dev))
-    _lib.check(rc, 'nrt_dice_mean_pair_f32')
+        rc = lib.nrt_dice_mean_f32(_lib.ptr(d), _lib.ptr(wt), int(L), int(B), per_batch, _lib.ptr(buf), _lib.stream_ptr(dev))
+    _lib.check(rc, 'nrt_dice_mean_f32')
     return buf
 
 

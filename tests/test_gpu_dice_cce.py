@@ -489,6 +489,10 @@ def test_mean_dice_pair_kernel(dev):
             np.testing.assert_allclose(pair[0], want, rtol=1e-6)
             got = float(nd.all_reduce_mean_dice(G(d, dev), None if w is None else w))
             np.testing.assert_allclose(got, want / (B * L), rtol=1e-6)
+            # a process that is alone reads the quotient the kernel formed (nrt_dice_mean_f32): the float32 division of the pair, bit for bit
+            assert np.float32(got) == np.float32(pair[0]) / np.float32(pair[1])
+            pend = nd.all_reduce_mean_dice(G(d, dev), None if w is None else w, async_op=True)
+            assert float(pend.result()) == got
     # run-to-run bit-identical (fixed summation order)
     d = G(rng.random((64, 32)).astype(F), dev)
     a, b = N(nd.mean_dice_pair(d)), N(nd.mean_dice_pair(d))
