@@ -14,17 +14,18 @@ through neurite_amd.fused.warp_dice, --unfused the eager two-kernel pipeline (de
 The JSON line always carries all three (`fused_pipeline` = the timed one, `fused_direct_pipeline`, `dropin_pipeline`) plus
 `roofline_dropin` (the stand-alone interpn kernel), `config2_batch1`, `bf16_storage` and `default_args_pipeline` (the reference's
 default range asserts on), measured in the same process.
-Workload: BASELINE config 2 (SpatialTransformer + Dice, 160^3 x 32 one-hot, fp32); every GPU holds
-`--batch-per-gpu` volumes (default 4 = config 4's sharding of B=32 over 8 GPUs), so scaling is weak
-and N=8 is exactly config 4.  1 voxel = 1 spatial output location.
+Workload: BASELINE config 2 / 4 (SpatialTransformer + Dice, 160^3 x 32 one-hot, fp32).  N = 1: a step is 4 volumes (config 4's
+per-GPU share at N = 8); the line also carries `value_strong_b32`, all 32 volumes of config 4 on the one GPU.  N > 1: the parsed line
+is BASELINE config 4 AS WRITTEN -- global batch 32 fixed, 32 / N volumes per rank, "scaling": "strong" ("total voxels/s =
+32 V / wall-time at world sizes 1, 2, 4, 8") -- and the weak run (`--batch-per-gpu` volumes on every rank) is the extra key
+`weak_per_gpu`; `--weak` swaps the two.  1 voxel = 1 spatial output location.
 
     python bench.py                       # 1 GPU
     python bench.py --gpus N              # N GPUs of this node: re-launches itself under torch.distributed.run, one rank per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W            # the same, launched by the driver
-    python bench.py --gpus N --global-batch 32    # BASELINE config 4 as SURVEY 8(d) defines it: B = 32 fixed, 32 / N volumes per GPU,
-                                                  # "scaling": "strong" (the default line is weak: 4 volumes per GPU whatever N is, and
-                                                  # carries the strong figure of the same run as `cfg4_strong`)
+    python bench.py --gpus N --weak       # N > 1 with 4 volumes per GPU whatever N is ("scaling": "weak") as the parsed line
+    python bench.py --global-batch 32     # N = 1 with all 32 volumes of config 4 as the parsed line
 
 Rank 0 prints ONE JSON line on stdout.  `roofline` is the dominant kernel: achieved = algorithmic bytes per
 launch / its average duration measured with HIP events inside the timed region.  Algorithmic bytes per
@@ -67,7 +68,12 @@ def parse():
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong scaling (BASELINE config 4: 32): the global batch is fixed and split over the ranks; 0 = weak scaling '
                          'with --batch-per-gpu volumes on every GPU')
-    ap.add_argument('--no-strong', action='store_true', help='skip the cfg4_strong measurement of the default (weak) run')
+    ap.add_argument('--weak', action='store_true',
+                    help='N > 1 only: make the weak-scaling run (--batch-per-gpu volumes on every rank) the parsed line; by default an N > 1 '
+                         'run is BASELINE config 4 as written (global batch 32, 32 / N per rank, "scaling": "strong") and carries the weak '
+                         'figure as `weak_per_gpu`')
+    ap.add_argument('--no-strong', action='store_true',
+                    help='skip the second scaling mode of the run (cfg4_strong at N = 1, weak_per_gpu at N > 1)')
     ap.add_argument('--stub-step', action='store_true',
                     help='CPU-only self-test of the launch / timing / JSON plumbing: gloo ranks, a stub step instead of the kernels '
                          '(tests/test_distributed_cpu.py); never a measurement')
@@ -757,6 +763,20 @@ def self_launch(n):
     print(lines[-1], flush=True)
 
 
+CFG4_GLOBAL_BATCH = 32          # BASELINE config 4: "Batch=32 of 160^3 volumes ... sharded across 8 x MI355X"
+
+
+def default_global_batch(global_batch, weak, world):
+    """The global batch of a run that did not name one.  N > 1: BASELINE config 4 as SURVEY 8(d) words it -- 32 volumes in TOTAL, 32 / N per
+    rank -- is the parsed line ("scaling": "strong"), so that the driver's value(N) / value(1) is the strong-scaling ratio; `--weak` (or a
+    world that does not divide 32) keeps --batch-per-gpu volumes on every rank.  N = 1 keeps the 4-volume step (config 4's per-GPU share at
+    N = 8, the workload `metric` is quoted on) and carries the 32-volume figure as `value_strong_b32`.  (The reference's only multi-device
+    code, neurite/tf/utils/model.py:298-321, splits ONE batch over the devices: strong scaling.)"""
+    if global_batch or weak or world == 1 or CFG4_GLOBAL_BATCH % world:
+        return global_batch
+    return CFG4_GLOBAL_BATCH
+
+
 def batch_plan(global_batch, batch_per_gpu, world):
     """(volumes per rank, global batch, scaling) of a run: `--global-batch G` is BASELINE config 4 as written (G volumes in total,
     G / N per rank, "strong"); otherwise every rank holds `--batch-per-gpu` volumes ("weak").  A global batch the ranks do not divide
@@ -778,7 +798,7 @@ def stub_main(args, rank, world):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
         group = dist
-    B, global_batch, scaling = batch_plan(args.global_batch, args.batch_per_gpu, world)
+    B, global_batch, scaling = batch_plan(default_global_batch(args.global_batch, args.weak, world), args.batch_per_gpu, world)
 
     def step(events):
         time.sleep(0.002 * B)
@@ -828,6 +848,8 @@ def main():
     from neurite_amd import synth
 
     # strong scaling: BASELINE config 4, the global batch is fixed; weak: every GPU holds the same number of volumes
+    named_batch = args.global_batch                      # what the command line named (0: the default of this world size applies)
+    args.global_batch = default_global_batch(args.global_batch, args.weak, world)
     B = batch_plan(args.global_batch, args.batch_per_gpu, world)[0]
     S, L = args.size, args.labels
     V = S ** 3
@@ -989,12 +1011,13 @@ def main():
         except Exception as e:   # noqa
             log('default-argument run failed: %s' % e)
             r_def = None
-    # BASELINE config 4 as SURVEY 8(d) words it -- B = 32 FIXED, 32 / N volumes per rank -- measured in the same run next to the weak
-    # line: the 8-vs-1 ratio of these values is the strong-scaling figure (32 volumes on one GPU: 35 GB of its 288)
+    # The other scaling mode of the same run, next to the parsed line.  N = 1 (parsed line: 4 volumes): BASELINE config 4 as SURVEY 8(d)
+    # words it -- B = 32 FIXED, all 32 volumes on this GPU (35 GB of its 288) -- so that value(N) / value_strong_b32 is the strong-scaling
+    # figure.  N > 1 (parsed line: global batch 32, 32 / N per rank): the weak run, --batch-per-gpu volumes on every rank.
     r_strong, Bs = None, 0
-    if not args.global_batch and not args.no_strong and not args.unfused and not args.rough and 32 % world == 0 and S == 160:
+    if not args.global_batch and not args.no_strong and not args.unfused and not args.rough and CFG4_GLOBAL_BATCH % world == 0 and S == 160:
         try:
-            Bs = 32 // world
+            Bs = CFG4_GLOBAL_BATCH // world
             if Bs == B:
                 smov, sfix, strf = mov, fix, trf
             else:
@@ -1006,6 +1029,20 @@ def main():
         except Exception as e:   # noqa
             log('cfg4_strong run failed on rank %d: %s' % (rank, e))
             r_strong = None
+    r_weak, Bw = None, args.batch_per_gpu
+    if args.global_batch and not named_batch and not args.no_strong and not args.unfused and not args.rough:
+        try:
+            if Bw == B:
+                r_weak = r_main                          # (N = 8: config 4's shard IS 4 volumes per rank)
+            else:
+                wmov, wfix, wtrf = synth.cfg2_batch(Bw, S, L, device=dev, seed0=100 + 3 * rank * Bw)
+                w_refsig = make_steps(wmov, wfix, wtrf)[2]
+                r_weak = timed(w_refsig, o_steps, 2, dist, dev)
+                del wmov, wfix, wtrf, w_refsig
+                torch.cuda.empty_cache()
+        except Exception as e:   # noqa
+            log('weak_per_gpu run failed on rank %d: %s' % (rank, e))
+            r_weak = None
     unet_multi = None
     if dist is not None and not args.no_unet:
         # "3D UNet fwd ms at 1/2/4/8 GPU": every rank runs the config-3 forward on its own volume (data parallel inference);
@@ -1097,7 +1134,8 @@ def main():
             'pipeline': ('reference_api' if not args.direct else 'fused_direct') if fused else 'unfused',
             'step_launch': 'one hipGraph replay per step (--graph)' if args.graph else 'direct kernel launches',
             'parallelism': 'dp%d (batch-sharded, one RCCL all-reduce of 2 floats per step)' % world,
-            'scaling_mode': 'strong: --global-batch %d split over the ranks' % args.global_batch if args.global_batch else 'weak: --batch-per-gpu %d on every rank' % B,
+            'scaling_mode': ('strong: global batch %d%s split over the ranks' % (args.global_batch, '' if named_batch else ' (BASELINE config 4, the default of an N > 1 run)'))
+                            if args.global_batch else 'weak: --batch-per-gpu %d on every rank' % B,
             'mean_dice': round(float(m), 6),
         },
         'roofline': {
@@ -1143,6 +1181,18 @@ def main():
             'value': round(32 * V * o_steps / r_strong['elapsed'] / 1e6, 2), 'unit': 'Mvoxels/s',
             'ms_per_step': round(r_strong['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(r_strong['k0_ms'], 4),
             'mean_dice': round(r_strong['mean'], 6)}
+        # N = 1: the denominator of the driver's strong-scaling ratio sits in the head of the line
+        out['value_strong_b32'] = out['cfg4_strong']['value']
+    if r_weak is not None:
+        w_steps = args.steps if r_weak is r_main else o_steps
+        out['weak_per_gpu'] = {
+            'what': 'the weak-scaling run next to the parsed (strong, global batch %d) line: %d volumes on each of %d GPUs, the reference-signature '
+                    'pipeline, one all-reduce per step; %d steps%s' % (args.global_batch, Bw, world, w_steps,
+                                                                        ' (this world size: the same run as the parsed line)' if r_weak is r_main else ''),
+            'scaling': 'weak', 'global_batch': Bw * world, 'volumes_per_gpu': Bw, 'n_gpus': world, 'rccl_ranks': r_weak['ranks'],
+            'value': round(world * Bw * V * w_steps / r_weak['elapsed'] / 1e6, 2), 'unit': 'Mvoxels/s',
+            'ms_per_step': round(r_weak['elapsed'] / w_steps * 1e3, 4), 'kernel_ms': round(r_weak['k0_ms'], 4),
+            'mean_dice': round(r_weak['mean'], 6)}
     if r_b1 is not None:
         rf, ru = r_b1
         out['config2_batch1'] = {
