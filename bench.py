@@ -725,9 +725,12 @@ def timed(step, steps, warmup, dist=None, dev=None):
             'mean': None if m is None else float(m)}
 
 
-def lookup_traffic(tfile, timed_kernel, B):
+def lookup_traffic(tfile, timed_kernel, B, ids=None):
     """HBM bytes per launch recorded for EXACTLY this kernel instantiation and batch (profiles/hbm_traffic.json, written by
-    tools/update_hbm_traffic.py from rocprofv3 --pmc passes), or (None, why).  Counters of another instantiation are never quoted."""
+    tools/update_hbm_traffic.py from rocprofv3 --pmc passes), or (None, why).  Counters of another instantiation are never quoted, and
+    neither are counters of another BINARY: an entry carries the id of the library it was measured on and of the gather's sources, and
+    `ids` = (id the loaded library reports, id of the tree's build, id of the tree's gather sources) must say that the loaded library is
+    the tree's build and that the gather's sources are still the entry's (a kernel edit that keeps the name does not keep the bytes)."""
     if not timed_kernel:
         return None, 'not recorded for the unfused pipeline (see roofline_dropin; profiles/hbm_traffic.json lists interpn_zrun_c32)'
     try:
@@ -736,7 +739,19 @@ def lookup_traffic(tfile, timed_kernel, B):
         ent = None
     if ent is None:
         return None, 'no counter pass recorded under profiles/hbm_traffic.json for the timed kernel %r at batch %d' % (timed_kernel, B)
-    return ent['bytes_per_launch'], 'static: profiles/hbm_traffic.json[%r][B%d] (%s)' % (timed_kernel, B, ent.get('source', 'rocprofv3 --pmc pass'))
+    if ids is not None:
+        lib_id, tree_id, gather_id = ids
+        if lib_id != tree_id:
+            return None, 'the loaded library (build id %s) is not the build of this tree (%s): recorded counters not quoted' % (lib_id, tree_id)
+        if 'gather_sources_id' in ent:
+            if ent['gather_sources_id'] != gather_id:
+                return None, ('stale: profiles/hbm_traffic.json[%r][B%d] was measured on gather sources %s (library %s), this library is built from %s'
+                              % (timed_kernel, B, ent['gather_sources_id'], ent.get('build_id'), gather_id))
+        elif ent.get('build_id') != lib_id:
+            return None, ('stale: profiles/hbm_traffic.json[%r][B%d] carries %s, the loaded library is %s'
+                          % (timed_kernel, B, ('build id %s' % ent['build_id']) if ent.get('build_id') else 'no build id (recorded before round 6)', lib_id))
+    return ent['bytes_per_launch'], 'static: profiles/hbm_traffic.json[%r][B%d] (%s; gather sources %s)' % (
+        timed_kernel, B, ent.get('source', 'rocprofv3 --pmc pass'), ent.get('gather_sources_id', ent.get('build_id')))
 
 
 def self_launch(n):
@@ -1084,7 +1099,9 @@ def main():
         from neurite_amd import _lib
         timed_kernel = _lib.lib().nrt_warp_dice_kernel_name(_lib.ints([S] * 3), _lib.ints([S] * 3), L, B, _lib.LOC_SHIFT, 0, 0, 0,
                                                             int(args.tune)).decode()
-    traffic, traffic_src = lookup_traffic(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'), timed_kernel, B)
+    from neurite_amd import _lib, build as nbuild
+    build_ids = (_lib.lib().nrt_build_id().decode(), nbuild.build_id(), nbuild.gather_sources_id())
+    traffic, traffic_src = lookup_traffic(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'), timed_kernel, B, build_ids)
 
     # drop-in (reference-signature) pipeline figures, whichever form was the timed one
     d_elapsed, d_steps, d_k0, d_k1, d_m = (o_elapsed, o_steps, o_k0, o_k1, o_m) if fused else (elapsed, args.steps, k0_ms, k1_ms, m)
@@ -1148,6 +1165,7 @@ def main():
             'traffic': traffic,
             'traffic_source': traffic_src,
             'timed_kernel': timed_kernel,
+            'library_build_id': build_ids[0],
             'algorithmic_bytes_per_launch': alg_bytes,
             'avg_launch_ms': round(kms, 4),
             'avg_launch_ms_covers': ('HIP events around the gather launch and, for the fused form, the two launches of its Dice second '

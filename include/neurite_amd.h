@@ -45,6 +45,18 @@ int nrt_abi_version(void);
 const char *nrt_build_id(void);
 /* Name of the GPU architecture the library was compiled for ("gfx950"). */
 const char *nrt_target_arch(void);
+/* Library state on the CURRENT device (no reference counterpart: TensorFlow owns its runtime state, neurite/tf has none).
+ * Kernels that coordinate their blocks through atomic counters (the persistent gather's work lists, the one-launch weighted
+ * cross-entropy) keep them in a device-resident pool of self-cleaning slots: one slot per stream for eager launches, a slot of its own
+ * for every launch recorded during stream capture (a captured graph may be replayed beside any eager work).
+ *   nrt_init            resolves the pool's address; optional (the first launch does it), but call it once per device BEFORE the first
+ *                       stream capture so that nothing but launches happens inside the capture.
+ *   nrt_counters_reset  zero-fills the pool on `stream`: recovery after a kernel was aborted mid-flight (nothing else leaves a slot
+ *                       dirty); not needed in normal operation, must not run beside launches of this library.
+ *   nrt_counters_slot_index   index of the slot a launch on `stream` would use right now (-1: pool exhausted); diagnostic / tests. */
+int nrt_init(void);
+int nrt_counters_reset(void *stream);
+int nrt_counters_slot_index(void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * interpn / SpatialTransformer / Resize

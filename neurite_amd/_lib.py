@@ -32,6 +32,9 @@ _SIGNATURES = {
     'nrt_abi_version': (_i, []),
     'nrt_target_arch': (C.c_char_p, []),
     'nrt_build_id': (C.c_char_p, []),
+    'nrt_init': (_i, []),
+    'nrt_counters_reset': (_i, [_vp]),
+    'nrt_counters_slot_index': (_i, [_vp]),
     'nrt_interpn_f32': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _vp]),
     'nrt_interpn_f32_ex': (_i, [_vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _i, _i, _i, _f, _i, _i, _vp]),
     'nrt_interpn_add_f32': (_i, [_vp, _vp, _vp, _vp, _i, _ip, _ip, _i, _i, _ll, _ll, _ll, _i, _i, _f, _vp]),
@@ -171,7 +174,20 @@ def require_device(*tensors):
             dev = t.device
         elif t.device != dev:
             raise NeuriteAmdError('tensors live on different devices: %s vs %s' % (dev, t.device))
+    if dev is not None and dev.index not in _initialised:
+        init_device(dev)
     return dev
+
+
+_initialised = set()
+
+
+def init_device(dev):
+    """nrt_init() on `dev`, once: the library resolves the address of its counter pool now -- outside any stream capture, where nothing
+    but launches should happen (include/neurite_amd.h)."""
+    with torch.cuda.device(dev):
+        check(lib().nrt_init(), 'nrt_init')
+    _initialised.add(dev.index)
 
 
 def stream_ptr(device):

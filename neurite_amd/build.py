@@ -49,9 +49,27 @@ def _read(path):
         return f.read()
 
 
+_compiler = None
+
+
+def compiler_version():
+    """first line of `hipcc --version` that names the HIP / clang build.  Part of the build id: several kernels rely on
+    hand-placed hazard padding and hand-counted waits around asm statements, which a different compiler may schedule differently -- a
+    library built by another hipcc is a different library and says so."""
+    global _compiler
+    if _compiler is None:
+        try:
+            out = subprocess.run([os.environ.get('HIPCC', 'hipcc'), '--version'], capture_output=True, text=True, timeout=60).stdout
+            lines = [ln.strip() for ln in out.splitlines() if 'version' in ln.lower()]
+            _compiler = ' | '.join(lines[:2]) or 'unknown'
+        except Exception:   # noqa
+            _compiler = 'unknown'
+    return _compiler
+
+
 def _common_hash():
-    """what every object depends on besides its own source: the headers and the compile flags"""
-    return _sha(' '.join(FLAGS), *[_read(h) for h in _headers()])
+    """what every object depends on besides its own source: the headers, the compile flags and the compiler"""
+    return _sha(' '.join(FLAGS), compiler_version(), *[_read(h) for h in _headers()])
 
 
 def build_id():
@@ -59,6 +77,19 @@ def build_id():
     The library carries the id it was built from (`nrt_build_id()`, a string constant in api.o); mtimes play no part -- a git checkout,
     a copied tree or a shipped binary newer than the sources it does not match are all told apart by content."""
     return _sha(_common_hash(), *[_read(s) for s in sources()])[:16]
+
+
+# the translation units (with every header) the C = 32 gather kernels of the bench line are compiled from: fused warp + Dice, the stand-alone
+# warp and the Dice reduction that follows them
+GATHER_SOURCES = ('fused.hip', 'interpn.hip', 'dice.hip')
+
+
+def gather_sources_id():
+    """Identity of the sources of the bench line's kernels (16 hex digits over flags, compiler, headers and GATHER_SOURCES).
+    profiles/hbm_traffic.json stamps every counter entry with it (and with the id of the whole library it was measured on); bench.py
+    quotes `roofline.traffic` only while the loaded library still is the tree's build AND this id is the entry's -- a kernel edit that
+    keeps the kernel's NAME no longer keeps its old bytes, while an edit of, say, lc3d.hip does not void them."""
+    return _sha(_common_hash(), *[_read(os.path.join(CSRC, f)) for f in GATHER_SOURCES])[:16]
 
 
 _ID_MARK = b'NRT_BUILD_ID='

@@ -305,8 +305,9 @@ int wcce_impl(const void *y_true, const void *y_pred, int dtype, const float *la
     hipStream_t st = nrt_stream(stream);
     float *part = (float *)workspace;
     unsigned nblk = 1;
-    WcceFin fin = {loss_sum, nrt_ring_slot(), divide_by};
-    if (!fin.counter) return NRT_ERR_LAUNCH;
+    unsigned *slot = nrt_ring_slot(st);
+    if (!slot) return NRT_ERR_WORKSPACE;                       // the counter pool is exhausted (api.hip)
+    WcceFin fin = {loss_sum, slot + NRT_RING_CCE_OFF, divide_by};
     const bool aligned = (((uintptr_t)y_true | (uintptr_t)y_pred) & 15) == 0;
     if (dtype == NRT_DT_F32)
         launch_any<float>(y_true, y_pred, label_weights, nvox_total, channels, from_logits, label_smoothing, aligned,

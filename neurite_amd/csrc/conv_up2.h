@@ -107,6 +107,24 @@ __device__ __forceinline__ float u2_row_ror(float v, const int n) {      // v of
     }
 }
 
+// order of a tile's chunks: bit k set = chunk k is a B (skip) chunk, the nB of them spread evenly among the nA + nB (Bresenham)
+__host__ __device__ inline unsigned u2_chunk_seq(int nA, int nB) {
+    const int n = nA + nB;
+    unsigned seq = 0;
+    for (int k = 0; k < n; ++k) seq |= (((k + 1) * nB) / n > (k * nB) / n ? 1u : 0u) << k;
+    return seq;
+}
+// What the folded head needs of that order (it was implied by c0 < c1, now it is checked where the kernel is chosen): its
+// scratch aliases the skip-halo buffer and its stores run in chunk 0 behind that chunk's `issue_next` -- so chunk 0 must be an A chunk
+// (the deferred stores live in bodyA) AND chunk 1 too (else chunk 0 requests the next skip halo into the scratch before the head has
+// read it), and the tile must end on a B chunk (the window "last B chunk read .. next B chunk requested" is what the scratch lives in).
+inline bool u2_head_order_ok(int nA, int nB) {
+    const int n = nA + nB;
+    if (nA < 2 || nB < 1 || n > 32) return false;
+    const unsigned seq = u2_chunk_seq(nA, nB);
+    return (seq & 3u) == 0u && ((seq >> (n - 1)) & 1u) == 1u;
+}
+
 struct U2Head { const float *w, *bias; int labels; };     // the 1x1x1 head: kernel in fragment order [labels / 16][64 lanes][4], bias [labels]
 
 template <int NT, int HNT = 0>
@@ -120,8 +138,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void conv3d_up2_mfma(ConvArgs
     const int li = lane & 15, kq = lane >> 4;
     const int px = w & 1, py = w >> 1, iy = li >> 3, iz = li & 7;
     const int nA = a.c1 >> 4, nB = a.c0 >> 4, n = nA + nB;
-    unsigned seq = 0;                                                   // bit k: chunk k of a tile is a B chunk (Bresenham)
-    for (int k = 0; k < n; ++k) seq |= (((k + 1) * nB) / n > (k * nB) / n ? 1u : 0u) << k;
+    const unsigned seq = u2_chunk_seq(nA, nB);                          // bit k: chunk k of a tile is a B chunk (Bresenham)
 
     // ---- tiles of this persistent block: XCD x owns the x-th contiguous eighth, its blocks interleave --------------
     const unsigned xcd = blockIdx.x % NRT_NXCD, J = gridDim.x / NRT_NXCD;
@@ -568,5 +585,5 @@ int launch_up2(const ConvArgs &a, const float *wpacked, int batch, hipStream_t s
 // channels (the chunk order of a tile is then A A .. B: the skip-halo buffer is idle while the head uses it as scratch)
 bool up2_head_ok(const ConvArgs &a, int labels) {
     return up2_ok(a, 1) && a.Cout == 16 && (labels == 16 || labels == 32) && a.OX % CT_X == 0 && a.OY % CT_Y == 0 && a.OZ % CT_Z == 0 &&
-           a.c0 < a.c1;
+           a.c0 < a.c1 && u2_head_order_ok(a.c1 >> 4, a.c0 >> 4);
 }

@@ -563,13 +563,13 @@ __global__ __launch_bounds__(256, 2) void warp_dice_wc_bwd(InterpArgs a, TileGeo
 
 // persistent blocks pay off when there are more work items than resident blocks
 inline bool wc_persistent(const TileGeom &tg) { return NRT_NXCD * tg.items_x > 2u * (unsigned)nrt_num_cus(); }
-static_assert((NRT_NXCD + 1) * 16 <= NRT_RING_WORDS, "work counters of a launch fit one ring slot");
+static_assert(NRT_RING_GATHER_OFF == 0 && (NRT_NXCD + 1) * 16 <= NRT_RING_CCE_OFF, "the work counters of a launch stay in the gather's words of a slot");
 
 template <int MODE, bool STORE, bool MM, bool FILL>
 int launch_wc_inst(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, int batch, const float *fixed, float *fpart, float *mpart,
                    hipStream_t st) {
     const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
-    unsigned *queue = wc_persistent(tg) ? nrt_ring_slot() : nullptr;
+    unsigned *queue = wc_persistent(tg) ? nrt_ring_slot(st) : nullptr;
     if (queue) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, STORE, MM, FILL, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WC_BLOCK_BYTES) != hipSuccess)
@@ -624,7 +624,7 @@ inline int launch_wc(const InterpArgs &a, const TileGeom &tg, unsigned nblocks, 
 template <int MODE, bool FILL>
 int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, hipStream_t st) {
     const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
-    unsigned *queue = (items > slots) ? nrt_ring_slot() : nullptr;
+    unsigned *queue = (items > slots) ? nrt_ring_slot(st) : nullptr;
     if (queue) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc<MODE, true, false, FILL, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)WC_BLOCK_BYTES) != hipSuccess)
@@ -644,7 +644,7 @@ int launch_wc_interpn_inst(const InterpArgs &a, const TileGeom &tg, hipStream_t 
 template <int MODE, bool FILL, int BWD>
 int launch_wc_bwd_inst(const InterpArgs &a, const TileGeom &tg, const float *rows, const WcBwd &bw, hipStream_t st) {
     const unsigned items = NRT_NXCD * tg.items_x, slots = 2u * (unsigned)nrt_num_cus();
-    unsigned *queue = (items > slots) ? nrt_ring_slot() : nullptr;
+    unsigned *queue = (items > slots) ? nrt_ring_slot(st) : nullptr;
     if (queue) {
         if (hipFuncSetAttribute((const void *)warp_dice_wc_bwd<MODE, FILL, BWD, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WC_BLOCK_BYTES) != hipSuccess)
             return NRT_ERR_LAUNCH;

@@ -202,6 +202,10 @@ class GradientBucket:
         dev = self.params[0].device
         if any(p.device != dev for p in self.params):
             raise ValueError('GradientBucket: all parameters must live on one device')
+        # (every check BEFORE the first .grad is re-pointed: a refused model is left exactly as it was -- ADVICE r5)
+        bad = [p.dtype for p in self.params if p.dtype != torch.float32]
+        if bad:
+            raise ValueError('GradientBucket: float32 parameters only (got %s)' % bad[0])
         self.sizes = [p.numel() for p in self.params]
         self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=dev)
         off = 0
@@ -209,8 +213,6 @@ class GradientBucket:
             view = self.flat[off:off + n].view_as(p)
             if p.grad is not None:
                 view.copy_(p.grad.to(torch.float32))
-            if p.dtype != torch.float32:
-                raise ValueError('GradientBucket: float32 parameters only (got %s)' % p.dtype)
             p.grad = view
             off += n
 
@@ -224,17 +226,22 @@ class GradientBucket:
             off += n
         return True
 
+    def _require_intact(self):
+        if not self.intact():
+            raise RuntimeError('GradientBucket: a parameter gradient no longer aliases the bucket (zero_grad(set_to_none=True)?)')
+
     def zero_(self):
+        # (at every world size: zeroing a buffer the optimizer no longer sees would silently keep accumulating gradients)
+        self._require_intact()
         self.flat.zero_()
 
     def all_reduce(self, async_op=False):
         """sum (average) over the ranks, in place; returns the number of collective calls issued (0 at world size 1) or, with
         async_op, the work handle (None at world size 1)"""
         rank, world = _world(self.group)
+        self._require_intact()
         if world == 1:
             return None if async_op else 0
-        if not self.intact():
-            raise RuntimeError('GradientBucket: a parameter gradient no longer aliases the bucket (zero_grad(set_to_none=True)?)')
         if self.average:
             # pre-divide: sum of g / W; one pass, and the collective's result needs no second kernel
             self.flat.div_(world)

@@ -149,27 +149,31 @@ def _wcce_launch(t, p, w, from_logits, label_smoothing, per_voxel, divide_by=Non
             rc = lib.nrt_wcce_mean(_lib.ptr(t), _lib.ptr(p), dt, _lib.ptr(w), N, yf, int(from_logits),
                                    float(label_smoothing), float(divide_by), _lib.ptr(loss_sum), _lib.ptr(pv), _lib.ptr(ws), nws,
                                    _lib.stream_ptr(dev))
-    _lib.check(rc, 'nrt_wcce')
+    _lib.check(rc, 'nrt_wcce' if divide_by is None else 'nrt_wcce_mean')
     return pv if per_voxel else loss_sum
 
 
 class _WcceFn(torch.autograd.Function):
-    """Weighted CCE: returns (sum of the per-voxel losses [1]) or the per-voxel losses; backward wrt y_pred."""
+    """Weighted CCE: returns (sum of the per-voxel losses [1], divided by `divide_by` IN the kernel when given: the same float32 sum and
+    float32 division as the call that builds no graph -- ADVICE r5: `sum / N` as a torch op multiplies by 1/N, one ulp apart) or the
+    per-voxel losses; backward wrt y_pred."""
 
     @staticmethod
-    def forward(ctx, t, p, w, from_logits, label_smoothing, per_voxel):
+    def forward(ctx, t, p, w, from_logits, label_smoothing, per_voxel, divide_by=None):
         ctx.save_for_backward(t, p, w)
-        ctx.cfg = (from_logits, label_smoothing, per_voxel)
-        return _wcce_launch(t, p, w, from_logits, label_smoothing, per_voxel)
+        ctx.cfg = (from_logits, label_smoothing, per_voxel, divide_by)
+        return _wcce_launch(t, p, w, from_logits, label_smoothing, per_voxel, divide_by=divide_by)
 
     @staticmethod
     def backward(ctx, grad):
         t, p, w = ctx.saved_tensors
-        from_logits, label_smoothing, per_voxel = ctx.cfg
+        from_logits, label_smoothing, per_voxel, divide_by = ctx.cfg
         if ctx.needs_input_grad[0]:
             raise NotImplementedError('neurite_amd: gradient of the CCE wrt y_true is not implemented')
         if not ctx.needs_input_grad[1]:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
+        if divide_by is not None:
+            grad = grad / float(divide_by)
         if p.dtype != torch.float32:
             raise NotImplementedError('neurite_amd: CCE backward takes float32 inputs')
         lib = _lib.lib()
@@ -184,7 +188,7 @@ class _WcceFn(torch.autograd.Function):
                                           _lib.ptr(g) if per_voxel else None, N, yf, int(from_logits),
                                           float(label_smoothing), 1.0, _lib.ptr(gp), _lib.stream_ptr(dev))
             _lib.check(rc, 'nrt_wcce_bwd_f32')
-        return None, gp, None, None, None, None
+        return None, gp, None, None, None, None, None
 
 
 class _SegLossFn(torch.autograd.Function):
@@ -508,11 +512,7 @@ class CategoricalCrossentropy:
     """
 
     def __init__(self, label_weights=None, **kwargs):
-        self.label_weights = None
-        if label_weights is not None:
-            self.label_weights = torch.as_tensor(np.asarray(label_weights, dtype=np.float32)
-                                                 if not isinstance(label_weights, torch.Tensor)
-                                                 else label_weights)
+        self.label_weights = label_weights              # (property: the object keeps its OWN copy)
         self.from_logits = bool(kwargs.pop('from_logits', False))
         self.label_smoothing = float(kwargs.pop('label_smoothing', 0.))
         self.reduction = kwargs.pop('reduction', 'auto')
@@ -528,17 +528,38 @@ class CategoricalCrossentropy:
     def __call__(self, y_true, y_pred, sample_weight=None):
         return self.cce(y_true, y_pred, sample_weight=sample_weight)
 
+    @property
+    def label_weights(self):
+        return self._label_weights
+
+    @label_weights.setter
+    def label_weights(self, value):
+        # a private copy (a tensor made with as_tensor from a NumPy array shares its memory -- edits of the array never showed
+        # in `_version` and the device copy went stale); assigning the attribute again is how the weights are changed
+        if value is None:
+            self._label_weights = None
+        elif isinstance(value, torch.Tensor):
+            self._label_weights = value.detach().clone()
+        else:
+            self._label_weights = torch.tensor(np.asarray(value, dtype=np.float32))
+        self._w_cache = {}
+
     def _weights_on(self, dev):
-        """label_weights as a float32 tensor on `dev`, copied once per device (and again if the tensor was modified in place or replaced):
-        a host-resident weight vector used to cost one pageable host-to-device copy per call, more than the kernel at config 5's size."""
-        lw = self.label_weights
+        """label_weights as a float32 tensor on `dev`, copied once per device (again after the attribute was assigned, or after an in-place
+        edit of the tensor the attribute returns): a host-resident weight vector used to cost one pageable host-to-device copy per call,
+        more than the kernel at config 5's size."""
+        lw = self._label_weights
         if lw is None:
             return None
-        key = (str(dev), id(lw), lw._version)
-        if getattr(self, '_w_cache_key', None) != key:
-            self._w_cache = lw.detach().to(dev, torch.float32).contiguous()
-            self._w_cache_key = key
-        return self._w_cache
+        try:
+            version = lw._version
+        except RuntimeError:                         # an inference tensor keeps no version counter and cannot be edited in place outside inference mode
+            version = -1
+        hit = self._w_cache.get(str(dev))
+        if hit is None or hit[0] != version:
+            hit = (version, lw.detach().to(dev, torch.float32).contiguous())
+            self._w_cache[str(dev)] = hit
+        return hit[1]
 
     def cce(self, y_true, y_pred, sample_weight=None):
         yf = y_pred.shape[-1]
@@ -560,12 +581,13 @@ class CategoricalCrossentropy:
         joint = None if need_pv else JointSegLoss.lookup(self, y_true, y_pred)
         if joint is not None:
             res = joint.result()[0]
-        elif torch.is_grad_enabled() and (p.requires_grad or t.requires_grad):
-            res = _WcceFn.apply(t, p, w, self.from_logits, self.label_smoothing, need_pv)
         else:
-            # nothing to differentiate: no autograd node, and the mean's division happens in the kernel (one launch per call)
+            # the mean's division happens in the kernel (one launch per call), with or without an autograd node: one formulation, one value
             mean = not need_pv and self.reduction != 'sum' and N > 0
-            res = _wcce_launch(t, p, w, self.from_logits, self.label_smoothing, need_pv, divide_by=N if mean else None)
+            if torch.is_grad_enabled() and (p.requires_grad or t.requires_grad):
+                res = _WcceFn.apply(t, p, w, self.from_logits, self.label_smoothing, need_pv, N if mean else None)
+            else:
+                res = _wcce_launch(t, p, w, self.from_logits, self.label_smoothing, need_pv, divide_by=N if mean else None)
             if mean:
                 return res[0]
         if not need_pv:

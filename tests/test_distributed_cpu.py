@@ -120,6 +120,20 @@ def test_world1_is_identity():
     assert b.all_reduce() == 0 and b.all_reduce(async_op=True) is None and torch.equal(prm.grad, torch.ones(3)) and b.intact()
     (prm * 2).sum().backward()                                   # autograd accumulates INTO the view
     assert b.intact() and torch.equal(b.flat, torch.full((3,), 3.0))
+    # a refused model is left as it was (the dtype check used to run after earlier .grad had been re-pointed) ...
+    p32, p16 = torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2, dtype=torch.bfloat16))
+    g32 = torch.ones(2)
+    p32.grad = g32
+    with pytest.raises(ValueError):
+        nd.GradientBucket([p32, p16])
+    assert p32.grad is g32
+    # ... and a bucket whose views were dropped says so at world size 1 too, in zero_() as well as in all_reduce()
+    prm.grad = None
+    assert not b.intact()
+    with pytest.raises(RuntimeError):
+        b.zero_()
+    with pytest.raises(RuntimeError):
+        b.all_reduce()
 
 
 def _bench_worker(rank, world, port, q):

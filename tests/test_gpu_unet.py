@@ -218,6 +218,33 @@ def test_decoder_conv_with_folded_head(dev, labels, S, B):
         assert _lib.lib().nrt_conv3d_up2_head_supported(args[0], args[1], args[2], args[3], _lib.ints(args[4])) == 0
 
 
+@pytest.mark.parametrize('labels', [16, 32])
+def test_folded_head_is_run_to_run_bit_identical(dev, labels):
+    """the folded head depends on hand-placed hazard padding inside asm statements (s_nop around 16-byte stores, five wait
+    states in front of loads addressed by spilled SGPRs) and on hand-counted vmcnt immediates -- the failures they fixed showed up as
+    results that CHANGED from run to run in a few lanes.  So: many launches on the same inputs (several tiles per persistent block, so
+    that the head of tile t runs inside the first chunk of tile t + 1), every one bit-identical to the first, which itself agrees with the
+    two kernels the fold replaces; other work runs on the device in between to move the timing around."""
+    rng = np.random.default_rng(77 + labels)
+    c0, c1, S, B = 16, 32, (32, 32, 64), 2
+    conv = nm._Conv('c', c0 + c1, 16, (3, 3, 3), 1, 'same', 'elu').to(dev)
+    set_weights(conv, rng)
+    head = nm._Conv('h', 16, labels, (1, 1, 1), 1, 'same', None).to(dev)
+    set_weights(head, rng)
+    skip = G(rng.standard_normal((B,) + S + (c0,)).astype(F), dev)
+    lo = G(rng.standard_normal((B,) + tuple(s // 2 for s in S) + (c1,)).astype(F), dev)
+    first = conv.run_with_head(skip, lo, head.kernel, head.bias).clone()
+    feat = conv(skip, lo=lo, up=(2, 2, 2), variant=4)
+    two = nm._conv1x1_softmax(feat, head.kernel, head.bias, True, 0)
+    np.testing.assert_allclose(N(first), N(two), rtol=2e-5, atol=2e-7)
+    filler = torch.empty(1 << 22, device=dev)
+    for k in range(24):
+        if k % 3 == 1:
+            filler.normal_()                         # (a different neighbour in the queue: the launch meets another machine state)
+        again = conv.run_with_head(skip, lo, head.kernel, head.bias)
+        assert torch.equal(again, first), 'launch %d differs from the first in %d elements' % (k, int((again != first).sum()))
+
+
 @pytest.mark.parametrize('cout,S,B', [(16, (8, 8, 32), 2), (32, (4, 12, 16), 1), (16, (32, 32, 64), 1)])
 def test_first_conv_with_folded_pooling(dev, cout, S, B):
     """nrt_conv3d_c1_pool_f32 (round 5): the single-channel first encoder convolution also emits MaxPooling3D(2) of its output

@@ -813,6 +813,23 @@ def test_bench_quotes_traffic_only_for_the_timed_kernel(tmp_path):
     assert t == 123 and 'B4' in why
     assert bench.lookup_traffic(str(f), 'warp_dice_tile<8, 1, false, 4, float>', 1)[0] is None          # another batch
     assert bench.lookup_traffic(str(f), None, 4)[0] is None
+    # ... and only for the BINARY the counters were taken on: an entry carries the id of the library and of the gather's
+    # sources; a kernel edit that keeps the kernel's name must not keep its old bytes
+    k = 'warp_dice_wc<1, false, false, false, true, true>'
+    f.write_text(json.dumps({'kernels': {k: {'B4': {'bytes_per_launch': 456, 'build_id': 'aaaa', 'gather_sources_id': 'gggg'}},
+                                         'old': {'B4': {'bytes_per_launch': 7}}, 'lib_only': {'B4': {'bytes_per_launch': 8, 'build_id': 'aaaa'}}}}))
+    assert bench.lookup_traffic(str(f), k, 4, ('aaaa', 'aaaa', 'gggg'))[0] == 456
+    assert bench.lookup_traffic(str(f), k, 4, ('bbbb', 'bbbb', 'gggg'))[0] == 456          # another file of the library changed: the gather did not
+    t, why = bench.lookup_traffic(str(f), k, 4, ('bbbb', 'bbbb', 'hhhh'))
+    assert t is None and 'stale' in why and 'gggg' in why and 'hhhh' in why
+    t, why = bench.lookup_traffic(str(f), k, 4, ('aaaa', 'cccc', 'gggg'))                  # the loaded library is not the tree's build
+    assert t is None and 'not the build of this tree' in why
+    t, why = bench.lookup_traffic(str(f), 'old', 4, ('aaaa', 'aaaa', 'gggg'))              # recorded before the ids existed
+    assert t is None and 'no build id' in why
+    assert bench.lookup_traffic(str(f), 'lib_only', 4, ('aaaa', 'aaaa', 'gggg'))[0] == 8
+    assert bench.lookup_traffic(str(f), 'lib_only', 4, ('bbbb', 'bbbb', 'gggg'))[0] is None
+    from neurite_amd import build as nbuild
+    assert len(nbuild.gather_sources_id()) == 16 and nbuild.gather_sources_id() != nbuild.build_id()
     # the library names what it launches (no GPU needed: geometry only)
     lib = ne._lib.lib()
     n160 = ne._lib.ints([160] * 3)

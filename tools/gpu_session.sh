@@ -95,6 +95,9 @@ pmc)
     echo "pmc $c rc=$?" | tee -a "$OUT/session.log"
   done
   python tools/summarize_pmc.py "$OUT" 2>&1 | tee -a "$OUT/session.log"
+  # which binary the counters belong to: the id of the library that ran and of the gather's sources (tools/update_hbm_traffic.py)
+  python -c "import json; from neurite_amd import build, _lib; print(json.dumps({'library_build_id': _lib.lib().nrt_build_id().decode(), 'tree_build_id': build.build_id(), 'gather_sources_id': build.gather_sources_id()}))" > "$OUT/pmc_build_ids.json" 2>> "$OUT/session.log"
+  cat "$OUT/pmc_build_ids.json" | tee -a "$OUT/session.log"
   ;;
 esac
 done

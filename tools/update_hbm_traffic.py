@@ -5,9 +5,12 @@ library which instantiation it launches (nrt_warp_dice_kernel_name) and quotes t
 of round 3 were taken on <..., 4, float> while <..., 3, float> was the timed kernel).
 FETCH_SIZE (KiB per dispatch) is corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950: the
 factor is calibrated on dice_soft_vec, a pure streaming read whose byte count is known (expected 2.0); WRITE_SIZE is used as is.
-The bench kernels must all have been launched at the headline batch (bench.py --no-batch1)."""
+The bench kernels must all have been launched at the headline batch (bench.py --no-batch1).
+Every entry is stamped with the ids the session wrote next to the counters (gpurun_out/pmc_build_ids.json: the library that ran, the
+sources of the gather kernels); bench.py quotes an entry only while both still describe the library it has loaded."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 label = sys.argv[1] if len(sys.argv) > 1 else 'unlabelled'
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 S, L = 160, 32
@@ -19,6 +22,12 @@ if not cal:
 kd, d = cal[0]
 dice_bytes = 2 * 4 * L * V * B
 factor = dice_bytes / (d['FETCH_SIZE_KiB_per_dispatch'] * 1024.0)
+try:
+    ids = json.load(open(os.path.join(ROOT, 'gpurun_out', 'pmc_build_ids.json')))
+    if ids['library_build_id'] != ids['tree_build_id']:
+        raise SystemExit('the session ran a library (%s) that is not the build of its tree (%s): counters not recorded' % (ids['library_build_id'], ids['tree_build_id']))
+except (OSError, ValueError, KeyError):
+    raise SystemExit('gpurun_out/pmc_build_ids.json missing: run the `pmc` stage of tools/gpu_session.sh (it records which binary the counters belong to)')
 path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
 old = json.load(open(path)) if os.path.exists(path) else {}
 out = {'note': 'HBM-side traffic per launch (bytes) of the bench kernels, keyed by exact kernel name and batch: rocprofv3 --pmc FETCH_SIZE and '
@@ -32,6 +41,6 @@ for k, v in summ.items():
     write = v.get('WRITE_SIZE_KiB_per_dispatch', 0) * 1024
     out['kernels'].setdefault(k, {})['B%d' % B] = {
         'bytes_per_launch': int(fetch + write), 'fetch_bytes': int(fetch), 'write_bytes': int(write), 'fetch_correction_factor': round(factor, 4),
-        'calibrated_on': kd, 'source': 'rocprofv3 --pmc passes of %s: profiles/%s/pmc_summary.json' % (label, label)}
+        'calibrated_on': kd, 'build_id': ids['library_build_id'], 'gather_sources_id': ids['gather_sources_id'], 'source': 'rocprofv3 --pmc passes of %s: profiles/%s/pmc_summary.json' % (label, label)}
 json.dump(out, open(path, 'w'), indent=1)
 print(json.dumps(out, indent=1))
