@@ -91,6 +91,10 @@ def parse():
                     help='time neurite_amd.fused.warp_dice called directly instead of the reference-signature calls (same kernel)')
     ap.add_argument('--no-batch1', action='store_true',
                     help='skip the extra batch = 1 runs (profiling: every launch of the gather kernels then has the headline shape)')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='independent steps are issued round-robin on this many HIP streams, so that the head of step k + 1 fills the tail of '
+                         'step k and the small second-stage kernels of a step run beside the next gather (1: strictly serial steps; the '
+                         'line always carries the serial figures as roofline.isolated_launch)')
     ap.add_argument('--graph', action='store_true',
                     help="capture a step's compute launches (gather + Dice second stage + mean pair) in one hipGraph")
     return ap.parse_args()
@@ -719,10 +723,50 @@ def timed(step, steps, warmup, dist=None, dev=None):
     if on_gpu:
         k0 = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
         k1 = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+        # device time from the first step's first event to the LAST event of the region, per step: with steps pipelined over several
+        # streams the kernels of consecutive steps overlap, k0 (a launch's own start-to-end time) then counts the shared stretches twice
+        # and this -- the rate at which launches complete -- is the time a launch costs
+        tail = evs[-min(len(evs), 8):]
+        span = max(evs[0][0].elapsed_time(e[2]) for e in tail) / steps
     else:
-        k0 = k1 = float('nan')
-    return {'elapsed': elapsed, 'per_rank_s': per_rank, 'ranks': ranks, 'k0_ms': k0, 'k1_ms': k1,
+        k0 = k1 = span = float('nan')
+    return {'elapsed': elapsed, 'per_rank_s': per_rank, 'ranks': ranks, 'k0_ms': k0, 'k1_ms': k1, 'span_ms': span,
             'mean': None if m is None else float(m)}
+
+
+class _OnStream:
+    """a PendingMean whose collection runs on the stream its step was issued on"""
+
+    def __init__(self, pending, stream):
+        self.pending, self.stream = pending, stream
+
+    def result(self):
+        with torch.cuda.stream(self.stream):
+            return self.pending.result()
+
+
+def pipelined(step, nstreams, dev):
+    """`step` issued round-robin on `nstreams` HIP streams (the reference's own batch loop, neurite/tf/layers.py:171
+    `tf.map_fn`, is serial: this is what a data-parallel host does with INDEPENDENT steps).  Every stream first waits for the work that was
+    current when the wrapper was made (the inputs), the steps themselves depend on nothing but their inputs, so consecutive steps may
+    overlap: the first blocks of step k + 1's gather run on the CUs that step k's last round has left idle, and the second-stage
+    launches of a step (partial rows -> sums -> dice, ~25 us of small kernels) run beside the next gather.  Scratch memory and work
+    counters are per stream (neurite_amd/_lib.py: workspace; csrc/api.hip: counter slots), results are bit-identical to serial steps
+    (tests/test_gpu_graph_capture.py, tools/two_stream_probe.py).  nstreams <= 1 returns `step` itself."""
+    if nstreams <= 1:
+        return step
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    for st_ in streams:
+        st_.wait_stream(torch.cuda.current_stream(dev))
+    count = [0]
+
+    def wrapped(events=None):
+        st_ = streams[count[0] % nstreams]
+        count[0] += 1
+        with torch.cuda.stream(st_):
+            return _OnStream(step(events), st_)
+    wrapped.streams = streams
+    return wrapped
 
 
 def lookup_traffic(tfile, timed_kernel, B, ids=None):
@@ -967,11 +1011,16 @@ def main():
     fused = not args.unfused
     # the timed pipeline: the reference's own two calls, SpatialTransformer -> Dice (the warp is deferred, Dice launches the fused
     # kernel); --direct times fused.warp_dice itself, --unfused the eager two-kernel form
-    main_step = (step_fused if args.direct else step_refsig) if fused else step_unfused
+    main_serial = (step_fused if args.direct else step_refsig) if fused else step_unfused
+    # independent steps go round-robin over --streams HIP streams (a captured graph owns its buffers: replays stay on one stream)
+    nstreams = 1 if (args.graph or args.unfused) else max(1, args.streams)
+    main_step = pipelined(main_serial, nstreams, dev)
     r_main = timed(main_step, args.steps, args.warmup, dist, dev)
     elapsed, k0_ms, k1_ms, m = r_main['elapsed'], r_main['k0_ms'], r_main['k1_ms'], r_main['mean']
-    # the other form of the same pipeline, shorter run, for the record
     o_steps = max(5, args.steps // 5)
+    # the same steps strictly one after the other (what rocprofv3's per-kernel durations of an isolated launch correspond to)
+    r_iso = timed(main_serial, o_steps, 2, dist, dev) if nstreams > 1 else r_main
+    # the other form of the same pipeline, shorter run, for the record
     r_other = timed(step_unfused if fused else step_fused, o_steps, 2, dist, dev)
     o_elapsed, o_k0, o_k1, o_m = r_other['elapsed'], r_other['k0_ms'], r_other['k1_ms'], r_other['mean']
     # the same kernel through the other entry (direct fused API when the reference-signature calls are the timed pipeline)
@@ -980,7 +1029,9 @@ def main():
     r_b1 = None
     if dist is None and B > 1 and not args.no_batch1:
         f1, u1, _ = make_steps(mov[:1], fix[:1], trf[:1])
-        r_b1 = (timed(f1, o_steps, 2, None, dev), timed(u1, o_steps, 2, None, dev))
+        b1_steps = 4 * o_steps                            # (a batch-1 step is a quarter of the headline step)
+        r_b1 = (timed(pipelined(f1, nstreams, dev), b1_steps, 4, None, dev), timed(u1, o_steps, 2, None, dev),
+                timed(f1, o_steps, 2, None, dev) if nstreams > 1 else None)
     # label maps stored as bfloat16 (exact for one-hot maps), float32 arithmetic: same Dice bit for bit, half the bytes per row
     r_bf16 = None
     if dist is None and not args.no_batch1:
@@ -1037,7 +1088,7 @@ def main():
                 smov, sfix, strf = mov, fix, trf
             else:
                 smov, sfix, strf = synth.cfg2_batch(Bs, S, L, device=dev, seed0=100 + 3 * rank * Bs)
-            s_refsig = make_steps(smov, sfix, strf)[2]
+            s_refsig = pipelined(make_steps(smov, sfix, strf)[2], nstreams, dev)
             r_strong = timed(s_refsig, o_steps, 2, dist, dev)
             del smov, sfix, strf, s_refsig
             torch.cuda.empty_cache()
@@ -1051,7 +1102,7 @@ def main():
                 r_weak = r_main                          # (N = 8: config 4's shard IS 4 volumes per rank)
             else:
                 wmov, wfix, wtrf = synth.cfg2_batch(Bw, S, L, device=dev, seed0=100 + 3 * rank * Bw)
-                w_refsig = make_steps(wmov, wfix, wtrf)[2]
+                w_refsig = pipelined(make_steps(wmov, wfix, wtrf)[2], nstreams, dev)
                 r_weak = timed(w_refsig, o_steps, 2, dist, dev)
                 del wmov, wfix, wtrf, w_refsig
                 torch.cuda.empty_cache()
@@ -1084,7 +1135,8 @@ def main():
         kname = ('fused SpatialTransformer gather + Dice reduction (exact instantiation: `timed_kernel`), one launch per step; reached through '
                  + ('fused.warp_dice' if args.direct else 'layers.SpatialTransformer -> metrics.Dice (deferred warp)'))
         alg_bytes = fused_bytes
-        kms = k0_ms
+        # pipelined steps: a launch costs the rate at which launches complete (its own start-to-end time overlaps its neighbours')
+        kms = r_main['span_ms'] if nstreams > 1 else k0_ms
     else:
         kname = 'interpn (SpatialTransformer gather), one launch per step'
         alg_bytes = interp_bytes
@@ -1105,7 +1157,7 @@ def main():
 
     # drop-in (reference-signature) pipeline figures, whichever form was the timed one
     d_elapsed, d_steps, d_k0, d_k1, d_m = (o_elapsed, o_steps, o_k0, o_k1, o_m) if fused else (elapsed, args.steps, k0_ms, k1_ms, m)
-    f_elapsed, f_steps, f_k0, f_m = (elapsed, args.steps, k0_ms, m) if fused else (o_elapsed, o_steps, o_k0, o_m)
+    f_elapsed, f_steps, f_k0, f_m = (elapsed, args.steps, kms, m) if fused else (o_elapsed, o_steps, o_k0, o_m)
     dropin = {'what': 'reference-signature calls run eagerly (neurite_amd.deferred.enabled = False): layers.SpatialTransformer(linear) '
                       '-> metrics.Dice().dice, two kernels, `warped` written and re-read; %d steps' % d_steps,
               'value': round(world * B * V * d_steps / d_elapsed / 1e6, 2), 'unit': 'Mvoxels/s',
@@ -1149,7 +1201,8 @@ def main():
                            else 'reference-signature calls run eagerly: two kernels'),
             'volumes_per_gpu': B, 'global_batch': B * world, 'size': S, 'labels': L,
             'pipeline': ('reference_api' if not args.direct else 'fused_direct') if fused else 'unfused',
-            'step_launch': 'one hipGraph replay per step (--graph)' if args.graph else 'direct kernel launches',
+            'step_launch': 'one hipGraph replay per step (--graph)' if args.graph else
+                           ('direct kernel launches, independent steps round-robin on %d HIP streams' % nstreams if nstreams > 1 else 'direct kernel launches, one stream'),
             'parallelism': 'dp%d (batch-sharded, one RCCL all-reduce of 2 floats per step)' % world,
             'scaling_mode': ('strong: global batch %d%s split over the ranks' % (args.global_batch, '' if named_batch else ' (BASELINE config 4, the default of an N > 1 run)'))
                             if args.global_batch else 'weak: --batch-per-gpu %d on every rank' % B,
@@ -1168,8 +1221,23 @@ def main():
             'library_build_id': build_ids[0],
             'algorithmic_bytes_per_launch': alg_bytes,
             'avg_launch_ms': round(kms, 4),
-            'avg_launch_ms_covers': ('HIP events around the gather launch and, for the fused form, the two launches of its Dice second '
+            'avg_launch_ms_covers': (('steps pipelined over %d HIP streams: device time from the first event of the timed region to its last, '
+                                      'divided by the launches -- the rate at which launches COMPLETE.  Consecutive gathers overlap (the head of '
+                                      'launch k + 1 runs on the CUs launch k\'s last round has left), so a launch\'s own start-to-end time '
+                                      '(`kernel_own_duration_ms`, what rocprofv3 lists per kernel) counts the shared stretches twice; '
+                                      '`isolated_launch` is the same launch with the device to itself (steps strictly serial)' % nstreams)
+                                     if (nstreams > 1 and fused) else
+                                     'HIP events around the gather launch and, for the fused form, the two launches of its Dice second '
                                      'stage (reduce_rows + dice_soft_finalize, ~0.03 ms together): rocprofv3 lists the gather alone'),
+            'steps_in_flight': nstreams,
+            'kernel_own_duration_ms': round(k0_ms, 4),
+            'isolated_launch': {
+                'what': 'the same launch with the device to itself: steps issued strictly one after the other on one stream, HIP events around '
+                        'the gather and its Dice second stage; %d steps.  This is the figure rocprofv3 --stats of a `--streams 1` run reproduces' % o_steps,
+                'avg_launch_ms': round(r_iso['k0_ms'], 4),
+                'achieved': round(alg_bytes / (r_iso['k0_ms'] * 1e-3) / 1e9, 1),
+                'frac': round(alg_bytes / (r_iso['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                'ms_per_step': round(r_iso['elapsed'] / (o_steps if nstreams > 1 else args.steps) * 1e3, 4)},
         },
         # the reference-signature path (what `SpatialTransformer` + `Dice` callers reach) next to the fused headline
         'roofline_dropin': {'kernel': 'interpn (SpatialTransformer gather, drop-in API), one launch per step', 'bound': 'hbm',
@@ -1212,20 +1280,31 @@ def main():
             'ms_per_step': round(r_weak['elapsed'] / w_steps * 1e3, 4), 'kernel_ms': round(r_weak['k0_ms'], 4),
             'mean_dice': round(r_weak['mean'], 6)}
     if r_b1 is not None:
-        rf, ru = r_b1
+        rf, ru, rf_iso = r_b1
+        b1_bytes = (4 * L + 12 + 4 * L) * V
+        b1_ms = rf['span_ms'] if nstreams > 1 else rf['k0_ms']
         out['config2_batch1'] = {
-            'what': 'BASELINE config 2 as written: batch = 1, one %d^3 x %d-label volume per step, %d steps' % (S, L, o_steps),
-            'fused': {'ms': round(rf['elapsed'] / o_steps * 1e3, 4), 'Mvoxels_per_s': round(V * o_steps / rf['elapsed'] / 1e6, 1),
-                      'kernel_ms': round(rf['k0_ms'], 4),
-                      'frac': round((4 * L + 12 + 4 * L) * V / (rf['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            'what': 'BASELINE config 2 as written: batch = 1, one %d^3 x %d-label volume per step, %d steps%s' % (
+                S, L, b1_steps, ' round-robin on %d streams' % nstreams if nstreams > 1 else ''),
+            'fused': {'ms': round(rf['elapsed'] / b1_steps * 1e3, 4), 'Mvoxels_per_s': round(V * b1_steps / rf['elapsed'] / 1e6, 1),
+                      'kernel_ms': round(b1_ms, 4), 'kernel_own_duration_ms': round(rf['k0_ms'], 4),
+                      'frac': round(b1_bytes / (b1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             'dropin': {'ms': round(ru['elapsed'] / o_steps * 1e3, 4), 'Mvoxels_per_s': round(V * o_steps / ru['elapsed'] / 1e6, 1),
                        'interpn_ms': round(ru['k0_ms'], 4), 'dice_ms': round(ru['k1_ms'], 4),
                        'interpn_frac': round(INTERPN_BYTES_PER_VOXEL(L, 3) * V / (ru['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        if rf_iso is not None:
+            out['config2_batch1']['fused_isolated'] = {
+                'ms': round(rf_iso['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(rf_iso['k0_ms'], 4),
+                'frac': round(b1_bytes / (rf_iso['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         # BASELINE config 2 names batch = 1: its figures also sit in the two objects a reader of the line's head keeps (`roofline`, `config`)
-        out['roofline']['batch1'] = {'what': 'the same fused kernel on ONE volume per launch (BASELINE config 2 as written)',
+        out['roofline']['batch1'] = {'what': 'the same fused kernel on ONE volume per launch (BASELINE config 2 as written)'
+                                             + ('; launches pipelined as in the headline, `isolated_frac` = strictly serial launches' if rf_iso is not None else ''),
                                      'avg_launch_ms': out['config2_batch1']['fused']['kernel_ms'],
                                      'frac': out['config2_batch1']['fused']['frac'],
                                      'standalone_interpn_frac': out['config2_batch1']['dropin']['interpn_frac']}
+        if rf_iso is not None:
+            out['roofline']['batch1']['isolated_frac'] = out['config2_batch1']['fused_isolated']['frac']
+            out['roofline']['batch1']['isolated_avg_launch_ms'] = out['config2_batch1']['fused_isolated']['kernel_ms']
         out['config']['batch1_ms_per_step'] = out['config2_batch1']['fused']['ms']
         out['config']['batch1_Mvoxels_per_s'] = out['config2_batch1']['fused']['Mvoxels_per_s']
     if r_def is not None:

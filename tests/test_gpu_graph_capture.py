@@ -149,6 +149,57 @@ def test_two_streams_do_not_share_scratch(dev):
                 assert torch.equal(x, y)
 
 
+def test_counter_slots_belong_to_streams_and_to_captured_launches(dev):
+    """the work counters of the persistent gather and the tickets of the one-launch CCE used to come from a 64-slot
+    round-robin ring -- two launches 64 ring launches apart on different streams, or a replayed graph and eager work, could meet in one
+    slot.  Now a stream owns its slot, every launch recorded during capture owns one, and nothing else is ever handed the same words."""
+    import ctypes as C
+    from neurite_amd import _lib
+    lib = _lib.lib()
+    _lib.init_device(dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    idx = lambda s: lib.nrt_counters_slot_index(C.c_void_p(s.cuda_stream))
+    i1, i2 = idx(s1), idx(s2)
+    assert i1 >= 0 and i2 >= 0 and i1 != i2
+    for _ in range(200):                                       # however many launches lie in between
+        assert idx(s1) == i1 and idx(s2) == i2
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cs = torch.cuda.current_stream()
+        c1, c2 = idx(cs), idx(cs)
+    assert c1 >= 0 and c2 >= 0 and len({c1, c2, i1, i2}) == 4   # one slot per recorded launch, none of them a stream's
+
+    # a graph replayed on one stream while eager launches of the same kernels run on another, many times over, different inputs
+    a = synth.cfg2_batch(2, 96, 32, device=dev, seed0=61)
+    b = synth.cfg2_batch(2, 96, 32, device=dev, seed0=87)
+    w = torch.rand(32, device=dev) + 0.5
+    cce = ne.losses.CategoricalCrossentropy(label_weights=w)
+
+    def ops(mov, fix, trf):
+        return [ne.fused.warp_dice(mov, trf, fix), cce.loss(fix, mov.clamp_min(1e-3))]
+    want_a = [t.clone() for t in ops(*a)]
+    want_b = [t.clone() for t in ops(*b)]
+    g, out = capture(lambda: ops(*a))
+    s3 = torch.cuda.Stream()
+    for k in range(40):
+        with torch.cuda.stream(s3):
+            got_b = ops(*b)
+        g.replay()
+        with torch.cuda.stream(s3):
+            got_b2 = ops(*b)
+        torch.cuda.synchronize()
+        for x, y in zip(out, want_a):
+            assert torch.equal(x, y), 'replay %d' % k
+        for got in (got_b, got_b2):
+            for x, y in zip(got, want_b):
+                assert torch.equal(x, y), 'eager launch beside replay %d' % k
+    # recovery entry: zero-fills the pool (nothing is in flight here), results unchanged afterwards
+    _lib.check(lib.nrt_counters_reset(_lib.stream_ptr(dev)), 'nrt_counters_reset')
+    torch.cuda.synchronize()
+    for x, y in zip(ops(*a), want_a):
+        assert torch.equal(x, y)
+
+
 def test_views_and_misaligned_storage(dev):
     """inputs that are views with a 4-byte storage offset (not 16-byte aligned) or non-contiguous: every op gives the numbers it gives
     on aligned contiguous copies (the vector kernels need 16-byte rows; the entry points must notice, not fault)"""

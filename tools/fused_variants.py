@@ -6,7 +6,9 @@ bench.py with NEURITE_AMD_LIB pointing at it.  The product sources carry NO such
 profiles/r04_lab/l1_access_curve.jsonl (NRT_FUSED_EXP) are in the history at commit e0b416e, those behind
 profiles/r05_lab/wc_probes.jsonl were never committed with the sources.
     FUSED_VARIANTS="A=1 A=1,B=2" python tools/fused_variants.py --build          (here, no GPU)
-    FUSED_VARIANTS="A=1 A=1,B=2" FUSED_REPS=3 python tools/fused_variants.py      (GPU box; variants alternate REPS times)"""
+    FUSED_VARIANTS="A=1 A=1,B=2" FUSED_REPS=3 python tools/fused_variants.py      (GPU box; variants alternate REPS times)
+    FUSED_FETCH=1 ...                              also one rocprofv3 --pmc FETCH_SIZE pass per variant over tools/fused_small.py (batch
+                                                   FUSED_BATCH, default 4): HBM-side read bytes per launch of the gather (x2-corrected)"""
 import glob
 import json
 import os
@@ -27,8 +29,33 @@ if '--build' in sys.argv:
         subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + [o, '-o', os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '').replace(',', '_'))])
     print('built', VARIANTS)
     sys.exit(0)
+def fetch_pass(k, lib):
+    """mean FETCH_SIZE (KiB, raw) per dispatch of the warp_dice kernels under this variant's library"""
+    import csv
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix='fv_', dir='/tmp')
+    env = dict(os.environ, NEURITE_AMD_LIB=lib, TMPDIR='/tmp', PYTHONPATH=ROOT)
+    subprocess.run(['rocprofv3', '--pmc', 'FETCH_SIZE', '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
+                    sys.executable, os.path.join(ROOT, 'tools', 'fused_small.py'), os.environ.get('FUSED_BATCH', '4')],
+                   env=env, cwd='/tmp', stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    vals = {}
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get('Counter_Name') == 'FETCH_SIZE' and 'warp_dice' in row.get('Kernel_Name', ''):
+                vals.setdefault(row['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:60], []).append(float(row['Counter_Value']))
+    shutil.rmtree(d, ignore_errors=True)
+    return {kn: round(2 * 1024 * sum(v) / len(v) / 1e9, 4) for kn, v in vals.items()}
+
+
 REPS = int(os.environ.get('FUSED_REPS', '1'))
 STEPS = os.environ.get('FUSED_STEPS', '40')
+if os.environ.get('FUSED_FETCH'):
+    for k in VARIANTS:
+        try:
+            print(json.dumps({'variant': k, 'fetch_GB_per_launch_x2_corrected': fetch_pass(k, os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '').replace(',', '_')))}), flush=True)
+        except Exception as e:      # noqa
+            print(json.dumps({'variant': k, 'fetch_error': str(e)[-300:]}), flush=True)
 for k in VARIANTS * REPS:
     env = dict(os.environ, NEURITE_AMD_LIB=os.path.join(LAB, 'libnrt_fused_%s.so' % k.replace('=', '').replace(',', '_')))
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', STEPS, '--warmup', '10', '--no-cpu-baseline', '--no-batch1', '--no-unet'],
