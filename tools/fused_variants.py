@@ -63,6 +63,7 @@ for k in VARIANTS * REPS:
     try:
         j = json.loads(r.stdout.strip().splitlines()[-1])
         print(json.dumps({'variant': k, 'Mvox_s': j['value'], 'ms_per_step': j['ms_per_step'], 'kernel_ms': j['roofline']['avg_launch_ms'],
+                          'isolated_kernel_ms': j['roofline'].get('isolated_launch', {}).get('avg_launch_ms'),
                           'standalone_interpn_ms': j['roofline'].get('standalone_interpn', {}).get('avg_launch_ms')}), flush=True)
     except Exception as e:      # noqa
         print(json.dumps({'variant': k, 'error': (r.stderr or str(e))[-300:]}), flush=True)
