@@ -95,6 +95,11 @@ def parse():
                     help='independent steps are issued round-robin on this many HIP streams, so that the head of step k + 1 fills the tail of '
                          'step k and the small second-stage kernels of a step run beside the next gather (1: strictly serial steps; the '
                          'line always carries the serial figures as roofline.isolated_launch)')
+    ap.add_argument('--prewarm-ms', type=float, default=250.0,
+                    help='untimed device activity (the step itself, repeated) in front of every measurement, BEFORE its --warmup steps: a '
+                         'fresh device needs 100-200 ms of continuous work to reach its steady clocks (the same 0.22 ms step ran 0.266 ms in '
+                         'its first 40 repetitions and 0.223 ms from the 500th on, tools/lab/b1_dbg.py); 0 = none.  The timed region stays '
+                         'EXACTLY --steps steps between barrier + synchronize pairs')
     ap.add_argument('--graph', action='store_true',
                     help="capture a step's compute launches (gather + Dice second stage + mean pair) in one hipGraph")
     return ap.parse_args()
@@ -664,7 +669,31 @@ def unet_train_bench(dev, size=160, labels=32, reps=3):
     return out
 
 
-def timed(step, steps, warmup, dist=None, dev=None):
+PREWARM_MS = 0.0             # set from --prewarm-ms in main()
+
+
+def prewarm(step, ms):
+    """`step` repeated for ~`ms` milliseconds of wall time, untimed; every pending mean is collected, the device is idle on return"""
+    if ms <= 0:
+        return 0
+    t0, n, pending = time.perf_counter(), 0, None
+    while True:
+        for _ in range(8):
+            nxt = step(None)
+            if pending is not None:
+                pending.result()
+            pending = nxt
+            n += 1
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t0) * 1e3 >= ms:
+            break
+    if pending is not None:
+        pending.result()
+    torch.cuda.synchronize()
+    return n
+
+
+def timed(step, steps, warmup, dist=None, dev=None, sparse_events=False):
     """
     The timed region of the bench contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier and a
     device synchronize on both sides; the wall time is the MAX over ranks.  `step(events)` enqueues one pass and returns a
@@ -672,6 +701,9 @@ def timed(step, steps, warmup, dist=None, dev=None):
     on the compute stream; a step's global mean is collected (a stream-level wait, no host sync) after the next step has
     been enqueued, and every mean is complete before the closing synchronize, so all K steps' work lies inside the region.
     dev = None runs the same loop without a device (the gloo tests of this logic, tests/test_distributed_cpu.py).
+    sparse_events: HIP events only around the first step and the last eight (pipelined steps: an event record is a barrier packet with a
+    time stamp in its stream -- three per step cost a 0.22 ms step 25 % and a 0.86 ms step 4 %, tools/b1_pipeline_probe.py against this
+    loop; the region's span needs its two ends only, k0 / k1 are then means over the last eight steps).
     Returns dict(elapsed = max over ranks [s], per_rank_s, ranks = size of the process group as the collective sees it,
     k0_ms / k1_ms = mean event intervals of a step's two kernel slots (NaN without a device), mean = last global mean).
     """
@@ -681,6 +713,8 @@ def timed(step, steps, warmup, dist=None, dev=None):
         if on_gpu:
             torch.cuda.synchronize()
 
+    if on_gpu:
+        prewarm(step, PREWARM_MS)
     pending, m = None, None
     for _ in range(warmup):
         nxt = step(None)
@@ -691,7 +725,8 @@ def timed(step, steps, warmup, dist=None, dev=None):
         m = pending.result()
     pending = None
     sync()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)] if on_gpu else [None] * steps
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if (not sparse_events or k == 0 or k >= steps - 8) else None
+           for k in range(steps)] if on_gpu else [None] * steps
     if dist is not None:
         dist.barrier()
     sync()
@@ -721,12 +756,13 @@ def timed(step, steps, warmup, dist=None, dev=None):
         ranks = int(round(float(ones[0])))
         elapsed = max(per_rank)
     if on_gpu:
-        k0 = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-        k1 = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+        have = [e for e in evs if e is not None]
+        k0 = float(np.mean([e[0].elapsed_time(e[1]) for e in have]))
+        k1 = float(np.mean([e[1].elapsed_time(e[2]) for e in have]))
         # device time from the first step's first event to the LAST event of the region, per step: with steps pipelined over several
         # streams the kernels of consecutive steps overlap, k0 (a launch's own start-to-end time) then counts the shared stretches twice
         # and this -- the rate at which launches complete -- is the time a launch costs
-        tail = evs[-min(len(evs), 8):]
+        tail = have[-min(len(have), 8):]
         span = max(evs[0][0].elapsed_time(e[2]) for e in tail) / steps
     else:
         k0 = k1 = span = float('nan')
@@ -745,6 +781,56 @@ class _OnStream:
             return self.pending.result()
 
 
+_STEP_STREAMS = {}
+
+
+def step_streams(nstreams, dev):
+    """the HIP streams independent steps are spread over: created ONCE per process and shared by every pipelined measurement -- torch hands
+    out pooled streams round-robin and the runtime maps streams onto a few hardware queues; a fresh pair per measurement ended up on ONE
+    queue by the third pair (the batch-1 run lost all of its overlap: 0.277 ms per step where tools/b1_pipeline_probe.py measures 0.225)"""
+    key = (str(dev), nstreams)
+    if key not in _STEP_STREAMS:
+        _STEP_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    return _STEP_STREAMS[key]
+
+
+def graph_pipelined(compute, nstreams, dev):
+    """Small steps (one volume: ~0.22 ms of device time) are host-bound when issued call by call over several streams (~0.28 ms of
+    Python per step): the compute launches of a step -- gather, Dice second stage, the [sum, count] pair -- are captured ONCE PER STREAM
+    (each capture on its own stream: scratch memory is per stream, every captured launch owns its counter slot, csrc/api.hip) and the
+    graphs are replayed round-robin, one replay per step.  `compute()` returns the [sum, count] device pair of a step; returns a step
+    function like `pipelined` does.  The all-reduce stays outside the graphs and works on a copy of the pair."""
+    from neurite_amd import distributed as nd
+    streams = step_streams(nstreams, dev)
+    graphs = []
+    for st_ in streams:
+        st_.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(st_):
+            for _ in range(2):
+                compute()                              # lazy allocations, workspace growth, counter-slot assignment: outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st_):
+            pair = compute()
+        graphs.append((g, pair))
+    count = [0]
+
+    def step(events=None):
+        k = count[0] % nstreams
+        count[0] += 1
+        g, pair = graphs[k]
+        with torch.cuda.stream(streams[k]):
+            if events is not None:
+                events[0].record()
+            g.replay()
+            if events is not None:
+                events[1].record()
+                events[2].record()
+            return _OnStream(nd.all_reduce_mean_pair(pair.clone(), async_op=True), streams[k])
+    step.graphs = graphs
+    return step
+
+
 def pipelined(step, nstreams, dev):
     """`step` issued round-robin on `nstreams` HIP streams (the reference's own batch loop, neurite/tf/layers.py:171
     `tf.map_fn`, is serial: this is what a data-parallel host does with INDEPENDENT steps).  Every stream first waits for the work that was
@@ -755,7 +841,7 @@ def pipelined(step, nstreams, dev):
     (tests/test_gpu_graph_capture.py, tools/two_stream_probe.py).  nstreams <= 1 returns `step` itself."""
     if nstreams <= 1:
         return step
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+    streams = step_streams(nstreams, dev)
     for st_ in streams:
         st_.wait_stream(torch.cuda.current_stream(dev))
     count = [0]
@@ -876,7 +962,9 @@ def stub_main(args, rank, world):
 
 
 def main():
+    global PREWARM_MS
     args = parse()
+    PREWARM_MS = 0.0 if args.stub_step else max(0.0, args.prewarm_ms)
     if ('WORLD_SIZE' not in os.environ and not os.environ.get('NRT_BENCH_CHILD')
             and (args.gpus > 1 or os.environ.get('NRT_FORCE_SPAWN'))):
         return self_launch(args.gpus)
@@ -1015,7 +1103,7 @@ def main():
     # independent steps go round-robin over --streams HIP streams (a captured graph owns its buffers: replays stay on one stream)
     nstreams = 1 if (args.graph or args.unfused) else max(1, args.streams)
     main_step = pipelined(main_serial, nstreams, dev)
-    r_main = timed(main_step, args.steps, args.warmup, dist, dev)
+    r_main = timed(main_step, args.steps, args.warmup, dist, dev, sparse_events=nstreams > 1)
     elapsed, k0_ms, k1_ms, m = r_main['elapsed'], r_main['k0_ms'], r_main['k1_ms'], r_main['mean']
     o_steps = max(5, args.steps // 5)
     # the same steps strictly one after the other (what rocprofv3's per-kernel durations of an isolated launch correspond to)
@@ -1030,7 +1118,18 @@ def main():
     if dist is None and B > 1 and not args.no_batch1:
         f1, u1, _ = make_steps(mov[:1], fix[:1], trf[:1])
         b1_steps = 4 * o_steps                            # (a batch-1 step is a quarter of the headline step)
-        r_b1 = (timed(pipelined(f1, nstreams, dev), b1_steps, 4, None, dev), timed(u1, o_steps, 2, None, dev),
+        b1_form = 'direct launches'
+        if nstreams > 1:
+            try:
+                m1, t1, x1 = mov[:1], trf[:1], fix[:1]
+                f1p = graph_pipelined(lambda: nd.mean_dice_pair(ne.fused.warp_dice(m1, t1, x1, _tune=args.tune)), nstreams, dev)
+                b1_form = 'one hipGraph replay per step, one captured graph per stream'
+            except Exception as e:   # noqa
+                log('batch-1 graph capture failed (%s): direct launches' % e)
+                f1p = pipelined(f1, nstreams, dev)
+        else:
+            f1p = f1
+        r_b1 = (timed(f1p, b1_steps, 4, None, dev, sparse_events=nstreams > 1), timed(u1, o_steps, 2, None, dev),
                 timed(f1, o_steps, 2, None, dev) if nstreams > 1 else None)
     # label maps stored as bfloat16 (exact for one-hot maps), float32 arithmetic: same Dice bit for bit, half the bytes per row
     r_bf16 = None
@@ -1058,7 +1157,7 @@ def main():
     # the reference's default arguments (check_input_limits=True, metrics.py:439-444).  On one-hot maps the reference's own assert
     # fires (a tri-linear blend of ones exceeds 1.0 by an ulp: tests/test_gpu_dice_cce.py), so the default path is timed on the
     # same maps scaled by 1/2: same kernels, same bytes, plus the read-back of the four extrema the assert looks at
-    r_def = None
+    r_def = r_def_eager = None
     if dist is None and not args.no_batch1:
         try:
             movh, fixh = mov * 0.5, fix * 0.5
@@ -1072,7 +1171,15 @@ def main():
                     events[1].record()
                     events[2].record()
                 return nd.all_reduce_mean_dice(d, async_op=True)
-            r_def = timed(step_default, o_steps, 2, None, dev)
+            r_def = timed(pipelined(step_default, nstreams, dev), o_steps, 2, None, dev, sparse_events=nstreams > 1)
+            ne.checked.flush()               # every range assert of the run has been looked at (none may have failed)
+            # the same with the assert raised at the call site (one host read-back of the extrema per step)
+            keep_checked = ne.checked.enabled
+            ne.checked.enabled = False
+            try:
+                r_def_eager = timed(step_default, o_steps, 2, None, dev)
+            finally:
+                ne.checked.enabled = keep_checked
             del movh, fixh
         except Exception as e:   # noqa
             log('default-argument run failed: %s' % e)
@@ -1089,7 +1196,7 @@ def main():
             else:
                 smov, sfix, strf = synth.cfg2_batch(Bs, S, L, device=dev, seed0=100 + 3 * rank * Bs)
             s_refsig = pipelined(make_steps(smov, sfix, strf)[2], nstreams, dev)
-            r_strong = timed(s_refsig, o_steps, 2, dist, dev)
+            r_strong = timed(s_refsig, o_steps, 2, dist, dev, sparse_events=nstreams > 1)
             del smov, sfix, strf, s_refsig
             torch.cuda.empty_cache()
         except Exception as e:   # noqa
@@ -1103,7 +1210,7 @@ def main():
             else:
                 wmov, wfix, wtrf = synth.cfg2_batch(Bw, S, L, device=dev, seed0=100 + 3 * rank * Bw)
                 w_refsig = pipelined(make_steps(wmov, wfix, wtrf)[2], nstreams, dev)
-                r_weak = timed(w_refsig, o_steps, 2, dist, dev)
+                r_weak = timed(w_refsig, o_steps, 2, dist, dev, sparse_events=nstreams > 1)
                 del wmov, wfix, wtrf, w_refsig
                 torch.cuda.empty_cache()
         except Exception as e:   # noqa
@@ -1201,6 +1308,7 @@ def main():
                            else 'reference-signature calls run eagerly: two kernels'),
             'volumes_per_gpu': B, 'global_batch': B * world, 'size': S, 'labels': L,
             'pipeline': ('reference_api' if not args.direct else 'fused_direct') if fused else 'unfused',
+            'prewarm_ms_before_the_warmup_steps': PREWARM_MS,
             'step_launch': 'one hipGraph replay per step (--graph)' if args.graph else
                            ('direct kernel launches, independent steps round-robin on %d HIP streams' % nstreams if nstreams > 1 else 'direct kernel launches, one stream'),
             'parallelism': 'dp%d (batch-sharded, one RCCL all-reduce of 2 floats per step)' % world,
@@ -1285,7 +1393,7 @@ def main():
         b1_ms = rf['span_ms'] if nstreams > 1 else rf['k0_ms']
         out['config2_batch1'] = {
             'what': 'BASELINE config 2 as written: batch = 1, one %d^3 x %d-label volume per step, %d steps%s' % (
-                S, L, b1_steps, ' round-robin on %d streams' % nstreams if nstreams > 1 else ''),
+                S, L, b1_steps, ' round-robin on %d streams (%s)' % (nstreams, b1_form) if nstreams > 1 else ''),
             'fused': {'ms': round(rf['elapsed'] / b1_steps * 1e3, 4), 'Mvoxels_per_s': round(V * b1_steps / rf['elapsed'] / 1e6, 1),
                       'kernel_ms': round(b1_ms, 4), 'kernel_own_duration_ms': round(rf['k0_ms'], 4),
                       'frac': round(b1_bytes / (b1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -1309,11 +1417,17 @@ def main():
         out['config']['batch1_Mvoxels_per_s'] = out['config2_batch1']['fused']['Mvoxels_per_s']
     if r_def is not None:
         out['default_args_pipeline'] = {
-            'what': 'SpatialTransformer -> metrics.Dice() with the reference defaults (check_input_limits=True: the range asserts read '
-                    'the extrema the fused kernel returns, one host read-back per step) on the bench maps scaled by 1/2 (on one-hot '
-                    'maps the reference assert itself fires, see tests); %d steps' % o_steps,
+            'what': 'SpatialTransformer -> metrics.Dice() with the reference defaults (check_input_limits=True, metrics.py:439-444) on the bench '
+                    'maps scaled by 1/2 (on one-hot maps the reference assert itself fires, see tests): the range asserts travel with the '
+                    'result (neurite_amd/checked.py: extrema from the fused kernel, raised when the values reach the host or at a later call), '
+                    'no host read-back per step; steps issued as in the headline; %d steps' % o_steps,
             'value': round(B * V * o_steps / r_def['elapsed'] / 1e6, 2), 'unit': 'Mvoxels/s',
-            'ms_per_step': round(r_def['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(r_def['k0_ms'], 4)}
+            'ms_per_step': round(r_def['elapsed'] / o_steps * 1e3, 4), 'kernel_ms': round(r_def['span_ms'] if nstreams > 1 else r_def['k0_ms'], 4),
+            'vs_headline': round(B * V * o_steps / r_def['elapsed'] / 1e6 / value, 4)}
+        if r_def_eager is not None:
+            out['default_args_pipeline']['assert_raised_at_the_call_site'] = {
+                'what': 'neurite_amd.checked.enabled = False: one host read-back of the four extrema per step, steps serial',
+                'value': round(B * V * o_steps / r_def_eager['elapsed'] / 1e6, 2), 'ms_per_step': round(r_def_eager['elapsed'] / o_steps * 1e3, 4)}
     if r_bf16 is not None:
         b16 = (2 * L + 12 + 2 * L) * V * B
         out['bf16_storage'] = {

@@ -18,6 +18,7 @@ __version__ = '0.1.0'
 from . import _lib  # noqa: F401
 from . import errors  # noqa: F401
 from . import deferred  # noqa: F401
+from . import checked  # noqa: F401
 from . import utils  # noqa: F401
 from . import layers  # noqa: F401
 from . import metrics  # noqa: F401

@@ -38,7 +38,9 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
     stored as bfloat16: float32 arithmetic on the widened values, exact for one-hot label maps, half the bytes), 3-D,
     L in {4, 8, 16, 32, 64, 128, 256}.  Linear interpolation.  Returns dice [B, L] (optionally also the warped
     volume and the partial sums [B, 3, L]).  check_input_limits defaults to False because a tri-linearly
-    warped one-hot map exceeds 1.0 by an ulp (see tests); pass True for the reference's asserts.
+    warped one-hot map exceeds 1.0 by an ulp (see tests); pass True for the reference's asserts (one read-back of the extrema per
+    call), or 'deferred' for the same asserts without the host round trip: the values come back as a `checked.CheckedTensor`
+    (neurite_amd/checked.py) that raises when they are brought to the host, or at a later call once the extrema have arrived.
     """
     lib = _lib.lib()
     dev = _lib.require_device(moving, trf, fixed)
@@ -102,6 +104,9 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
                                                 _lib.ptr(minmax) if check_input_limits else None,
                                                 int(_tune), _lib.ptr(ws), nws, _lib.stream_ptr(dev))
         _lib.check(rc, 'nrt_warp_dice_soft')
+        if check_input_limits == 'deferred':
+            from . import checked
+            return checked.wrap(dice, minmax, 'fused warp + Dice')
         if check_input_limits:
             mn_t, mx_t, mn_p, mx_p = [float(v) for v in minmax.tolist()]
             if not (mn_t >= 0. and mn_p >= 0. and mx_t <= 1. and mx_p <= 1.):
@@ -122,6 +127,8 @@ def warp_dice(moving, trf, fixed, indexing='ij', single_transform=False, fill_va
         raise NotImplementedError('warp_dice: only the transform is differentiable in the fused form; use '
                                   'layers.SpatialTransformer + metrics.Dice for gradients wrt the volumes')
     if torch.is_grad_enabled() and shift.requires_grad:
+        if check_input_limits == 'deferred':
+            check_input_limits = True                  # (a graph is being recorded: the assert is looked at before the node exists)
         d = _WarpDiceFn.apply(shift, run, run_backward)
     else:
         d = run()

@@ -366,10 +366,13 @@ class Dice:
         src = warp._sources
         if other.data_ptr() % 16 or src['vol'].data_ptr() % 16 or not other.is_contiguous():
             return None                 # what the fused kernel cannot take goes the ordinary way (which evaluates the warp)
+        from . import checked
+        # the range asserts of :439-444 on this (already lazy) pipeline travel with the result instead of stopping the host at every
+        # call (checked.py); `checked.enabled = False` raises at the call site as everywhere else
+        limits = ('deferred' if checked.enabled else True) if self.check_input_limits else False
         try:
             return fused.warp_dice(src['vol'], src['shift'], other, indexing='ij', single_transform=src['single_transform'],
-                                   fill_value=src['fill_value'], laplace_smoothing=eps,
-                                   check_input_limits=bool(self.check_input_limits))
+                                   fill_value=src['fill_value'], laplace_smoothing=eps, check_input_limits=limits)
         except (NotImplementedError, _lib.NeuriteAmdError):
             # sizes beyond the fused kernel's 32-bit offsets and the like: the eager pipeline handles them
             return None
@@ -466,6 +469,9 @@ class Dice:
     def mean_dice(self, y_true, y_pred):
         """mean dice across all patches and labels, optionally weighted (neurite/tf/metrics.py:484-510)."""
         dice_metric = self.dice(y_true, y_pred)
+        from . import checked
+        if isinstance(dice_metric, checked.CheckedTensor):
+            dice_metric = dice_metric.checked()     # (the finite test below stops the host anyway: the range assert is looked at here)
         if self.weights is not None:                                                      # :502-505
             w = self.weights
             assert len(w.shape) == 2, 'weights should be a matrix broadcastable to [batch_size, nb_labels]'

@@ -68,11 +68,71 @@ def test_deferred_pipeline_matches_eager_and_oracle(dev, batch):
     np.testing.assert_allclose(N(dice.dice(fix, w3)), N(d_e), rtol=0, atol=0)
 
 
+def test_default_range_assert_without_a_host_round_trip(dev, batch):
+    """VERDICT r5 item 5 (neurite/tf/metrics.py:439-444): `Dice()` with the reference's default `check_input_limits=True` on the
+    deferred-warp pipeline does not stop the host at every call.  The values come back as a CheckedTensor: device operations pass, host
+    access raises `InvalidArgumentError('value outside range')`; a result that never reaches the host raises at a LATER deferred-assert call
+    (or at `checked.flush()`), once its extrema have arrived; `checked.enabled = False` raises at the call site."""
+    from neurite_amd import checked
+    mov, fix, trf = batch
+    st = ne.layers.SpatialTransformer()
+    D = ne.metrics.Dice()
+    checked.flush()
+    overshoots = float(eager(lambda: st([mov, trf])).max()) > 1.0
+    assert overshoots                                            # (one-hot maps, tri-linear weights: an ulp above 1)
+    want = ne.metrics.Dice(check_input_limits=False).dice(fix, st([mov, trf]))
+    # ---- a FAILING assert -----------------------------------------------------------------------------------------------------------
+    d = D.dice(fix, st([mov, trf]))                              # no exception here, no host synchronisation
+    assert isinstance(d, checked.CheckedTensor) and tuple(d.shape) == tuple(want.shape) and d.device == want.device
+    m = (d * 2.0).sum()                                          # device operations see the values
+    assert type(m) is torch.Tensor and float(m) == float((want * 2.0).sum())
+    for touch in (lambda: d.cpu(), lambda: d[0, 0].item(), lambda: d.tolist(), lambda: d.detach().cpu().numpy(), lambda: repr(d),
+                  lambda: d.numpy(), lambda: d.reshape(-1)[:3].clone().tolist(), lambda: float(d[1, 2])):
+        with pytest.raises(ne.errors.InvalidArgumentError, match='value outside range'):
+            touch()
+    assert checked.pending_count() == 0
+    # ... that nobody looks at on the host is reported by a later call, or by flush()
+    d1 = D.dice(fix, st([mov, trf]))
+    torch.cuda.synchronize()
+    with pytest.raises(ne.errors.InvalidArgumentError, match='value outside range'):
+        D.dice(fix, st([mov, trf]))
+    checked._pending.clear()
+    d2 = D.dice(fix, st([mov, trf]))
+    with pytest.raises(ne.errors.InvalidArgumentError):
+        checked.flush()
+    assert checked.pending_count() == 0
+    del d1, d2
+    # mean_dice stops the host for its finite test anyway: the assert is looked at there
+    with pytest.raises(ne.errors.InvalidArgumentError, match='value outside range'):
+        D.mean_dice(fix, st([mov, trf]))
+    checked.flush()
+    # ---- a PASSING assert: maps scaled into the range ---------------------------------------------------------------------------------
+    movh, fixh = mov * 0.5, fix * 0.5
+    wanth = ne.metrics.Dice(check_input_limits=False).dice(fixh, st([movh, trf]))
+    for _ in range(3):
+        dh = D.dice(fixh, st([movh, trf]))
+        assert isinstance(dh, checked.CheckedTensor)
+    assert torch.equal(dh.cpu(), wanth.cpu()) and bits_equal(N(dh), N(wanth))
+    checked.flush()
+    assert checked.pending_count() == 0
+    assert float(D.mean_dice(fixh, st([movh, trf]))) == float(wanth.mean())
+    # ---- the switch: eager raise at the call site ---------------------------------------------------------------------------------------
+    keep = checked.enabled
+    checked.enabled = False
+    try:
+        with pytest.raises(ne.errors.InvalidArgumentError, match='value outside range'):
+            D.dice(fix, st([mov, trf]))
+        assert type(D.dice(fixh, st([movh, trf]))) is torch.Tensor
+    finally:
+        checked.enabled = keep
+
+
 def test_deferred_respects_semantics(dev, batch):
     mov, fix, trf = batch
     st = ne.layers.SpatialTransformer()
-    # the reference's default range assert fires for a tri-linearly warped one-hot map (an ulp above 1) in both forms
-    for form in (lambda: ne.metrics.Dice().dice(fix, st([mov, trf])), lambda: eager(lambda: ne.metrics.Dice().dice(fix, st([mov, trf])))):
+    # the reference's default range assert fires for a tri-linearly warped one-hot map (an ulp above 1) in both forms (the deferred
+    # pipeline raises when the values are brought to the host: neurite_amd/checked.py, test_default_range_assert_without_a_host_round_trip)
+    for form in (lambda: ne.metrics.Dice().dice(fix, st([mov, trf])).cpu(), lambda: eager(lambda: ne.metrics.Dice().dice(fix, st([mov, trf])))):
         try:
             form()
             raised = False
