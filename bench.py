@@ -770,6 +770,16 @@ def timed(step, steps, warmup, dist=None, dev=None, sparse_events=False):
             'mean': None if m is None else float(m)}
 
 
+class _Done:
+    """a step result with nothing left to collect (keeps the step's output alive until the next step has been issued)"""
+
+    def __init__(self, value=None):
+        self.value = value
+
+    def result(self):
+        return None
+
+
 class _OnStream:
     """a PendingMean whose collection runs on the stream its step was issued on"""
 
@@ -1113,6 +1123,24 @@ def main():
     o_elapsed, o_k0, o_k1, o_m = r_other['elapsed'], r_other['k0_ms'], r_other['k1_ms'], r_other['mean']
     # the same kernel through the other entry (direct fused API when the reference-signature calls are the timed pipeline)
     r_ref = timed(step_fused if (fused and not args.direct) else step_refsig, o_steps, 2, dist, dev)
+    # the stand-alone warp (the drop-in op that WRITES the warped volume) issued like the headline steps: independent launches
+    # round-robin over the step streams, nothing else in between -- the rate at which interpn launches complete
+    r_warp = None
+    if dist is None and fused and nstreams > 1 and not args.no_batch1:
+        try:
+            def step_warp(events=None):
+                if events is not None:
+                    events[0].record()
+                w = ne.deferred.materialize(st([mov, trf]))
+                if events is not None:
+                    events[1].record()
+                    events[2].record()
+                return _Done(w)
+            r_warp = timed(pipelined(step_warp, nstreams, dev), o_steps, 2, None, dev, sparse_events=True)
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa
+            log('pipelined stand-alone warp failed: %s' % e)
+            r_warp = None
     # BASELINE config 2 proper is batch = 1: the same two pipelines on the first volume only (N = 1 runs)
     r_b1 = None
     if dist is None and B > 1 and not args.no_batch1:
@@ -1440,7 +1468,14 @@ def main():
             'max_abs_diff_vs_default_f32_kernel': r_bf16['max_abs_diff_vs_default_f32_kernel']}
     # the stand-alone op (the drop-in `interpn` / SpatialTransformer call that WRITES the warped volume; 268 B per voxel as well)
     out['roofline']['standalone_interpn'] = {'frac': dropin['interpn_frac_of_peak'], 'avg_launch_ms': dropin['interpn_ms'],
-                                             'achieved': dropin['interpn_GBs'], 'volumes_per_launch': B}
+                                             'achieved': dropin['interpn_GBs'], 'volumes_per_launch': B,
+                                             'what': 'isolated launches (the eager two-kernel pipeline, steps serial)'}
+    if r_warp is not None:
+        out['roofline']['standalone_interpn']['pipelined'] = {
+            'what': 'the warp alone, independent launches round-robin on %d streams (as the headline steps): device time of the region / launches; %d launches' % (nstreams, o_steps),
+            'avg_launch_ms': round(r_warp['span_ms'], 4),
+            'achieved': round(interp_bytes / (r_warp['span_ms'] * 1e-3) / 1e9, 1),
+            'frac': round(interp_bytes / (r_warp['span_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if fused:
         out['roofline']['unfused_api_accounting_524B_per_voxel_GBs'] = round(
             (INTERPN_BYTES_PER_VOXEL(L, 3) + DICE_BYTES_PER_VOXEL(L)) * V * B / (kms * 1e-3) / 1e9, 1)

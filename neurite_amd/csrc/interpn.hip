@@ -682,6 +682,7 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
                           vol_bytes < (1ull << 32);
     const bool can_lean = (method == NRT_INTERP_LINEAR ? (loc_mode == NRT_LOC_LINSPACE || loc) : (loc_mode != NRT_LOC_LINSPACE && loc)) &&
                           nrt_lean_supported(a.S, a.O, channels, ndim, vol, loc, out, vol_batch_stride, loc_batch_stride);
+    const bool variant_was_auto = variant == 0;
     if (variant == 0) {
         if (can_zrun) {
             // Displacement fields and absolute locations: the wave-cache kernel (variant 10, fused_wc.h) since its round-5 schedule --
@@ -720,9 +721,12 @@ extern "C" int nrt_interpn_f32_ex(const float *vol, const float *loc, float *out
         case 3:
         case 4: launch_zrun(a, batch, loc_mode, variant, tune, st); break;
         case 5: launch_tile_any(a, batch, loc_mode, tune, st); break;
-        case 8:
+        case 8:                             // few channels: tile form (one voxel per lane, corners through the texture unit)
             if (!can_lean) return NRT_ERR_UNSUPPORTED;
-            return nrt_lean_launch(&a, batch, loc_mode, method == NRT_INTERP_NEAREST ? 1 : 0, st);
+            return nrt_lean_launch(&a, batch, loc_mode, method == NRT_INTERP_NEAREST ? 1 : 0, st, variant_was_auto ? NRT_LEAN_FORM_AUTO : NRT_LEAN_FORM_TILE);
+        case 11:                            // few channels, per-voxel locations, linear: box form (source box of a tile staged in LDS)
+            if (!can_lean || method != NRT_INTERP_LINEAR || loc_mode == NRT_LOC_LINSPACE) return NRT_ERR_UNSUPPORTED;
+            return nrt_lean_launch(&a, batch, loc_mode, 0, st, NRT_LEAN_FORM_BOX);
         case 10:                            // wave-private LDS row cache (fused_wc.h) without the Dice half
             if (!can_zrun || !nrt_wc_interpn_supported(&a, batch)) return NRT_ERR_UNSUPPORTED;
             return nrt_wc_interpn_launch(&a, batch, loc_mode, st);

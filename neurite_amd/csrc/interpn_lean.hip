@@ -400,6 +400,193 @@ __global__ __launch_bounds__(256) void interpn_lean_tile(InterpArgs a, int ltz, 
     }
 }
 
+// ---- box form (per-voxel locations, linear; round 6; variant 11, NOT the default: measured slower, see nrt_lean_launch) ---------------
+// The tile form above is bound by the texture-address unit: with a displacement field the lanes of a corner load are not consecutive
+// dwords and TA serves them about one LANE per clock -- 4 lane accesses per voxel at C = 1, 8 at C = 3: 0.117 / 0.264 ms per 4 x 160^3
+// against a roof of 0.041 / 0.082 (profiles/r04_smallc).  This form stages what north_star names: a block owns a
+// TX x 8 x 32 (x, y, z) tile of OUTPUT voxels, finds the bounding box of the source voxels its corners touch (a block-wide min / max of the
+// clipped floors), copies the box from HBM into LDS with 16-byte loads that are consecutive along z (one line request per ~8 lanes
+// instead of one per lane), and every lane gathers its 8 corners from LDS (`ds_read`: 64 independent addresses per instruction).
+// Rounds 1-2 had built this idea twice (variants 6 and 9: 450 issue slots per voxel for boxes found per wave, divisions and 64-bit
+// addresses in the copy -- slower than the plain gather); here the box is per BLOCK, the copy is a row loop with one multiply-shift
+// per 16-byte piece, the location of a voxel is read once and kept in registers across both phases.  A box that does not fit the LDS
+// budget (steep or incoherent fields: the tile's source footprint grows with the displacement gradient) takes the direct gather of
+// the tile form for that tile -- decided per tile, inside the kernel, from the same min / max.
+// Same float32 operations in the same order as the tile form (lean_corner, (wx wy) wz, corners in itertools.product order): bit-identical.
+constexpr int BOX_TY = 8, BOX_TZ = 32;
+
+template <int C, int MODE, int TX>
+__global__ __launch_bounds__(256) void interpn_lean_box(InterpArgs a, unsigned nTy, unsigned nTz, unsigned ntiles, unsigned box_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char box[];           // box_bytes + 32 (slack for the hi-corner over-read) + 96 (bbox exchange)
+    const unsigned tile = nrt_xcd_block(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
+    const unsigned tzi = tile % nTz, t2 = tile / nTz, tyi = t2 % nTy, txi = t2 / nTy;     // uniform: scalar ALU
+    const unsigned t = threadIdx.x;
+    const int lz = (int)(t & 31u), ly = (int)(t >> 5);
+    const int b = blockIdx.y;
+    const char *locb = (const char *)(a.loc + (long long)b * a.loc_bs);
+    float *out = (float *)a.out + (long long)b * a.out_bs;
+    const float *addb = a.addend ? a.addend + (long long)b * a.addend_bs : nullptr;
+    const float mxx = (float)(a.S[0] - 1), mxy = (float)(a.S[1] - 1), mxz = (float)(a.S[2] - 1);
+    const unsigned SY = (unsigned)a.S[1], SZ = (unsigned)a.S[2];
+    constexpr unsigned C4 = (unsigned)(C * 4);
+    const int O0 = a.O[0], O1 = a.O[1], O2 = a.O[2];
+    const int y = (int)tyi * BOX_TY + ly, z = (int)tzi * BOX_TZ + lz;
+    const bool yzv = y < O1 && z < O2;
+    const int yc = min(y, O1 - 1), zc = min(z, O2 - 1);
+
+    // ---- phase 1: the locations of this lane's TX voxels (one per x-plane of the tile), the box of their lower corners -------------
+    float p[TX][3];
+    unsigned qf[TX];
+    int mn0 = 0x7fffffff, mn1 = 0x7fffffff, mn2 = 0x7fffffff, mx0 = 0, mx1 = 0, mx2 = 0;
+#pragma unroll
+    for (int k = 0; k < TX; ++k) {
+        const int xc = min((int)txi * TX + k, O0 - 1);                   // (voxels past the volume repeat its last plane: loads stay unconditional)
+        qf[k] = nrt_mad24(nrt_mad24((unsigned)xc, (unsigned)O1, (unsigned)yc), (unsigned)O2, (unsigned)zc);
+        const float *lp = (const float *)(locb + (size_t)(nrt_times3(qf[k]) << 2));
+        const float r0 = lp[0], r1 = lp[1], r2 = lp[2];
+        if (MODE == NRT_LOC_SHIFT) { p[k][0] = nrt_add((float)xc, r0); p[k][1] = nrt_add((float)yc, r1); p[k][2] = nrt_add((float)zc, r2); }
+        else { p[k][0] = r0; p[k][1] = r1; p[k][2] = r2; }
+        // lower corner as lean_corner forms it (floor, clip, integer clamp for NaN)
+        const int i0 = min(max((int)__builtin_amdgcn_fmed3f(floorf(p[k][0]), 0.0f, mxx), 0), a.S[0] - 1);
+        const int i1 = min(max((int)__builtin_amdgcn_fmed3f(floorf(p[k][1]), 0.0f, mxy), 0), a.S[1] - 1);
+        const int i2 = min(max((int)__builtin_amdgcn_fmed3f(floorf(p[k][2]), 0.0f, mxz), 0), a.S[2] - 1);
+        mn0 = min(mn0, i0); mx0 = max(mx0, i0); mn1 = min(mn1, i1); mx1 = max(mx1, i1); mn2 = min(mn2, i2); mx2 = max(mx2, i2);
+    }
+#pragma unroll
+    for (int off = 1; off < NRT_WAVE; off <<= 1) {
+        mn0 = min(mn0, __shfl_xor(mn0, off, NRT_WAVE)); mx0 = max(mx0, __shfl_xor(mx0, off, NRT_WAVE));
+        mn1 = min(mn1, __shfl_xor(mn1, off, NRT_WAVE)); mx1 = max(mx1, __shfl_xor(mx1, off, NRT_WAVE));
+        mn2 = min(mn2, __shfl_xor(mn2, off, NRT_WAVE)); mx2 = max(mx2, __shfl_xor(mx2, off, NRT_WAVE));
+    }
+    int *bb = (int *)(box + box_bytes + 32u);                            // [4 waves][6]
+    if ((t & 63u) == 0u) {
+        int *w = bb + (t >> 6) * 6u;
+        w[0] = mn0; w[1] = mx0; w[2] = mn1; w[3] = mx1; w[4] = mn2; w[5] = mx2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        mn0 = min(mn0, bb[w * 6 + 0]); mx0 = max(mx0, bb[w * 6 + 1]); mn1 = min(mn1, bb[w * 6 + 2]);
+        mx1 = max(mx1, bb[w * 6 + 3]); mn2 = min(mn2, bb[w * 6 + 4]); mx2 = max(mx2, bb[w * 6 + 5]);
+    }
+    // (uniform for the compiler too: the copy loop's bounds and the row stride live in scalar registers)
+    const unsigned x0b = (unsigned)__builtin_amdgcn_readfirstlane(mn0), y0b = (unsigned)__builtin_amdgcn_readfirstlane(mn1);
+    const unsigned z0v = (unsigned)__builtin_amdgcn_readfirstlane(mn2);
+    const unsigned nx = (unsigned)min(__builtin_amdgcn_readfirstlane(mx0) + 1, a.S[0] - 1) - x0b + 1u;       // upper corners: one further, inside the volume
+    const unsigned ny = (unsigned)min(__builtin_amdgcn_readfirstlane(mx1) + 1, a.S[1] - 1) - y0b + 1u;
+    const unsigned z1v = (unsigned)min(__builtin_amdgcn_readfirstlane(mx2) + 1, a.S[2] - 1);
+    const unsigned zb0 = (z0v * C4) & ~15u, cpr = ((((z1v + 1u) * C4 + 15u) & ~15u) - zb0) >> 4;           // 16-byte pieces of a z-run
+    // LDS rows are 16 / 32 / 64 pieces long (the lanes that walk a row): a wave instruction then fills 4 / 2 / 1 CONSECUTIVE rows -- the
+    // form LDS-DMA needs (destination = M0 + 16 lane) -- and a sweep of the block 4 KB
+    const unsigned lsh = cpr <= 16u ? 4u : (cpr <= 32u ? 5u : 6u);
+    const unsigned rowb = 16u << lsh, rps = 256u >> lsh, nrows = nx * ny;
+    const unsigned nsweep = (nrows + rps - 1u) / rps;
+    const bool staged = nsweep * 4096u <= box_bytes && nrows * ny < 65536u && cpr <= 64u;
+
+    // ---- phase 2: the box, HBM -> LDS by LDS-DMA (no registers in between, every piece requested before the first one is waited for) --
+    if (staged) {
+        const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)((const float *)a.vol + (long long)b * a.vol_bs), 0, (int)((unsigned)a.S[0] * SY * SZ * C4), 0x00020000);
+        const unsigned k = t & ((1u << lsh) - 1u), r0 = t >> lsh;
+        const unsigned m_ny = (65536u + ny - 1u) / ny;                                                    // r / ny = (r m) >> 16 for r ny < 2^16
+        const unsigned wave_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(t >> 6)) * 1024u;          // this wave's KB of a sweep
+        typedef __attribute__((address_space(3))) void bx_lds;
+        for (unsigned sw = 0; sw < nsweep; ++sw) {
+            const unsigned r = sw * rps + r0;
+            const bool act = r < nrows && k < cpr;
+            const unsigned rx = (r * m_ny) >> 16, ry = r - rx * ny;
+            const unsigned goff = nrt_mad24(nrt_mad24(x0b + rx, SY, y0b + ry), SZ, 0u) * C4 + zb0 + (k << 4);
+            // (a piece that reaches past the volume's end comes back zero-padded; inactive lanes read nothing and store zeros)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (bx_lds *)(box + sw * 4096u + wave_dst), 16, act ? goff : 0xffffffffu, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                                  // vmcnt(0): this wave's pieces have landed
+    }
+    __syncthreads();
+
+    // ---- phase 3: corners from LDS (or, for a box that did not fit, from memory as the tile form reads them), blend, store -----------
+    const char *vol = (const char *)((const float *)a.vol + (long long)b * a.vol_bs);
+    const unsigned str_x = SY * SZ * C4, str_y = SZ * C4;
+#pragma unroll
+    for (int k = 0; k < TX; ++k) {
+        int ix, iy, iz, ux, uy, uz;
+        float w0x, w1x, w0y, w1y, w0z, w1z;
+        lean_corner(p[k][0], mxx, a.S[0] - 1, ix, ux, w0x, w1x);
+        lean_corner(p[k][1], mxy, a.S[1] - 1, iy, uy, w0y, w1y);
+        lean_corner(p[k][2], mxz, a.S[2] - 1, iz, uz, w0z, w1z);
+        const float wxy[4] = {nrt_mul(w0x, w0y), nrt_mul(w0x, w1y), nrt_mul(w1x, w0y), nrt_mul(w1x, w1y)};
+        float v[8][C];
+        if (staged) {
+            const unsigned base = nrt_mad24(nrt_mad24((unsigned)ix - x0b, ny, (unsigned)iy - y0b), rowb, (unsigned)iz * C4 - zb0);
+            const unsigned sx = ux ? ny * rowb : 0u, sy = uy ? rowb : 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *lp = (const float *)(box + base + ((r & 2) ? sx : 0u) + ((r & 1) ? sy : 0u));
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float lo_v = lp[c], hi_v = lp[C + c];          // (the z-neighbour is read whether or not it is a corner: one ds_read2 / wider read)
+                    v[2 * r][c] = lo_v;
+                    v[2 * r + 1][c] = uz ? hi_v : lo_v;
+                }
+            }
+        } else {
+            const unsigned base = nrt_mad24(nrt_mad24((unsigned)ix, SY, (unsigned)iy), SZ, (unsigned)iz) * C4;
+            const unsigned sx = ux ? str_x : 0u, sy = uy ? str_y : 0u, sz = uz ? C4 : 0u;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner)
+                load_c<C>(vol, base + ((corner & 4) ? sx : 0u) + ((corner & 2) ? sy : 0u) + ((corner & 1) ? sz : 0u), v[corner]);
+        }
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.0f;                       // :160
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const float wt = nrt_mul(wxy[corner >> 1], (corner & 1) ? w1z : w0z);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = nrt_add(acc[c], nrt_mul(wt, v[corner][c]));     // :191
+        }
+        if (a.has_fill) {
+            const bool oob = (p[k][0] < 0.0f) || (p[k][0] > mxx) || (p[k][1] < 0.0f) || (p[k][1] > mxy) || (p[k][2] < 0.0f) || (p[k][2] > mxz);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = apply_fill(acc[c], oob, a.fill_f);
+        }
+        if (addb) {
+            const float *pa = addb + (size_t)qf[k] * (unsigned)C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = nrt_add(pa[c], acc[c]);
+        }
+        if (yzv && (int)txi * TX + k < O0) {
+            float *po = out + (size_t)qf[k] * (unsigned)C;
+            if constexpr (C == 4) __builtin_nontemporal_store((nrt_f4){acc[0], acc[1], acc[2], acc[3]}, (nrt_f4 *)po);
+            else if constexpr (C == 2) __builtin_nontemporal_store((nrt_f2){acc[0], acc[1]}, (nrt_f2 *)po);
+            else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) __builtin_nontemporal_store(acc[c], po + c);
+            }
+        }
+    }
+}
+
+// box budget per block: the C = 1 box of an 8 x 8 x 32 tile whose footprint stretches by g is (8 g + 2)^2 rows of 256 bytes (z extents up
+// to 64 floats) -- 31 KB at g = 1.1, 49 KB at g = 1.5: 48 KB = three blocks per CU; C >= 2 tiles are 4 planes thick and take 64 KB
+template <int C>
+int launch_lean_box(const InterpArgs &a, int batch, int mode, hipStream_t st) {
+    constexpr int TX = C == 1 ? 8 : 4;
+    const unsigned box_bytes = C == 1 ? 48u * 1024u : 64u * 1024u;
+    const unsigned nTx = (a.O[0] + TX - 1) / TX, nTy = (a.O[1] + BOX_TY - 1) / BOX_TY, nTz = (a.O[2] + BOX_TZ - 1) / BOX_TZ;
+    const unsigned ntiles = nTx * nTy * nTz;
+    const unsigned shm = box_bytes + 32u + 96u;
+    dim3 grid(nrt_xcd_grid(ntiles), batch), blk(256);
+    if (mode == NRT_LOC_ABSOLUTE) {
+        if (hipFuncSetAttribute((const void *)interpn_lean_box<C, NRT_LOC_ABSOLUTE, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return NRT_ERR_LAUNCH;
+        hipLaunchKernelGGL((interpn_lean_box<C, NRT_LOC_ABSOLUTE, TX>), grid, blk, shm, st, a, nTy, nTz, ntiles, box_bytes);
+    } else {
+        if (hipFuncSetAttribute((const void *)interpn_lean_box<C, NRT_LOC_SHIFT, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return NRT_ERR_LAUNCH;
+        hipLaunchKernelGGL((interpn_lean_box<C, NRT_LOC_SHIFT, TX>), grid, blk, shm, st, a, nTy, nTz, ntiles, box_bytes);
+    }
+    return NRT_OK;
+}
+
 template <int C>
 void launch_lean_tile(const InterpArgs &a, int batch, int mode, int method_kind, hipStream_t st) {
     // 2 x 4 x 32 tiles (a wave: two 32-voxel z-runs); linear interpolation of 2..4 channels: 8 x 2 x 16 (a wave: 2 x 2 x 16), whose
@@ -483,9 +670,28 @@ bool nrt_lean_supported(const int *vol_shape, const int *out_shape, int channels
     return true;
 }
 
-int nrt_lean_launch(const void *args, int batch, int mode, int method_kind, void *stream) {
+int nrt_lean_launch(const void *args, int batch, int mode, int method_kind, void *stream, int form) {
     const InterpArgs &a = *(const InterpArgs *)args;
     hipStream_t st = nrt_stream(stream);
+    // per-voxel locations, linear: the tile form unless the box form (source bounding box of a tile staged in LDS, variant 11) is asked
+    // for by name -- measured on MI355X, 4 x 160^3 (tools/box_ab.py, profiles/r06_lab/box_ab.jsonl): the box form is bit-identical and
+    // SLOWER on every field and channel count (bench field C = 1 0.137 - 0.159 ms against 0.114 - 0.127, C = 3 0.271 against 0.257; gentle
+    // field C = 1 0.081 against 0.072): what it saves the texture unit it spends on the box search, the barriers between its three
+    // phases and boxes that outgrow the LDS where the field is steep.  Kept as the A/B partner; needs a z extent of at least a tile's 32.
+    if (mode != NRT_LOC_LINSPACE && method_kind == 0 && form == NRT_LEAN_FORM_BOX) {
+        if (a.O[2] < BOX_TZ || batch > 65535) return NRT_ERR_UNSUPPORTED;
+        int rc;
+        switch (a.C) {
+            case 1: rc = launch_lean_box<1>(a, batch, mode, st); break;
+            case 2: rc = launch_lean_box<2>(a, batch, mode, st); break;
+            case 3: rc = launch_lean_box<3>(a, batch, mode, st); break;
+            default: rc = launch_lean_box<4>(a, batch, mode, st); break;
+        }
+        if (rc != NRT_OK) return rc;
+        NRT_CHECK_LAUNCH();
+        return NRT_OK;
+    }
+    if (form == NRT_LEAN_FORM_BOX) return NRT_ERR_UNSUPPORTED;
     if (mode != NRT_LOC_LINSPACE) {           // per-voxel locations: one voxel per lane, compact tiles
         switch (a.C) {
             case 1: launch_lean_tile<1>(a, batch, mode, method_kind, st); break;

@@ -210,6 +210,56 @@ def test_low_dims_int_volumes_and_edge_shapes(dev):
     assert bits_equal(N(ne.utils.interpn(G(one, dev), G(ls, dev), fill_value=0.)), npo.interpn(one, ls, fill_value=0.))
 
 
+@pytest.mark.parametrize('C', [1, 2, 3, 4])
+def test_few_channel_box_form(dev, C):
+    """Round 6 (utils.py:137-191 at the call site models.py:804): the LDS-staged form of the few-channel linear warp --
+    a block stages the source bounding box of an 8 x 8 x 32 / 4 x 8 x 32 output tile in LDS (LDS-DMA, 16-byte pieces consecutive along z)
+    and gathers the corners with ds_read (`interpn_lean_box`, variant 11) instead of sending 4-8 scattered lane accesses per voxel
+    through the texture unit (`interpn_lean_tile`, variant 8, the default: the box form measured slower on every field,
+    profiles/r06_lab/box_ab.jsonl).  Bit-identical to the tile form and to the oracle: ragged volumes (partial tiles on every side),
+    locations outside the volume, fill, absolute locations, the addend epilogue (VecInt), NaN / inf locations (memory-safe), and a field
+    steep enough that the boxes do not fit the LDS budget (the kernel then gathers that tile directly)."""
+    rng = np.random.default_rng(600 + C)
+    for S, O in (((40, 37, 70), (40, 37, 70)), ((17, 9, 33), (21, 13, 45)), ((64, 64, 96), (64, 64, 96))):
+        vol = rng.standard_normal(S + (C,)).astype(F)
+        base = np.stack(np.meshgrid(*[np.linspace(0, s - 1, o) for s, o in zip(S, O)], indexing='ij'), -1)
+        for amp, fill in ((1.5, None), (4.0, 0.25), (60.0, None)):
+            loc = (base + rng.normal(0, amp, O + (3,))).astype(F)
+            got = N(ne.utils.interpn(G(vol, dev), G(loc, dev), fill_value=fill, _variant=11))
+            tile = N(ne.utils.interpn(G(vol, dev), G(loc, dev), fill_value=fill, _variant=8))
+            auto = N(ne.utils.interpn(G(vol, dev), G(loc, dev), fill_value=fill))
+            assert bits_equal(got, tile) and bits_equal(auto, got), (S, O, amp)
+            if np.prod(O) <= 40 * 37 * 70:
+                assert bits_equal(got, npo.interpn(vol, loc, 'linear', fill)), (S, O, amp)
+    # SpatialTransformer (identity grid + shift), batched, and the addend epilogue of VecInt / compose
+    S = (24, 40, 64)
+    vol = rng.standard_normal((2,) + S + (C,)).astype(F)
+    trf = rng.normal(0, 2.5, (2,) + S + (3,)).astype(F)
+    st = ne.layers.SpatialTransformer()
+    a = N(st([G(vol, dev), G(trf, dev)]))
+    st8 = ne.layers.SpatialTransformer()
+    st8._variant = 8
+    assert bits_equal(a, N(st8([G(vol, dev), G(trf, dev)])))
+    for bi in range(2):
+        assert bits_equal(a[bi], npo.interpn(vol[bi], ijk(S) + trf[bi]))
+    # non-finite locations: same bits as the tile form wherever the reference is defined, no fault anywhere
+    loc = (ijk(S) + trf[0]).astype(F)
+    loc[3, 3, 3] = [np.inf, -np.inf, 1e30]
+    loc[5, 6, 7] = [np.nan, np.nan, np.nan]
+    g11 = N(ne.utils.interpn(G(vol[0], dev), G(loc, dev), _variant=11))
+    g8 = N(ne.utils.interpn(G(vol[0], dev), G(loc, dev), _variant=8))
+    ok = np.ones(S, bool)
+    ok[5, 6, 7] = False
+    assert bits_equal(g11[ok], g8[ok])
+    torch.cuda.synchronize()
+    # a z extent below the tile's 32 keeps the tile form; variant 11 then says so
+    small = rng.standard_normal((8, 8, 16, C)).astype(F)
+    ls = rng.uniform(0, 7, (8, 8, 16, 3)).astype(F)
+    assert bits_equal(N(ne.utils.interpn(G(small, dev), G(ls, dev))), npo.interpn(small, ls))
+    with pytest.raises(ne._lib.NeuriteAmdError):
+        ne.utils.interpn(G(small, dev), G(ls, dev), _variant=11)
+
+
 def test_non_finite_locations_are_memory_safe(dev):
     rng = np.random.default_rng(2)
     vol = rng.standard_normal((6, 6, 6, 32)).astype(F)
