@@ -91,7 +91,7 @@ def parse():
                     help='time neurite_amd.fused.warp_dice called directly instead of the reference-signature calls (same kernel)')
     ap.add_argument('--no-batch1', action='store_true',
                     help='skip the extra batch = 1 runs (profiling: every launch of the gather kernels then has the headline shape)')
-    ap.add_argument('--streams', type=int, default=2,
+    ap.add_argument('--streams', type=int, default=3,
                     help='independent steps are issued round-robin on this many HIP streams, so that the head of step k + 1 fills the tail of '
                          'step k and the small second-stage kernels of a step run beside the next gather (1: strictly serial steps; the '
                          'line always carries the serial figures as roofline.isolated_launch)')
