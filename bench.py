@@ -27,8 +27,17 @@ is BASELINE config 4 AS WRITTEN -- global batch 32 fixed, 32 / N volumes per ran
     python bench.py --gpus N --weak       # N > 1 with 4 volumes per GPU whatever N is ("scaling": "weak") as the parsed line
     python bench.py --global-batch 32     # N = 1 with all 32 volumes of config 4 as the parsed line
 
-Rank 0 prints ONE JSON line on stdout.  `roofline` is the dominant kernel: achieved = algorithmic bytes per
-launch / its average duration measured with HIP events inside the timed region.  Algorithmic bytes per
+Steps are INDEPENDENT (each warps and scores its own batch), so they are issued round-robin over `--streams` HIP streams (default 3): the
+first blocks of step k + 1's gather run on the CUs step k's last round has left, the ~25 us of small second-stage kernels of a step run
+beside the next gather -- what a data-parallel host does with independent work, and what the all-reduce overlap above already did for the
+collective.  Every result is bit-identical to serial steps (tools/two_stream_probe.py).  `--streams 1` issues them strictly one after
+the other.  In front of every measurement, BEFORE its --warmup steps, the step runs untimed for `--prewarm-ms` (250 ms): a fresh device
+needs 100-200 ms of continuous work to reach steady clocks; the timed region is exactly --steps steps.
+
+Rank 0 prints ONE JSON line on stdout.  `roofline` is the dominant kernel: achieved = algorithmic bytes per launch / the time a launch
+costs, measured with HIP events over the timed region -- with pipelined steps that is the device time of the region / launches (the rate at
+which launches complete; a launch's own start-to-end time, `kernel_own_duration_ms`, overlaps its neighbours'), and `roofline.isolated_launch`
+carries the same launch with the device to itself (serial steps: the figure rocprofv3 --stats of a `--streams 1` run reproduces).  Algorithmic bytes per
 voxel (DESIGN.md 4): fused kernel 4C (moving row) + 12 (shift) + 4L (fixed row) = 268 B at C=L=32;
 unfused interpn 4C + 12 + 4C = 268 B, Dice 2*4L = 256 B.  `cpu_baseline` is the C oracle (a port of the
 reference algorithm, oracle/oracle.c) on the host cores this process may use, over a bounded sample, plus BASELINE config 1
