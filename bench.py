@@ -1126,7 +1126,7 @@ def main():
     elapsed, k0_ms, k1_ms, m = r_main['elapsed'], r_main['k0_ms'], r_main['k1_ms'], r_main['mean']
     o_steps = max(5, args.steps // 5)
     # the same steps strictly one after the other (what rocprofv3's per-kernel durations of an isolated launch correspond to)
-    r_iso = timed(main_serial, o_steps, 2, dist, dev) if nstreams > 1 else r_main
+    r_iso = timed(main_serial, args.steps, args.warmup, dist, dev) if nstreams > 1 else r_main
     # the other form of the same pipeline, shorter run, for the record
     r_other = timed(step_unfused if fused else step_fused, o_steps, 2, dist, dev)
     o_elapsed, o_k0, o_k1, o_m = r_other['elapsed'], r_other['k0_ms'], r_other['k1_ms'], r_other['mean']
@@ -1378,11 +1378,11 @@ def main():
             'kernel_own_duration_ms': round(k0_ms, 4),
             'isolated_launch': {
                 'what': 'the same launch with the device to itself: steps issued strictly one after the other on one stream, HIP events around '
-                        'the gather and its Dice second stage; %d steps.  This is the figure rocprofv3 --stats of a `--streams 1` run reproduces' % o_steps,
+                        'the gather and its Dice second stage; %d steps.  This is the figure rocprofv3 --stats of a `--streams 1` run reproduces' % args.steps,
                 'avg_launch_ms': round(r_iso['k0_ms'], 4),
                 'achieved': round(alg_bytes / (r_iso['k0_ms'] * 1e-3) / 1e9, 1),
                 'frac': round(alg_bytes / (r_iso['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                'ms_per_step': round(r_iso['elapsed'] / (o_steps if nstreams > 1 else args.steps) * 1e3, 4)},
+                'ms_per_step': round(r_iso['elapsed'] / args.steps * 1e3, 4)},
         },
         # the reference-signature path (what `SpatialTransformer` + `Dice` callers reach) next to the fused headline
         'roofline_dropin': {'kernel': 'interpn (SpatialTransformer gather, drop-in API), one launch per step', 'bound': 'hbm',

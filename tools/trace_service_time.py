@@ -49,5 +49,7 @@ if rows:
         summary.append({'launches': len(run), 'span_ms': round((e1 - s0) / 1e6, 4), 'service_ms_per_launch': round((e1 - s0) / len(run) / 1e6, 4),
                         'mean_own_duration_ms': round(sum(e - s for s, e, _ in run) / len(run) / 1e6, 4),
                         'fraction_of_span_with_two_or_more_in_flight': round(both / (e1 - s0), 3)})
-    out['runs_of_back_to_back_launches'] = summary
+    summary.sort(key=lambda r: -r['launches'])
+    out['number_of_runs'] = len(summary)
+    out['longest_runs_of_back_to_back_launches'] = summary[:4]
 print(json.dumps(out, indent=1))
