@@ -169,7 +169,7 @@ class CheckedTensor(torch.Tensor):
         out = func(*tree_map(un, args), **tree_map(un, kwargs))
         if not to_host and func in _same_values() and len(checks) == 1 and (not checks[0].done or checks[0].failed):
             def re(o):
-                return CheckedTensor(o, checks[0]) if (type(o) is torch.Tensor and o.device.type != 'cpu') else o
+                return CheckedTensor(o, checks[0]) if type(o) is torch.Tensor else o
             out = tree_map(re, out)
         return out
 

@@ -870,3 +870,56 @@ def test_multiple_losses_decorator_host_side():
             assert metrics.JointSegLoss.lookup(d, t, t) is j and metrics.JointSegLoss.lookup(d, t, t.clone()) is None
             j.result()
     assert getattr(metrics.JointSegLoss._tls, 'current', None) is None
+
+
+def test_checked_tensor_mechanics_on_cpu():
+    """neurite_amd/checked.py without a device: a CheckedTensor lets device-side (here: any torch) operations through to the real values,
+    host access looks at the assert first, operations that return the same values (detach, views, slices, clone) keep the pending assert,
+    derived values are plain tensors.  (The extrema's asynchronous journey is GPU business: tests/test_gpu_deferred.py.)"""
+    from neurite_amd import checked
+    from neurite_amd.errors import InvalidArgumentError
+
+    class Fake:
+        def __init__(self, fail):
+            self.fail, self.done, self.failed, self.looks = fail, False, False, 0
+
+        def resolve(self, block=True):
+            self.looks += 1
+            self.done, self.failed = True, self.fail
+            if self.fail:
+                raise InvalidArgumentError('value outside range')
+            return True
+
+    v = torch.arange(6.).reshape(2, 3)
+    ok = Fake(False)
+    d = checked.CheckedTensor(v, ok)
+    assert tuple(d.shape) == (2, 3) and d.dtype == v.dtype and d.data_ptr() == v.data_ptr()
+    s = (d * 2).sum()
+    assert type(s) is torch.Tensor and float(s) == 30.0 and ok.looks == 0          # derived values: no look at the assert
+    assert d.tolist() == v.tolist() and ok.looks == 1
+    assert checked.unwrap(d) is v and checked.unwrap(v) is v
+    for touch in (lambda t: t.tolist(), lambda t: t[0, 0].item(), lambda t: t.numpy(), lambda t: repr(t), lambda t: torch.equal(t, v),
+                  lambda t: np.asarray(t), lambda t: t.detach().reshape(-1)[:2].clone().tolist()):
+        bad = Fake(True)
+        with pytest.raises(InvalidArgumentError, match='value outside range'):
+            touch(checked.CheckedTensor(v, bad))
+        assert bad.looks == 1
+
+
+def test_trace_service_time_tool(tmp_path):
+    """tools/trace_service_time.py on a synthetic dispatch trace: three launches in flight -> own duration 3x the service time"""
+    import json
+    import subprocess
+    rows = ['"Kind","Kernel_Name","Start_Timestamp","End_Timestamp"']
+    for k in range(30):                                # a launch completes every 1 ms, each one is in flight for 3 ms
+        rows.append('"KERNEL_DISPATCH","void (anonymous namespace)::warp_dice_wc<1, false>(int)",%d,%d' % (k * 1000000, k * 1000000 + 3000000))
+    rows.append('"KERNEL_DISPATCH","other_kernel(int)",5,6')
+    f = tmp_path / 'x_kernel_trace.csv'
+    f.write_text('\n'.join(rows) + '\n')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'trace_service_time.py'), str(tmp_path), 'warp_dice_wc<1, false>'],
+                         capture_output=True, text=True, timeout=60)
+    j = json.loads(out.stdout)
+    assert j['dispatches'] == 30 and j['mean_own_duration_ms'] == 3.0
+    run = j['longest_runs_of_back_to_back_launches'][0]
+    assert run['launches'] == 30 and abs(run['service_ms_per_launch'] - 32.0 / 30) < 1e-3 and run['fraction_of_span_with_two_or_more_in_flight'] > 0.9
