@@ -53,7 +53,8 @@ const char *nrt_target_arch(void);
  *                       stream capture so that nothing but launches happens inside the capture.
  *   nrt_counters_reset  zero-fills the pool on `stream`: recovery after a kernel was aborted mid-flight (nothing else leaves a slot
  *                       dirty); not needed in normal operation, must not run beside launches of this library.
- *   nrt_counters_slot_index   index of the slot a launch on `stream` would use right now (-1: pool exhausted); diagnostic / tests. */
+ *   nrt_counters_slot_index   index of the slot a launch on `stream` would use right now (-1: more streams than the pool has stream
+ *                       slots); diagnostic / tests. */
 int nrt_init(void);
 int nrt_counters_reset(void *stream);
 int nrt_counters_slot_index(void *stream);

@@ -14,12 +14,14 @@
 // graph and eager work, meet in one slot once more than 64 launches lay between them):
 //   * eager launches: ONE slot per (device, stream), taken from the bottom of the pool the first time the stream is seen.  Launches on a
 //     stream execute in order, so the slot is clean whenever the next kernel on that stream starts; no other stream ever sees it.
-//   * launches recorded during stream capture: a slot of their own from the TOP of the pool, never handed out again -- a captured graph
-//     may be replayed on any stream next to any eager work (replays of ONE graph are ordered by the runtime; replaying the same graph
-//     concurrently with itself is as wrong for its output buffers as for its counters).
+//   * launches recorded during stream capture: a slot of their own from the upper part of the pool -- a captured graph may be replayed
+//     on any stream next to any eager work (replays of ONE graph are ordered by the runtime; replaying the same graph concurrently with
+//     itself is as wrong for its output buffers as for its counters).  Captured slots are handed out in a ring of NRT_RING_SLOTS -
+//     NRT_RING_STREAM_SLOTS entries: a process would have to keep more than that many captured launches ALIVE (7 168: graphs are rarely
+//     destroyed and never reported to this library) before the oldest graph's slot meets a new one.
 //   * the two users keep disjoint words (gather: NRT_RING_GATHER_OFF, weighted CCE: NRT_RING_CCE_OFF), so even kernels that did share a
 //     slot could not read each other's tickets.
-// nullptr when the pool is exhausted (2048 streams + captured launches per device): the callers fall back to their counter-free form
+// nullptr when more than NRT_RING_STREAM_SLOTS streams have launched on a device: the callers fall back to their counter-free form
 // (fused_wc.h: one block per item) or report NRT_ERR_WORKSPACE.  nrt_init() resolves the symbol outside any capture; nrt_counters_reset()
 // re-zeroes the pool after a kernel was aborted mid-flight (a fault, a hipDeviceReset-less recovery): nothing else leaves a slot dirty.
 __device__ unsigned nrt_ring_words[NRT_RING_SLOTS * NRT_RING_WORDS];
@@ -27,8 +29,8 @@ __device__ unsigned nrt_ring_words[NRT_RING_SLOTS * NRT_RING_WORDS];
 namespace {
 struct RingDev {
     unsigned *base = nullptr;
-    unsigned next_stream = 0;                       // slots [0, next_stream) belong to streams
-    unsigned next_graph = NRT_RING_SLOTS;           // slots [next_graph, NRT_RING_SLOTS) belong to captured launches
+    unsigned next_stream = 0;                       // slots [0, next_stream) belong to streams (at most NRT_RING_STREAM_SLOTS)
+    unsigned next_graph = 0;                        // captured launches: slot NRT_RING_STREAM_SLOTS + next_graph % (the rest), a ring
     std::unordered_map<uintptr_t, unsigned> by_stream;
 };
 RingDev g_ring[64];
@@ -55,13 +57,12 @@ unsigned *nrt_ring_slot(hipStream_t st) {
     if (!r) return nullptr;
     unsigned slot;
     if (capturing) {
-        if (r->next_graph <= r->next_stream) return nullptr;
-        slot = --r->next_graph;
+        slot = NRT_RING_STREAM_SLOTS + (r->next_graph++ % (NRT_RING_SLOTS - NRT_RING_STREAM_SLOTS));
     } else {
         auto it = r->by_stream.find((uintptr_t)st);
         if (it != r->by_stream.end()) slot = it->second;
         else {
-            if (r->next_stream >= r->next_graph) return nullptr;
+            if (r->next_stream >= NRT_RING_STREAM_SLOTS) return nullptr;
             slot = r->next_stream++;
             r->by_stream.emplace((uintptr_t)st, slot);
         }

@@ -93,7 +93,7 @@ static inline hipError_t nrt_zero_async(void *p, size_t bytes, hipStream_t st) {
 
 // a slot of NRT_RING_WORDS zeroed device words for the atomic counters of the launches of ONE stream (or of one captured launch); a
 // kernel's last block leaves its words zeroed (api.hip).  The users keep disjoint words inside a slot.
-constexpr unsigned NRT_RING_SLOTS = 2048, NRT_RING_WORDS = 512;
+constexpr unsigned NRT_RING_SLOTS = 8192, NRT_RING_STREAM_SLOTS = 1024, NRT_RING_WORDS = 512;     // 16 MB of device memory
 constexpr unsigned NRT_RING_GATHER_OFF = 0, NRT_RING_CCE_OFF = 256;
 unsigned *nrt_ring_slot(hipStream_t st);
 
