@@ -114,6 +114,9 @@ def parse():
     return ap.parse_args()
 
 
+PREWARM_MS = 0.0             # set from --prewarm-ms in main()
+
+
 def usable_cores():
     """host threads this process may really use: the affinity mask and the cgroup CPU quota, not just os.cpu_count()"""
     n = os.cpu_count() or 1
@@ -376,6 +379,18 @@ def sweep(args, dev, mov, fix, trf):
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md
 
 
+def warm_calls(fn, at_least):
+    """`fn` at least `at_least` times and for at least PREWARM_MS of wall time (steady clocks: see --prewarm-ms), untimed"""
+    t0, n = time.perf_counter(), 0
+    while n < at_least or (time.perf_counter() - t0) * 1e3 < PREWARM_MS:
+        fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    return n
+
+
 def unet_fwd_ms(dev, size=160, labels=32, reps=20, warmup=5):
     """median forward ms of the BASELINE config 3 unet on this rank's GPU (used for the N > 1 line of the metric)"""
     import contextlib
@@ -384,9 +399,7 @@ def unet_fwd_ms(dev, size=160, labels=32, reps=20, warmup=5):
     with contextlib.redirect_stdout(sys.stderr):
         model = ne.models.unet(16, (size, size, size, 1), 3, 3, labels, feat_mult=2).to(dev)
     x = torch.randn(1, size, size, size, 1, device=dev)
-    for _ in range(warmup):
-        model(x)
-    torch.cuda.synchronize()
+    warm_calls(lambda: model(x), warmup)
     times = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -447,9 +460,8 @@ def unet_bench(dev, size=160, labels=32, nb_conv_per_level=1, reps=20, warmup=5)
         model = ne.models.unet(16, (size, size, size, 1), 3, 3, labels, feat_mult=2,
                                nb_conv_per_level=nb_conv_per_level).to(dev)
     x = torch.randn(1, size, size, size, 1, device=dev)
-    for _ in range(warmup):
-        y = model(x)
-    torch.cuda.synchronize()
+    y = model(x)
+    warm_calls(lambda: model(x), warmup)
     times = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
@@ -678,7 +690,6 @@ def unet_train_bench(dev, size=160, labels=32, reps=3):
     return out
 
 
-PREWARM_MS = 0.0             # set from --prewarm-ms in main()
 
 
 def prewarm(step, ms):

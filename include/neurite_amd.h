@@ -322,6 +322,15 @@ int nrt_conv3d_f32(const float *src0, int c0, const float *src1, int c1, const i
 int nrt_conv3d_c1_pool_supported(const int *shape, int cout);
 int nrt_conv3d_c1_pool_f32(const float *src /* [batch, shape, 1] */, const float *weights, const float *bias, float *out,
                            float *pool_out, int batch, const int *shape, int cout, int activation, void *stream);
+/*
+ * The same pattern below the first level (round 6): a 3x3x3 SAME convolution over c0 = 16 k input channels (packed weights of
+ * nrt_conv3d_pack_weights_f32) and the MaxPooling3D(2) of its activated output from one kernel (models.py:1378-1388 + 1436-1438) --
+ * `out` [batch, shape, cout] as nrt_conv3d_f32 (variant 5) writes it, `pool_out` [batch, shape / 2, cout] in addition.  cout 32, 48 or
+ * 64, shape a multiple of (4, 4, 16); bit-identical to nrt_conv3d_f32 followed by nrt_maxpool3d_f32.
+ */
+int nrt_conv3d_pool_supported(int c0, int cout, const int *shape, int batch);
+int nrt_conv3d_pool_f32(const float *src /* [batch, shape, c0] */, int c0, const float *packed_weights, const float *bias, float *out,
+                        float *pool_out, int batch, const int *shape, int cout, int activation, void *stream);
 
 /*
  * The decoder convolution of models.unet (neurite/tf/models.py:1531-1555: UpSampling3D(2) -> concatenate([skip, up]) ->

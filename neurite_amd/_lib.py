@@ -66,6 +66,8 @@ _SIGNATURES = {
     'nrt_conv3d_f32': (_i, [_vp, _i, _vp, _i, _ip, _vp, _vp, _vp, _vp, _i, _ip, _ip, _i, _i, _i, _i, _i, _vp]),
     'nrt_conv3d_c1_pool_supported': (_i, [_ip, _i]),
     'nrt_conv3d_c1_pool_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ip, _i, _i, _vp]),
+    'nrt_conv3d_pool_supported': (_i, [_i, _i, _ip, _i]),
+    'nrt_conv3d_pool_f32': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _ip, _i, _i, _vp]),
     'nrt_conv3d_up2_supported': (_i, [_i, _i, _i, _ip]),
     'nrt_conv3d_up2_packed_weight_floats': (_sz, [_i, _i, _i]),
     'nrt_conv3d_up2_pack_weights_f32': (_i, [_vp, _i, _i, _i, _vp, _vp]),

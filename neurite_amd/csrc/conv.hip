@@ -1204,6 +1204,35 @@ extern "C" int nrt_conv3d_c1_pool_f32(const float *src, const float *weights, co
     return NRT_OK;
 }
 
+// A 3x3x3 'same' convolution over 16 k input channels AND the MaxPooling3D(2) of its activated output from one kernel (conv_p27.h, POOL):
+// the encoder pattern of models.py:1378-1388 + 1436-1438 below the first level (whose single-channel form is nrt_conv3d_c1_pool_f32)
+extern "C" int nrt_conv3d_pool_supported(int c0, int cout, const int *shape, int batch) {
+    if (!shape || batch < 1 || batch > 65535) return 0;
+    ConvArgs a;
+    const int k3[3] = {3, 3, 3};
+    float dummy;
+    if (conv_args(a, &dummy, c0, nullptr, 0, nullptr, nullptr, &dummy, shape, k3, cout, 1, 1, ACT_NONE) != NRT_OK) return 0;
+    return mfma_ok(a, 1) && p27_pool_ok(a, batch) ? 1 : 0;
+}
+extern "C" int nrt_conv3d_pool_f32(const float *src, int c0, const float *packed_weights, const float *bias, float *out, float *pool_out,
+                                   int batch, const int *shape, int cout, int activation, void *stream) {
+    if (!pool_out || !packed_weights) return NRT_ERR_INVALID_ARG;
+    ConvArgs a;
+    const int k3[3] = {3, 3, 3};
+    int rc = conv_args(a, src, c0, nullptr, 0, nullptr, bias, out, shape, k3, cout, 1, 1, activation);
+    if (rc != NRT_OK) return rc;
+    if (batch < 1 || batch > 65535) return NRT_ERR_INVALID_ARG;
+    if (activation < ACT_NONE || activation > ACT_LAST_FUSED) return NRT_ERR_INVALID_ARG;
+    if ((((uintptr_t)out) | ((uintptr_t)pool_out)) & 15) return NRT_ERR_INVALID_ARG;
+    if (!mfma_ok(a, 1) || !p27_pool_ok(a, batch)) return NRT_ERR_UNSUPPORTED;
+    hipStream_t st = nrt_stream(stream);
+    switch (cout / 16) {
+        case 2: return launch_p27<2, true>(a, packed_weights, batch, st, pool_out);
+        case 3: return launch_p27<3, true>(a, packed_weights, batch, st, pool_out);
+        default: return launch_p27<4, true>(a, packed_weights, batch, st, pool_out);
+    }
+}
+
 extern "C" int nrt_conv1x1_softmax_f32(const float *x, const float *weights, const float *bias, float *y,
                                        long long nvox, int cin, int cout, int softmax, int activation, void *stream) {
     if (!x || !weights || !y || nvox < 0 || cin < 1 || cout < 1) return NRT_ERR_INVALID_ARG;

@@ -12,12 +12,19 @@
 
 constexpr int P27_BUF_FLOATS = U2_B_FLOATS + U2_GAP_FLOATS;          // one halo buffer (+ the overrun of its last DMA instruction)
 constexpr int P27_LDS_FLOATS = 2 * P27_BUF_FLOATS;
+// POOL (round 6): the MaxPooling3D(2) that follows an encoder convolution (models.py:1436-1438) out of the same kernel -- the
+// full-resolution tensor is written as before (the decoder's skip connection reads it), the pooled one in addition, instead of a kernel
+// that reads the full-resolution tensor back.  In the parity row mapping the z pairs of a pooling window are two M-tiles of ONE lane
+// (mt >> 1); the x and y pairs are the four waves of the block (px, py), same lane: they meet in 4 x 8 NT x 64 floats of LDS behind the
+// halo buffers, one block barrier per tile, and every wave stores a quarter of the tile's 2 x 2 x 8 pooled voxels.  Whole tiles only.
+constexpr int p27_pool_floats(int NT) { return 4 * 8 * NT * 64; }
 
-template <int NT>
+template <int NT, bool POOL = false>
 __global__ __launch_bounds__(256, 1) void conv3d_p27_mfma(ConvArgs a, const float *__restrict__ wpacked, const float *__restrict__ zeros,
-                                                          unsigned ntiles, unsigned nbx, unsigned nby, unsigned nbz) {
+                                                          unsigned ntiles, unsigned nbx, unsigned nby, unsigned nbz, float *__restrict__ pool_out) {
+    static_assert(!POOL || NT >= 2, "the pooled form rides the immediate stores of the NT >= 2 instantiations");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr bool DEFER = NT <= 1;                                     // deferred stores as in conv_up2.h
+    constexpr bool DEFER = NT <= 1 && !POOL;                            // deferred stores as in conv_up2.h
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds);
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, kq = lane >> 4;
@@ -50,6 +57,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_p27_mfma(ConvArgs a, const floa
         const float *pB;             // first channel of the tile origin
         unsigned okB;                // per DMA piece: inside the volume
         unsigned out;                // byte offset of output voxel (x0, y0, z0), channel 0
+        unsigned pool;               // POOL: float offset of pooled voxel (x0 / 2, y0 / 2, z0 / 2), channel 0
         int x0, y0, z0;
         unsigned full;
     };
@@ -59,6 +67,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_p27_mfma(ConvArgs a, const floa
         T.x0 = bx * CT_X; T.y0 = by * CT_Y; T.z0 = bz * CT_Z;
         T.pB = a.src0 + ((long long)b * a.X * a.Y * a.Z + ((long long)T.x0 * a.Y + T.y0) * a.Z + T.z0) * a.c0;
         T.out = (unsigned)((((long long)b * a.OX + T.x0) * a.OY + T.y0) * a.OZ + T.z0) * (unsigned)a.Cout * 4u;
+        T.pool = POOL ? (unsigned)((((long long)b * (a.OX / 2) + T.x0 / 2) * (a.OY / 2) + T.y0 / 2) * (a.OZ / 2) + T.z0 / 2) * (unsigned)a.Cout : 0u;
         T.full = T.x0 + CT_X <= a.OX && T.y0 + CT_Y <= a.OY && T.z0 + CT_Z <= a.OZ && (a.Cout & 15) == 0 && DEFER;
         const bool inner = T.x0 >= 1 && T.y0 >= 1 && T.z0 >= 1 && T.x0 + CT_X + 1 <= a.X && T.y0 + CT_Y + 1 <= a.Y && T.z0 + CT_Z + 1 <= a.Z;
         T.okB = validB;
@@ -206,6 +215,32 @@ __global__ __launch_bounds__(256, 1) void conv3d_p27_mfma(ConvArgs a, const floa
                                 activate(acc[mt][nt][r] + bv[nt], a.act);
                     }
             }
+            if constexpr (POOL) {
+                // entry e = (ix * 4 + r) * NT + nt of a lane: max over the z pair (M-tiles ix and ix + 2); [wave][entry][lane] in LDS
+                float *pl = lds + P27_LDS_FLOATS;
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            pl[(w * 8 * NT + (ix * 4 + r) * NT + nt) * 64 + lane] =
+                                fmaxf(activate(acc[ix][nt][r] + bv[nt], a.act), activate(acc[ix + 2][nt][r] + bv[nt], a.act));
+                __syncthreads();
+                // wave w finishes entries 2 NT w .. 2 NT w + 2 NT - 1: max over the four waves = the x and y pairs
+                float *pb = pool_out + cur.pool;
+                const unsigned pZ = (unsigned)a.Cout, pY = (unsigned)(a.OZ / 2) * pZ, pX = (unsigned)(a.OY / 2) * pY;
+#pragma unroll
+                for (int j = 0; j < 2 * NT; ++j) {
+                    const int e = w * 2 * NT + j;
+                    float m = pl[e * 64 + lane];
+#pragma unroll
+                    for (int ww = 1; ww < 4; ++ww) m = fmaxf(m, pl[(ww * 8 * NT + e) * 64 + lane]);
+                    const int nt = e % NT, r = (e / NT) % 4, ix = e / (4 * NT);
+                    pb[ix * pX + (kq >> 1) * pY + (4 * (kq & 1) + r) * pZ + nt * 16 + li] = m;
+                }
+                // (the next write to `pl` lies a whole tile ahead, behind chunk barriers every wave has to reach first)
+            }
         }
         if (!has_next) break;
         tile = ntile;
@@ -235,17 +270,24 @@ bool p27_ok(const ConvArgs &a, int padding_same, int batch) {
            a.fold == 0 && (long long)a.X * a.Y * a.Z * a.c0 < (1ll << 30) && (long long)batch * a.X * a.Y * a.Z * a.Cout < (1ll << 30);
 }
 
-template <int NT>
-int launch_p27(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st) {
+template <int NT, bool POOL = false>
+int launch_p27(const ConvArgs &a, const float *wpacked, int batch, hipStream_t st, float *pool_out = nullptr) {
     const unsigned nbx = (a.OX + CT_X - 1) / CT_X, nby = (a.OY + CT_Y - 1) / CT_Y, nbz = (a.OZ + CT_Z - 1) / CT_Z;
     const unsigned ntiles = nbx * nby * nbz * (unsigned)batch;
-    if (hipFuncSetAttribute((const void *)conv3d_p27_mfma<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, P27_LDS_FLOATS * 4) != hipSuccess)
+    const int shm = (P27_LDS_FLOATS + (POOL ? p27_pool_floats(NT) : 0)) * 4;
+    if (hipFuncSetAttribute((const void *)conv3d_p27_mfma<NT, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, shm) != hipSuccess)
         return NRT_ERR_LAUNCH;
     const unsigned T8 = (ntiles + NRT_NXCD - 1) / NRT_NXCD, per_xcd = (unsigned)nrt_num_cus() / NRT_NXCD;
     const unsigned J = T8 < per_xcd ? T8 : per_xcd;
     const float *zeros = p27_zero_block(st);
     if (!zeros) return NRT_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv3d_p27_mfma<NT>), dim3(NRT_NXCD * J), dim3(256), P27_LDS_FLOATS * 4, st, a, wpacked, zeros, ntiles, nbx, nby, nbz);
+    hipLaunchKernelGGL((conv3d_p27_mfma<NT, POOL>), dim3(NRT_NXCD * J), dim3(256), shm, st, a, wpacked, zeros, ntiles, nbx, nby, nbz, pool_out);
     NRT_CHECK_LAUNCH();
     return NRT_OK;
+}
+
+// the pooled form takes: what p27_ok takes, 32 .. 64 output channels in whole groups of 16 (the immediate-store instantiations),
+// volumes made of whole 4 x 4 x 16 tiles (every pooling window then lies inside one tile), 32-bit pooled offsets
+bool p27_pool_ok(const ConvArgs &a, int batch) {
+    return p27_ok(a, 1, batch) && a.Cout >= 32 && a.Cout % 16 == 0 && a.OX % CT_X == 0 && a.OY % CT_Y == 0 && a.OZ % CT_Z == 0;
 }

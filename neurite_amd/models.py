@@ -219,15 +219,19 @@ class _Conv(nn.Module):
         return y
 
     def pool_foldable(self, x, variant):
-        """the single-channel first layer whose 2x2x2 max-pooling can come out of the same kernel (csrc/conv.hip: conv3d_c1_mfma<NT, true>)"""
-        if variant not in (0, 1) or self.cin != 1 or x.shape[-1] != 1 or self.ksize3 != (3, 3, 3) or self.dilation != 1:
+        """a 3x3x3 'same' encoder convolution whose 2x2x2 max-pooling can come out of the same kernel: the single-channel first layer
+        (csrc/conv.hip: conv3d_c1_mfma<NT, true>) and, round 6, layers over 16 k input channels with 32 .. 64 filters in the persistent
+        schedule (csrc/conv_p27.h: conv3d_p27_mfma<NT, true>)"""
+        if self.ksize3 != (3, 3, 3) or self.dilation != 1 or x.shape[-1] != self.cin:
             return False
         if self.padding != 'same' or self.act > _ACT_LAST_FUSED or self.post_softmax or x.dtype != torch.float32:
             return False
-        return _lib.lib().nrt_conv3d_c1_pool_supported(_lib.ints(list(x.shape[1:4])), self.cout) == 1
+        if self.cin == 1:
+            return variant in (0, 1) and _lib.lib().nrt_conv3d_c1_pool_supported(_lib.ints(list(x.shape[1:4])), self.cout) == 1
+        return variant in (0, 5) and _lib.lib().nrt_conv3d_pool_supported(self.cin, self.cout, _lib.ints(list(x.shape[1:4])), int(x.shape[0])) == 1
 
     def run_with_pool(self, x):
-        """(act(conv(x)), MaxPooling3D(2) of it) from one kernel (nrt_conv3d_c1_pool_f32).  Inference only."""
+        """(act(conv(x)), MaxPooling3D(2) of it) from one kernel (nrt_conv3d_c1_pool_f32 / nrt_conv3d_pool_f32).  Inference only."""
         lib = _lib.lib()
         dev = _lib.require_device(x, self.kernel)
         x = x.contiguous()
@@ -235,9 +239,13 @@ class _Conv(nn.Module):
         out = torch.empty([B] + S + [self.cout], dtype=torch.float32, device=dev)
         pooled = torch.empty([B] + [v // 2 for v in S] + [self.cout], dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.nrt_conv3d_c1_pool_f32(_lib.ptr(x), _lib.ptr(self.kernel.detach().contiguous()), _lib.ptr(self.bias.detach()),
-                                            _lib.ptr(out), _lib.ptr(pooled), B, _lib.ints(S), self.cout, self.act, _lib.stream_ptr(dev))
-        _lib.check(rc, 'nrt_conv3d_c1_pool_f32')
+            if self.cin == 1:
+                rc = lib.nrt_conv3d_c1_pool_f32(_lib.ptr(x), _lib.ptr(self.kernel.detach().contiguous()), _lib.ptr(self.bias.detach()),
+                                                _lib.ptr(out), _lib.ptr(pooled), B, _lib.ints(S), self.cout, self.act, _lib.stream_ptr(dev))
+            else:
+                rc = lib.nrt_conv3d_pool_f32(_lib.ptr(x), self.cin, _lib.ptr(self._packed_weights()), _lib.ptr(self.bias.detach()),
+                                             _lib.ptr(out), _lib.ptr(pooled), B, _lib.ints(S), self.cout, self.act, _lib.stream_ptr(dev))
+        _lib.check(rc, 'nrt_conv3d_c1_pool_f32' if self.cin == 1 else 'nrt_conv3d_pool_f32')
         return out, pooled
 
     def _packed_head(self, head_kernel, labels, dev):

@@ -262,6 +262,29 @@ def test_first_conv_with_folded_pooling(dev, cout, S, B):
     assert not nm._Conv('d', 1, 8, (3, 3, 3), 1, 'same', 'elu').to(dev).pool_foldable(x, 0)             # 8 features
 
 
+@pytest.mark.parametrize('cin,cout,S,B', [(16, 32, (8, 8, 32), 2), (16, 32, (40, 40, 48), 1), (32, 64, (12, 16, 16), 1), (16, 48, (8, 4, 16), 3)])
+def test_encoder_conv_with_folded_pooling(dev, cin, cout, S, B):
+    """nrt_conv3d_pool_f32 (round 6): an encoder convolution over 16 k channels also emits MaxPooling3D(2) of its output
+    (models.py:1378-1388, 1436-1438) from the persistent kernel's epilogue: both tensors bit-identical to the convolution in the same
+    schedule (variant 5) followed by the pooling kernel -- also with several tiles per persistent block and several batch entries"""
+    rng = np.random.default_rng(cin + cout + S[0])
+    conv = nm._Conv('c', cin, cout, (3, 3, 3), 1, 'same', 'elu').to(dev)
+    set_weights(conv, rng)
+    x = G(rng.standard_normal((B,) + S + (cin,)).astype(F), dev)
+    assert conv.pool_foldable(x, 0) and conv.pool_foldable(x, 5)
+    y, p = conv.run_with_pool(x)
+    y2 = conv(x, variant=5)
+    p2 = nm._maxpool(y2, (2, 2, 2), 'valid')
+    assert np.array_equal(N(y), N(y2)) and np.array_equal(N(p), N(p2))
+    assert np.array_equal(N(p), N(nm._maxpool(conv(x), (2, 2, 2), 'valid')))                       # (whatever kernel the layer takes by itself)
+    for k in range(6):                                                                              # same bits every time
+        y3, p3 = conv.run_with_pool(x)
+        assert torch.equal(y3, y) and torch.equal(p3, p)
+    assert not conv.pool_foldable(G(rng.standard_normal((1, 6, 8, 16, cin)).astype(F), dev), 0)     # not whole tiles
+    assert not nm._Conv('d', cin, 16, (3, 3, 3), 1, 'same', 'elu').to(dev).pool_foldable(x, 0)      # 16 filters: the deferred-store form
+    assert not conv.pool_foldable(x, 2)                                                             # another kernel was asked for
+
+
 def test_unet_forward_folds_the_head(dev):
     """a unet whose last decoder convolution has 16 features and whose volume is made of whole tiles takes the folded head in
     inference (and only there); the prediction equals the layer-by-layer forward, intermediate tensors can still be requested"""
