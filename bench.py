@@ -733,6 +733,22 @@ def timed(step, steps, warmup, dist=None, dev=None, sparse_events=False):
         if on_gpu:
             torch.cuda.synchronize()
 
+    # The host's garbage collector stays out of the measurement: a full collection of a process with torch loaded takes milliseconds to
+    # tens of milliseconds.  Inside the timed region it leaves the device idle (one evidence session of round 6: 3.9 ms of a 16.6 ms region);
+    # between the pre-warming and the timed steps it lets the clocks fall again (another session: every figure 13 % slow).  So: collect
+    # FIRST, then pre-warm, warm up and time with the collector off; what the steps allocate is small and is collected afterwards.
+    import gc
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return _timed(step, steps, warmup, dist, dev, sparse_events, on_gpu, sync)
+    finally:
+        if gc_was_enabled:
+            gc.enable()
+
+
+def _timed(step, steps, warmup, dist, dev, sparse_events, on_gpu, sync):
     if on_gpu:
         prewarm(step, PREWARM_MS)
     pending, m = None, None
@@ -747,33 +763,22 @@ def timed(step, steps, warmup, dist=None, dev=None, sparse_events=False):
     sync()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] if (not sparse_events or k == 0 or k >= steps - 8) else None
            for k in range(steps)] if on_gpu else [None] * steps
-    # the host's garbage collector stays out of the timed region: a full collection of a process with torch loaded takes milliseconds
-    # (one evidence session of round 6 lost 3.9 ms of a 16.6 ms region on the host with the device idle: 1.02 ms per step of wall time
-    # against 0.83 ms of device time); what the steps allocate is small and is collected right after
-    import gc
-    gc.collect()
-    gc_was_enabled = gc.isenabled()
-    gc.disable()
-    try:
-        if dist is not None:
-            dist.barrier()
-        sync()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            nxt = step(evs[k])
-            if pending is not None:
-                m = pending.result()
-            pending = nxt
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        nxt = step(evs[k])
         if pending is not None:
             m = pending.result()
-        sync()
-        if dist is not None:
-            dist.barrier()
-        sync()
-        elapsed = time.perf_counter() - t0
-    finally:
-        if gc_was_enabled:
-            gc.enable()
+        pending = nxt
+    if pending is not None:
+        m = pending.result()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
     per_rank, ranks = [elapsed], 1
     if dist is not None:
         world = dist.get_world_size()
