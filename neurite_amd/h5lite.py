@@ -1,0 +1,869 @@
+"""
+A small HDF5 reader and writer in plain Python + NumPy: what Keras weight files need, no h5py.
+
+Why it is here.  The reference loads networks from Keras HDF5 files -- `LoadableModel.load` /
+`load_config` (neurite/tf/modelio.py:111-143: `h5py.File(path)`, `attrs['model_config']`, `model.load_weights(path)`) and its
+checkpoint callbacks write them (neurite/tf/callbacks.py:349-481).  h5py is not importable by the interpreter this package runs on, so
+the `.h5` branch of `ConvNet.load_weights / save_weights / save` and of `models.load` could only ever meet a stand-in.  This module reads
+the files the HDF5 library writes for Keras -- the layout of `save_weights` (root attributes `layer_names`, `backend`, `keras_version`;
+one group per layer with the attribute `weight_names` and one dataset per variable, whose '/' in `conv/kernel:0` makes nested groups)
+and of `model.save` (`model_config`, `training_config`, the groups `model_weights` and `optimizer_weights`) -- and writes files the
+HDF5 library reads back.  tests/golden/h5/*.h5 are written by h5py 3.3 / HDF5 1.10.6 with exactly the calls Keras makes
+(tests/golden/make_h5_golden.py); tests/test_h5lite.py reads them with this module and, where an h5py is found in the image, has h5py
+read what this module wrote.
+
+Format coverage (HDF5 File Format Specification 3.0; the library's default `libver='earliest'` is what h5py and Keras use):
+  read   superblock 0 / 1 (2 / 3: root object header), object headers v1 and v2, header continuations, old-style groups (symbol table:
+         B-tree v1 + local heap + SNOD), new-style groups with compact link messages, attributes v1 / v2 / v3, dataspaces v1 / v2,
+         datatypes: fixed point, IEEE float, fixed strings, variable-length strings (global heap), enums over integers (h5py's bool);
+         layouts: compact, contiguous, chunked (B-tree v1) with the deflate / shuffle / fletcher32 filters
+  write  superblock 0, object headers v1, symbol-table groups (local heap, symbol nodes, B-tree v1 of any depth -- the library's default
+         node sizes), contiguous datasets, attributes of numbers, fixed-length strings and arrays of them
+  not    dense link / attribute storage (fractal heaps), layout v4 chunk indices, compound / reference / array types, external files:
+         NotImplementedError names what was met.
+The API is the subset of h5py the package uses: File(path, 'r' | 'w') as a context manager, `name in group`, `group[name]` (paths with
+'/'), `.attrs[...]` (get / set / `in` / iteration), `create_group`, `create_dataset(name, data=...)`, `np.asarray(dataset)`,
+`dataset[()]`, `.shape`, `.dtype`, `keys()`.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+SIGNATURE = b'\x89HDF\r\n\x1a\n'
+UNDEF = 0xffffffffffffffff
+
+
+class H5Error(OSError):
+    pass
+
+
+# ---------------------------------------------------------------------------------------------------------------- reading
+
+class _Buf:
+    """the file's bytes with little-endian field readers (sizes of offsets / lengths come from the superblock)"""
+
+    def __init__(self, data):
+        self.d = data
+        self.O = 8
+        self.L = 8
+
+    def u(self, off, n):
+        return int.from_bytes(self.d[off:off + n], 'little')
+
+    def off(self, pos):
+        return self.u(pos, self.O)
+
+    def len(self, pos):
+        return self.u(pos, self.L)
+
+
+def _pad8(n):
+    return (n + 7) & ~7
+
+
+class _Datatype:
+    """a parsed datatype message: `np` = the NumPy dtype of one element in the file, `kind` in {'num', 'str', 'vstr'}"""
+
+    def __init__(self, buf, pos):
+        d = buf.d
+        cv = d[pos]
+        self.cls, self.version = cv & 15, cv >> 4
+        b0, b1, b2 = d[pos + 1], d[pos + 2], d[pos + 3]
+        self.size = buf.u(pos + 4, 4)
+        self.kind = 'num'
+        self.enum = None
+        if self.cls == 0:                                      # fixed point
+            order = '>' if b0 & 1 else '<'
+            self.np = np.dtype('%s%s%d' % (order, 'i' if b0 & 8 else 'u', self.size))
+        elif self.cls == 1:                                    # floating point (IEEE layouts only)
+            order = '>' if b0 & 1 else '<'
+            if self.size not in (2, 4, 8):
+                raise NotImplementedError('HDF5 floating-point type of %d bytes' % self.size)
+            self.np = np.dtype('%sf%d' % (order, self.size))
+        elif self.cls == 3:                                    # fixed-length string
+            self.np = np.dtype('S%d' % self.size)
+            self.kind = 'str'
+            self.cset = b0 >> 4
+        elif self.cls == 9:                                    # variable length
+            if (b0 & 15) != 1:
+                raise NotImplementedError('HDF5 variable-length sequences (only variable-length strings are read)')
+            self.kind = 'vstr'
+            self.cset = b1 & 15
+            self.np = np.dtype('O')
+        elif self.cls == 8:                                    # enumeration over an integer base (h5py stores bool this way)
+            base = _Datatype(buf, pos + 8)
+            self.np = base.np
+            self.enum = True
+        else:
+            names = {2: 'time', 4: 'bit field', 5: 'opaque', 6: 'compound', 7: 'reference', 10: 'array'}
+            raise NotImplementedError('HDF5 datatype class %d (%s)' % (self.cls, names.get(self.cls, '?')))
+
+
+def _dataspace(buf, pos):
+    """shape of a dataspace message (None for a null dataspace)"""
+    ver, rank, flags = buf.d[pos], buf.d[pos + 1], buf.d[pos + 2]
+    if ver == 1:
+        p = pos + 8
+    elif ver == 2:
+        if buf.d[pos + 3] == 2:                                # null dataspace
+            return None
+        p = pos + 4
+    else:
+        raise NotImplementedError('HDF5 dataspace message version %d' % ver)
+    return tuple(buf.len(p + i * buf.L) for i in range(rank))
+
+
+class _GlobalHeaps:
+    def __init__(self, buf):
+        self.buf = buf
+        self.cache = {}
+
+    def get(self, addr, index):
+        objs = self.cache.get(addr)
+        if objs is None:
+            b = self.buf
+            if b.d[addr:addr + 4] != b'GCOL':
+                raise H5Error('global heap collection expected at %d' % addr)
+            size = b.len(addr + 8)
+            p, end, objs = addr + 8 + b.L, addr + size, {}
+            while p + 8 + b.L <= end:
+                idx = b.u(p, 2)
+                osz = b.len(p + 8)
+                if idx == 0:
+                    break
+                objs[idx] = bytes(b.d[p + 8 + b.L:p + 8 + b.L + osz])
+                p += 8 + b.L + _pad8(osz)
+            self.cache[addr] = objs
+        return objs[index]
+
+
+def _decode_elements(f, dt, shape, raw):
+    """raw bytes of `prod(shape)` elements -> what h5py hands back (arrays; scalars for shape ())"""
+    n = 1
+    for s in (shape or ()):
+        n *= s
+    if shape is None:
+        return None                                            # h5py.Empty
+    if dt.kind == 'vstr':
+        b = f._buf
+        out = np.empty(n, dtype=object)
+        w = 4 + b.O + 4
+        for i in range(n):
+            ln = int.from_bytes(raw[i * w:i * w + 4], 'little')
+            addr = int.from_bytes(raw[i * w + 4:i * w + 4 + b.O], 'little')
+            idx = int.from_bytes(raw[i * w + 4 + b.O:i * w + w], 'little')
+            s = b'' if (addr == 0 or ln == 0) else f._gheaps.get(addr, idx)[:ln]
+            out[i] = s.decode('utf-8', 'surrogateescape') if dt.cset == 1 else s
+        return out.reshape(shape) if shape else out[0]
+    a = np.frombuffer(raw, dtype=dt.np, count=n).reshape(shape)
+    if dt.np.byteorder == '>':
+        a = a.astype(dt.np.newbyteorder('<'))
+    if dt.enum and dt.np.itemsize == 1:
+        a = a.astype(bool)
+    if not shape:
+        return a[()]
+    return a.copy()
+
+
+class _Messages:
+    """the header messages of one object: list of (type, flags, position, size)"""
+
+    def __init__(self, buf, addr):
+        self.buf = buf
+        self.items = []
+        d = buf.d
+        if d[addr:addr + 4] == b'OHDR':
+            self._v2(addr)
+        elif d[addr] == 1:
+            self._v1(addr)
+        else:
+            raise H5Error('no object header at %d' % addr)
+
+    def _v1(self, addr):
+        b = self.buf
+        nmsg = b.u(addr + 2, 2)
+        hsize = b.u(addr + 8, 4)
+        blocks = [(addr + 16, hsize)]
+        while blocks and len(self.items) < nmsg:
+            p, size = blocks.pop(0)
+            end = p + size
+            while p + 8 <= end and len(self.items) < nmsg:
+                mtype, msize, mflags = b.u(p, 2), b.u(p + 2, 2), b.d[p + 4]
+                body = p + 8
+                if mtype == 0x10:
+                    blocks.append((b.off(body), b.len(body + b.O)))
+                self.items.append((mtype, mflags, body, msize))
+                p = body + msize
+
+    def _v2(self, addr):
+        b = self.buf
+        flags = b.d[addr + 5]
+        p = addr + 6
+        if flags & 0x20:
+            p += 16
+        if flags & 0x10:
+            p += 4
+        csz = 1 << (flags & 3)
+        size0 = b.u(p, csz)
+        p += csz
+        tracked = bool(flags & 4)
+        blocks = [(p, size0)]
+        while blocks:
+            p, size = blocks.pop(0)
+            end = p + size
+            while p + 4 + (2 if tracked else 0) <= end:
+                mtype, msize, mflags = b.d[p], b.u(p + 1, 2), b.d[p + 3]
+                body = p + 4 + (2 if tracked else 0)
+                if mtype == 0x10:
+                    ca, cl = b.off(body), b.len(body + b.O)
+                    blocks.append((ca + 4, cl - 8))             # 'OCHK' ... checksum
+                self.items.append((mtype, mflags, body, msize))
+                p = body + msize
+
+    def of(self, mtype):
+        return [(pos, size) for t, _, pos, size in self.items if t == mtype]
+
+
+class _Attrs:
+    """attributes of an object, decoded on first use; assignment works on files opened for writing"""
+
+    def __init__(self, node):
+        self._node = node
+        self._vals = None
+
+    def _load(self):
+        if self._vals is not None:
+            return self._vals
+        node = self._node
+        vals = {}
+        if node._file._mode == 'r':
+            f = node._file
+            b = f._buf
+            if node._msgs.of(0x15):
+                for pos, _ in node._msgs.of(0x15):
+                    flags = b.d[pos + 1]
+                    p = pos + 2 + (2 if flags & 1 else 0)
+                    if b.off(p) != UNDEF:
+                        raise NotImplementedError('HDF5 dense attribute storage (fractal heap) on %r' % node.name)
+            for pos, _ in node._msgs.of(0x0c):
+                ver = b.d[pos]
+                nsz, tsz, ssz = b.u(pos + 2, 2), b.u(pos + 4, 2), b.u(pos + 6, 2)
+                if ver == 1:
+                    p = pos + 8
+                    name = bytes(b.d[p:p + nsz]).split(b'\0')[0]
+                    p += _pad8(nsz)
+                    dt = _Datatype(b, p)
+                    p += _pad8(tsz)
+                    shape = _dataspace(b, p)
+                    p += _pad8(ssz)
+                elif ver in (2, 3):
+                    if b.d[pos + 1] & 3:
+                        raise NotImplementedError('HDF5 shared attribute datatypes / dataspaces')
+                    p = pos + 8 + (1 if ver == 3 else 0)
+                    name = bytes(b.d[p:p + nsz]).split(b'\0')[0]
+                    p += nsz
+                    dt = _Datatype(b, p)
+                    p += tsz
+                    shape = _dataspace(b, p)
+                    p += ssz
+                else:
+                    raise NotImplementedError('HDF5 attribute message version %d' % ver)
+                n = 1
+                for s in (shape or ()):
+                    n *= s
+                esz = (4 + b.O + 4) if dt.kind == 'vstr' else dt.size
+                vals[name.decode('utf-8')] = _decode_elements(f, dt, shape, bytes(b.d[p:p + n * esz]))
+        self._vals = vals
+        return vals
+
+    def __getitem__(self, k):
+        v = self._load()
+        if k not in v:
+            raise KeyError("Can't open attribute (can't locate attribute: %r)" % k)
+        return v[k]
+
+    def __setitem__(self, k, val):
+        if self._node._file._mode != 'w':
+            raise H5Error('file is open read-only')
+        self._load()[k] = val
+
+    def __contains__(self, k):
+        return k in self._load()
+
+    def __iter__(self):
+        return iter(self._load())
+
+    def __len__(self):
+        return len(self._load())
+
+    def keys(self):
+        return self._load().keys()
+
+    def items(self):
+        return self._load().items()
+
+    def get(self, k, default=None):
+        return self._load().get(k, default)
+
+
+class Dataset:
+    def __init__(self, file, name, msgs=None, data=None):
+        self._file, self.name, self._msgs = file, name, msgs
+        self.attrs = _Attrs(self)
+        self._data = data
+        if msgs is not None:
+            b = file._buf
+            (tp, _), = msgs.of(0x03)
+            (sp, _), = msgs.of(0x01)
+            self._dt = _Datatype(b, tp)
+            self.shape = _dataspace(b, sp)
+            self.dtype = np.dtype('O') if self._dt.kind == 'vstr' else (np.dtype(bool) if (self._dt.enum and self._dt.np.itemsize == 1)
+                                                                       else self._dt.np.newbyteorder('='))
+        else:
+            self.shape, self.dtype = data.shape, data.dtype
+
+    def _read(self):
+        if self._data is not None:
+            return self._data
+        f, b, dt = self._file, self._file._buf, self._dt
+        (lp, _), = self._msgs.of(0x08)
+        shape = self.shape
+        n = 1
+        for s in (shape or ()):
+            n *= s
+        esz = (4 + b.O + 4) if dt.kind == 'vstr' else dt.size
+        ver = b.d[lp]
+        if ver in (3, 4):
+            cls = b.d[lp + 1]
+            if ver == 4 and cls == 2:
+                raise NotImplementedError('HDF5 chunked layout version 4 (chunk indices of libver="latest" files) in %r' % self.name)
+            if cls == 0:
+                sz = b.u(lp + 2, 2)
+                raw = bytes(b.d[lp + 4:lp + 4 + sz])
+            elif cls == 1:
+                addr = b.off(lp + 2)
+                raw = b'\0' * (n * esz) if addr == UNDEF else bytes(b.d[addr:addr + n * esz])
+            elif cls == 2:
+                rank = b.d[lp + 2]
+                bt = b.off(lp + 3)
+                cdims = [b.u(lp + 3 + b.O + 4 * i, 4) for i in range(rank)]
+                raw = self._read_chunks(bt, cdims[:-1], esz, n)
+            else:
+                raise NotImplementedError('HDF5 data layout class %d' % cls)
+        elif ver in (1, 2):
+            rank, cls = b.d[lp + 1], b.d[lp + 2]
+            p = lp + 8
+            addr = None
+            if cls != 0:
+                addr = b.off(p)
+                p += b.O
+            dims = [b.u(p + 4 * i, 4) for i in range(rank)]
+            p += 4 * rank
+            if cls == 0:
+                sz = b.u(p, 4)
+                raw = bytes(b.d[p + 4:p + 4 + sz])
+            elif cls == 1:
+                raw = b'\0' * (n * esz) if addr == UNDEF else bytes(b.d[addr:addr + n * esz])
+            else:
+                raw = self._read_chunks(addr, dims[:-1], esz, n)
+        else:
+            raise NotImplementedError('HDF5 data layout message version %d (written with libver="latest"?)' % ver)
+        self._data = _decode_elements(f, dt, shape, raw)
+        return self._data
+
+    def _filters(self):
+        b = self._file._buf
+        out = []
+        for pos, _ in self._msgs.of(0x0b):
+            ver, nf = b.d[pos], b.d[pos + 1]
+            p = pos + (8 if ver == 1 else 2)
+            for _ in range(nf):
+                fid = b.u(p, 2)
+                if ver == 1 or fid >= 256:
+                    nlen = b.u(p + 2, 2)
+                    p += 2
+                else:
+                    nlen = 0
+                ncd = b.u(p + 4, 2)
+                p += 6
+                p += _pad8(nlen) if ver == 1 else nlen
+                cd = [b.u(p + 4 * i, 4) for i in range(ncd)]
+                p += 4 * ncd
+                if ver == 1 and ncd % 2:
+                    p += 4
+                out.append((fid, cd))
+        return out
+
+    def _read_chunks(self, btree, cdims, esz, n):
+        b = self._file._buf
+        shape = self.shape
+        rank = len(shape)
+        out = np.zeros(n * esz, dtype=np.uint8).reshape(tuple(shape) + (esz,))
+        if btree == UNDEF:
+            return out.tobytes()
+        filters = self._filters()
+        csize = esz
+        for c in cdims:
+            csize *= c
+
+        def walk(addr):
+            if b.d[addr:addr + 4] != b'TREE' or b.d[addr + 4] != 1:
+                raise H5Error('chunk B-tree node expected at %d' % addr)
+            level, used = b.d[addr + 5], b.u(addr + 6, 2)
+            p = addr + 8 + 2 * b.O
+            ksz = 8 + 8 * (rank + 1)
+            for _ in range(used):
+                nbytes, mask = b.u(p, 4), b.u(p + 4, 4)
+                offs = [b.u(p + 8 + 8 * i, 8) for i in range(rank)]
+                child = b.off(p + ksz)
+                p += ksz + b.O
+                if level:
+                    walk(child)
+                    continue
+                raw = bytes(b.d[child:child + nbytes])
+                for k in range(len(filters) - 1, -1, -1):
+                    if mask & (1 << k):
+                        continue
+                    fid, cd = filters[k]
+                    if fid == 1:
+                        raw = zlib.decompress(raw)
+                    elif fid == 2:
+                        w = cd[0] if cd else esz
+                        raw = np.frombuffer(raw, np.uint8).reshape(w, -1).T.tobytes() if w > 1 else raw
+                    elif fid == 3:
+                        raw = raw[:-4]
+                    else:
+                        raise NotImplementedError('HDF5 filter %d' % fid)
+                chunk = np.frombuffer(raw[:csize], np.uint8).reshape(tuple(cdims) + (esz,))
+                sl_o, sl_c = [], []
+                for o, c, s in zip(offs, cdims, shape):
+                    m = min(c, s - o)
+                    sl_o.append(slice(o, o + m))
+                    sl_c.append(slice(0, m))
+                out[tuple(sl_o)] = chunk[tuple(sl_c)]
+        walk(btree)
+        return out.tobytes()
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.asarray(self._read())
+        return a.astype(dtype) if dtype is not None else a
+
+    def __getitem__(self, idx):
+        v = self._read()
+        if isinstance(idx, tuple) and idx == ():
+            return v
+        return np.asarray(v)[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def size(self):
+        n = 1
+        for s in (self.shape or ()):
+            n *= s
+        return n
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+
+class Group:
+    def __init__(self, file, name, msgs=None):
+        self._file, self.name, self._msgs = file, name, msgs
+        self.attrs = _Attrs(self)
+        self._links = None if msgs is not None else {}          # name -> object-header address (reading) / node (writing)
+        self._nodes = {}
+
+    # ---- reading
+    def _load_links(self):
+        if self._links is not None:
+            return self._links
+        b = self._file._buf
+        links = {}
+        for pos, _ in self._msgs.of(0x11):                      # symbol table: B-tree v1 + local heap
+            bt, heap = b.off(pos), b.off(pos + b.O)
+            if b.d[heap:heap + 4] != b'HEAP':
+                raise H5Error('local heap expected at %d' % heap)
+            hdata = b.off(heap + 8 + 2 * b.L)
+
+            def walk(addr):
+                if b.d[addr:addr + 4] == b'SNOD':
+                    nsym = b.u(addr + 6, 2)
+                    p = addr + 8
+                    for _ in range(nsym):
+                        noff, oh = b.off(p), b.off(p + b.O)
+                        end = b.d.index(b'\0', hdata + noff)
+                        links[bytes(b.d[hdata + noff:end]).decode('utf-8')] = oh
+                        p += 2 * b.O + 24
+                    return
+                if b.d[addr:addr + 4] != b'TREE' or b.d[addr + 4] != 0:
+                    raise H5Error('group B-tree node expected at %d' % addr)
+                used = b.u(addr + 6, 2)
+                p = addr + 8 + 2 * b.O + b.L                    # first child pointer (behind key 0)
+                for _ in range(used):
+                    walk(b.off(p))
+                    p += b.O + b.L
+            if bt != UNDEF:
+                walk(bt)
+        for pos, _ in self._msgs.of(0x02):                      # link info: dense storage is not read
+            flags = b.d[pos + 1]
+            p = pos + 2 + (8 if flags & 1 else 0)
+            if b.off(p) != UNDEF:
+                raise NotImplementedError('HDF5 dense link storage (fractal heap) in group %r: the file was written with libver="latest"' % self.name)
+        for pos, _ in self._msgs.of(0x06):                      # compact link messages
+            flags = b.d[pos + 1]
+            p = pos + 2
+            ltype = 0
+            if flags & 8:
+                ltype = b.d[p]
+                p += 1
+            if flags & 4:
+                p += 8
+            if flags & 16:
+                p += 1
+            lsz = 1 << (flags & 3)
+            nlen = b.u(p, lsz)
+            p += lsz
+            name = bytes(b.d[p:p + nlen]).decode('utf-8')
+            p += nlen
+            if ltype != 0:
+                continue                                        # soft / external links are not followed
+            links[name] = b.off(p)
+        self._links = links
+        return links
+
+    def _child(self, name):
+        if name in self._nodes:
+            return self._nodes[name]
+        links = self._load_links()
+        if name not in links:
+            raise KeyError("Unable to open object (object %r doesn't exist)" % name)
+        target = links[name]
+        if not isinstance(target, int):
+            return target
+        path = (self.name.rstrip('/') + '/' + name)
+        node = self._file._object_at(target, path)
+        self._nodes[name] = node
+        return node
+
+    def __getitem__(self, path):
+        if isinstance(path, bytes):
+            path = path.decode('utf-8')
+        node = self._file if path.startswith('/') else self
+        for part in [p for p in path.split('/') if p]:
+            if not isinstance(node, Group):
+                raise KeyError('%r is not a group' % node.name)
+            node = node._child(part)
+        return node
+
+    def __contains__(self, path):
+        try:
+            self[path]
+            return True
+        except KeyError:
+            return False
+
+    def keys(self):
+        return sorted(self._load_links())
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self._load_links())
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    # ---- writing
+    def _writable(self):
+        if self._file._mode != 'w':
+            raise H5Error('file is open read-only')
+
+    def create_group(self, path):
+        self._writable()
+        if isinstance(path, bytes):
+            path = path.decode('utf-8')
+        node = self
+        parts = [p for p in path.split('/') if p]
+        for i, part in enumerate(parts):
+            if part in node._links:
+                if i == len(parts) - 1:
+                    raise ValueError('Unable to create group (name already exists)')
+                node = node._links[part]
+                continue
+            g = Group(self._file, node.name.rstrip('/') + '/' + part)
+            node._links[part] = g
+            node = g
+        return node
+
+    def create_dataset(self, path, shape=None, dtype=None, data=None):
+        self._writable()
+        if isinstance(path, bytes):
+            path = path.decode('utf-8')
+        parts = [p for p in path.split('/') if p]
+        node = self
+        for part in parts[:-1]:
+            node = node._links[part] if part in node._links else node.create_group(part)
+        if parts[-1] in node._links:
+            raise ValueError('Unable to create dataset (name already exists)')
+        if data is None:
+            data = np.zeros(shape, dtype=dtype or np.float32)
+        a = np.array(data, dtype=dtype) if dtype is not None else np.array(data)
+        if shape is not None and tuple(np.shape(a)) != tuple(shape if isinstance(shape, (tuple, list)) else (shape,)):
+            a = a.reshape(shape)
+        ds = Dataset(self._file, node.name.rstrip('/') + '/' + parts[-1], data=a)
+        node._links[parts[-1]] = ds
+        return ds
+
+
+class File(Group):
+    """h5py.File look-alike: File(path, 'r') parses the file in memory; File(path, 'w') collects groups, datasets and attributes and
+    writes the file when it is closed"""
+
+    def __init__(self, path, mode='r'):
+        if mode not in ('r', 'w'):
+            raise ValueError("h5lite.File opens files 'r' or 'w' (got %r)" % (mode,))
+        self._mode, self._path, self._closed = mode, path, False
+        if mode == 'w':
+            Group.__init__(self, self, '/')
+            open(path, 'wb').close()                            # fail now if the place cannot be written
+            return
+        with open(path, 'rb') as fh:
+            data = fh.read()
+        b = self._buf = _Buf(data)
+        base = 0
+        while bytes(b.d[base:base + 8]) != SIGNATURE:
+            base = 512 if base == 0 else base * 2
+            if base + 8 > len(data):
+                raise H5Error('Unable to open file (file signature not found): %s' % path)
+        if base:
+            raise NotImplementedError('HDF5 file with a user block (superblock at %d)' % base)
+        ver = b.d[8]
+        self._gheaps = _GlobalHeaps(b)
+        if ver in (0, 1):
+            b.O, b.L = b.d[13], b.d[14]
+            p = 24 + (4 if ver == 1 else 0)
+            p += 4 * b.O                                        # base, free-space, end-of-file, driver-information addresses
+            root = b.off(p + b.O)                               # root symbol-table entry: link name offset, object header address
+        elif ver in (2, 3):
+            b.O, b.L = b.d[9], b.d[10]
+            root = b.off(12 + 3 * b.O)
+        else:
+            raise NotImplementedError('HDF5 superblock version %d' % ver)
+        Group.__init__(self, self, '/', _Messages(b, root))
+
+    def _object_at(self, addr, path):
+        msgs = _Messages(self._buf, addr)
+        if msgs.of(0x08) or (msgs.of(0x03) and msgs.of(0x01)):
+            return Dataset(self, path, msgs)
+        return Group(self, path, msgs)
+
+    def close(self):
+        if self._closed:
+            return
+        self._closed = True
+        if self._mode == 'w':
+            with open(self._path, 'wb') as fh:
+                fh.write(_Writer().build(self))
+
+    def flush(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None or self._mode == 'r':
+            self.close()
+        return False
+
+    @property
+    def filename(self):
+        return self._path
+
+    @property
+    def mode(self):
+        return self._mode
+
+
+# ---------------------------------------------------------------------------------------------------------------- writing
+
+def _dt_message(dt):
+    """datatype message body for a NumPy dtype (numbers and fixed-length byte strings)"""
+    dt = np.dtype(dt)
+    if dt.kind in 'iu':
+        bits = 0x08 if dt.kind == 'i' else 0
+        return struct.pack('<BBBBI', 0x10, bits, 0, 0, dt.itemsize) + struct.pack('<HH', 0, 8 * dt.itemsize)
+    if dt.kind == 'b':
+        return _dt_message(np.int8)
+    if dt.kind == 'f':
+        # bit fields: byte order 0, padding 0, mantissa normalisation 2 (implied msb), sign location; properties: bit offset, precision,
+        # exponent location, exponent size, mantissa location, mantissa size, exponent bias
+        lay = {2: (15, 10, 5, 0, 10, 15), 4: (31, 23, 8, 0, 23, 127), 8: (63, 52, 11, 0, 52, 1023)}[dt.itemsize]
+        sign, eloc, esz, mloc, msz, bias = lay
+        return (struct.pack('<BBBBI', 0x11, 0x20, sign, 0, dt.itemsize) +
+                struct.pack('<HHBBBBI', 0, 8 * dt.itemsize, eloc, esz, mloc, msz, bias))
+    if dt.kind == 'S':
+        return struct.pack('<BBBBI', 0x13, 0x01, 0, 0, max(1, dt.itemsize))       # null-padded, ASCII (what h5py writes for 'S')
+    raise TypeError('h5lite cannot store dtype %r' % (dt,))
+
+
+def _ds_message(shape):
+    if shape == ():
+        return struct.pack('<BBBB4x', 1, 0, 0, 0)
+    return struct.pack('<BBBB4x', 1, len(shape), 1, 0) + b''.join(struct.pack('<Q', s) for s in shape) * 2
+
+
+def _as_storable(val):
+    """Python / NumPy value -> array of a dtype _dt_message knows"""
+    if isinstance(val, str):
+        val = val.encode('utf-8')
+    if isinstance(val, (bytes, np.bytes_)):
+        return np.array(bytes(val), dtype='S%d' % max(1, len(val)))
+    if isinstance(val, (list, tuple)):
+        val = [v.encode('utf-8') if isinstance(v, str) else v for v in val]
+        if len(val) == 0:
+            return np.zeros((0,), np.float64)                  # np.asarray([]) -- what h5py stores for Keras' empty weight_names
+    a = np.asarray(val)
+    if a.dtype.kind == 'U':
+        a = np.char.encode(a, 'utf-8')
+    if a.dtype.kind == 'O':
+        raise TypeError('h5lite cannot store object arrays')
+    if a.dtype.byteorder == '>':
+        a = a.astype(a.dtype.newbyteorder('<'))
+    return a
+
+
+class _Writer:
+    """lays a tree of Group / Dataset nodes out as an HDF5 file the way the library's defaults do: superblock 0, version-1 object
+    headers, symbol-table groups (local heap, symbol nodes of 2 K = 8 entries under version-1 B-tree nodes of up to 2 K = 32 children)"""
+    K_LEAF, K_INT = 4, 16
+    SNOD_BYTES = 8 + 2 * K_LEAF * 40
+    TREE_BYTES = 24 + (2 * K_INT + 1) * 8 + 2 * K_INT * 8
+
+    def build(self, root):
+        self.out = bytearray(96)                               # superblock 0 with 8-byte offsets: 56 bytes + the root entry (40)
+        root_oh, root_bt, root_heap = self._group(root)
+        while len(self.out) % 8:
+            self.out.append(0)
+        eof = len(self.out)
+        sb = bytearray()
+        sb += SIGNATURE
+        sb += struct.pack('<BBBBBBBB', 0, 0, 0, 0, 0, 8, 8, 0)
+        sb += struct.pack('<HHI', self.K_LEAF, self.K_INT, 0)
+        sb += struct.pack('<QQQQ', 0, UNDEF, eof, UNDEF)
+        sb += struct.pack('<QQII', 0, root_oh, 1, 0) + struct.pack('<QQ', root_bt, root_heap)
+        assert len(sb) == 96
+        self.out[:96] = sb
+        return bytes(self.out)
+
+    def _alloc(self, data):
+        while len(self.out) % 8:
+            self.out.append(0)
+        addr = len(self.out)
+        self.out += data
+        return addr
+
+    def _attr_messages(self, node):
+        msgs = []
+        for name, val in node.attrs.items():
+            a = _as_storable(val)
+            nm = name.encode('utf-8') + b'\0'
+            dtm, dsm = _dt_message(a.dtype), _ds_message(a.shape)
+            body = struct.pack('<BBHHH', 1, 0, len(nm), len(dtm), len(dsm))
+            body += nm.ljust(_pad8(len(nm)), b'\0') + dtm.ljust(_pad8(len(dtm)), b'\0') + dsm.ljust(_pad8(len(dsm)), b'\0')
+            body += np.ascontiguousarray(a).tobytes() if a.dtype.kind != 'S' or a.dtype.itemsize else b'\0' * a.size
+            if len(body) > 65528:
+                raise ValueError('Unable to create attribute (object header message is too large): %r -- split it as Keras does '
+                                 '(name0, name1, ...)' % name)
+            msgs.append((0x0c, body))
+        return msgs
+
+    def _object_header(self, msgs):
+        """version-1 object header holding `msgs` = [(type, body)]; bodies are padded to 8 bytes.  A header block's size is a 32-bit
+        field but each message's a 16-bit one; everything goes in the first block (no continuation)"""
+        blob = bytearray()
+        for mtype, body in msgs:
+            body = bytes(body).ljust(_pad8(len(body)), b'\0')
+            blob += struct.pack('<HHB3x', mtype, len(body), 0) + body
+        hdr = struct.pack('<BBHII4x', 1, 0, len(msgs), 1, len(blob))
+        return self._alloc(hdr + blob)
+
+    def _dataset(self, ds):
+        a = np.asarray(ds._data)
+        if a.dtype.kind == 'U':
+            a = np.char.encode(a, 'utf-8')
+        if a.dtype.kind == 'b':
+            a = a.astype(np.int8)
+        if a.dtype.byteorder == '>':
+            a = a.astype(a.dtype.newbyteorder('<'))
+        raw = np.ascontiguousarray(a).tobytes()
+        addr = self._alloc(raw) if raw else UNDEF
+        msgs = [(0x01, _ds_message(a.shape)), (0x03, _dt_message(a.dtype)),
+                (0x05, struct.pack('<BBBBI', 2, 2, 0, 1, 0)),                            # fill value v2: allocate late, fill at allocation, default value
+                (0x08, struct.pack('<BBQQ', 3, 1, addr, len(raw)))]
+        return self._object_header(msgs + self._attr_messages(ds))
+
+    def _group(self, g):
+        """returns (object header, B-tree, local heap) addresses"""
+        names = sorted(g._links, key=lambda s: s.encode('utf-8'))
+        # children first (their addresses go into the symbol nodes)
+        entries = []
+        heap = bytearray(b'\0' * 8)                             # offset 0: the empty string (entries are 8-byte aligned, as the library lays them)
+        for nm in names:
+            node = g._links[nm]
+            if isinstance(node, Dataset):
+                oh, cache = self._dataset(node), None
+            else:
+                oh, bt, hp = self._group(node)
+                cache = (bt, hp)
+            noff = len(heap)
+            enc = nm.encode('utf-8') + b'\0'
+            heap += enc.ljust(_pad8(len(enc)), b'\0')
+            entries.append((noff, oh, cache))
+        # local heap: prefix (32 bytes) with its data segment right behind it; one free block closes the segment
+        free_off = len(heap)
+        heap += struct.pack('<QQ', 1, 16)                       # free block: next = 1 (H5HL_FREE_NULL), size
+        while len(self.out) % 8:
+            self.out.append(0)
+        heap_addr = len(self.out)
+        self._alloc(b'HEAP' + struct.pack('<B3xQQQ', 0, len(heap), free_off, heap_addr + 32) + bytes(heap))
+        # symbol nodes of up to 2 K entries, full-size on disk (the library reads whole nodes)
+        cap = 2 * self.K_LEAF
+        level = []                                              # (address, heap offset of the largest name below)
+        for i in range(0, len(entries), cap):
+            part = entries[i:i + cap]
+            snod = bytearray(b'SNOD' + struct.pack('<BBH', 1, 0, len(part)))
+            for noff, oh, cache in part:
+                if cache is None:
+                    snod += struct.pack('<QQII16x', noff, oh, 0, 0)
+                else:
+                    snod += struct.pack('<QQII', noff, oh, 1, 0) + struct.pack('<QQ', cache[0], cache[1])
+            level.append((self._alloc(bytes(snod).ljust(self.SNOD_BYTES, b'\0')), part[-1][0]))
+        # version-1 B-tree over them: key 0 of the leftmost node is the empty string, key i + 1 the largest name of child i
+        depth, fan = 0, 2 * self.K_INT
+        while True:
+            nodes = [level[i:i + fan] for i in range(0, len(level), fan)] or [[]]
+            while len(self.out) % 8:
+                self.out.append(0)
+            base = len(self.out)
+            nxt = []
+            for k, kids in enumerate(nodes):
+                left = base + (k - 1) * self.TREE_BYTES if k else UNDEF
+                right = base + (k + 1) * self.TREE_BYTES if k + 1 < len(nodes) else UNDEF
+                node = bytearray(b'TREE' + struct.pack('<BBH', 0, depth, len(kids)) + struct.pack('<QQ', left, right))
+                node += struct.pack('<Q', nodes[k - 1][-1][1] if k else 0)
+                for addr, mx in kids:
+                    node += struct.pack('<QQ', addr, mx)
+                self._alloc(bytes(node).ljust(self.TREE_BYTES, b'\0'))
+                nxt.append((base + k * self.TREE_BYTES, kids[-1][1] if kids else 0))
+            if len(nodes) == 1:
+                bt_addr = base
+                break
+            level, depth = nxt, depth + 1
+        oh = self._object_header([(0x11, struct.pack('<QQ', bt_addr, heap_addr))] + self._attr_messages(g))
+        return oh, bt_addr, heap_addr

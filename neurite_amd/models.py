@@ -112,12 +112,42 @@ def _store_config(func):
 
 
 def _h5py():
+    """h5py where the interpreter has it, else the package's own reader / writer of the same calls (neurite_amd/h5lite.py:
+    the HDF5 subset Keras files use, checked against files the HDF5 library wrote -- tests/test_h5lite.py)"""
     try:
         import h5py
-    except ImportError as e:                # noqa
-        raise ImportError('reading / writing Keras HDF5 files needs h5py, which is not installed; export the weights with '
-                          'np.savez(path, *model.get_weights()) on the TensorFlow side or use the .npz format') from e
-    return h5py
+        return h5py
+    except ImportError:
+        from . import h5lite
+        return h5lite
+
+
+def _h5_attr(group, name):
+    """Keras splits attributes that would not fit an object header (64512 bytes) into name0, name1, ... (hdf5_format.py:
+    save_attributes_to_hdf5_group / load_attributes_from_hdf5_group): read either form"""
+    if name in group.attrs:
+        return list(group.attrs[name])
+    out, k = [], 0
+    while '%s%d' % (name, k) in group.attrs:
+        out.extend(group.attrs['%s%d' % (name, k)])
+        k += 1
+    if not k:
+        raise KeyError('no attribute %r in %s' % (name, getattr(group, 'name', group)))
+    return out
+
+
+def _h5_set_attr(group, name, data):
+    """a list of byte strings as Keras stores it: one attribute, or name0, name1, ... when it would exceed an object header"""
+    arr = np.asarray(data)
+    chunks, n = [arr], 1
+    while any(c.nbytes > 64512 for c in chunks):
+        n += 1
+        chunks = np.array_split(arr, n)
+    if n == 1:
+        group.attrs[name] = data
+    else:
+        for k, c in enumerate(chunks):
+            group.attrs['%s%d' % (name, k)] = c
 
 
 def _is_h5(path):
@@ -1062,8 +1092,8 @@ class ConvNet(nn.Module):
 
     def save_weights(self, path):
         """
-        `.npz` (default; np.savez archive keyed by `layer/variable`) or, for a path ending in .h5 / .hdf5 and with h5py
-        installed, the Keras `save_weights` HDF5 layout (root attrs `layer_names`; per layer a group with attr `weight_names`
+        `.npz` (default; np.savez archive keyed by `layer/variable`) or, for a path ending in .h5 / .hdf5, the Keras
+        `save_weights` HDF5 layout (root attrs `layer_names`; per layer a group with attr `weight_names`
         and one dataset per variable, `layer/kernel:0` ...) so that the file loads into the Keras-built neurite unet.
         """
         if _is_h5(path):
@@ -1079,22 +1109,24 @@ class ConvNet(nn.Module):
     def _write_h5_weights(self, f):
         arrays = dict(zip([n for n, _, _ in self._weight_tensors()], self.get_weights()))
         groups = self._weights_by_layer()
-        f.attrs['layer_names'] = [l.encode('utf8') for l, _ in groups]
-        f.attrs['backend'] = b'neurite_amd'
+        _h5_set_attr(f, 'layer_names', [l.encode('utf8') for l, _ in groups])
+        # (what Keras' loader looks at: without `keras_version` it takes the file for Keras 1 and transposes convolution kernels)
+        f.attrs['backend'] = b'tensorflow'
+        f.attrs['keras_version'] = b'2.4.0'
         for layer, vs in groups:
             g = f.create_group(layer)
             names = ['%s/%s:0' % (layer, var) for var, _, _ in vs]
-            g.attrs['weight_names'] = [n.encode('utf8') for n in names]
+            _h5_set_attr(g, 'weight_names', [n.encode('utf8') for n in names])
             for n, (var, _, _) in zip(names, vs):
                 g.create_dataset(n, data=arrays[layer + '/' + var])
 
     def _read_h5_weights(self, f, by_name):
         """Keras HDF5 weights (the file itself for `save_weights`, its `model_weights` group for `model.save`):
         layers are matched by name when every layer of this model is present (or by_name), else in order, as Keras does."""
-        if 'layer_names' not in f.attrs and 'model_weights' in f:
+        if 'layer_names' not in f.attrs and 'layer_names0' not in f.attrs and 'model_weights' in f:
             f = f['model_weights']
-        stored = [_h5_str(n) for n in f.attrs['layer_names']]
-        with_w = [n for n in stored if len(f[n].attrs['weight_names'])]
+        stored = [_h5_str(n) for n in _h5_attr(f, 'layer_names')]
+        with_w = [n for n in stored if len(_h5_attr(f[n], 'weight_names'))]
         groups = self._weights_by_layer()
         mine = [l for l, _ in groups]
         if by_name:
@@ -1109,7 +1141,7 @@ class ConvNet(nn.Module):
         out = {}
         for (layer, vs), src in pairs:
             g = f[src]
-            wn = [_h5_str(n) for n in g.attrs['weight_names']]
+            wn = [_h5_str(n) for n in _h5_attr(g, 'weight_names')]
             if len(wn) != len(vs):
                 raise ValueError('Layer %s expects %d weights, the file holds %d for %s' % (layer, len(vs), len(wn), src))
             for (var, _, _), n in zip(vs, wn):
@@ -1117,8 +1149,8 @@ class ConvNet(nn.Module):
         return out
 
     def load_weights(self, path, by_name=False):
-        """counterpart of `save_weights`; also reads HDF5 files written by Keras (`model.save_weights` / `model.save`) when
-        h5py is installed.  by_name=True loads only the layers found in the file (Keras semantics)."""
+        """counterpart of `save_weights`; also reads HDF5 files written by Keras (`model.save_weights` / `model.save`: h5py if
+        installed, else neurite_amd.h5lite).  by_name=True loads only the layers found in the file (Keras semantics)."""
         if _is_h5(path):
             h5py = _h5py()
             with h5py.File(path, 'r') as f:
