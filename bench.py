@@ -1161,8 +1161,8 @@ def main():
     r_ref = timed(step_fused if (fused and not args.direct) else step_refsig, o_steps, 2, dist, dev)
     # the stand-alone warp (the drop-in op that WRITES the warped volume) issued like the headline steps: independent launches
     # round-robin over the step streams, nothing else in between -- the rate at which interpn launches complete
-    r_warp = None
-    if dist is None and fused and nstreams > 1 and not args.no_batch1:
+    r_warp = r_warp_serial = None
+    if dist is None and fused and not args.no_batch1:
         try:
             def step_warp(events=None):
                 if events is not None:
@@ -1172,11 +1172,15 @@ def main():
                     events[1].record()
                     events[2].record()
                 return _Done(w)
-            r_warp = timed(pipelined(step_warp, nstreams, dev), o_steps, 2, None, dev, sparse_events=True)
+            # ... and strictly one after the other with nothing else in between (the drop-in pipeline's `interpn_ms` is the same launch
+            # alternating with the Dice kernels, --steps // 5 steps)
+            r_warp_serial = timed(step_warp, args.steps, 2, None, dev)
+            if nstreams > 1:
+                r_warp = timed(pipelined(step_warp, nstreams, dev), args.steps, 2, None, dev, sparse_events=True)
             torch.cuda.empty_cache()
         except Exception as e:   # noqa
-            log('pipelined stand-alone warp failed: %s' % e)
-            r_warp = None
+            log('stand-alone warp run failed: %s' % e)
+            r_warp = r_warp_serial = None
     # BASELINE config 2 proper is batch = 1: the same two pipelines on the first volume only (N = 1 runs)
     r_b1 = None
     if dist is None and B > 1 and not args.no_batch1:
@@ -1251,7 +1255,7 @@ def main():
     # The other scaling mode of the same run, next to the parsed line.  N = 1 (parsed line: 4 volumes): BASELINE config 4 as SURVEY 8(d)
     # words it -- B = 32 FIXED, all 32 volumes on this GPU (35 GB of its 288) -- so that value(N) / value_strong_b32 is the strong-scaling
     # figure.  N > 1 (parsed line: global batch 32, 32 / N per rank): the weak run, --batch-per-gpu volumes on every rank.
-    r_strong, Bs = None, 0
+    r_strong, Bs, r_warp32 = None, 0, None
     if not args.global_batch and not args.no_strong and not args.unfused and not args.rough and CFG4_GLOBAL_BATCH % world == 0 and S == 160:
         try:
             Bs = CFG4_GLOBAL_BATCH // world
@@ -1261,6 +1265,23 @@ def main():
                 smov, sfix, strf = synth.cfg2_batch(Bs, S, L, device=dev, seed0=100 + 3 * rank * Bs)
             s_refsig = pipelined(make_steps(smov, sfix, strf)[2], nstreams, dev)
             r_strong = timed(s_refsig, o_steps, 2, dist, dev, sparse_events=nstreams > 1)
+            if dist is None and fused and Bs != B:
+                # the stand-alone warp on the same 32 volumes (serial launches): north_star's per-volume target is quoted at any batch
+                del sfix
+
+                def step_warp32(events=None):
+                    if events is not None:
+                        events[0].record()
+                    w = ne.deferred.materialize(st([smov, strf]))
+                    if events is not None:
+                        events[1].record()
+                        events[2].record()
+                    return _Done(w)
+                try:
+                    r_warp32 = timed(step_warp32, o_steps, 1, None, dev)
+                except Exception as e:   # noqa
+                    log('stand-alone warp at batch %d failed: %s' % (Bs, e))
+                sfix = None
             del smov, sfix, strf, s_refsig
             torch.cuda.empty_cache()
         except Exception as e:   # noqa
@@ -1503,15 +1524,29 @@ def main():
             'frac_of_peak': round(b16 / (r_bf16['k0_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'same_dice': r_bf16['same_dice'],
             'max_abs_diff_vs_default_f32_kernel': r_bf16['max_abs_diff_vs_default_f32_kernel']}
     # the stand-alone op (the drop-in `interpn` / SpatialTransformer call that WRITES the warped volume; 268 B per voxel as well)
-    out['roofline']['standalone_interpn'] = {'frac': dropin['interpn_frac_of_peak'], 'avg_launch_ms': dropin['interpn_ms'],
-                                             'achieved': dropin['interpn_GBs'], 'volumes_per_launch': B,
-                                             'what': 'isolated launches (the eager two-kernel pipeline, steps serial)'}
+    sa = {'frac': dropin['interpn_frac_of_peak'], 'avg_launch_ms': dropin['interpn_ms'], 'achieved': dropin['interpn_GBs'], 'volumes_per_launch': B,
+          'what': 'isolated launches (the eager two-kernel pipeline, steps serial)'}
+    if r_warp_serial is not None:
+        w_ms = r_warp_serial['k0_ms']
+        sa = {'frac': round(interp_bytes / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'avg_launch_ms': round(w_ms, 4),
+              'achieved': round(interp_bytes / (w_ms * 1e-3) / 1e9, 1), 'volumes_per_launch': B, 'ms_per_volume': round(w_ms / B, 4),
+              'what': 'the warp alone, launches strictly one after the other on one stream, HIP events around every launch; %d launches' % args.steps,
+              'ms_per_launch_wall': round(r_warp_serial['elapsed'] / args.steps * 1e3, 4),
+              'in_dropin_pipeline': {'what': 'the same launch alternating with the Dice kernels of the eager two-kernel pipeline (`dropin_pipeline`)',
+                                     'avg_launch_ms': dropin['interpn_ms'], 'frac': dropin['interpn_frac_of_peak']}}
+    out['roofline']['standalone_interpn'] = sa
     if r_warp is not None:
         out['roofline']['standalone_interpn']['pipelined'] = {
-            'what': 'the warp alone, independent launches round-robin on %d streams (as the headline steps): device time of the region / launches; %d launches' % (nstreams, o_steps),
+            'what': 'the warp alone, independent launches round-robin on %d streams (as the headline steps): device time of the region / launches; %d launches' % (nstreams, args.steps),
             'avg_launch_ms': round(r_warp['span_ms'], 4),
             'achieved': round(interp_bytes / (r_warp['span_ms'] * 1e-3) / 1e9, 1),
             'frac': round(interp_bytes / (r_warp['span_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if r_warp32 is not None:
+        w32 = r_warp32['k0_ms']
+        out['roofline']['standalone_interpn']['batch%d' % Bs] = {
+            'what': 'the warp alone on the %d volumes of the strong-scaling run, serial launches; %d launches.  north_star: 60 %% of the roof = 0.229 ms per volume' % (Bs, o_steps),
+            'avg_launch_ms': round(w32, 4), 'ms_per_volume': round(w32 / Bs, 4),
+            'frac': round(INTERPN_BYTES_PER_VOXEL(L, 3) * V * Bs / (w32 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if fused:
         out['roofline']['unfused_api_accounting_524B_per_voxel_GBs'] = round(
             (INTERPN_BYTES_PER_VOXEL(L, 3) + DICE_BYTES_PER_VOXEL(L)) * V * B / (kms * 1e-3) / 1e9, 1)
