@@ -25,6 +25,7 @@ The API is the subset of h5py the package uses: File(path, 'r' | 'w') as a conte
 '/'), `.attrs[...]` (get / set / `in` / iteration), `create_group`, `create_dataset(name, data=...)`, `np.asarray(dataset)`,
 `dataset[()]`, `.shape`, `.dtype`, `keys()`.
 """
+import mmap
 import struct
 import zlib
 
@@ -495,7 +496,7 @@ class Group:
                     p = addr + 8
                     for _ in range(nsym):
                         noff, oh = b.off(p), b.off(p + b.O)
-                        end = b.d.index(b'\0', hdata + noff)
+                        end = b.d.find(b'\0', hdata + noff)
                         links[bytes(b.d[hdata + noff:end]).decode('utf-8')] = oh
                         p += 2 * b.O + 24
                     return
@@ -632,13 +633,18 @@ class File(Group):
             Group.__init__(self, self, '/')
             open(path, 'wb').close()                            # fail now if the place cannot be written
             return
-        with open(path, 'rb') as fh:
-            data = fh.read()
+        # the file is mapped, not read: weight files run to gigabytes and a load touches each dataset once
+        self._fh = open(path, 'rb')
+        try:
+            data = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        except (ValueError, OSError):                          # empty file / a file system without mmap
+            data = self._fh.read()
         b = self._buf = _Buf(data)
         base = 0
         while bytes(b.d[base:base + 8]) != SIGNATURE:
             base = 512 if base == 0 else base * 2
             if base + 8 > len(data):
+                self.close()
                 raise H5Error('Unable to open file (file signature not found): %s' % path)
         if base:
             raise NotImplementedError('HDF5 file with a user block (superblock at %d)' % base)
@@ -669,6 +675,11 @@ class File(Group):
         if self._mode == 'w':
             with open(self._path, 'wb') as fh:
                 fh.write(_Writer().build(self))
+            return
+        data, self._buf.d = self._buf.d, b''
+        if isinstance(data, mmap.mmap):
+            data.close()
+        self._fh.close()
 
     def flush(self):
         pass
