@@ -692,10 +692,16 @@ def unet_train_bench(dev, size=160, labels=32, reps=3):
 
 
 
-def prewarm(step, ms):
-    """`step` repeated for ~`ms` milliseconds of wall time, untimed; every pending mean is collected, the device is idle on return"""
+def prewarm(step, ms, dist=None, dev=None, sync=None):
+    """`step` repeated for ~`ms` milliseconds of wall time, untimed; every pending mean is collected, the device is idle on return.
+    With a process group every step carries a collective, so ALL ranks must run the same number of steps: a rank that stopped by its own
+    clock while another went on for eight more would leave that one waiting in an all-reduce for ever.  The ranks therefore agree after
+    every batch of steps (one all-reduce of a flag, MAX: all stop as soon as one has had its time) -- tests/test_distributed_cpu.py runs
+    this with ranks that enter at different times."""
     if ms <= 0:
         return 0
+    if sync is None:
+        sync = torch.cuda.synchronize
     t0, n, pending = time.perf_counter(), 0, None
     while True:
         for _ in range(8):
@@ -704,12 +710,17 @@ def prewarm(step, ms):
                 pending.result()
             pending = nxt
             n += 1
-        torch.cuda.synchronize()
-        if (time.perf_counter() - t0) * 1e3 >= ms:
+        sync()
+        done = (time.perf_counter() - t0) * 1e3 >= ms
+        if dist is not None:
+            flag = torch.tensor([1.0 if done else 0.0], dtype=torch.float32, **({'device': dev} if dev is not None else {}))
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            done = bool(float(flag[0]) > 0.0)
+        if done:
             break
     if pending is not None:
         pending.result()
-    torch.cuda.synchronize()
+    sync()
     return n
 
 
@@ -750,7 +761,7 @@ def timed(step, steps, warmup, dist=None, dev=None, sparse_events=False):
 
 def _timed(step, steps, warmup, dist, dev, sparse_events, on_gpu, sync):
     if on_gpu:
-        prewarm(step, PREWARM_MS)
+        prewarm(step, PREWARM_MS, dist, dev)
     pending, m = None, None
     for _ in range(warmup):
         nxt = step(None)

@@ -190,6 +190,45 @@ def test_bench_timed_loop_world4():
     assert r['ranks'] == 1 and r['mean'] is None and len(r['per_rank_s']) == 1
 
 
+def _prewarm_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import time
+        import bench
+        from neurite_amd import distributed as nd
+        time.sleep(0.013 * rank)                              # the ranks reach the measurement at different times ...
+
+        def step(events):
+            time.sleep(0.001 * (rank + 1))                    # ... and run at different speeds
+            return nd.all_reduce_mean_dice(torch.full((2, 4), float(rank)), async_op=True)
+        n = bench.prewarm(step, 60.0, dist, None, sync=lambda: None)
+        q.put((rank, n))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_bench_prewarm_stops_on_every_rank_together():
+    """the untimed pre-warming in front of every measurement runs by the clock; with a collective in every step the ranks must agree on
+    when to stop (a rank that went on alone would wait in its all-reduce for ever -- the multi-GPU bench would hang)"""
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_prewarm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=200) for _ in procs])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    counts = {n for _, n in res}
+    assert len(counts) == 1 and counts.pop() % 8 == 0 and res[0][1] >= 8
+
+
 @pytest.mark.timeout(300)
 def test_bench_self_launches_its_ranks_cpu_stub():
     """`python bench.py --gpus 2` with no launcher around it: bench.py re-runs itself under torch.distributed.run (one process per rank),
