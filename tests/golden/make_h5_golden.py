@@ -17,6 +17,8 @@ Also written: files that exercise what a Keras file does not (chunked + deflate 
 attributes, big-endian and integer data, a compact dataset, many links under one group) for the reader's own sake.
 
     python tests/golden/make_h5_golden.py            # stage 1 here, stage 2 re-invoked under the interpreter that has h5py
+A re-run reproduces the committed files byte for byte (the modification times the library stamps on datasets are set to a constant
+afterwards; the libver='latest' file is written with time tracking off).
 """
 import json
 import os
@@ -45,6 +47,31 @@ def stage1():
         np.savez(os.path.join(tmp, tag + '.npz'), **{k + ':0': v for k, v in vals.items()})
     os.makedirs(OUT, exist_ok=True)
     subprocess.run([H5PY_PYTHON, os.path.abspath(__file__), '--stage2', tmp], check=True)
+    # The library stamps every dataset with its modification time (message 0x0012: Keras files carry them too, the reader skips them).
+    # Set the seconds to a constant so that a re-run reproduces the committed files byte for byte (version-1 headers have no checksum).
+    for fn in sorted(os.listdir(OUT)):
+        if fn.endswith('.h5') and fn != 'latest_small.h5':
+            fix_times(os.path.join(OUT, fn))
+
+
+def fix_times(path, seconds=1700000000):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from neurite_amd import h5lite
+    patches = []
+    with h5lite.File(path, 'r') as f:
+        def walk(node):
+            for mtype, _, pos, _ in node._msgs.items:
+                if mtype == 0x12 and f._buf.d[pos] == 1:
+                    patches.append(pos + 4)
+            if isinstance(node, h5lite.Group):
+                for k in node.keys():
+                    walk(node[k])
+        walk(f)
+    with open(path, 'r+b') as fh:
+        for pos in patches:
+            fh.seek(pos)
+            fh.write(int(seconds).to_bytes(4, 'little'))
+    return len(patches)
 
 
 # ---- stage 2: runs under the interpreter with h5py --------------------------------------------------------------------------------
@@ -148,6 +175,7 @@ def stage2(tmp):
         f.attrs['bool'] = True
         f.attrs['empty_list'] = []
         f.attrs['empty'] = h5py.Empty('f')
+        f.attrs['big_json'] = json.dumps({'layers': [{'name': 'layer_%05d' % i, 'config': {'filters': i, 'note': 'x' * 40}} for i in range(2000)]}).encode('utf8')   # > 64 KB: a variable-length string in the global heap, as a large model_config is
         f['chunked'].attrs['note'] = b'attribute on a dataset'
         g = f.create_group('nested/deeper/deepest')
         g.attrs['depth'] = 3
@@ -161,13 +189,24 @@ def stage2(tmp):
             layers[i]['weights'] = [n]
             arrays[n] = np.full((2, 2), float(i), np.float32)
         save_weights_to_hdf5_group(f, layers, arrays, '2.4.0')
-    # the same small tree with libver='latest' (version-2 object headers, compact link messages)
-    with h5py.File(os.path.join(OUT, 'latest_small.h5'), 'w', libver='latest') as f:
+    # the same small tree with libver='latest' (version-2 object headers, compact link messages).  Version-2 headers carry four time stamps
+    # under a checksum: times are switched off on every object (low-level property lists) so that the file is reproducible
+    fapl = h5py.h5p.create(h5py.h5p.FILE_ACCESS)
+    fapl.set_libver_bounds(h5py.h5f.LIBVER_LATEST, h5py.h5f.LIBVER_LATEST)
+    fcpl = h5py.h5p.create(h5py.h5p.FILE_CREATE)
+    fcpl.set_obj_track_times(False)
+    fid = h5py.h5f.create(os.path.join(OUT, 'latest_small.h5').encode(), h5py.h5f.ACC_TRUNC, fcpl=fcpl, fapl=fapl)
+    with h5py.File(fid) as f:
         f.attrs['layer_names'] = [b'a', b'b']
         for n in ('a', 'b'):
-            g = f.create_group(n)
+            gcpl = h5py.h5p.create(h5py.h5p.GROUP_CREATE)
+            gcpl.set_obj_track_times(False)
+            g = h5py.Group(h5py.h5g.create(f.id, n.encode(), gcpl=gcpl))
             g.attrs['weight_names'] = [('%s/kernel:0' % n).encode()]
-            g.create_dataset('%s/kernel:0' % n, data=np.arange(6, dtype=np.float32).reshape(2, 3) + ord(n))
+            gcpl2 = h5py.h5p.create(h5py.h5p.GROUP_CREATE)
+            gcpl2.set_obj_track_times(False)
+            h5py.h5g.create(g.id, n.encode(), gcpl=gcpl2)
+            g.create_dataset('%s/kernel:0' % n, data=np.arange(6, dtype=np.float32).reshape(2, 3) + ord(n), track_times=False)
     print('h5py', h5py.__version__, 'HDF5', h5py.version.hdf5_version, '->', sorted(os.listdir(OUT)))
 
 

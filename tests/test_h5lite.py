@@ -122,7 +122,9 @@ def test_reads_the_storage_forms_of_the_library():
         assert list(a['str_list']) == ['a', 'bb', 'ccc'] and a['int'] == 7 and bool(a['bool']) is True
         np.testing.assert_array_equal(a['float_array'], np.arange(5) / 4)
         assert len(a['empty_list']) == 0 and a['empty'] is None
-        assert 'missing' not in a and sorted(a) == sorted(['str_scalar', 'bytes_scalar', 'str_list', 'int', 'float_array', 'bool', 'empty_list', 'empty'])
+        big = json.loads(a['big_json'].decode('utf-8'))          # 190 KB through the global heap (how a large Keras model_config is stored)
+        assert len(a['big_json']) > 100000 and len(big['layers']) == 2000 and big['layers'][1999]['config']['filters'] == 1999
+        assert 'missing' not in a and sorted(a) == sorted(['str_scalar', 'bytes_scalar', 'str_list', 'int', 'float_array', 'bool', 'empty_list', 'empty', 'big_json'])
         with pytest.raises(KeyError):
             a['missing']
         assert f['chunked'].attrs['note'] == b'attribute on a dataset'
