@@ -11,7 +11,6 @@ import contextlib
 import io
 import json
 import os
-import shutil
 import subprocess
 import sys
 import warnings

@@ -2,7 +2,6 @@
 """A/B of the zig-zag march (NRT_WC_ZIG=1, fused_wc.h ZIG) against the shipped 4 x 8 columns: run once per setting (the switch is read once per
 process), compare the printed checksums / Dice values across runs.   NRT_WC_ZIG=0|1 python tools/lab/zig_ab.py [quick]"""
 import json, os, sys, time, zlib
-import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import neurite_amd as ne
