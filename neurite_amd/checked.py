@@ -16,19 +16,44 @@ the assert is deferred as well:
     device code (a mean that is all-reduced, a loss that is back-propagated) still fails loudly, one or two steps late, like an
     asynchronous HIP error.
 
-`neurite_amd.checked.enabled = False` (env NRT_DEFER_LIMIT_CHECKS=0) restores the eager raise at the call site everywhere.
+`neurite_amd.checked.enabled = False` (env NRT_DEFER_LIMIT_CHECKS=0) restores the eager raise at the call site everywhere;
+`with neurite_amd.checked.scope(False):` does so for one block of one thread.
 Every other path (materialised tensors, hard Dice, the joint loss, training graphs) raises eagerly as before.
 """
 
 import collections
+import contextlib
 import os
+import threading
 
 import torch
 from torch.utils._pytree import tree_map
 
 from .errors import InvalidArgumentError
 
-enabled = os.environ.get('NRT_DEFER_LIMIT_CHECKS', '1') != '0'
+enabled = os.environ.get('NRT_DEFER_LIMIT_CHECKS', '1') != '0'      # process-wide default; `scope()` overrides it per thread and block
+
+_local = threading.local()
+
+
+def is_enabled():
+    """what Dice consults: the innermost `scope()` of this thread, else the process-wide `enabled`"""
+    stack = getattr(_local, 'stack', None)
+    return stack[-1] if stack else enabled
+
+
+@contextlib.contextmanager
+def scope(on):
+    """`with neurite_amd.checked.scope(False): ...` -- range asserts raise at the call site inside the block (this thread only); nests"""
+    stack = getattr(_local, 'stack', None)
+    if stack is None:
+        stack = _local.stack = []
+    stack.append(bool(on))
+    try:
+        yield
+    finally:
+        stack.pop()
+
 
 _pending = collections.deque()
 _pinned = []                      # recycled 4-float pinned host buffers

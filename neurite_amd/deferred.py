@@ -21,15 +21,40 @@ returns.  A deferred warp reads its inputs when it is first used, and PyTorch le
 volume and the transform it aliases and checks them when it is evaluated -- by `materialize()` or by the fused Dice kernel: if
 either was modified in place, the result the eager path would have produced no longer exists and a `DeferredWarpError` is raised
 (loudly, at the use site, naming the remedy: keep the inputs unchanged until the result is used, pass clones, or set
-`neurite_amd.deferred.enabled = False`).  Inputs that had to be converted (dtype, layout) are private copies and cannot change.
+`neurite_amd.deferred.enabled = False`, or for one block of one thread `with neurite_amd.deferred.scope(False):`).  Inputs that had to be converted (dtype, layout) are private copies and cannot change.
 """
 
+import contextlib
 import os
+import threading
 
 import torch
 from torch.utils._pytree import tree_map
 
-enabled = os.environ.get('NRT_DEFER_WARP', '1') != '0'
+enabled = os.environ.get('NRT_DEFER_WARP', '1') != '0'      # process-wide default; `scope()` overrides it for one thread and one block
+
+_local = threading.local()
+
+
+def is_enabled():
+    """what SpatialTransformer consults: the innermost `scope()` of this thread, else the process-wide `enabled`"""
+    stack = getattr(_local, 'stack', None)
+    return stack[-1] if stack else enabled
+
+
+@contextlib.contextmanager
+def scope(on):
+    """`with neurite_amd.deferred.scope(False): ...` -- eager warps inside the block, in this thread only, whatever the process-wide
+    switch says (and the other way round); nests.  A library that calls into neurite_amd from several threads, or only wants one
+    evaluation eager, does not have to touch the module attribute."""
+    stack = getattr(_local, 'stack', None)
+    if stack is None:
+        stack = _local.stack = []
+    stack.append(bool(on))
+    try:
+        yield
+    finally:
+        stack.pop()
 
 
 class DeferredWarpError(RuntimeError):

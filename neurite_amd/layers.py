@@ -212,7 +212,7 @@ class SpatialTransformer(_Layer):
         # gradient the warp is deferred so that Dice can run the fused kernel and `warped` is never written
         # (neurite_amd/deferred.py); any other use of the result evaluates it with the stand-alone kernel, bit-identically
         L = vol.shape[-1]
-        if (deferred.enabled and self.interp_method == 'linear' and D == 3 and vol.dtype == torch.float32
+        if (deferred.is_enabled() and self.interp_method == 'linear' and D == 3 and vol.dtype == torch.float32
                 and self._variant == 0 and self._tune == 0 and L % 4 == 0 and (L // 4) in (1, 2, 4, 8, 16, 32, 64)
                 and shift.numel() > 0 and vol.numel() > 0
                 and not (torch.is_grad_enabled() and (vol.requires_grad or shift.requires_grad))

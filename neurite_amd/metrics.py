@@ -369,7 +369,7 @@ class Dice:
         from . import checked
         # the range asserts of :439-444 on this (already lazy) pipeline travel with the result instead of stopping the host at every
         # call (checked.py); `checked.enabled = False` raises at the call site as everywhere else
-        limits = ('deferred' if checked.enabled else True) if self.check_input_limits else False
+        limits = ('deferred' if checked.is_enabled() else True) if self.check_input_limits else False
         try:
             return fused.warp_dice(src['vol'], src['shift'], other, indexing='ij', single_transform=src['single_transform'],
                                    fill_value=src['fill_value'], laplace_smoothing=eps, check_input_limits=limits)

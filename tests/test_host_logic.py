@@ -665,6 +665,45 @@ def test_lc3d_relayout_plan_reproduces_the_reference_layer():
         np.testing.assert_allclose(y, g['out'], rtol=1e-5, atol=1e-6 * np.abs(g['out']).max(), err_msg=tag)
 
 
+def test_scoped_switches_are_thread_local_and_nest():
+    """`deferred.scope()` / `checked.scope()`: an override for one block of one thread on top of the process-wide `enabled` attribute
+    (a global mutable switch is a surprising thing for a drop-in user to have to touch)"""
+    import threading
+    from neurite_amd import checked, deferred
+    for mod in (deferred, checked):
+        base = mod.enabled
+        assert mod.is_enabled() is base
+        seen = {}
+
+        def other():
+            seen['inside'] = mod.is_enabled()                          # another thread does not see this thread's scope
+            with mod.scope(not base):
+                seen['own'] = mod.is_enabled()
+        with mod.scope(not base):
+            assert mod.is_enabled() is (not base) and mod.enabled is base
+            with mod.scope(base):
+                assert mod.is_enabled() is base
+            assert mod.is_enabled() is (not base)
+            t = threading.Thread(target=other)
+            t.start()
+            t.join()
+        assert seen == {'inside': base, 'own': not base} and mod.is_enabled() is base
+        try:
+            with mod.scope(not base):
+                raise KeyError('leaves the scope by an exception')
+        except KeyError:
+            pass
+        assert mod.is_enabled() is base
+        keep = mod.enabled
+        try:
+            mod.enabled = not keep                                        # the process-wide switch still works where no scope is open
+            assert mod.is_enabled() is (not keep)
+            with mod.scope(keep):
+                assert mod.is_enabled() is keep
+        finally:
+            mod.enabled = keep
+
+
 def test_deferred_warp_tensor_mechanics_cpu():
     """neurite_amd/deferred.py without a GPU: a DeferredWarp carries real metadata, evaluates its thunk exactly once on the first use by
     a torch op or by a host accessor that bypasses the dispatcher, and then behaves like the tensor it stands for"""
