@@ -49,6 +49,9 @@
 
 namespace {
 
+#ifndef WC_NST_WARP
+#define WC_NST_WARP 3                                           // pass states of the stand-alone warp (2: as the fused forms)
+#endif
 constexpr int WC_SLOTS = 128;                                   // direct-mapped rows per wave
 constexpr int WC_OVF = 16;                                      // overflow rows (orphans of the current pass)
 constexpr int WC_TRASH_ROW = WC_SLOTS + WC_OVF;                 // where the list entries without a row store (branch-free masking)
@@ -193,7 +196,11 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     };
     // a pass under management: from the tag read (m1a) to the fetch list (m1c)
     struct Mg { float w0x, w0y, w0z; bool oob, miss; unsigned rid, slot, t1, t2, mytag; float mk[3]; };
-    Pass A, B;
+    // NST states: a pass is managed NST steps before it is blended and its rows are requested NST - 1 steps before.  The fused forms keep
+    // two (a third state does not fit their 219 registers: 618 spills in round 5); the stand-alone warp (161 registers) takes three --
+    // its row requests leave TWO steps ahead of their use
+    constexpr int NST = WC_NST_WARP > 2 && !DICE && !BWD ? 3 : 2;
+    Pass A, B, C;
     auto reset = [&](Pass &s) {
         s.w0x = s.w0y = s.w0z = 0.f; s.n = 0; s.xq = x0; s.oob = false; s.mk[0] = s.mk[1] = s.mk[2] = 0.f;
         s.T = (nrt_f4){0.f, 0.f, 0.f, 0.f};
@@ -204,6 +211,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         s.pn[0] = s.pn[1] = s.pn[2] = 0.f;
     };
     reset(A); reset(B);
+    if (NST == 3) reset(C);
 
     auto fetch_loc = [&](int pass, Pass &s) {
         if (MODE != NRT_LOC_LINSPACE) {
@@ -313,8 +321,8 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         }
     };
 
-    // One pass.  `s` holds pass `pass` (managed two steps ago, rows in flight since the last step), `o` pass + 1 (managed in the last
-    // step, its loads go out first thing here); the management of pass + 2 is threaded through the blend so that each of its LDS round
+    // One pass.  `s` holds pass `pass` (managed NST steps ago, rows in flight since NST - 1 steps), `o` pass + NST - 1 (managed in the last
+    // step, its loads go out first thing here); the management of pass + NST is threaded through the blend so that each of its LDS round
     // trips has arithmetic to hide behind.  MASKED: the wave has voxels outside the volume (edge patches) whose sums must not count.
     // (Tried and measured slower, profiles/r05_lab/wc_probes.jsonl: the management BEFORE the row stores with the requests of pass + 2
     // leaving in the same step, 1.10 ms against 0.95; three management states with the requests two steps ahead: 256 registers, spills.)
@@ -329,7 +337,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         for (int corner = 0; corner < 8; ++corner) R[corner] = *(const wc_lds_f4 *)(lrow + s.sl[corner]);
         __builtin_amdgcn_sched_barrier(0);
         Mg m;
-        m1a(min(pass + 2, last), s, m);
+        m1a(min(pass + NST, last), s, m);
         __builtin_amdgcn_sched_barrier(0);
         // corner weights (wx * wy) * wz in the reference's order, two corners per packed multiply
         const float w1x = nrt_sub(1.0f, s.w0x), w1y = nrt_sub(1.0f, s.w0y), w1z = nrt_sub(1.0f, s.w0z);      // corner_1d's w1
@@ -379,7 +387,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         const nrt_f4 Tcur = s.T;
         asm volatile("" : "+v"(acc));
         __builtin_amdgcn_sched_barrier(0);
-        m1c(min(pass + 2, last), m, s);
+        m1c(min(pass + NST, last), m, s);
         __builtin_amdgcn_sched_barrier(0);
         if (BWD) {
             // d loss / d warped for this lane's four labels, then its slope along the three axes (interpn_core.h: loc_grad_rows)
@@ -426,11 +434,35 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         if (DICE && !BWD) asm volatile("" : "+v"(stp_l), "+v"(stp_h), "+v"(stt_l), "+v"(stt_h), "+v"(spp_l), "+v"(spp_h));
         else asm volatile("" :: "v"(acc));
         __builtin_amdgcn_sched_barrier(0);
-        fetch_loc(min(pass + 4, last), s);
+        fetch_loc(min(pass + 2 * NST, last), s);
         __builtin_amdgcn_sched_barrier(0);
     };
     auto march = [&](auto masked) {
         Mg m;
+        if constexpr (NST == 3) {
+            // pass p lives in state p % 3; step p requests the rows of pass p + 2 (managed in step p - 1) and manages pass p + 3
+            fetch_loc(0, A);
+            fetch_loc(min(1, last), B);
+            fetch_loc(min(2, last), C);
+            m1a(0, A, m); m1b(m); m1c(0, m, A);
+            issue(A);
+            fetch_loc(min(3, last), A);
+            m1a(min(1, last), B, m); m1b(m); m1c(min(1, last), m, B);
+            issue(B);
+            fetch_loc(min(4, last), B);
+            m1a(min(2, last), C, m); m1b(m); m1c(min(2, last), m, C);
+            fetch_loc(min(5, last), C);
+            __builtin_amdgcn_sched_barrier(0);
+            int pass = 0;
+            for (; pass + 2 < npass; pass += 3) {
+                step(pass, A, C, masked);
+                step(pass + 1, B, A, masked);
+                step(pass + 2, C, B, masked);
+            }
+            if (pass < npass) step(pass, A, C, masked);           // (what the last steps prepare beyond the end is not used)
+            if (pass + 1 < npass) step(pass + 1, B, A, masked);
+            return;
+        }
         fetch_loc(0, A);
         fetch_loc(min(1, last), B);
         m1a(0, A, m); m1b(m); m1c(0, m, A);
