@@ -50,7 +50,13 @@
 namespace {
 
 #ifndef WC_NST_WARP
-#define WC_NST_WARP 3                                           // pass states of the stand-alone warp (2: as the fused forms)
+#define WC_NST_WARP 3                                           // pass states of the stand-alone warp (2: requests one step ahead)
+#endif
+#ifndef WC_NST_FUSED
+#define WC_NST_FUSED 2                                          // pass states of the fused warp + Dice (forward)
+#endif
+#ifndef WC_NST_BWD
+#define WC_NST_BWD 3                                            // pass states of the backward forms (they store the location gradient every pass)
 #endif
 constexpr int WC_SLOTS = 128;                                   // direct-mapped rows per wave
 constexpr int WC_OVF = 16;                                      // overflow rows (orphans of the current pass)
@@ -196,11 +202,19 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     };
     // a pass under management: from the tag read (m1a) to the fetch list (m1c)
     struct Mg { float w0x, w0y, w0z; bool oob, miss; unsigned rid, slot, t1, t2, mytag; float mk[3]; };
-    // NST states: a pass is managed NST steps before it is blended and its rows are requested NST - 1 steps before.  The fused forms keep
-    // two (a third state does not fit their 219 registers: 618 spills in round 5); the stand-alone warp (161 registers) takes three --
-    // its row requests leave TWO steps ahead of their use
-    constexpr int NST = WC_NST_WARP > 2 && !DICE && !BWD ? 3 : 2;
+    // NST states: a pass is managed NST steps before it is blended and its rows are requested NST - 1 steps before.  Memory operations of a
+    // wave complete IN ORDER, stores included: a row requested one step ahead waits for the acknowledgement of the store of the pass in front
+    // of it; requested two steps ahead it does not.  Measured, alternating libraries on one box (profiles/r06_lab/e6_three_states_standalone.jsonl,
+    // e7_three_states_fused.jsonl): the stand-alone warp (a 128-byte store per voxel) 6 - 8 % faster with three states at every batch size, the
+    // backward forms (a 12-byte store per voxel) 4 - 5 %, the fused forward (no store in its stream) within 1 % -- it keeps two (its third state
+    // only fits at 251 - 255 registers).
+    constexpr int NST = ((BWD ? WC_NST_BWD : (DICE ? WC_NST_FUSED : WC_NST_WARP)) > 2) ? 3 : 2;
+    // XSH: the rows 32 .. 63 of a long fetch list (19 % of the passes) travel through ONE shared set of registers, requested at the end of the
+    // step before their use, instead of a set per state requested with the others -- what lets a third state fit next to the Dice / gradient
+    // registers (backward forms: 217 - 243 registers; the stand-alone warp keeps a set per state: 198 - 221)
+    constexpr bool XSH = NST == 3 && DICE;
     Pass A, B, C;
+    nrt_f4 FxS[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     auto reset = [&](Pass &s) {
         s.w0x = s.w0y = s.w0z = 0.f; s.n = 0; s.xq = x0; s.oob = false; s.mk[0] = s.mk[1] = s.mk[2] = 0.f;
         s.T = (nrt_f4){0.f, 0.f, 0.f, 0.f};
@@ -305,11 +319,19 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     auto issue = [&](Pass &s) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) s.F[i] = fetch_row(s.lr[i]);
-        if (__builtin_expect(s.n > 32, 0)) {
+        if (!XSH && __builtin_expect(s.n > 32, 0)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) s.Fx[i] = fetch_row(s.xr[i]);
         }
         if (DICE) s.T = __builtin_bit_cast(nrt_f4, __builtin_amdgcn_raw_buffer_load_b128(fres, row_lane, (unsigned)s.xq * row_step, 2));
+    };
+    // (XSH) the rows 32 .. of the pass in s, into the shared registers: called at the end of the step BEFORE the one that blends the pass,
+    // behind the delivery of the previous pass's
+    auto issue_x = [&](Pass &s) {
+        if (XSH && __builtin_expect(s.n > 32, 0)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) FxS[i] = fetch_row(s.xr[i]);
+        }
     };
     // D: rows fetched for the pass -> their cache / overflow rows
     auto deliver = [&](Pass &s) {
@@ -317,7 +339,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         for (int i = 0; i < 4; ++i) *(wc_lds_f4 *)(lrow + s.ld[i]) = s.F[i];
         if (__builtin_expect(s.n > 32, 0)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *(wc_lds_f4 *)(lrow + s.xd[i]) = s.Fx[i];
+            for (int i = 0; i < 4; ++i) *(wc_lds_f4 *)(lrow + s.xd[i]) = XSH ? FxS[i] : s.Fx[i];
         }
     };
 
@@ -327,7 +349,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
     // (Tried and measured slower, profiles/r05_lab/wc_probes.jsonl: the management BEFORE the row stores with the requests of pass + 2
     // leaving in the same step, 1.10 ms against 0.95; three management states with the requests two steps ahead: 256 registers, spills.)
     const int last = npass - 1;
-    auto step = [&](int pass, Pass &s, Pass &o, auto masked) {
+    auto step = [&](int pass, Pass &s, Pass &o, Pass &nx, auto masked) {
         constexpr bool MASKED = decltype(masked)::value;
         issue(o);                    // (before the wait for this pass's rows: a late row must not hold back the next pass's requests)
         __builtin_amdgcn_sched_barrier(0);
@@ -435,6 +457,7 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         else asm volatile("" :: "v"(acc));
         __builtin_amdgcn_sched_barrier(0);
         fetch_loc(min(pass + 2 * NST, last), s);
+        issue_x(nx);                 // (XSH: nx = the pass of the next step)
         __builtin_amdgcn_sched_barrier(0);
     };
     auto march = [&](auto masked) {
@@ -452,15 +475,16 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
             fetch_loc(min(4, last), B);
             m1a(min(2, last), C, m); m1b(m); m1c(min(2, last), m, C);
             fetch_loc(min(5, last), C);
+            issue_x(A);
             __builtin_amdgcn_sched_barrier(0);
             int pass = 0;
             for (; pass + 2 < npass; pass += 3) {
-                step(pass, A, C, masked);
-                step(pass + 1, B, A, masked);
-                step(pass + 2, C, B, masked);
+                step(pass, A, C, B, masked);
+                step(pass + 1, B, A, C, masked);
+                step(pass + 2, C, B, A, masked);
             }
-            if (pass < npass) step(pass, A, C, masked);           // (what the last steps prepare beyond the end is not used)
-            if (pass + 1 < npass) step(pass + 1, B, A, masked);
+            if (pass < npass) step(pass, A, C, B, masked);        // (what the last steps prepare beyond the end is not used)
+            if (pass + 1 < npass) step(pass + 1, B, A, C, masked);
             return;
         }
         fetch_loc(0, A);
@@ -473,10 +497,10 @@ __device__ __forceinline__ void wc_item(const InterpArgs &a, const TileGeom &tg,
         __builtin_amdgcn_sched_barrier(0);
         int pass = 0;
         for (; pass + 1 < npass; pass += 2) {
-            step(pass, A, B, masked);
-            step(pass + 1, B, A, masked);
+            step(pass, A, B, B, masked);
+            step(pass + 1, B, A, A, masked);
         }
-        if (pass < npass) step(pass, A, B, masked);               // odd march: one more pass (what it prepares beyond the end is not used)
+        if (pass < npass) step(pass, A, B, B, masked);            // odd march: one more pass (what it prepares beyond the end is not used)
     };
     if (npass > 0) {
         // (wave-uniform) edge patches mask the sums of the lanes whose voxel lies outside the volume
