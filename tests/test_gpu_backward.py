@@ -466,6 +466,32 @@ def test_grad_loc_wave_cache_and_register_kernels_agree(dev, fill, monkeypatch):
         close(got['1'][1][b], lo.grad.numpy(), 'plain grad_flow b%d' % b)
 
 
+@pytest.mark.parametrize('X', [18, 19, 20])
+def test_grad_loc_wave_cache_three_states_every_march_length(dev, X, monkeypatch):
+    """the backward forms of the wave-cache gather keep three pass states with one shared set of registers for the rows 32.. of a long fetch
+    list (fused_wc.h: NST, XSH): marches of 3 k, 3 k + 1, 3 k + 2 planes, coherent and incoherent fields, bit for bit against the
+    register-pipelined kernel (NRT_BWD_WC=0) that shares the gradient arithmetic"""
+    rng = np.random.default_rng(77 + X)
+    B, S, L = 4, (X, 64, 64), 32
+    mov = rng.random((B,) + S + (L,)).astype(F)
+    fix = rng.random((B,) + S + (L,)).astype(F)
+    flow = (rng.standard_normal((B,) + S + (3,)) * 1.5).astype(F)
+    flow[3] = rng.uniform(-30, 30, S + (3,)).astype(F)                   # long fetch lists / the fallback of the cache
+    w = rng.standard_normal((B,) + S + (L,)).astype(F)
+    got = {}
+    for wc in ('1', '0'):
+        monkeypatch.setenv('NRT_BWD_WC', wc)
+        f = G(flow, dev, True)
+        d = ne.fused.warp_dice(G(mov, dev), f, G(fix, dev), laplace_smoothing=0.05)
+        (-d.mean()).backward()
+        f2 = G(flow, dev, True)
+        out = ne.layers.SpatialTransformer()([G(mov, dev), f2])
+        (out * G(w, dev)).sum().backward()
+        got[wc] = (N(f.grad), N(f2.grad))
+    assert np.array_equal(got['1'][0], got['0'][0]), 'fused: %g' % np.abs(got['1'][0] - got['0'][0]).max()
+    assert np.array_equal(got['1'][1], got['0'][1]), 'plain: %g' % np.abs(got['1'][1] - got['0'][1]).max()
+
+
 def test_fused_backward_at_bench_size(dev, monkeypatch):
     """BASELINE config 2 / 4 size (160^3 x 32 one-hot maps, the bench's smooth field), two volumes: properties of d (-mean Dice) / d field
     that do not need the (slow) oracle -- (i) the wave-cache and the register-pipelined kernels give the same bits; (ii) the directional

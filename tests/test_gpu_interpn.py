@@ -358,6 +358,24 @@ def test_wave_cache_warp_variant(dev):
         ne.utils.interpn(G(v1[:8, :8, :8], dev), G(loc[:4, :4, :4], dev), _variant=10)
 
 
+@pytest.mark.parametrize('X', [16, 17, 18, 19, 20, 21])
+def test_wave_cache_warp_three_states_every_march_length(dev, X):
+    """The stand-alone warp keeps THREE pass states (fused_wc.h: NST; row requests two steps ahead of their use): marches of 3 k, 3 k + 1
+    and 3 k + 2 planes -- whole columns and the pieces the schedule cuts them into -- against the oracle, bit for bit, with fill and with
+    locations far outside (the tail steps prepare passes beyond the end that must never be blended)"""
+    rng = np.random.default_rng(300 + X)
+    B, S = 4, (X, 64, 64)
+    vol = rng.standard_normal((B,) + S + (32,)).astype(F)
+    trf = rng.normal(0, 1.2, (B,) + S + (3,)).astype(F)
+    trf[1] = rng.uniform(-40, 40, S + (3,)).astype(F)                     # one entry incoherent: lists longer than 32, then the fallback
+    trf[2, X // 2:] = 0                                                   # exactly on the grid from the middle on
+    for fill in (None, 0.5):
+        st = ne.layers.SpatialTransformer(fill_value=fill)
+        st._variant = 10
+        got = N(st([G(vol, dev), G(trf, dev)]))
+        assert bits_equal(got, npo.spatial_transformer(vol, trf, fill_value=fill)), (X, fill)
+
+
 def test_full_size_cfg2_spatial_transformer(dev):
     """BASELINE config 2 size: 160^3 x 32-label one-hot, smooth and worst-case fields, vs the C oracle."""
     mov, _, trf = synth.cfg2_batch(1, 160, 32, device=dev, seed0=1)
