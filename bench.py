@@ -1032,7 +1032,9 @@ def main():
         return stub_main(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (MI355X); there is no CPU path.')
-    dev = torch.device('cuda', local_rank)
+    # (NRT_DEVICE: every rank on one given device -- the two-ranks-on-one-GPU test of the multi-process control flow, which needs a backend
+    # that accepts two ranks per device: NRT_DIST_BACKEND=gloo; a real run is one rank per GPU over nccl = RCCL)
+    dev = torch.device('cuda', int(os.environ.get('NRT_DEVICE', local_rank)))
     torch.cuda.set_device(dev)
     dist = None
     real_stdout = None
@@ -1043,7 +1045,11 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get('NRT_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         log('warning: --gpus %d but WORLD_SIZE=%d; reporting n_gpus=%d' % (args.gpus, world, world))
 

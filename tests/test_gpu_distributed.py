@@ -58,3 +58,31 @@ def test_bench_self_spawn_forced_on_one_gpu(dev):
     assert j['n_gpus'] == 1 and j['rccl_ranks'] == 1 and j['steps'] == 3
     assert j['scaling'] == 'strong' and j['config']['volumes_per_gpu'] == 2 and j['config']['global_batch'] == 2 and j['value'] > 0
     assert 'bench.py: launching 1 ranks' in p.stderr
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo(dev):
+    """The multi-process CONTROL FLOW of bench.py with world size 2 on real kernels: two ranks on the one GPU of the box (NRT_DEVICE=0), the
+    collective over gloo (RCCL refuses two ranks per device).  What it proves before an 8-GPU node runs the nccl form of the same code: both
+    ranks leave the clock-bounded pre-warming together (an all-reduced flag -- ranks deciding by their own clocks would hang here), the
+    strong-scaling default (global batch 32, 16 volumes per rank), one JSON line from rank 0, a mean Dice that is the mean over BOTH shards."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'NRT_BENCH_CHILD')}
+    env.update(NRT_DIST_BACKEND='gloo', NRT_DEVICE='0', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--size', '64',
+           '--prewarm-ms', '120', '--no-cpu-baseline', '--no-unet', '--no-batch1']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line on stdout, got %r' % (lines,)
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['rccl_ranks'] == 2 and j['steps'] == 4 and len(j['ms_per_step_per_rank']) == 2
+    assert j['scaling'] == 'strong' and j['config']['global_batch'] == 32 and j['config']['volumes_per_gpu'] == 16 and j['value'] > 0
+    assert j['weak_per_gpu']['volumes_per_gpu'] == 4 and j['weak_per_gpu']['rccl_ranks'] == 2
+    # the global mean is the mean over both ranks' shards: the single-process run over all 32 volumes gives the same number
+    env1 = {k: v for k, v in env.items() if k not in ('NRT_DIST_BACKEND', 'NRT_DEVICE')}
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--size', '64', '--batch-per-gpu', '32',
+                         '--prewarm-ms', '0', '--no-cpu-baseline', '--no-unet', '--no-batch1', '--no-strong'], cwd=ROOT, env=env1,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    j1 = json.loads([ln for ln in p1.stdout.splitlines() if ln.strip().startswith('{')][-1])
+    assert abs(j['config']['mean_dice'] - j1['config']['mean_dice']) <= 3e-6
